@@ -1,0 +1,206 @@
+/*
+ * n2m_hip.h -- C ABI of libn2m_hip.so: the MI355X (gfx950) implementation of nerf2mesh's hot path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one function of the
+ * reference's `_backend` extension modules; the reference interface it stands in for is cited next to it
+ * (paths relative to the reference checkout).  The host-side Python above this ABI
+ * (nerf2mesh_amd/backends/_raymarching_mob.py, _gridencoder.py, _shencoder.py, and the operator modules
+ * nerf2mesh_amd/{raymarching,gridencoder,shencoder}.py) binds these symbols with ctypes.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer (HBM) unless the name ends in _host.
+ *  - all outputs are pre-allocated by the caller and written in place; the library never allocates or frees
+ *    caller-visible memory and never synchronises the stream (exception: n2m_prof_* readers, documented there).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Work is enqueued, not awaited.
+ *  - return value: 0 on success, otherwise a negative N2M_E* code for a rejected argument or the positive
+ *    hipError_t of a failed launch.  n2m_last_error() returns a static, thread-local message for the last
+ *    non-zero return on this thread.
+ *  - `dtype` selects the embedding/feature element type of the grid encoder: N2M_F32 or N2M_F16 (IEEE half).
+ *    Ray marching, compositing and SH always compute in fp32 (the reference wrappers cast to fp32 with
+ *    custom_fwd(cast_inputs=torch.float32): raymarching/raymarching.py:21,54,130,186,250,313,364).
+ */
+#ifndef N2M_HIP_H
+#define N2M_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define N2M_ABI_VERSION 1
+
+enum { N2M_F32 = 0, N2M_F16 = 1 };
+
+enum {
+    N2M_OK = 0,
+    N2M_EINVAL = -1,      /* bad scalar argument (unsupported D / C / degree ...) */
+    N2M_ENULL = -2,       /* required pointer is NULL */
+    N2M_EUNSUPPORTED = -3 /* valid in the reference, not implemented here (message says what) */
+};
+
+int n2m_abi_version(void);
+const char* n2m_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * raymarching   (reference: raymarching/src/raymarching.h:7-19, raymarching/src/bindings.cpp:5-20)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* raymarching.h:7  near_far_from_aabb   kernel raymarching.cu:91-145
+ * rays_o, rays_d [N,3]; aabb [6] = (xmin,ymin,zmin,xmax,ymax,zmax); nears, fars [N].
+ * Miss => nears[n] = fars[n] = FLT_MAX.  near is clamped from below to min_near. */
+int n2m_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
+                           float min_near, float* nears, float* fars, void* stream);
+
+/* raymarching.h:8  sph_from_ray   kernel raymarching.cu:162-198.  coords [N,2] in [-1,1]. */
+int n2m_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                     void* stream);
+
+/* raymarching.h:9-10  morton3D / morton3D_invert   kernels raymarching.cu:214-254.
+ * coords [N,3] int32 (10 bits per axis are used), indices [N] int32. */
+int n2m_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream);
+int n2m_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream);
+
+/* raymarching.h:11  packbits   kernel raymarching.cu:267-289.
+ * grid [N*8] fp32, bitfield [N] u8: bit i of byte n  <=>  grid[8n+i] > density_thresh  (strict, LSB first). */
+int n2m_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream);
+
+/* raymarching.h:12  flatten_rays   kernel raymarching.cu:303-319.
+ * rays [N,2] = (offset,count); res [M] int32: res[offset .. offset+count) = n.  Other entries untouched. */
+int n2m_flatten_rays(const int32_t* rays, uint32_t N, uint32_t M, int32_t* res, void* stream);
+
+/* raymarching.h:14  march_rays_train   kernel raymarching.cu:337-475, host :477-489.
+ * Two-pass protocol of raymarching/raymarching.py:229-241:
+ *   pass 1: xyzs == dirs == ts == NULL.  Counts the kept samples of every ray and writes
+ *           rays[n] = (offset, count), counter[0] += sum(count).
+ *           Offsets are the EXCLUSIVE PREFIX SUM of the counts IN RAY ORDER starting at the value counter[0]
+ *           held on entry (the reference hands out offsets with atomicAdd in thread-arrival order,
+ *           raymarching.cu:471: any consistent packing is valid there; ray order is the deterministic one and
+ *           is what a serial execution of the reference produces).
+ *   pass 2: xyzs [M,3], dirs [M,3], ts [M,2] given.  Re-marches with the same arithmetic and writes the
+ *           samples of ray n at rays[n].offset.  counter is not touched.
+ * grid = density bitfield [C*H^3/8] u8, Morton order inside each cascade.  noises [N] in [0,1). */
+int n2m_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                         int contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                         const float* nears, const float* fars, float* xyzs, float* dirs, float* ts,
+                         int32_t* rays, int32_t* counter, const float* noises, void* stream);
+
+/* raymarching.h:15  composite_rays_train_forward   kernel raymarching.cu:500-578.
+ * sigmas [M], rgbs [M,3], ts [M,2], rays [N,2] -> weights [M] (caller zero-fills; entries after an early
+ * stop are left untouched), weights_sum [N], depth [N], image [N,3]. */
+int n2m_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* ts,
+                                     const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
+                                     int alpha_mode, float* weights, float* weights_sum, float* depth,
+                                     float* image, void* stream);
+
+/* raymarching.h:16  composite_rays_train_backward   kernel raymarching.cu:604-694.
+ * grad_sigmas [M], grad_rgbs [M,3] are caller-zero-filled; samples after the early stop stay zero. */
+int n2m_composite_rays_train_backward(const float* grad_weights, const float* grad_weights_sum,
+                                      const float* grad_depth, const float* grad_image, const float* sigmas,
+                                      const float* rgbs, const float* ts, const int32_t* rays,
+                                      const float* weights_sum, const float* depth, const float* image,
+                                      uint32_t M, uint32_t N, float T_thresh, int alpha_mode,
+                                      float* grad_sigmas, float* grad_rgbs, void* stream);
+
+/* raymarching.h:18  march_rays (inference)   kernel raymarching.cu:712-828.
+ * Fixed n_step slots per alive ray; xyzs/dirs/ts [n_alive*n_step, .] are caller-zero-filled, a slot with
+ * ts[.,0] == 0 is an empty slot.  noises [n_alive]. */
+int n2m_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                   const float* rays_o, const float* rays_d, float bound, int contract, float dt_gamma,
+                   uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* nears,
+                   const float* fars, float* xyzs, float* dirs, float* ts, const float* noises, void* stream);
+
+/* raymarching.h:19  composite_rays (inference)   kernel raymarching.cu:841-924.
+ * Accumulates into weights_sum/depth/image [N] in place; rays_alive[n] = -1 when the ray ended, otherwise
+ * rays_t[ray] = last t. */
+int n2m_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int alpha_mode, int32_t* rays_alive,
+                       float* rays_t, const float* sigmas, const float* rgbs, const float* ts,
+                       float* weights_sum, float* depth, float* image, void* stream);
+
+/* New (no reference counterpart): stream compaction of the alive list,
+ * out[0..n_out) = the entries of rays_alive[0..n_alive) that are >= 0, order preserved; *n_out_dev = count.
+ * Replaces `rays_alive = rays_alive[rays_alive >= 0]` (nerf/renderer.py:798). */
+int n2m_compact_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out, int32_t* n_out_dev,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * gridencoder   (reference: gridencoder/src/gridencoder.h:12-15, gridencoder/src/bindings.cpp:5-9)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* gridencoder.h:12  grid_encode_forward   kernel gridencoder.cu:87-244, host :371-399,447-470.
+ * inputs [B,D] fp32 in [0,1]; embeddings [rows,C] (dtype); offsets [L+1] int32 (device);
+ * outputs [L,B,C] (dtype, LEVEL-MAJOR as in the reference); levels >= max_level are not written.
+ * dy_dx: NULL or [B,L,D,C] (dtype).  S = log2(per_level_scale), H = base resolution.
+ * gridtype 0 hash / 1 tiled; interp 0 linear / 1 smoothstep.  D in {2,3,4,5}, C in {1,2,4,8}. */
+int n2m_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets,
+                            void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                            uint32_t max_level, float S, uint32_t H, void* dy_dx, uint32_t gridtype,
+                            int align_corners, uint32_t interp, int dtype, void* stream);
+
+/* gridencoder.h:13  grid_encode_backward   kernels gridencoder.cu:247-339 (+ :342-368), host :401-443,472-502.
+ * grad [L,B,C] (dtype); grad_embeddings [rows,C] (dtype) is caller-zero-filled and accumulated with atomics;
+ * dy_dx/grad_inputs: both NULL, or dy_dx [B,L,D,C] and grad_inputs [B,D] (dtype). */
+int n2m_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
+                             const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D,
+                             uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                             const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                             uint32_t interp, int dtype, void* stream);
+
+/* gridencoder.h:15  grad_total_variation   kernel gridencoder.cu:505-609.
+ * inputs [B,D] (dtype! the reference reads them as scalar_t, gridencoder.cu:507,642) in [0,1];
+ * adds the TV gradient of the cell containing each input into `grad` [rows,C] in place (atomics). */
+int n2m_grad_total_variation(const void* inputs, const void* embeddings, void* grad, const int32_t* offsets,
+                             float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                             uint32_t H, uint32_t gridtype, int align_corners, int dtype, void* stream);
+
+/* New, opt-in layout variant used by the host operator (not by the reference's grid.py): identical
+ * arithmetic to n2m_grid_encode_forward but writes outputs SAMPLE-MAJOR [B, L*C] directly, which is what
+ * gridencoder/grid.py:63 produces with an extra permute pass.  Levels >= max_level are zero-filled. */
+int n2m_grid_encode_forward_bm(const float* inputs, const void* embeddings, const int32_t* offsets,
+                               void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                               uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
+                               int align_corners, uint32_t interp, int dtype, void* stream);
+/* ... and the matching backward taking grad SAMPLE-MAJOR [B, L*C] (saves the permute of grid.py:81). */
+int n2m_grid_encode_backward_bm(const void* grad, const float* inputs, const void* embeddings,
+                                const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D,
+                                uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * shencoder   (reference: shencoder/src/shencoder.h:9-10, shencoder/src/bindings.cpp:5-8)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* shencoder.h:9  sh_encode_forward   kernel shencoder.cu:27-356.
+ * inputs [B,3] unit vectors; outputs [B,degree^2]; dy_dx NULL or [B,3,degree^2].  degree in 1..8, D == 3. */
+int n2m_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t degree,
+                          float* dy_dx, void* stream);
+
+/* shencoder.h:10  sh_encode_backward   kernel shencoder.cu:358-382.
+ * grad_inputs[b,d] += sum_ch grad[b,ch] * dy_dx[b,d,ch]   (accumulates, as the reference does). */
+int n2m_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t degree,
+                           const float* dy_dx, float* grad_inputs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * per-kernel timing (measurement support for bench.py; not part of the reference surface)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Kernel ids for n2m_prof_*: one per launch site family. */
+enum {
+    N2M_K_GRID_FWD = 0, N2M_K_GRID_BWD, N2M_K_GRID_TV, N2M_K_MARCH_COUNT, N2M_K_MARCH_WRITE,
+    N2M_K_COMPOSITE_FWD, N2M_K_COMPOSITE_BWD, N2M_K_NEAR_FAR, N2M_K_PACKBITS, N2M_K_MLP_FWD, N2M_K_MLP_BWD,
+    N2M_K_RASTER, N2M_K_COUNT
+};
+/* When enabled, every launch of a profiled kernel is bracketed by a hipEvent pair recorded on the launch
+ * stream (events come from a fixed pool; launches beyond the pool are counted but not timed). */
+int n2m_prof_enable(int on);
+int n2m_prof_reset(void);
+/* Synchronises the recorded events, then returns the number of timed launches of `kernel_id`, their summed
+ * duration in milliseconds and the algorithmic bytes the library attributed to them. */
+int n2m_prof_read(int kernel_id, uint64_t* launches, double* total_ms, double* algo_bytes);
+const char* n2m_prof_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* N2M_HIP_H */

@@ -1,0 +1,155 @@
+"""Synthetic stand-in for nerf_synthetic/lego (no dataset ships with the container).
+
+* cameras: 100 poses on the upper hemisphere of a sphere of radius 4.0311289 * 0.8 (lego's camera distance
+  times `--scale 0.8`, scripts/runall_syn.sh:1), OpenGL convention (-z forward), 800x800, focal 1111.111
+  (camera_angle_x = 0.6911112, nerf/provider.py:251-263).
+* rays: exactly the arithmetic of get_rays (nerf/utils.py:242-290): pixel centres at +0.5, un-normalised
+  directions ((i-cx)/fx, -(j-cy)/fy, -1) @ R^T, origin = pose[:3,3].
+* scene: an analytic "lego-like" union of axis-aligned boxes inside [-0.6,0.6]^3 (z up), used both as the
+  ground truth (first-hit shading -> RGBA pixels) and to rasterise an occupancy grid in Morton order.
+
+Everything is plain torch and runs on CPU or on the GPU (device of the inputs).
+"""
+import math
+
+import torch
+
+LEGO_RADIUS = 4.0311289 * 0.8
+LEGO_HW = 800
+LEGO_FOCAL = 0.5 * LEGO_HW / math.tan(0.5 * 0.6911112070083618)
+
+# (xmin, ymin, zmin, xmax, ymax, zmax, r, g, b)
+_BOXES = [
+    (-0.55, -0.35, -0.45, 0.55, 0.35, -0.37, 0.55, 0.55, 0.58),   # base plate
+    (-0.40, -0.22, -0.37, 0.30, 0.22, -0.12, 0.95, 0.75, 0.10),   # chassis
+    (-0.05, -0.18, -0.12, 0.28, 0.18, 0.16, 0.92, 0.70, 0.08),    # cab
+    (-0.40, -0.06, -0.12, -0.05, 0.06, 0.02, 0.25, 0.25, 0.28),   # boom base
+    (-0.58, -0.04, 0.02, -0.20, 0.04, 0.10, 0.90, 0.72, 0.10),    # boom
+    (-0.60, -0.16, -0.20, -0.52, 0.16, 0.10, 0.35, 0.35, 0.38),   # bucket
+    (-0.46, -0.30, -0.45, -0.22, -0.22, -0.25, 0.12, 0.12, 0.12), # wheel fl
+    (-0.46, 0.22, -0.45, -0.22, 0.30, -0.25, 0.12, 0.12, 0.12),   # wheel fr
+    (0.08, -0.30, -0.45, 0.32, -0.22, -0.25, 0.12, 0.12, 0.12),   # wheel rl
+    (0.08, 0.22, -0.45, 0.32, 0.30, -0.25, 0.12, 0.12, 0.12),     # wheel rr
+    (0.02, -0.10, 0.16, 0.10, -0.02, 0.22, 0.80, 0.10, 0.10),     # beacon
+    (0.30, -0.20, -0.37, 0.50, 0.20, -0.30, 0.30, 0.30, 0.75),    # rear step
+]
+
+
+def boxes(device="cpu"):
+    return torch.tensor(_BOXES, dtype=torch.float32, device=device)
+
+
+def make_cameras(n=100, radius=LEGO_RADIUS, seed=0, device="cpu"):
+    """[n,4,4] camera-to-world poses looking at the origin from the upper hemisphere (z up)."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(n, generator=g)
+    v = torch.rand(n, generator=g)
+    theta = 2 * math.pi * u
+    elev = torch.deg2rad(5.0 + 75.0 * v)                       # 5..80 degrees above the horizon
+    c = torch.stack([torch.cos(elev) * torch.cos(theta), torch.cos(elev) * torch.sin(theta), torch.sin(elev)], -1) * radius
+    fwd = -c / c.norm(dim=-1, keepdim=True)                    # camera looks along -z_cam
+    up = torch.tensor([0.0, 0.0, 1.0]).expand_as(fwd)
+    right = torch.cross(fwd, up, dim=-1)
+    right = right / right.norm(dim=-1, keepdim=True)
+    true_up = torch.cross(right, fwd, dim=-1)
+    poses = torch.eye(4).repeat(n, 1, 1)
+    poses[:, :3, 0] = right
+    poses[:, :3, 1] = true_up
+    poses[:, :3, 2] = -fwd
+    poses[:, :3, 3] = c
+    return poses.to(device)
+
+
+def rays_from_pixels(poses, cam_idx, pix, H=LEGO_HW, W=LEGO_HW, focal=LEGO_FOCAL):
+    """get_rays restated (nerf/utils.py:242-290). pix = flat pixel index j*W + i; returns rays_o, rays_d [N,3]."""
+    i = (pix % W).float() + 0.5
+    j = torch.div(pix, W, rounding_mode="floor").float() + 0.5
+    cx, cy = W / 2, H / 2
+    dirs = torch.stack([(i - cx) / focal, -(j - cy) / focal, -torch.ones_like(i)], -1)          # [N,3]
+    R = poses[cam_idx, :3, :3]                                                                    # [N,3,3]
+    rays_d = (dirs.unsqueeze(1) @ R.transpose(-1, -2)).squeeze(1)
+    rays_o = poses[cam_idx, :3, 3]
+    return rays_o.contiguous(), rays_d.contiguous()
+
+
+def random_rays(poses, N, generator=None, H=LEGO_HW, W=LEGO_HW, focal=LEGO_FOCAL):
+    """N random pixels over all images (random_image_batch, nerf/provider.py:302-303)."""
+    dev = poses.device
+    cam = torch.randint(0, poses.shape[0], (N,), device=dev, generator=generator)
+    pix = torch.randint(0, H * W, (N,), device=dev, generator=generator)
+    o, d = rays_from_pixels(poses, cam, pix, H, W, focal)
+    return o, d
+
+
+def crop_rays(poses, cam=0, size=64, H=LEGO_HW, W=LEGO_HW, focal=LEGO_FOCAL):
+    """Central size x size crop of one view (BASELINE config 1)."""
+    dev = poses.device
+    j0, i0 = (H - size) // 2, (W - size) // 2
+    jj, ii = torch.meshgrid(torch.arange(j0, j0 + size, device=dev), torch.arange(i0, i0 + size, device=dev), indexing="ij")
+    pix = (jj * W + ii).reshape(-1)
+    return rays_from_pixels(poses, torch.full_like(pix, cam), pix, H, W, focal)
+
+
+def scene_inside(xyz, bx=None):
+    """[...,3] -> bool: inside the union of boxes."""
+    bx = boxes(xyz.device) if bx is None else bx
+    p = xyz.unsqueeze(-2)                                           # [...,1,3]
+    return ((p >= bx[:, 0:3]) & (p <= bx[:, 3:6])).all(-1).any(-1)
+
+
+def render_gt(rays_o, rays_d, bx=None):
+    """First-hit shading of the box scene. Returns rgba [N,4] (alpha 0 = background)."""
+    bx = boxes(rays_o.device) if bx is None else bx
+    o, d = rays_o.unsqueeze(1), rays_d.unsqueeze(1)                 # [N,1,3]
+    inv = 1.0 / torch.where(d.abs() < 1e-12, torch.full_like(d, 1e-12), d)
+    t0, t1 = (bx[:, 0:3] - o) * inv, (bx[:, 3:6] - o) * inv         # [N,K,3]
+    tn, tf = torch.minimum(t0, t1), torch.maximum(t0, t1)
+    tnear, axis = tn.max(-1)
+    tfar = tf.min(-1).values
+    hit = (tnear <= tfar) & (tfar > 0)
+    tnear = torch.where(hit, tnear, torch.full_like(tnear, float("inf")))
+    t, k = tnear.min(-1)                                            # first box
+    any_hit = torch.isfinite(t)
+    ax = axis.gather(1, k.unsqueeze(1)).squeeze(1)
+    shade = torch.tensor([0.80, 0.65, 1.00], device=rays_o.device)[ax]   # per-axis "lambert"
+    rgb = bx[k, 6:9] * shade.unsqueeze(-1)
+    rgba = torch.cat([rgb, torch.ones_like(rgb[:, :1])], -1)
+    return torch.where(any_hit.unsqueeze(-1), rgba, torch.zeros_like(rgba))
+
+
+def _part1by2(v):
+    v = v & 0x3FF
+    v = (v | (v << 16)) & 0xFF0000FF
+    v = (v | (v << 8)) & 0x0F00F00F
+    v = (v | (v << 4)) & 0xC30C30C3
+    v = (v | (v << 2)) & 0x49249249
+    return v
+
+
+def morton3D_torch(coords):
+    """int64 [N,3] -> int64 [N]; x in bit 0 (same code as raymarching.morton3D, used here for CPU-side setup)."""
+    c = coords.long()
+    return _part1by2(c[:, 0]) | (_part1by2(c[:, 1]) << 1) | (_part1by2(c[:, 2]) << 2)
+
+
+def scene_density_grid(H=128, cascade=1, bound=1.0, sigma=50.0, device="cpu"):
+    """density_grid [cascade, H^3] fp32 in Morton order: sigma where the cell centre region touches the scene.
+
+    Cell (x,y,z) of cascade c covers [-b,b]^3 with b = min(2^c, bound), like update_extra_state
+    (nerf/renderer.py:1094-1118) lays the grid out.  A cell is occupied if any of its 8 corners or its centre
+    is inside a box (conservative enough for a marcher test scene)."""
+    ar = torch.arange(H, device=device)
+    xx, yy, zz = torch.meshgrid(ar, ar, ar, indexing="ij")
+    coords = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)
+    idx = morton3D_torch(coords)
+    grid = torch.zeros(cascade, H ** 3, dtype=torch.float32, device=device)
+    bx = boxes(device)
+    offs = torch.tensor([[0.5, 0.5, 0.5]] + [[a, b, c] for a in (0.0, 1.0) for b in (0.0, 1.0) for c in (0.0, 1.0)], device=device)
+    for cas in range(cascade):
+        b = min(2.0 ** cas, bound)
+        occ = torch.zeros(H ** 3, dtype=torch.bool, device=device)
+        for o in offs:
+            p = ((coords.float() + o) / H * 2 - 1) * b
+            occ |= scene_inside(p, bx)
+        grid[cas, idx] = occ.float() * sigma
+    return grid
