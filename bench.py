@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Stage-0 training throughput of the nerf2mesh hot path on MI355X (BASELINE.json: "train rays/sec & samples/sec,
+Lego 800x800 stage-0").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one full stage-0 iteration of the reference's loop (nerf/utils.py:1152-1180) on the lego recipe
+(`-O --bound 1 --dt_gamma 0`, scripts/runall_syn.sh:1): [every 16th step: 128^3 occupancy refresh] -> 4096..N adaptive
+rays over 100 synthetic 800x800 views -> near/far -> occupancy march -> 2 hash-grid encodes + 3 tiny MLPs (fp16 autocast)
+-> compositing -> MSE/mask/specular loss -> backward -> TV gradient -> Adam over 18.4 M parameters.  Nothing is skipped
+inside the timed region.  Data: synthetic lego-like scene (nerf2mesh_amd/synthetic.py), random-init network that is
+first trained for `--pretrain` untimed iterations so that the occupancy grid is in its pruned, steady state.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant HIP kernel of the step: algorithmic bytes per launch / mean launch duration, measured with
+                  hipEvents recorded on the launch stream inside the timed region (n2m_prof_*), against the 8 TB/s HBM peak
+  cpu_baseline -- the CPU oracle (oracle/n2m_oracle.c, OpenMP over all host cores) + PyTorch-CPU MLPs timed on a bounded
+                  sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling is 6290 GB/s
+
+
+def cpu_baseline(n_rays=4096, reps=2):
+    """One stage-0 iteration's kernels on the host: oracle (C, OpenMP) for march/encode/composite/TV, torch-CPU for the
+    MLPs.  Returns dict for the JSON line.  Bounded: ~n_rays rays of the same synthetic workload."""
+    from oracle import oracle as orc
+    from nerf2mesh_amd import synthetic as S
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    poses = S.make_cameras(100, seed=0)
+    grid = S.scene_density_grid(H=128)
+    bits = orc.packbits(grid.numpy(), 10.0)
+    o, d = S.random_rays(poses, n_rays, torch.Generator().manual_seed(1))
+    # rays that hit the object dominate the work; keep the natural mix
+    o, d = o.numpy(), d.numpy()
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    pls = float(np.exp2(np.log2(2048 / 16) / 15))
+    offs = orc.level_offsets(3, 16, pls, 16, 19)
+    S_ = float(np.log2(pls))
+    rng = np.random.default_rng(0)
+    emb1 = ((rng.random((int(offs[-1]), 1), dtype=np.float32) * 2 - 1) * 1e-4)
+    emb2 = ((rng.random((int(offs[-1]), 2), dtype=np.float32) * 2 - 1) * 1e-4)
+    sigma_net = torch.nn.Sequential(torch.nn.Linear(19, 32, bias=False), torch.nn.ReLU(), torch.nn.Linear(32, 1, bias=False))
+    color_net = torch.nn.Sequential(torch.nn.Linear(35, 64, bias=False), torch.nn.ReLU(), torch.nn.Linear(64, 64, bias=False),
+                                    torch.nn.ReLU(), torch.nn.Linear(64, 6, bias=False))
+    spec_net = torch.nn.Sequential(torch.nn.Linear(6, 32, bias=False), torch.nn.ReLU(), torch.nn.Linear(32, 3, bias=False))
+    best, M = None, 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        nears, fars = orc.near_far_from_aabb(o, d, aabb, 0.05)
+        noises = rng.random(n_rays).astype(np.float32)
+        xyzs, dirs, ts, rays = orc.march_rays_train(o, d, 1.0, False, bits, 1, 128, nears, fars, noises, 0.0, 1024)
+        M = xyzs.shape[0]
+        x01 = (xyzs + 1) / 2
+        f1 = orc.grid_encode_forward(x01, emb1, offs, S_, 16, sample_major=True)
+        f2 = orc.grid_encode_forward(x01, emb2, offs, S_, 16, sample_major=True)
+        xt = torch.from_numpy(xyzs)
+        h1 = torch.from_numpy(f1).requires_grad_(True)
+        h2 = torch.from_numpy(f2).requires_grad_(True)
+        sig = torch.exp(sigma_net(torch.cat([xt, h1], -1))[:, 0])
+        geo = torch.sigmoid(color_net(torch.cat([xt, h2], -1)))
+        dn = torch.from_numpy(dirs)
+        dn = dn / dn.norm(dim=-1, keepdim=True)
+        spec = torch.sigmoid(spec_net(torch.cat([dn, geo[:, 3:]], -1)))
+        rgb = (spec + geo[:, :3]).clamp(0, 1)
+        w, ws, dp, im = orc.composite_rays_train_forward(sig.detach().numpy(), rgb.detach().numpy(), ts, rays)
+        gi = (2 * (im - 0.5) / im.size).astype(np.float32)
+        gs, gr = orc.composite_rays_train_backward(np.zeros(M, np.float32), np.zeros(n_rays, np.float32), np.zeros(n_rays, np.float32),
+                                                   gi, sig.detach().numpy(), rgb.detach().numpy(), ts, rays, ws, dp, im)
+        torch.autograd.backward([sig, rgb], [torch.from_numpy(gs), torch.from_numpy(gr)])
+        g1 = orc.grid_encode_backward(h1.grad.numpy(), x01, emb1, offs, S_, 16, sample_major=True)
+        orc.grid_encode_backward(h2.grad.numpy(), x01, emb2, offs, S_, 16, sample_major=True)
+        orc.grad_total_variation(x01, emb1, g1, offs, 1e-8, S_, 16)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": M / best, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"1 stage-0 iteration (march+2 encodes+MLPs+composite fwd/bwd+TV, no Adam/occupancy refresh) on {n_rays} rays = "
+                      f"{M} samples, best of {reps}; oracle C/OpenMP + torch-CPU MLPs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--pretrain", type=int, default=300, help="untimed iterations before warmup so the occupancy grid is pruned")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel hipEvents in the timed region")
+    args = ap.parse_args()
+
+    from nerf2mesh_amd import _lib, synthetic
+    from nerf2mesh_amd.network import NeRFNetwork
+    from nerf2mesh_amd.options import make_options
+    from nerf2mesh_amd.parallel import init_from_env
+    from nerf2mesh_amd.trainer import Stage0Trainer
+
+    rank, world, local = init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    _lib.lib()
+
+    torch.manual_seed(0)                                           # seed_everything(0), identical init on every rank
+    opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000)   # scripts/runall_syn.sh:1
+    model = NeRFNetwork(opt)
+    poses = synthetic.make_cameras(100, seed=0)
+    tr = Stage0Trainer(model, opt, poses, device, rank=rank, world_size=world, seed=0)
+    tr.mark_untrained()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.pretrain + args.warmup):
+        tr.train_step()
+    barrier()
+    if not args.no_prof:
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+    s0, r0 = tr.samples_seen, tr.rays_seen
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    samples, rays = tr.samples_seen - s0, tr.rays_seen - r0
+
+    stats = torch.tensor([dt, float(samples), float(rays)], dtype=torch.float64, device=device)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt, samples, rays = float(mx[0]), float(sm[1]), float(sm[2])
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    kernels = {}
+    if not args.no_prof:
+        for name in ("grid_encode_forward", "grid_encode_backward", "grad_total_variation", "march_rays_train_count",
+                     "march_rays_train_write", "composite_rays_train_forward", "composite_rays_train_backward",
+                     "near_far_from_aabb", "packbits"):
+            n, ms, by = _lib.prof_read(name)
+            if n:
+                kernels[name] = {"launches": n, "avg_us": 1e3 * ms / n, "algo_bytes_per_launch": by / n,
+                                 "GBps": (by / n) / (ms / n * 1e-3) / 1e9 if ms > 0 else None,
+                                 "ms_per_step": ms / args.steps}
+    roof = None
+    if kernels:
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        k = kernels[dom]
+        roof = {"kernel": dom, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (k["GBps"] / HBM_PEAK_GBS) if k["GBps"] else None, "traffic": None,
+                "avg_us": k["avg_us"], "algo_bytes_per_launch": k["algo_bytes_per_launch"],
+                "note": "achieved = algorithmic bytes per launch (SURVEY.md 8d; cache hits count) / mean hipEvent duration over the timed region"}
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline()
+        except Exception as e:   # the baseline is a reported extra; never lose the GPU number over it
+            cpu = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+
+    try:
+        psnr = tr.eval_psnr()
+    except Exception as e:
+        psnr = f"failed: {e!r}"
+
+    line = {
+        "metric": "train_samples_per_sec", "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 march/composite, f16 autocast encode+MLP (reference -O recipe)", "data": "synthetic",
+        "rays_per_sec": rays / dt,
+        "config": {"workload": "nerf_synthetic/lego stage-0 -O --bound 1 --dt_gamma 0, 800x800 x 100 synthetic views, "
+                               "num_points target 2^18/GPU (adaptive num_rays), occupancy refresh every 16 steps",
+                   "parallelism": f"dp{world} (rays sharded, grad all-reduce)" if world > 1 else "single GPU",
+                   "pretrain_steps": args.pretrain, "samples_per_step_per_gpu": samples / args.steps / world,
+                   "rays_per_step_per_gpu": rays / args.steps / world, "params": 18367240},
+        "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "psnr_view0_quarter_res": psnr,
+        "loss_mean": float(tr.loss_acc / max(tr.global_step, 1)),
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,113 @@
+"""ctypes binding of libn2m_hip.so (the C ABI declared in include/n2m_hip.h).
+
+The HIP library IS the product: if it is missing or a call fails, this module raises -- there is no CPU or
+PyTorch fallback anywhere in the package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libn2m_hip.so")
+
+_u32, _i32, _f32, _vp, _int = ctypes.c_uint32, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
+
+# name -> argtypes (restype is always int); mirrors include/n2m_hip.h one to one
+SIGNATURES = {
+    "n2m_near_far_from_aabb": [_vp, _vp, _vp, _u32, _f32, _vp, _vp, _vp],
+    "n2m_sph_from_ray": [_vp, _vp, _f32, _u32, _vp, _vp],
+    "n2m_morton3D": [_vp, _u32, _vp, _vp],
+    "n2m_morton3D_invert": [_vp, _u32, _vp, _vp],
+    "n2m_packbits": [_vp, _u32, _f32, _vp, _vp],
+    "n2m_flatten_rays": [_vp, _u32, _u32, _vp, _vp],
+    "n2m_march_rays_train": [_vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "n2m_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _int, _vp, _vp, _vp, _vp, _vp],
+    "n2m_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _int, _vp, _vp, _vp],
+    "n2m_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "n2m_composite_rays": [_u32, _u32, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "n2m_compact_alive": [_vp, _u32, _vp, _vp, _vp],
+    "n2m_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _int, _u32, _int, _vp],
+    "n2m_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _int, _u32, _int, _vp],
+    "n2m_grad_total_variation": [_vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _int, _vp],
+    "n2m_grid_encode_forward_bm": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int, _vp],
+    "n2m_grid_encode_backward_bm": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int, _vp],
+    "n2m_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp],
+    "n2m_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
+    "n2m_prof_enable": [_int],
+    "n2m_prof_reset": [],
+    "n2m_prof_read": [_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
+}
+
+F32, F16 = 0, 1
+
+KERNEL_IDS = {"grid_encode_forward": 0, "grid_encode_backward": 1, "grad_total_variation": 2, "march_rays_train_count": 3,
+              "march_rays_train_write": 4, "composite_rays_train_forward": 5, "composite_rays_train_backward": 6,
+              "near_far_from_aabb": 7, "packbits": 8, "mlp_forward": 9, "mlp_backward": 10, "rasterize": 11}
+
+_lib = None
+
+
+def lib():
+    """Load the library once. Raises if the HIP build is not present (no fallback by design)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"nerf2mesh_amd: {LIB_PATH} is missing -- build it with `python -m nerf2mesh_amd.build` "
+                "(hipcc, gfx950). There is no CPU / PyTorch fallback for the hot path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)      # AttributeError here = header/library mismatch: fail loudly
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        L.n2m_last_error.restype = ctypes.c_char_p
+        L.n2m_prof_name.restype = ctypes.c_char_p
+        L.n2m_prof_name.argtypes = [_int]
+        L.n2m_abi_version.restype = ctypes.c_int
+        if L.n2m_abi_version() != 1:
+            raise RuntimeError("nerf2mesh_amd: libn2m_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {L.n2m_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check_cuda(**tensors):
+    """The reference's CHECK_CUDA / CHECK_CONTIGUOUS (gridencoder.cu:15-18): RuntimeError like TORCH_CHECK."""
+    for name, t in tensors.items():
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} must be a contiguous tensor")
+
+
+def prof_enable(on=True):
+    call("n2m_prof_enable", int(bool(on)))
+
+
+def prof_reset():
+    call("n2m_prof_reset")
+
+
+def prof_read(kernel):
+    """(launches, total_ms, algorithmic_bytes) of the timed launches of `kernel` since the last reset."""
+    kid = KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+    n, ms, by = ctypes.c_uint64(0), ctypes.c_double(0), ctypes.c_double(0)
+    call("n2m_prof_read", kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by))
+    return int(n.value), float(ms.value), float(by.value)

@@ -1,0 +1,592 @@
+// Multiresolution hash/tiled grid encoder for gfx950.  Replaces the reference's _gridencoder extension
+// (gridencoder/src/gridencoder.cu); entry points are declared in include/n2m_hip.h.
+//
+// Layout in HBM: one table [rows, C] (fp32 or fp16) holding all levels back to back, level l at rows
+// offsets[l]..offsets[l+1]; inputs [B, D] fp32 in [0,1]; features either LEVEL-major [L, B, C] (the reference
+// layout) or SAMPLE-major [B, L*C] (the layout the network consumes).
+//
+// Per-level geometry (scale = 2^(l*S)*H - 1, resolution = ceil(scale)+1) is computed ON THE HOST with the same
+// libm calls as oracle/n2m_oracle.c and handed to the kernels by value, so every lane of every kernel and the
+// oracle agree on it bit for bit (a device exp2f that is 1 ulp off would move ceil() for near-integer scales).
+// The file is compiled with -ffp-contract=off: interpolation weights and fp32 outputs match the oracle exactly;
+// fp16 outputs round at the same points as the reference's at::Half accumulator (gridencoder.cu:163,186).
+#include <math.h>
+
+#include "n2m_common.hpp"
+
+namespace {
+
+constexpr uint32_t kMaxLevels = 32;
+
+struct LevelTable {
+    float scale[kMaxLevels];
+    uint32_t resolution[kMaxLevels];
+};
+
+__host__ LevelTable make_levels(uint32_t L, float S, uint32_t H) {
+    LevelTable t;
+    for (uint32_t l = 0; l < kMaxLevels; ++l) {
+        const float sc = l < L ? exp2f((float)l * S) * (float)H - 1.0f : 0.0f;
+        t.scale[l] = sc;
+        t.resolution[l] = (uint32_t)ceilf(sc) + 1u;
+    }
+    return t;
+}
+
+template <uint32_t D> struct Primes;
+__device__ constexpr uint32_t kPrimes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+
+// How a level maps a grid vertex to a table row; uniform per (kernel, level) so it lives in SGPRs.
+template <uint32_t D>
+struct Indexer {
+    uint32_t stride[D];   // dense strides of the axes that take part (0 = axis dropped: table too small)
+    uint32_t size;
+    uint32_t mask;        // size-1 when size is a power of two
+    bool hashed, pow2, wrap;
+
+    __device__ __forceinline__ Indexer(uint32_t size_, uint32_t resolution, uint32_t gridtype, bool align_corners) : size(size_) {
+        uint32_t s = 1;
+#pragma unroll
+        for (uint32_t d = 0; d < D; ++d) {
+            if (s <= size) {
+                stride[d] = s;
+                s *= align_corners ? resolution : resolution + 1u;
+            } else {
+                stride[d] = 0;
+            }
+        }
+        hashed = (gridtype == 0) && s > size;
+        pow2 = (size & (size - 1u)) == 0u;
+        mask = size - 1u;
+        // a dense index is already < size when every axis has resolution+1 entries (cell+1 <= resolution);
+        // with align_corners an input of exactly 1.0 lands on entry `resolution`, so keep the reference's modulo
+        wrap = hashed || s > size || align_corners;
+    }
+
+    __device__ __forceinline__ uint32_t row(const uint32_t (&v)[D]) const {
+        uint32_t idx = 0;
+        if (hashed) {
+#pragma unroll
+            for (uint32_t d = 0; d < D; ++d) idx ^= v[d] * kPrimes[d];
+        } else {
+#pragma unroll
+            for (uint32_t d = 0; d < D; ++d) idx += v[d] * stride[d];
+        }
+        if (wrap) idx = pow2 ? (idx & mask) : (idx % size);
+        return idx;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- feature I/O
+// A table row / feature vector of C channels, moved with the widest single access.
+template <typename T, uint32_t C> struct Row;
+
+template <uint32_t C>
+struct Row<float, C> {
+    float v[C];
+    __device__ __forceinline__ static Row load(const float* p) {
+        Row r;
+        if constexpr (C == 1) r.v[0] = *p;
+        else if constexpr (C == 2) { const float2 t = *reinterpret_cast<const float2*>(p); r.v[0] = t.x; r.v[1] = t.y; }
+        else {
+#pragma unroll
+            for (uint32_t k = 0; k < C; k += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(p + k);
+                r.v[k] = t.x; r.v[k + 1] = t.y; r.v[k + 2] = t.z; r.v[k + 3] = t.w;
+            }
+        }
+        return r;
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        if constexpr (C == 1) *p = v[0];
+        else if constexpr (C == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+        else {
+#pragma unroll
+            for (uint32_t k = 0; k < C; k += 4) *reinterpret_cast<float4*>(p + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+        }
+    }
+};
+
+template <uint32_t C>
+struct Row<_Float16, C> {
+    _Float16 v[C];
+    __device__ __forceinline__ static Row load(const _Float16* p) {
+        Row r;
+        if constexpr (C == 1) r.v[0] = *p;
+        else if constexpr (C == 2) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); const h2 t = *reinterpret_cast<const h2*>(p); r.v[0] = t.x; r.v[1] = t.y; }
+        else if constexpr (C == 4) { typedef _Float16 h4 __attribute__((ext_vector_type(4))); const h4 t = *reinterpret_cast<const h4*>(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
+        else {
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            const h8 t = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) r.v[k] = t[k];
+        }
+        return r;
+    }
+    __device__ __forceinline__ void store(_Float16* p) const {
+        if constexpr (C == 1) *p = v[0];
+        else if constexpr (C == 2) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); h2 t; t.x = v[0]; t.y = v[1]; *reinterpret_cast<h2*>(p) = t; }
+        else if constexpr (C == 4) { typedef _Float16 h4 __attribute__((ext_vector_type(4))); h4 t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; *reinterpret_cast<h4*>(p) = t; }
+        else {
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            h8 t;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) t[k] = v[k];
+            *reinterpret_cast<h8*>(p) = t;
+        }
+    }
+};
+
+// acc += w * g with the reference's rounding points: fp32 -> one mul + one add (no contraction); fp16 -> the
+// product is rounded to half, then added in half (at::Half `+=` semantics).
+__device__ __forceinline__ void accum(float& acc, float w, float g) { acc += w * g; }
+__device__ __forceinline__ void accum(_Float16& acc, float w, _Float16 g) {
+    const _Float16 p = (_Float16)(w * (float)g);
+    acc = (_Float16)((float)acc + (float)p);
+}
+
+template <uint32_t D>
+__device__ __forceinline__ bool outside_unit_cube(const float (&x)[D]) {
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) oob |= (x[d] < 0.0f) | (x[d] > 1.0f);
+    return oob;
+}
+
+template <uint32_t D>
+__device__ __forceinline__ void locate(const float (&x)[D], float scale, bool align_corners, uint32_t interp,
+                                       uint32_t (&cell)[D], float (&frac)[D], float (&dfrac)[D]) {
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) {
+        float p = x[d] * scale + (align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(p);
+        cell[d] = (uint32_t)fl;
+        p -= (float)cell[d];
+        if (interp == 1) {
+            dfrac[d] = 6 * p * (1.0f - p);
+            p = p * p * (3.0f - 2.0f * p);
+        } else {
+            dfrac[d] = 1.0f;
+        }
+        frac[d] = p;
+    }
+}
+
+template <uint32_t D>
+__device__ __forceinline__ void load_point(const float* __restrict__ inputs, uint32_t b, float (&x)[D]) {
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) x[d] = inputs[(size_t)b * D + d];
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// grid = (ceil(B/256), max_level): one level per blockIdx.y so that a block row works out of one level table.
+template <typename T, uint32_t D, uint32_t C, bool SAMPLE_MAJOR>
+__global__ void __launch_bounds__(256)
+grid_forward_kernel(const float* __restrict__ inputs, const T* __restrict__ table, const int32_t* __restrict__ offsets,
+                    T* __restrict__ outputs, uint32_t B, uint32_t L, LevelTable lv, T* __restrict__ dy_dx,
+                    uint32_t gridtype, bool align_corners, uint32_t interp) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t level = blockIdx.y;
+    if (b >= B) return;
+    const uint32_t row0 = (uint32_t)offsets[level];
+    const uint32_t size = (uint32_t)offsets[level + 1] - row0;
+    const float scale = lv.scale[level];
+    const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
+    const T* __restrict__ tab = table + (size_t)row0 * C;
+    T* out = SAMPLE_MAJOR ? outputs + ((size_t)b * L + level) * C : outputs + ((size_t)level * B + b) * C;
+    T* gout = dy_dx ? dy_dx + ((size_t)b * L + level) * D * C : nullptr;
+
+    float x[D];
+    load_point<D>(inputs, b, x);
+    if (outside_unit_cube<D>(x)) {
+        Row<T, C> z;
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) z.v[c] = (T)0;
+        z.store(out);
+        if (gout) {
+#pragma unroll
+            for (uint32_t d = 0; d < D; ++d) z.store(gout + d * C);
+        }
+        return;
+    }
+    uint32_t cell[D];
+    float frac[D], dfrac[D];
+    locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
+
+    // issue all 2^D gathers before consuming any of them
+    Row<T, C> g[1u << D];
+    float w[1u << D];
+#pragma unroll
+    for (uint32_t corner = 0; corner < (1u << D); ++corner) {
+        uint32_t v[D];
+        float ww = 1.0f;
+#pragma unroll
+        for (uint32_t d = 0; d < D; ++d) {
+            if (corner & (1u << d)) { ww *= frac[d]; v[d] = cell[d] + 1; }
+            else { ww *= 1 - frac[d]; v[d] = cell[d]; }
+        }
+        w[corner] = ww;
+        g[corner] = Row<T, C>::load(tab + (size_t)ix.row(v) * C);
+    }
+    Row<T, C> acc;
+#pragma unroll
+    for (uint32_t c = 0; c < C; ++c) acc.v[c] = (T)0;
+#pragma unroll
+    for (uint32_t corner = 0; corner < (1u << D); ++corner) {
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) accum(acc.v[c], w[corner], g[corner].v[c]);
+    }
+    acc.store(out);
+
+    if (!gout) return;
+    // d out / d x[gd]: the 2^D corner values are already in registers; pair them along axis gd
+#pragma unroll
+    for (uint32_t gd = 0; gd < D; ++gd) {
+        Row<T, C> ga;
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) ga.v[c] = (T)0;
+#pragma unroll
+        for (uint32_t sub = 0; sub < (1u << (D - 1)); ++sub) {
+            float ww = scale;
+            uint32_t left = 0;
+#pragma unroll
+            for (uint32_t nd = 0; nd < D - 1; ++nd) {
+                const uint32_t d = nd >= gd ? nd + 1 : nd;
+                if (sub & (1u << nd)) { ww *= frac[d]; left |= 1u << d; }
+                else ww *= 1 - frac[d];
+            }
+            const uint32_t right = left | (1u << gd);
+#pragma unroll
+            for (uint32_t c = 0; c < C; ++c) {
+                if constexpr (sizeof(T) == 2) {
+                    const T diff = (T)((float)g[right].v[c] - (float)g[left].v[c]);
+                    const T p = (T)(ww * (float)diff * dfrac[gd]);
+                    ga.v[c] = (T)((float)ga.v[c] + (float)p);
+                } else {
+                    ga.v[c] += ww * (g[right].v[c] - g[left].v[c]) * dfrac[gd];
+                }
+            }
+        }
+        ga.store(gout + gd * C);
+    }
+}
+
+// zero-fill of the levels >= max_level for the sample-major layout
+template <typename T>
+__global__ void zero_levels_kernel(T* __restrict__ outputs, uint32_t B, uint32_t LC, uint32_t first, uint32_t count) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)B * count) return;
+    const uint32_t b = (uint32_t)(t / count), k = (uint32_t)(t - (uint64_t)b * count);
+    outputs[(size_t)b * LC + first + k] = (T)0;
+}
+
+// ----------------------------------------------------------------------------------------------- backward
+__device__ __forceinline__ void atomic_add_row(float* dst, const float* v, uint32_t C) {
+    for (uint32_t c = 0; c < C; ++c) unsafeAtomicAdd(dst + c, v[c]);
+}
+
+// one thread per (sample, level): scatter w * grad into the 2^D rows
+template <typename T, uint32_t D, uint32_t C, bool SAMPLE_MAJOR>
+__global__ void __launch_bounds__(256)
+grid_backward_kernel(const T* __restrict__ grad, const float* __restrict__ inputs, const int32_t* __restrict__ offsets,
+                     T* __restrict__ grad_table, uint32_t B, uint32_t L, LevelTable lv, uint32_t gridtype,
+                     bool align_corners, uint32_t interp) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t level = blockIdx.y;
+    if (b >= B) return;
+    const uint32_t row0 = (uint32_t)offsets[level];
+    const uint32_t size = (uint32_t)offsets[level + 1] - row0;
+    const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
+    T* __restrict__ gtab = grad_table + (size_t)row0 * C;
+
+    float x[D];
+    load_point<D>(inputs, b, x);
+    if (outside_unit_cube<D>(x)) return;
+    uint32_t cell[D];
+    float frac[D], dfrac[D];
+    locate<D>(x, lv.scale[level], align_corners, interp, cell, frac, dfrac);
+    const Row<T, C> gr = Row<T, C>::load(SAMPLE_MAJOR ? grad + ((size_t)b * L + level) * C : grad + ((size_t)level * B + b) * C);
+
+#pragma unroll
+    for (uint32_t corner = 0; corner < (1u << D); ++corner) {
+        uint32_t v[D];
+        float w = 1.0f;
+#pragma unroll
+        for (uint32_t d = 0; d < D; ++d) {
+            if (corner & (1u << d)) { w *= frac[d]; v[d] = cell[d] + 1; }
+            else { w *= 1 - frac[d]; v[d] = cell[d]; }
+        }
+        T* dst = gtab + (size_t)ix.row(v) * C;
+        if constexpr (sizeof(T) == 2) {
+            // packed fp16 atomics (global_atomic_pk_add_f16), two channels per instruction (gridencoder.cu:324-330)
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (uint32_t c = 0; c < C; c += 2) {
+                h2 val;
+                val.x = (_Float16)(w * (float)gr.v[c]);
+                val.y = (_Float16)(w * (float)gr.v[c + 1]);
+                (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(dst + c), val);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < C; ++c) unsafeAtomicAdd(dst + c, w * gr.v[c]);
+        }
+    }
+}
+
+// grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]; accumulates in T like the reference (:357-365)
+template <typename T, uint32_t D, uint32_t C>
+__global__ void grid_input_backward_kernel(const T* __restrict__ grad, const T* __restrict__ dy_dx, T* __restrict__ grad_inputs,
+                                           uint32_t B, uint32_t L) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const T* j = dy_dx + (size_t)b * L * D * C + (size_t)d * C;
+    T acc = (T)0;
+    for (uint32_t l = 0; l < L; ++l) {
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) {
+            const T gv = grad[((size_t)l * B + b) * C + c], jv = j[(size_t)l * D * C + c];
+            if constexpr (sizeof(T) == 2) {
+                const T p = (T)((float)gv * (float)jv);
+                acc = (T)((float)acc + (float)p);
+            } else {
+                acc += gv * jv;
+            }
+        }
+    }
+    grad_inputs[t] = acc;
+}
+
+// ------------------------------------------------------------------------------------------ total variation
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256)
+grid_tv_kernel(const float* __restrict__ inputs, const float* __restrict__ table, float* __restrict__ grad,
+               const int32_t* __restrict__ offsets, float weight, uint32_t B, LevelTable lv, uint32_t gridtype,
+               bool align_corners) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t level = blockIdx.y;
+    if (b >= B) return;
+    const uint32_t row0 = (uint32_t)offsets[level];
+    const uint32_t size = (uint32_t)offsets[level + 1] - row0;
+    const uint32_t resolution = lv.resolution[level];
+    const float scale = lv.scale[level];
+    const Indexer<D> ix(size, resolution, gridtype, align_corners);
+    const float* __restrict__ tab = table + (size_t)row0 * C;
+    float* gtab = grad + (size_t)row0 * C;
+
+    float x[D];
+    load_point<D>(inputs, b, x);
+    if (outside_unit_cube<D>(x)) return;
+    uint32_t cell[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) cell[d] = (uint32_t)floorf(x[d] * scale + (align_corners ? 0.0f : 0.5f));
+
+    const uint32_t here = ix.row(cell);
+    const Row<float, C> centre = Row<float, C>::load(tab + (size_t)here * C);
+    float sum[C], sq[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; ++c) { sum[c] = 0.f; sq[c] = 0.f; }
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) {
+        const uint32_t cur = cell[d];
+        if (cur < resolution) {
+            cell[d] = cur + 1;
+            const Row<float, C> nb = Row<float, C>::load(tab + (size_t)ix.row(cell) * C);
+#pragma unroll
+            for (uint32_t c = 0; c < C; ++c) { const float dv = centre.v[c] - nb.v[c]; sum[c] += dv; sq[c] += dv * dv; }
+        }
+        if (cur > 0) {
+            cell[d] = cur - 1;
+            const Row<float, C> nb = Row<float, C>::load(tab + (size_t)ix.row(cell) * C);
+#pragma unroll
+            for (uint32_t c = 0; c < C; ++c) { const float dv = centre.v[c] - nb.v[c]; sum[c] += dv; sq[c] += dv * dv; }
+        }
+        cell[d] = cur;
+    }
+    const float w = weight / (float)(2 * D);
+#pragma unroll
+    for (uint32_t c = 0; c < C; ++c) unsafeAtomicAdd(gtab + (size_t)here * C + c, w * sum[c] * (1.0f / sqrtf(sq[c] + 1e-9f)));
+}
+
+// ------------------------------------------------------------------------------------------------ dispatch
+
+struct FwdArgs {
+    const float* inputs; const void* table; const int32_t* offsets; void* outputs;
+    uint32_t B, L, max_level; LevelTable lv; void* dy_dx; uint32_t gridtype; bool align; uint32_t interp; hipStream_t s;
+};
+
+template <typename T, uint32_t D, uint32_t C, bool BM>
+void launch_forward(const FwdArgs& a) {
+    const dim3 grid(n2m_ceil_div(a.B, 256), a.max_level);
+    grid_forward_kernel<T, D, C, BM><<<grid, 256, 0, a.s>>>(a.inputs, (const T*)a.table, a.offsets, (T*)a.outputs, a.B, a.L, a.lv,
+                                                            (T*)a.dy_dx, a.gridtype, a.align, a.interp);
+}
+
+struct BwdArgs {
+    const void* grad; const float* inputs; const int32_t* offsets; void* grad_table;
+    uint32_t B, L, max_level; LevelTable lv; uint32_t gridtype; bool align; uint32_t interp; hipStream_t s;
+    const void* dy_dx; void* grad_inputs;
+};
+
+template <typename T, uint32_t D, uint32_t C, bool BM>
+void launch_backward(const BwdArgs& a) {
+    const dim3 grid(n2m_ceil_div(a.B, 256), a.max_level);
+    grid_backward_kernel<T, D, C, BM><<<grid, 256, 0, a.s>>>((const T*)a.grad, a.inputs, a.offsets, (T*)a.grad_table, a.B, a.L,
+                                                             a.lv, a.gridtype, a.align, a.interp);
+    if (!BM && a.dy_dx && a.grad_inputs)
+        grid_input_backward_kernel<T, D, C><<<n2m_ceil_div((uint64_t)a.B * D, 256), 256, 0, a.s>>>(
+            (const T*)a.grad, (const T*)a.dy_dx, (T*)a.grad_inputs, a.B, a.L);
+}
+
+struct TvArgs {
+    const float* inputs; const float* table; float* grad; const int32_t* offsets; float weight;
+    uint32_t B, L; LevelTable lv; uint32_t gridtype; bool align; hipStream_t s;
+};
+
+template <uint32_t D, uint32_t C>
+void launch_tv(const TvArgs& a) {
+    const dim3 grid(n2m_ceil_div(a.B, 256), a.L);
+    grid_tv_kernel<D, C><<<grid, 256, 0, a.s>>>(a.inputs, a.table, a.grad, a.offsets, a.weight, a.B, a.lv, a.gridtype, a.align);
+}
+
+// D in {2,3,4,5} x C in {1,2,4,8}: pick the instantiation
+#define N2M_DISPATCH_DC(D, C, FN, ...)                                             \
+    switch ((D) * 16 + (C)) {                                                      \
+        case 2 * 16 + 1: FN(2, 1, __VA_ARGS__); break;                             \
+        case 2 * 16 + 2: FN(2, 2, __VA_ARGS__); break;                             \
+        case 2 * 16 + 4: FN(2, 4, __VA_ARGS__); break;                             \
+        case 2 * 16 + 8: FN(2, 8, __VA_ARGS__); break;                             \
+        case 3 * 16 + 1: FN(3, 1, __VA_ARGS__); break;                             \
+        case 3 * 16 + 2: FN(3, 2, __VA_ARGS__); break;                             \
+        case 3 * 16 + 4: FN(3, 4, __VA_ARGS__); break;                             \
+        case 3 * 16 + 8: FN(3, 8, __VA_ARGS__); break;                             \
+        case 4 * 16 + 1: FN(4, 1, __VA_ARGS__); break;                             \
+        case 4 * 16 + 2: FN(4, 2, __VA_ARGS__); break;                             \
+        case 4 * 16 + 4: FN(4, 4, __VA_ARGS__); break;                             \
+        case 4 * 16 + 8: FN(4, 8, __VA_ARGS__); break;                             \
+        case 5 * 16 + 1: FN(5, 1, __VA_ARGS__); break;                             \
+        case 5 * 16 + 2: FN(5, 2, __VA_ARGS__); break;                             \
+        case 5 * 16 + 4: FN(5, 4, __VA_ARGS__); break;                             \
+        case 5 * 16 + 8: FN(5, 8, __VA_ARGS__); break;                             \
+        default: break;                                                            \
+    }
+
+int check_dims(const char* fn, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, int dtype) {
+    N2M_REQUIRE(D >= 2 && D <= 5, N2M_EINVAL, "%s: GridEncoding: D must be 2, 3, 4 or 5 (got %u)", fn, D);
+    N2M_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8, N2M_EINVAL, "%s: GridEncoding: C must be 1, 2, 4, or 8 (got %u)", fn, C);
+    N2M_REQUIRE(L >= 1 && L <= kMaxLevels, N2M_EINVAL, "%s: L must be in 1..%u (got %u)", fn, kMaxLevels, L);
+    N2M_REQUIRE(max_level <= L, N2M_EINVAL, "%s: max_level %u > L %u", fn, max_level, L);
+    N2M_REQUIRE(dtype == N2M_F32 || dtype == N2M_F16, N2M_EINVAL, "%s: dtype must be N2M_F32 or N2M_F16 (got %d)", fn, dtype);
+    return 0;
+}
+
+#define FWD_CASE(D, C, T, BM, a) launch_forward<T, D, C, BM>(a)
+#define BWD_CASE(D, C, T, BM, a) launch_backward<T, D, C, BM>(a)
+#define TV_CASE(D, C, a) launch_tv<D, C>(a)
+
+template <bool BM>
+int forward_any(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D,
+                uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H, void* dy_dx, uint32_t gridtype,
+                int align_corners, uint32_t interp, int dtype, void* stream, const char* fn) {
+    if (int rc = check_dims(fn, D, C, L, max_level, dtype)) return rc;
+    N2M_REQUIRE(inputs && embeddings && offsets && outputs, N2M_ENULL, "%s: NULL tensor", fn);
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) return 0;
+    const size_t esz = dtype == N2M_F16 ? 2 : 4;
+    if (BM && max_level < L) {
+        const uint32_t first = max_level * C, count = (L - max_level) * C;
+        const uint32_t nb = n2m_ceil_div((uint64_t)B * count, 256);
+        if (dtype == N2M_F16) zero_levels_kernel<_Float16><<<nb, 256, 0, s>>>((_Float16*)outputs, B, L * C, first, count);
+        else zero_levels_kernel<float><<<nb, 256, 0, s>>>((float*)outputs, B, L * C, first, count);
+        N2M_CHECK_LAUNCH();
+    }
+    if (max_level == 0) return 0;
+    FwdArgs a{inputs, embeddings, offsets, outputs, B, L, max_level, make_levels(L, S, H), dy_dx, gridtype, align_corners != 0, interp, s};
+    const double bytes = (double)B * (4.0 * D + (double)max_level * (1u << D) * C * esz + (double)max_level * C * esz +
+                                      (dy_dx ? (double)max_level * D * C * esz : 0.0));
+    N2M_PROF(N2M_K_GRID_FWD, s, bytes);
+    if (dtype == N2M_F16) { N2M_DISPATCH_DC(D, C, FWD_CASE, _Float16, BM, a); }
+    else { N2M_DISPATCH_DC(D, C, FWD_CASE, float, BM, a); }
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+template <bool BM>
+int backward_any(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets, void* grad_embeddings,
+                 uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H, const void* dy_dx,
+                 void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void* stream,
+                 const char* fn) {
+    (void)embeddings;
+    if (int rc = check_dims(fn, D, C, L, max_level, dtype)) return rc;
+    N2M_REQUIRE(grad && inputs && offsets && grad_embeddings, N2M_ENULL, "%s: NULL tensor", fn);
+    N2M_REQUIRE((dy_dx == nullptr) == (grad_inputs == nullptr), N2M_EINVAL, "%s: dy_dx and grad_inputs go together", fn);
+    N2M_REQUIRE(!(dtype == N2M_F16 && (C & 1u)), N2M_EUNSUPPORTED,
+                "%s: fp16 tables with odd C are not supported (the reference's atomicAdd(at::Half*) is an empty stub, "
+                "gridencoder.cu:22-26, and grid.py:45 never selects it)", fn);
+    if (B == 0 || max_level == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t esz = dtype == N2M_F16 ? 2 : 4;
+    BwdArgs a{grad, inputs, offsets, grad_embeddings, B, L, max_level, make_levels(L, S, H), gridtype, align_corners != 0, interp, s,
+              dy_dx, grad_inputs};
+    const double bytes = (double)B * (4.0 * D + (double)max_level * C * esz + 2.0 * max_level * (1u << D) * C * esz);
+    N2M_PROF(N2M_K_GRID_BWD, s, bytes);
+    if (dtype == N2M_F16) { N2M_DISPATCH_DC(D, C, BWD_CASE, _Float16, BM, a); }
+    else { N2M_DISPATCH_DC(D, C, BWD_CASE, float, BM, a); }
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================== C ABI
+
+extern "C" int n2m_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                       uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S,
+                                       uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners, uint32_t interp,
+                                       int dtype, void* stream) {
+    return forward_any<false>(inputs, embeddings, offsets, outputs, B, D, C, L, max_level, S, H, dy_dx, gridtype, align_corners,
+                              interp, dtype, stream, "grid_encode_forward");
+}
+
+extern "C" int n2m_grid_encode_forward_bm(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                          uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S,
+                                          uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                          void* stream) {
+    return forward_any<true>(inputs, embeddings, offsets, outputs, B, D, C, L, max_level, S, H, nullptr, gridtype, align_corners,
+                             interp, dtype, stream, "grid_encode_forward_bm");
+}
+
+extern "C" int n2m_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                        void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                        uint32_t max_level, float S, uint32_t H, const void* dy_dx, void* grad_inputs,
+                                        uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void* stream) {
+    return backward_any<false>(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, max_level, S, H, dy_dx, grad_inputs,
+                               gridtype, align_corners, interp, dtype, stream, "grid_encode_backward");
+}
+
+extern "C" int n2m_grid_encode_backward_bm(const void* grad, const float* inputs, const void* embeddings,
+                                           const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                                           uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
+                                           int align_corners, uint32_t interp, int dtype, void* stream) {
+    return backward_any<true>(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, max_level, S, H, nullptr, nullptr,
+                              gridtype, align_corners, interp, dtype, stream, "grid_encode_backward_bm");
+}
+
+extern "C" int n2m_grad_total_variation(const void* inputs, const void* embeddings, void* grad, const int32_t* offsets,
+                                        float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                        uint32_t gridtype, int align_corners, int dtype, void* stream) {
+    if (int rc = check_dims("grad_total_variation", D, C, L, L, dtype)) return rc;
+    N2M_REQUIRE(inputs && embeddings && grad && offsets, N2M_ENULL, "grad_total_variation: NULL tensor");
+    N2M_REQUIRE(dtype == N2M_F32, N2M_EUNSUPPORTED,
+                "grad_total_variation: fp32 tables only (the reference's fp16 path ends in the empty atomicAdd(at::Half*) "
+                "stub, gridencoder.cu:22-26,606; gridencoder/grid.py:170 runs TV with autocast disabled)");
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    TvArgs a{(const float*)inputs, (const float*)embeddings, (float*)grad, offsets, weight, B, L, make_levels(L, S, H), gridtype,
+             align_corners != 0, s};
+    N2M_PROF(N2M_K_GRID_TV, s, (double)B * (4.0 * D + (double)L * (1 + 2 * D) * C * 4.0 + (double)L * C * 8.0));
+    N2M_DISPATCH_DC(D, C, TV_CASE, a);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}

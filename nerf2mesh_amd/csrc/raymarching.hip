@@ -1,0 +1,702 @@
+// Ray marching + compositing for gfx950 (wave64).  Replaces the reference's _raymarching_mob extension
+// (raymarching/src/raymarching.cu); entry points and their reference counterparts are listed in
+// include/n2m_hip.h.
+//
+// Design notes (MI355X):
+//  * marchers: one ray per lane, 64-thread workgroups so that even a 4096-ray batch spreads over 64 CUs with
+//    one wave per SIMD (the loop is latency-bound: a dependent DDA chain with bit-field lookups that stay in
+//    L1/L2 -- 256 KiB for lego).  Index-deciding arithmetic follows oracle/n2m_oracle.c operation for
+//    operation and this file is compiled with -ffp-contract=off, so sample counts, offsets and sample
+//    positions are bit-identical to the oracle.
+//  * sample packing: counts are turned into offsets by an exclusive scan IN RAY ORDER (deterministic; the
+//    reference's atomicAdd hands out offsets in arrival order).  A wave's 64 rays therefore own one contiguous
+//    slab of the sample buffers.
+//  * compositing (train): one WAVE per ray, lanes = 64 consecutive samples, transmittance by a wave prefix
+//    product, colour/depth sums by wave reductions (forward) / prefix sums (backward).  All loads/stores are
+//    coalesced; the serial per-ray loop of the reference becomes ceil(count/64) wave steps.
+#include <float.h>
+
+#include "n2m_common.hpp"
+
+namespace {
+
+constexpr float kSqrt3 = 1.7320508075688772f;
+
+// ------------------------------------------------------------------------------------------- small kernels
+
+__global__ void near_far_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                const float* __restrict__ aabb, uint32_t N, float min_near,
+                                float* __restrict__ nears, float* __restrict__ fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float tn = 0.f, tf = 0.f;
+    bool hit = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (!hit) break;
+        const float inv = 1.0f / rays_d[3 * n + a];
+        const float org = rays_o[3 * n + a];
+        float lo = (aabb[a] - org) * inv, hi = (aabb[a + 3] - org) * inv;
+        if (lo > hi) { const float t = lo; lo = hi; hi = t; }
+        if (a == 0) { tn = lo; tf = hi; continue; }
+        if (tn > hi || lo > tf) { hit = false; break; }
+        if (lo > tn) tn = lo;
+        if (hi < tf) tf = hi;
+    }
+    if (!hit) { nears[n] = FLT_MAX; fars[n] = FLT_MAX; return; }
+    if (tn < min_near) tn = min_near;
+    nears[n] = tn;
+    fars[n] = tf;
+}
+
+__global__ void sph_from_ray_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, float radius,
+                                    uint32_t N, float* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float rpi = 0.3183098861837907f;
+    const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+    const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+    const float A = dx * dx + dy * dy + dz * dz;
+    const float Bh = ox * dx + oy * dy + oz * dz;
+    const float Cc = ox * ox + oy * oy + oz * oz - radius * radius;
+    const float t = (-Bh + sqrtf(Bh * Bh - A * Cc)) / A;
+    const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+    coords[2 * n] = 2 * atan2f(sqrtf(x * x + z * z), y) * rpi - 1;
+    coords[2 * n + 1] = atan2f(z, x) * rpi;
+}
+
+__global__ void morton_kernel(const int32_t* __restrict__ coords, uint32_t N, int32_t* __restrict__ indices) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int32_t)n2m_morton((uint32_t)coords[3 * n], (uint32_t)coords[3 * n + 1], (uint32_t)coords[3 * n + 2]);
+}
+
+__global__ void morton_invert_kernel(const int32_t* __restrict__ indices, uint32_t N, int32_t* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int32_t v = indices[n];
+    coords[3 * n] = (int32_t)n2m_gather3((uint32_t)(v >> 0));
+    coords[3 * n + 1] = (int32_t)n2m_gather3((uint32_t)(v >> 1));
+    coords[3 * n + 2] = (int32_t)n2m_gather3((uint32_t)(v >> 2));
+}
+
+// One lane packs 4 output bytes from 32 floats read as 8 x float4 (128 B per lane, 8 KiB per wave-iteration).
+__global__ void packbits_kernel(const float* __restrict__ grid, uint32_t N, float thresh, uint8_t* __restrict__ bitfield) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;   // index of a group of 4 output bytes
+    const uint32_t nq = N >> 2;
+    if (q < nq) {
+        const float4* src = reinterpret_cast<const float4*>(grid) + (size_t)q * 8;
+        uint32_t word = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 v = src[k];
+            word |= (uint32_t)(v.x > thresh) << (4 * k);
+            word |= (uint32_t)(v.y > thresh) << (4 * k + 1);
+            word |= (uint32_t)(v.z > thresh) << (4 * k + 2);
+            word |= (uint32_t)(v.w > thresh) << (4 * k + 3);
+        }
+        reinterpret_cast<uint32_t*>(bitfield)[q] = word;
+    } else if (q == nq) {   // tail bytes when N is not a multiple of 4
+        for (uint32_t n = nq * 4; n < N; ++n) {
+            uint32_t bits = 0;
+            for (int i = 0; i < 8; ++i) bits |= (uint32_t)(grid[(size_t)n * 8 + i] > thresh) << i;
+            bitfield[n] = (uint8_t)bits;
+        }
+    }
+}
+
+__global__ void packbits_bytes_kernel(const float* __restrict__ grid, uint32_t N, float thresh, uint8_t* __restrict__ bitfield) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bits |= (uint32_t)(grid[(size_t)n * 8 + i] > thresh) << i;
+    bitfield[n] = (uint8_t)bits;
+}
+
+// one wave per ray: lanes fill the ray's run cooperatively
+__global__ void flatten_rays_kernel(const int32_t* __restrict__ rays, uint32_t N, uint32_t M, int32_t* __restrict__ res) {
+    const uint32_t n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const uint32_t off = (uint32_t)rays[2 * n], cnt = (uint32_t)rays[2 * n + 1];
+    for (uint32_t i = lane; i < cnt; i += 64)
+        if (off + i < M) res[off + i] = (int32_t)n;
+}
+
+// ------------------------------------------------------------------------------------------------ marcher
+
+struct MarchCtx {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+    float bound, dt_gamma, dt_min, dt_max, rH, H3f, Hf, Cf, top;
+    double Hd;
+    bool contract;
+    const uint8_t* __restrict__ bits;
+};
+
+struct MarchSample { float cx, cy, cz, t_after, dt; };
+
+__device__ __forceinline__ int level_from_exponent(float mx, float cascades) {
+    int e;
+    (void)frexpf(mx, &e);
+    return (int)fminf(cascades - 1.0f, fmaxf(0.0f, (float)e));
+}
+
+__device__ __forceinline__ void march_ctx_init(MarchCtx& c, const float* o, const float* d, float eps, const uint8_t* bits,
+                                               float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t C,
+                                               uint32_t H) {
+    c.ox = o[0]; c.oy = o[1]; c.oz = o[2];
+    c.dx = d[0]; c.dy = d[1]; c.dz = d[2];
+    c.rdx = 1.0f / (c.dx + eps); c.rdy = 1.0f / (c.dy + eps); c.rdz = 1.0f / (c.dz + eps);
+    c.bound = bound; c.dt_gamma = dt_gamma; c.contract = contract; c.bits = bits;
+    c.Hf = (float)H; c.Hd = (double)H; c.Cf = (float)C; c.top = (float)(H - 1);
+    c.rH = 1.0f / (float)H;
+    c.H3f = (float)(H * H * H);
+    c.dt_min = 2 * kSqrt3 / (float)max_steps;
+    c.dt_max = 2 * kSqrt3 * bound / (float)H;
+}
+
+// One iteration of the occupancy-grid DDA.  Returns true when a sample is kept (t advanced by one step),
+// false when an empty voxel was skipped (t advanced past its exit face in whole steps).
+__device__ __forceinline__ bool march_step(const MarchCtx& c, float& t, MarchSample& s) {
+    const float x = n2m_clampf(c.ox + t * c.dx, -c.bound, c.bound);
+    const float y = n2m_clampf(c.oy + t * c.dy, -c.bound, c.bound);
+    const float z = n2m_clampf(c.oz + t * c.dz, -c.bound, c.bound);
+    float dt = n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+
+    const float mag = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    const int lp = level_from_exponent(mag, c.Cf);
+    const int ld = level_from_exponent((float)((double)(dt * c.Hf) * 0.5), c.Cf);
+    const int level = lp > ld ? lp : ld;
+    const float mip_bound = fminf(scalbnf(1.0f, level), c.bound);
+    const float mip_rbound = 1.0f / mip_bound;
+
+    float cx = x, cy = y, cz = z;
+    const bool outside = c.contract && mag > 1.0f;
+    if (outside) {
+        const float k = (2.0f - 1.0f / mag) / mag;
+        cx *= k; cy *= k; cz *= k;
+    }
+    const int nx = (int)n2m_clampf((float)(0.5 * (double)(cx * mip_rbound + 1.0f) * c.Hd), 0.0f, c.top);
+    const int ny = (int)n2m_clampf((float)(0.5 * (double)(cy * mip_rbound + 1.0f) * c.Hd), 0.0f, c.top);
+    const int nz = (int)n2m_clampf((float)(0.5 * (double)(cz * mip_rbound + 1.0f) * c.Hd), 0.0f, c.top);
+    const uint32_t index = (uint32_t)((float)level * c.H3f + (float)n2m_morton((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    const bool occ = (c.bits[index >> 3] >> (index & 7u)) & 1u;
+
+    if (occ || outside) {
+        t += dt;
+        s.cx = cx; s.cy = cy; s.cz = cz; s.t_after = t; s.dt = dt;
+        return true;
+    }
+    const float tx = ((((float)nx + 0.5f + 0.5f * copysignf(1.0f, c.dx)) * c.rH * 2 - 1) * mip_bound - cx) * c.rdx;
+    const float ty = ((((float)ny + 0.5f + 0.5f * copysignf(1.0f, c.dy)) * c.rH * 2 - 1) * mip_bound - cy) * c.rdy;
+    const float tz = ((((float)nz + 0.5f + 0.5f * copysignf(1.0f, c.dz)) * c.rH * 2 - 1) * mip_bound - cz) * c.rdz;
+    const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    do {
+        dt = n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+        t += dt;
+    } while (t < tt);
+    return false;
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(64)
+march_train_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
+                   float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                   const float* __restrict__ nears, const float* __restrict__ fars, float* __restrict__ xyzs,
+                   float* __restrict__ dirs, float* __restrict__ ts, int32_t* __restrict__ rays,
+                   const float* __restrict__ noises) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    MarchCtx c;
+    march_ctx_init(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, 0.0f, grid, bound, contract, dt_gamma, max_steps, C, H);
+    uint32_t budget = max_steps;
+    float *px = nullptr, *pd = nullptr, *pt = nullptr;
+    if (WRITE) {
+        const uint32_t off = (uint32_t)rays[2 * n];
+        budget = (uint32_t)rays[2 * n + 1];
+        px = xyzs + 3 * (size_t)off; pd = dirs + 3 * (size_t)off; pt = ts + 2 * (size_t)off;
+    }
+    const float far = fars[n];
+    float t = nears[n];
+    t += n2m_clampf(t * dt_gamma, c.dt_min, c.dt_max) * noises[n];
+    uint32_t kept = 0;
+    MarchSample s;
+    while (t < far && kept < budget) {
+        if (!march_step(c, t, s)) continue;
+        if (WRITE) {
+            px[0] = s.cx; px[1] = s.cy; px[2] = s.cz;
+            pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+            *reinterpret_cast<float2*>(pt) = make_float2(s.t_after, s.dt);
+            px += 3; pd += 3; pt += 2;
+        }
+        ++kept;
+    }
+    if (!WRITE) rays[2 * n + 1] = (int32_t)kept;
+}
+
+__global__ void __launch_bounds__(64)
+march_infer_kernel(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive, const float* __restrict__ rays_t,
+                   const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound, bool contract,
+                   float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                   const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs,
+                   float* __restrict__ ts, const float* __restrict__ noises) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int32_t ray = rays_alive[n];
+    MarchCtx c;
+    march_ctx_init(c, rays_o + 3 * (size_t)ray, rays_d + 3 * (size_t)ray, 1e-10f, grid, bound, contract, dt_gamma, max_steps, C, H);
+    float* px = xyzs + 3 * (size_t)n * n_step;
+    float* pd = dirs + 3 * (size_t)n * n_step;
+    float* pt = ts + 2 * (size_t)n * n_step;
+    const float far = fars[ray];
+    float t = rays_t[ray];
+    t += n2m_clampf(t * dt_gamma, c.dt_min, c.dt_max) * noises[n];
+    uint32_t kept = 0;
+    MarchSample s;
+    while (t < far && kept < n_step) {
+        if (!march_step(c, t, s)) continue;
+        px[0] = s.cx; px[1] = s.cy; px[2] = s.cz;
+        pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+        *reinterpret_cast<float2*>(pt) = make_float2(s.t_after, s.dt);
+        px += 3; pd += 3; pt += 2;
+        ++kept;
+    }
+}
+
+// -------------------------------------------------------------------------------------- exclusive scans
+// Generic exclusive scan over n items; Op supplies load(i), store(i, value, exclusive_prefix), base(), finish(total).
+
+template <class Op>
+__global__ void __launch_bounds__(1024) scan_single_block_kernel(Op op, uint32_t n) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t tile_tot;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint32_t carry = op.base();
+    __syncthreads();   // every lane has read the base before lane 0 may overwrite it in finish()
+    for (uint32_t start = 0; start < n; start += 1024) {
+        const uint32_t i = start + tid;
+        const uint32_t v = i < n ? op.load(i) : 0u;
+        const uint32_t incl = n2m_wave_scan_add_u32(v, (int)lane);
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        if (wid == 0) {
+            const uint32_t tv = lane < 16 ? wave_tot[lane] : 0u;
+            const uint32_t ti = n2m_wave_scan_add_u32(tv, (int)lane);
+            if (lane < 16) wave_tot[lane] = ti - tv;
+            if (lane == 15) tile_tot = ti;
+        }
+        __syncthreads();
+        if (i < n) op.store(i, v, carry + wave_tot[wid] + incl - v);
+        carry += tile_tot;
+        __syncthreads();
+    }
+    if (tid == 0) op.finish(carry);
+}
+
+constexpr uint32_t kScanTile = 2048;   // items per 256-thread block in the 3-phase path (8 per lane)
+
+template <class Op>
+__global__ void __launch_bounds__(256) scan_block_sums_kernel(Op op, uint32_t n, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t base = blockIdx.x * kScanTile;
+    uint32_t acc = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanTile / 256; ++k) {
+        const uint32_t i = base + k * 256 + tid;
+        acc += i < n ? op.load(i) : 0u;
+    }
+    acc = n2m_wave_sum_u32(acc);
+    if (lane == 0) wave_tot[wid] = acc;
+    __syncthreads();
+    if (tid == 0) block_sums[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+// phase B of the 3-phase path: one block turns the per-block sums into exclusive prefixes that already contain
+// op.base() (read here, by a single block, before anything is written back), total -> sums[n_blocks].
+template <class Op>
+struct BlockSumsOp {
+    Op op;
+    uint32_t* sums;
+    uint32_t n_blocks;
+    __device__ uint32_t base() const { return op.base(); }
+    __device__ uint32_t load(uint32_t i) const { return sums[i]; }
+    __device__ void store(uint32_t i, uint32_t, uint32_t excl) const { sums[i] = excl; }
+    __device__ void finish(uint32_t total) const { sums[n_blocks] = total; }
+};
+
+template <class Op>
+__global__ void __launch_bounds__(256) scan_apply_kernel(Op op, uint32_t n, const uint32_t* __restrict__ block_sums,
+                                                         uint32_t n_blocks) {
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t base = blockIdx.x * kScanTile;
+    uint32_t carry = block_sums[blockIdx.x];
+#pragma unroll 1
+    for (uint32_t k = 0; k < kScanTile / 256; ++k) {
+        const uint32_t i = base + k * 256 + tid;
+        const uint32_t v = i < n ? op.load(i) : 0u;
+        const uint32_t incl = n2m_wave_scan_add_u32(v, (int)lane);
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) {
+            const uint32_t x = wave_tot[w];
+            if (w < wid) before += x;
+            total += x;
+        }
+        if (i < n) op.store(i, v, carry + before + incl - v);
+        carry += total;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && tid == 0) op.finish(block_sums[n_blocks]);
+}
+
+template <class Op>
+int run_exclusive_scan(Op op, uint32_t n, hipStream_t stream) {
+    if (n <= 131072u) {
+        scan_single_block_kernel<Op><<<1, 1024, 0, stream>>>(op, n);
+        return 0;
+    }
+    const uint32_t n_blocks = n2m_ceil_div(n, kScanTile);
+    uint32_t* sums = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&sums), sizeof(uint32_t) * (n_blocks + 1), stream);
+    if (e != hipSuccess) return (int)e;
+    scan_block_sums_kernel<Op><<<n_blocks, 256, 0, stream>>>(op, n, sums);
+    scan_single_block_kernel<BlockSumsOp<Op>><<<1, 1024, 0, stream>>>(BlockSumsOp<Op>{op, sums, n_blocks}, n_blocks);
+    scan_apply_kernel<Op><<<n_blocks, 256, 0, stream>>>(op, n, sums, n_blocks);
+    e = hipFreeAsync(sums, stream);
+    return (int)e;
+}
+
+struct RayOffsetsOp {   // rays[n] = (offset, count): offsets from counts, counter[0] += total
+    int32_t* rays;
+    int32_t* counter;
+    __device__ uint32_t base() const { return (uint32_t)counter[0]; }
+    __device__ uint32_t load(uint32_t i) const { return (uint32_t)rays[2 * i + 1]; }
+    __device__ void store(uint32_t i, uint32_t, uint32_t excl) const { rays[2 * i] = (int32_t)excl; }
+    __device__ void finish(uint32_t total) const { counter[0] = (int32_t)total; }
+};
+
+struct CompactOp {
+    const int32_t* in;
+    int32_t* out;
+    int32_t* n_out;
+    __device__ uint32_t base() const { return 0u; }
+    __device__ uint32_t load(uint32_t i) const { return in[i] >= 0 ? 1u : 0u; }
+    __device__ void store(uint32_t i, uint32_t v, uint32_t excl) const { if (v) out[excl] = in[i]; }
+    __device__ void finish(uint32_t total) const { n_out[0] = (int32_t)total; }
+};
+
+// ------------------------------------------------------------------------------------ compositing (train)
+
+// 4 waves per workgroup, one ray per wave.
+__global__ void __launch_bounds__(256)
+composite_train_fwd_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ ts,
+                           const int32_t* __restrict__ rays, uint32_t M, uint32_t N, float T_thresh, bool alpha_mode,
+                           float* __restrict__ weights, float* __restrict__ weights_sum, float* __restrict__ depth,
+                           float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const uint32_t off = (uint32_t)rays[2 * n], cnt = (uint32_t)rays[2 * n + 1];
+    float r = 0, g = 0, b = 0, ws = 0, d = 0;
+    if (cnt != 0 && off + cnt <= M) {
+        float carry_T = 1.0f;
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            const uint32_t k = base + lane;
+            const bool valid = k < cnt;
+            const size_t i = (size_t)off + k;
+            float alpha = 0.f, tmid = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+            if (valid) {
+                const float2 tt = *reinterpret_cast<const float2*>(ts + 2 * i);
+                const float sg = sigmas[i];
+                alpha = alpha_mode ? sg : (1.0f - expf(-sg * tt.y));
+                tmid = tt.x;
+                cr = rgbs[3 * i]; cg = rgbs[3 * i + 1]; cb = rgbs[3 * i + 2];
+            }
+            const float incl = n2m_wave_scan_mul(1.0f - alpha, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T_before = carry_T * excl, T_after = carry_T * incl;
+            // the sample that drives T below the threshold is still composited; everything after it is not
+            const unsigned long long stop = __ballot(valid && T_after < T_thresh);
+            const int last = stop ? (int)__ffsll((long long)stop) - 1 : 63;
+            const bool live = valid && lane <= last;
+            const float w = live ? alpha * T_before : 0.f;
+            if (live) weights[i] = w;
+            r += w * cr; g += w * cg; b += w * cb; ws += w; d += w * tmid;
+            if (stop) break;
+            carry_T = __shfl(T_after, 63, 64);
+        }
+        r = n2m_wave_sum(r); g = n2m_wave_sum(g); b = n2m_wave_sum(b); ws = n2m_wave_sum(ws); d = n2m_wave_sum(d);
+    }
+    if (lane == 0) {
+        weights_sum[n] = ws;
+        depth[n] = d;
+        image[3 * n] = r; image[3 * n + 1] = g; image[3 * n + 2] = b;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+composite_train_bwd_kernel(const float* __restrict__ grad_weights, const float* __restrict__ grad_weights_sum,
+                           const float* __restrict__ grad_depth, const float* __restrict__ grad_image,
+                           const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ ts,
+                           const int32_t* __restrict__ rays, const float* __restrict__ weights_sum,
+                           const float* __restrict__ depth, const float* __restrict__ image, uint32_t M, uint32_t N,
+                           float T_thresh, bool alpha_mode, float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs) {
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const uint32_t off = (uint32_t)rays[2 * n], cnt = (uint32_t)rays[2 * n + 1];
+    if (cnt == 0 || off + cnt > M) return;
+    const float gi0 = grad_image[3 * n], gi1 = grad_image[3 * n + 1], gi2 = grad_image[3 * n + 2];
+    const float gws = grad_weights_sum[n], gd = grad_depth[n];
+    const float rF = image[3 * n], gF = image[3 * n + 1], bF = image[3 * n + 2], wsF = weights_sum[n], dF = depth[n];
+    float carry_T = 1.0f, r0 = 0, g0 = 0, b0 = 0, ws0 = 0, d0 = 0;   // running sums before this chunk
+    for (uint32_t base = 0; base < cnt; base += 64) {
+        const uint32_t k = base + lane;
+        const bool valid = k < cnt;
+        const size_t i = (size_t)off + k;
+        float alpha = 0.f, tmid = 0.f, dt = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, gw = 0.f;
+        if (valid) {
+            const float2 tt = *reinterpret_cast<const float2*>(ts + 2 * i);
+            const float sg = sigmas[i];
+            alpha = alpha_mode ? sg : (1.0f - expf(-sg * tt.y));
+            tmid = tt.x; dt = tt.y;
+            cr = rgbs[3 * i]; cg = rgbs[3 * i + 1]; cb = rgbs[3 * i + 2];
+            gw = grad_weights[i];
+        }
+        const float incl = n2m_wave_scan_mul(1.0f - alpha, lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float T_before = carry_T * excl, T_after = carry_T * incl;
+        const unsigned long long stop = __ballot(valid && T_after < T_thresh);
+        const int last = stop ? (int)__ffsll((long long)stop) - 1 : 63;
+        const bool live = valid && lane <= last;
+        const float w = live ? alpha * T_before : 0.f;
+        // inclusive running sums up to and including this sample
+        const float r = r0 + n2m_wave_scan_add(w * cr, lane);
+        const float g = g0 + n2m_wave_scan_add(w * cg, lane);
+        const float b = b0 + n2m_wave_scan_add(w * cb, lane);
+        const float ws = ws0 + n2m_wave_scan_add(w, lane);
+        const float d = d0 + n2m_wave_scan_add(w * tmid, lane);
+        if (live) {
+            grad_rgbs[3 * i] = gi0 * w; grad_rgbs[3 * i + 1] = gi1 * w; grad_rgbs[3 * i + 2] = gi2 * w;
+            const float scale = alpha_mode ? (1.0f / (1.0f - alpha)) : dt;
+            grad_sigmas[i] = scale * (gi0 * (T_after * cr - (rF - r)) + gi1 * (T_after * cg - (gF - g)) +
+                                      gi2 * (T_after * cb - (bF - b)) + (gws + gw) * (T_after - (wsF - ws)) +
+                                      gd * (T_after * tmid - (dF - d)));
+        }
+        if (stop) break;
+        carry_T = __shfl(T_after, 63, 64);
+        r0 = __shfl(r, 63, 64); g0 = __shfl(g, 63, 64); b0 = __shfl(b, 63, 64);
+        ws0 = __shfl(ws, 63, 64); d0 = __shfl(d, 63, 64);
+    }
+}
+
+// ----------------------------------------------------------------------------------- compositing (inference)
+
+__global__ void composite_infer_kernel(uint32_t n_alive, uint32_t n_step, float T_thresh, bool alpha_mode,
+                                       int32_t* __restrict__ rays_alive, float* __restrict__ rays_t,
+                                       const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                       const float* __restrict__ ts, float* __restrict__ weights_sum,
+                                       float* __restrict__ depth, float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int32_t ray = rays_alive[n];
+    const size_t base = (size_t)n * n_step;
+    float t = 0.0f;
+    float d = depth[ray], r = image[3 * ray], g = image[3 * ray + 1], b = image[3 * ray + 2], ws = weights_sum[ray];
+    uint32_t step = 0;
+    while (step < n_step) {
+        const size_t i = base + step;
+        const float2 tt = *reinterpret_cast<const float2*>(ts + 2 * i);
+        if (tt.x == 0) break;
+        const float alpha = alpha_mode ? sigmas[i] : (1.0f - expf(-sigmas[i] * tt.y));
+        const float T = 1 - ws;
+        const float w = alpha * T;
+        ws += w;
+        t = tt.x;
+        d += w * t;
+        r += w * rgbs[3 * i]; g += w * rgbs[3 * i + 1]; b += w * rgbs[3 * i + 2];
+        if (T < T_thresh) break;
+        ++step;
+    }
+    if (step < n_step) rays_alive[n] = -1; else rays_t[ray] = t;
+    weights_sum[ray] = ws;
+    depth[ray] = d;
+    image[3 * ray] = r; image[3 * ray + 1] = g; image[3 * ray + 2] = b;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+
+extern "C" int n2m_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
+                                      float min_near, float* nears, float* fars, void* stream) {
+    N2M_NOTNULL(rays_o); N2M_NOTNULL(rays_d); N2M_NOTNULL(aabb); N2M_NOTNULL(nears); N2M_NOTNULL(fars);
+    if (N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    N2M_PROF(N2M_K_NEAR_FAR, s, 32.0 * N);
+    near_far_kernel<<<n2m_ceil_div(N, 256), 256, 0, s>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                                void* stream) {
+    N2M_NOTNULL(rays_o); N2M_NOTNULL(rays_d); N2M_NOTNULL(coords);
+    if (N == 0) return 0;
+    sph_from_ray_kernel<<<n2m_ceil_div(N, 256), 256, 0, (hipStream_t)stream>>>(rays_o, rays_d, radius, N, coords);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream) {
+    N2M_NOTNULL(coords); N2M_NOTNULL(indices);
+    if (N == 0) return 0;
+    morton_kernel<<<n2m_ceil_div(N, 256), 256, 0, (hipStream_t)stream>>>(coords, N, indices);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream) {
+    N2M_NOTNULL(coords); N2M_NOTNULL(indices);
+    if (N == 0) return 0;
+    morton_invert_kernel<<<n2m_ceil_div(N, 256), 256, 0, (hipStream_t)stream>>>(indices, N, coords);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream) {
+    N2M_NOTNULL(grid); N2M_NOTNULL(bitfield);
+    if (N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    N2M_PROF(N2M_K_PACKBITS, s, 33.0 * N);
+    const bool aligned = (((uintptr_t)grid & 15u) == 0) && (((uintptr_t)bitfield & 3u) == 0);
+    if (aligned) packbits_kernel<<<n2m_ceil_div((uint64_t)(N >> 2) + 1, 256), 256, 0, s>>>(grid, N, density_thresh, bitfield);
+    else packbits_bytes_kernel<<<n2m_ceil_div(N, 256), 256, 0, s>>>(grid, N, density_thresh, bitfield);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_flatten_rays(const int32_t* rays, uint32_t N, uint32_t M, int32_t* res, void* stream) {
+    N2M_NOTNULL(rays); N2M_NOTNULL(res);
+    if (N == 0) return 0;
+    flatten_rays_kernel<<<n2m_ceil_div((uint64_t)N * 64, 256), 256, 0, (hipStream_t)stream>>>(rays, N, M, res);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                                    int contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                    const float* nears, const float* fars, float* xyzs, float* dirs, float* ts,
+                                    int32_t* rays, int32_t* counter, const float* noises, void* stream) {
+    N2M_NOTNULL(rays_o); N2M_NOTNULL(rays_d); N2M_NOTNULL(grid); N2M_NOTNULL(nears); N2M_NOTNULL(fars);
+    N2M_NOTNULL(rays); N2M_NOTNULL(noises);
+    N2M_REQUIRE(C >= 1 && H >= 1 && H <= 1024 && max_steps >= 1, N2M_EINVAL,
+                "march_rays_train: need C>=1, 1<=H<=1024, max_steps>=1 (got C=%u H=%u max_steps=%u)", C, H, max_steps);
+    N2M_REQUIRE((double)C * H * H * H < 16777216.0 * 8, N2M_EINVAL, "march_rays_train: C*H^3 too large (%u x %u^3)", C, H);
+    const bool first_pass = (xyzs == nullptr);
+    if (!first_pass) { N2M_NOTNULL(dirs); N2M_NOTNULL(ts); }
+    else N2M_NOTNULL(counter);
+    hipStream_t s = (hipStream_t)stream;
+    if (first_pass) {
+        if (N > 0) {
+            N2M_PROF(N2M_K_MARCH_COUNT, s, 52.0 * N);
+            march_train_kernel<false><<<n2m_ceil_div(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
+                                                                         max_steps, N, C, H, nears, fars, nullptr, nullptr,
+                                                                         nullptr, rays, noises);
+            N2M_CHECK_LAUNCH();
+        }
+        const int rc = run_exclusive_scan(RayOffsetsOp{rays, counter}, N, s);
+        if (rc) { n2m_set_error("march_rays_train: offset scan failed (%d)", rc); return rc; }
+        N2M_CHECK_LAUNCH();
+    } else if (N > 0) {
+        N2M_PROF(N2M_K_MARCH_WRITE, s, 44.0 * N);   // + 32 B per sample, added by the caller who knows M
+        march_train_kernel<true><<<n2m_ceil_div(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
+                                                                    max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
+                                                                    noises);
+        N2M_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int n2m_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* ts,
+                                                const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
+                                                int alpha_mode, float* weights, float* weights_sum, float* depth,
+                                                float* image, void* stream) {
+    N2M_NOTNULL(rays); N2M_NOTNULL(weights_sum); N2M_NOTNULL(depth); N2M_NOTNULL(image);
+    if (M > 0) { N2M_NOTNULL(sigmas); N2M_NOTNULL(rgbs); N2M_NOTNULL(ts); N2M_NOTNULL(weights); }
+    if (N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    N2M_PROF(N2M_K_COMPOSITE_FWD, s, 28.0 * M + 28.0 * N);
+    composite_train_fwd_kernel<<<n2m_ceil_div(N, 4), 256, 0, s>>>(sigmas, rgbs, ts, rays, M, N, T_thresh, alpha_mode != 0,
+                                                                   weights, weights_sum, depth, image);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_composite_rays_train_backward(const float* grad_weights, const float* grad_weights_sum,
+                                                 const float* grad_depth, const float* grad_image, const float* sigmas,
+                                                 const float* rgbs, const float* ts, const int32_t* rays,
+                                                 const float* weights_sum, const float* depth, const float* image,
+                                                 uint32_t M, uint32_t N, float T_thresh, int alpha_mode,
+                                                 float* grad_sigmas, float* grad_rgbs, void* stream) {
+    N2M_NOTNULL(rays); N2M_NOTNULL(grad_weights_sum); N2M_NOTNULL(grad_depth); N2M_NOTNULL(grad_image);
+    N2M_NOTNULL(weights_sum); N2M_NOTNULL(depth); N2M_NOTNULL(image);
+    if (M == 0 || N == 0) return 0;
+    N2M_NOTNULL(grad_weights); N2M_NOTNULL(sigmas); N2M_NOTNULL(rgbs); N2M_NOTNULL(ts);
+    N2M_NOTNULL(grad_sigmas); N2M_NOTNULL(grad_rgbs);
+    hipStream_t s = (hipStream_t)stream;
+    N2M_PROF(N2M_K_COMPOSITE_BWD, s, 44.0 * M + 48.0 * N);
+    composite_train_bwd_kernel<<<n2m_ceil_div(N, 4), 256, 0, s>>>(grad_weights, grad_weights_sum, grad_depth, grad_image, sigmas,
+                                                                   rgbs, ts, rays, weights_sum, depth, image, M, N, T_thresh,
+                                                                   alpha_mode != 0, grad_sigmas, grad_rgbs);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                              const float* rays_o, const float* rays_d, float bound, int contract, float dt_gamma,
+                              uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* nears,
+                              const float* fars, float* xyzs, float* dirs, float* ts, const float* noises, void* stream) {
+    (void)nears;
+    if (n_alive == 0 || n_step == 0) return 0;
+    N2M_NOTNULL(rays_alive); N2M_NOTNULL(rays_t); N2M_NOTNULL(rays_o); N2M_NOTNULL(rays_d); N2M_NOTNULL(grid);
+    N2M_NOTNULL(fars); N2M_NOTNULL(xyzs); N2M_NOTNULL(dirs); N2M_NOTNULL(ts); N2M_NOTNULL(noises);
+    N2M_REQUIRE(C >= 1 && H >= 1 && H <= 1024 && max_steps >= 1, N2M_EINVAL, "march_rays: bad C/H/max_steps");
+    march_infer_kernel<<<n2m_ceil_div(n_alive, 64), 64, 0, (hipStream_t)stream>>>(n_alive, n_step, rays_alive, rays_t, rays_o,
+                                                                                 rays_d, bound, contract != 0, dt_gamma,
+                                                                                 max_steps, C, H, grid, fars, xyzs, dirs, ts,
+                                                                                 noises);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int alpha_mode, int32_t* rays_alive,
+                                  float* rays_t, const float* sigmas, const float* rgbs, const float* ts,
+                                  float* weights_sum, float* depth, float* image, void* stream) {
+    if (n_alive == 0) return 0;
+    N2M_NOTNULL(rays_alive); N2M_NOTNULL(rays_t); N2M_NOTNULL(weights_sum); N2M_NOTNULL(depth); N2M_NOTNULL(image);
+    if (n_step > 0) { N2M_NOTNULL(sigmas); N2M_NOTNULL(rgbs); N2M_NOTNULL(ts); }
+    composite_infer_kernel<<<n2m_ceil_div(n_alive, 128), 128, 0, (hipStream_t)stream>>>(n_alive, n_step, T_thresh,
+                                                                                       alpha_mode != 0, rays_alive, rays_t,
+                                                                                       sigmas, rgbs, ts, weights_sum, depth,
+                                                                                       image);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_compact_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out, int32_t* n_out_dev,
+                                 void* stream) {
+    N2M_NOTNULL(n_out_dev);
+    if (n_alive > 0) { N2M_NOTNULL(rays_alive); N2M_NOTNULL(out); }
+    const int rc = run_exclusive_scan(CompactOp{rays_alive, out, n_out_dev}, n_alive, (hipStream_t)stream);
+    if (rc) { n2m_set_error("compact_alive: scan failed (%d)", rc); return rc; }
+    N2M_CHECK_LAUNCH();
+    return 0;
+}

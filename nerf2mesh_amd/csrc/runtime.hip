@@ -1,0 +1,98 @@
+// Library runtime: error reporting and the hipEvent-based per-kernel timing pool behind n2m_prof_*.
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "n2m_common.hpp"
+
+static thread_local char g_err[512] = "";
+
+void n2m_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int n2m_abi_version(void) { return N2M_ABI_VERSION; }
+extern "C" const char* n2m_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------ profiling
+namespace {
+struct Slot {
+    hipEvent_t a, b;
+    int kernel;
+    double bytes;
+};
+constexpr int kPool = 16384;
+std::mutex g_mu;
+std::vector<Slot> g_slots;     // events are created lazily and reused after n2m_prof_reset
+int g_used = 0;
+bool g_on = false;
+uint64_t g_untimed[N2M_K_COUNT];
+const char* kNames[N2M_K_COUNT] = {"grid_encode_forward", "grid_encode_backward", "grad_total_variation",
+                                   "march_rays_train_count", "march_rays_train_write", "composite_rays_train_forward",
+                                   "composite_rays_train_backward", "near_far_from_aabb", "packbits", "mlp_forward",
+                                   "mlp_backward", "rasterize"};
+}  // namespace
+
+N2mProfScope::N2mProfScope(int kernel_id, hipStream_t s, double algo_bytes) : slot(-1), stream(s) {
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_used >= kPool) {
+        g_untimed[kernel_id]++;
+        return;
+    }
+    if (g_used >= (int)g_slots.size()) {
+        Slot sl;
+        if (hipEventCreate(&sl.a) != hipSuccess || hipEventCreate(&sl.b) != hipSuccess) return;
+        g_slots.push_back(sl);
+    }
+    slot = g_used++;
+    g_slots[slot].kernel = kernel_id;
+    g_slots[slot].bytes = algo_bytes;
+    (void)hipEventRecord(g_slots[slot].a, stream);
+}
+
+N2mProfScope::~N2mProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_slots[slot].b, stream);
+}
+
+extern "C" int n2m_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    return 0;
+}
+
+extern "C" int n2m_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_used = 0;
+    memset(g_untimed, 0, sizeof(g_untimed));
+    return 0;
+}
+
+extern "C" int n2m_prof_read(int kernel_id, uint64_t* launches, double* total_ms, double* algo_bytes) {
+    N2M_REQUIRE(kernel_id >= 0 && kernel_id < N2M_K_COUNT, N2M_EINVAL, "n2m_prof_read: bad kernel id %d", kernel_id);
+    std::lock_guard<std::mutex> lk(g_mu);
+    uint64_t n = 0;
+    double ms = 0, bytes = 0;
+    for (int i = 0; i < g_used; ++i) {
+        if (g_slots[i].kernel != kernel_id) continue;
+        N2M_HIP(hipEventSynchronize(g_slots[i].b));
+        float t = 0;
+        N2M_HIP(hipEventElapsedTime(&t, g_slots[i].a, g_slots[i].b));
+        ms += t;
+        bytes += g_slots[i].bytes;
+        ++n;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (algo_bytes) *algo_bytes = bytes;
+    return 0;
+}
+
+extern "C" const char* n2m_prof_name(int kernel_id) {
+    return (kernel_id >= 0 && kernel_id < N2M_K_COUNT) ? kNames[kernel_id] : "?";
+}

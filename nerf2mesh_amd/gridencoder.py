@@ -1,0 +1,177 @@
+"""Multiresolution hash-grid encoder on libn2m_hip.so -- host-side mirror of the reference's gridencoder/grid.py.
+
+`grid_encode` and `GridEncoder` keep the reference's names, arguments, parameter/buffer names and shapes
+(`embeddings [rows, C]`, `offsets [L+1] int32`, so reference checkpoints load unchanged) and its autocast policy
+(fp16 tables iff autocast is on and C is even, grid.py:45).  Differences, all internal:
+
+* features are produced directly SAMPLE-major [B, L*C] by the kernel (n2m_grid_encode_forward_bm) and the
+  backward consumes the incoming gradient in that layout, so the two permute/contiguous passes of
+  grid.py:63,81 (128 B per sample each way) disappear; the level-major ABI entry points remain for the
+  reference's own wrapper (nerf2mesh_amd/backends/_gridencoder.py);
+* level offsets are kept on the host as well, no device read is needed to size anything.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib as L
+
+_p = L.ptr
+
+_gridtype_to_id = {"hash": 0, "tiled": 1}
+_interp_to_id = {"linear": 0, "smoothstep": 1}
+
+
+def _dtype_id(t):
+    return L.F16 if t.dtype == torch.float16 else L.F32
+
+
+class _grid_encode(Function):
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
+                align_corners=False, interpolation=0, max_level=None):
+        inputs = inputs.float().contiguous()
+        B, D = inputs.shape
+        Lv = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = float(np.log2(per_level_scale))
+        H = int(base_resolution)
+        max_level = Lv if max_level is None else min(int(max_level), Lv)
+
+        # autocast policy of the reference: half tables only when C is even (packed fp16 atomics in backward)
+        if torch.is_autocast_enabled() and C % 2 == 0:
+            embeddings = embeddings.to(torch.half)
+        embeddings = embeddings.contiguous()
+        dt = _dtype_id(embeddings)
+        s = L.stream()
+
+        if calc_grad_inputs:
+            # inputs need a gradient (SDF normals through autograd, stage-1 vertex offsets): keep dy_dx
+            outputs = torch.empty(Lv, B, C, device=inputs.device, dtype=embeddings.dtype)
+            dy_dx = torch.empty(B, Lv * D * C, device=inputs.device, dtype=embeddings.dtype)
+            if max_level < Lv:
+                outputs.zero_()
+                dy_dx.zero_()
+            L.call("n2m_grid_encode_forward", _p(inputs), _p(embeddings), _p(offsets), _p(outputs), B, D, C, Lv, max_level, S, H,
+                   _p(dy_dx), gridtype, int(bool(align_corners)), interpolation, dt, s)
+            outputs = outputs.permute(1, 0, 2).reshape(B, Lv * C)
+        else:
+            dy_dx = None
+            outputs = torch.empty(B, Lv * C, device=inputs.device, dtype=embeddings.dtype)
+            L.call("n2m_grid_encode_forward_bm", _p(inputs), _p(embeddings), _p(offsets), _p(outputs), B, D, C, Lv, max_level, S, H,
+                   gridtype, int(bool(align_corners)), interpolation, dt, s)
+
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.cfg = (B, D, C, Lv, S, H, gridtype, interpolation, max_level, int(bool(align_corners)))
+        return outputs
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, Lv, S, H, gridtype, interpolation, max_level, align = ctx.cfg
+        dt = _dtype_id(embeddings)
+        s = L.stream()
+        grad = grad.to(embeddings.dtype)
+        grad_embeddings = torch.zeros_like(embeddings)
+        grad_inputs = None
+        if dy_dx is None:
+            grad = grad.contiguous()                       # [B, L*C], consumed as is
+            L.call("n2m_grid_encode_backward_bm", _p(grad), _p(inputs), _p(embeddings), _p(offsets), _p(grad_embeddings), B, D, C,
+                   Lv, max_level, S, H, gridtype, align, interpolation, dt, s)
+        else:
+            grad = grad.view(B, Lv, C).permute(1, 0, 2).contiguous()
+            grad_inputs = torch.zeros(B, D, device=inputs.device, dtype=embeddings.dtype)
+            L.call("n2m_grid_encode_backward", _p(grad), _p(inputs), _p(embeddings), _p(offsets), _p(grad_embeddings), B, D, C, Lv,
+                   max_level, S, H, _p(dy_dx), _p(grad_inputs), gridtype, align, interpolation, dt, s)
+            grad_inputs = grad_inputs.to(inputs.dtype)
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None
+
+
+def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
+                align_corners=False, interpolation=0, max_level=None):
+    """inputs [B,D] in [0,1], embeddings [rows,C], offsets [L+1] -> features [B, L*C] (gridencoder/grid.py:24-98)."""
+    return _grid_encode.apply(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs, gridtype,
+                              align_corners, interpolation, max_level)
+
+
+def level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners=False):
+    """Row offset of every level (gridencoder/grid.py:121-135): (res+1)^D entries capped at 2^log2_hashmap_size,
+    rounded up to a multiple of 8."""
+    cap = 2 ** log2_hashmap_size
+    offs, off = [], 0
+    for i in range(num_levels):
+        res = int(np.ceil(base_resolution * per_level_scale ** i))
+        n = min(cap, (res if align_corners else res + 1) ** input_dim)
+        n = int(np.ceil(n / 8) * 8)
+        offs.append(off)
+        off += n
+    offs.append(off)
+    return offs
+
+
+class GridEncoder(nn.Module):
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
+                 desired_resolution=None, gridtype="hash", align_corners=False, interpolation="linear"):
+        super().__init__()
+        if desired_resolution is not None:   # finest resolution wins over per_level_scale (grid.py:106-108)
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+        self.input_dim = input_dim
+        self.num_levels = num_levels
+        self.level_dim = level_dim
+        self.per_level_scale = per_level_scale
+        self.log2_hashmap_size = log2_hashmap_size
+        self.base_resolution = base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype = gridtype
+        self.gridtype_id = _gridtype_to_id[gridtype]
+        self.interpolation = interpolation
+        self.interp_id = _interp_to_id[interpolation]
+        self.align_corners = align_corners
+        self.max_params = 2 ** log2_hashmap_size
+
+        offs = level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners)
+        self.host_offsets = offs
+        self.register_buffer("offsets", torch.tensor(offs, dtype=torch.int32))
+        self.n_params = offs[-1] * level_dim
+        self.embeddings = nn.Parameter(torch.empty(offs[-1], level_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.embeddings.data.uniform_(-1e-4, 1e-4)   # grid.py:144-146
+
+    def __repr__(self):
+        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"resolution={self.base_resolution} -> {int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
+                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} gridtype={self.gridtype} "
+                f"align_corners={self.align_corners} interpolation={self.interpolation}")
+
+    def forward(self, inputs, bound=1, max_level=None):
+        """inputs [..., input_dim] in [-bound, bound] -> [..., num_levels*level_dim] (grid.py:151-168)."""
+        inputs = (inputs + bound) / (2 * bound)
+        prefix = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.input_dim)
+        out = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, inputs.requires_grad,
+                          self.gridtype_id, self.align_corners, self.interp_id, max_level)
+        return out.view(prefix + [self.output_dim])
+
+    @torch.no_grad()
+    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
+        """Adds the TV gradient of the cells containing `inputs` into embeddings.grad, in place, in fp32
+        (grid.py:170-192).  Call after backward (and after GradScaler.unscale_) and before optimizer.step."""
+        D, C = self.input_dim, self.embeddings.shape[1]
+        Lv = self.offsets.shape[0] - 1
+        S = float(np.log2(self.per_level_scale))
+        if inputs is None or inputs.size(0) == 0:
+            inputs = torch.rand(B, D, device=self.embeddings.device)
+        else:
+            inputs = ((inputs + bound) / (2 * bound)).view(-1, D)
+            B = inputs.shape[0]
+        if self.embeddings.grad is None:
+            raise ValueError("grad is None, should be called after loss.backward() and before optimizer.step()!")
+        inputs = inputs.float().contiguous()
+        emb = self.embeddings.detach().float().contiguous()
+        L.call("n2m_grad_total_variation", _p(inputs), _p(emb), _p(self.embeddings.grad), _p(self.offsets), float(weight), B, D, C,
+               Lv, S, int(self.base_resolution), self.gridtype_id, int(bool(self.align_corners)), L.F32, L.stream())

@@ -1,0 +1,118 @@
+"""The stage-0/1 field: two hash-grid encoders + three tiny bias-free MLPs, as nerf/network.py:57-208 defines it.
+
+Parameter and buffer names/shapes are the reference's (`encoder.embeddings [6119864,1]`,
+`sigma_net.net.{0,1}.weight [32,19],[1,32]`, `encoder_color.embeddings [6119864,2]`,
+`color_net.net.{0,1,2}.weight [64,35],[64,64],[6,64]`, `specular_net.net.{0,1}.weight [32,6],[3,32]`,
+SURVEY.md section 8b), so a reference checkpoint's model state_dict loads with strict=True.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .activation import trunc_exp
+from .encoding import get_encoder
+from .renderer import NeRFRenderer
+
+
+class MLP(nn.Module):
+    """Linear(+ReLU) stack, `bias=False` everywhere in nerf2mesh (nerf/network.py:10-54; the geom_init /
+    weight_norm variants are only reachable from commented-out code there and are not carried over)."""
+
+    def __init__(self, dim_in, dim_out, dim_hidden, num_layers, bias=True):
+        super().__init__()
+        self.dim_in, self.dim_out, self.dim_hidden, self.num_layers = dim_in, dim_out, dim_hidden, num_layers
+        self.net = nn.ModuleList([
+            nn.Linear(dim_in if l == 0 else dim_hidden, dim_out if l == num_layers - 1 else dim_hidden, bias=bias)
+            for l in range(num_layers)])
+
+    def forward(self, x):
+        for l, layer in enumerate(self.net):
+            x = layer(x)
+            if l != self.num_layers - 1:
+                x = F.relu(x, inplace=True)
+        return x
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, opt, specular_dim=3):
+        super().__init__(opt)
+        if getattr(opt, "tcnn", False):
+            raise NotImplementedError("--tcnn is out of scope (north_star: no tiny-cuda-nn)")
+        # density branch: C=1 table (fp32 even under autocast, grid.py:45) -> 19 -> 32 -> 1
+        self.encoder, self.in_dim_density = get_encoder("hashgrid", level_dim=1, desired_resolution=2048 * self.bound, interpolation="linear")
+        self.sigma_net = MLP(3 + self.in_dim_density, 1, 32, 2, bias=False)
+        # colour branch: C=2 table (fp16 under autocast) -> 35 -> 64 -> 64 -> 3 diffuse + 3 specular features
+        self.encoder_color, self.in_dim_color = get_encoder("hashgrid", level_dim=2, desired_resolution=2048 * self.bound, interpolation="linear")
+        self.color_net = MLP(3 + self.in_dim_color + self.individual_dim, 3 + specular_dim, 64, 3, bias=False)
+        # view-dependent branch: raw direction (no encoding, nerf/network.py:74) + features -> 32 -> 3
+        self.encoder_dir, self.in_dim_dir = get_encoder("None")
+        self.specular_net = MLP(specular_dim + self.in_dim_dir, 3, 32, 2, bias=False)
+        if self.opt.sdf:
+            self.register_parameter("variance", nn.Parameter(torch.tensor(0.3, dtype=torch.float32)))
+
+    def forward(self, x, d, c=None, shading="full"):
+        sigma = self.density(x)["sigma"]
+        color, specular = self.rgb(x, d, c, shading)
+        return sigma, color, specular
+
+    def density(self, x):
+        h = self.encoder(x, bound=self.bound, max_level=self.max_level)
+        h = self.sigma_net(torch.cat([x, h], dim=-1))
+        sigma = h[..., 0].float() if self.opt.sdf else trunc_exp(h[..., 0])
+        return {"sigma": sigma}
+
+    def init_double_sphere(self, r1=0.5, r2=1.5, iters=8192, batch_size=8192):
+        """SDF pre-training towards two nested spheres (nerf/network.py:111-132); SDF mode only."""
+        if not self.opt.sdf:
+            return
+        opt = torch.optim.Adam(list(self.parameters()), lr=1e-3)
+        dev = self.embeddings_device()
+        for _ in range(iters):
+            xyzs = torch.rand(batch_size, 3, device=dev) * 2 * self.bound - self.bound
+            d = torch.norm(xyzs, p=2, dim=-1)
+            gt = torch.where(d < (r1 + r2) / 2, d - r1, r2 - d)
+            loss = F.mse_loss(self.density(xyzs)["sigma"], gt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
+    def embeddings_device(self):
+        return self.encoder.embeddings.device
+
+    def normal(self, x, epsilon=1e-4):
+        """Central finite differences of the density/SDF: 6 extra density() evaluations (nerf/network.py:143-154)."""
+        comps = []
+        for axis in range(3):
+            off = torch.zeros(1, 3, device=x.device)
+            off[0, axis] = epsilon
+            pos = self.density((x + off).clamp(-self.bound, self.bound))["sigma"]
+            neg = self.density((x - off).clamp(-self.bound, self.bound))["sigma"]
+            comps.append(0.5 * (pos - neg) / epsilon)
+        return torch.stack(comps, dim=-1)
+
+    def geo_feat(self, x, c=None):
+        h = self.encoder_color(x, bound=self.bound, max_level=self.max_level)
+        h = torch.cat([x, h], dim=-1)
+        if c is not None:
+            h = torch.cat([h, c.repeat(x.shape[0], 1) if c.shape[0] == 1 else c], dim=-1)
+        return torch.sigmoid(self.color_net(h))
+
+    def rgb(self, x, d, c=None, shading="full"):
+        geo_feat = self.geo_feat(x, c)
+        diffuse = geo_feat[..., :3]
+        if shading == "diffuse":
+            return diffuse, None
+        d = self.encoder_dir(d)
+        specular = torch.sigmoid(self.specular_net(torch.cat([d, geo_feat[..., 3:]], dim=-1)))
+        color = specular if shading == "specular" else (specular + diffuse).clamp(0, 1)
+        return color, specular
+
+    def get_params(self, lr):
+        params = super().get_params(lr)
+        params.extend([{"params": m.parameters(), "lr": lr}
+                       for m in (self.encoder, self.encoder_color, self.sigma_net, self.color_net, self.specular_net)])
+        if self.opt.sdf:
+            params.append({"params": self.variance, "lr": lr * 0.1})
+        return params

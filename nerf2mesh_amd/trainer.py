@@ -1,0 +1,136 @@
+"""Minimal stage-0 training loop: the per-iteration behaviour of the reference's Trainer.train_one_epoch /
+train_step / post_train_step (nerf/utils.py:628-823,1132-1211) and main.py:221-241, without its I/O
+(checkpoints, logging, tensorboard, evaluation images stay the reference's Python).
+
+One iteration = [every 16th: occupancy refresh] -> sample rays -> render (march, encode, MLPs, composite) -> MSE (+ mask,
++ specular reg) -> scaled backward -> [multi-GPU: gradient all-reduce] -> unscale -> in-place TV gradient -> Adam -> LR step.
+Rays come from nerf2mesh_amd.synthetic (no dataset ships with the container); everything stays on the device.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import synthetic
+from .parallel import GradSync
+
+
+class Stage0Trainer:
+    def __init__(self, model, opt, poses, device, rank=0, world_size=1, seed=0):
+        self.model, self.opt, self.device = model.to(device), opt, device
+        self.poses = poses.to(device)
+        self.rank, self.world = rank, world_size
+        self.global_step = 0
+        self.num_rays = opt.num_rays
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(seed + rank)                  # every rank draws its own rays
+        self.optimizer = torch.optim.Adam(model.get_params(opt.lr), eps=1e-15, fused=(device.type == "cuda"))   # main.py:221
+        iters = opt.iters
+        self.scheduler = torch.optim.lr_scheduler.LambdaLR(
+            self.optimizer, lambda it: 0.01 + 0.99 * (it / 500) if it <= 500 else 0.1 ** ((it - 500) / (iters - 500)))   # main.py:239
+        self.scaler = torch.amp.GradScaler("cuda", enabled=bool(opt.fp16) and device.type == "cuda")
+        self.sync = GradSync(model, world_size) if world_size > 1 else None
+        self.boxes = synthetic.boxes(device)
+        self.loss_acc = torch.zeros((), device=device)
+        self.samples_seen = 0
+        self.rays_seen = 0
+        self.last_num_points = 0
+
+    def mark_untrained(self):
+        if self.opt.mark_untrained:
+            f = synthetic.LEGO_FOCAL
+            self.model.mark_untrained_grid(self.poses, (f, f, synthetic.LEGO_HW / 2, synthetic.LEGO_HW / 2))
+
+    def batch(self):
+        rays_o, rays_d = synthetic.random_rays(self.poses, self.num_rays, self.gen)
+        rgba = synthetic.render_gt(rays_o, rays_d, self.boxes)
+        return rays_o, rays_d, rgba
+
+    def train_step(self):
+        opt, model = self.opt, self.model
+        model.train()
+        if self.global_step % opt.update_extra_interval == 0:          # nerf/utils.py:1155-1156
+            if self.sync is not None:
+                self.sync.sync_rng_for_grid_update(self.global_step)
+            model.update_extra_state()
+        self.global_step += 1
+        self.optimizer.zero_grad(set_to_none=False)
+
+        rays_o, rays_d, images = self.batch()
+        N = rays_o.shape[0]
+        bg_color = 1 if opt.background == "white" else torch.rand(N, 3, device=self.device, generator=self.gen)
+        gt_mask = images[..., 3:]
+        gt_rgb = images[..., :3] * gt_mask + bg_color * (1 - gt_mask)
+        if opt.sdf:
+            opt.cos_anneal_ratio = min(1, self.global_step / (0.5 * opt.iters))
+            opt.normal_anneal_epsilon = 1e-1 * (1 - min(0.999, self.global_step / (0.5 * opt.iters)))
+        if opt.progressive_level:
+            model.max_level = 4 + int(12 * min(1, self.global_step / (0.5 * opt.iters)))
+        shading = "diffuse" if (self.global_step < opt.diffuse_step or opt.diffuse_only) else "full"
+
+        out = model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, shading=shading, dt_gamma=opt.dt_gamma,
+                           max_steps=opt.max_steps)
+        loss = opt.lambda_rgb * F.mse_loss(out["image"], gt_rgb, reduction="none").mean(-1)
+        if opt.lambda_mask > 0:
+            loss = loss + opt.lambda_mask * F.mse_loss(out["weights_sum"], gt_mask.squeeze(1), reduction="none")
+        loss = loss.mean()
+        if opt.lambda_entropy > 0:
+            w = out["weights"].clamp(1e-5, 1 - 1e-5)
+            w2 = out["weights_sum"].clamp(1e-5, 1 - 1e-5)
+            ent = lambda p: (-p * torch.log2(p) - (1 - p) * torch.log2(1 - p)).mean()
+            loss = loss + opt.lambda_entropy * (ent(w) + ent(w2))
+        if opt.lambda_specular > 0 and out["speculars"] is not None:
+            loss = loss + opt.lambda_specular * (out["speculars"] ** 2).sum(-1).mean()
+        if opt.sdf and opt.lambda_eikonal > 0:
+            loss = loss + opt.lambda_eikonal * ((torch.linalg.norm(out["normal"], ord=2, dim=-1) - 1) ** 2).mean()
+
+        M = out["num_points"]
+        self.last_num_points = M
+        self.samples_seen += M
+        self.rays_seen += N
+        if opt.adaptive_num_rays and M > 0:                              # nerf/utils.py:796-797
+            self.num_rays = max(1, int(round((opt.num_points / M) * self.num_rays)))
+
+        self.scaler.scale(loss).backward()
+
+        xyzs = out["xyzs"]
+        if self.sync is None:
+            self.scaler.unscale_(self.optimizer)                         # nerf/utils.py:812
+            self._tv(xyzs, 1.0)
+        else:
+            # multi-GPU: every rank adds its own TV term (pre-multiplied by the loss scale), then the summed
+            # gradients are averaged, then unscaled -- so all ranks see identical gradients and inf flags
+            self._tv(xyzs, self.scaler.get_scale() if self.scaler.is_enabled() else 1.0)
+            self.sync.all_reduce()
+            self.scaler.unscale_(self.optimizer)
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+        self.scheduler.step()
+        self.loss_acc += loss.detach()
+        return loss
+
+    def _tv(self, xyzs, scale):
+        opt, model = self.opt, self.model
+        if opt.lambda_tv <= 0 or xyzs is None or xyzs.shape[0] == 0:
+            return
+        lam = opt.lambda_tv * scale
+        if opt.bound > 1:                                                # nerf/utils.py:815-821
+            inner = xyzs.abs().amax(dim=-1) <= 1
+            model.encoder.grad_total_variation(lam, xyzs[inner].contiguous(), model.bound)
+            model.encoder.grad_total_variation(lam * 10, xyzs[~inner].contiguous(), model.bound)
+        else:
+            model.encoder.grad_total_variation(lam, xyzs, model.bound)
+
+    @torch.no_grad()
+    def eval_psnr(self, cam=0, downscale=4):
+        """PSNR of one rendered view against the analytic ground truth (white background)."""
+        self.model.eval()
+        H = W = synthetic.LEGO_HW // downscale
+        dev = self.device
+        jj, ii = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+        pix = (jj * downscale * synthetic.LEGO_HW + ii * downscale).reshape(-1)
+        rays_o, rays_d = synthetic.rays_from_pixels(self.poses, torch.full_like(pix, cam), pix)
+        rgba = synthetic.render_gt(rays_o, rays_d, self.boxes)
+        gt = rgba[:, :3] * rgba[:, 3:] + (1 - rgba[:, 3:])
+        out = self.model.render(rays_o, rays_d, bg_color=1, perturb=False, shading="full", dt_gamma=self.opt.dt_gamma,
+                                max_steps=self.opt.max_steps, T_thresh=1e-4)
+        mse = F.mse_loss(out["image"], gt)
+        return float(-10 * torch.log10(mse))

@@ -1,0 +1,456 @@
+"""GPU parity: libn2m_hip.so (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bars (north_star): bit-exact for ray/sample indexing, occupancy counts and every integer/byte output;
+fp32 tolerance stated per test for floating-point outputs.  Many fp32 outputs are in fact bit-identical to the
+oracle because the HIP sources are compiled with -ffp-contract=off and follow the oracle's operation order;
+where the kernel re-associates (wave-parallel compositing, atomics) the tolerance is written down.
+"""
+import numpy as np
+import pytest
+
+from conftest import lego_offsets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    import torch
+    assert torch.cuda.is_available()
+    from nerf2mesh_amd import backends, _lib
+    _lib.lib()                       # raises if the HIP library is missing: no silent fallback
+    backends.install()
+    import _raymarching_mob, _gridencoder, _shencoder
+    return {"rm": _raymarching_mob, "ge": _gridencoder, "sh": _shencoder, "torch": torch}
+
+
+def dev(be, a):
+    return be["torch"].from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bits_equal(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    v = {2: np.uint16, 4: np.uint32, 1: np.uint8}[a.dtype.itemsize]
+    return np.array_equal(a.view(v), b.view(v))
+
+
+def make_rays(scene, n, seed=0):
+    torch, S = scene["torch"], scene["S"]
+    g = torch.Generator().manual_seed(seed)
+    o, d = S.random_rays(scene["poses"], n, g)
+    return o.numpy(), d.numpy()
+
+
+def test_morton_packbits_flatten(be, oracle):
+    torch, rm = be["torch"], be["rm"]
+    rng = np.random.default_rng(0)
+    c = rng.integers(0, 1024, (100003, 3)).astype(np.int32)
+    out = torch.empty(c.shape[0], dtype=torch.int32, device="cuda")
+    rm.morton3D(dev(be, c), c.shape[0], out)
+    assert np.array_equal(out.cpu().numpy(), oracle.morton3D(c))
+    back = torch.empty(c.shape[0], 3, dtype=torch.int32, device="cuda")
+    rm.morton3D_invert(out, c.shape[0], back)
+    assert np.array_equal(back.cpu().numpy(), c)
+    # full-size occupancy grid (C=1, H=128) and a 5-cascade one with an unaligned tail
+    for n_floats in (128 ** 3, 5 * 128 ** 3, 8 * 1237):
+        grid = rng.normal(size=n_floats).astype(np.float32)
+        grid[:8] = [0.5, np.nextafter(np.float32(0.5), np.float32(1)), 0.4999999, -1, np.nan, np.inf, 0.5, 1]
+        bf = torch.zeros(n_floats // 8, dtype=torch.uint8, device="cuda")
+        rm.packbits(dev(be, grid), n_floats // 8, 0.5, bf)
+        assert np.array_equal(bf.cpu().numpy(), oracle.packbits(grid, 0.5))
+    rays = np.array([[0, 3], [3, 0], [3, 70], [73, 1]], np.int32)
+    res = torch.zeros(74, dtype=torch.int32, device="cuda")
+    rm.flatten_rays(dev(be, rays), 4, 74, res)
+    assert np.array_equal(res.cpu().numpy(), oracle.flatten_rays(rays, 74))
+
+
+def test_near_far(be, oracle, scene):
+    torch, rm = be["torch"], be["rm"]
+    N = 50000
+    o, d = make_rays(scene, N)
+    d[:50, 0] = 0.0
+    d[50:60] = 0.0
+    o[60:80] *= 0.1
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears = torch.empty(N, device="cuda")
+    fars = torch.empty(N, device="cuda")
+    rm.near_far_from_aabb(dev(be, o), dev(be, d), dev(be, aabb), N, 0.05, nears, fars)
+    on, of = oracle.near_far_from_aabb(o, d, aabb, 0.05)
+    assert bits_equal(nears.cpu().numpy(), on) and bits_equal(fars.cpu().numpy(), of)
+
+
+def test_sph_from_ray(be, oracle, scene):
+    torch, rm = be["torch"], be["rm"]
+    o, d = make_rays(scene, 1000)
+    c = torch.empty(1000, 2, device="cuda")
+    rm.sph_from_ray(dev(be, o), dev(be, d), 5.0, 1000, c)
+    np.testing.assert_allclose(c.cpu().numpy(), oracle.sph_from_ray(o, d, 5.0), rtol=0, atol=5e-6)   # atan2/sqrt libm vs ocml
+
+
+def _hip_march_train(be, o, d, bits, bound, contract, dt_gamma, max_steps, C, H, nears, fars, noises):
+    torch, rm = be["torch"], be["rm"]
+    N = o.shape[0]
+    rays = torch.empty(N, 2, dtype=torch.int32, device="cuda")
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    args = (dev(be, o), dev(be, d), dev(be, bits), bound, contract, dt_gamma, max_steps, N, C, H, dev(be, nears), dev(be, fars))
+    nz = dev(be, noises)
+    rm.march_rays_train(*args, None, None, None, rays, counter, nz)
+    M = int(counter.item())
+    xyzs = torch.zeros(M, 3, device="cuda"); dirs = torch.zeros(M, 3, device="cuda"); ts = torch.zeros(M, 2, device="cuda")
+    rm.march_rays_train(*args, xyzs, dirs, ts, rays, counter, nz)
+    return xyzs.cpu().numpy(), dirs.cpu().numpy(), ts.cpu().numpy(), rays.cpu().numpy()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(bound=1.0, contract=False, dt_gamma=0.0, C=1, N=4096),
+    dict(bound=1.0, contract=False, dt_gamma=1 / 256, C=1, N=4096),
+    dict(bound=4.0, contract=False, dt_gamma=1 / 256, C=3, N=3000),
+    dict(bound=4.0, contract=True, dt_gamma=0.0, C=2, N=3000),
+    dict(bound=1.0, contract=False, dt_gamma=0.0, C=1, N=2000, max_steps=64, dense=True),
+    dict(bound=1.0, contract=False, dt_gamma=0.0, C=1, N=200000),          # > 131072 rays: 3-phase scan path
+    dict(bound=1.0, contract=False, dt_gamma=0.0, C=1, N=1000, empty=True),  # all-empty grid: M = 0
+])
+def test_march_rays_train_bit_exact(be, oracle, scene, cfg):
+    S = scene["S"]
+    C, H = cfg["C"], 128 if cfg["C"] == 1 else 64
+    rng = np.random.default_rng(5)
+    if cfg.get("dense"):
+        bits = np.full(C * H ** 3 // 8, 255, np.uint8)
+    elif cfg.get("empty"):
+        bits = np.zeros(C * H ** 3 // 8, np.uint8)
+    elif C == 1:
+        bits = scene["bits"]
+    else:
+        grid = S.scene_density_grid(H=H, cascade=C, bound=cfg["bound"] if not cfg["contract"] else 2.0).numpy()
+        grid += (rng.random(grid.shape) < 0.02).astype(np.float32) * 50
+        bits = oracle.packbits(grid, 10.0)
+    N = cfg["N"]
+    o, d = make_rays(scene, N, seed=9)
+    if cfg["bound"] > 1:
+        o = o * 1.1
+    b = cfg["bound"]
+    nears, fars = oracle.near_far_from_aabb(o, d, np.array([-b, -b, -b, b, b, b], np.float32), 0.05)
+    noises = rng.random(N).astype(np.float32)
+    ms = cfg.get("max_steps", 1024)
+    hx, hd, ht, hr = _hip_march_train(be, o, d, bits, b, cfg["contract"], cfg["dt_gamma"], ms, C, H, nears, fars, noises)
+    ox, od, ot, orr = oracle.march_rays_train(o, d, b, cfg["contract"], bits, C, H, nears, fars, noises, cfg["dt_gamma"], ms)
+    assert np.array_equal(hr, orr), "per-ray (offset, count) must match the oracle exactly"
+    if cfg.get("empty"):
+        assert hx.shape[0] == 0
+        return
+    assert orr[:, 1].sum() > 1000
+    assert bits_equal(hx, ox) and bits_equal(hd, od) and bits_equal(ht, ot)
+
+
+def test_march_counter_base_and_repeatability(be, oracle, scene):
+    """offsets start at the counter's entry value; two runs give identical packing (deterministic scan)."""
+    torch, rm = be["torch"], be["rm"]
+    N = 3000
+    o, d = make_rays(scene, N, seed=21)
+    nears, fars = oracle.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.05)
+    noises = np.zeros(N, np.float32)
+    args = (dev(be, o), dev(be, d), dev(be, scene["bits"]), 1.0, False, 0.0, 1024, N, 1, 128, dev(be, nears), dev(be, fars))
+    outs = []
+    for base in (0, 0, 777):
+        rays = torch.empty(N, 2, dtype=torch.int32, device="cuda")
+        counter = torch.full((1,), base, dtype=torch.int32, device="cuda")
+        rm.march_rays_train(*args, None, None, None, rays, counter, dev(be, noises))
+        outs.append((rays.cpu().numpy(), int(counter.item())))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[2][0][:, 0], outs[0][0][:, 0] + 777) and outs[2][1] == outs[0][1] + 777
+    _, _, _, orr = oracle.march_rays_train(o, d, 1.0, False, scene["bits"], 1, 128, nears, fars, noises, 0.0, 1024, counter0=777)
+    assert np.array_equal(outs[2][0], orr)
+
+
+@pytest.mark.parametrize("alpha_mode", [False, True])
+def test_composite_train(be, oracle, alpha_mode):
+    torch, rm = be["torch"], be["rm"]
+    rng = np.random.default_rng(3)
+    N = 5000
+    counts = rng.integers(0, 200, N).astype(np.int32)
+    counts[:5] = 0
+    counts[10] = 1024
+    offs = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int32)
+    rays = np.stack([offs, counts], 1).astype(np.int32)
+    M = int(counts.sum())
+    rays[7] = [M - 2, 10]                      # overflowing ray -> zeros (guard raymarching.cu:521)
+    sig = (rng.random(M) * (1.0 if alpha_mode else 60.0)).astype(np.float32)
+    sig[offs[10]:offs[10] + 1024] *= 0.002      # a long, thin ray: many chunks before the early stop
+    if alpha_mode:
+        sig = np.clip(sig, 0, 0.98)
+    rgb = rng.random((M, 3)).astype(np.float32)
+    ts = np.stack([np.cumsum(rng.random(M)).astype(np.float32) * 0.01 + 2, np.full(M, 0.0034, np.float32)], 1).astype(np.float32)
+    w = torch.zeros(M, device="cuda"); ws = torch.empty(N, device="cuda"); dp = torch.empty(N, device="cuda"); im = torch.empty(N, 3, device="cuda")
+    rm.composite_rays_train_forward(dev(be, sig), dev(be, rgb), dev(be, ts), dev(be, rays), M, N, 1e-4, alpha_mode, w, ws, dp, im)
+    ow, ows, odp, oim = oracle.composite_rays_train_forward(sig, rgb, ts, rays, 1e-4, alpha_mode)
+    # wave-parallel prefix product / tree sums vs the oracle's serial recurrence: fp32 re-association only.
+    tol = dict(rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(w.cpu().numpy(), ow, **tol)
+    np.testing.assert_allclose(ws.cpu().numpy(), ows, **tol)
+    np.testing.assert_allclose(dp.cpu().numpy(), odp, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(im.cpu().numpy(), oim, **tol)
+    # samples after the early stop are untouched in both (exact zeros), up to threshold ties
+    assert np.mean((w.cpu().numpy() == 0) != (ow == 0)) < 1e-4
+    gw, gws, gd, gi = (rng.normal(size=M).astype(np.float32), rng.normal(size=N).astype(np.float32),
+                       rng.normal(size=N).astype(np.float32), rng.normal(size=(N, 3)).astype(np.float32))
+    gs = torch.zeros(M, device="cuda"); gr = torch.zeros(M, 3, device="cuda")
+    rm.composite_rays_train_backward(dev(be, gw), dev(be, gws), dev(be, gd), dev(be, gi), dev(be, sig), dev(be, rgb), dev(be, ts),
+                                     dev(be, rays), dev(be, ows), dev(be, odp), dev(be, oim), M, N, 1e-4, alpha_mode, gs, gr)
+    ogs, ogr = oracle.composite_rays_train_backward(gw, gws, gd, gi, sig, rgb, ts, rays, ows, odp, oim, 1e-4, alpha_mode)
+    np.testing.assert_allclose(gr.cpu().numpy(), ogr, rtol=2e-5, atol=2e-6)
+    # grad_sigma subtracts nearly equal suffix sums: absolute tolerance scaled to the magnitudes involved
+    scale = np.abs(ogs).max()
+    np.testing.assert_allclose(gs.cpu().numpy(), ogs, rtol=1e-3, atol=2e-5 * max(scale, 1.0))
+
+
+def test_composite_train_matches_autograd(be):
+    """Backward kernel == autograd of the same recurrence in float64."""
+    torch = be["torch"]
+    from nerf2mesh_amd import raymarching
+    rng = np.random.default_rng(12)
+    N = 64
+    counts = rng.integers(1, 90, N)
+    offs = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    rays = torch.tensor(np.stack([offs, counts], 1), dtype=torch.int32, device="cuda")
+    M = int(counts.sum())
+    sig = torch.tensor(rng.random(M) * 20, dtype=torch.float32, device="cuda", requires_grad=True)
+    rgb = torch.tensor(rng.random((M, 3)), dtype=torch.float32, device="cuda", requires_grad=True)
+    ts = torch.tensor(np.stack([np.cumsum(rng.random(M)) * 0.01 + 2, np.full(M, 0.01)], 1), dtype=torch.float32, device="cuda")
+    w, ws, dp, im = raymarching.composite_rays_train(sig, rgb, ts, rays, 0.0, False)     # T_thresh 0: no early stop
+    cw = torch.tensor(rng.normal(size=M), dtype=torch.float32, device="cuda")
+    (im.sum() * 0.7 + (ws * 1.3).sum() + (dp * 0.2).sum() + (w * cw).sum()).backward()
+    s64 = sig.detach().double().cpu().requires_grad_(True)
+    r64 = rgb.detach().double().cpu().requires_grad_(True)
+    t64 = ts.double().cpu()
+    tot = 0
+    for n in range(N):
+        sl = slice(int(offs[n]), int(offs[n] + counts[n]))
+        a = 1 - torch.exp(-s64[sl] * t64[sl, 1])
+        T = torch.cumprod(torch.cat([torch.ones(1, dtype=torch.float64), 1 - a[:-1]]), 0)
+        ww = a * T
+        tot = tot + (ww[:, None] * r64[sl]).sum() * 0.7 + ww.sum() * 1.3 + (ww * t64[sl, 0]).sum() * 0.2 + (ww * cw.double().cpu()[sl]).sum()
+    tot.backward()
+    np.testing.assert_allclose(sig.grad.cpu().numpy(), s64.grad.numpy(), rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(rgb.grad.cpu().numpy(), r64.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_inference_loop(be, oracle, scene):
+    """march_rays / composite_rays / compact_alive over several rounds, state carried on both sides."""
+    torch, rm = be["torch"], be["rm"]
+    from nerf2mesh_amd import raymarching
+    N = 20000
+    o, d = make_rays(scene, N, seed=11)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.05)
+    rng = np.random.default_rng(2)
+    alive_o = np.arange(N, dtype=np.int32)
+    rays_t_o = nears.copy()
+    ws_o, dp_o, im_o = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    alive_h = dev(be, alive_o); rays_t_h = dev(be, rays_t_o)
+    ws_h, dp_h, im_h = dev(be, ws_o), dev(be, dp_o), dev(be, im_o)
+    O, D, B = dev(be, o), dev(be, d), dev(be, scene["bits"])
+    NE, FA = dev(be, nears), dev(be, fars)
+    total = 0
+    for it in range(8):
+        n_alive = alive_o.shape[0]
+        if n_alive == 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        M = n_alive * n_step
+        noises = np.zeros(n_alive, np.float32)
+        xyzs = torch.zeros(M, 3, device="cuda"); dirs = torch.zeros(M, 3, device="cuda"); ts = torch.zeros(M, 2, device="cuda")
+        rm.march_rays(n_alive, n_step, alive_h, rays_t_h, O, D, 1.0, False, 0.0, 1024, 1, 128, B, NE, FA, xyzs, dirs, ts, dev(be, noises))
+        ox, od, ot = oracle.march_rays(n_alive, n_step, alive_o, rays_t_o, o, d, 1.0, False, scene["bits"], 1, 128, nears, fars, noises)
+        assert bits_equal(xyzs.cpu().numpy(), ox) and bits_equal(dirs.cpu().numpy(), od) and bits_equal(ts.cpu().numpy(), ot)
+        total += int((ot[:, 0] > 0).sum())
+        sig = (rng.random(M) * 40).astype(np.float32)
+        rgb = rng.random((M, 3)).astype(np.float32)
+        rm.composite_rays(n_alive, n_step, 1e-2, False, alive_h, rays_t_h, dev(be, sig), dev(be, rgb), ts, ws_h, dp_h, im_h)
+        oracle.composite_rays(n_alive, n_step, alive_o, rays_t_o, sig, rgb, ot, ws_o, dp_o, im_o, 1e-2, False)
+        assert np.array_equal(alive_h.cpu().numpy(), alive_o)             # same rays end, exactly
+        assert bits_equal(rays_t_h.cpu().numpy(), rays_t_o)
+        # same serial arithmetic per ray on both sides (no re-association): bit-identical unless expf differs
+        np.testing.assert_allclose(ws_h.cpu().numpy(), ws_o, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(im_h.cpu().numpy(), im_o, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(dp_h.cpu().numpy(), dp_o, rtol=1e-6, atol=1e-6)
+        alive_h = raymarching.compact_alive(alive_h)
+        alive_o = oracle.compact_alive(alive_o).copy()
+        assert np.array_equal(alive_h.cpu().numpy(), alive_o)
+        # hand the oracle's accumulators to the device so rounding differences cannot compound across rounds
+        ws_h, dp_h, im_h = dev(be, ws_o), dev(be, dp_o), dev(be, im_o)
+    assert total > 5000
+
+
+def test_compact_alive_large(be, oracle):
+    torch = be["torch"]
+    from nerf2mesh_amd import raymarching
+    rng = np.random.default_rng(4)
+    for n in (0, 1, 63, 1024, 131072, 131073, 640000):
+        a = rng.integers(-1, 5, n).astype(np.int32)
+        a[a >= 0] = np.arange((a >= 0).sum(), dtype=np.int32)
+        got = raymarching.compact_alive(dev(be, a)).cpu().numpy() if n else np.zeros(0, np.int32)
+        assert np.array_equal(got, oracle.compact_alive(a))
+
+
+GRID_CASES = [
+    (3, 1, False, 0, False, 0),
+    (3, 2, True, 0, False, 0),
+    (3, 2, False, 0, False, 0),
+    (3, 4, True, 1, False, 1),
+    (2, 8, False, 0, True, 0),
+    (3, 8, True, 0, False, 1),
+    (4, 2, False, 0, False, 0),
+    (5, 1, False, 0, False, 0),
+    (2, 4, False, 1, True, 1),
+]
+
+
+@pytest.mark.parametrize("D,C,half,gridtype,align,interp", GRID_CASES)
+def test_grid_encode_forward_exact(be, oracle, D, C, half, gridtype, align, interp):
+    """Forward (+dy_dx), both layouts: BIT-identical to the oracle in fp32 and fp16."""
+    torch, ge = be["torch"], be["ge"]
+    from nerf2mesh_amd import _lib as L
+    rng = np.random.default_rng(4)
+    Lv, H = (16, 16) if D == 3 else (8, 8)
+    pls = 1.3819129 if D == 3 else 1.5
+    offs = oracle.level_offsets(D, Lv, pls, H, 19 if D == 3 else 14, align)
+    S = float(np.log2(pls))
+    emb = (rng.random((int(offs[-1]), C), dtype=np.float32) * 2 - 1) * (0.5 if half else 1e-1)
+    B = 20011
+    x = rng.random((B, D), dtype=np.float32)
+    x[0] = 0.0; x[1] = 1.0; x[2, 0] = -0.001; x[3, 1] = 1.001
+    embt = emb.astype(np.float16) if half else emb
+    tdt = torch.float16 if half else torch.float32
+    X, E, O = dev(be, x), dev(be, embt), dev(be, offs)
+    for max_level in (Lv, 5):
+        out = torch.zeros(Lv, B, C, dtype=tdt, device="cuda")
+        dy = torch.zeros(B, Lv * D * C, dtype=tdt, device="cuda")
+        ge.grid_encode_forward(X, E, O, out, B, D, C, Lv, max_level, S, H, dy, gridtype, align, interp)
+        oo, ody = oracle.grid_encode_forward(x, embt, offs, S, H, max_level, True, gridtype, align, interp)
+        assert bits_equal(out.cpu().numpy(), oo)
+        assert bits_equal(dy.cpu().numpy(), ody)
+        bm = torch.full((B, Lv * C), 7.0, dtype=tdt, device="cuda")
+        L.call("n2m_grid_encode_forward_bm", X.data_ptr(), E.data_ptr(), O.data_ptr(), bm.data_ptr(), B, D, C, Lv, max_level, S, H,
+               gridtype, int(align), interp, L.F16 if half else L.F32, L.stream())
+        assert bits_equal(bm.cpu().numpy(), oo.transpose(1, 0, 2).reshape(B, Lv * C))
+
+
+@pytest.mark.parametrize("D,C,half,gridtype,align,interp", [c for c in GRID_CASES if not (c[2] and c[1] % 2)])
+def test_grid_encode_backward(be, oracle, D, C, half, gridtype, align, interp):
+    """Backward: atomics make the summation order free, so fp tolerance (fp32: 1e-5 rel; fp16: half ulps of the sums)."""
+    torch, ge = be["torch"], be["ge"]
+    from nerf2mesh_amd import _lib as L
+    rng = np.random.default_rng(14)
+    Lv, H = (16, 16) if D == 3 else (8, 8)
+    pls = 1.3819129 if D == 3 else 1.5
+    offs = oracle.level_offsets(D, Lv, pls, H, 19 if D == 3 else 14, align)
+    S = float(np.log2(pls))
+    emb = (rng.random((int(offs[-1]), C), dtype=np.float32) * 2 - 1) * 0.1
+    B = 6007
+    x = rng.random((B, D), dtype=np.float32)
+    x[2, 0] = -0.001
+    embt = emb.astype(np.float16) if half else emb
+    tdt = torch.float16 if half else torch.float32
+    X, E, O = dev(be, x), dev(be, embt), dev(be, offs)
+    g = rng.normal(size=(Lv, B, C)).astype(embt.dtype)
+    _, ody = oracle.grid_encode_forward(x, embt, offs, S, H, Lv, True, gridtype, align, interp)
+    for max_level in (Lv, 5):
+        ge_out = torch.zeros(int(offs[-1]), C, dtype=tdt, device="cuda")
+        gin = torch.zeros(B, D, dtype=tdt, device="cuda")
+        ge.grid_encode_backward(dev(be, g), X, E, O, ge_out, B, D, C, Lv, max_level, S, H, dev(be, ody), gin, gridtype, align, interp)
+        og, ogi = oracle.grid_encode_backward(g, x, embt, offs, S, H, max_level, ody, gridtype, align, interp)
+        got = ge_out.cpu().numpy().astype(np.float32)
+        ref = og.astype(np.float32)
+        if half:
+            # coarse rows sum hundreds of half-rounded terms: compare against an fp64 accumulation bound
+            np.testing.assert_allclose(got, ref, rtol=3e-2, atol=3e-2 * np.abs(ref).max())
+        else:
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+        assert bits_equal(gin.cpu().numpy(), ogi)           # input gradient is a serial per-thread sum: exact
+        gbm = torch.zeros(int(offs[-1]), C, dtype=tdt, device="cuda")
+        gsm = dev(be, np.ascontiguousarray(g.transpose(1, 0, 2)).reshape(B, Lv * C))
+        L.call("n2m_grid_encode_backward_bm", gsm.data_ptr(), X.data_ptr(), E.data_ptr(), O.data_ptr(), gbm.data_ptr(), B, D, C, Lv,
+               max_level, S, H, gridtype, int(align), interp, L.F16 if half else L.F32, L.stream())
+        got2 = gbm.cpu().numpy().astype(np.float32)
+        if half:
+            np.testing.assert_allclose(got2, ref, rtol=3e-2, atol=3e-2 * np.abs(ref).max())
+        else:
+            np.testing.assert_allclose(got2, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+
+
+def test_grid_backward_linearity_full_size(be):
+    """Size-independent property at the BASELINE size (B = 2^18, lego tables): backward is linear in grad and
+    sum(grad_embeddings) == sum_b sum_l grad[b,l] (the 8 interpolation weights of a sample sum to 1)."""
+    torch = be["torch"]
+    from nerf2mesh_amd.gridencoder import GridEncoder
+    enc = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    B = 2 ** 18
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand(B, 3, device="cuda", generator=g) * 2 - 1
+    out = enc(x, bound=1)
+    assert out.shape == (B, 16)
+    w = torch.randn(B, 16, device="cuda", generator=g)
+    (out * w).sum().backward()
+    g1 = enc.embeddings.grad.clone()
+    enc.embeddings.grad = None
+    (enc(x, bound=1) * (2.5 * w)).sum().backward()
+    np.testing.assert_allclose(enc.embeddings.grad.sum().item(), 2.5 * g1.sum().item(), rtol=1e-3)
+    np.testing.assert_allclose(g1.double().sum().item(), w.double().sum().item(), rtol=1e-3, atol=1.0)
+    # per-level mass conservation
+    offs = enc.host_offsets
+    for l in (0, 4, 5, 15):
+        np.testing.assert_allclose(g1[offs[l]:offs[l + 1]].double().sum().item(), w[:, l].double().sum().item(), rtol=1e-3, atol=0.5)
+
+
+def test_grad_total_variation(be, oracle):
+    torch, ge = be["torch"], be["ge"]
+    rng = np.random.default_rng(6)
+    offs, S = lego_offsets(1.0)
+    emb = (rng.random((int(offs[-1]), 1), dtype=np.float32) * 2 - 1) * 1e-2
+    x = rng.random((50000, 3), dtype=np.float32)
+    x[:3] = [[0, 0, 0], [1, 1, 1], [1.2, 0.5, 0.5]]
+    g0 = rng.normal(size=emb.shape).astype(np.float32) * 1e-6
+    g_h = dev(be, g0)
+    g_o = g0.copy()
+    ge.grad_total_variation(dev(be, x), dev(be, emb), g_h, dev(be, offs), 1e-3, 50000, 3, 1, 16, S, 16, 0, False)
+    oracle.grad_total_variation(x, emb, g_o, offs, 1e-3, S, 16, 0, False)
+    np.testing.assert_allclose(g_h.cpu().numpy(), g_o, rtol=1e-4, atol=1e-8)    # atomic order only
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_sh_encode(be, oracle, degree):
+    torch, sh = be["torch"], be["sh"]
+    rng = np.random.default_rng(7)
+    B = 10007
+    v = rng.normal(size=(B, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v[0] = [0, 0, 1]; v[1] = [1, 0, 0]; v[2] = [0, -1, 0]
+    out = torch.empty(B, degree ** 2, device="cuda")
+    dy = torch.empty(B, 3 * degree ** 2, device="cuda")
+    sh.sh_encode_forward(dev(be, v), out, B, 3, degree, dy)
+    oo, ody = oracle.sh_encode_forward(v, degree, True)
+    # fp32 recurrences vs the oracle's double evaluation: a few ulp of O(1) values, derivative entries up to O(100)
+    np.testing.assert_allclose(out.cpu().numpy(), oo, rtol=0, atol=4e-6)
+    np.testing.assert_allclose(dy.cpu().numpy(), ody, rtol=4e-6, atol=1e-4)
+    out2 = torch.empty(B, degree ** 2, device="cuda")
+    sh.sh_encode_forward(dev(be, v), out2, B, 3, degree, None)
+    assert bits_equal(out2.cpu().numpy(), out.cpu().numpy())
+    g = rng.normal(size=(B, degree ** 2)).astype(np.float32)
+    gi = torch.zeros(B, 3, device="cuda")
+    sh.sh_encode_backward(dev(be, g), dev(be, v), B, 3, degree, dev(be, ody), gi)
+    assert bits_equal(gi.cpu().numpy(), oracle.sh_encode_backward(g, v, degree, ody))
+
+
+def test_error_behaviour(be):
+    """Same error surface as the reference: RuntimeError for unsupported C/D and bad tensors."""
+    torch, ge = be["torch"], be["ge"]
+    x = torch.rand(8, 3, device="cuda")
+    emb = torch.rand(64, 3, device="cuda")
+    offs = torch.tensor([0, 64], dtype=torch.int32, device="cuda")
+    out = torch.empty(1, 8, 3, device="cuda")
+    with pytest.raises(RuntimeError, match="C must be 1, 2, 4, or 8"):
+        ge.grid_encode_forward(x, emb, offs, out, 8, 3, 3, 1, 1, 0.5, 16, None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        ge.grid_encode_forward(x.cpu(), emb, offs, out, 8, 3, 3, 1, 1, 0.5, 16, None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ge.grid_encode_forward(x.t().contiguous().t(), emb, offs, out, 8, 3, 3, 1, 1, 0.5, 16, None, 0, False, 0)

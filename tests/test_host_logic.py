@@ -1,0 +1,74 @@
+"""CPU tests of the host-side logic: options, level geometry, network parameter inventory, synthetic rays."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from nerf2mesh_amd import synthetic as S
+from nerf2mesh_amd.gridencoder import level_offsets
+from nerf2mesh_amd.options import make_options
+
+
+def test_options_recipes():
+    o = make_options(O=True, bound=1, dt_gamma=0)            # scripts/runall_syn.sh:1
+    assert o.fp16 and o.mark_untrained and o.adaptive_num_rays and o.cuda_ray and not o.contract
+    o = make_options(O=True, bound=16, sdf=True)             # main.py:138-157
+    assert o.contract and o.density_thresh == 0.001 and o.progressive_level and not o.mark_untrained
+    with pytest.raises(TypeError):
+        make_options(nonsense=1)
+
+
+def test_level_offsets_known_answers():
+    pls = np.exp2(np.log2(2048 / 16) / 15)
+    offs = level_offsets(3, 16, pls, 16, 19)
+    assert offs[-1] == 6119864
+    assert np.diff(offs).tolist() == [4920, 13824, 32768, 85184, 216000] + [524288] * 11
+    pls16 = np.exp2(np.log2(2048 * 16 / 16) / 15)
+    assert level_offsets(3, 16, pls16, 16, 19)[-1] == 6837544
+    pls2 = np.exp2(np.log2(2048 * 2 / 16) / 15)
+    assert level_offsets(3, 16, pls2, 16, 19)[-1] == 6328848
+
+
+def test_network_inventory_matches_reference_checkpoint_keys():
+    from nerf2mesh_amd.network import NeRFNetwork
+    m = NeRFNetwork(make_options(O=True, bound=1, dt_gamma=0))
+    sd = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert sum(p.numel() for p in m.parameters()) == 18367240
+    assert sd["encoder.embeddings"] == (6119864, 1) and sd["encoder_color.embeddings"] == (6119864, 2)
+    assert sd["sigma_net.net.0.weight"] == (32, 19) and sd["sigma_net.net.1.weight"] == (1, 32)
+    assert sd["color_net.net.0.weight"] == (64, 35) and sd["color_net.net.2.weight"] == (6, 64)
+    assert sd["specular_net.net.0.weight"] == (32, 6) and sd["specular_net.net.1.weight"] == (3, 32)
+    assert sd["density_grid"] == (1, 128 ** 3) and sd["density_bitfield"] == (128 ** 3 // 8,)
+    assert sd["encoder.offsets"] == (17,) and m.encoder.offsets.dtype == torch.int32
+    assert float(m.encoder.embeddings.abs().max()) <= 1e-4
+    m5 = NeRFNetwork(make_options(bound=16))
+    assert m5.cascade == 5 and m5.density_bitfield.numel() == 5 * 128 ** 3 // 8
+
+
+def test_rays_follow_get_rays():
+    poses = S.make_cameras(4, seed=1)
+    # pixel centre of the image looks straight down -z of the camera, i.e. at the origin
+    pix = torch.tensor([400 * 800 + 400])
+    o, d = S.rays_from_pixels(poses, torch.tensor([2]), pix)
+    assert abs(float(o.norm()) - S.LEGO_RADIUS) < 1e-4
+    fwd = -poses[2, :3, 2]
+    dn = d[0] / d[0].norm()
+    assert float((dn - fwd).abs().max()) < 2e-3                     # half-pixel offset only
+    # the direction's camera-space z is exactly -1 (un-normalised, so t is z-depth: nerf/utils.py:282-288)
+    assert abs(float((d[0] @ poses[2, :3, 2])) + 1.0) < 1e-6
+    assert abs(S.LEGO_FOCAL - 1111.111) < 0.01
+
+
+def test_scene_and_gt():
+    g = S.scene_density_grid(H=64)
+    occ = float((g > 0).float().mean())
+    assert 0.01 < occ < 0.10
+    poses = S.make_cameras(8, seed=2)
+    o, d = S.random_rays(poses, 2000, torch.Generator().manual_seed(0))
+    rgba = S.render_gt(o, d)
+    assert 0.03 < float(rgba[:, 3].mean()) < 0.6
+    assert float(rgba[:, :3].max()) <= 1.0
+    # Morton helper agrees with its definition
+    c = torch.tensor([[1, 0, 0], [0, 1, 0], [0, 0, 1], [127, 127, 127]])
+    assert S.morton3D_torch(c).tolist() == [1, 2, 4, 2 ** 21 - 1]
