@@ -11,6 +11,7 @@
 // The file is compiled with -ffp-contract=off: interpolation weights and fp32 outputs match the oracle exactly;
 // fp16 outputs round at the same points as the reference's at::Half accumulator (gridencoder.cu:163,186).
 #include <math.h>
+#include <stdlib.h>
 
 #include "n2m_common.hpp"
 
@@ -334,6 +335,172 @@ grid_backward_kernel(const T* __restrict__ grad, const float* __restrict__ input
     }
 }
 
+
+// ------------------------------------------------------------------------- backward, LDS-privatised (D = 3)
+// Measured on MI355X (tools/atomic_bench.hip): a float atomic costs one request per DISTINCT 64-byte line per
+// wave instruction, ~21 G requests/s chip-wide whatever the scope or the XCD; 16 lanes on one line merge into a
+// single request (317 G atomics/s).  The per-sample scatter of the kernel above issues 8 scattered atomics per
+// (sample, level) = 33.5 M line requests for 2^18 samples -> ~2 ms.  This kernel removes them from the hot loop:
+//
+//   work item = (level, partition of <= P table rows, group of samples); one 1024-thread workgroup per item keeps
+//   the partition's gradient in LDS as fp32 (P*C*4 = 128 KiB), sweeps its samples, recomputes the 8 vertex rows
+//   and ds_add's the ones that fall into its partition, then flushes the partition with COALESCED global atomics
+//   (consecutive lanes -> consecutive rows -> 16 lanes per 64 B line).
+//
+// Re-deriving the rows once per partition costs ALU only (~70 VALU ops per sample-level-partition, ~50 us for the
+// lego tables); scattered traffic stays inside the CU.  Dense (coarse) levels put long runs of consecutive samples
+// of a ray on the same row, which would serialise in the LDS atomic unit, so for those levels equal-row runs of
+// adjacent lanes are first combined with a segmented wave scan and only run tails touch LDS.
+// fp16 tables: products are accumulated in fp32 and rounded to half once per flush (the reference rounds every
+// product to half and adds in half, gridencoder.cu:324-330 -- this is strictly more accurate, same expectation).
+// Gradients are read LEVEL-major [L,B,C]; a sample-major producer is transposed first (33 MB, ~10 us).
+
+template <typename T>
+__global__ void transpose_to_level_major_kernel(const T* __restrict__ src /*[B, LC]*/, T* __restrict__ dst /*[LC/C... as [L,B,C]]*/,
+                                                uint32_t B, uint32_t L, uint32_t C) {
+    // thread -> (j = l*C + c, b) with b fastest: coalesced writes, line-granular (L1/L2-absorbed) reads
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t LC = L * C;
+    if (t >= (uint64_t)B * LC) return;
+    const uint32_t j = (uint32_t)(t / B), b = (uint32_t)(t - (uint64_t)j * B);
+    const uint32_t l = j / C, c = j - l * C;
+    dst[((size_t)l * B + b) * C + c] = src[(size_t)b * LC + j];
+}
+
+constexpr uint32_t kLdsBytes = 131072;   // accumulator bytes per workgroup (one workgroup per CU)
+
+template <typename T, uint32_t C>
+__global__ void __launch_bounds__(1024)
+grid_backward_lds_kernel(const T* __restrict__ grad /*[L,B,C]*/, const float* __restrict__ inputs,
+                         const int32_t* __restrict__ offsets, T* __restrict__ grad_table, uint32_t B, uint32_t max_level,
+                         LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t G) {
+    constexpr uint32_t D = 3;
+    constexpr uint32_t P = kLdsBytes / (4 * C);          // table rows per partition
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    __shared__ uint32_t item_prefix[kMaxLevels + 1];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t l = 0; l < max_level; ++l) {
+            const uint32_t size = (uint32_t)(offsets[l + 1] - offsets[l]);
+            item_prefix[l] = run;
+            run += ((size + P - 1) / P) * G;
+        }
+        item_prefix[max_level] = run;
+    }
+    __syncthreads();
+    const uint32_t total_items = item_prefix[max_level];
+    const uint32_t chunk = (((B + G - 1) / G) + 63u) & ~63u;     // samples per group, wave aligned
+
+    for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x) {
+        uint32_t level = 0;
+        while (item >= item_prefix[level + 1]) ++level;
+        const uint32_t local = item - item_prefix[level];
+        const uint32_t part = local / G, grp = local - part * G;
+        const uint32_t row0 = (uint32_t)offsets[level];
+        const uint32_t size = (uint32_t)offsets[level + 1] - row0;
+        const uint32_t part_row0 = part * P;
+        const uint32_t rows_here = min(P, size - part_row0);
+        const float scale = lv.scale[level];
+        const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
+        const bool merge_runs = !ix.hashed;               // coarse dense levels: long equal-row runs along a ray
+
+        for (uint32_t i = tid; i < rows_here * C; i += 1024) acc[i] = 0.0f;
+        __syncthreads();
+
+        const uint32_t s_begin = grp * chunk;
+        const uint32_t s_end = min(B, s_begin + chunk);
+        const T* __restrict__ glevel = grad + (size_t)level * B * C;
+        for (uint32_t base = s_begin + (tid & ~63u); base < s_end; base += 1024) {
+            const uint32_t s = base + lane;
+            bool valid = s < s_end;
+            float x[D] = {0.f, 0.f, 0.f};
+            float gv[C];
+#pragma unroll
+            for (uint32_t c = 0; c < C; ++c) gv[c] = 0.f;
+            if (valid) {
+                load_point<D>(inputs, s, x);
+                valid = !outside_unit_cube<D>(x);
+                const Row<T, C> gr = Row<T, C>::load(glevel + (size_t)s * C);
+#pragma unroll
+                for (uint32_t c = 0; c < C; ++c) gv[c] = (float)gr.v[c];
+            }
+            uint32_t cell[D];
+            float frac[D], dfrac[D];
+            locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
+#pragma unroll
+            for (uint32_t corner = 0; corner < 8; ++corner) {
+                uint32_t v[D];
+                float w = 1.0f;
+#pragma unroll
+                for (uint32_t d = 0; d < D; ++d) {
+                    if (corner & (1u << d)) { w *= frac[d]; v[d] = cell[d] + 1; }
+                    else { w *= 1 - frac[d]; v[d] = cell[d]; }
+                }
+                const uint32_t rel = ix.row(v) - part_row0;
+                const bool mine = valid && rel < rows_here;
+                if (!merge_runs) {
+                    if (mine) {
+#pragma unroll
+                        for (uint32_t c = 0; c < C; ++c)
+                            __hip_atomic_fetch_add(&acc[rel * C + c], w * gv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                } else {
+                    // combine runs of equal rows in adjacent lanes (segmented inclusive scan), add once per run
+                    const uint32_t key = mine ? rel : 0xFFFFFFFFu;
+                    const uint32_t prev = __shfl_up(key, 1, 64);
+                    const uint32_t next = __shfl_down(key, 1, 64);
+                    bool head = (lane == 0) || (prev != key);
+                    const bool tail = (lane == 63) || (next != key);
+                    float val[C];
+#pragma unroll
+                    for (uint32_t c = 0; c < C; ++c) val[c] = mine ? w * gv[c] : 0.f;
+#pragma unroll
+                    for (uint32_t o = 1; o < 64; o <<= 1) {
+                        const int h2 = __shfl_up((int)head, o, 64);
+                        float v2[C];
+#pragma unroll
+                        for (uint32_t c = 0; c < C; ++c) v2[c] = __shfl_up(val[c], o, 64);
+                        if (lane >= o && !head) {
+#pragma unroll
+                            for (uint32_t c = 0; c < C; ++c) val[c] += v2[c];
+                            head = h2 != 0;
+                        }
+                    }
+                    if (mine && tail) {
+#pragma unroll
+                        for (uint32_t c = 0; c < C; ++c)
+                            __hip_atomic_fetch_add(&acc[rel * C + c], val[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // flush: consecutive lanes -> consecutive table entries (coalesced atomics); untouched entries are skipped
+        T* __restrict__ gtab = grad_table + ((size_t)row0 + part_row0) * C;
+        if constexpr (sizeof(T) == 2) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            for (uint32_t i = tid; i < rows_here * C / 2; i += 1024) {
+                const float a = acc[2 * i], b2 = acc[2 * i + 1];
+                if (a != 0.f || b2 != 0.f) {
+                    h2 val;
+                    val.x = (_Float16)a;
+                    val.y = (_Float16)b2;
+                    (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gtab + 2 * i), val);
+                }
+            }
+        } else {
+            for (uint32_t i = tid; i < rows_here * C; i += 1024) {
+                const float a = acc[i];
+                if (a != 0.f) unsafeAtomicAdd(gtab + i, a);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]; accumulates in T like the reference (:357-365)
 template <typename T, uint32_t D, uint32_t C>
 __global__ void grid_input_backward_kernel(const T* __restrict__ grad, const T* __restrict__ dy_dx, T* __restrict__ grad_inputs,
@@ -431,6 +598,37 @@ struct BwdArgs {
 
 template <typename T, uint32_t D, uint32_t C, bool BM>
 void launch_backward(const BwdArgs& a) {
+    static const bool use_scatter = getenv("N2M_GRID_BWD_SCATTER") != nullptr;   // A/B switch for measurements
+    if (D == 3 && !use_scatter && !(sizeof(T) == 2 && (C & 1u))) {
+        if constexpr (D == 3) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)grid_backward_lds_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)kLdsBytes);
+                attr_set = true;
+            }
+            const T* g = (const T*)a.grad;
+            T* scratch = nullptr;
+            if (BM) {   // sample-major producer: transpose to level-major first
+                const size_t n = (size_t)a.B * a.L * C;
+                if (hipMallocAsync((void**)&scratch, n * sizeof(T), a.s) != hipSuccess) scratch = nullptr;
+                if (scratch) {
+                    transpose_to_level_major_kernel<T><<<n2m_ceil_div(n, 256), 256, 0, a.s>>>((const T*)a.grad, scratch, a.B, a.L, C);
+                    g = scratch;
+                }
+            }
+            if (!BM || scratch) {
+                const uint32_t G = a.B >= (1u << 18) ? 4u : a.B >= (1u << 16) ? 2u : 1u;
+                grid_backward_lds_kernel<T, C><<<1024, 1024, kLdsBytes, a.s>>>(g, a.inputs, a.offsets, (T*)a.grad_table, a.B,
+                                                                                a.max_level, a.lv, a.gridtype, a.align, a.interp, G);
+                if (scratch) (void)hipFreeAsync(scratch, a.s);
+                if (!BM && a.dy_dx && a.grad_inputs)
+                    grid_input_backward_kernel<T, D, C><<<n2m_ceil_div((uint64_t)a.B * D, 256), 256, 0, a.s>>>(
+                        (const T*)a.grad, (const T*)a.dy_dx, (T*)a.grad_inputs, a.B, a.L);
+                return;
+            }
+        }
+    }
     const dim3 grid(n2m_ceil_div(a.B, 256), a.max_level);
     grid_backward_kernel<T, D, C, BM><<<grid, 256, 0, a.s>>>((const T*)a.grad, a.inputs, a.offsets, (T*)a.grad_table, a.B, a.L,
                                                              a.lv, a.gridtype, a.align, a.interp);

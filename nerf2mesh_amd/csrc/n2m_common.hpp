@@ -58,10 +58,12 @@ __device__ __forceinline__ float n2m_clampf(float v, float lo, float hi) { retur
 
 // 10-bit-per-axis Morton code, x in bit 0.
 __device__ __forceinline__ uint32_t n2m_spread3(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
+    // same bit moves as the multiply form (v*0x00010001 == v | v<<16 for non-overlapping fields), but every step is
+    // one full-rate v_lshl_or_b32 + v_and instead of a quarter-rate v_mul_lo_u32
+    v = (v | (v << 16)) & 0xFF0000FFu;
+    v = (v | (v << 8)) & 0x0F00F00Fu;
+    v = (v | (v << 4)) & 0xC30C30C3u;
+    v = (v | (v << 2)) & 0x49249249u;
     return v;
 }
 __device__ __forceinline__ uint32_t n2m_morton(uint32_t x, uint32_t y, uint32_t z) {

@@ -15,6 +15,7 @@
 //    product, colour/depth sums by wave reductions (forward) / prefix sums (backward).  All loads/stores are
 //    coalesced; the serial per-ray loop of the reference becomes ceil(count/64) wave steps.
 #include <float.h>
+#include <stdlib.h>
 
 #include "n2m_common.hpp"
 
@@ -128,8 +129,7 @@ __global__ void flatten_rays_kernel(const int32_t* __restrict__ rays, uint32_t N
 
 struct MarchCtx {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
-    float bound, dt_gamma, dt_min, dt_max, rH, H3f, Hf, Cf, top;
-    double Hd;
+    float bound, dt_gamma, dt_min, dt_max, rH, H3f, Hf, Cf, top, halfH;
     bool contract;
     const uint8_t* __restrict__ bits;
 };
@@ -149,7 +149,7 @@ __device__ __forceinline__ void march_ctx_init(MarchCtx& c, const float* o, cons
     c.dx = d[0]; c.dy = d[1]; c.dz = d[2];
     c.rdx = 1.0f / (c.dx + eps); c.rdy = 1.0f / (c.dy + eps); c.rdz = 1.0f / (c.dz + eps);
     c.bound = bound; c.dt_gamma = dt_gamma; c.contract = contract; c.bits = bits;
-    c.Hf = (float)H; c.Hd = (double)H; c.Cf = (float)C; c.top = (float)(H - 1);
+    c.Hf = (float)H; c.halfH = 0.5f * (float)H; c.Cf = (float)C; c.top = (float)(H - 1);
     c.rH = 1.0f / (float)H;
     c.H3f = (float)(H * H * H);
     c.dt_min = 2 * kSqrt3 / (float)max_steps;
@@ -166,7 +166,7 @@ __device__ __forceinline__ bool march_step(const MarchCtx& c, float& t, MarchSam
 
     const float mag = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
     const int lp = level_from_exponent(mag, c.Cf);
-    const int ld = level_from_exponent((float)((double)(dt * c.Hf) * 0.5), c.Cf);
+    const int ld = level_from_exponent((dt * c.Hf) * 0.5f, c.Cf);   // *0.5 is exact in either precision
     const int level = lp > ld ? lp : ld;
     const float mip_bound = fminf(scalbnf(1.0f, level), c.bound);
     const float mip_rbound = 1.0f / mip_bound;
@@ -177,9 +177,12 @@ __device__ __forceinline__ bool march_step(const MarchCtx& c, float& t, MarchSam
         const float k = (2.0f - 1.0f / mag) / mag;
         cx *= k; cy *= k; cz *= k;
     }
-    const int nx = (int)n2m_clampf((float)(0.5 * (double)(cx * mip_rbound + 1.0f) * c.Hd), 0.0f, c.top);
-    const int ny = (int)n2m_clampf((float)(0.5 * (double)(cy * mip_rbound + 1.0f) * c.Hd), 0.0f, c.top);
-    const int nz = (int)n2m_clampf((float)(0.5 * (double)(cz * mip_rbound + 1.0f) * c.Hd), 0.0f, c.top);
+    // reference: clamp(0.5 * (c*r + 1) * H) evaluated in double and narrowed (raymarching.cu:422-424).  0.5*H is
+    // exactly representable and the double product of a float by it is exact before the single narrowing, so one
+    // fp32 multiply by 0.5f*H gives the identical, correctly rounded value for every H (oracle-checked).
+    const int nx = (int)n2m_clampf((cx * mip_rbound + 1.0f) * c.halfH, 0.0f, c.top);
+    const int ny = (int)n2m_clampf((cy * mip_rbound + 1.0f) * c.halfH, 0.0f, c.top);
+    const int nz = (int)n2m_clampf((cz * mip_rbound + 1.0f) * c.halfH, 0.0f, c.top);
     const uint32_t index = (uint32_t)((float)level * c.H3f + (float)n2m_morton((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
     const bool occ = (c.bits[index >> 3] >> (index & 7u)) & 1u;
 
@@ -197,6 +200,144 @@ __device__ __forceinline__ bool march_step(const MarchCtx& c, float& t, MarchSam
         t += dt;
     } while (t < tt);
     return false;
+}
+
+
+// ---------------------------------------------------------------------------------- wave-per-ray marcher (train)
+// Both ways the reference advances a ray -- the sampling step (`t += dt`, raymarching.cu:433-434) and the empty-voxel
+// skip (`do { dt = clamp(t*dt_gamma); t += dt; } while (t < tt)`, :460-463) -- apply the SAME update
+//     t <- t + clamp(t * dt_gamma, dt_min, dt_max)
+// so every t a ray ever visits is a member of one sequence T_0 = t0, T_{k+1} = T_k + clamp(T_k*g, ..) that does not
+// depend on the occupancy grid.  One wavefront therefore marches one ray 64 candidates at a time:
+//   1. lane j derives T_{base+j} with the sequential fp32 recurrence (bit-identical to the serial loop),
+//   2. every lane evaluates its candidate in parallel: clamped position, cascade level, voxel, occupancy bit and, for
+//      an empty voxel, the exit time tt of that voxel (the exact expressions of march_step),
+//   3. the visited subsequence is resolved with ballots: a run of occupied lanes is kept wholesale, an empty lane
+//      jumps to the first later lane with T >= tt (carried into the next chunk when it lies beyond this one),
+//   4. WRITE pass: kept lanes store their sample at offset + popcount(kept lanes below) -- consecutive lanes,
+//      consecutive rows, coalesced.
+// Result: identical samples, counts and order as the serial kernel, ~64x shorter dependent chain per ray, and
+// N waves (not N/64) to fill the machine.
+struct LaneEval { float cx, cy, cz, dt, tt; bool keep; };
+
+__device__ __forceinline__ LaneEval eval_candidate(const MarchCtx& c, float t) {
+    LaneEval e;
+    const float x = n2m_clampf(c.ox + t * c.dx, -c.bound, c.bound);
+    const float y = n2m_clampf(c.oy + t * c.dy, -c.bound, c.bound);
+    const float z = n2m_clampf(c.oz + t * c.dz, -c.bound, c.bound);
+    const float dt = n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+    const float mag = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    const int lp = level_from_exponent(mag, c.Cf);
+    const int ld = level_from_exponent((dt * c.Hf) * 0.5f, c.Cf);
+    const int level = lp > ld ? lp : ld;
+    const float mip_bound = fminf(scalbnf(1.0f, level), c.bound);
+    const float mip_rbound = 1.0f / mip_bound;
+    float cx = x, cy = y, cz = z;
+    const bool outside = c.contract && mag > 1.0f;
+    if (outside) {
+        const float k = (2.0f - 1.0f / mag) / mag;
+        cx *= k; cy *= k; cz *= k;
+    }
+    const int nx = (int)n2m_clampf((cx * mip_rbound + 1.0f) * c.halfH, 0.0f, c.top);
+    const int ny = (int)n2m_clampf((cy * mip_rbound + 1.0f) * c.halfH, 0.0f, c.top);
+    const int nz = (int)n2m_clampf((cz * mip_rbound + 1.0f) * c.halfH, 0.0f, c.top);
+    const uint32_t index = (uint32_t)((float)level * c.H3f + (float)n2m_morton((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    const bool occ = (c.bits[index >> 3] >> (index & 7u)) & 1u;
+    const float tx = ((((float)nx + 0.5f + 0.5f * copysignf(1.0f, c.dx)) * c.rH * 2 - 1) * mip_bound - cx) * c.rdx;
+    const float ty = ((((float)ny + 0.5f + 0.5f * copysignf(1.0f, c.dy)) * c.rH * 2 - 1) * mip_bound - cy) * c.rdy;
+    const float tz = ((((float)nz + 0.5f + 0.5f * copysignf(1.0f, c.dz)) * c.rH * 2 - 1) * mip_bound - cz) * c.rdz;
+    e.cx = cx; e.cy = cy; e.cz = cz; e.dt = dt;
+    e.tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    e.keep = occ || outside;
+    return e;
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(256)
+march_train_wave_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
+                        float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                        const float* __restrict__ nears, const float* __restrict__ fars, float* __restrict__ xyzs,
+                        float* __restrict__ dirs, float* __restrict__ ts, int32_t* __restrict__ rays,
+                        const float* __restrict__ noises) {
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);      // one wave per ray, 4 rays per workgroup
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    MarchCtx c;
+    march_ctx_init(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, 0.0f, grid, bound, contract, dt_gamma, max_steps, C, H);
+    uint32_t budget = max_steps;
+    size_t out = 0;
+    if (WRITE) {
+        out = (size_t)(uint32_t)rays[2 * n];
+        budget = (uint32_t)rays[2 * n + 1];
+        if (budget == 0) return;
+    }
+    const float far = fars[n];
+    float t_base = nears[n];
+    t_base += n2m_clampf(t_base * dt_gamma, c.dt_min, c.dt_max) * noises[n];
+
+    uint32_t kept = 0;
+    bool pending = false;      // an empty voxel's exit time lies beyond the previous chunk
+    float pending_tt = 0.f;
+    // a ray can only end by t >= far or by the sample budget; the chunk cap turns a non-advancing t (far = inf with
+    // t so large that t + dt == t: the serial reference would spin forever) into a bounded loop
+    for (uint32_t chunk = 0; chunk < (1u << 20) && t_base < far && kept < budget; ++chunk) {
+        // 1. lane j <- T_{base + j}: j sequential applications of the update, in serial fp32 order
+        float t = t_base;
+#pragma unroll 1
+        for (int i = 0; i < 63; ++i) {
+            const float nt = t + n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+            t = i < lane ? nt : t;
+        }
+        const float t_next_base = __shfl(t + n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max), 63, 64);   // T_{base+64}
+        // 2. evaluate all candidates of the chunk
+        const bool active = t < far;
+        LaneEval e;
+        e.keep = false; e.tt = t; e.cx = e.cy = e.cz = e.dt = 0.f;
+        if (active) e = eval_candidate(c, t);
+        const unsigned long long active_mask = __ballot(active);             // a prefix of the lanes (T increases)
+        const unsigned long long keep_mask = __ballot(active && e.keep);
+        // 3. resolve the visited subsequence
+        unsigned long long kept_mask = 0ull;
+        int cur = 0;
+        bool done = false;
+        if (pending) {
+            const unsigned long long reach = __ballot(t >= pending_tt);
+            if (reach == 0ull) cur = 64;                                     // whole chunk lies inside the skipped voxel
+            else { cur = (int)__ffsll((long long)reach) - 1; pending = false; }
+        }
+        while (cur < 64) {
+            if (!((active_mask >> cur) & 1ull)) { done = true; break; }      // T_cur >= far
+            if ((keep_mask >> cur) & 1ull) {
+                const unsigned long long stop = ~keep_mask >> cur;           // first lane >= cur that is not kept
+                const uint32_t run = stop ? (uint32_t)__ffsll((long long)stop) - 1u : (uint32_t)(64 - cur);
+                const uint32_t take = min(run, budget - kept);
+                kept_mask |= (take >= 64u ? ~0ull : ((1ull << take) - 1ull)) << cur;
+                kept += take;
+                if (kept >= budget) { done = true; break; }
+                cur += (int)run;
+            } else {
+                const float tt = __shfl(e.tt, cur, 64);
+                const unsigned long long later = cur >= 63 ? 0ull : (~0ull << (cur + 1));
+                const unsigned long long reach = __ballot(t >= tt) & later;
+                if (reach) cur = (int)__ffsll((long long)reach) - 1;
+                else { pending = true; pending_tt = tt; cur = 64; }
+            }
+        }
+        // 4. emit
+        if (WRITE && kept_mask) {
+            if ((kept_mask >> lane) & 1ull) {
+                const uint32_t rank = (uint32_t)__popcll(kept_mask & ((1ull << lane) - 1ull));
+                const size_t row = out + rank;
+                xyzs[3 * row] = e.cx; xyzs[3 * row + 1] = e.cy; xyzs[3 * row + 2] = e.cz;
+                dirs[3 * row] = c.dx; dirs[3 * row + 1] = c.dy; dirs[3 * row + 2] = c.dz;
+                *reinterpret_cast<float2*>(ts + 2 * row) = make_float2(t + e.dt, e.dt);
+            }
+            out += (size_t)__popcll(kept_mask);
+        }
+        if (done) break;
+        t_base = t_next_base;
+    }
+    if (!WRITE && lane == 0) rays[2 * n + 1] = (int32_t)kept;
 }
 
 template <bool WRITE>
@@ -531,6 +672,11 @@ __global__ void composite_infer_kernel(uint32_t n_alive, uint32_t n_step, float 
     image[3 * ray] = r; image[3 * ray + 1] = g; image[3 * ray + 2] = b;
 }
 
+bool serial_march() {   // A/B switch: N2M_MARCH_SERIAL=1 selects the one-ray-per-lane kernels
+    static const bool v = getenv("N2M_MARCH_SERIAL") != nullptr;
+    return v;
+}
+
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -607,9 +753,14 @@ extern "C" int n2m_march_rays_train(const float* rays_o, const float* rays_d, co
     if (first_pass) {
         if (N > 0) {
             N2M_PROF(N2M_K_MARCH_COUNT, s, 52.0 * N);
-            march_train_kernel<false><<<n2m_ceil_div(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
-                                                                         max_steps, N, C, H, nears, fars, nullptr, nullptr,
-                                                                         nullptr, rays, noises);
+            if (serial_march())
+                march_train_kernel<false><<<n2m_ceil_div(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
+                                                                             max_steps, N, C, H, nears, fars, nullptr, nullptr,
+                                                                             nullptr, rays, noises);
+            else
+                march_train_wave_kernel<false><<<n2m_ceil_div(N, 4), 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0,
+                                                                                  dt_gamma, max_steps, N, C, H, nears, fars, nullptr,
+                                                                                  nullptr, nullptr, rays, noises);
             N2M_CHECK_LAUNCH();
         }
         const int rc = run_exclusive_scan(RayOffsetsOp{rays, counter}, N, s);
@@ -617,9 +768,14 @@ extern "C" int n2m_march_rays_train(const float* rays_o, const float* rays_d, co
         N2M_CHECK_LAUNCH();
     } else if (N > 0) {
         N2M_PROF(N2M_K_MARCH_WRITE, s, 44.0 * N);   // + 32 B per sample, added by the caller who knows M
-        march_train_kernel<true><<<n2m_ceil_div(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
-                                                                    max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
-                                                                    noises);
+        if (serial_march())
+            march_train_kernel<true><<<n2m_ceil_div(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
+                                                                        max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
+                                                                        noises);
+        else
+            march_train_wave_kernel<true><<<n2m_ceil_div(N, 4), 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
+                                                                             max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
+                                                                             noises);
         N2M_CHECK_LAUNCH();
     }
     return 0;

@@ -187,7 +187,9 @@ def test_composite_train(be, oracle, alpha_mode):
     tol = dict(rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(w.cpu().numpy(), ow, **tol)
     np.testing.assert_allclose(ws.cpu().numpy(), ows, **tol)
-    np.testing.assert_allclose(dp.cpu().numpy(), odp, rtol=2e-5, atol=2e-5)
+    # depth sums w*t with t ~ 2..12 over up to 1024 samples: the oracle's SERIAL fp32 sum carries ~n*eps/2 = 6e-5
+    # relative error itself, the wave tree sum less; 2e-4 covers the worst (1024-sample) ray
+    np.testing.assert_allclose(dp.cpu().numpy(), odp, rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(im.cpu().numpy(), oim, **tol)
     # samples after the early stop are untouched in both (exact zeros), up to threshold ties
     assert np.mean((w.cpu().numpy() == 0) != (ow == 0)) < 1e-4
@@ -204,7 +206,10 @@ def test_composite_train(be, oracle, alpha_mode):
 
 
 def test_composite_train_matches_autograd(be):
-    """Backward kernel == autograd of the same recurrence in float64."""
+    """Backward kernel == autograd of the same recurrence in float64, for the image, alpha and
+    depth outputs.  (The `weights` output is left out on purpose: the reference multiplies the whole suffix by
+    grad_weights[i] instead of the per-sample grad_weights[j], raymarching.cu:676 -- exact only for a constant
+    grad_weights; that behaviour is reproduced and pinned by the oracle comparison above, not by autograd.)"""
     torch = be["torch"]
     from nerf2mesh_amd import raymarching
     rng = np.random.default_rng(12)
@@ -217,8 +222,7 @@ def test_composite_train_matches_autograd(be):
     rgb = torch.tensor(rng.random((M, 3)), dtype=torch.float32, device="cuda", requires_grad=True)
     ts = torch.tensor(np.stack([np.cumsum(rng.random(M)) * 0.01 + 2, np.full(M, 0.01)], 1), dtype=torch.float32, device="cuda")
     w, ws, dp, im = raymarching.composite_rays_train(sig, rgb, ts, rays, 0.0, False)     # T_thresh 0: no early stop
-    cw = torch.tensor(rng.normal(size=M), dtype=torch.float32, device="cuda")
-    (im.sum() * 0.7 + (ws * 1.3).sum() + (dp * 0.2).sum() + (w * cw).sum()).backward()
+    (im.sum() * 0.7 + (ws * 1.3).sum() + (dp * 0.2).sum()).backward()
     s64 = sig.detach().double().cpu().requires_grad_(True)
     r64 = rgb.detach().double().cpu().requires_grad_(True)
     t64 = ts.double().cpu()
@@ -228,7 +232,7 @@ def test_composite_train_matches_autograd(be):
         a = 1 - torch.exp(-s64[sl] * t64[sl, 1])
         T = torch.cumprod(torch.cat([torch.ones(1, dtype=torch.float64), 1 - a[:-1]]), 0)
         ww = a * T
-        tot = tot + (ww[:, None] * r64[sl]).sum() * 0.7 + ww.sum() * 1.3 + (ww * t64[sl, 0]).sum() * 0.2 + (ww * cw.double().cpu()[sl]).sum()
+        tot = tot + (ww[:, None] * r64[sl]).sum() * 0.7 + ww.sum() * 1.3 + (ww * t64[sl, 0]).sum() * 0.2
     tot.backward()
     np.testing.assert_allclose(sig.grad.cpu().numpy(), s64.grad.numpy(), rtol=2e-3, atol=2e-5)
     np.testing.assert_allclose(rgb.grad.cpu().numpy(), r64.grad.numpy(), rtol=1e-4, atol=1e-6)
