@@ -1,0 +1,60 @@
+/*
+ * n2m_mlp.h -- fused field MLPs of nerf2mesh (the "M" row of SURVEY.md section 8a).
+ *
+ * New operator without a reference boundary: the reference evaluates its three tiny bias-free MLPs with
+ * nn.Linear + F.relu under fp16 autocast (nerf/network.py:10-54,92-108,159-189), i.e. 7 GEMM launches forward and
+ * ~14 backward with K <= 64, several of them degenerate tall-skinny shapes.  These entry points evaluate the whole
+ * field head in one kernel per direction with the weights resident in LDS and the layer chain in MFMA registers.
+ * The unfused torch path stays the parity baseline (tests/test_mlp_parity.py).
+ *
+ * Fixed architecture (nerf/network.py:66-75):
+ *   sigma_net    : [x(3) | h1(16)] -> 32 -> 1            sigma = exp(.)            (trunc_exp, activation.py:5-17)
+ *   color_net    : [x(3) | h2(32)] -> 64 -> 64 -> 6      geo = sigmoid(.) ; diffuse = geo[0:3], feat = geo[3:6]
+ *   specular_net : [d(3) | feat(3)] -> 32 -> 3           specular = sigmoid(.)
+ *   color = diffuse                       (shading 0, "diffuse")
+ *         = clamp(specular + diffuse,0,1) (shading 1, "full")
+ *         = specular                      (shading 2, "specular")
+ * Numerics follow autocast: layer inputs, weights and layer outputs are rounded to fp16, accumulation is fp32
+ * (v_mfma_f32_32x32x8_f16), exp runs in fp32.
+ *
+ * Weight pointers are the fp32 master parameters, row-major [out, in] exactly as nn.Linear stores them:
+ *   w_sigma0 [32,19]  w_sigma1 [1,32]  w_color0 [64,35]  w_color1 [64,64]  w_color2 [6,64]  w_spec0 [32,6]  w_spec1 [3,32]
+ * All pointers are device pointers; conventions as in n2m_hip.h.
+ */
+#ifndef N2M_MLP_H
+#define N2M_MLP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Forward.  xyz [M,3] f32 (grid-bound coordinates, as fed to the encoders), dirs [M,3] f32 (normalised; may be NULL
+ * when shading == 0), h1 [M,16] f32 (density features, sample-major), h2 [M,32] f16 (colour features; may be NULL
+ * when rgb == NULL: density-only evaluation as in update_extra_state).
+ * Outputs: sigma [M] f32; rgb [M,3] f32 and specular [M,3] f32 (either may be NULL; specular is not written for
+ * shading 0). */
+int n2m_field_forward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
+                      const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
+                      const float* w_spec0, const float* w_spec1, uint32_t M, int shading, float* sigma, float* rgb,
+                      float* specular, void* stream);
+
+/* Backward of n2m_field_forward (activations are recomputed, nothing is saved but the inputs).
+ * Incoming: d_sigma [M], d_rgb [M,3], d_specular [M,3] or NULL (gradient of the loss w.r.t. the three outputs).
+ * Outgoing:
+ *   d_h1 [16, M] f32      LEVEL-major, the layout n2m_grid_encode_backward consumes for the C=1 encoder
+ *   d_h2 [16, M, 2] f16   LEVEL-major for the C=2 encoder (fp16 like autocast's grad of an fp16 tensor)
+ *   d_w_* : fp32, same shapes as the weights, ACCUMULATED into (caller zero-fills or keeps running sums)
+ * grad_scale multiplies nothing here; pass already-scaled upstream gradients (GradScaler) as they are. */
+int n2m_field_backward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
+                       const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
+                       const float* w_spec0, const float* w_spec1, uint32_t M, int shading, const float* d_sigma,
+                       const float* d_rgb, const float* d_specular, float* d_h1, void* d_h2, float* d_w_sigma0,
+                       float* d_w_sigma1, float* d_w_color0, float* d_w_color1, float* d_w_color2, float* d_w_spec0,
+                       float* d_w_spec1, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* N2M_MLP_H */

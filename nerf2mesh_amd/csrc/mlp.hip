@@ -1,0 +1,610 @@
+// Fused field MLPs (sigma_net, color_net, specular_net of nerf/network.py:66-75) for gfx950 -- include/n2m_mlp.h.
+//
+// Why fuse: per sample the three networks are 7 648 MACs with K <= 64.  As nn.Linear calls they become 7 GEMM launches
+// forward and ~14 backward; the weight-gradient GEMMs are (out x 262144) x (262144 x in) with out, in <= 64, which the
+// BLAS library runs as ONE workgroup each (1.8 ms + 2 x 0.5 ms per step measured, profiles/r01_*).  Here each wavefront
+// carries a tile of 32 samples through the whole head with the weights in LDS and everything else in registers.
+//
+// Orientation.  v_mfma_f32_32x32x8_f16 computes D[32 x 32] += A[32 x 8] * B[8 x 32] with the lane maps
+//     A: lane l -> A[m = l%32][k = 4*(l/32) + i]      B: lane l -> B[k = 4*(l/32) + i][n = l%32]      (i = 0..3)
+//     D: lane l, reg r -> D[m = 8*(r/4) + 4*(l/32) + r%4][n = l%32]
+// Putting the SAMPLES on n and the FEATURES on m/k (H^T = W * X^T) makes the D layout of one layer exactly the B
+// layout of the next: regs 4kb..4kb+3 of lane l hold features 8kb + 4*(l/32) + 0..3 of sample l%32.  So a layer is
+// "ReLU, round to fp16, pack 4 values" -- no LDS round trip, no shuffles -- and the chain stays in VGPRs.  The same
+// holds for the backward activation-gradient chain (dX^T = W^T * dY^T).
+// Weight gradients contract over SAMPLES (dW = dY^T X), which live on lanes; for those the 32-sample tiles of X and dY
+// are transposed through a small per-wave LDS scratch and accumulated with MFMA into per-wave fp32 register tiles
+// for the whole launch (persistent waves), then reduced once per workgroup in LDS and flushed with coalesced atomics.
+//
+// Numerics = autocast: operands fp16, fp32 accumulate, layer outputs rounded to fp16; exp (trunc_exp) in fp32.
+// Input feature order inside the kernel is [encoder features | xyz | 0-pad] (the weight columns are permuted while
+// staging), so the encoder rows load as aligned 8-byte chunks.
+#include "n2m_common.hpp"
+#include "../../include/n2m_mlp.h"
+
+namespace {
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f16x __attribute__((ext_vector_type(16)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x8f16((a), (b), (c), 0, 0, 0)
+
+// ---------------------------------------------------------------------------------------------- LDS layout (halves)
+// forward operands W[out_pad][k_pad + 4]; backward operands W^T[in_pad][out_pad + 4]
+constexpr int P_S0 = 28, P_S1 = 36, P_C0 = 44, P_C1 = 68, P_C2 = 68, P_P0 = 12, P_P1 = 36;        // forward pitches
+constexpr int P_S1T = 12, P_S0T = 36, P_C2T = 12, P_C1T = 68, P_C0T = 68, P_P1T = 12, P_P0T = 36; // backward pitches
+constexpr int O_S0 = 0;
+constexpr int O_S1 = O_S0 + 32 * P_S0;
+constexpr int O_C0 = O_S1 + 32 * P_S1;
+constexpr int O_C1 = O_C0 + 64 * P_C0;
+constexpr int O_C2 = O_C1 + 64 * P_C1;
+constexpr int O_P0 = O_C2 + 32 * P_C2;
+constexpr int O_P1 = O_P0 + 32 * P_P0;
+constexpr int FWD_HALVES = O_P1 + 32 * P_P1;
+constexpr int O_S1T = FWD_HALVES;
+constexpr int O_S0T = O_S1T + 32 * P_S1T;
+constexpr int O_C2T = O_S0T + 32 * P_S0T;
+constexpr int O_C1T = O_C2T + 64 * P_C2T;
+constexpr int O_C0T = O_C1T + 64 * P_C1T;
+constexpr int O_P1T = O_C0T + 64 * P_C0T;
+constexpr int O_P0T = O_P1T + 32 * P_P1T;
+constexpr int ALL_W_HALVES = O_P0T + 32 * P_P0T;
+constexpr int TILE_PITCH = 68;                                   // per-wave transpose tiles [32 samples][64 + 4]
+constexpr int TILE_HALVES = 32 * TILE_PITCH;
+constexpr int BWD_HALVES = ALL_W_HALVES + 4 * 2 * TILE_HALVES;   // 4 waves x (X tile + dY tile)
+
+// logical input feature k -> column of the nn.Linear weight (or -1 for padding)
+__device__ __forceinline__ int col_color0(int k) { return k < 32 ? 3 + k : (k < 35 ? k - 32 : -1); }
+__device__ __forceinline__ int col_sigma0(int k) { return k < 16 ? 3 + k : (k < 19 ? k - 16 : -1); }
+__device__ __forceinline__ int col_plain(int k, int in) { return k < in ? k : -1; }
+
+enum Perm { PERM_PLAIN = 0, PERM_COLOR0 = 1, PERM_SIGMA0 = 2 };
+__device__ __forceinline__ int col_of(int perm, int k, int in) {
+    return perm == PERM_COLOR0 ? col_color0(k) : perm == PERM_SIGMA0 ? col_sigma0(k) : col_plain(k, in);
+}
+
+// W[out,in] fp32 (global) -> LDS fp16 [m_pad][pitch], logical k order, zero padded
+__device__ void stage_w(_Float16* dst, int pitch, const float* __restrict__ W, int out, int in, int m_pad, int k_pad, int perm) {
+    for (int idx = threadIdx.x; idx < m_pad * k_pad; idx += blockDim.x) {
+        const int m = idx / k_pad, k = idx - m * k_pad;
+        const int c = col_of(perm, k, in);
+        dst[m * pitch + k] = (_Float16)((m < out && c >= 0) ? W[m * in + c] : 0.0f);
+    }
+}
+// transposed: LDS [m = logical in feature][k = out feature]
+__device__ void stage_wt(_Float16* dst, int pitch, const float* __restrict__ W, int out, int in, int m_pad, int k_pad, int perm) {
+    for (int idx = threadIdx.x; idx < m_pad * k_pad; idx += blockDim.x) {
+        const int m = idx / k_pad, k = idx - m * k_pad;
+        const int c = col_of(perm, m, in);
+        dst[m * pitch + k] = (_Float16)((k < out && c >= 0) ? W[k * in + c] : 0.0f);
+    }
+}
+
+__device__ __forceinline__ h4 ld_a(const _Float16* W, int pitch, int mb, int kb, int lane) {
+    return *reinterpret_cast<const h4*>(W + (32 * mb + (lane & 31)) * pitch + 8 * kb + 4 * (lane >> 5));
+}
+
+__device__ __forceinline__ h4 zero4() { h4 z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0}; return z; }
+__device__ __forceinline__ f16x zero16() {
+    f16x z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// regs 4q..4q+3 of an accumulator -> fp16 fragment, with ReLU (the next layer's B operand for K-block q)
+template <int Q>
+__device__ __forceinline__ h4 relu_pack(const f16x& d) {
+    h4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 v = (_Float16)d[4 * Q + i];
+        r[i] = v > (_Float16)0 ? v : (_Float16)0;
+    }
+    return r;
+}
+// gradient fragment: round to fp16 and apply the ReLU mask of the forward fragment
+template <int Q>
+__device__ __forceinline__ h4 mask_pack(const f16x& d, const h4& fwd) {
+    h4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fwd[i] > (_Float16)0 ? (_Float16)d[4 * Q + i] : (_Float16)0;
+    return r;
+}
+
+__device__ __forceinline__ float sigmoid_h(float pre_acc) {
+    // autocast: the Linear output is fp16, sigmoid evaluates it and returns fp16
+    const float x = (float)(_Float16)pre_acc;
+    return (float)(_Float16)(1.0f / (1.0f + expf(-x)));
+}
+
+struct FieldArgs {
+    const float* xyz; const float* dirs; const float* h1; const _Float16* h2;
+    const float* w[7];       // sigma0, sigma1, color0, color1, color2, spec0, spec1
+    uint32_t M; int shading;
+    float* sigma; float* rgb; float* specular;
+    // backward only
+    const float* d_sigma; const float* d_rgb; const float* d_specular;
+    float* d_h1; _Float16* d_h2; float* dw[7];
+};
+
+// ---------------------------------------------------------------------------------------------- input fragments
+__device__ __forceinline__ void load_density_inputs(const FieldArgs& a, uint32_t s, bool valid, int g, h4 (&b)[3]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) v = *reinterpret_cast<const float4*>(a.h1 + (size_t)s * 16 + 8 * kb + 4 * g);
+        b[kb][0] = (_Float16)v.x; b[kb][1] = (_Float16)v.y; b[kb][2] = (_Float16)v.z; b[kb][3] = (_Float16)v.w;
+    }
+    b[2] = zero4();
+    if (valid && g == 0) {
+        b[2][0] = (_Float16)a.xyz[(size_t)s * 3]; b[2][1] = (_Float16)a.xyz[(size_t)s * 3 + 1]; b[2][2] = (_Float16)a.xyz[(size_t)s * 3 + 2];
+    }
+}
+__device__ __forceinline__ void load_color_inputs(const FieldArgs& a, uint32_t s, bool valid, int g, h4 (&b)[5]) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        b[kb] = zero4();
+        if (valid) b[kb] = *reinterpret_cast<const h4*>(a.h2 + (size_t)s * 32 + 8 * kb + 4 * g);
+    }
+    b[4] = zero4();
+    if (valid && g == 0) {
+        b[4][0] = (_Float16)a.xyz[(size_t)s * 3]; b[4][1] = (_Float16)a.xyz[(size_t)s * 3 + 1]; b[4][2] = (_Float16)a.xyz[(size_t)s * 3 + 2];
+    }
+}
+
+// ================================================================================================== forward
+template <bool DO_COLOR>
+__global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    stage_w(lds + O_S0, P_S0, a.w[0], 32, 19, 32, 24, PERM_SIGMA0);
+    stage_w(lds + O_S1, P_S1, a.w[1], 1, 32, 32, 32, PERM_PLAIN);
+    if (DO_COLOR) {
+        stage_w(lds + O_C0, P_C0, a.w[2], 64, 35, 64, 40, PERM_COLOR0);
+        stage_w(lds + O_C1, P_C1, a.w[3], 64, 64, 64, 64, PERM_PLAIN);
+        stage_w(lds + O_C2, P_C2, a.w[4], 6, 64, 32, 64, PERM_PLAIN);
+        if (a.shading != 0) {
+            stage_w(lds + O_P0, P_P0, a.w[5], 32, 6, 32, 8, PERM_PLAIN);
+            stage_w(lds + O_P1, P_P1, a.w[6], 3, 32, 32, 32, PERM_PLAIN);
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, n = lane & 31, g = lane >> 5;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const uint32_t n_tiles = (a.M + 31) / 32;
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t s = tile * 32 + n;
+        const bool valid = s < a.M;
+        {   // ---- density: [h1 | xyz] -> 32 -> 1 -> exp
+            h4 b0[3];
+            load_density_inputs(a, s, valid, g, b0);
+            f16x d = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) d = MFMA(ld_a(lds + O_S0, P_S0, 0, kb, lane), b0[kb], d);
+            const h4 b1[4] = {relu_pack<0>(d), relu_pack<1>(d), relu_pack<2>(d), relu_pack<3>(d)};
+            f16x o = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) o = MFMA(ld_a(lds + O_S1, P_S1, 0, kb, lane), b1[kb], o);
+            if (valid && g == 0) a.sigma[s] = expf((float)(_Float16)o[0]);
+        }
+        if (DO_COLOR) {   // ---- colour: [h2 | xyz] -> 64 -> 64 -> 6 -> sigmoid ; specular: [d | feat] -> 32 -> 3 -> sigmoid
+            h4 b0[5];
+            load_color_inputs(a, s, valid, g, b0);
+            f16x d1[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int kb = 0; kb < 5; ++kb) d1[mb] = MFMA(ld_a(lds + O_C0, P_C0, mb, kb, lane), b0[kb], d1[mb]);
+            const h4 b1[8] = {relu_pack<0>(d1[0]), relu_pack<1>(d1[0]), relu_pack<2>(d1[0]), relu_pack<3>(d1[0]),
+                              relu_pack<0>(d1[1]), relu_pack<1>(d1[1]), relu_pack<2>(d1[1]), relu_pack<3>(d1[1])};
+            f16x d2[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) d2[mb] = MFMA(ld_a(lds + O_C1, P_C1, mb, kb, lane), b1[kb], d2[mb]);
+            const h4 b2[8] = {relu_pack<0>(d2[0]), relu_pack<1>(d2[0]), relu_pack<2>(d2[0]), relu_pack<3>(d2[0]),
+                              relu_pack<0>(d2[1]), relu_pack<1>(d2[1]), relu_pack<2>(d2[1]), relu_pack<3>(d2[1])};
+            f16x d3 = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) d3 = MFMA(ld_a(lds + O_C2, P_C2, 0, kb, lane), b2[kb], d3);
+            // rows 0..3 live in regs 0..3 of the g = 0 lanes, rows 4,5 in regs 0,1 of the g = 1 lanes
+            const float q0 = sigmoid_h(d3[0]), q1 = sigmoid_h(d3[1]), q2 = sigmoid_h(d3[2]), q3 = sigmoid_h(d3[3]);
+            float cr = q0, cg = q1, cb = q2;          // diffuse (g = 0 lanes)
+            if (a.shading != 0) {
+                h4 bp = zero4();                      // K order of specular_net layer 0: d0 d1 d2 f0 | f1 f2 0 0
+                if (g == 0) {
+                    if (valid) { bp[0] = (_Float16)a.dirs[(size_t)s * 3]; bp[1] = (_Float16)a.dirs[(size_t)s * 3 + 1]; bp[2] = (_Float16)a.dirs[(size_t)s * 3 + 2]; }
+                    bp[3] = (_Float16)q3;
+                } else { bp[0] = (_Float16)q0; bp[1] = (_Float16)q1; }   // g = 1: q0,q1 are rows 4,5 = feat1, feat2
+                f16x p1 = MFMA(ld_a(lds + O_P0, P_P0, 0, 0, lane), bp, zero16());
+                const h4 bq[4] = {relu_pack<0>(p1), relu_pack<1>(p1), relu_pack<2>(p1), relu_pack<3>(p1)};
+                f16x p2 = zero16();
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) p2 = MFMA(ld_a(lds + O_P1, P_P1, 0, kb, lane), bq[kb], p2);
+                const float s0 = sigmoid_h(p2[0]), s1 = sigmoid_h(p2[1]), s2 = sigmoid_h(p2[2]);
+                if (valid && g == 0 && a.specular) {
+                    a.specular[(size_t)s * 3] = s0; a.specular[(size_t)s * 3 + 1] = s1; a.specular[(size_t)s * 3 + 2] = s2;
+                }
+                if (a.shading == 2) { cr = s0; cg = s1; cb = s2; }
+                else {   // (specular + diffuse).clamp(0, 1) evaluated in fp16 like the autocast graph
+                    cr = fminf(fmaxf((float)(_Float16)(s0 + q0), 0.f), 1.f);
+                    cg = fminf(fmaxf((float)(_Float16)(s1 + q1), 0.f), 1.f);
+                    cb = fminf(fmaxf((float)(_Float16)(s2 + q2), 0.f), 1.f);
+                }
+            }
+            if (valid && g == 0 && a.rgb) {
+                a.rgb[(size_t)s * 3] = cr; a.rgb[(size_t)s * 3 + 1] = cg; a.rgb[(size_t)s * 3 + 2] = cb;
+            }
+        }
+    }
+}
+
+// ================================================================================================= backward
+// per-wave transpose scratch: tile[sample][feature] fp16
+__device__ __forceinline__ void tile_put(_Float16* tile, int kb, const h4& f, int lane) {
+    *reinterpret_cast<h4*>(tile + (lane & 31) * TILE_PITCH + 8 * kb + 4 * (lane >> 5)) = f;
+}
+// operand of the sample-contraction MFMA: element i = tile[sample 8*kq + 4*(lane/32) + i][feature 32*fb + lane%32]
+__device__ __forceinline__ h4 tile_get(const _Float16* tile, int kq, int fb, int lane) {
+    const _Float16* p = tile + (8 * kq + 4 * (lane >> 5)) * TILE_PITCH + 32 * fb + (lane & 31);
+    h4 r;
+    r[0] = p[0]; r[1] = p[TILE_PITCH]; r[2] = p[2 * TILE_PITCH]; r[3] = p[3 * TILE_PITCH];
+    return r;
+}
+// acc[mb][nb] += dY^T (features 32mb..) x X (features 32nb..) over the 32 samples of the tile
+template <int MB, int NB>
+__device__ __forceinline__ void dw_tile(f16x (&acc)[MB][NB], const _Float16* tY, const _Float16* tX, int lane) {
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        h4 ay[MB], bx[NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) ay[mb] = tile_get(tY, kq, mb, lane);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bx[nb] = tile_get(tX, kq, nb, lane);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = MFMA(ay[mb], bx[nb], acc[mb][nb]);
+    }
+}
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// accumulator tile -> LDS fp32 staging (logical [out_pad][in_pad]) with LDS atomics
+template <int MB, int NB>
+__device__ __forceinline__ void dw_to_lds(float* stage, int in_pad, const f16x (&acc)[MB][NB], int lane) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * mb + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), col = 32 * nb + (lane & 31);
+                __hip_atomic_fetch_add(&stage[row * in_pad + col], acc[mb][nb][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+}
+// LDS staging -> global fp32 weight gradient [out, in] (nn.Linear layout), undoing the logical column order
+__device__ void dw_flush(float* __restrict__ dW, const float* stage, int in_pad, int out, int in, int k_real, int perm) {
+    for (int idx = threadIdx.x; idx < out * k_real; idx += blockDim.x) {
+        const int m = idx / k_real, k = idx - m * k_real;
+        const int c = col_of(perm, k, in);
+        const float v = stage[m * in_pad + k];
+        if (c >= 0 && v != 0.f) unsafeAtomicAdd(dW + m * in + c, v);
+    }
+}
+
+template <bool DO_COLOR>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) field_backward_kernel(FieldArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    stage_w(lds + O_S0, P_S0, a.w[0], 32, 19, 32, 24, PERM_SIGMA0);
+    stage_w(lds + O_S1, P_S1, a.w[1], 1, 32, 32, 32, PERM_PLAIN);
+    stage_wt(lds + O_S1T, P_S1T, a.w[1], 1, 32, 32, 8, PERM_PLAIN);
+    stage_wt(lds + O_S0T, P_S0T, a.w[0], 32, 19, 32, 32, PERM_SIGMA0);
+    if (DO_COLOR) {
+        stage_w(lds + O_C0, P_C0, a.w[2], 64, 35, 64, 40, PERM_COLOR0);
+        stage_w(lds + O_C1, P_C1, a.w[3], 64, 64, 64, 64, PERM_PLAIN);
+        stage_w(lds + O_C2, P_C2, a.w[4], 6, 64, 32, 64, PERM_PLAIN);
+        stage_wt(lds + O_C2T, P_C2T, a.w[4], 6, 64, 64, 8, PERM_PLAIN);
+        stage_wt(lds + O_C1T, P_C1T, a.w[3], 64, 64, 64, 64, PERM_PLAIN);
+        stage_wt(lds + O_C0T, P_C0T, a.w[2], 64, 35, 64, 64, PERM_COLOR0);
+        if (a.shading != 0) {
+            stage_w(lds + O_P0, P_P0, a.w[5], 32, 6, 32, 8, PERM_PLAIN);
+            stage_w(lds + O_P1, P_P1, a.w[6], 3, 32, 32, 32, PERM_PLAIN);
+            stage_wt(lds + O_P1T, P_P1T, a.w[6], 3, 32, 32, 8, PERM_PLAIN);
+            stage_wt(lds + O_P0T, P_P0T, a.w[5], 32, 6, 32, 32, PERM_PLAIN);
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, n = lane & 31, g = lane >> 5, wid = threadIdx.x >> 6;
+    _Float16* tX = lds + ALL_W_HALVES + wid * 2 * TILE_HALVES;
+    _Float16* tY = tX + TILE_HALVES;
+    const uint32_t wave = blockIdx.x * 4 + wid, n_waves = gridDim.x * 4;
+    const uint32_t n_tiles = (a.M + 31) / 32;
+    const size_t Mz = a.M;
+
+    // weight-gradient accumulators, fp32, live for the whole launch
+    f16x gS0[1][1] = {{zero16()}}, gS1[1][1] = {{zero16()}};
+    f16x gC0[2][2], gC1[2][2], gC2[1][2], gP0[1][1] = {{zero16()}}, gP1[1][1] = {{zero16()}};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { gC0[i][j] = zero16(); gC1[i][j] = zero16(); gC2[0][j] = zero16(); }
+
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t s = tile * 32 + n;
+        const bool valid = s < a.M;
+        {   // ------------------------------------------------------------------------------------------ density net
+            h4 b0[3];
+            load_density_inputs(a, s, valid, g, b0);
+            f16x d = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) d = MFMA(ld_a(lds + O_S0, P_S0, 0, kb, lane), b0[kb], d);
+            const h4 b1[4] = {relu_pack<0>(d), relu_pack<1>(d), relu_pack<2>(d), relu_pack<3>(d)};
+            f16x o = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) o = MFMA(ld_a(lds + O_S1, P_S1, 0, kb, lane), b1[kb], o);
+            // trunc_exp backward: g * exp(clamp(x, -15, 15)) (activation.py:13-17), then into the fp16 Linear backward
+            h4 dy1 = zero4();
+            if (valid && g == 0) {
+                const float pre = (float)(_Float16)o[0];
+                dy1[0] = (_Float16)(a.d_sigma[s] * expf(fminf(fmaxf(pre, -15.f), 15.f)));
+            }
+            // dW1 = dy1^T x H1
+            wave_lds_fence();
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) { tile_put(tX, kb, b1[kb], lane); tile_put(tY, kb, kb == 0 ? dy1 : zero4(), lane); }
+            wave_lds_fence();
+            dw_tile<1, 1>(gS1, tY, tX, lane);
+            // dH1 = W1^T dy1, masked
+            const f16x dh = MFMA(ld_a(lds + O_S1T, P_S1T, 0, 0, lane), dy1, zero16());
+            const h4 dy0[4] = {mask_pack<0>(dh, b1[0]), mask_pack<1>(dh, b1[1]), mask_pack<2>(dh, b1[2]), mask_pack<3>(dh, b1[3])};
+            wave_lds_fence();
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) { tile_put(tY, kb, dy0[kb], lane); tile_put(tX, kb, kb < 3 ? b0[kb] : zero4(), lane); }
+            wave_lds_fence();
+            dw_tile<1, 1>(gS0, tY, tX, lane);
+            // dX0 = W0^T dH1 : rows 0..15 are d h1 -> level-major [16][M] fp32 (values carry fp16 precision like autocast)
+            f16x dx = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) dx = MFMA(ld_a(lds + O_S0T, P_S0T, 0, kb, lane), dy0[kb], dx);
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int row = 8 * (r >> 2) + 4 * g + (r & 3);
+                    a.d_h1[(size_t)row * Mz + s] = (float)(_Float16)dx[r];
+                }
+            }
+        }
+        if (DO_COLOR) {   // ---------------------------------------------------------------------------- colour + specular
+            h4 b0[5];
+            load_color_inputs(a, s, valid, g, b0);
+            f16x d1[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int kb = 0; kb < 5; ++kb) d1[mb] = MFMA(ld_a(lds + O_C0, P_C0, mb, kb, lane), b0[kb], d1[mb]);
+            const h4 b1[8] = {relu_pack<0>(d1[0]), relu_pack<1>(d1[0]), relu_pack<2>(d1[0]), relu_pack<3>(d1[0]),
+                              relu_pack<0>(d1[1]), relu_pack<1>(d1[1]), relu_pack<2>(d1[1]), relu_pack<3>(d1[1])};
+            f16x d2[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) d2[mb] = MFMA(ld_a(lds + O_C1, P_C1, mb, kb, lane), b1[kb], d2[mb]);
+            const h4 b2[8] = {relu_pack<0>(d2[0]), relu_pack<1>(d2[0]), relu_pack<2>(d2[0]), relu_pack<3>(d2[0]),
+                              relu_pack<0>(d2[1]), relu_pack<1>(d2[1]), relu_pack<2>(d2[1]), relu_pack<3>(d2[1])};
+            f16x d3 = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) d3 = MFMA(ld_a(lds + O_C2, P_C2, 0, kb, lane), b2[kb], d3);
+            const float q0 = sigmoid_h(d3[0]), q1 = sigmoid_h(d3[1]), q2 = sigmoid_h(d3[2]), q3 = sigmoid_h(d3[3]);
+
+            // upstream gradients (g = 0 lanes own sample s)
+            float gr = 0.f, gg = 0.f, gb = 0.f, es0 = 0.f, es1 = 0.f, es2 = 0.f;
+            if (valid && g == 0) {
+                gr = a.d_rgb[(size_t)s * 3]; gg = a.d_rgb[(size_t)s * 3 + 1]; gb = a.d_rgb[(size_t)s * 3 + 2];
+                if (a.d_specular && a.shading != 0) {
+                    es0 = a.d_specular[(size_t)s * 3]; es1 = a.d_specular[(size_t)s * 3 + 1]; es2 = a.d_specular[(size_t)s * 3 + 2];
+                }
+            }
+            float dq0 = 0.f, dq1 = 0.f, dq2 = 0.f, dq3 = 0.f;   // d geo rows 0..3 (g = 0) / rows 4,5 in dq0,dq1 (g = 1)
+            if (a.shading == 0) { dq0 = gr; dq1 = gg; dq2 = gb; }
+            else {
+                h4 bp = zero4();
+                if (g == 0) {
+                    if (valid) { bp[0] = (_Float16)a.dirs[(size_t)s * 3]; bp[1] = (_Float16)a.dirs[(size_t)s * 3 + 1]; bp[2] = (_Float16)a.dirs[(size_t)s * 3 + 2]; }
+                    bp[3] = (_Float16)q3;
+                } else { bp[0] = (_Float16)q0; bp[1] = (_Float16)q1; }
+                const f16x p1 = MFMA(ld_a(lds + O_P0, P_P0, 0, 0, lane), bp, zero16());
+                const h4 bq[4] = {relu_pack<0>(p1), relu_pack<1>(p1), relu_pack<2>(p1), relu_pack<3>(p1)};
+                f16x p2 = zero16();
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) p2 = MFMA(ld_a(lds + O_P1, P_P1, 0, kb, lane), bq[kb], p2);
+                const float s0 = sigmoid_h(p2[0]), s1 = sigmoid_h(p2[1]), s2 = sigmoid_h(p2[2]);
+                float ts0 = es0, ts1 = es1, ts2 = es2;          // d loss / d specular, total
+                if (a.shading == 2) { ts0 += gr; ts1 += gg; ts2 += gb; }
+                else {   // clamp backward passes the gradient where 0 <= x <= 1
+                    const float t0 = (float)(_Float16)(s0 + q0), t1 = (float)(_Float16)(s1 + q1), t2 = (float)(_Float16)(s2 + q2);
+                    const float p0g = (t0 >= 0.f && t0 <= 1.f) ? gr : 0.f, p1g = (t1 >= 0.f && t1 <= 1.f) ? gg : 0.f,
+                                p2g = (t2 >= 0.f && t2 <= 1.f) ? gb : 0.f;
+                    ts0 += p0g; ts1 += p1g; ts2 += p2g;
+                    dq0 = p0g; dq1 = p1g; dq2 = p2g;
+                }
+                h4 dsp = zero4();                                // d specular_net output (pre-sigmoid), rows 0..2
+                if (g == 0) {
+                    dsp[0] = (_Float16)(ts0 * s0 * (1.f - s0)); dsp[1] = (_Float16)(ts1 * s1 * (1.f - s1)); dsp[2] = (_Float16)(ts2 * s2 * (1.f - s2));
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) { tile_put(tX, kb, bq[kb], lane); tile_put(tY, kb, kb == 0 ? dsp : zero4(), lane); }
+                wave_lds_fence();
+                dw_tile<1, 1>(gP1, tY, tX, lane);
+                const f16x dhp = MFMA(ld_a(lds + O_P1T, P_P1T, 0, 0, lane), dsp, zero16());
+                const h4 dyp[4] = {mask_pack<0>(dhp, bq[0]), mask_pack<1>(dhp, bq[1]), mask_pack<2>(dhp, bq[2]), mask_pack<3>(dhp, bq[3])};
+                wave_lds_fence();
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) { tile_put(tY, kb, dyp[kb], lane); tile_put(tX, kb, kb == 0 ? bp : zero4(), lane); }
+                wave_lds_fence();
+                dw_tile<1, 1>(gP0, tY, tX, lane);
+                f16x dxp = zero16();
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) dxp = MFMA(ld_a(lds + O_P0T, P_P0T, 0, kb, lane), dyp[kb], dxp);
+                // rows 3 (g=0, reg 3), 4 and 5 (g=1, regs 0,1) are d feat
+                if (g == 0) dq3 = (float)(_Float16)dxp[3];
+                else { dq0 = (float)(_Float16)dxp[0]; dq1 = (float)(_Float16)dxp[1]; }
+            }
+            // through the sigmoid of color_net's output
+            h4 dc = zero4();
+            if (g == 0) {
+                dc[0] = (_Float16)(dq0 * q0 * (1.f - q0)); dc[1] = (_Float16)(dq1 * q1 * (1.f - q1));
+                dc[2] = (_Float16)(dq2 * q2 * (1.f - q2)); dc[3] = (_Float16)(dq3 * q3 * (1.f - q3));
+            } else { dc[0] = (_Float16)(dq0 * q0 * (1.f - q0)); dc[1] = (_Float16)(dq1 * q1 * (1.f - q1)); }
+            if (!valid) dc = zero4();
+            // layer 3: dW = dc^T x H2 ; dH2 = W3^T dc
+            wave_lds_fence();
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) tile_put(tX, kb, b2[kb], lane);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) tile_put(tY, kb, kb == 0 ? dc : zero4(), lane);
+            wave_lds_fence();
+            dw_tile<1, 2>(gC2, tY, tX, lane);
+            f16x e2[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) e2[mb] = MFMA(ld_a(lds + O_C2T, P_C2T, mb, 0, lane), dc, zero16());
+            const h4 dy2[8] = {mask_pack<0>(e2[0], b2[0]), mask_pack<1>(e2[0], b2[1]), mask_pack<2>(e2[0], b2[2]), mask_pack<3>(e2[0], b2[3]),
+                               mask_pack<0>(e2[1], b2[4]), mask_pack<1>(e2[1], b2[5]), mask_pack<2>(e2[1], b2[6]), mask_pack<3>(e2[1], b2[7])};
+            // layer 2: dW = dy2^T x H1 ; dH1 = W2^T dy2
+            wave_lds_fence();
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) { tile_put(tX, kb, b1[kb], lane); tile_put(tY, kb, dy2[kb], lane); }
+            wave_lds_fence();
+            dw_tile<2, 2>(gC1, tY, tX, lane);
+            f16x e1[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) e1[mb] = MFMA(ld_a(lds + O_C1T, P_C1T, mb, kb, lane), dy2[kb], e1[mb]);
+            const h4 dy1[8] = {mask_pack<0>(e1[0], b1[0]), mask_pack<1>(e1[0], b1[1]), mask_pack<2>(e1[0], b1[2]), mask_pack<3>(e1[0], b1[3]),
+                               mask_pack<0>(e1[1], b1[4]), mask_pack<1>(e1[1], b1[5]), mask_pack<2>(e1[1], b1[6]), mask_pack<3>(e1[1], b1[7])};
+            // layer 1: dW = dy1^T x X0 ; d h2 = rows 0..31 of W1^T dy1
+            wave_lds_fence();
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) { tile_put(tY, kb, dy1[kb], lane); tile_put(tX, kb, kb < 5 ? b0[kb] : zero4(), lane); }
+            wave_lds_fence();
+            dw_tile<2, 2>(gC0, tY, tX, lane);
+            f16x e0 = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) e0 = MFMA(ld_a(lds + O_C0T, P_C0T, 0, kb, lane), dy1[kb], e0);
+            if (valid) {   // rows (2l, 2l+1) = level l of the C=2 encoder -> [16][M][2] fp16
+                typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int row = 8 * (r >> 2) + 4 * g + (r & 3);      // even
+                    h2v v;
+                    v.x = (_Float16)e0[r]; v.y = (_Float16)e0[r + 1];
+                    *reinterpret_cast<h2v*>(a.d_h2 + ((size_t)(row >> 1) * Mz + s) * 2) = v;
+                }
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------------------- reduce dW: registers -> LDS -> HBM
+    __syncthreads();
+    float* stage = reinterpret_cast<float*>(lds);        // weights are dead now; 64 x 64 floats fit in the weight area
+    auto reduce = [&](auto& acc, int out_pad, int in_pad, float* dW, int out, int in, int k_real, int perm) {
+        for (int i = threadIdx.x; i < out_pad * in_pad; i += blockDim.x) stage[i] = 0.f;
+        __syncthreads();
+        dw_to_lds(stage, in_pad, acc, lane);
+        __syncthreads();
+        dw_flush(dW, stage, in_pad, out, in, k_real, perm);
+        __syncthreads();
+    };
+    reduce(gS1, 32, 32, a.dw[1], 1, 32, 32, PERM_PLAIN);
+    reduce(gS0, 32, 32, a.dw[0], 32, 19, 19, PERM_SIGMA0);
+    if (DO_COLOR) {
+        reduce(gC2, 32, 64, a.dw[4], 6, 64, 64, PERM_PLAIN);
+        reduce(gC1, 64, 64, a.dw[3], 64, 64, 64, PERM_PLAIN);
+        reduce(gC0, 64, 64, a.dw[2], 64, 35, 35, PERM_COLOR0);
+        if (a.shading != 0) {
+            reduce(gP1, 32, 32, a.dw[6], 3, 32, 32, PERM_PLAIN);
+            reduce(gP0, 32, 32, a.dw[5], 32, 6, 6, PERM_PLAIN);
+        }
+    }
+}
+
+int check_field(const char* fn, const float* xyz, const float* h1, const float* const* w, uint32_t M, int shading) {
+    N2M_REQUIRE(shading >= 0 && shading <= 2, N2M_EINVAL, "%s: shading must be 0 (diffuse), 1 (full) or 2 (specular)", fn);
+    N2M_REQUIRE(xyz && h1, N2M_ENULL, "%s: xyz / h1 is NULL", fn);
+    N2M_REQUIRE(w[0] && w[1], N2M_ENULL, "%s: sigma_net weights are NULL", fn);
+    (void)M;
+    return 0;
+}
+
+uint32_t persistent_grid(uint32_t M) {
+    const uint32_t tiles = (M + 31) / 32;
+    const uint32_t need = (tiles + 3) / 4;
+    return need < 256u ? (need ? need : 1u) : 256u;      // one 4-wave workgroup per CU, waves stride over the tiles
+}
+
+}  // namespace
+
+extern "C" int n2m_field_forward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
+                                 const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
+                                 const float* w_spec0, const float* w_spec1, uint32_t M, int shading, float* sigma, float* rgb,
+                                 float* specular, void* stream) {
+    const float* w[7] = {w_sigma0, w_sigma1, w_color0, w_color1, w_color2, w_spec0, w_spec1};
+    if (int rc = check_field("field_forward", xyz, h1, w, M, shading)) return rc;
+    N2M_NOTNULL(sigma);
+    const bool color = rgb != nullptr;
+    if (color) {
+        N2M_REQUIRE(h2 && w[2] && w[3] && w[4], N2M_ENULL, "field_forward: colour branch needs h2 and color_net weights");
+        if (shading != 0) N2M_REQUIRE(dirs && w[5] && w[6], N2M_ENULL, "field_forward: shading != 0 needs dirs and specular_net weights");
+    }
+    if (M == 0) return 0;
+    FieldArgs a{};
+    a.xyz = xyz; a.dirs = dirs; a.h1 = h1; a.h2 = (const _Float16*)h2;
+    for (int i = 0; i < 7; ++i) a.w[i] = w[i];
+    a.M = M; a.shading = shading; a.sigma = sigma; a.rgb = rgb; a.specular = specular;
+    hipStream_t s = (hipStream_t)stream;
+    N2M_PROF(N2M_K_MLP_FWD, s, (double)M * (12 + 64 + 4 + (color ? 64 + 12 + 12 + 12 : 0)));
+    const size_t smem = (size_t)FWD_HALVES * 2;
+    if (color) field_forward_kernel<true><<<persistent_grid(M) * 2, 256, smem, s>>>(a);
+    else field_forward_kernel<false><<<persistent_grid(M) * 2, 256, smem, s>>>(a);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
+                                  const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
+                                  const float* w_spec0, const float* w_spec1, uint32_t M, int shading, const float* d_sigma,
+                                  const float* d_rgb, const float* d_specular, float* d_h1, void* d_h2, float* d_w_sigma0,
+                                  float* d_w_sigma1, float* d_w_color0, float* d_w_color1, float* d_w_color2, float* d_w_spec0,
+                                  float* d_w_spec1, void* stream) {
+    const float* w[7] = {w_sigma0, w_sigma1, w_color0, w_color1, w_color2, w_spec0, w_spec1};
+    float* dw[7] = {d_w_sigma0, d_w_sigma1, d_w_color0, d_w_color1, d_w_color2, d_w_spec0, d_w_spec1};
+    if (int rc = check_field("field_backward", xyz, h1, w, M, shading)) return rc;
+    N2M_REQUIRE(d_sigma && d_h1 && dw[0] && dw[1], N2M_ENULL, "field_backward: density gradients are NULL");
+    const bool color = d_rgb != nullptr;
+    if (color) {
+        N2M_REQUIRE(h2 && d_h2 && w[2] && w[3] && w[4] && dw[2] && dw[3] && dw[4], N2M_ENULL, "field_backward: colour branch tensors are NULL");
+        if (shading != 0) N2M_REQUIRE(dirs && w[5] && w[6] && dw[5] && dw[6], N2M_ENULL, "field_backward: specular branch tensors are NULL");
+    }
+    if (M == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)field_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_HALVES * 2);
+        (void)hipFuncSetAttribute((const void*)field_backward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_HALVES * 2);
+        attr_set = true;
+    }
+    FieldArgs a{};
+    a.xyz = xyz; a.dirs = dirs; a.h1 = h1; a.h2 = (const _Float16*)h2;
+    for (int i = 0; i < 7; ++i) { a.w[i] = w[i]; a.dw[i] = dw[i]; }
+    a.M = M; a.shading = shading;
+    a.d_sigma = d_sigma; a.d_rgb = d_rgb; a.d_specular = d_specular; a.d_h1 = d_h1; a.d_h2 = (_Float16*)d_h2;
+    hipStream_t s = (hipStream_t)stream;
+    N2M_PROF(N2M_K_MLP_BWD, s, (double)M * (12 + 64 + 4 + 64 + (color ? 64 + 12 + 24 + 64 : 0)));
+    const size_t smem = (size_t)BWD_HALVES * 2;
+    if (color) field_backward_kernel<true><<<persistent_grid(M), 256, smem, s>>>(a);
+    else field_backward_kernel<false><<<persistent_grid(M), 256, smem, s>>>(a);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}

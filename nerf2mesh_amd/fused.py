@@ -1,0 +1,125 @@
+"""Fused field evaluation: both hash-grid encodes + sigma_net / color_net / specular_net in three kernels forward
+(two encodes, one MFMA field kernel) and three backward (one MFMA field kernel, two LDS-privatised table scatters).
+
+Opt-in replacement (`opt.fused_mlp`) for NeRFNetwork.forward / .density as nerf/network.py:81-108,159-189 composes
+them from nn.Linear calls; the unfused path stays the parity baseline (tests/test_mlp_parity.py).  The C ABI is
+include/n2m_mlp.h.  Semantics follow the autocast graph of the reference: density table fp32, colour table fp16,
+fp16 MLP operands with fp32 accumulation, exp in fp32.
+"""
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+_p = L.ptr
+SHADING = {"diffuse": 0, "full": 1, "specular": 2}
+
+L.SIGNATURES.update({
+    "n2m_field_forward": [L._vp] * 11 + [L._u32, L._int] + [L._vp] * 4,
+    "n2m_field_backward": [L._vp] * 11 + [L._u32, L._int] + [L._vp] * 13,
+})
+
+
+def _bind():
+    lib = L.lib()
+    for name in ("n2m_field_forward", "n2m_field_backward"):
+        fn = getattr(lib, name)
+        fn.argtypes = L.SIGNATURES[name]
+        fn.restype = L._int
+
+
+def _encode_bm(x01, emb, enc, max_level):
+    B = x01.shape[0]
+    Lv, C = enc.num_levels, emb.shape[1]
+    out = torch.empty(B, Lv * C, device=x01.device, dtype=emb.dtype)
+    L.call("n2m_grid_encode_forward_bm", _p(x01), _p(emb), _p(enc.offsets), _p(out), B, 3, C, Lv, max_level,
+           float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), enc.interp_id,
+           L.F16 if emb.dtype == torch.float16 else L.F32, L.stream())
+    return out
+
+
+def _encode_backward_lm(grad_lm, x01, emb, enc, max_level):
+    B = x01.shape[0]
+    Lv, C = enc.num_levels, emb.shape[1]
+    g = torch.zeros_like(emb)
+    L.call("n2m_grid_encode_backward", _p(grad_lm), _p(x01), _p(emb), _p(enc.offsets), _p(g), B, 3, C, Lv, max_level,
+           float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None, None, enc.gridtype_id, int(bool(enc.align_corners)),
+           enc.interp_id, L.F16 if emb.dtype == torch.float16 else L.F32, L.stream())
+    return g
+
+
+class _fused_field(Function):
+    @staticmethod
+    def forward(ctx, xyz, dirs, emb1, emb2, w0, w1, w2, w3, w4, w5, w6, net, shading, want_color):
+        _bind()
+        xyz = xyz.float().contiguous()
+        M = xyz.shape[0]
+        bound, max_level = float(net.bound), int(min(net.max_level, net.encoder.num_levels))
+        x01 = (xyz + bound) / (2 * bound)
+        emb1 = emb1.float().contiguous()
+        h1 = _encode_bm(x01, emb1, net.encoder, max_level)
+        sigma = torch.empty(M, dtype=torch.float32, device=xyz.device)
+        rgb = spec = h2 = emb2h = None
+        ws = [w.float().contiguous() for w in (w0, w1, w2, w3, w4, w5, w6)]
+        if want_color:
+            emb2h = emb2.half().contiguous()               # autocast: C even -> fp16 table (gridencoder/grid.py:45)
+            h2 = _encode_bm(x01, emb2h, net.encoder_color, max_level)
+            dirs = dirs.float().contiguous() if shading != 0 else None
+            rgb = torch.empty(M, 3, dtype=torch.float32, device=xyz.device)
+            spec = torch.empty(M, 3, dtype=torch.float32, device=xyz.device) if shading != 0 else None
+        L.call("n2m_field_forward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, _p(sigma), _p(rgb), _p(spec),
+               L.stream())
+        ctx.net, ctx.shading, ctx.want_color, ctx.max_level = net, shading, want_color, max_level
+        ctx.save_for_backward(xyz, dirs, x01, h1, h2, emb1, emb2h, *ws)
+        if not want_color:
+            return sigma
+        if spec is None:
+            return sigma, rgb
+        return sigma, rgb, spec
+
+    @staticmethod
+    def backward(ctx, d_sigma, d_rgb=None, d_spec=None):
+        xyz, dirs, x01, h1, h2, emb1, emb2h, *ws = ctx.saved_tensors
+        net, shading, want_color, max_level = ctx.net, ctx.shading, ctx.want_color, ctx.max_level
+        M = xyz.shape[0]
+        dev = xyz.device
+        d_sigma = torch.zeros(M, device=dev) if d_sigma is None else d_sigma.float().contiguous()
+        d_h1 = torch.zeros(16, M, dtype=torch.float32, device=dev) if max_level < 16 else torch.empty(16, M, dtype=torch.float32, device=dev)
+        d_h2 = None
+        if want_color:
+            d_rgb = torch.zeros(M, 3, device=dev) if d_rgb is None else d_rgb.float().contiguous()
+            d_spec = d_spec.float().contiguous() if (d_spec is not None and shading != 0) else None
+            d_h2 = torch.empty(16, M, 2, dtype=torch.float16, device=dev)
+        else:
+            d_rgb = d_spec = None
+        dws = [torch.zeros_like(w) for w in ws]
+        L.call("n2m_field_backward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, _p(d_sigma), _p(d_rgb),
+               _p(d_spec), _p(d_h1), _p(d_h2), *[_p(g) for g in dws], L.stream())
+        g1 = _encode_backward_lm(d_h1, x01, emb1, net.encoder, max_level)
+        g2 = None
+        if want_color:
+            g2 = _encode_backward_lm(d_h2, x01, emb2h, net.encoder_color, max_level).float()
+        if not want_color:
+            dws[2:] = [None] * 5
+        elif shading == 0:
+            dws[5:] = [None] * 2
+        return (None, None, g1, g2, *dws, None, None, None)
+
+
+def fused_field(net, xyz, dirs, shading="full"):
+    """sigma [M], rgb [M,3], specular [M,3] | None -- NeRFNetwork.forward without individual codes."""
+    sh = SHADING[shading]
+    out = _fused_field.apply(xyz, dirs, net.encoder.embeddings, net.encoder_color.embeddings, net.sigma_net.net[0].weight,
+                             net.sigma_net.net[1].weight, net.color_net.net[0].weight, net.color_net.net[1].weight,
+                             net.color_net.net[2].weight, net.specular_net.net[0].weight, net.specular_net.net[1].weight, net, sh, True)
+    if sh == 0:
+        return out[0], out[1], None
+    return out
+
+
+def fused_density(net, xyz):
+    """sigma [M] only (occupancy refresh, nerf/renderer.py:1112-1113)."""
+    return _fused_field.apply(xyz, None, net.encoder.embeddings, net.encoder_color.embeddings, net.sigma_net.net[0].weight,
+                              net.sigma_net.net[1].weight, net.color_net.net[0].weight, net.color_net.net[1].weight,
+                              net.color_net.net[2].weight, net.specular_net.net[0].weight, net.specular_net.net[1].weight, net, 0, False)

@@ -16,6 +16,10 @@ from .encoding import get_encoder
 from .renderer import NeRFRenderer
 
 
+def x_is_cuda(net):
+    return net.encoder.embeddings.is_cuda
+
+
 class MLP(nn.Module):
     """Linear(+ReLU) stack, `bias=False` everywhere in nerf2mesh (nerf/network.py:10-54; the geom_init /
     weight_norm variants are only reachable from commented-out code there and are not carried over)."""
@@ -52,12 +56,21 @@ class NeRFNetwork(NeRFRenderer):
         if self.opt.sdf:
             self.register_parameter("variance", nn.Parameter(torch.tensor(0.3, dtype=torch.float32)))
 
+    def _can_fuse(self, c=None):
+        return bool(getattr(self.opt, "fused_mlp", False)) and c is None and not self.opt.sdf and x_is_cuda(self)
+
     def forward(self, x, d, c=None, shading="full"):
+        if self._can_fuse(c):
+            from .fused import fused_field
+            return fused_field(self, x.view(-1, 3), d.view(-1, 3), shading)
         sigma = self.density(x)["sigma"]
         color, specular = self.rgb(x, d, c, shading)
         return sigma, color, specular
 
     def density(self, x):
+        if self._can_fuse() and not x.requires_grad:
+            from .fused import fused_density
+            return {"sigma": fused_density(self, x.reshape(-1, 3)).view(x.shape[:-1])}
         h = self.encoder(x, bound=self.bound, max_level=self.max_level)
         h = self.sigma_net(torch.cat([x, h], dim=-1))
         sigma = h[..., 0].float() if self.opt.sdf else trunc_exp(h[..., 0])

@@ -14,6 +14,7 @@ _DEFAULTS = dict(
     contract=False, patch_size=1, trainable_density_grid=False, color_space="srgb", ind_dim=0, ind_num=500,
     ssaa=2, texture_size=4096, refine=False, gui=False,
     cos_anneal_ratio=1.0, normal_anneal_epsilon=1e-4,
+    fused_mlp=False,     # opt-in: fused MFMA field kernels (nerf2mesh_amd/fused.py) instead of nn.Linear calls
 )
 
 

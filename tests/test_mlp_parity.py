@@ -1,0 +1,132 @@
+"""Fused MFMA field kernels (include/n2m_mlp.h) against the unfused autocast graph (nn.Linear + F.relu as in
+nerf/network.py:10-54,92-108,159-189) on the same weights and samples.
+
+Both sides use fp16 operands with fp32 accumulation and round every layer output to fp16; they differ only in the
+accumulation order inside a dot product, so values agree up to occasional 1-ulp fp16 flips that propagate through the
+following layers.  Tolerances below are stated in those terms."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_nets(seed=0, emb_scale=0.5):
+    import torch
+    from nerf2mesh_amd.network import NeRFNetwork
+    from nerf2mesh_amd.options import make_options
+    torch.manual_seed(seed)
+    ref = NeRFNetwork(make_options(O=True, bound=1, dt_gamma=0)).cuda()
+    with torch.no_grad():
+        ref.encoder.embeddings.uniform_(-emb_scale, emb_scale)
+        ref.encoder_color.embeddings.uniform_(-emb_scale, emb_scale)
+    fused = NeRFNetwork(make_options(O=True, bound=1, dt_gamma=0, fused_mlp=True)).cuda()
+    fused.load_state_dict(ref.state_dict())
+    return ref, fused
+
+
+def samples(M, seed=1):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.rand(M, 3, device="cuda", generator=g) * 1.9 - 0.95
+    d = torch.nn.functional.normalize(torch.randn(M, 3, device="cuda", generator=g), dim=-1)
+    return x, d
+
+
+@pytest.mark.parametrize("shading", ["diffuse", "full", "specular"])
+@pytest.mark.parametrize("M", [1, 31, 4096 + 17])
+def test_fused_forward(shading, M):
+    import torch
+    ref, fused = make_nets()
+    x, d = samples(M)
+    with torch.no_grad():
+        with torch.autocast("cuda", dtype=torch.float16):
+            s0, c0, p0 = ref(x, d, None, shading)
+        s1, c1, p1 = fused(x, d, None, shading)
+    # rgb/specular are fp16-quantised sigmoids in [0,1]: a handful of fp16 ulps (2^-11 each)
+    assert (c0.float() - c1).abs().max().item() < 6e-3
+    assert (c0.float() - c1).abs().mean().item() < 3e-4
+    if shading != "diffuse":
+        assert (p0.float() - p1).abs().max().item() < 6e-3
+    else:
+        assert p1 is None
+    # sigma = exp(fp16 pre-activation): one fp16 ulp of the exponent is up to 0.8 % of sigma
+    rel = ((s0.float() - s1).abs() / s0.float().abs().clamp(min=1e-3))
+    assert rel.max().item() < 3e-2 and rel.mean().item() < 2e-3
+
+
+def test_fused_density_only():
+    import torch
+    ref, fused = make_nets()
+    x, _ = samples(50000)
+    with torch.no_grad():
+        with torch.autocast("cuda", dtype=torch.float16):
+            s0 = ref.density(x)["sigma"]
+        s1 = fused.density(x)["sigma"]
+    rel = ((s0.float() - s1).abs() / s0.float().abs().clamp(min=1e-3))
+    assert rel.max().item() < 3e-2 and rel.mean().item() < 2e-3
+
+
+@pytest.mark.parametrize("shading", ["diffuse", "full"])
+def test_fused_backward(shading):
+    """Gradients of a scalar loss w.r.t. every MLP weight and both hash tables."""
+    import torch
+    ref, fused = make_nets()
+    M = 8192 + 5
+    x, d = samples(M, seed=3)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    cs, cc, cp = torch.randn(M, device="cuda", generator=g), torch.randn(M, 3, device="cuda", generator=g), torch.randn(M, 3, device="cuda", generator=g)
+    scale = 128.0                                               # a GradScaler-like loss scale keeps fp16 grads in range
+
+    def loss_of(net, use_autocast):
+        if use_autocast:
+            with torch.autocast("cuda", dtype=torch.float16):
+                s, c, p = net(x, d, None, shading)
+        else:
+            s, c, p = net(x, d, None, shading)
+        l = (torch.log1p(s.float()) * cs).sum() + (c.float() * cc).sum()
+        if p is not None:
+            l = l + 0.3 * (p.float() * cp).sum()
+        return l * scale / M
+
+    loss_of(ref, True).backward()
+    loss_of(fused, False).backward()
+    names = ["sigma_net.net.0.weight", "sigma_net.net.1.weight", "color_net.net.0.weight", "color_net.net.1.weight", "color_net.net.2.weight"]
+    if shading != "diffuse":
+        names += ["specular_net.net.0.weight", "specular_net.net.1.weight"]
+    pr, pf = dict(ref.named_parameters()), dict(fused.named_parameters())
+    for nme in names:
+        a, b = pr[nme].grad.float(), pf[nme].grad.float()
+        denom = a.abs().max().item() + 1e-12
+        err = (a - b).abs().max().item() / denom
+        # reference dW is an fp16-rounded GEMM output, ours an fp32 sum of the same fp16 products; activation-gradient
+        # ulp flips add a little on top
+        assert err < 2e-2, f"{nme}: rel err {err}"
+    for nme in ("encoder.embeddings", "encoder_color.embeddings"):
+        a, b = pr[nme].grad.float(), pf[nme].grad.float()
+        assert torch.isfinite(b).all()
+        denom = a.abs().max().item() + 1e-12
+        # tables: compare in aggregate (per-level sums) and pointwise relative to the largest entry
+        assert (a - b).abs().max().item() / denom < 5e-2, nme
+        assert abs(a.sum().item() - b.sum().item()) <= 2e-2 * a.abs().sum().item() + 1e-6, nme
+    if shading == "diffuse":
+        assert pf["specular_net.net.0.weight"].grad is None
+
+
+def test_fused_training_matches_unfused_loss_curve():
+    """Same seed, same rays: 60 optimisation steps with and without fusion end at the same loss (within 5 %)."""
+    import torch
+    from nerf2mesh_amd import synthetic
+    from nerf2mesh_amd.network import NeRFNetwork
+    from nerf2mesh_amd.options import make_options
+    from nerf2mesh_amd.trainer import Stage0Trainer
+    losses = []
+    for fused in (False, True):
+        torch.manual_seed(0)
+        opt = make_options(O=True, bound=1, dt_gamma=0, fused_mlp=fused)
+        tr = Stage0Trainer(NeRFNetwork(opt), opt, synthetic.make_cameras(20, seed=0), torch.device("cuda"), seed=0)
+        tr.mark_untrained()
+        acc = []
+        for i in range(60):
+            acc.append(float(tr.train_step()))
+        losses.append(np.mean(acc[-10:]))
+    assert abs(losses[0] - losses[1]) / losses[0] < 0.10, losses
