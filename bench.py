@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--pretrain", type=int, default=300, help="untimed iterations before warmup so the occupancy grid is pruned")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel hipEvents in the timed region")
+    ap.add_argument("--unfused", action="store_true", help="A/B: evaluate the MLPs with nn.Linear calls (the reference graph) instead of the fused MFMA kernels")
     args = ap.parse_args()
 
     from nerf2mesh_amd import _lib, synthetic
@@ -119,7 +120,7 @@ def main():
     _lib.lib()
 
     torch.manual_seed(0)                                           # seed_everything(0), identical init on every rank
-    opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000)   # scripts/runall_syn.sh:1
+    opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=not args.unfused)   # scripts/runall_syn.sh:1
     model = NeRFNetwork(opt)
     poses = synthetic.make_cameras(100, seed=0)
     tr = Stage0Trainer(model, opt, poses, device, rank=rank, world_size=world, seed=0)
@@ -163,7 +164,7 @@ def main():
     if not args.no_prof:
         for name in ("grid_encode_forward", "grid_encode_backward", "grad_total_variation", "march_rays_train_count",
                      "march_rays_train_write", "composite_rays_train_forward", "composite_rays_train_backward",
-                     "near_far_from_aabb", "packbits"):
+                     "near_far_from_aabb", "packbits", "mlp_forward", "mlp_backward"):
             n, ms, by = _lib.prof_read(name)
             if n:
                 kernels[name] = {"launches": n, "avg_us": 1e3 * ms / n, "algo_bytes_per_launch": by / n,
@@ -198,7 +199,7 @@ def main():
         "config": {"workload": "nerf_synthetic/lego stage-0 -O --bound 1 --dt_gamma 0, 800x800 x 100 synthetic views, "
                                "num_points target 2^18/GPU (adaptive num_rays), occupancy refresh every 16 steps",
                    "parallelism": f"dp{world} (rays sharded, grad all-reduce)" if world > 1 else "single GPU",
-                   "pretrain_steps": args.pretrain, "samples_per_step_per_gpu": samples / args.steps / world,
+                   "mlp": "nn.Linear (unfused)" if args.unfused else "fused MFMA field kernels", "pretrain_steps": args.pretrain, "samples_per_step_per_gpu": samples / args.steps / world,
                    "rays_per_step_per_gpu": rays / args.steps / world, "params": 18367240},
         "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "psnr_view0_quarter_res": psnr,
         "loss_mean": float(tr.loss_acc / max(tr.global_step, 1)),

@@ -347,10 +347,10 @@ grid_backward_kernel(const T* __restrict__ grad, const float* __restrict__ input
 //   and ds_add's the ones that fall into its partition, then flushes the partition with COALESCED global atomics
 //   (consecutive lanes -> consecutive rows -> 16 lanes per 64 B line).
 //
-// Re-deriving the rows once per partition costs ALU only (~70 VALU ops per sample-level-partition, ~50 us for the
-// lego tables); scattered traffic stays inside the CU.  Dense (coarse) levels put long runs of consecutive samples
-// of a ray on the same row, which would serialise in the LDS atomic unit, so for those levels equal-row runs of
-// adjacent lanes are first combined with a segmented wave scan and only run tails touch LDS.
+// Re-deriving the rows once per partition costs ALU only (the per-axis hash / stride terms are hoisted, so a corner
+// is two xors/adds, a mask and a range test); scattered traffic stays inside the CU.  Consecutive samples of a ray
+// share cells at the coarse levels, which would serialise in the LDS atomic unit if they sat in adjacent lanes, so
+// each lane starts its 8 corners at a different one (lane % 8) there, spreading a same-cell run over its 8 rows.
 // fp16 tables: products are accumulated in fp32 and rounded to half once per flush (the reference rounds every
 // product to half and adds in half, gridencoder.cu:324-330 -- this is strictly more accurate, same expectation).
 // Gradients are read LEVEL-major [L,B,C]; a sample-major producer is transposed first (33 MB, ~10 us).
@@ -369,132 +369,297 @@ __global__ void transpose_to_level_major_kernel(const T* __restrict__ src /*[B, 
 
 constexpr uint32_t kLdsBytes = 131072;   // accumulator bytes per workgroup (one workgroup per CU)
 
-template <typename T, uint32_t C>
+// Which table rows a work item owns.  Rows are dealt to the `parts` partitions of a level in 16-row blocks (one 64-byte
+// line of fp32 C=1 / fp16 C=2 entries), round-robin: block b belongs to partition b % parts and sits at local block
+// b / parts.  Interleaving keeps the partitions of the DENSE levels balanced (their row index is x + y*s1 + z*s2, so
+// contiguous ranges would be z-slabs and a compact scene would pile onto one of them) while the flush still writes
+// whole lines.  parts is a power of two for the hashed levels (shift/mask), otherwise a reciprocal multiply.
+struct PartMap {
+    uint32_t parts, part, magic, log2p;
+    bool interleaved;
+    // contiguous: partition = row / P (P = 2^log2p rows); used for the hashed levels, whose rows are uniform anyway.
+    //   (Interleaving those was measured SLOWER: a partition's lines then share their low address bits and its flush
+    //    lands on one memory channel.)
+    // interleaved: 16-row blocks dealt round-robin; used for dense levels that span several partitions.
+    __device__ __forceinline__ PartMap(uint32_t parts_, uint32_t part_, uint32_t log2p_, bool interleaved_)
+        : parts(parts_), part(part_), log2p(log2p_), interleaved(interleaved_) {
+        magic = 0xFFFFFFFFu / parts + 1u;              // exact quotient for block indices < 2^32 / parts
+    }
+    __device__ __forceinline__ bool mine(uint32_t row, uint32_t& rel) const {
+        if (!interleaved) {
+            if ((row >> log2p) != part) return false;
+            rel = row & ((1u << log2p) - 1u);
+            return true;
+        }
+        const uint32_t blk = row >> 4;
+        const uint32_t q = __umulhi(blk, magic);
+        if (blk - q * parts != part) return false;
+        rel = (q << 4) | (row & 15u);
+        return true;
+    }
+    __device__ __forceinline__ uint32_t global_row(uint32_t rel) const {
+        return interleaved ? ((((rel >> 4) * parts + part) << 4) | (rel & 15u)) : ((part << log2p) + rel);
+    }
+};
+
+// MODE 0: generic Indexer::row (tiled grids with a wrap, non power-of-two hashed tables)
+// MODE 1: hashed level with a power-of-two table: row = (x*1 ^ y*p1 ^ z*p2) & mask
+// MODE 2: dense level without wrap:               row = x + y*s1 + z*s2
+template <typename T, uint32_t C, int MODE>
+__device__ __forceinline__ void backward_sweep(float* acc, const T* __restrict__ glevel, const float* __restrict__ inputs,
+                                               const Indexer<3>& ix, float scale, bool align_corners, uint32_t interp,
+                                               uint32_t s_first, uint32_t run, uint32_t s_end, const PartMap pm) {
+    constexpr uint32_t D = 3;
+    const uint32_t lane = threadIdx.x & 63u;
+    // coalesced assignment: at iteration `it` the block covers samples s_first + it*1024 .. +1023 (s_first = group
+    // start + thread id).  Consecutive samples of a ray share a cell at the coarse (dense) levels, so adjacent lanes would
+    // hit the SAME LDS word corner after corner; for those levels each lane starts at a different corner (lane % 8), which
+    // spreads a same-cell run of lanes over its 8 rows and cuts the LDS atomic serialisation by ~8x at no extra traffic.
+    // the loop is latency-bound (one dependent load round trip per iteration), so the NEXT iteration's point and
+    // gradient row are requested before the current one is consumed
+    float xn[D] = {2.f, 2.f, 2.f};
+    Row<T, C> gn;
+#pragma unroll
+    for (uint32_t c = 0; c < C; ++c) gn.v[c] = (T)0;
+    if (s_first < s_end) { load_point<D>(inputs, s_first, xn); gn = Row<T, C>::load(glevel + (size_t)s_first * C); }
+    for (uint32_t it = 0; it < run; ++it) {
+        const uint32_t s = s_first + it * 1024u;
+        if (s >= s_end) break;
+        float x[D] = {xn[0], xn[1], xn[2]};
+        const Row<T, C> gr = gn;
+        const uint32_t s2 = s + 1024u;
+        if (it + 1 < run && s2 < s_end) { load_point<D>(inputs, s2, xn); gn = Row<T, C>::load(glevel + (size_t)s2 * C); }
+        if (outside_unit_cube<D>(x)) continue;
+        uint32_t cell[D];
+        float frac[D], dfrac[D];
+        locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
+        const float wx[2] = {1 - frac[0], frac[0]}, wy[2] = {1 - frac[1], frac[1]}, wz[2] = {1 - frac[2], frac[2]};
+        uint32_t tx[2], ty[2], tz[2];
+        if (MODE == 1) {
+            tx[0] = cell[0]; tx[1] = cell[0] + 1;
+            ty[0] = cell[1] * kPrimes[1]; ty[1] = ty[0] + kPrimes[1];
+            tz[0] = cell[2] * kPrimes[2]; tz[1] = tz[0] + kPrimes[2];
+        } else if (MODE == 2) {
+            tx[0] = cell[0]; tx[1] = cell[0] + 1;
+            ty[0] = cell[1] * ix.stride[1]; ty[1] = ty[0] + ix.stride[1];
+            tz[0] = cell[2] * ix.stride[2]; tz[1] = tz[0] + ix.stride[2];
+        }
+#pragma unroll
+        for (uint32_t cc = 0; cc < 8; ++cc) {
+            const uint32_t corner = MODE == 1 ? cc : ((cc + lane) & 7u);
+            const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
+            uint32_t row;
+            if (MODE == 1) row = (tx[i] ^ ty[j] ^ tz[k]) & ix.mask;
+            else if (MODE == 2) row = (i ? tx[1] : tx[0]) + (j ? ty[1] : ty[0]) + (k ? tz[1] : tz[0]);
+            else {
+                const uint32_t v[D] = {cell[0] + i, cell[1] + j, cell[2] + k};
+                row = ix.row(v);
+            }
+            uint32_t rel;
+            if (pm.mine(row, rel)) {
+                const float w = ((i ? wx[1] : wx[0]) * (j ? wy[1] : wy[0])) * (k ? wz[1] : wz[0]);   // forward's association
+#pragma unroll
+                for (uint32_t c = 0; c < C; ++c)
+                    __hip_atomic_fetch_add(&acc[rel * C + c], w * (float)gr.v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+}
+
+// Total-variation sweep (gridencoder.cu:505-609) for one (level, partition) item: the cell of every sample is looked
+// up, and when its row belongs to this partition the TV term  w * sum_nb (g - g_nb) / sqrt(sum_nb (g - g_nb)^2 + 1e-9)
+// over the up-to-6 axis neighbours is added to the partition's LDS accumulator (instead of one scattered global
+// atomic per sample and level).  fp32 tables only, like the reference's effective path.
+template <uint32_t C>
+__device__ __forceinline__ void tv_apply(float* acc, const float* __restrict__ tab, const float* __restrict__ inputs,
+                                         const Indexer<3>& ix, float scale, bool align_corners, uint32_t resolution, float w,
+                                         uint32_t s, const PartMap& pm) {
+    constexpr uint32_t D = 3;
+    float x[D];
+    load_point<D>(inputs, s, x);
+    uint32_t cell[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) cell[d] = (uint32_t)floorf(x[d] * scale + (align_corners ? 0.0f : 0.5f));
+    const uint32_t here = ix.row(cell);
+    uint32_t rel = 0;
+    (void)pm.mine(here, rel);
+    // issue all 7 row reads before using any of them
+    uint32_t nb_row[2 * D];
+    bool nb_ok[2 * D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) {
+        const uint32_t cur = cell[d];
+        nb_ok[2 * d] = cur < resolution;
+        cell[d] = cur + 1;
+        nb_row[2 * d] = nb_ok[2 * d] ? ix.row(cell) : here;
+        nb_ok[2 * d + 1] = cur > 0;
+        cell[d] = cur - 1;
+        nb_row[2 * d + 1] = nb_ok[2 * d + 1] ? ix.row(cell) : here;
+        cell[d] = cur;
+    }
+    const Row<float, C> centre = Row<float, C>::load(tab + (size_t)here * C);
+    Row<float, C> nb[2 * D];
+#pragma unroll
+    for (uint32_t k = 0; k < 2 * D; ++k) nb[k] = Row<float, C>::load(tab + (size_t)nb_row[k] * C);
+    float sum[C], sq[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; ++c) { sum[c] = 0.f; sq[c] = 0.f; }
+#pragma unroll
+    for (uint32_t k = 0; k < 2 * D; ++k) {   // same order as the reference: +1 then -1 neighbour, axis by axis
+        if (nb_ok[k]) {
+#pragma unroll
+            for (uint32_t c = 0; c < C; ++c) { const float dv = centre.v[c] - nb[k].v[c]; sum[c] += dv; sq[c] += dv * dv; }
+        }
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < C; ++c)
+        __hip_atomic_fetch_add(&acc[rel * C + c], w * sum[c] * (1.0f / sqrtf(sq[c] + 1e-9f)), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Total-variation sweep (gridencoder.cu:505-609) for one (level, partition) item.  Only ~1/partitions of the samples
+// have their cell in this partition; evaluating the 7-row stencil under that divergence would make every wave pay the
+// full stencil latency on every iteration.  Instead each wave COMPACTS the qualifying sample ids into a small LDS queue
+// (ballot + popcount) and runs the stencil only on full batches of 64.
+template <uint32_t C>
+__device__ __forceinline__ void tv_sweep(float* acc, uint32_t* queue /*[128] per wave*/, const float* __restrict__ tab,
+                                         const float* __restrict__ inputs, const Indexer<3>& ix, float scale, bool align_corners,
+                                         uint32_t resolution, float w, uint32_t s_first, uint32_t run, uint32_t s_end,
+                                         const PartMap pm) {
+    constexpr uint32_t D = 3;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t qn = 0;                                   // wave-uniform queue length
+    for (uint32_t it = 0; it < run; ++it) {
+        const uint32_t s = s_first + it * 1024u;
+        bool mine = false;
+        if (s < s_end) {
+            float x[D];
+            load_point<D>(inputs, s, x);
+            if (!outside_unit_cube<D>(x)) {
+                uint32_t cell[D];
+#pragma unroll
+                for (uint32_t d = 0; d < D; ++d) cell[d] = (uint32_t)floorf(x[d] * scale + (align_corners ? 0.0f : 0.5f));
+                uint32_t rel;
+                mine = pm.mine(ix.row(cell), rel);
+            }
+        }
+        const unsigned long long m = __ballot(mine);
+        if (mine) queue[qn + (uint32_t)__popcll(m & below)] = s;
+        qn += (uint32_t)__popcll(m);
+        if (qn >= 64u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t sq = queue[lane];
+            const uint32_t tail = lane + 64u < qn ? queue[lane + 64u] : 0u;
+            tv_apply<C>(acc, tab, inputs, ix, scale, align_corners, resolution, w, sq, pm);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane + 64u < qn) queue[lane] = tail;
+            qn -= 64u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < qn) tv_apply<C>(acc, tab, inputs, ix, scale, align_corners, resolution, w, queue[lane], pm);
+}
+
+template <typename T, uint32_t C, bool TV>
 __global__ void __launch_bounds__(1024)
 grid_backward_lds_kernel(const T* __restrict__ grad /*[L,B,C]*/, const float* __restrict__ inputs,
                          const int32_t* __restrict__ offsets, T* __restrict__ grad_table, uint32_t B, uint32_t max_level,
-                         LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t G) {
+                         LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t G,
+                         const float* __restrict__ tv_table, float tv_weight) {
     constexpr uint32_t D = 3;
     constexpr uint32_t P = kLdsBytes / (4 * C);          // table rows per partition
     extern __shared__ __attribute__((aligned(16))) float acc[];
     __shared__ uint32_t item_prefix[kMaxLevels + 1];
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t tid = threadIdx.x;
 
+    // LDS float atomics sustain only ~0.8 G/s per CU (measured), so an item's cost is its number of LDS updates:
+    // 8 * samples / partitions(level).  A level with few partitions (the small dense tables: ONE partition receives
+    // every update) therefore gets proportionally more sample groups, so that all items carry about `target` updates.
+    __shared__ uint32_t level_groups[kMaxLevels];
+    __shared__ uint32_t tv_queue[TV ? 16 * 128 : 1];       // per-wave compaction queues of the TV sweep
     if (tid == 0) {
+        const uint32_t target = 24576u / (C > 2 ? 2 : C) * 2u;     // LDS updates per item (C float atomics each)
         uint32_t run = 0;
         for (uint32_t l = 0; l < max_level; ++l) {
             const uint32_t size = (uint32_t)(offsets[l + 1] - offsets[l]);
+            const uint32_t parts = (((size + 15u) >> 4) + (P / 16u) - 1) / (P / 16u);   // partitions hold whole 16-row blocks
+            const uint64_t updates = (uint64_t)(TV ? 1 : 8) * B;   // LDS updates of the whole level
+            uint32_t g = (uint32_t)((updates + (uint64_t)parts * target - 1) / ((uint64_t)parts * target));
+            g = g < G ? G : (g > 256u ? 256u : g);
+            level_groups[l] = g;
             item_prefix[l] = run;
-            run += ((size + P - 1) / P) * G;
+            run += parts * g;
         }
         item_prefix[max_level] = run;
     }
     __syncthreads();
     const uint32_t total_items = item_prefix[max_level];
-    const uint32_t chunk = (((B + G - 1) / G) + 63u) & ~63u;     // samples per group, wave aligned
 
     for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x) {
         uint32_t level = 0;
         while (item >= item_prefix[level + 1]) ++level;
+        const uint32_t Gl = level_groups[level];
+        const uint32_t chunk = (((B + Gl - 1) / Gl) + 1023u) & ~1023u;   // samples per group, a multiple of the block size
+        const uint32_t run = chunk / 1024u;                              // iterations per lane
         const uint32_t local = item - item_prefix[level];
-        const uint32_t part = local / G, grp = local - part * G;
+        const uint32_t part = local / Gl, grp = local - part * Gl;
         const uint32_t row0 = (uint32_t)offsets[level];
         const uint32_t size = (uint32_t)offsets[level + 1] - row0;
-        const uint32_t part_row0 = part * P;
-        const uint32_t rows_here = min(P, size - part_row0);
+        const uint32_t parts = (((size + 15u) >> 4) + (P / 16u) - 1) / (P / 16u);
         const float scale = lv.scale[level];
         const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
-        const bool merge_runs = !ix.hashed;               // coarse dense levels: long equal-row runs along a ray
+        constexpr uint32_t kLog2P = 31u - __builtin_clz(P);            // P is a power of two for C in {1,2,4,8}
+        const bool interleaved = !ix.hashed && parts > 1u;
+        const PartMap pm(parts, part, kLog2P, interleaved);
+        const uint32_t n_blocks = (size + 15u) >> 4;
+        const uint32_t my_blocks = interleaved ? (part < n_blocks ? (n_blocks - part + parts - 1) / parts : 0u)
+                                               : min(P / 16u, n_blocks - min(n_blocks, part * (P / 16u)));
+        const uint32_t rows_here = my_blocks << 4;                      // <= P by construction
 
         for (uint32_t i = tid; i < rows_here * C; i += 1024) acc[i] = 0.0f;
         __syncthreads();
 
         const uint32_t s_begin = grp * chunk;
         const uint32_t s_end = min(B, s_begin + chunk);
+        const uint32_t s_first = s_begin + tid;
         const T* __restrict__ glevel = grad + (size_t)level * B * C;
-        for (uint32_t base = s_begin + (tid & ~63u); base < s_end; base += 1024) {
-            const uint32_t s = base + lane;
-            bool valid = s < s_end;
-            float x[D] = {0.f, 0.f, 0.f};
-            float gv[C];
-#pragma unroll
-            for (uint32_t c = 0; c < C; ++c) gv[c] = 0.f;
-            if (valid) {
-                load_point<D>(inputs, s, x);
-                valid = !outside_unit_cube<D>(x);
-                const Row<T, C> gr = Row<T, C>::load(glevel + (size_t)s * C);
-#pragma unroll
-                for (uint32_t c = 0; c < C; ++c) gv[c] = (float)gr.v[c];
-            }
-            uint32_t cell[D];
-            float frac[D], dfrac[D];
-            locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
-#pragma unroll
-            for (uint32_t corner = 0; corner < 8; ++corner) {
-                uint32_t v[D];
-                float w = 1.0f;
-#pragma unroll
-                for (uint32_t d = 0; d < D; ++d) {
-                    if (corner & (1u << d)) { w *= frac[d]; v[d] = cell[d] + 1; }
-                    else { w *= 1 - frac[d]; v[d] = cell[d]; }
-                }
-                const uint32_t rel = ix.row(v) - part_row0;
-                const bool mine = valid && rel < rows_here;
-                if (!merge_runs) {
-                    if (mine) {
-#pragma unroll
-                        for (uint32_t c = 0; c < C; ++c)
-                            __hip_atomic_fetch_add(&acc[rel * C + c], w * gv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                } else {
-                    // combine runs of equal rows in adjacent lanes (segmented inclusive scan), add once per run
-                    const uint32_t key = mine ? rel : 0xFFFFFFFFu;
-                    const uint32_t prev = __shfl_up(key, 1, 64);
-                    const uint32_t next = __shfl_down(key, 1, 64);
-                    bool head = (lane == 0) || (prev != key);
-                    const bool tail = (lane == 63) || (next != key);
-                    float val[C];
-#pragma unroll
-                    for (uint32_t c = 0; c < C; ++c) val[c] = mine ? w * gv[c] : 0.f;
-#pragma unroll
-                    for (uint32_t o = 1; o < 64; o <<= 1) {
-                        const int h2 = __shfl_up((int)head, o, 64);
-                        float v2[C];
-#pragma unroll
-                        for (uint32_t c = 0; c < C; ++c) v2[c] = __shfl_up(val[c], o, 64);
-                        if (lane >= o && !head) {
-#pragma unroll
-                            for (uint32_t c = 0; c < C; ++c) val[c] += v2[c];
-                            head = h2 != 0;
-                        }
-                    }
-                    if (mine && tail) {
-#pragma unroll
-                        for (uint32_t c = 0; c < C; ++c)
-                            __hip_atomic_fetch_add(&acc[rel * C + c], val[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-            }
-        }
+        if constexpr (TV) {
+            if constexpr (sizeof(T) == 4)
+                tv_sweep<C>(acc, &tv_queue[(tid >> 6) * 128u], tv_table + (size_t)row0 * C, inputs, ix, scale, align_corners,
+                            lv.resolution[level], tv_weight / (float)(2 * D), s_first, run, s_end, pm);
+        } else if (ix.hashed && ix.pow2)
+            backward_sweep<T, C, 1>(acc, glevel, inputs, ix, scale, align_corners, interp, s_first, run, s_end, pm);
+        else if (!ix.hashed && !ix.wrap)
+            backward_sweep<T, C, 2>(acc, glevel, inputs, ix, scale, align_corners, interp, s_first, run, s_end, pm);
+        else
+            backward_sweep<T, C, 0>(acc, glevel, inputs, ix, scale, align_corners, interp, s_first, run, s_end, pm);
         __syncthreads();
 
-        // flush: consecutive lanes -> consecutive table entries (coalesced atomics); untouched entries are skipped
-        T* __restrict__ gtab = grad_table + ((size_t)row0 + part_row0) * C;
-        if constexpr (sizeof(T) == 2) {
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            for (uint32_t i = tid; i < rows_here * C / 2; i += 1024) {
-                const float a = acc[2 * i], b2 = acc[2 * i + 1];
-                if (a != 0.f || b2 != 0.f) {
-                    h2 val;
-                    val.x = (_Float16)a;
-                    val.y = (_Float16)b2;
-                    (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gtab + 2 * i), val);
+        // flush: 16 consecutive lanes -> the 16 rows of one block = one 64-byte line; untouched entries are skipped
+        T* __restrict__ gtab = grad_table + (size_t)row0 * C;
+        for (uint32_t rel = tid; rel < rows_here; rel += 1024) {
+            const uint32_t row = pm.global_row(rel);
+            if (row >= size) continue;
+            if constexpr (sizeof(T) == 2) {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (uint32_t c = 0; c < C; c += 2) {
+                    const float a = acc[rel * C + c], b2 = acc[rel * C + c + 1];
+                    if (a != 0.f || b2 != 0.f) {
+                        h2 val;
+                        val.x = (_Float16)a;
+                        val.y = (_Float16)b2;
+                        (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gtab + (size_t)row * C + c), val);
+                    }
                 }
-            }
-        } else {
-            for (uint32_t i = tid; i < rows_here * C; i += 1024) {
-                const float a = acc[i];
-                if (a != 0.f) unsafeAtomicAdd(gtab + i, a);
+            } else {
+#pragma unroll
+                for (uint32_t c = 0; c < C; ++c) {
+                    const float a = acc[rel * C + c];
+                    if (a != 0.f) unsafeAtomicAdd(gtab + (size_t)row * C + c, a);
+                }
             }
         }
         __syncthreads();
@@ -603,7 +768,7 @@ void launch_backward(const BwdArgs& a) {
         if constexpr (D == 3) {
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)grid_backward_lds_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                (void)hipFuncSetAttribute((const void*)grid_backward_lds_kernel<T, C, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)kLdsBytes);
                 attr_set = true;
             }
@@ -619,8 +784,9 @@ void launch_backward(const BwdArgs& a) {
             }
             if (!BM || scratch) {
                 const uint32_t G = a.B >= (1u << 18) ? 4u : a.B >= (1u << 16) ? 2u : 1u;
-                grid_backward_lds_kernel<T, C><<<1024, 1024, kLdsBytes, a.s>>>(g, a.inputs, a.offsets, (T*)a.grad_table, a.B,
-                                                                                a.max_level, a.lv, a.gridtype, a.align, a.interp, G);
+                grid_backward_lds_kernel<T, C, false><<<2048, 1024, kLdsBytes, a.s>>>(g, a.inputs, a.offsets, (T*)a.grad_table, a.B,
+                                                                                       a.max_level, a.lv, a.gridtype, a.align, a.interp, G,
+                                                                                       nullptr, 0.0f);
                 if (scratch) (void)hipFreeAsync(scratch, a.s);
                 if (!BM && a.dy_dx && a.grad_inputs)
                     grid_input_backward_kernel<T, D, C><<<n2m_ceil_div((uint64_t)a.B * D, 256), 256, 0, a.s>>>(
@@ -644,6 +810,20 @@ struct TvArgs {
 
 template <uint32_t D, uint32_t C>
 void launch_tv(const TvArgs& a) {
+    static const bool use_scatter = getenv("N2M_GRID_TV_SCATTER") != nullptr;   // A/B switch
+    if constexpr (D == 3) {
+        if (!use_scatter) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)grid_backward_lds_kernel<float, C, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)kLdsBytes);
+                attr_set = true;
+            }
+            grid_backward_lds_kernel<float, C, true><<<2048, 1024, kLdsBytes, a.s>>>(nullptr, a.inputs, a.offsets, a.grad, a.B, a.L, a.lv,
+                                                                                      a.gridtype, a.align, 0u, 2u, a.table, a.weight);
+            return;
+        }
+    }
     const dim3 grid(n2m_ceil_div(a.B, 256), a.L);
     grid_tv_kernel<D, C><<<grid, 256, 0, a.s>>>(a.inputs, a.table, a.grad, a.offsets, a.weight, a.B, a.lv, a.gridtype, a.align);
 }
