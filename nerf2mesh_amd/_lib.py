@@ -32,6 +32,9 @@ SIGNATURES = {
     "n2m_grid_encode_backward_bm": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int, _vp],
     "n2m_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp],
     "n2m_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
+    # include/n2m_mlp.h
+    "n2m_field_forward": [_vp] * 11 + [_u32, _int] + [_vp] * 4,
+    "n2m_field_backward": [_vp] * 11 + [_u32, _int] + [_vp] * 13,
     "n2m_prof_enable": [_int],
     "n2m_prof_reset": [],
     "n2m_prof_read": [_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],

@@ -15,18 +15,9 @@ from . import _lib as L
 _p = L.ptr
 SHADING = {"diffuse": 0, "full": 1, "specular": 2}
 
-L.SIGNATURES.update({
-    "n2m_field_forward": [L._vp] * 11 + [L._u32, L._int] + [L._vp] * 4,
-    "n2m_field_backward": [L._vp] * 11 + [L._u32, L._int] + [L._vp] * 13,
-})
-
 
 def _bind():
-    lib = L.lib()
-    for name in ("n2m_field_forward", "n2m_field_backward"):
-        fn = getattr(lib, name)
-        fn.argtypes = L.SIGNATURES[name]
-        fn.restype = L._int
+    L.lib()
 
 
 def _encode_bm(x01, emb, enc, max_level):

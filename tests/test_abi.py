@@ -43,7 +43,7 @@ def test_ctypes_table_covers_the_header(libpath):
     declared = set(declared_symbols()) - {"n2m_abi_version", "n2m_last_error", "n2m_prof_name"}
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     # argument counts agree with the header prototypes
-    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "n2m_hip.h")).read(), flags=re.S)
+    src = "\n".join(re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S) for h in glob.glob(os.path.join(ROOT, "include", "*.h")))
     for name, argtypes in _lib.SIGNATURES.items():
         m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
         assert m, name
