@@ -35,6 +35,14 @@ SIGNATURES = {
     # include/n2m_mlp.h
     "n2m_field_forward": [_vp] * 11 + [_u32, _int] + [_vp] * 4,
     "n2m_field_backward": [_vp] * 11 + [_u32, _int] + [_vp] * 13,
+    # include/n2m_raster.h
+    "n2m_rasterize_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    "n2m_rasterize_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp],
+    "n2m_interpolate_forward": [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp],
+    "n2m_interpolate_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    "n2m_antialias_build_topology": [_vp, _u32, _vp, _u32, _vp],
+    "n2m_antialias_forward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp],
+    "n2m_antialias_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _vp, _vp, _vp],
     "n2m_prof_enable": [_int],
     "n2m_prof_reset": [],
     "n2m_prof_read": [_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],

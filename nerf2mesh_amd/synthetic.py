@@ -153,3 +153,42 @@ def scene_density_grid(H=128, cascade=1, bound=1.0, sigma=50.0, device="cpu"):
             occ |= scene_inside(p, bx)
         grid[cas, idx] = occ.float() * sigma
     return grid
+
+
+def scene_mesh(target_faces=300000, device="cpu"):
+    """Triangle mesh of the box scene (every box face tessellated into k x k quads so that the total is close to
+    `target_faces`, the reference's decimate_target, main.py:101).  Returns vertices [V,3] f32, faces [F,3] i32.
+    Boxes keep their own vertices (the union is not remeshed); each box is individually watertight."""
+    bx = torch.tensor(_BOXES, dtype=torch.float32)
+    n_box = bx.shape[0]
+    k = max(1, int(round(math.sqrt(target_faces / (n_box * 6 * 2)))))
+    lin = torch.linspace(0, 1, k + 1)
+    uu, vv = torch.meshgrid(lin, lin, indexing="ij")
+    uv = torch.stack([uu.reshape(-1), vv.reshape(-1)], -1)                     # [(k+1)^2, 2]
+    ii, jj = torch.meshgrid(torch.arange(k), torch.arange(k), indexing="ij")
+    q = (ii * (k + 1) + jj).reshape(-1)
+    quad = torch.stack([q, q + (k + 1), q + (k + 2), q, q + (k + 2), q + 1], -1).reshape(-1, 3)   # two triangles per cell
+    verts, faces, base = [], [], 0
+    for b in range(n_box):
+        lo, hi = bx[b, 0:3], bx[b, 3:6]
+        for axis in range(3):
+            a1, a2 = (axis + 1) % 3, (axis + 2) % 3
+            for side in (0, 1):
+                p = torch.zeros(uv.shape[0], 3)
+                p[:, axis] = hi[axis] if side else lo[axis]
+                p[:, a1] = lo[a1] + uv[:, 0] * (hi[a1] - lo[a1])
+                p[:, a2] = lo[a2] + uv[:, 1] * (hi[a2] - lo[a2])
+                verts.append(p)
+                f = quad + base
+                faces.append(f if side else f[:, [0, 2, 1]])                   # outward winding
+                base += uv.shape[0]
+    return torch.cat(verts).to(device), torch.cat(faces).int().to(device)
+
+
+def mvp_matrix(pose, H=LEGO_HW, W=LEGO_HW, focal=LEGO_FOCAL, near=0.05, far=100.0):
+    """projection @ inverse(pose) with the reference's projection (nerf/provider.py:266-276: y flipped, OpenGL z)."""
+    proj = torch.tensor([[2 * focal / W, 0, 0, 0],
+                         [0, -2 * focal / H, 0, 0],
+                         [0, 0, -(far + near) / (far - near), -(2 * far * near) / (far - near)],
+                         [0, 0, -1, 0]], dtype=torch.float32, device=pose.device)
+    return proj @ torch.inverse(pose)

@@ -14,11 +14,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libn2m_oracle.so")
-_SRC = os.path.join(_HERE, "n2m_oracle.c")
+_SRCS = [os.path.join(_HERE, "n2m_oracle.c"), os.path.join(_HERE, "n2m_raster_oracle.c")]
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in _SRCS):
         subprocess.run(["make", "-C", _HERE, "libn2m_oracle.so"] + (["-B"] if force else []), check=True,
                        stdout=subprocess.DEVNULL)
     return _SO
@@ -274,3 +274,29 @@ def sh_encode_backward(grad, inputs, degree, dy_dx, grad_inputs=None):
         grad_inputs = np.zeros((B, D), np.float32)
     _call("sh_encode_backward", _p(grad), _p(inputs), _u32(B), _u32(D), _u32(degree), _p(dy_dx), _p(grad_inputs))
     return grad_inputs
+
+
+# ------------------------------------------------------------------------------------------- stage-1 raster
+
+def rasterize(pos, tri, H, W):
+    pos, tri = _c(pos, np.float32).reshape(-1, 4), _c(tri, np.int32).reshape(-1, 3)
+    rast = np.zeros((H, W, 4), np.float32)
+    _call("rasterize", _p(pos), _p(tri), _u32(pos.shape[0]), _u32(tri.shape[0]), _u32(H), _u32(W), _p(rast))
+    return rast
+
+
+def interpolate(attr, rast, tri):
+    attr, rast, tri = _c(attr, np.float32), _c(rast, np.float32), _c(tri, np.int32).reshape(-1, 3)
+    H, W = rast.shape[0], rast.shape[1]
+    out = np.zeros((H, W, attr.shape[1]), np.float32)
+    _call("interpolate", _p(attr), _p(rast), _p(tri), _u32(attr.shape[0]), _u32(tri.shape[0]), _u32(attr.shape[1]), _u32(H), _u32(W), _p(out))
+    return out
+
+
+def antialias(color, rast, pos, tri):
+    color, rast = _c(color, np.float32), _c(rast, np.float32)
+    pos, tri = _c(pos, np.float32).reshape(-1, 4), _c(tri, np.int32).reshape(-1, 3)
+    H, W, C = color.shape
+    out = np.zeros_like(color)
+    _call("antialias", _p(color), _p(rast), _p(pos), _p(tri), _u32(pos.shape[0]), _u32(tri.shape[0]), _u32(C), _u32(H), _u32(W), _p(out))
+    return out
