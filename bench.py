@@ -93,6 +93,54 @@ def cpu_baseline(n_rays=4096, reps=2):
                       f"{M} samples, best of {reps}; oracle C/OpenMP + torch-CPU MLPs"}
 
 
+def bench_stage1(args, rank, world, device):
+    """One step = render_stage1 of one 800x800 view at 1600x1600 (ssaa 2) on a ~300k-face mesh + loss + backward + Adam
+    (nerf/utils.py:708-721, nerf/renderer.py:816-921); views shard across ranks."""
+    from nerf2mesh_amd import _lib, synthetic
+    from nerf2mesh_amd.network import NeRFNetwork
+    from nerf2mesh_amd.options import make_options
+    from nerf2mesh_amd.trainer import Stage1Trainer
+    torch.manual_seed(0)
+    opt = make_options(O=True, bound=1, dt_gamma=0, stage=1, fused_mlp=not args.unfused)
+    v, f = synthetic.scene_mesh(300000)
+    tr = Stage1Trainer(NeRFNetwork(opt), opt, synthetic.make_cameras(100, seed=0), v, f, device, rank=rank, world_size=world)
+    for _ in range(args.warmup):
+        tr.train_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if not args.no_prof:
+        _lib.prof_reset(); _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    stats = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dt = float(stats[0])
+    if rank == 0:
+        px = 800 * 800 * args.steps * world
+        kernels = {}
+        for name in ("rasterize", "mlp_forward", "mlp_backward", "grid_encode_forward", "grid_encode_backward"):
+            n, ms, by = _lib.prof_read(name)
+            if n:
+                kernels[name] = {"launches": n, "avg_us": 1e3 * ms / n, "ms_per_step": ms / args.steps}
+        print(json.dumps({"metric": "stage1_train_pixels_per_sec", "value": px / dt, "unit": "output pixels/s (800x800 views, rendered at 1600x1600)",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 raster, f16 autocast shading",
+                          "data": "synthetic", "config": {"workload": f"nerf_synthetic/lego stage-1 -O --bound 1: {f.shape[0]} faces, "
+                                                                       f"{v.shape[0]} vertices, ssaa 2, refine error tracking on",
+                                                          "parallelism": f"views sharded over {world} GPU(s)"},
+                          "kernels": kernels}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +149,8 @@ def main():
     ap.add_argument("--pretrain", type=int, default=300, help="untimed iterations before warmup so the occupancy grid is pruned")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel hipEvents in the timed region")
+    ap.add_argument("--stage", type=int, default=0, choices=[0, 1], help="0: stage-0 volume rendering (the headline metric); "
+                    "1: stage-1 mesh/texture refinement step (BASELINE config 3)")
     ap.add_argument("--unfused", action="store_true", help="A/B: evaluate the MLPs with nn.Linear calls (the reference graph) instead of the fused MFMA kernels")
     args = ap.parse_args()
 
@@ -118,6 +168,9 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     _lib.lib()
+
+    if args.stage == 1:
+        return bench_stage1(args, rank, world, device)
 
     torch.manual_seed(0)                                           # seed_everything(0), identical init on every rank
     opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=not args.unfused)   # scripts/runall_syn.sh:1

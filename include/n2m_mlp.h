@@ -34,7 +34,8 @@ extern "C" {
  * when shading == 0), h1 [M,16] f32 (density features, sample-major), h2 [M,32] f16 (colour features; may be NULL
  * when rgb == NULL: density-only evaluation as in update_extra_state).
  * Outputs: sigma [M] f32; rgb [M,3] f32 and specular [M,3] f32 (either may be NULL; specular is not written for
- * shading 0). */
+ * shading 0).  sigma == NULL selects the colour-only evaluation of stage 1 (NeRFNetwork.rgb, nerf/renderer.py:875-881):
+ * h1 and the sigma_net weights are then not read. */
 int n2m_field_forward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
                       const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
                       const float* w_spec0, const float* w_spec1, uint32_t M, int shading, float* sigma, float* rgb,
@@ -46,7 +47,8 @@ int n2m_field_forward(const float* xyz, const float* dirs, const float* h1, cons
  *   d_h1 [16, M] f32      LEVEL-major, the layout n2m_grid_encode_backward consumes for the C=1 encoder
  *   d_h2 [16, M, 2] f16   LEVEL-major for the C=2 encoder (fp16 like autocast's grad of an fp16 tensor)
  *   d_w_* : fp32, same shapes as the weights, ACCUMULATED into (caller zero-fills or keeps running sums)
- * grad_scale multiplies nothing here; pass already-scaled upstream gradients (GradScaler) as they are. */
+ * d_sigma == NULL (colour only) or d_rgb == NULL (density only) skip the corresponding branch and its outputs.
+ * Pass already-scaled upstream gradients (GradScaler) as they are. */
 int n2m_field_backward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
                        const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
                        const float* w_spec0, const float* w_spec1, uint32_t M, int shading, const float* d_sigma,

@@ -154,11 +154,13 @@ __device__ __forceinline__ void load_color_inputs(const FieldArgs& a, uint32_t s
 }
 
 // ================================================================================================== forward
-template <bool DO_COLOR>
+template <bool DO_DENSITY, bool DO_COLOR>
 __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-    stage_w(lds + O_S0, P_S0, a.w[0], 32, 19, 32, 24, PERM_SIGMA0);
-    stage_w(lds + O_S1, P_S1, a.w[1], 1, 32, 32, 32, PERM_PLAIN);
+    if (DO_DENSITY) {
+        stage_w(lds + O_S0, P_S0, a.w[0], 32, 19, 32, 24, PERM_SIGMA0);
+        stage_w(lds + O_S1, P_S1, a.w[1], 1, 32, 32, 32, PERM_PLAIN);
+    }
     if (DO_COLOR) {
         stage_w(lds + O_C0, P_C0, a.w[2], 64, 35, 64, 40, PERM_COLOR0);
         stage_w(lds + O_C1, P_C1, a.w[3], 64, 64, 64, 64, PERM_PLAIN);
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t s = tile * 32 + n;
         const bool valid = s < a.M;
-        {   // ---- density: [h1 | xyz] -> 32 -> 1 -> exp
+        if (DO_DENSITY) {   // ---- density: [h1 | xyz] -> 32 -> 1 -> exp
             h4 b0[3];
             load_density_inputs(a, s, valid, g, b0);
             f16x d = zero16();
@@ -293,13 +295,15 @@ __device__ void dw_flush(float* __restrict__ dW, const float* stage, int in_pad,
     }
 }
 
-template <bool DO_COLOR>
+template <bool DO_DENSITY, bool DO_COLOR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) field_backward_kernel(FieldArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-    stage_w(lds + O_S0, P_S0, a.w[0], 32, 19, 32, 24, PERM_SIGMA0);
-    stage_w(lds + O_S1, P_S1, a.w[1], 1, 32, 32, 32, PERM_PLAIN);
-    stage_wt(lds + O_S1T, P_S1T, a.w[1], 1, 32, 32, 8, PERM_PLAIN);
-    stage_wt(lds + O_S0T, P_S0T, a.w[0], 32, 19, 32, 32, PERM_SIGMA0);
+    if (DO_DENSITY) {
+        stage_w(lds + O_S0, P_S0, a.w[0], 32, 19, 32, 24, PERM_SIGMA0);
+        stage_w(lds + O_S1, P_S1, a.w[1], 1, 32, 32, 32, PERM_PLAIN);
+        stage_wt(lds + O_S1T, P_S1T, a.w[1], 1, 32, 32, 8, PERM_PLAIN);
+        stage_wt(lds + O_S0T, P_S0T, a.w[0], 32, 19, 32, 32, PERM_SIGMA0);
+    }
     if (DO_COLOR) {
         stage_w(lds + O_C0, P_C0, a.w[2], 64, 35, 64, 40, PERM_COLOR0);
         stage_w(lds + O_C1, P_C1, a.w[3], 64, 64, 64, 64, PERM_PLAIN);
@@ -334,7 +338,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t s = tile * 32 + n;
         const bool valid = s < a.M;
-        {   // ------------------------------------------------------------------------------------------ density net
+        if (DO_DENSITY) {   // --------------------------------------------------------------------------- density net
             h4 b0[3];
             load_density_inputs(a, s, valid, g, b0);
             f16x d = zero16();
@@ -518,8 +522,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         dw_flush(dW, stage, in_pad, out, in, k_real, perm);
         __syncthreads();
     };
-    reduce(gS1, 32, 32, a.dw[1], 1, 32, 32, PERM_PLAIN);
-    reduce(gS0, 32, 32, a.dw[0], 32, 19, 19, PERM_SIGMA0);
+    if (DO_DENSITY) {
+        reduce(gS1, 32, 32, a.dw[1], 1, 32, 32, PERM_PLAIN);
+        reduce(gS0, 32, 32, a.dw[0], 32, 19, 19, PERM_SIGMA0);
+    }
     if (DO_COLOR) {
         reduce(gC2, 32, 64, a.dw[4], 6, 64, 64, PERM_PLAIN);
         reduce(gC1, 64, 64, a.dw[3], 64, 64, 64, PERM_PLAIN);
@@ -531,11 +537,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
-int check_field(const char* fn, const float* xyz, const float* h1, const float* const* w, uint32_t M, int shading) {
+int check_field(const char* fn, const float* xyz, const float* h1, const float* const* w, bool density, int shading) {
     N2M_REQUIRE(shading >= 0 && shading <= 2, N2M_EINVAL, "%s: shading must be 0 (diffuse), 1 (full) or 2 (specular)", fn);
-    N2M_REQUIRE(xyz && h1, N2M_ENULL, "%s: xyz / h1 is NULL", fn);
-    N2M_REQUIRE(w[0] && w[1], N2M_ENULL, "%s: sigma_net weights are NULL", fn);
-    (void)M;
+    N2M_REQUIRE(xyz, N2M_ENULL, "%s: xyz is NULL", fn);
+    if (density) N2M_REQUIRE(h1 && w[0] && w[1], N2M_ENULL, "%s: density branch needs h1 and sigma_net weights", fn);
     return 0;
 }
 
@@ -552,9 +557,10 @@ extern "C" int n2m_field_forward(const float* xyz, const float* dirs, const floa
                                  const float* w_spec0, const float* w_spec1, uint32_t M, int shading, float* sigma, float* rgb,
                                  float* specular, void* stream) {
     const float* w[7] = {w_sigma0, w_sigma1, w_color0, w_color1, w_color2, w_spec0, w_spec1};
-    if (int rc = check_field("field_forward", xyz, h1, w, M, shading)) return rc;
-    N2M_NOTNULL(sigma);
+    const bool density = sigma != nullptr;
+    if (int rc = check_field("field_forward", xyz, h1, w, density, shading)) return rc;
     const bool color = rgb != nullptr;
+    N2M_REQUIRE(density || color, N2M_ENULL, "field_forward: both sigma and rgb are NULL");
     if (color) {
         N2M_REQUIRE(h2 && w[2] && w[3] && w[4], N2M_ENULL, "field_forward: colour branch needs h2 and color_net weights");
         if (shading != 0) N2M_REQUIRE(dirs && w[5] && w[6], N2M_ENULL, "field_forward: shading != 0 needs dirs and specular_net weights");
@@ -567,8 +573,9 @@ extern "C" int n2m_field_forward(const float* xyz, const float* dirs, const floa
     hipStream_t s = (hipStream_t)stream;
     N2M_PROF(N2M_K_MLP_FWD, s, (double)M * (12 + 64 + 4 + (color ? 64 + 12 + 12 + 12 : 0)));
     const size_t smem = (size_t)FWD_HALVES * 2;
-    if (color) field_forward_kernel<true><<<persistent_grid(M) * 2, 256, smem, s>>>(a);
-    else field_forward_kernel<false><<<persistent_grid(M) * 2, 256, smem, s>>>(a);
+    if (color && density) field_forward_kernel<true, true><<<persistent_grid(M) * 2, 256, smem, s>>>(a);
+    else if (color) field_forward_kernel<false, true><<<persistent_grid(M) * 2, 256, smem, s>>>(a);
+    else field_forward_kernel<true, false><<<persistent_grid(M) * 2, 256, smem, s>>>(a);
     N2M_CHECK_LAUNCH();
     return 0;
 }
@@ -581,9 +588,11 @@ extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const flo
                                   float* d_w_spec1, void* stream) {
     const float* w[7] = {w_sigma0, w_sigma1, w_color0, w_color1, w_color2, w_spec0, w_spec1};
     float* dw[7] = {d_w_sigma0, d_w_sigma1, d_w_color0, d_w_color1, d_w_color2, d_w_spec0, d_w_spec1};
-    if (int rc = check_field("field_backward", xyz, h1, w, M, shading)) return rc;
-    N2M_REQUIRE(d_sigma && d_h1 && dw[0] && dw[1], N2M_ENULL, "field_backward: density gradients are NULL");
+    const bool density = d_sigma != nullptr;
+    if (int rc = check_field("field_backward", xyz, h1, w, density, shading)) return rc;
+    if (density) N2M_REQUIRE(d_h1 && dw[0] && dw[1], N2M_ENULL, "field_backward: density gradients are NULL");
     const bool color = d_rgb != nullptr;
+    N2M_REQUIRE(density || color, N2M_ENULL, "field_backward: both d_sigma and d_rgb are NULL");
     if (color) {
         N2M_REQUIRE(h2 && d_h2 && w[2] && w[3] && w[4] && dw[2] && dw[3] && dw[4], N2M_ENULL, "field_backward: colour branch tensors are NULL");
         if (shading != 0) N2M_REQUIRE(dirs && w[5] && w[6] && dw[5] && dw[6], N2M_ENULL, "field_backward: specular branch tensors are NULL");
@@ -591,8 +600,9 @@ extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const flo
     if (M == 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)field_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_HALVES * 2);
-        (void)hipFuncSetAttribute((const void*)field_backward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_HALVES * 2);
+        (void)hipFuncSetAttribute((const void*)field_backward_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_HALVES * 2);
+        (void)hipFuncSetAttribute((const void*)field_backward_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_HALVES * 2);
+        (void)hipFuncSetAttribute((const void*)field_backward_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_HALVES * 2);
         attr_set = true;
     }
     FieldArgs a{};
@@ -603,8 +613,9 @@ extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const flo
     hipStream_t s = (hipStream_t)stream;
     N2M_PROF(N2M_K_MLP_BWD, s, (double)M * (12 + 64 + 4 + 64 + (color ? 64 + 12 + 24 + 64 : 0)));
     const size_t smem = (size_t)BWD_HALVES * 2;
-    if (color) field_backward_kernel<true><<<persistent_grid(M), 256, smem, s>>>(a);
-    else field_backward_kernel<false><<<persistent_grid(M), 256, smem, s>>>(a);
+    if (color && density) field_backward_kernel<true, true><<<persistent_grid(M), 256, smem, s>>>(a);
+    else if (color) field_backward_kernel<false, true><<<persistent_grid(M), 256, smem, s>>>(a);
+    else field_backward_kernel<true, false><<<persistent_grid(M), 256, smem, s>>>(a);
     N2M_CHECK_LAUNCH();
     return 0;
 }

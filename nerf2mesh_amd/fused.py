@@ -42,15 +42,19 @@ def _encode_backward_lm(grad_lm, x01, emb, enc, max_level):
 
 class _fused_field(Function):
     @staticmethod
-    def forward(ctx, xyz, dirs, emb1, emb2, w0, w1, w2, w3, w4, w5, w6, net, shading, want_color):
+    def forward(ctx, xyz, dirs, emb1, emb2, w0, w1, w2, w3, w4, w5, w6, net, shading, want_color, want_density):
         _bind()
         xyz = xyz.float().contiguous()
         M = xyz.shape[0]
         bound, max_level = float(net.bound), int(min(net.max_level, net.encoder.num_levels))
         x01 = (xyz + bound) / (2 * bound)
-        emb1 = emb1.float().contiguous()
-        h1 = _encode_bm(x01, emb1, net.encoder, max_level)
-        sigma = torch.empty(M, dtype=torch.float32, device=xyz.device)
+        sigma = h1 = None
+        if want_density:
+            emb1 = emb1.float().contiguous()
+            h1 = _encode_bm(x01, emb1, net.encoder, max_level)
+            sigma = torch.empty(M, dtype=torch.float32, device=xyz.device)
+        else:
+            emb1 = None
         rgb = spec = h2 = emb2h = None
         ws = [w.float().contiguous() for w in (w0, w1, w2, w3, w4, w5, w6)]
         if want_color:
@@ -61,22 +65,27 @@ class _fused_field(Function):
             spec = torch.empty(M, 3, dtype=torch.float32, device=xyz.device) if shading != 0 else None
         L.call("n2m_field_forward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, _p(sigma), _p(rgb), _p(spec),
                L.stream())
-        ctx.net, ctx.shading, ctx.want_color, ctx.max_level = net, shading, want_color, max_level
+        ctx.net, ctx.shading, ctx.want_color, ctx.max_level, ctx.want_density = net, shading, want_color, max_level, want_density
         ctx.save_for_backward(xyz, dirs, x01, h1, h2, emb1, emb2h, *ws)
         if not want_color:
             return sigma
-        if spec is None:
-            return sigma, rgb
-        return sigma, rgb, spec
+        outs = ([sigma] if want_density else []) + [rgb] + ([spec] if spec is not None else [])
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, d_sigma, d_rgb=None, d_spec=None):
+    def backward(ctx, *grads):
         xyz, dirs, x01, h1, h2, emb1, emb2h, *ws = ctx.saved_tensors
-        net, shading, want_color, max_level = ctx.net, ctx.shading, ctx.want_color, ctx.max_level
+        net, shading, want_color, max_level, want_density = ctx.net, ctx.shading, ctx.want_color, ctx.max_level, ctx.want_density
+        grads = list(grads)
+        d_sigma = grads.pop(0) if want_density else None
+        d_rgb = grads.pop(0) if want_color else None
+        d_spec = grads.pop(0) if grads else None
         M = xyz.shape[0]
         dev = xyz.device
-        d_sigma = torch.zeros(M, device=dev) if d_sigma is None else d_sigma.float().contiguous()
-        d_h1 = torch.zeros(16, M, dtype=torch.float32, device=dev) if max_level < 16 else torch.empty(16, M, dtype=torch.float32, device=dev)
+        d_h1 = None
+        if want_density:
+            d_sigma = torch.zeros(M, device=dev) if d_sigma is None else d_sigma.float().contiguous()
+            d_h1 = torch.zeros(16, M, dtype=torch.float32, device=dev) if max_level < 16 else torch.empty(16, M, dtype=torch.float32, device=dev)
         d_h2 = None
         if want_color:
             d_rgb = torch.zeros(M, 3, device=dev) if d_rgb is None else d_rgb.float().contiguous()
@@ -87,7 +96,7 @@ class _fused_field(Function):
         dws = [torch.zeros_like(w) for w in ws]
         L.call("n2m_field_backward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, _p(d_sigma), _p(d_rgb),
                _p(d_spec), _p(d_h1), _p(d_h2), *[_p(g) for g in dws], L.stream())
-        g1 = _encode_backward_lm(d_h1, x01, emb1, net.encoder, max_level)
+        g1 = _encode_backward_lm(d_h1, x01, emb1, net.encoder, max_level) if want_density else None
         g2 = None
         if want_color:
             g2 = _encode_backward_lm(d_h2, x01, emb2h, net.encoder_color, max_level).float()
@@ -95,7 +104,9 @@ class _fused_field(Function):
             dws[2:] = [None] * 5
         elif shading == 0:
             dws[5:] = [None] * 2
-        return (None, None, g1, g2, *dws, None, None, None)
+        if not want_density:
+            dws[:2] = [None] * 2
+        return (None, None, g1, g2, *dws, None, None, None, None)
 
 
 def fused_field(net, xyz, dirs, shading="full"):
@@ -103,7 +114,7 @@ def fused_field(net, xyz, dirs, shading="full"):
     sh = SHADING[shading]
     out = _fused_field.apply(xyz, dirs, net.encoder.embeddings, net.encoder_color.embeddings, net.sigma_net.net[0].weight,
                              net.sigma_net.net[1].weight, net.color_net.net[0].weight, net.color_net.net[1].weight,
-                             net.color_net.net[2].weight, net.specular_net.net[0].weight, net.specular_net.net[1].weight, net, sh, True)
+                             net.color_net.net[2].weight, net.specular_net.net[0].weight, net.specular_net.net[1].weight, net, sh, True, True)
     if sh == 0:
         return out[0], out[1], None
     return out
@@ -113,4 +124,13 @@ def fused_density(net, xyz):
     """sigma [M] only (occupancy refresh, nerf/renderer.py:1112-1113)."""
     return _fused_field.apply(xyz, None, net.encoder.embeddings, net.encoder_color.embeddings, net.sigma_net.net[0].weight,
                               net.sigma_net.net[1].weight, net.color_net.net[0].weight, net.color_net.net[1].weight,
-                              net.color_net.net[2].weight, net.specular_net.net[0].weight, net.specular_net.net[1].weight, net, 0, False)
+                              net.color_net.net[2].weight, net.specular_net.net[0].weight, net.specular_net.net[1].weight, net, 0, False, True)
+
+
+def fused_color(net, xyz, dirs, shading="full"):
+    """rgb [M,3], specular [M,3] | None -- NeRFNetwork.rgb without individual codes (stage 1: nerf/renderer.py:875-881)."""
+    sh = SHADING[shading]
+    out = _fused_field.apply(xyz, dirs, net.encoder.embeddings, net.encoder_color.embeddings, net.sigma_net.net[0].weight,
+                             net.sigma_net.net[1].weight, net.color_net.net[0].weight, net.color_net.net[1].weight,
+                             net.color_net.net[2].weight, net.specular_net.net[0].weight, net.specular_net.net[1].weight, net, sh, True, False)
+    return (out[0], None) if sh == 0 else (out[0], out[1])

@@ -113,6 +113,9 @@ class NeRFNetwork(NeRFRenderer):
         return torch.sigmoid(self.color_net(h))
 
     def rgb(self, x, d, c=None, shading="full"):
+        if self._can_fuse(c) and not x.requires_grad:
+            from .fused import fused_color
+            return fused_color(self, x.reshape(-1, 3), d.reshape(-1, 3), shading)
         geo_feat = self.geo_feat(x, c)
         diffuse = geo_feat[..., :3]
         if shading == "diffuse":

@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import raymarching
+from . import raster as dr
 
 
 def safe_normalize(x, eps=1e-20):
@@ -206,3 +207,96 @@ class NeRFRenderer(nn.Module):
                 seen = (z > near) & (cam[:, :, 0].abs() < cx / fx * z + hgs * 2) & (cam[:, :, 1].abs() < cy / fy * z + hgs * 2)
                 mask_cam[cas] += seen.any(0)
         self.density_grid[(mask_cam == 0) | (mask_aabb == 0)] = -1
+
+
+    # ------------------------------------------------------------------------------------------ stage 1
+    def init_stage1(self, vertices, triangles, v_cumsum=None):
+        """Attach the stage-0 mesh (what NeRFRenderer.__init__ loads from mesh_stage0/*.ply, nerf/renderer.py:123-165):
+        vertices [V,3] f32, triangles [F,3] int32, learnable per-vertex offsets, per-face error accumulators."""
+        dev = self.density_bitfield.device
+        self.glctx = dr.RasterizeGLContext(output_db=False)
+        self.vertices = vertices.float().to(dev).contiguous()
+        self.triangles = triangles.int().to(dev).contiguous()
+        self.v_cumsum = v_cumsum if v_cumsum is not None else [0, self.vertices.shape[0]]
+        self.vertices_offsets = nn.Parameter(torch.zeros_like(self.vertices))
+        self.triangles_errors = torch.zeros(self.triangles.shape[0], dtype=torch.float32, device=dev)
+        self.triangles_errors_cnt = torch.zeros(self.triangles.shape[0], dtype=torch.float32, device=dev)
+        self.triangles_errors_id = None
+
+    def render_stage1(self, rays_o, rays_d, mvp, h0, w0, index=None, bg_color=None, shading="full", **kwargs):
+        """Rasterise the mesh, shade covered pixels with the colour networks, antialias (nerf/renderer.py:816-921)."""
+        prefix = rays_d.shape[:-1]
+        rays_d = rays_d.contiguous().view(-1, 3)
+        device = rays_d.device
+        ssaa = int(self.opt.ssaa)
+        if ssaa > 1:
+            h, w = int(h0 * ssaa), int(w0 * ssaa)
+            dirs = F.interpolate(rays_d.view(1, h0, w0, 3).permute(0, 3, 1, 2), (h, w), mode="nearest").permute(0, 2, 3, 1).reshape(-1, 3).contiguous()
+        else:
+            h, w = h0, w0
+            dirs = rays_d
+        dirs = safe_normalize(dirs)
+        if bg_color is None:
+            bg_color = 1
+        if torch.is_tensor(bg_color) and bg_color.dim() == 2:
+            bg_color = bg_color.view(h0, w0, 3)
+
+        vertices = self.vertices + self.vertices_offsets
+        vertices_clip = torch.matmul(F.pad(vertices, pad=(0, 1), mode="constant", value=1.0), torch.transpose(mvp, 0, 1)).float().unsqueeze(0)
+        rast, _ = dr.rasterize(self.glctx, vertices_clip, self.triangles, (h, w))
+        xyzs, _ = dr.interpolate(vertices.unsqueeze(0), rast, self.triangles)
+        mask, _ = dr.interpolate(torch.ones_like(vertices[:, :1]).unsqueeze(0), rast, self.triangles)
+        mask_flatten = (mask > 0).view(-1).detach()
+        xyzs = xyzs.view(-1, 3)
+        if self.opt.contract:
+            xyzs = contract(xyzs)
+        rgbs = torch.zeros(h * w, 3, device=device, dtype=torch.float32)
+        idx = torch.nonzero(mask_flatten, as_tuple=False).squeeze(1)
+        if idx.numel() > 0:
+            pts = xyzs[idx] if self.opt.enable_offset_nerf_grad else xyzs[idx].detach()
+            with torch.autocast(device_type="cuda", dtype=torch.float16, enabled=bool(self.opt.fp16)):
+                mask_rgbs, _ = self.rgb(pts, dirs[idx], None, shading)
+            rgbs = rgbs.index_copy(0, idx, mask_rgbs.float())
+        rgbs = rgbs.view(1, h, w, 3)
+        alphas = mask.float()
+        boost = self.opt.pos_gradient_boost
+        alphas = dr.antialias(alphas, rast, vertices_clip, self.triangles, pos_gradient_boost=boost).squeeze(0).clamp(0, 1)
+        rgbs = dr.antialias(rgbs, rast, vertices_clip, self.triangles, pos_gradient_boost=boost).squeeze(0).clamp(0, 1)
+        image = alphas * rgbs
+        depth = alphas * rast[0, :, :, [2]]
+        T = 1 - alphas
+        trig_id = rast[0, :, :, -1] - 1
+        if ssaa > 1:
+            def down(x):   # bilinear minification like scale_img_hwc (nerf/renderer.py:46-65)
+                return F.interpolate(x.permute(2, 0, 1).unsqueeze(0), (h0, w0), mode="bilinear").squeeze(0).permute(1, 2, 0).contiguous()
+            image, depth, T = down(image), down(depth), down(T)
+            trig_id = F.interpolate(trig_id.view(1, 1, h, w), (h0, w0), mode="nearest").view(h0, w0)
+        self.triangles_errors_id = trig_id
+        image = image + T * bg_color
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": (1 - T).view(*prefix)}
+
+    @torch.no_grad()
+    def update_triangles_errors(self, loss):
+        """Accumulates the per-pixel loss on the triangle visible at each pixel (nerf/renderer.py:924-943)."""
+        indices = self.triangles_errors_id.view(-1).long()
+        keep = indices >= 0
+        indices = indices[keep].contiguous()
+        values = loss.view(-1)[keep].contiguous()
+        self.triangles_errors.scatter_add_(0, indices, values)
+        self.triangles_errors_cnt.scatter_add_(0, indices, torch.ones_like(values))
+        self.triangles_errors_id = None
+
+    @torch.no_grad()
+    def mark_unseen_triangles(self, vertices, triangles, mvps, H, W):
+        """Faces not hit by any training camera (nerf/renderer.py:947-981)."""
+        dev = self.density_bitfield.device
+        vertices = torch.as_tensor(vertices).float().to(dev).contiguous()
+        triangles = torch.as_tensor(triangles).int().to(dev).contiguous()
+        seen = torch.zeros(triangles.shape[0], dtype=torch.bool, device=dev)
+        ctx = self.glctx or dr.RasterizeGLContext(output_db=False)
+        for mvp in mvps:
+            clip = torch.matmul(F.pad(vertices, pad=(0, 1), mode="constant", value=1.0), torch.transpose(mvp.to(dev), 0, 1)).float().unsqueeze(0)
+            rast, _ = dr.rasterize(ctx, clip, triangles, (H, W))
+            ids = rast[..., -1].long().view(-1) - 1
+            seen[ids[ids >= 0]] = True
+        return ~seen

@@ -134,3 +134,72 @@ class Stage0Trainer:
                                 max_steps=self.opt.max_steps, T_thresh=1e-4)
         mse = F.mse_loss(out["image"], gt)
         return float(-10 * torch.log10(mse))
+
+
+def laplacian_smooth_loss(verts, faces):
+    """Uniform-Laplacian smoothness of the mesh (nerf/utils.py:176-221): || L v ||^2 with L = D - A, row-normalised."""
+    V = verts.shape[0]
+    f = faces.long()
+    ii = torch.cat([f[:, 0], f[:, 1], f[:, 1], f[:, 2], f[:, 2], f[:, 0]])
+    jj = torch.cat([f[:, 1], f[:, 0], f[:, 2], f[:, 1], f[:, 0], f[:, 2]])
+    key = torch.unique(ii * V + jj)
+    ii, jj = key // V, key % V
+    deg = torch.zeros(V, device=verts.device).index_add_(0, ii, torch.ones_like(ii, dtype=torch.float32))
+    nb = torch.zeros_like(verts).index_add_(0, ii, verts[jj])
+    lap = nb / deg.clamp(min=1).unsqueeze(1) - verts
+    return (lap ** 2).sum(-1).mean()
+
+
+class Stage1Trainer:
+    """Stage-1 iteration of the reference (nerf/utils.py:708-721,745-789; one full view per step, nerf/provider.py:298-306):
+    rasterise at ssaa x resolution, shade covered pixels with the colour networks, antialias, downscale, MSE (+ mask,
+    + Laplacian smoothness, + offset L2), Adam on colour networks + vertex offsets."""
+
+    def __init__(self, model, opt, poses, vertices, triangles, device, H=synthetic.LEGO_HW, W=synthetic.LEGO_HW, rank=0, world_size=1, seed=0):
+        self.model, self.opt, self.device = model.to(device), opt, device
+        self.H, self.W = H, W
+        self.poses = poses.to(device)
+        self.views = list(range(rank, poses.shape[0], world_size))            # views shard across ranks
+        self.mvps = torch.stack([synthetic.mvp_matrix(p, H, W) for p in self.poses])
+        model.init_stage1(vertices, triangles)
+        params = model.get_params(opt.lr) + [{"params": model.vertices_offsets, "lr": opt.lr_vert, "weight_decay": 0}]
+        self.optimizer = torch.optim.Adam(params, eps=1e-15)
+        self.scaler = torch.amp.GradScaler("cuda", enabled=bool(opt.fp16))
+        self.sync = GradSync(model, world_size) if world_size > 1 else None
+        self.boxes = synthetic.boxes(device)
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(seed + rank)
+        self.global_step = 0
+        jj, ii = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
+        self.pix = (jj * W + ii).reshape(-1)
+        self.covered_seen = 0
+
+    def train_step(self):
+        opt, model = self.opt, self.model
+        model.train()
+        v = self.views[self.global_step % len(self.views)]
+        self.global_step += 1
+        rays_o, rays_d = synthetic.rays_from_pixels(self.poses, torch.full_like(self.pix, v), self.pix, self.H, self.W)
+        rgba = synthetic.render_gt(rays_o, rays_d, self.boxes)
+        bg = torch.rand(self.H * self.W, 3, device=self.device, generator=self.gen)
+        gt_mask = rgba[:, 3:]
+        gt_rgb = rgba[:, :3] * gt_mask + bg * (1 - gt_mask)
+        self.optimizer.zero_grad(set_to_none=False)
+        out = model.render_stage1(rays_o, rays_d, self.mvps[v], self.H, self.W, bg_color=bg, shading="full")
+        loss = opt.lambda_rgb * F.mse_loss(out["image"], gt_rgb, reduction="none").mean(-1)
+        if opt.lambda_mask > 0:
+            loss = loss + opt.lambda_mask * F.mse_loss(out["weights_sum"].view(-1), gt_mask.view(-1), reduction="none")
+        if opt.refine:
+            model.update_triangles_errors(loss.detach())
+        loss = loss.mean()
+        if opt.lambda_lap > 0:
+            loss = loss + opt.lambda_lap * laplacian_smooth_loss(model.vertices + model.vertices_offsets, model.triangles)
+        if opt.lambda_offsets > 0:
+            loss = loss + opt.lambda_offsets * (model.vertices_offsets ** 2).sum(-1).mean()
+        self.scaler.scale(loss).backward()
+        if self.sync is not None:
+            self.sync.all_reduce()
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+        self.covered_seen += int((out["weights_sum"] > 0).sum()) if (self.global_step % 16 == 0) else 0
+        return loss
