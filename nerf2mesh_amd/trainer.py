@@ -136,18 +136,27 @@ class Stage0Trainer:
         return float(-10 * torch.log10(mse))
 
 
+class UniformLaplacian:
+    """Uniform-Laplacian smoothness of the mesh (nerf/utils.py:176-221): mean || mean_nb(v) - v ||^2.  The unique
+    directed edge list depends on the topology only, so it is built once per mesh (the reference rebuilds its sparse
+    matrix every step) and the loss is two index_add passes."""
+
+    def __init__(self, faces, n_verts):
+        f = faces.long()
+        ii = torch.cat([f[:, 0], f[:, 1], f[:, 1], f[:, 2], f[:, 2], f[:, 0]])
+        jj = torch.cat([f[:, 1], f[:, 0], f[:, 2], f[:, 1], f[:, 0], f[:, 2]])
+        key = torch.unique(ii * n_verts + jj)
+        self.ii, self.jj = key // n_verts, key % n_verts
+        deg = torch.zeros(n_verts, device=faces.device).index_add_(0, self.ii, torch.ones_like(self.ii, dtype=torch.float32))
+        self.inv_deg = (1.0 / deg.clamp(min=1)).unsqueeze(1)
+
+    def __call__(self, verts):
+        nb = torch.zeros_like(verts).index_add_(0, self.ii, verts[self.jj])
+        return ((nb * self.inv_deg - verts) ** 2).sum(-1).mean()
+
+
 def laplacian_smooth_loss(verts, faces):
-    """Uniform-Laplacian smoothness of the mesh (nerf/utils.py:176-221): || L v ||^2 with L = D - A, row-normalised."""
-    V = verts.shape[0]
-    f = faces.long()
-    ii = torch.cat([f[:, 0], f[:, 1], f[:, 1], f[:, 2], f[:, 2], f[:, 0]])
-    jj = torch.cat([f[:, 1], f[:, 0], f[:, 2], f[:, 1], f[:, 0], f[:, 2]])
-    key = torch.unique(ii * V + jj)
-    ii, jj = key // V, key % V
-    deg = torch.zeros(V, device=verts.device).index_add_(0, ii, torch.ones_like(ii, dtype=torch.float32))
-    nb = torch.zeros_like(verts).index_add_(0, ii, verts[jj])
-    lap = nb / deg.clamp(min=1).unsqueeze(1) - verts
-    return (lap ** 2).sum(-1).mean()
+    return UniformLaplacian(faces, verts.shape[0])(verts)
 
 
 class Stage1Trainer:
@@ -172,6 +181,8 @@ class Stage1Trainer:
         self.global_step = 0
         jj, ii = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
         self.pix = (jj * W + ii).reshape(-1)
+        self.laplacian = UniformLaplacian(model.triangles, model.vertices.shape[0])
+        self.view_cache = {}          # per view: rays + ground-truth RGBA, resident in HBM like the reference's --preload
         self.covered_seen = 0
 
     def train_step(self):
@@ -179,8 +190,10 @@ class Stage1Trainer:
         model.train()
         v = self.views[self.global_step % len(self.views)]
         self.global_step += 1
-        rays_o, rays_d = synthetic.rays_from_pixels(self.poses, torch.full_like(self.pix, v), self.pix, self.H, self.W)
-        rgba = synthetic.render_gt(rays_o, rays_d, self.boxes)
+        if v not in self.view_cache:
+            rays_o, rays_d = synthetic.rays_from_pixels(self.poses, torch.full_like(self.pix, v), self.pix, self.H, self.W)
+            self.view_cache[v] = (rays_o, rays_d, synthetic.render_gt(rays_o, rays_d, self.boxes))
+        rays_o, rays_d, rgba = self.view_cache[v]
         bg = torch.rand(self.H * self.W, 3, device=self.device, generator=self.gen)
         gt_mask = rgba[:, 3:]
         gt_rgb = rgba[:, :3] * gt_mask + bg * (1 - gt_mask)
@@ -193,7 +206,7 @@ class Stage1Trainer:
             model.update_triangles_errors(loss.detach())
         loss = loss.mean()
         if opt.lambda_lap > 0:
-            loss = loss + opt.lambda_lap * laplacian_smooth_loss(model.vertices + model.vertices_offsets, model.triangles)
+            loss = loss + opt.lambda_lap * self.laplacian(model.vertices + model.vertices_offsets)
         if opt.lambda_offsets > 0:
             loss = loss + opt.lambda_offsets * (model.vertices_offsets ** 2).sum(-1).mean()
         self.scaler.scale(loss).backward()
@@ -201,5 +214,4 @@ class Stage1Trainer:
             self.sync.all_reduce()
         self.scaler.step(self.optimizer)
         self.scaler.update()
-        self.covered_seen += int((out["weights_sum"] > 0).sum()) if (self.global_step % 16 == 0) else 0
         return loss
