@@ -31,7 +31,8 @@ extern "C" {
 #endif
 
 /* Forward.  xyz [M,3] f32 (grid-bound coordinates, as fed to the encoders), dirs [M,3] f32 (normalised; may be NULL
- * when shading == 0), h1 [M,16] f32 (density features, sample-major), h2 [M,32] f16 (colour features; may be NULL
+ * when shading == 0), h1 [16,M] f32 (density features, LEVEL-major as n2m_grid_encode_forward writes them), h2 [16,M,2] f16
+ * (colour features, level-major; may be NULL
  * when rgb == NULL: density-only evaluation as in update_extra_state).
  * Outputs: sigma [M] f32; rgb [M,3] f32 and specular [M,3] f32 (either may be NULL; specular is not written for
  * shading 0).  sigma == NULL selects the colour-only evaluation of stage 1 (NeRFNetwork.rgb, nerf/renderer.py:875-881):

@@ -272,6 +272,136 @@ grid_forward_kernel(const float* __restrict__ inputs, const T* __restrict__ tabl
     }
 }
 
+// ---------------------------------------------------------------------------------- forward, D = 3 fast path
+// The generic kernel above issues 8 scattered row reads per (sample, level).  Measured (tools/grid_bench.py): on
+// coherent samples it already runs at ~0.9 lane-requests/clk/CU, i.e. at the vector-memory request rate of a CU
+// (one scattered lane per clock), so the only lever left is FEWER REQUESTS:
+//   * the two corners that differ in x are neighbours in memory -- always for a dense level (row = x + y*s1 + z*s2),
+//     and for a hashed level whenever x is even (x*1 ^ h differs from (x+1)*1 ^ h in bit 0 only).  One 8-byte access
+//     (2 rows of C=1 fp32 or C=2 fp16; only dword alignment is required) fetches both: 4 requests instead of 8 for dense
+//     levels, 6 on average for hashed ones;
+//   * (experiment, N2M_GRID_FWD_XCD=1) XCD-aware level mapping: blocks numbered so that XCD k (= block id % 8, the observed
+//     dispatch pattern) works on levels k and 15-k, so that each XCD's 4 MiB L2 holds exactly two 2 MiB level tables.
+//     MEASURED SLOWER (2^21 coherent samples: 492 us vs 325 us level-major): the per-XCD work is unbalanced (hashed vs dense
+//     levels) and a level's table is then served by ONE L2 instead of eight.  Kept off.
+// Arithmetic is unchanged (same weights, same accumulation order over the 8 corners), so results stay bit-identical.
+template <typename T, uint32_t C>
+struct RowPair { Row<T, C> lo, hi; };
+
+template <typename T, uint32_t C>
+__device__ __forceinline__ RowPair<T, C> load_pair(const T* p) {   // rows r and r+1, contiguous
+    RowPair<T, C> r;
+    if constexpr (sizeof(T) * C == 4) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        *reinterpret_cast<uint32_t*>(&r.lo) = v.x; *reinterpret_cast<uint32_t*>(&r.hi) = v.y;
+    } else if constexpr (sizeof(T) * C == 8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        uint2 a = make_uint2(v.x, v.y), b = make_uint2(v.z, v.w);
+        *reinterpret_cast<uint2*>(&r.lo) = a; *reinterpret_cast<uint2*>(&r.hi) = b;
+    } else {
+        r.lo = Row<T, C>::load(p); r.hi = Row<T, C>::load(p + C);
+    }
+    return r;
+}
+
+template <typename T, uint32_t C, bool SAMPLE_MAJOR>
+__global__ void __launch_bounds__(256)
+grid_forward3_kernel(const float* __restrict__ inputs, const T* __restrict__ table, const int32_t* __restrict__ offsets,
+                     T* __restrict__ outputs, uint32_t B, uint32_t L, uint32_t max_level, LevelTable lv, uint32_t gridtype,
+                     bool align_corners, uint32_t interp, uint32_t n_tiles, bool xcd_map) {
+    constexpr uint32_t D = 3;
+    // block -> (tile, level): XCD k gets levels k, 15-k, 16+k, ... (boustrophedon so cheap coarse and expensive fine levels pair up)
+    uint32_t level, tile;
+    if (xcd_map) {
+        const uint32_t lin = blockIdx.x, xcd = lin & 7u, j = lin >> 3;
+        const uint32_t slots = (max_level + 7u) >> 3;
+        const uint32_t slot = j % slots;
+        tile = j / slots;
+        level = (slot & 1u) ? 8u * (slot + 1u) - 1u - xcd : 8u * slot + xcd;
+    } else {   // level-major block order of the generic kernel
+        const uint32_t per_level = n_tiles;
+        level = blockIdx.x / per_level;
+        tile = blockIdx.x - level * per_level;
+    }
+    if (level >= max_level || tile >= n_tiles) return;
+    const uint32_t b = tile * 256 + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t row0 = (uint32_t)offsets[level];
+    const uint32_t size = (uint32_t)offsets[level + 1] - row0;
+    const float scale = lv.scale[level];
+    const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
+    const T* __restrict__ tab = table + (size_t)row0 * C;
+    T* out = SAMPLE_MAJOR ? outputs + ((size_t)b * L + level) * C : outputs + ((size_t)level * B + b) * C;
+
+    float x[D];
+    load_point<D>(inputs, b, x);
+    if (outside_unit_cube<D>(x)) {
+        Row<T, C> z;
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) z.v[c] = (T)0;
+        z.store(out);
+        return;
+    }
+    uint32_t cell[D];
+    float frac[D], dfrac[D];
+    locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
+
+    Row<T, C> g[8];
+    const bool dense = !ix.hashed && !ix.wrap;
+    if (dense) {
+        const uint32_t base = cell[0] + cell[1] * ix.stride[1] + cell[2] * ix.stride[2];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {          // q = (y bit, z bit); x pair in one access
+            const uint32_t r = base + ((q & 1u) ? ix.stride[1] : 0u) + ((q & 2u) ? ix.stride[2] : 0u);
+            const RowPair<T, C> pr = load_pair<T, C>(tab + (size_t)r * C);
+            g[2 * q] = pr.lo; g[2 * q + 1] = pr.hi;
+        }
+    } else if (ix.hashed && ix.pow2) {
+        const uint32_t hy0 = cell[1] * kPrimes[1], hy1 = hy0 + kPrimes[1], hz0 = cell[2] * kPrimes[2], hz1 = hz0 + kPrimes[2];
+        const bool x_even = (cell[0] & 1u) == 0u;
+        // 4 unconditional 8-byte reads of the ALIGNED row pair that holds corner x (rows r & ~1, r | 1); for even x the
+        // other row of the pair is corner x+1 ((x+1) ^ h == (x ^ h) ^ 1).  For odd x one extra read per (y,z) fetches x+1.
+        uint32_t rx[4], rx1[4];
+        RowPair<T, C> pr[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t h = ((q & 1u) ? hy1 : hy0) ^ ((q & 2u) ? hz1 : hz0);
+            rx[q] = (cell[0] ^ h) & ix.mask;
+            rx1[q] = ((cell[0] + 1u) ^ h) & ix.mask;
+            pr[q] = load_pair<T, C>(tab + (size_t)(rx[q] & ~1u) * C);
+        }
+        Row<T, C> extra[4];
+        if (!x_even) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) extra[q] = Row<T, C>::load(tab + (size_t)rx1[q] * C);
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const bool odd_row = (rx[q] & 1u) != 0u;
+            g[2 * q] = odd_row ? pr[q].hi : pr[q].lo;
+            g[2 * q + 1] = x_even ? (odd_row ? pr[q].lo : pr[q].hi) : extra[q];
+        }
+    } else {
+#pragma unroll
+        for (uint32_t corner = 0; corner < 8; ++corner) {
+            const uint32_t v[D] = {cell[0] + (corner & 1u), cell[1] + ((corner >> 1) & 1u), cell[2] + (corner >> 2)};
+            g[corner] = Row<T, C>::load(tab + (size_t)ix.row(v) * C);
+        }
+    }
+    Row<T, C> acc;
+#pragma unroll
+    for (uint32_t c = 0; c < C; ++c) acc.v[c] = (T)0;
+#pragma unroll
+    for (uint32_t corner = 0; corner < 8; ++corner) {   // corner bit 0 = x, bit 1 = y, bit 2 = z: the reference's order
+        float w = 1.0f;
+#pragma unroll
+        for (uint32_t d = 0; d < D; ++d) w *= (corner & (1u << d)) ? frac[d] : 1 - frac[d];
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) accum(acc.v[c], w, g[corner].v[c]);
+    }
+    acc.store(out);
+}
+
 // zero-fill of the levels >= max_level for the sample-major layout
 template <typename T>
 __global__ void zero_levels_kernel(T* __restrict__ outputs, uint32_t B, uint32_t LC, uint32_t first, uint32_t count) {
@@ -750,6 +880,18 @@ struct FwdArgs {
 
 template <typename T, uint32_t D, uint32_t C, bool BM>
 void launch_forward(const FwdArgs& a) {
+    static const bool generic_only = getenv("N2M_GRID_FWD_GENERIC") != nullptr;   // A/B switch
+    if constexpr (D == 3) {
+        if (!generic_only && a.dy_dx == nullptr) {
+            static const bool xcd_map = getenv("N2M_GRID_FWD_XCD") != nullptr;   // measured slower: off by default
+            const uint32_t n_tiles = n2m_ceil_div(a.B, 256);
+            const uint32_t slots = (a.max_level + 7u) / 8u;
+            const uint32_t nblk = xcd_map ? n_tiles * slots * 8u : n_tiles * a.max_level;
+            grid_forward3_kernel<T, C, BM><<<nblk, 256, 0, a.s>>>(a.inputs, (const T*)a.table, a.offsets, (T*)a.outputs, a.B, a.L,
+                                                                  a.max_level, a.lv, a.gridtype, a.align, a.interp, n_tiles, xcd_map);
+            return;
+        }
+    }
     const dim3 grid(n2m_ceil_div(a.B, 256), a.max_level);
     grid_forward_kernel<T, D, C, BM><<<grid, 256, 0, a.s>>>(a.inputs, (const T*)a.table, a.offsets, (T*)a.outputs, a.B, a.L, a.lv,
                                                             (T*)a.dy_dx, a.gridtype, a.align, a.interp);

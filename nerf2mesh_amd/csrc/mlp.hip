@@ -129,12 +129,17 @@ struct FieldArgs {
 };
 
 // ---------------------------------------------------------------------------------------------- input fragments
+// Encoder features arrive LEVEL-major (the layout grid_encode_forward writes fastest): h1 [16][M] fp32, h2 [16][M][2] fp16.
+// For a fixed feature the 32 samples of a tile are contiguous, so every access below is a coalesced 128-byte row.
 __device__ __forceinline__ void load_density_inputs(const FieldArgs& a, uint32_t s, bool valid, int g, h4 (&b)[3]) {
+    const size_t Mz = a.M;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) v = *reinterpret_cast<const float4*>(a.h1 + (size_t)s * 16 + 8 * kb + 4 * g);
-        b[kb][0] = (_Float16)v.x; b[kb][1] = (_Float16)v.y; b[kb][2] = (_Float16)v.z; b[kb][3] = (_Float16)v.w;
+        b[kb] = zero4();
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[kb][i] = (_Float16)a.h1[(size_t)(8 * kb + 4 * g + i) * Mz + s];
+        }
     }
     b[2] = zero4();
     if (valid && g == 0) {
@@ -142,10 +147,16 @@ __device__ __forceinline__ void load_density_inputs(const FieldArgs& a, uint32_t
     }
 }
 __device__ __forceinline__ void load_color_inputs(const FieldArgs& a, uint32_t s, bool valid, int g, h4 (&b)[5]) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    const size_t Mz = a.M;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         b[kb] = zero4();
-        if (valid) b[kb] = *reinterpret_cast<const h4*>(a.h2 + (size_t)s * 32 + 8 * kb + 4 * g);
+        if (valid) {   // features 8kb+4g .. +3 = levels 4kb+2g and 4kb+2g+1, two channels each
+            const h2v lo = *reinterpret_cast<const h2v*>(a.h2 + ((size_t)(4 * kb + 2 * g) * Mz + s) * 2);
+            const h2v hi = *reinterpret_cast<const h2v*>(a.h2 + ((size_t)(4 * kb + 2 * g + 1) * Mz + s) * 2);
+            b[kb][0] = lo.x; b[kb][1] = lo.y; b[kb][2] = hi.x; b[kb][3] = hi.y;
+        }
     }
     b[4] = zero4();
     if (valid && g == 0) {

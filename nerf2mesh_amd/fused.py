@@ -20,12 +20,13 @@ def _bind():
     L.lib()
 
 
-def _encode_bm(x01, emb, enc, max_level):
+def _encode_lm(x01, emb, enc, max_level):
+    """Level-major features [L, B, C] (the reference kernel's own layout): fastest to write, and what the fused MLP reads."""
     B = x01.shape[0]
     Lv, C = enc.num_levels, emb.shape[1]
-    out = torch.empty(B, Lv * C, device=x01.device, dtype=emb.dtype)
-    L.call("n2m_grid_encode_forward_bm", _p(x01), _p(emb), _p(enc.offsets), _p(out), B, 3, C, Lv, max_level,
-           float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), enc.interp_id,
+    out = torch.empty(Lv, B, C, device=x01.device, dtype=emb.dtype) if max_level >= Lv else torch.zeros(Lv, B, C, device=x01.device, dtype=emb.dtype)
+    L.call("n2m_grid_encode_forward", _p(x01), _p(emb), _p(enc.offsets), _p(out), B, 3, C, Lv, max_level,
+           float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None, enc.gridtype_id, int(bool(enc.align_corners)), enc.interp_id,
            L.F16 if emb.dtype == torch.float16 else L.F32, L.stream())
     return out
 
@@ -51,7 +52,7 @@ class _fused_field(Function):
         sigma = h1 = None
         if want_density:
             emb1 = emb1.float().contiguous()
-            h1 = _encode_bm(x01, emb1, net.encoder, max_level)
+            h1 = _encode_lm(x01, emb1, net.encoder, max_level)
             sigma = torch.empty(M, dtype=torch.float32, device=xyz.device)
         else:
             emb1 = None
@@ -59,7 +60,7 @@ class _fused_field(Function):
         ws = [w.float().contiguous() for w in (w0, w1, w2, w3, w4, w5, w6)]
         if want_color:
             emb2h = emb2.half().contiguous()               # autocast: C even -> fp16 table (gridencoder/grid.py:45)
-            h2 = _encode_bm(x01, emb2h, net.encoder_color, max_level)
+            h2 = _encode_lm(x01, emb2h, net.encoder_color, max_level)
             dirs = dirs.float().contiguous() if shading != 0 else None
             rgb = torch.empty(M, 3, dtype=torch.float32, device=xyz.device)
             spec = torch.empty(M, 3, dtype=torch.float32, device=xyz.device) if shading != 0 else None

@@ -208,3 +208,53 @@ def compact_alive(rays_alive):
     count = torch.zeros(1, dtype=torch.int32, device=rays_alive.device)
     L.call("n2m_compact_alive", _p(rays_alive), n, _p(out), _p(count), L.stream())
     return out[: int(count.item())]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Split form of march_rays_train for software pipelining.  Pass 1 (counting + offsets) depends on the rays and the
+# occupancy bit field only -- not on the network parameters -- so a training loop can issue it for batch i+1 while the
+# GPU is still busy with step i, and pick up the sample count without ever draining the queue: `march_rays_train_begin`
+# enqueues pass 1 and an asynchronous copy of the counter into pinned host memory; `march_rays_train_finish` waits for
+# that copy only (an event, normally long complete) and enqueues pass 2.  Results are identical to march_rays_train.
+class MarchTicket:
+    __slots__ = ("args", "rays", "counter", "noises", "host_count", "event", "keep")
+
+
+@torch.no_grad()
+def march_rays_train_begin(rays_o, rays_d, bound, contract, density_bitfield, C, H, nears, fars, perturb=False, dt_gamma=0,
+                           max_steps=1024, noises=None):
+    rays_o = _f32c(_dev(rays_o)).view(-1, 3)
+    rays_d = _f32c(_dev(rays_d)).view(-1, 3)
+    bits = _dev(density_bitfield).contiguous()
+    nears, fars = _f32c(nears), _f32c(fars)
+    dev = rays_o.device
+    N = rays_o.shape[0]
+    if noises is None:
+        noises = torch.rand(N, dtype=torch.float32, device=dev) if perturb else torch.zeros(N, dtype=torch.float32, device=dev)
+    t = MarchTicket()
+    t.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    t.rays = torch.empty(N, 2, dtype=torch.int32, device=dev)
+    t.noises = _f32c(noises)
+    t.keep = (rays_o, rays_d, bits, nears, fars)
+    t.args = (_p(rays_o), _p(rays_d), _p(bits), float(bound), int(bool(contract)), float(dt_gamma), int(max_steps), N, int(C), int(H),
+              _p(nears), _p(fars))
+    L.call("n2m_march_rays_train", *t.args, None, None, None, _p(t.rays), _p(t.counter), _p(t.noises), L.stream())
+    t.host_count = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    t.host_count.copy_(t.counter, non_blocking=True)
+    t.event = torch.cuda.Event()
+    t.event.record()
+    return t
+
+
+@torch.no_grad()
+def march_rays_train_finish(t):
+    t.event.synchronize()
+    M = int(t.host_count[0])
+    rays_o = t.keep[0]
+    dev = rays_o.device
+    xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    ts = torch.empty(M, 2, dtype=torch.float32, device=dev)
+    if M > 0:
+        L.call("n2m_march_rays_train", *t.args, _p(xyzs), _p(dirs), _p(ts), _p(t.rays), _p(t.counter), _p(t.noises), L.stream())
+    return xyzs, dirs, ts, t.rays

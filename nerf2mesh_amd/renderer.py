@@ -79,17 +79,31 @@ class NeRFRenderer(nn.Module):
         self.aabb_infer = self.aabb_train.clone()
 
     # ------------------------------------------------------------------------------------------ stage 0
+    @torch.no_grad()
+    def march_ahead(self, rays_o, rays_d, dt_gamma=0, perturb=True, max_steps=1024, cam_near_far=None):
+        """Enqueue near/far + march pass 1 for a FUTURE training batch (they read only the occupancy bit field) and return a
+        ticket for render(..., ticket=...).  Lets the training loop keep the GPU queue full across the sample-count read-back."""
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
+        if cam_near_far is not None:
+            nears = torch.maximum(nears, cam_near_far[:, 0])
+            fars = torch.minimum(fars, cam_near_far[:, 1])
+        return raymarching.march_rays_train_begin(rays_o, rays_d, self.real_bound, self.opt.contract, self.density_bitfield, self.cascade,
+                                                  self.grid_size, nears, fars, perturb, dt_gamma, max_steps)
+
     def render(self, rays_o, rays_d, index=None, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-4,
-               cam_near_far=None, shading="full", **kwargs):
+               cam_near_far=None, shading="full", ticket=None, **kwargs):
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         N, device = rays_o.shape[0], rays_o.device
 
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
-        if cam_near_far is not None:
-            nears = torch.maximum(nears, cam_near_far[:, 0])
-            fars = torch.minimum(fars, cam_near_far[:, 1])
+        if ticket is None:
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+            if cam_near_far is not None:
+                nears = torch.maximum(nears, cam_near_far[:, 0])
+                fars = torch.minimum(fars, cam_near_far[:, 1])
         if bg_color is None:
             bg_color = 1
         ind_code = None
@@ -99,8 +113,11 @@ class NeRFRenderer(nn.Module):
         amp = torch.autocast(device_type="cuda", dtype=torch.float16, enabled=bool(self.opt.fp16))
 
         if self.training:
-            xyzs, dirs, ts, rays = raymarching.march_rays_train(rays_o, rays_d, self.real_bound, self.opt.contract, self.density_bitfield,
-                                                                self.cascade, self.grid_size, nears, fars, perturb, dt_gamma, max_steps)
+            if ticket is not None:
+                xyzs, dirs, ts, rays = raymarching.march_rays_train_finish(ticket)
+            else:
+                xyzs, dirs, ts, rays = raymarching.march_rays_train(rays_o, rays_d, self.real_bound, self.opt.contract, self.density_bitfield,
+                                                                    self.cascade, self.grid_size, nears, fars, perturb, dt_gamma, max_steps)
             if ind_code is not None and ind_code.shape[0] > 1:
                 ind_code = ind_code[raymarching.flatten_rays(rays, xyzs.shape[0]).long()]
             dirs = safe_normalize(dirs)

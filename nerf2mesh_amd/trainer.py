@@ -33,6 +33,8 @@ class Stage0Trainer:
         self.samples_seen = 0
         self.rays_seen = 0
         self.last_num_points = 0
+        self.pipeline = True          # issue march pass 1 of the next batch one step ahead (results are identical)
+        self._next = None
 
     def mark_untrained(self):
         if self.opt.mark_untrained:
@@ -44,17 +46,26 @@ class Stage0Trainer:
         rgba = synthetic.render_gt(rays_o, rays_d, self.boxes)
         return rays_o, rays_d, rgba
 
-    def train_step(self):
+    def _prepare(self):
+        """Occupancy refresh (every 16th step, nerf/utils.py:1155-1156) + next batch + march pass 1 for it."""
         opt, model = self.opt, self.model
-        model.train()
-        if self.global_step % opt.update_extra_interval == 0:          # nerf/utils.py:1155-1156
+        if self.global_step % opt.update_extra_interval == 0:
             if self.sync is not None:
                 self.sync.sync_rng_for_grid_update(self.global_step)
             model.update_extra_state()
+        rays_o, rays_d, images = self.batch()
+        ticket = model.march_ahead(rays_o, rays_d, dt_gamma=opt.dt_gamma, perturb=True, max_steps=opt.max_steps) if self.pipeline else None
+        return rays_o, rays_d, images, ticket
+
+    def train_step(self):
+        opt, model = self.opt, self.model
+        model.train()
+        if self._next is None:
+            self._next = self._prepare()
+        rays_o, rays_d, images, ticket = self._next
+        self._next = None
         self.global_step += 1
         self.optimizer.zero_grad(set_to_none=False)
-
-        rays_o, rays_d, images = self.batch()
         N = rays_o.shape[0]
         bg_color = 1 if opt.background == "white" else torch.rand(N, 3, device=self.device, generator=self.gen)
         gt_mask = images[..., 3:]
@@ -67,7 +78,7 @@ class Stage0Trainer:
         shading = "diffuse" if (self.global_step < opt.diffuse_step or opt.diffuse_only) else "full"
 
         out = model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, shading=shading, dt_gamma=opt.dt_gamma,
-                           max_steps=opt.max_steps)
+                           max_steps=opt.max_steps, ticket=ticket)
         loss = opt.lambda_rgb * F.mse_loss(out["image"], gt_rgb, reduction="none").mean(-1)
         if opt.lambda_mask > 0:
             loss = loss + opt.lambda_mask * F.mse_loss(out["weights_sum"], gt_mask.squeeze(1), reduction="none")
@@ -105,6 +116,10 @@ class Stage0Trainer:
         self.scaler.update()
         self.scheduler.step()
         self.loss_acc += loss.detach()
+        if self.pipeline:
+            # everything the next step needs before its sample count is known goes into the queue now, behind this step's
+            # optimizer update (same order as the reference: refresh -> batch -> march), so the GPU never drains at the read-back
+            self._next = self._prepare()
         return loss
 
     def _tv(self, xyzs, scale):

@@ -142,6 +142,25 @@ def test_march_rays_train_bit_exact(be, oracle, scene, cfg):
     assert bits_equal(hx, ox) and bits_equal(hd, od) and bits_equal(ht, ot)
 
 
+def test_march_split_form_equals_single_call(be, oracle, scene):
+    """march_rays_train_begin/finish (pass 1 issued ahead, count read through a pinned copy + event) == march_rays_train."""
+    torch = be["torch"]
+    from nerf2mesh_amd import raymarching as R
+    N = 5000
+    o, d = make_rays(scene, N, seed=33)
+    nears, fars = oracle.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.05)
+    noises = np.random.default_rng(2).random(N).astype(np.float32)
+    a = (dev(be, o), dev(be, d), 1.0, False, dev(be, scene["bits"]), 1, 128, dev(be, nears), dev(be, fars))
+    ref = R.march_rays_train(*a, True, 1 / 256, 1024, dev(be, noises))
+    ticket = R.march_rays_train_begin(*a, True, 1 / 256, 1024, dev(be, noises))
+    junk = torch.randn(1 << 22, device="cuda").sin_().sum()      # unrelated work queued between the two halves
+    got = R.march_rays_train_finish(ticket)
+    assert junk.isfinite()
+    assert ref[0].shape[0] > 1000
+    for x, y in zip(ref, got):
+        assert torch.equal(x, y)
+
+
 def test_march_counter_base_and_repeatability(be, oracle, scene):
     """offsets start at the counter's entry value; two runs give identical packing (deterministic scan)."""
     torch, rm = be["torch"], be["rm"]
