@@ -66,9 +66,10 @@ def rays_from_pixels(poses, cam_idx, pix, H=LEGO_HW, W=LEGO_HW, focal=LEGO_FOCAL
     j = torch.div(pix, W, rounding_mode="floor").float() + 0.5
     cx, cy = W / 2, H / 2
     dirs = torch.stack([(i - cx) / focal, -(j - cy) / focal, -torch.ones_like(i)], -1)          # [N,3]
-    R = poses[cam_idx, :3, :3]                                                                    # [N,3,3]
-    rays_d = (dirs.unsqueeze(1) @ R.transpose(-1, -2)).squeeze(1)
-    rays_o = poses[cam_idx, :3, 3]
+    P = poses[cam_idx]                                                                            # [N,4,4], one gather
+    # d = R @ dir as three broadcast FMAs (a [N,1,3]x[N,3,3] bmm goes through the batched-GEMM library path)
+    rays_d = dirs[:, 0:1] * P[:, :3, 0] + dirs[:, 1:2] * P[:, :3, 1] + dirs[:, 2:3] * P[:, :3, 2]
+    rays_o = P[:, :3, 3]
     return rays_o.contiguous(), rays_d.contiguous()
 
 
@@ -97,6 +98,40 @@ def scene_inside(xyz, bx=None):
     return ((p >= bx[:, 0:3]) & (p <= bx[:, 3:6])).all(-1).any(-1)
 
 
+_SHADE = {}
+
+
+def _shade(device):
+    if device not in _SHADE:          # built once: torch.tensor(..., device=cuda) is a blocking host-to-device copy
+        _SHADE[device] = torch.tensor([0.80, 0.65, 1.00], device=device)
+    return _SHADE[device]
+
+
+def preload_images(poses, bx=None, H=LEGO_HW, W=LEGO_HW, focal=LEGO_FOCAL, chunk=1 << 21):
+    """All views' ground-truth RGBA, [n_views, H*W, 4] fp32 resident on the device -- the stand-in for the reference's
+    preloaded `self.images` (nerf/provider.py:224-233 keeps the whole training set on the GPU and gathers pixels from it)."""
+    dev = poses.device
+    n = poses.shape[0]
+    out = torch.empty(n, H * W, 4, dtype=torch.float32, device=dev)
+    pix = torch.arange(H * W, device=dev)
+    for v in range(n):
+        for s in range(0, H * W, chunk):
+            p = pix[s:s + chunk]
+            o, d = rays_from_pixels(poses, torch.full_like(p, v), p, H, W, focal)
+            out[v, s:s + chunk] = render_gt(o, d, bx)
+    return out
+
+
+def random_batch(poses, images, N, generator=None, H=LEGO_HW, W=LEGO_HW, focal=LEGO_FOCAL):
+    """N random pixels over all images with their ground truth gathered from the preloaded set
+    (random_image_batch, nerf/provider.py:302-303 + :330 `torch.gather(images, 1, ...)`)."""
+    dev = poses.device
+    cam = torch.randint(0, poses.shape[0], (N,), device=dev, generator=generator)
+    pix = torch.randint(0, H * W, (N,), device=dev, generator=generator)
+    o, d = rays_from_pixels(poses, cam, pix, H, W, focal)
+    return o, d, images[cam, pix]
+
+
 def render_gt(rays_o, rays_d, bx=None):
     """First-hit shading of the box scene. Returns rgba [N,4] (alpha 0 = background)."""
     bx = boxes(rays_o.device) if bx is None else bx
@@ -111,7 +146,8 @@ def render_gt(rays_o, rays_d, bx=None):
     t, k = tnear.min(-1)                                            # first box
     any_hit = torch.isfinite(t)
     ax = axis.gather(1, k.unsqueeze(1)).squeeze(1)
-    shade = torch.tensor([0.80, 0.65, 1.00], device=rays_o.device)[ax]   # per-axis "lambert"
+    shade = bx.new_tensor([0.80, 0.65, 1.00]) if rays_o.device.type == "cpu" else _shade(rays_o.device)
+    shade = shade[ax]                                               # per-axis "lambert"
     rgb = bx[k, 6:9] * shade.unsqueeze(-1)
     rgba = torch.cat([rgb, torch.ones_like(rgb[:, :1])], -1)
     return torch.where(any_hit.unsqueeze(-1), rgba, torch.zeros_like(rgba))

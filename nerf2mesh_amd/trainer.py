@@ -33,6 +33,8 @@ class Stage0Trainer:
         self.samples_seen = 0
         self.rays_seen = 0
         self.last_num_points = 0
+        self.preload = True           # ground-truth images resident on the device, batches gathered from them
+        self.images = None
         self.pipeline = True          # issue march pass 1 of the next batch one step ahead (results are identical)
         self._next = None
 
@@ -42,6 +44,10 @@ class Stage0Trainer:
             self.model.mark_untrained_grid(self.poses, (f, f, synthetic.LEGO_HW / 2, synthetic.LEGO_HW / 2))
 
     def batch(self):
+        if self.images is None and self.preload:
+            self.images = synthetic.preload_images(self.poses, self.boxes)     # nerf/provider.py:224-233 (`preload`)
+        if self.images is not None:
+            return synthetic.random_batch(self.poses, self.images, self.num_rays, self.gen)
         rays_o, rays_d = synthetic.random_rays(self.poses, self.num_rays, self.gen)
         rgba = synthetic.render_gt(rays_o, rays_d, self.boxes)
         return rays_o, rays_d, rgba
