@@ -167,6 +167,29 @@ int n2m_grid_encode_backward_bm(const void* grad, const float* inputs, const voi
                                 uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
                                 void* stream);
 
+/* New (no reference counterpart): the production backward of the host operator.  Same result as
+ * n2m_grid_encode_backward / n2m_grad_total_variation (gridencoder.cu:247-339 / :505-609) for D = 3 and the two table
+ * formats nerf2mesh trains with (fp32 C=1, fp16 C=2), computed by binning the per-vertex updates by table partition
+ * and summing them in 64-bit fixed point: every (sample, level) is visited once, the sums are exact
+ * from 2^-38 of the level's largest gradient down and, for the hashed levels, bit-reproducible run to run.
+ *   host_offsets : HOST pointer to the L+1 int32 level offsets (the list gridencoder/grid.py:117-128 builds)
+ *   workspace    : device scratch of at least n2m_grid_binned_workspace_bytes(...) bytes, 256-byte aligned; contents
+ *                  are undefined on entry and exit, the calls are stream-ordered so one buffer can be shared
+ *   B            : at most 2^19 samples per call
+ * n2m_grid_binned_workspace_bytes returns 0 when the configuration is not covered (callers then use the generic
+ * entry points above). */
+uint64_t n2m_grid_binned_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t max_level,
+                                         const int32_t* host_offsets, int dtype, int tv);
+int n2m_grid_encode_backward_binned(const void* grad, const float* inputs, const int32_t* host_offsets,
+                                    void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                    uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                    uint32_t interp, int dtype, void* workspace, uint64_t workspace_bytes,
+                                    void* stream);
+int n2m_grad_total_variation_binned(const float* inputs, const float* embeddings, float* grad,
+                                    const int32_t* host_offsets, float weight, uint32_t B, uint32_t D, uint32_t C,
+                                    uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                    void* workspace, uint64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * shencoder   (reference: shencoder/src/shencoder.h:9-10, shencoder/src/bindings.cpp:5-8)
  * ---------------------------------------------------------------------------------------------------- */

@@ -7,9 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libn2m_hip.so")
+LIB_PATH = os.environ.get("N2M_HIP_LIB") or os.path.join(_HERE, "lib", "libn2m_hip.so")   # override: A/B builds of the same ABI
 
-_u32, _i32, _f32, _vp, _int = ctypes.c_uint32, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
+_u32, _i32, _f32, _vp, _int, _u64 = ctypes.c_uint32, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64
 
 # name -> argtypes (restype is always int); mirrors include/n2m_hip.h one to one
 SIGNATURES = {
@@ -30,6 +30,9 @@ SIGNATURES = {
     "n2m_grad_total_variation": [_vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _int, _vp],
     "n2m_grid_encode_forward_bm": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int, _vp],
     "n2m_grid_encode_backward_bm": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int, _vp],
+    "n2m_grid_binned_workspace_bytes": [_u32, _u32, _u32, _u32, _vp, _int, _int],          # returns uint64 (RESTYPES)
+    "n2m_grid_encode_backward_binned": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int, _vp, _u64, _vp],
+    "n2m_grad_total_variation_binned": [_vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _vp, _u64, _vp],
     "n2m_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp],
     "n2m_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
     # include/n2m_mlp.h
@@ -47,6 +50,8 @@ SIGNATURES = {
     "n2m_prof_reset": [],
     "n2m_prof_read": [_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
 }
+
+RESTYPES = {"n2m_grid_binned_workspace_bytes": _u64}   # everything else returns an int status
 
 F32, F16 = 0, 1
 
@@ -69,7 +74,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)      # AttributeError here = header/library mismatch: fail loudly
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = RESTYPES.get(name, ctypes.c_int)
         L.n2m_last_error.restype = ctypes.c_char_p
         L.n2m_prof_name.restype = ctypes.c_char_p
         L.n2m_prof_name.argtypes = [_int]
@@ -85,6 +90,21 @@ def call(name, *args):
     rc = getattr(L, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {L.n2m_last_error().decode()}")
+
+
+_WORKSPACE = {}
+
+
+def workspace(device, nbytes):
+    """Grow-only device scratch shared by the binned grid kernels (stream-ordered, so one buffer per device is enough)."""
+    import torch
+    buf = _WORKSPACE.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _WORKSPACE.pop(device, None)
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _WORKSPACE[device] = buf
+    return buf
 
 
 def ptr(t):

@@ -527,6 +527,18 @@ struct PartMap {
         rel = (q << 4) | (row & 15u);
         return true;
     }
+    // which partition a row belongs to and where it sits inside it (independent of `part`)
+    __device__ __forceinline__ void split(uint32_t row, uint32_t& p, uint32_t& rel) const {
+        if (!interleaved) {
+            p = row >> log2p;
+            rel = row & ((1u << log2p) - 1u);
+        } else {
+            const uint32_t blk = row >> 4;
+            const uint32_t q = __umulhi(blk, magic);
+            p = blk - q * parts;
+            rel = (q << 4) | (row & 15u);
+        }
+    }
     __device__ __forceinline__ uint32_t global_row(uint32_t rel) const {
         return interleaved ? ((((rel >> 4) * parts + part) << 4) | (rel & 15u)) : ((part << log2p) + rel);
     }
@@ -589,8 +601,9 @@ __device__ __forceinline__ void backward_sweep(float* acc, const T* __restrict__
             if (pm.mine(row, rel)) {
                 const float w = ((i ? wx[1] : wx[0]) * (j ? wy[1] : wy[0])) * (k ? wz[1] : wz[0]);   // forward's association
 #pragma unroll
-                for (uint32_t c = 0; c < C; ++c)
+                for (uint32_t c = 0; c < C; ++c) {
                     __hip_atomic_fetch_add(&acc[rel * C + c], w * (float)gr.v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
     }
@@ -796,6 +809,327 @@ grid_backward_lds_kernel(const T* __restrict__ grad /*[L,B,C]*/, const float* __
     }
 }
 
+// ------------------------------------------------------------------------------------- binned backward / TV
+// The partition kernel above visits every sample once per PARTITION of a level (16-32 times for a 2^19-row level) and
+// is bound by that redundant ALU work (measured: dropping its LDS atomics altogether saves only 15 %).  The binned
+// path visits every (sample, level) ONCE:
+//
+//   bin_fill_kernel        one workgroup per (tile of 1024 samples, level): each thread derives its sample's 8 vertex
+//                          updates (partition, row-in-partition, w*g), the tile is counting-sorted by partition in LDS
+//                          (ds_add_rtn_u32 slots + a scan) and written as ONE contiguous, fully coalesced segment of the
+//                          update log; a small directory records where each partition's run starts inside the tile.
+//   bin_accumulate_kernel  one workgroup per (level, partition[, tile group]): walks the directory, streams its runs
+//                          (coalesced 8-byte entries) into an LDS accumulator and flushes it with coalesced stores.
+//
+// The accumulator is 64-bit FIXED POINT: LDS integer atomics run ~9x faster than float ones on gfx950 (measured 7.1 vs
+// 0.78 G/s per CU, tools/lds_atomic_bench.hip), and an integer sum does not depend on the order of its terms.  The unit
+// is 2^-38 of the level's largest |gradient| (found by bin_fill_kernel), so every product w*g is represented to at least
+// 14 bits below fp32's own resolution of the largest term and the sum is EXACT from there on; it is rounded to the
+// table's type once, at the flush.  Partitions owned by a single workgroup are flushed with plain read-modify-writes,
+// which makes the result bit-reproducible run to run (the reference's atomicAdd order is not, gridencoder.cu:324-334);
+// only partitions split over several tile groups (the small dense levels) end in float atomics.
+// fp16 tables: each product is rounded to half as in the reference (:326), then summed exactly.
+// Layout of the caller-provided workspace: [level_max u32[32]] [directory u32] [log u64], see make_bin_plan.
+
+constexpr uint32_t kBinAccBytes = 65536;          // LDS accumulator per accumulate workgroup (two workgroups per CU)
+constexpr uint32_t kTileEntries = 8192;           // 1024 threads x 8 entries per tile and level
+constexpr uint32_t kMaxPartsPerLevel = 2048;      // LDS counters of bin_fill_kernel
+constexpr uint32_t kBinChunk = 1u << 19;          // samples per pass over the workspace
+
+struct BinPlan {
+    uint32_t row0[kMaxLevels], size[kMaxLevels], parts[kMaxLevels], groups[kMaxLevels];
+    uint32_t dir_base[kMaxLevels];                // first directory word of the level, laid out [tile][parts + 1]
+    uint32_t item_prefix[kMaxLevels + 1];         // accumulate work items: level -> parts * groups
+    uint32_t tiles, levels;
+};
+
+template <uint32_t C> struct BinGeom {
+    static constexpr uint32_t P = kBinAccBytes / (8u * C);          // table rows per partition (u64 per channel)
+    static constexpr uint32_t kLog2P = 31u - __builtin_clz(P);
+};
+
+// value -> fixed point.  x = v * 2^ex is an exact power-of-two scaling with |x| < 2^38; split it into a 22-bit high part
+// and a 16-bit low part, both exactly representable, and recombine in 64-bit integers.
+__device__ __forceinline__ long long to_fixed(float v, float scale) {
+    const float x = v * scale;
+    const float hi = truncf(x * (1.0f / 65536.0f));
+    const float lo = x - hi * 65536.0f;
+    return ((long long)(int32_t)hi << 16) + (long long)(int32_t)rintf(lo);
+}
+
+template <typename T, uint32_t C, bool TV>
+__global__ void __launch_bounds__(1024)
+bin_fill_kernel(const T* __restrict__ grad /*[L,B,C]*/, const float* __restrict__ inputs, const float* __restrict__ tv_table,
+                float tv_weight, uint32_t B, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp,
+                uint32_t* __restrict__ level_max, uint32_t* __restrict__ directory, uint64_t* __restrict__ log) {
+    constexpr uint32_t D = 3;
+    extern __shared__ __attribute__((aligned(16))) uint64_t bin_stage[];       // kTileEntries entries, grouped by partition
+    __shared__ uint32_t cnt[kMaxPartsPerLevel];
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t tile = blockIdx.x, level = blockIdx.y;
+    const uint32_t parts = plan.parts[level], size = plan.size[level];
+    for (uint32_t i = tid; i < parts; i += 1024) cnt[i] = 0;
+    __syncthreads();
+
+    const float scale = lv.scale[level];
+    const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
+    const PartMap pm(parts, 0, BinGeom<C>::kLog2P, !ix.hashed && parts > 1u);
+    uint32_t e_part[8], e_rel[8], e_val[8], e_slot[8];
+    uint32_t vmask = 0;
+    float vmax = 0.0f;        // largest finite |value source| seen by this lane
+
+    if constexpr (!TV) {
+        const uint32_t s = tile * 1024u + tid;
+        float x[D] = {2.f, 2.f, 2.f};
+        if (s < B) load_point<D>(inputs, s, x);
+        if (!outside_unit_cube<D>(x)) {
+            const Row<T, C> gr = Row<T, C>::load(grad + ((size_t)level * B + s) * C);
+#pragma unroll
+            for (uint32_t c = 0; c < C; ++c) {
+                const float a = fabsf((float)gr.v[c]);
+                vmax = fmaxf(vmax, a <= 3.0e38f ? a : 1.0f);             // inf / nan: keep the level alive, they bypass the fixed point
+            }
+            uint32_t cell[D];
+            float frac[D], dfrac[D];
+            locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
+            const float wx[2] = {1 - frac[0], frac[0]}, wy[2] = {1 - frac[1], frac[1]}, wz[2] = {1 - frac[2], frac[2]};
+#pragma unroll
+            for (uint32_t corner = 0; corner < 8; ++corner) {
+                const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
+                const uint32_t v[D] = {cell[0] + i, cell[1] + j, cell[2] + k};
+                const uint32_t row = ix.row(v);
+                const float w = (wx[i] * wy[j]) * wz[k];                 // forward's association
+                uint32_t bits;
+                bool nz;
+                if constexpr (sizeof(T) == 4) {
+                    const float p = w * (float)gr.v[0];
+                    bits = __float_as_uint(p);
+                    nz = (bits << 1) != 0u;
+                } else {
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    h2 p;
+                    p.x = (_Float16)(w * (float)gr.v[0]);
+                    p.y = (_Float16)(w * (float)gr.v[1]);
+                    bits = __builtin_bit_cast(uint32_t, p);
+                    nz = (bits & 0x7FFF7FFFu) != 0u;
+                }
+                pm.split(row, e_part[corner], e_rel[corner]);
+                e_val[corner] = bits;
+                if (nz) vmask |= 1u << corner;
+            }
+        }
+    } else {
+        // total variation (gridencoder.cu:505-609): one entry per sample, 8 samples per thread
+        const float w = tv_weight / (float)(2 * D);
+        const uint32_t resolution = lv.resolution[level];
+#pragma unroll
+        for (uint32_t c8 = 0; c8 < 8; ++c8) {
+            const uint32_t s = tile * kTileEntries + c8 * 1024u + tid;
+            float x[D] = {2.f, 2.f, 2.f};
+            if (s < B) load_point<D>(inputs, s, x);
+            if (outside_unit_cube<D>(x)) continue;
+            uint32_t cell[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; ++d) cell[d] = (uint32_t)floorf(x[d] * scale + (align_corners ? 0.0f : 0.5f));
+            const uint32_t here = ix.row(cell);
+            uint32_t nb_row[2 * D];
+            bool nb_ok[2 * D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; ++d) {
+                const uint32_t cur = cell[d];
+                nb_ok[2 * d] = cur < resolution;
+                cell[d] = cur + 1;
+                nb_row[2 * d] = nb_ok[2 * d] ? ix.row(cell) : here;
+                nb_ok[2 * d + 1] = cur > 0;
+                cell[d] = cur - 1;
+                nb_row[2 * d + 1] = nb_ok[2 * d + 1] ? ix.row(cell) : here;
+                cell[d] = cur;
+            }
+            const float* __restrict__ tab = tv_table + (size_t)plan.row0[level];
+            const float centre = tab[here];
+            float nb[2 * D];
+#pragma unroll
+            for (uint32_t k = 0; k < 2 * D; ++k) nb[k] = tab[nb_row[k]];
+            float sum = 0.f, sq = 0.f;
+#pragma unroll
+            for (uint32_t k = 0; k < 2 * D; ++k)      // same order as the reference: +1 then -1 neighbour, axis by axis
+                if (nb_ok[k]) { const float dv = centre - nb[k]; sum += dv; sq += dv * dv; }
+            const float p = w * sum * (1.0f / sqrtf(sq + 1e-9f));
+            const uint32_t bits = __float_as_uint(p);
+            pm.split(here, e_part[c8], e_rel[c8]);
+            e_val[c8] = bits;
+            if ((bits << 1) != 0u) {
+                vmask |= 1u << c8;
+                const float a = fabsf(p);
+                vmax = fmaxf(vmax, a <= 3.0e38f ? a : 1.0f);
+            }
+        }
+    }
+
+    // the level's largest finite magnitude -> the fixed-point unit of bin_accumulate_kernel.  Same-address global atomics
+    // retire one every ~11 ns (measured: 65 k of them cost 0.75 ms), so the workgroup reduces first and only issues one
+    // when it would actually raise the value (a stale read merely costs a redundant atomic).
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if (lane == 0) wave_tot[wid] = __float_as_uint(vmax);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) m = max(m, wave_tot[w]);
+        if (m > __hip_atomic_load(&level_max[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&level_max[level], m);
+    }
+
+    // slot of every entry inside its partition's run of this tile
+    if (parts == 1u) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) {
+            const bool v = (vmask >> c) & 1u;
+            const unsigned long long m = __ballot(v);
+            uint32_t base = 0;
+            if (lane == 0 && m) base = atomicAdd(&cnt[0], (uint32_t)__popcll(m));
+            base = __shfl(base, 0, 64);
+            e_slot[c] = base + (uint32_t)__popcll(m & below);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c)
+            if ((vmask >> c) & 1u) e_slot[c] = atomicAdd(&cnt[e_part[c]], 1u);
+    }
+    __syncthreads();
+
+    // exclusive scan of the counters in place (two per thread), run starts into the directory
+    const uint32_t i0 = 2u * tid, i1 = i0 + 1u;
+    const uint32_t a0 = i0 < parts ? cnt[i0] : 0u, a1 = i1 < parts ? cnt[i1] : 0u;
+    const uint32_t incl = n2m_wave_scan_add_u32(a0 + a1, (int)lane);
+    if (lane == 63u) wave_tot[wid] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; ++w) {
+        const uint32_t t = wave_tot[w];
+        if (w < wid) woff += t;
+        total += t;
+    }
+    const uint32_t excl = woff + incl - (a0 + a1);
+    uint32_t* __restrict__ dir = directory + plan.dir_base[level] + (size_t)tile * (parts + 1u);
+    if (i0 < parts) { cnt[i0] = excl; dir[i0] = excl; }
+    if (i1 < parts) { cnt[i1] = excl + a0; dir[i1] = excl + a0; }
+    if (tid == 0) dir[parts] = total;
+    __syncthreads();
+
+#pragma unroll
+    for (uint32_t c = 0; c < 8; ++c)
+        if ((vmask >> c) & 1u) bin_stage[cnt[e_part[c]] + e_slot[c]] = ((uint64_t)e_rel[c] << 32) | e_val[c];
+    __syncthreads();
+
+    uint64_t* __restrict__ seg = log + ((size_t)level * plan.tiles + tile) * kTileEntries;
+    for (uint32_t i = tid; i < total; i += 1024) seg[i] = bin_stage[i];
+}
+
+template <typename T, uint32_t C>
+__global__ void __launch_bounds__(1024)
+bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners,
+                      const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ directory,
+                      const uint64_t* __restrict__ log) {
+    constexpr uint32_t P = BinGeom<C>::P;
+    extern __shared__ __attribute__((aligned(16))) unsigned long long bin_acc[];   // P * C
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t total_items = plan.item_prefix[plan.levels];
+
+    for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x) {
+        uint32_t level = 0;
+        while (item >= plan.item_prefix[level + 1]) ++level;
+        const uint32_t vm = level_max[level];
+        if (vm == 0u) continue;                                             // no non-zero finite update in this level
+        const uint32_t Gl = plan.groups[level];
+        const uint32_t local = item - plan.item_prefix[level];
+        const uint32_t part = local / Gl, grp = local - part * Gl;
+        const uint32_t parts = plan.parts[level], size = plan.size[level];
+        const Indexer<3> ix(size, lv.resolution[level], gridtype, align_corners);
+        const bool interleaved = !ix.hashed && parts > 1u;                  // same rule as bin_fill_kernel
+        const uint32_t row0 = plan.row0[level];
+        const PartMap pm(parts, part, BinGeom<C>::kLog2P, interleaved);
+        const uint32_t n_blocks = (size + 15u) >> 4;
+        const uint32_t my_blocks = interleaved ? (part < n_blocks ? (n_blocks - part + parts - 1) / parts : 0u)
+                                               : min(P / 16u, n_blocks - min(n_blocks, part * (P / 16u)));
+        const uint32_t rows_here = my_blocks << 4;
+
+        // unit = 2^-ex with |v| * 2^ex < 2^38 for every finite v of the level
+        int ex = 37 - ((int)((vm >> 23) & 255u) - 127);
+        ex = ex < -126 ? -126 : (ex > 126 ? 126 : ex);
+        const float scale = __uint_as_float((uint32_t)(ex + 127) << 23);
+        const float inv = __uint_as_float((uint32_t)(127 - ex) << 23);
+
+        for (uint32_t i = tid; i < rows_here * C; i += 1024) bin_acc[i] = 0ull;
+        __syncthreads();
+
+        T* __restrict__ gtab = grad_table + (size_t)row0 * C;
+        const uint32_t* __restrict__ dir_l = directory + plan.dir_base[level];
+        for (uint32_t t = grp + wid * Gl; t < plan.tiles; t += 16u * Gl) {   // one wave per tile run
+            const uint32_t* __restrict__ dir = dir_l + (size_t)t * (parts + 1u);
+            const uint32_t off = dir[part], end = dir[part + 1u];
+            const uint64_t* __restrict__ seg = log + ((size_t)level * plan.tiles + t) * kTileEntries;
+            for (uint32_t i = off + lane; i < end; i += 64u) {
+                const uint64_t e = seg[i];
+                const uint32_t rel = (uint32_t)(e >> 32), bits = (uint32_t)e;
+                if constexpr (sizeof(T) == 4) {
+                    const float v = __uint_as_float(bits);
+                    if (fabsf(v) <= 3.0e38f)
+                        __hip_atomic_fetch_add(&bin_acc[rel], (unsigned long long)to_fixed(v, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else
+                        unsafeAtomicAdd(gtab + pm.global_row(rel), v);          // inf / nan propagate as they are
+                } else {
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const h2 p = __builtin_bit_cast(h2, bits);
+                    const float v0 = (float)p.x, v1 = (float)p.y;
+                    if (fabsf(v0) <= 3.0e38f && fabsf(v1) <= 3.0e38f) {
+                        if (v0 != 0.f) __hip_atomic_fetch_add(&bin_acc[rel * 2u], (unsigned long long)to_fixed(v0, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (v1 != 0.f) __hip_atomic_fetch_add(&bin_acc[rel * 2u + 1u], (unsigned long long)to_fixed(v1, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gtab + (size_t)pm.global_row(rel) * 2u), p);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        for (uint32_t rel = tid; rel < rows_here; rel += 1024) {
+            const uint32_t row = pm.global_row(rel);
+            if (row >= size) continue;
+            if constexpr (sizeof(T) == 4) {
+                const long long a = (long long)bin_acc[rel];
+                if (a != 0) {
+                    const float f = (float)a * inv;
+                    if (Gl == 1u) gtab[row] += f;
+                    else unsafeAtomicAdd(gtab + row, f);
+                }
+            } else {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const long long a0 = (long long)bin_acc[rel * 2u], a1 = (long long)bin_acc[rel * 2u + 1u];
+                if ((a0 | a1) != 0) {
+                    const float f0 = (float)a0 * inv, f1 = (float)a1 * inv;
+                    h2* dst = reinterpret_cast<h2*>(gtab + (size_t)row * 2u);
+                    if (Gl == 1u) {
+                        h2 o = *dst;
+                        o.x = (_Float16)((float)o.x + f0);
+                        o.y = (_Float16)((float)o.y + f1);
+                        *dst = o;
+                    } else {
+                        h2 val;
+                        val.x = (_Float16)f0;
+                        val.y = (_Float16)f1;
+                        (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)dst, val);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]; accumulates in T like the reference (:357-365)
 template <typename T, uint32_t D, uint32_t C>
 __global__ void grid_input_backward_kernel(const T* __restrict__ grad, const T* __restrict__ dy_dx, T* __restrict__ grad_inputs,
@@ -970,6 +1304,89 @@ void launch_tv(const TvArgs& a) {
     grid_tv_kernel<D, C><<<grid, 256, 0, a.s>>>(a.inputs, a.table, a.grad, a.offsets, a.weight, a.B, a.lv, a.gridtype, a.align);
 }
 
+
+// ---- binned path: host plan + launches
+struct BinLayout {
+    BinPlan plan;
+    size_t dir_words, log_entries, bytes;
+    bool ok;
+};
+
+BinLayout make_bin_plan(uint32_t Bc, uint32_t C, uint32_t max_level, const int32_t* host_offsets, bool tv) {
+    BinLayout o{};
+    o.ok = max_level >= 1 && max_level <= kMaxLevels && (C == 1 || C == 2);
+    if (!o.ok) return o;
+    const uint32_t P = kBinAccBytes / (8u * C);
+    const uint32_t per_tile = tv ? kTileEntries : 1024u;                     // samples per tile
+    const uint32_t tiles = (Bc + per_tile - 1) / per_tile;
+    o.plan.tiles = tiles;
+    o.plan.levels = max_level;
+    size_t dir = 0;
+    uint32_t items = 0;
+    for (uint32_t l = 0; l < max_level; ++l) {
+        const int64_t size = (int64_t)host_offsets[l + 1] - (int64_t)host_offsets[l];
+        if (size <= 0 || host_offsets[l] < 0) { o.ok = false; return o; }
+        const uint32_t n_blocks = ((uint32_t)size + 15u) >> 4;
+        const uint32_t parts = (n_blocks + P / 16u - 1) / (P / 16u);
+        if (parts > kMaxPartsPerLevel) { o.ok = false; return o; }
+        const uint64_t per_part = (uint64_t)(tv ? 1 : 8) * Bc / parts;       // expected entries of one partition
+        uint32_t g = (uint32_t)((per_part + 65535u) / 65536u);
+        g = g < 1u ? 1u : (g > 64u ? 64u : g);
+        g = g > tiles ? tiles : g;
+        o.plan.row0[l] = (uint32_t)host_offsets[l];
+        o.plan.size[l] = (uint32_t)size;
+        o.plan.parts[l] = parts;
+        o.plan.groups[l] = g;
+        o.plan.dir_base[l] = (uint32_t)dir;
+        o.plan.item_prefix[l] = items;
+        dir += (size_t)tiles * (parts + 1u);
+        items += parts * g;
+    }
+    o.plan.item_prefix[max_level] = items;
+    o.dir_words = dir;
+    o.log_entries = (size_t)max_level * tiles * kTileEntries;
+    o.bytes = 256 + ((dir * 4 + 255) & ~(size_t)255) + o.log_entries * 8;
+    if (dir >= (1ull << 32)) o.ok = false;
+    return o;
+}
+
+template <typename T, uint32_t C, bool TV>
+int launch_binned(const T* grad, const float* inputs, const float* tv_table, float tv_weight, T* grad_table, uint32_t B, uint32_t max_level,
+                  const int32_t* host_offsets, const LevelTable& lv, uint32_t gridtype, bool align, uint32_t interp, void* workspace,
+                  size_t workspace_bytes, hipStream_t s, const char* fn) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)bin_fill_kernel<T, C, TV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 8));
+        (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinAccBytes);
+        attr_set = true;
+    }
+    for (uint32_t b0 = 0; b0 < B; b0 += kBinChunk) {
+        const uint32_t Bc = B - b0 < kBinChunk ? B - b0 : kBinChunk;
+        const BinLayout lay = make_bin_plan(Bc, C, max_level, host_offsets, TV);
+        N2M_REQUIRE(lay.ok, N2M_EUNSUPPORTED, "%s: table layout not supported by the binned path", fn);
+        N2M_REQUIRE(workspace_bytes >= lay.bytes, N2M_EINVAL, "%s: workspace too small (%zu < %zu bytes)", fn, workspace_bytes, lay.bytes);
+        uint32_t* level_max = (uint32_t*)workspace;
+        uint32_t* directory = (uint32_t*)((char*)workspace + 256);
+        uint64_t* log = (uint64_t*)((char*)workspace + 256 + ((lay.dir_words * 4 + 255) & ~(size_t)255));
+        N2M_HIP(hipMemsetAsync(level_max, 0, 256, s));
+        // grad is [L, B, C]: a chunk of samples is a column block, so the kernel gets the full-B pointer arithmetic through
+        // its own B; inputs are offset on the host.  (B <= kBinChunk in training, where this loop runs once.)
+        const T* g = grad;
+        const float* x = inputs + (size_t)b0 * 3;
+        if (B > kBinChunk) {
+            N2M_REQUIRE(false, N2M_EUNSUPPORTED, "%s: more than %u samples per call are not supported by the binned path", fn, kBinChunk);
+        }
+        bin_fill_kernel<T, C, TV><<<dim3(lay.plan.tiles, max_level), 1024, kTileEntries * 8, s>>>(g, x, tv_table, tv_weight, Bc, lay.plan, lv, gridtype,
+                                                                                                   align, interp, level_max, directory, log);
+        N2M_CHECK_LAUNCH();
+        const uint32_t items = lay.plan.item_prefix[max_level];
+        bin_accumulate_kernel<T, C><<<items < 2048u ? items : 2048u, 1024, kBinAccBytes, s>>>(grad_table, lay.plan, lv, gridtype, align, level_max,
+                                                                                                directory, log);
+        N2M_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 // D in {2,3,4,5} x C in {1,2,4,8}: pick the instantiation
 #define N2M_DISPATCH_DC(D, C, FN, ...)                                             \
     switch ((D) * 16 + (C)) {                                                      \
@@ -1109,4 +1526,49 @@ extern "C" int n2m_grad_total_variation(const void* inputs, const void* embeddin
     N2M_DISPATCH_DC(D, C, TV_CASE, a);
     N2M_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" uint64_t n2m_grid_binned_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t max_level, const int32_t* host_offsets,
+                                                    int dtype, int tv) {
+    if (D != 3 || !host_offsets || B == 0 || B > kBinChunk) return 0;
+    if (tv ? !(dtype == N2M_F32 && C == 1) : !((dtype == N2M_F32 && C == 1) || (dtype == N2M_F16 && C == 2))) return 0;
+    const BinLayout lay = make_bin_plan(B, C, max_level, host_offsets, tv != 0);
+    return lay.ok ? (uint64_t)lay.bytes : 0;
+}
+
+extern "C" int n2m_grid_encode_backward_binned(const void* grad, const float* inputs, const int32_t* host_offsets, void* grad_embeddings,
+                                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                               uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void* workspace,
+                                               uint64_t workspace_bytes, void* stream) {
+    const char* fn = "grid_encode_backward_binned";
+    if (int rc = check_dims(fn, D, C, L, max_level, dtype)) return rc;
+    N2M_REQUIRE(grad && inputs && host_offsets && grad_embeddings && workspace, N2M_ENULL, "%s: NULL tensor", fn);
+    N2M_REQUIRE(D == 3 && ((dtype == N2M_F32 && C == 1) || (dtype == N2M_F16 && C == 2)), N2M_EUNSUPPORTED,
+                "%s: D=3 with fp32 C=1 or fp16 C=2 tables only (use n2m_grid_encode_backward otherwise)", fn);
+    if (B == 0 || max_level == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t esz = dtype == N2M_F16 ? 2 : 4;
+    const LevelTable lv = make_levels(L, S, H);
+    N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (4.0 * D + (double)max_level * C * esz + 2.0 * max_level * (1u << D) * C * esz));
+    if (dtype == N2M_F16)
+        return launch_binned<_Float16, 2, false>((const _Float16*)grad, inputs, nullptr, 0.f, (_Float16*)grad_embeddings, B, max_level, host_offsets,
+                                                 lv, gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn);
+    return launch_binned<float, 1, false>((const float*)grad, inputs, nullptr, 0.f, (float*)grad_embeddings, B, max_level, host_offsets, lv,
+                                          gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn);
+}
+
+extern "C" int n2m_grad_total_variation_binned(const float* inputs, const float* embeddings, float* grad, const int32_t* host_offsets,
+                                               float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                               uint32_t gridtype, int align_corners, void* workspace, uint64_t workspace_bytes,
+                                               void* stream) {
+    const char* fn = "grad_total_variation_binned";
+    if (int rc = check_dims(fn, D, C, L, L, N2M_F32)) return rc;
+    N2M_REQUIRE(inputs && embeddings && grad && host_offsets && workspace, N2M_ENULL, "%s: NULL tensor", fn);
+    N2M_REQUIRE(D == 3 && C == 1, N2M_EUNSUPPORTED, "%s: D=3, C=1 fp32 tables only (use n2m_grad_total_variation otherwise)", fn);
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const LevelTable lv = make_levels(L, S, H);
+    N2M_PROF(N2M_K_GRID_TV, s, (double)B * (4.0 * D + (double)L * (1 + 2 * D) * C * 4.0 + (double)L * C * 8.0));
+    return launch_binned<float, 1, true>(nullptr, inputs, embeddings, weight, grad, B, L, host_offsets, lv, gridtype, align_corners != 0, 0u,
+                                         workspace, (size_t)workspace_bytes, s, fn);
 }

@@ -35,6 +35,9 @@ def _encode_backward_lm(grad_lm, x01, emb, enc, max_level):
     B = x01.shape[0]
     Lv, C = enc.num_levels, emb.shape[1]
     g = torch.zeros_like(emb)
+    from .gridencoder import binned_backward
+    if binned_backward(enc, grad_lm, x01, g, max_level):
+        return g
     L.call("n2m_grid_encode_backward", _p(grad_lm), _p(x01), _p(emb), _p(enc.offsets), _p(g), B, 3, C, Lv, max_level,
            float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None, None, enc.gridtype_id, int(bool(enc.align_corners)),
            enc.interp_id, L.F16 if emb.dtype == torch.float16 else L.F32, L.stream())

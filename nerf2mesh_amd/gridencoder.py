@@ -90,6 +90,46 @@ class _grid_encode(Function):
         return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None
 
 
+def _host_offsets(enc):
+    """int32 numpy copy of the level offsets for the binned kernels' host-side plan (cached on the encoder)."""
+    arr = getattr(enc, "_host_offsets_np", None)
+    if arr is None:
+        arr = np.ascontiguousarray(np.asarray(enc.host_offsets, dtype=np.int32))
+        enc._host_offsets_np = arr
+    return arr
+
+
+def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level):
+    """grad_embeddings += scatter of grad_lm [L,B,C] through the binned fixed-point kernels (include/n2m_hip.h);
+    returns False when the configuration is not covered (caller uses n2m_grid_encode_backward)."""
+    B, C = x01.shape[0], grad_embeddings.shape[1]
+    if x01.shape[1] != 3 or B > (1 << 19) or not hasattr(enc, "host_offsets"):
+        return False
+    dt = _dtype_id(grad_embeddings)
+    ho = _host_offsets(enc)
+    need = L.lib().n2m_grid_binned_workspace_bytes(B, 3, C, max_level, ho.ctypes.data, dt, 0)
+    if need == 0:
+        return False
+    ws = L.workspace(x01.device, need)
+    L.call("n2m_grid_encode_backward_binned", _p(grad_lm), _p(x01), ho.ctypes.data, _p(grad_embeddings), B, 3, C, enc.num_levels, max_level,
+           float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), enc.interp_id, dt,
+           _p(ws), ws.numel(), L.stream())
+    return True
+
+
+def binned_tv(enc, x01, emb, grad, weight):
+    B, C = x01.shape[0], emb.shape[1]
+    ho = _host_offsets(enc)
+    need = L.lib().n2m_grid_binned_workspace_bytes(B, 3, C, enc.num_levels, ho.ctypes.data, L.F32, 1)
+    if need == 0:
+        return False
+    ws = L.workspace(x01.device, need)
+    L.call("n2m_grad_total_variation_binned", _p(x01), _p(emb), _p(grad), ho.ctypes.data, weight, B, 3, C, enc.num_levels,
+           float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), _p(ws), ws.numel(),
+           L.stream())
+    return True
+
+
 def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
                 align_corners=False, interpolation=0, max_level=None):
     """inputs [B,D] in [0,1], embeddings [rows,C], offsets [L+1] -> features [B, L*C] (gridencoder/grid.py:24-98)."""
@@ -173,5 +213,17 @@ class GridEncoder(nn.Module):
             raise ValueError("grad is None, should be called after loss.backward() and before optimizer.step()!")
         inputs = inputs.float().contiguous()
         emb = self.embeddings.detach().float().contiguous()
+        grad = self.embeddings.grad
+        if D == 3 and grad.dtype == torch.float32 and grad.is_contiguous():
+            done = 0
+            while done < B:                                   # the binned kernels take at most 2^19 samples per call
+                n = min(B - done, 1 << 19)
+                if not binned_tv(self, inputs[done:done + n], emb, grad, float(weight)):
+                    break
+                done += n
+            if done == B:
+                return
+            inputs = inputs[done:].contiguous()
+            B -= done
         L.call("n2m_grad_total_variation", _p(inputs), _p(emb), _p(self.embeddings.grad), _p(self.offsets), float(weight), B, D, C,
                Lv, S, int(self.base_resolution), self.gridtype_id, int(bool(self.align_corners)), L.F32, L.stream())

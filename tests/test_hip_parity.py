@@ -440,6 +440,120 @@ def test_grad_total_variation(be, oracle):
     np.testing.assert_allclose(g_h.cpu().numpy(), g_o, rtol=1e-4, atol=1e-8)    # atomic order only
 
 
+def _binned_backward(be, g, X, offs, ge_out, C, Lv, max_level, S, H, gridtype, align, interp, half):
+    from nerf2mesh_amd import _lib as L
+    ho = np.ascontiguousarray(offs, dtype=np.int32)
+    B = X.shape[0]
+    dt = L.F16 if half else L.F32
+    need = L.lib().n2m_grid_binned_workspace_bytes(B, 3, C, max_level, ho.ctypes.data, dt, 0)
+    assert need > 0
+    ws = be["torch"].empty(need, dtype=be["torch"].uint8, device="cuda")
+    L.call("n2m_grid_encode_backward_binned", g.data_ptr(), X.data_ptr(), ho.ctypes.data, ge_out.data_ptr(), B, 3, C, Lv, max_level, S, H,
+           gridtype, int(align), interp, dt, ws.data_ptr(), need, L.stream())
+
+
+@pytest.mark.parametrize("C,half,gridtype,align,interp,log2", [
+    (1, False, 0, False, 0, 19), (2, True, 0, False, 0, 19), (1, False, 1, False, 1, 19), (2, True, 0, True, 0, 19),
+    (1, False, 0, False, 0, 14), (2, True, 1, True, 1, 16)])
+def test_grid_encode_backward_binned(be, oracle, C, half, gridtype, align, interp, log2):
+    """Binned fixed-point backward == oracle (same bars as the generic kernel), accumulates into a pre-filled table,
+    is bit-reproducible run to run, and lets inf/nan through untouched."""
+    torch = be["torch"]
+    rng = np.random.default_rng(15)
+    Lv, H, pls = 16, 16, 1.3819129
+    offs = oracle.level_offsets(3, Lv, pls, H, log2, align)
+    S = float(np.log2(pls))
+    B = 6007
+    x = rng.random((B, 3), dtype=np.float32)
+    x[2, 0] = -0.001
+    x[5] = 1.0
+    tdt = torch.float16 if half else torch.float32
+    ndt = np.float16 if half else np.float32
+    emb = np.zeros((int(offs[-1]), C), ndt)
+    g = rng.normal(size=(Lv, B, C)) * np.exp(rng.normal(size=(Lv, B, 1)) * (1.5 if half else 3))      # wide dynamic range
+    g = np.clip(g, -3e4, 3e4).astype(ndt)
+    g[:, 7] = 0
+    X, G = dev(be, x), dev(be, g)
+    for max_level in (Lv, 5):
+        pre = (rng.normal(size=emb.shape) * 0.01).astype(ndt)
+        out = dev(be, pre.copy())
+        _binned_backward(be, G, X, offs, out, C, Lv, max_level, S, H, gridtype, align, interp, half)
+        og = oracle.grid_encode_backward(g, x, emb, offs, S, H, max_level, None, gridtype, align, interp)
+        got = out.cpu().numpy().astype(np.float64) - pre.astype(np.float64)
+        ref = og.astype(np.float64)
+        if half:
+            np.testing.assert_allclose(got, ref, rtol=3e-2, atol=3e-2 * np.abs(ref).max())
+        else:
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+        assert np.array_equal(out.cpu().numpy()[offs[max_level]:], pre[offs[max_level]:])     # levels >= max_level untouched
+        out2 = dev(be, pre.copy())
+        _binned_backward(be, G, X, offs, out2, C, Lv, max_level, S, H, gridtype, align, interp, half)
+        assert torch.equal(out, out2), "integer accumulation + single-owner flush must be bit-reproducible"
+    # non-finite gradients propagate to exactly the rows they touch
+    g2 = g.copy()
+    g2[3, 11] = np.inf
+    out = torch.zeros(int(offs[-1]), C, dtype=tdt, device="cuda")
+    _binned_backward(be, dev(be, g2), X, offs, out, C, Lv, Lv, S, H, gridtype, align, interp, half)
+    clean = torch.zeros(int(offs[-1]), C, dtype=tdt, device="cuda")
+    _binned_backward(be, G, X, offs, clean, C, Lv, Lv, S, H, gridtype, align, interp, half)
+    bad = ~torch.isfinite(out).all(dim=1)
+    assert 1 <= int(bad.sum()) <= 8
+    lo, hi = int(offs[3]), int(offs[4])
+    assert bool(bad[lo:hi].any()) and not bool(bad[:lo].any()) and not bool(bad[hi:].any())
+    assert torch.equal(out[~bad], clean[~bad])
+
+
+def test_grid_backward_binned_full_size(be):
+    """BASELINE size (B = 2^18, lego tables, both table formats): per-level mass conservation, agreement with the
+    partition kernel, reproducibility of the single-owner (hashed) levels."""
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L
+    from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward
+    B = 2 ** 18
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand(B, 3, device="cuda", generator=gen)
+    for C, tdt in ((1, torch.float32), (2, torch.float16)):
+        enc = GridEncoder(level_dim=C, desired_resolution=2048).cuda()
+        offs = enc.host_offsets
+        grad = (torch.randn(16, B, C, device="cuda", generator=gen) * 0.05).to(tdt)
+        a = torch.zeros(offs[-1], C, device="cuda", dtype=tdt)
+        assert binned_backward(enc, grad, x, a, 16)
+        b = torch.zeros_like(a)
+        assert binned_backward(enc, grad, x, b, 16)
+        ref = torch.zeros_like(a)
+        emb = enc.embeddings.detach().to(tdt)
+        L.call("n2m_grid_encode_backward", grad.data_ptr(), x.data_ptr(), emb.data_ptr(), enc.offsets.data_ptr(), ref.data_ptr(), B, 3, C, 16, 16,
+               float(np.log2(enc.per_level_scale)), 16, None, None, 0, 0, 0, L.F16 if C == 2 else L.F32, L.stream())
+        tol = 2e-2 if C == 2 else 1e-4
+        np.testing.assert_allclose(a.float().cpu().numpy(), ref.float().cpu().numpy(), rtol=tol, atol=tol * float(ref.float().abs().max()))
+        for l in range(16):
+            sl = slice(offs[l], offs[l + 1])
+            np.testing.assert_allclose(a[sl].double().sum().item(), grad[l].double().sum().item(), rtol=2e-3, atol=0.5 if C == 2 else 0.05)
+            if offs[l + 1] - offs[l] == 2 ** 19:
+                assert torch.equal(a[sl], b[sl])
+
+
+def test_grad_total_variation_binned(be, oracle):
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L
+    rng = np.random.default_rng(7)
+    offs, S = lego_offsets(1.0)
+    emb = (rng.random((int(offs[-1]), 1), dtype=np.float32) * 2 - 1) * 1e-2
+    B = 50000
+    x = rng.random((B, 3), dtype=np.float32)
+    x[:3] = [[0, 0, 0], [1, 1, 1], [1.2, 0.5, 0.5]]
+    g0 = rng.normal(size=emb.shape).astype(np.float32) * 1e-6
+    g_h, g_o = dev(be, g0), g0.copy()
+    ho = np.ascontiguousarray(offs, dtype=np.int32)
+    need = L.lib().n2m_grid_binned_workspace_bytes(B, 3, 1, 16, ho.ctypes.data, L.F32, 1)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    L.call("n2m_grad_total_variation_binned", dev(be, x).data_ptr(), dev(be, emb).data_ptr(), g_h.data_ptr(), ho.ctypes.data, 1e-3, B, 3, 1, 16, S,
+           16, 0, 0, ws.data_ptr(), need, L.stream())
+    oracle.grad_total_variation(x, emb, g_o, offs, 1e-3, S, 16, 0, False)
+    np.testing.assert_allclose(g_h.cpu().numpy(), g_o, rtol=1e-4, atol=1e-8)
+
+
 @pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_sh_encode(be, oracle, degree):
     torch, sh = be["torch"], be["sh"]

@@ -74,7 +74,13 @@ for C, dt in ((1, torch.float32), (2, torch.float16)):
                 us, gbs = timed("grid_encode_backward", lambda: L.call("n2m_grid_encode_backward", p(grad), p(x), p(emb), p(enc.offsets), p(gemb), B, 3,
                                                                         C, 16, ml, S_, 16, None, None, 0, 0, 0, dtid, L.stream()))
                 print(f"C={C} {str(dt)[6:]:8s} B=2^{int(np.log2(B))} {kind:9s} backward max_level={ml:2d} {us:9.1f} us  {gbs:7.0f} GB/s algorithmic")
+            from nerf2mesh_amd.gridencoder import binned_backward, binned_tv
+            for ml in levels:
+                us, gbs = timed("grid_encode_backward", lambda: binned_backward(enc, grad, x, gemb, ml))
+                print(f"C={C} {str(dt)[6:]:8s} B=2^{int(np.log2(B))} {kind:9s} backward BINNED max_level={ml:2d} {us:9.1f} us  {gbs:7.0f} GB/s algorithmic")
             if C == 1:
+                us, gbs = timed("grad_total_variation", lambda: binned_tv(enc, x, emb, gemb, 1e-8))
+                print(f"C={C} {str(dt)[6:]:8s} B=2^{int(np.log2(B))} {kind:9s} TV BINNED    {us:9.1f} us  {gbs:7.0f} GB/s algorithmic")
                 us, gbs = timed("grad_total_variation", lambda: L.call("n2m_grad_total_variation", p(x), p(emb), p(gemb), p(enc.offsets), 1e-8, B, 3, C,
                                                                         16, S_, 16, 0, 0, dtid, L.stream()))
                 print(f"C={C} {str(dt)[6:]:8s} B=2^{int(np.log2(B))} {kind:9s} TV           {us:9.1f} us  {gbs:7.0f} GB/s algorithmic")
