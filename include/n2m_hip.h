@@ -191,6 +191,25 @@ int n2m_grad_total_variation_binned(const float* inputs, const float* embeddings
                                     void* workspace, uint64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * training-step helpers (no reference kernel: the reference composes these from torch ops)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Photometric loss head of the stage-0 step in one launch per direction:
+ *   pred   = image + (1 - weights_sum) * bg                      nerf/renderer.py:747
+ *   target = gt.rgb * gt.a + bg * (1 - gt.a)                     nerf/utils.py:663-664
+ *   loss   = mean_r [ lambda_rgb * mean_c (pred - target)^2 + lambda_mask * (weights_sum - gt.a)^2 ]   :679-683,797
+ * image [N,3] (composited colour BEFORE the background blend), weights_sum [N], gt_rgba [N,4]; bg [N,3] or NULL
+ * (then bg_scalar is the uniform background, 1 = white).  partial: scratch of ceil(N/256) floats; ticket: one
+ * uint32 that is zero on entry (left zero on exit); loss: [1].  The sum order is fixed, so the value is reproducible.
+ * backward: grad_loss [1] (device; the GradScaler factor) -> d_image [N,3], d_weights_sum [N]. */
+int n2m_photo_loss_forward(const float* image, const float* weights_sum, const float* gt_rgba, const float* bg,
+                           float bg_scalar, float lambda_rgb, float lambda_mask, uint32_t N, float* partial,
+                           uint32_t* ticket, float* loss, void* stream);
+int n2m_photo_loss_backward(const float* image, const float* weights_sum, const float* gt_rgba, const float* bg,
+                            float bg_scalar, float lambda_rgb, float lambda_mask, uint32_t N,
+                            const float* grad_loss, float* d_image, float* d_weights_sum, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * shencoder   (reference: shencoder/src/shencoder.h:9-10, shencoder/src/bindings.cpp:5-8)
  * ---------------------------------------------------------------------------------------------------- */
 

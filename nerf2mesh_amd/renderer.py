@@ -93,7 +93,7 @@ class NeRFRenderer(nn.Module):
                                                   self.grid_size, nears, fars, perturb, dt_gamma, max_steps)
 
     def render(self, rays_o, rays_d, index=None, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-4,
-               cam_near_far=None, shading="full", ticket=None, **kwargs):
+               cam_near_far=None, shading="full", ticket=None, blend_bg=True, **kwargs):
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
@@ -158,7 +158,8 @@ class NeRFRenderer(nn.Module):
                 rays_alive = raymarching.compact_alive(rays_alive)
                 step += n_step
 
-        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        if blend_bg:       # blend_bg=False: the caller folds the blend into its loss kernel (losses.photo_loss)
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         results["depth"] = depth.view(*prefix)
         results["image"] = image.view(*prefix, 3)
         return results

@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from . import synthetic
+from .losses import photo_loss
 from .parallel import GradSync
 
 
@@ -35,6 +36,7 @@ class Stage0Trainer:
         self.last_num_points = 0
         self.preload = True           # ground-truth images resident on the device, batches gathered from them
         self.images = None
+        self.fused_loss = True        # losses.photo_loss instead of the torch graph of nerf/utils.py:658-683
         self.pipeline = True          # issue march pass 1 of the next batch one step ahead (results are identical)
         self._next = None
 
@@ -74,8 +76,6 @@ class Stage0Trainer:
         self.optimizer.zero_grad(set_to_none=False)
         N = rays_o.shape[0]
         bg_color = 1 if opt.background == "white" else torch.rand(N, 3, device=self.device, generator=self.gen)
-        gt_mask = images[..., 3:]
-        gt_rgb = images[..., :3] * gt_mask + bg_color * (1 - gt_mask)
         if opt.sdf:
             opt.cos_anneal_ratio = min(1, self.global_step / (0.5 * opt.iters))
             opt.normal_anneal_epsilon = 1e-1 * (1 - min(0.999, self.global_step / (0.5 * opt.iters)))
@@ -84,11 +84,17 @@ class Stage0Trainer:
         shading = "diffuse" if (self.global_step < opt.diffuse_step or opt.diffuse_only) else "full"
 
         out = model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, shading=shading, dt_gamma=opt.dt_gamma,
-                           max_steps=opt.max_steps, ticket=ticket)
-        loss = opt.lambda_rgb * F.mse_loss(out["image"], gt_rgb, reduction="none").mean(-1)
-        if opt.lambda_mask > 0:
-            loss = loss + opt.lambda_mask * F.mse_loss(out["weights_sum"], gt_mask.squeeze(1), reduction="none")
-        loss = loss.mean()
+                           max_steps=opt.max_steps, ticket=ticket, blend_bg=not self.fused_loss)
+        if self.fused_loss:
+            # background blend + ground-truth compositing + rgb/mask MSE + mean in one kernel (nerf/utils.py:658-683)
+            loss = photo_loss(out["image"], out["weights_sum"], images, bg_color, opt.lambda_rgb, max(opt.lambda_mask, 0.0))
+        else:
+            gt_mask = images[..., 3:]
+            gt_rgb = images[..., :3] * gt_mask + bg_color * (1 - gt_mask)
+            loss = opt.lambda_rgb * F.mse_loss(out["image"], gt_rgb, reduction="none").mean(-1)
+            if opt.lambda_mask > 0:
+                loss = loss + opt.lambda_mask * F.mse_loss(out["weights_sum"], gt_mask.squeeze(1), reduction="none")
+            loss = loss.mean()
         if opt.lambda_entropy > 0:
             w = out["weights"].clamp(1e-5, 1 - 1e-5)
             w2 = out["weights_sum"].clamp(1e-5, 1 - 1e-5)
