@@ -30,8 +30,9 @@
 extern "C" {
 #endif
 
-/* Forward.  xyz [M,3] f32 (grid-bound coordinates, as fed to the encoders), dirs [M,3] f32 (normalised; may be NULL
- * when shading == 0), h1 [16,M] f32 (density features, LEVEL-major as n2m_grid_encode_forward writes them), h2 [16,M,2] f16
+/* Forward.  xyz [M,3] f32 (grid-bound coordinates, as fed to the encoders), dirs [M,3] f32 (may be NULL when
+ * shading == 0; unit vectors, or with normalize_dirs != 0 the raw ray directions march_rays_train hands out, which are
+ * then normalised on load exactly like safe_normalize, nerf/renderer.py:704), h1 [16,M] f32 (density features, LEVEL-major as n2m_grid_encode_forward writes them), h2 [16,M,2] f16
  * (colour features, level-major; may be NULL
  * when rgb == NULL: density-only evaluation as in update_extra_state).
  * Outputs: sigma [M] f32; rgb [M,3] f32 and specular [M,3] f32 (either may be NULL; specular is not written for
@@ -39,7 +40,7 @@ extern "C" {
  * h1 and the sigma_net weights are then not read. */
 int n2m_field_forward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
                       const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
-                      const float* w_spec0, const float* w_spec1, uint32_t M, int shading, float* sigma, float* rgb,
+                      const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs, float* sigma, float* rgb,
                       float* specular, void* stream);
 
 /* Backward of n2m_field_forward (activations are recomputed, nothing is saved but the inputs).
@@ -52,7 +53,7 @@ int n2m_field_forward(const float* xyz, const float* dirs, const float* h1, cons
  * Pass already-scaled upstream gradients (GradScaler) as they are. */
 int n2m_field_backward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
                        const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
-                       const float* w_spec0, const float* w_spec1, uint32_t M, int shading, const float* d_sigma,
+                       const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs, const float* d_sigma,
                        const float* d_rgb, const float* d_specular, float* d_h1, void* d_h2, float* d_w_sigma0,
                        float* d_w_sigma1, float* d_w_color0, float* d_w_color1, float* d_w_color2, float* d_w_spec0,
                        float* d_w_spec1, void* stream);

@@ -38,8 +38,8 @@ SIGNATURES = {
     "n2m_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp],
     "n2m_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
     # include/n2m_mlp.h
-    "n2m_field_forward": [_vp] * 11 + [_u32, _int] + [_vp] * 4,
-    "n2m_field_backward": [_vp] * 11 + [_u32, _int] + [_vp] * 13,
+    "n2m_field_forward": [_vp] * 11 + [_u32, _int, _int] + [_vp] * 4,
+    "n2m_field_backward": [_vp] * 11 + [_u32, _int, _int] + [_vp] * 13,
     # include/n2m_raster.h
     "n2m_rasterize_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "n2m_rasterize_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp],

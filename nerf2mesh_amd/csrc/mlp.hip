@@ -121,12 +121,25 @@ __device__ __forceinline__ float sigmoid_h(float pre_acc) {
 struct FieldArgs {
     const float* xyz; const float* dirs; const float* h1; const _Float16* h2;
     const float* w[7];       // sigma0, sigma1, color0, color1, color2, spec0, spec1
-    uint32_t M; int shading;
+    uint32_t M; int shading; int normalize_dirs;
     float* sigma; float* rgb; float* specular;
     // backward only
     const float* d_sigma; const float* d_rgb; const float* d_specular;
     float* d_h1; _Float16* d_h2; float* dw[7];
 };
+
+// View direction of sample s as fp16 MLP operands.  normalize_dirs: the march kernel hands out the raw ray direction
+// (raymarching.cu:466-468) and the reference normalises it per sample in torch (safe_normalize, nerf/renderer.py:704,
+// nerf/utils.py:43-44: x / sqrt(clamp(sum x^2, 1e-20))); folding that here saves five [M,3] elementwise passes.
+template <typename P>
+__device__ __forceinline__ void load_dir(const FieldArgs& a, uint32_t s, P& bp) {
+    float d0 = a.dirs[(size_t)s * 3], d1 = a.dirs[(size_t)s * 3 + 1], d2 = a.dirs[(size_t)s * 3 + 2];
+    if (a.normalize_dirs) {
+        const float n = sqrtf(fmaxf((d0 * d0 + d1 * d1) + d2 * d2, 1e-20f));
+        d0 /= n; d1 /= n; d2 /= n;
+    }
+    bp[0] = (_Float16)d0; bp[1] = (_Float16)d1; bp[2] = (_Float16)d2;
+}
 
 // ---------------------------------------------------------------------------------------------- input fragments
 // Encoder features arrive LEVEL-major (the layout grid_encode_forward writes fastest): h1 [16][M] fp32, h2 [16][M][2] fp16.
@@ -227,7 +240,7 @@ __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
             if (a.shading != 0) {
                 h4 bp = zero4();                      // K order of specular_net layer 0: d0 d1 d2 f0 | f1 f2 0 0
                 if (g == 0) {
-                    if (valid) { bp[0] = (_Float16)a.dirs[(size_t)s * 3]; bp[1] = (_Float16)a.dirs[(size_t)s * 3 + 1]; bp[2] = (_Float16)a.dirs[(size_t)s * 3 + 2]; }
+                    if (valid) load_dir(a, s, bp);
                     bp[3] = (_Float16)q3;
                 } else { bp[0] = (_Float16)q0; bp[1] = (_Float16)q1; }   // g = 1: q0,q1 are rows 4,5 = feat1, feat2
                 f16x p1 = MFMA(ld_a(lds + O_P0, P_P0, 0, 0, lane), bp, zero16());
@@ -426,7 +439,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             else {
                 h4 bp = zero4();
                 if (g == 0) {
-                    if (valid) { bp[0] = (_Float16)a.dirs[(size_t)s * 3]; bp[1] = (_Float16)a.dirs[(size_t)s * 3 + 1]; bp[2] = (_Float16)a.dirs[(size_t)s * 3 + 2]; }
+                    if (valid) load_dir(a, s, bp);
                     bp[3] = (_Float16)q3;
                 } else { bp[0] = (_Float16)q0; bp[1] = (_Float16)q1; }
                 const f16x p1 = MFMA(ld_a(lds + O_P0, P_P0, 0, 0, lane), bp, zero16());
@@ -565,7 +578,7 @@ uint32_t persistent_grid(uint32_t M) {
 
 extern "C" int n2m_field_forward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
                                  const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
-                                 const float* w_spec0, const float* w_spec1, uint32_t M, int shading, float* sigma, float* rgb,
+                                 const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs, float* sigma, float* rgb,
                                  float* specular, void* stream) {
     const float* w[7] = {w_sigma0, w_sigma1, w_color0, w_color1, w_color2, w_spec0, w_spec1};
     const bool density = sigma != nullptr;
@@ -578,7 +591,7 @@ extern "C" int n2m_field_forward(const float* xyz, const float* dirs, const floa
     }
     if (M == 0) return 0;
     FieldArgs a{};
-    a.xyz = xyz; a.dirs = dirs; a.h1 = h1; a.h2 = (const _Float16*)h2;
+    a.xyz = xyz; a.dirs = dirs; a.h1 = h1; a.h2 = (const _Float16*)h2; a.normalize_dirs = normalize_dirs;
     for (int i = 0; i < 7; ++i) a.w[i] = w[i];
     a.M = M; a.shading = shading; a.sigma = sigma; a.rgb = rgb; a.specular = specular;
     hipStream_t s = (hipStream_t)stream;
@@ -593,7 +606,7 @@ extern "C" int n2m_field_forward(const float* xyz, const float* dirs, const floa
 
 extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
                                   const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
-                                  const float* w_spec0, const float* w_spec1, uint32_t M, int shading, const float* d_sigma,
+                                  const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs, const float* d_sigma,
                                   const float* d_rgb, const float* d_specular, float* d_h1, void* d_h2, float* d_w_sigma0,
                                   float* d_w_sigma1, float* d_w_color0, float* d_w_color1, float* d_w_color2, float* d_w_spec0,
                                   float* d_w_spec1, void* stream) {
@@ -617,7 +630,7 @@ extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const flo
         attr_set = true;
     }
     FieldArgs a{};
-    a.xyz = xyz; a.dirs = dirs; a.h1 = h1; a.h2 = (const _Float16*)h2;
+    a.xyz = xyz; a.dirs = dirs; a.h1 = h1; a.h2 = (const _Float16*)h2; a.normalize_dirs = normalize_dirs;
     for (int i = 0; i < 7; ++i) { a.w[i] = w[i]; a.dw[i] = dw[i]; }
     a.M = M; a.shading = shading;
     a.d_sigma = d_sigma; a.d_rgb = d_rgb; a.d_specular = d_specular; a.d_h1 = d_h1; a.d_h2 = (_Float16*)d_h2;

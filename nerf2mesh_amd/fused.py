@@ -46,7 +46,7 @@ def _encode_backward_lm(grad_lm, x01, emb, enc, max_level):
 
 class _fused_field(Function):
     @staticmethod
-    def forward(ctx, xyz, dirs, emb1, emb2, w0, w1, w2, w3, w4, w5, w6, net, shading, want_color, want_density):
+    def forward(ctx, xyz, dirs, emb1, emb2, w0, w1, w2, w3, w4, w5, w6, net, shading, want_color, want_density, normalize_dirs):
         _bind()
         xyz = xyz.float().contiguous()
         M = xyz.shape[0]
@@ -67,9 +67,10 @@ class _fused_field(Function):
             dirs = dirs.float().contiguous() if shading != 0 else None
             rgb = torch.empty(M, 3, dtype=torch.float32, device=xyz.device)
             spec = torch.empty(M, 3, dtype=torch.float32, device=xyz.device) if shading != 0 else None
-        L.call("n2m_field_forward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, _p(sigma), _p(rgb), _p(spec),
-               L.stream())
+        L.call("n2m_field_forward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, int(normalize_dirs), _p(sigma), _p(rgb),
+               _p(spec), L.stream())
         ctx.net, ctx.shading, ctx.want_color, ctx.max_level, ctx.want_density = net, shading, want_color, max_level, want_density
+        ctx.normalize_dirs = int(normalize_dirs)
         ctx.save_for_backward(xyz, dirs, x01, h1, h2, emb1, emb2h, *ws)
         if not want_color:
             return sigma
@@ -97,8 +98,12 @@ class _fused_field(Function):
             d_h2 = torch.empty(16, M, 2, dtype=torch.float16, device=dev)
         else:
             d_rgb = d_spec = None
-        dws = [torch.zeros_like(w) for w in ws]
-        L.call("n2m_field_backward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, _p(d_sigma), _p(d_rgb),
+        flat = torch.zeros(sum(w.numel() for w in ws), dtype=torch.float32, device=dev)      # one fill for the seven dW
+        dws, o = [], 0
+        for w in ws:
+            dws.append(flat[o:o + w.numel()].view_as(w))
+            o += w.numel()
+        L.call("n2m_field_backward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, ctx.normalize_dirs, _p(d_sigma), _p(d_rgb),
                _p(d_spec), _p(d_h1), _p(d_h2), *[_p(g) for g in dws], L.stream())
         g1 = _encode_backward_lm(d_h1, x01, emb1, net.encoder, max_level) if want_density else None
         g2 = None
@@ -110,15 +115,16 @@ class _fused_field(Function):
             dws[5:] = [None] * 2
         if not want_density:
             dws[:2] = [None] * 2
-        return (None, None, g1, g2, *dws, None, None, None, None)
+        return (None, None, g1, g2, *dws, None, None, None, None, None)
 
 
-def fused_field(net, xyz, dirs, shading="full"):
-    """sigma [M], rgb [M,3], specular [M,3] | None -- NeRFNetwork.forward without individual codes."""
+def fused_field(net, xyz, dirs, shading="full", normalize_dirs=False):
+    """sigma [M], rgb [M,3], specular [M,3] | None -- NeRFNetwork.forward without individual codes.
+    normalize_dirs: `dirs` are raw ray directions and get safe_normalize'd inside the kernel."""
     sh = SHADING[shading]
     out = _fused_field.apply(xyz, dirs, net.encoder.embeddings, net.encoder_color.embeddings, net.sigma_net.net[0].weight,
                              net.sigma_net.net[1].weight, net.color_net.net[0].weight, net.color_net.net[1].weight,
-                             net.color_net.net[2].weight, net.specular_net.net[0].weight, net.specular_net.net[1].weight, net, sh, True, True)
+                             net.color_net.net[2].weight, net.specular_net.net[0].weight, net.specular_net.net[1].weight, net, sh, True, True, normalize_dirs)
     if sh == 0:
         return out[0], out[1], None
     return out
@@ -128,7 +134,7 @@ def fused_density(net, xyz):
     """sigma [M] only (occupancy refresh, nerf/renderer.py:1112-1113)."""
     return _fused_field.apply(xyz, None, net.encoder.embeddings, net.encoder_color.embeddings, net.sigma_net.net[0].weight,
                               net.sigma_net.net[1].weight, net.color_net.net[0].weight, net.color_net.net[1].weight,
-                              net.color_net.net[2].weight, net.specular_net.net[0].weight, net.specular_net.net[1].weight, net, 0, False, True)
+                              net.color_net.net[2].weight, net.specular_net.net[0].weight, net.specular_net.net[1].weight, net, 0, False, True, False)
 
 
 def fused_color(net, xyz, dirs, shading="full"):
@@ -136,5 +142,5 @@ def fused_color(net, xyz, dirs, shading="full"):
     sh = SHADING[shading]
     out = _fused_field.apply(xyz, dirs, net.encoder.embeddings, net.encoder_color.embeddings, net.sigma_net.net[0].weight,
                              net.sigma_net.net[1].weight, net.color_net.net[0].weight, net.color_net.net[1].weight,
-                             net.color_net.net[2].weight, net.specular_net.net[0].weight, net.specular_net.net[1].weight, net, sh, True, False)
+                             net.color_net.net[2].weight, net.specular_net.net[0].weight, net.specular_net.net[1].weight, net, sh, True, False, False)
     return (out[0], None) if sh == 0 else (out[0], out[1])

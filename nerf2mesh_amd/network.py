@@ -59,10 +59,12 @@ class NeRFNetwork(NeRFRenderer):
     def _can_fuse(self, c=None):
         return bool(getattr(self.opt, "fused_mlp", False)) and c is None and not self.opt.sdf and x_is_cuda(self)
 
-    def forward(self, x, d, c=None, shading="full"):
+    def forward(self, x, d, c=None, shading="full", raw_dirs=False):
+        """raw_dirs: `d` are un-normalised ray directions (only valid when _can_fuse(c): the kernel normalises on load)."""
         if self._can_fuse(c):
             from .fused import fused_field
-            return fused_field(self, x.view(-1, 3), d.view(-1, 3), shading)
+            return fused_field(self, x.view(-1, 3), d.view(-1, 3), shading, normalize_dirs=raw_dirs)
+        assert not raw_dirs
         sigma = self.density(x)["sigma"]
         color, specular = self.rgb(x, d, c, shading)
         return sigma, color, specular

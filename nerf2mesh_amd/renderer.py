@@ -120,9 +120,11 @@ class NeRFRenderer(nn.Module):
                                                                     self.cascade, self.grid_size, nears, fars, perturb, dt_gamma, max_steps)
             if ind_code is not None and ind_code.shape[0] > 1:
                 ind_code = ind_code[raymarching.flatten_rays(rays, xyzs.shape[0]).long()]
-            dirs = safe_normalize(dirs)
+            in_kernel = hasattr(self, "_can_fuse") and self._can_fuse(ind_code)      # fused field: safe_normalize happens on load
+            if not in_kernel:
+                dirs = safe_normalize(dirs)
             with amp:
-                sigmas, rgbs, speculars = self(xyzs, dirs, ind_code, shading)
+                sigmas, rgbs, speculars = self(xyzs, dirs, ind_code, shading, raw_dirs=True) if in_kernel else self(xyzs, dirs, ind_code, shading)
             if self.opt.sdf:
                 raw_normal = self.normal(xyzs, self.opt.normal_anneal_epsilon)
                 results["normal"] = raw_normal

@@ -73,7 +73,7 @@ class Stage0Trainer:
         rays_o, rays_d, images, ticket = self._next
         self._next = None
         self.global_step += 1
-        self.optimizer.zero_grad(set_to_none=False)
+        self.optimizer.zero_grad(set_to_none=True)
         N = rays_o.shape[0]
         bg_color = 1 if opt.background == "white" else torch.rand(N, 3, device=self.device, generator=self.gen)
         if opt.sdf:
@@ -224,7 +224,7 @@ class Stage1Trainer:
         bg = torch.rand(self.H * self.W, 3, device=self.device, generator=self.gen)
         gt_mask = rgba[:, 3:]
         gt_rgb = rgba[:, :3] * gt_mask + bg * (1 - gt_mask)
-        self.optimizer.zero_grad(set_to_none=False)
+        self.optimizer.zero_grad(set_to_none=True)
         out = model.render_stage1(rays_o, rays_d, self.mvps[v], self.H, self.W, bg_color=bg, shading="full")
         loss = opt.lambda_rgb * F.mse_loss(out["image"], gt_rgb, reduction="none").mean(-1)
         if opt.lambda_mask > 0:

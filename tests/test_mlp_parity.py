@@ -54,6 +54,28 @@ def test_fused_forward(shading, M):
     assert rel.max().item() < 3e-2 and rel.mean().item() < 2e-3
 
 
+def test_in_kernel_dir_normalisation_is_bit_identical():
+    """raw_dirs=True (safe_normalize on load, nerf/renderer.py:704) == normalising in torch first: forward and gradients."""
+    import torch
+    from nerf2mesh_amd.renderer import safe_normalize
+    _, fused = make_nets()
+    x, d = samples(20011)
+    raw = d * (torch.rand(d.shape[0], 1, device="cuda") * 3 + 0.2)
+    raw[5] = 0.0                                                       # the eps clamp of safe_normalize
+    outs = []
+    for mode in (False, True):
+        fused.zero_grad(set_to_none=True)
+        s, c, p = fused(x, raw if mode else safe_normalize(raw), None, "full", raw_dirs=mode)
+        (s.sum() + (c * c).sum() + p.sum()).backward()
+        outs.append((s.detach(), c.detach(), p.detach(), [q.grad.clone() for q in fused.parameters() if q.grad is not None]))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    assert len(outs[0][3]) == len(outs[1][3]) > 0
+    for a, b in zip(outs[0][3], outs[1][3]):
+        # the dW reduction uses atomics at its final flush: order noise only
+        np.testing.assert_allclose(a.float().cpu().numpy(), b.float().cpu().numpy(), rtol=1e-3, atol=1e-5 * float(a.abs().max()) + 1e-12)
+
+
 def test_fused_density_only():
     import torch
     ref, fused = make_nets()
