@@ -183,12 +183,20 @@ uint64_t n2m_grid_binned_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uin
 int n2m_grid_encode_backward_binned(const void* grad, const float* inputs, const int32_t* host_offsets,
                                     void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                     uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
-                                    uint32_t interp, int dtype, void* workspace, uint64_t workspace_bytes,
-                                    void* stream);
-int n2m_grad_total_variation_binned(const float* inputs, const float* embeddings, float* grad,
-                                    const int32_t* host_offsets, float weight, uint32_t B, uint32_t D, uint32_t C,
-                                    uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                    uint32_t interp, int dtype, const float* tv_embeddings, float tv_weight,
+                                    float tv_weight_outer, float tv_inner01, const float* tv_scale,
                                     void* workspace, uint64_t workspace_bytes, void* stream);
+/* tv_embeddings != NULL (fp32 C=1 table, max_level == L) folds grad_total_variation over the same inputs into the
+ * backward: the TV cell floor(x*scale+0.5) is vertex 000 of the interpolation cell, so its term rides on that vertex's
+ * update at no extra entry.  TV weighting, here and in n2m_grad_total_variation_binned: `weight` for inputs with
+ * |x - 0.5|_inf <= inner01, `weight_outer` for the rest (nerf/utils.py:815-821 runs TV twice, x10 outside the unit box
+ * when bound > 1; inner01 = 0.5/bound, >= 0.5 disables the split), both multiplied by *scale when that device pointer is
+ * given (the GradScaler factor: the term can then be added to gradients that are still scaled). */
+int n2m_grad_total_variation_binned(const float* inputs, const float* embeddings, float* grad,
+                                    const int32_t* host_offsets, float weight, float weight_outer, float inner01,
+                                    const float* weight_scale, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                    uint32_t H, uint32_t gridtype, int align_corners, void* workspace,
+                                    uint64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * training-step helpers (no reference kernel: the reference composes these from torch ops)

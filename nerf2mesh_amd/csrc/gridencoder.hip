@@ -857,11 +857,51 @@ __device__ __forceinline__ long long to_fixed(float v, float scale) {
     return ((long long)(int32_t)hi << 16) + (long long)(int32_t)rintf(lo);
 }
 
-template <typename T, uint32_t C, bool TV>
+// Total-variation term of one cell (gridencoder.cu:505-609): w * sum_nb (g - g_nb) / sqrt(sum_nb (g - g_nb)^2 + 1e-9) over the
+// up-to-6 axis neighbours, in the reference's order (+1 then -1 neighbour, axis by axis).  C = 1 tables.
+__device__ __forceinline__ float tv_term(const float* __restrict__ tab, const Indexer<3>& ix, uint32_t (&cell)[3], uint32_t here,
+                                         uint32_t resolution, float w) {
+    constexpr uint32_t D = 3;
+    uint32_t nb_row[2 * D];
+    bool nb_ok[2 * D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) {
+        const uint32_t cur = cell[d];
+        nb_ok[2 * d] = cur < resolution;
+        cell[d] = cur + 1;
+        nb_row[2 * d] = nb_ok[2 * d] ? ix.row(cell) : here;
+        nb_ok[2 * d + 1] = cur > 0;
+        cell[d] = cur - 1;
+        nb_row[2 * d + 1] = nb_ok[2 * d + 1] ? ix.row(cell) : here;
+        cell[d] = cur;
+    }
+    const float centre = tab[here];
+    float nb[2 * D];
+#pragma unroll
+    for (uint32_t k = 0; k < 2 * D; ++k) nb[k] = tab[nb_row[k]];
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (uint32_t k = 0; k < 2 * D; ++k)
+        if (nb_ok[k]) { const float dv = centre - nb[k]; sum += dv; sq += dv * dv; }
+    return w * sum * (1.0f / sqrtf(sq + 1e-9f));
+}
+
+// TV weighting of the fused / stand-alone TV: weight (inner region) or weight_outer (|xyz|_inf > 1, nerf/utils.py:815-821),
+// both times *scale_ptr when given (the GradScaler factor, so that the term can be added to still-scaled gradients).
+struct TvParams {
+    const float* table;       // fp32 [rows, 1]; NULL = no TV
+    float weight, weight_outer, inner01;      // inner01: half extent of the inner region in [0,1] input space (>= 0.5: everything is inner)
+    const float* scale_ptr;
+};
+
+// MODE 0: backward entries; MODE 1: TV entries only (8 samples per thread); MODE 2: backward + TV folded into vertex 000's
+// entry (the TV cell floor(x*scale+0.5) IS that vertex) -- fp32 C=1 tables.
+template <typename T, uint32_t C, int MODE>
 __global__ void __launch_bounds__(1024)
-bin_fill_kernel(const T* __restrict__ grad /*[L,B,C]*/, const float* __restrict__ inputs, const float* __restrict__ tv_table,
-                float tv_weight, uint32_t B, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp,
-                uint32_t* __restrict__ level_max, uint32_t* __restrict__ directory, uint64_t* __restrict__ log) {
+bin_fill_kernel(const T* __restrict__ grad /*[L,B,C]*/, const float* __restrict__ inputs, TvParams tv, uint32_t B, BinPlan plan,
+                LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max,
+                uint32_t* __restrict__ directory, uint64_t* __restrict__ log) {
+    constexpr bool TV = MODE == 1;
     constexpr uint32_t D = 3;
     extern __shared__ __attribute__((aligned(16))) uint64_t bin_stage[];       // kTileEntries entries, grouped by partition
     __shared__ uint32_t cnt[kMaxPartsPerLevel];
@@ -891,9 +931,18 @@ bin_fill_kernel(const T* __restrict__ grad /*[L,B,C]*/, const float* __restrict_
                 vmax = fmaxf(vmax, a <= 3.0e38f ? a : 1.0f);             // inf / nan: keep the level alive, they bypass the fixed point
             }
             uint32_t cell[D];
+            float tvv = 0.0f;
             float frac[D], dfrac[D];
             locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
             const float wx[2] = {1 - frac[0], frac[0]}, wy[2] = {1 - frac[1], frac[1]}, wz[2] = {1 - frac[2], frac[2]};
+            if constexpr (MODE == 2) {
+                const bool inner = fmaxf(fmaxf(fabsf(x[0] - 0.5f), fabsf(x[1] - 0.5f)), fabsf(x[2] - 0.5f)) <= tv.inner01;
+                float w = (inner ? tv.weight : tv.weight_outer);
+                if (tv.scale_ptr) w *= *tv.scale_ptr;
+                tvv = tv_term(tv.table + (size_t)plan.row0[level], ix, cell, ix.row(cell), lv.resolution[level], w / (float)(2 * D));
+                const float a = fabsf(tvv);
+                vmax += a <= 3.0e38f ? a : 1.0f;                         // |w*g + tv| <= |g| + |tv|
+            }
 #pragma unroll
             for (uint32_t corner = 0; corner < 8; ++corner) {
                 const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
@@ -903,7 +952,8 @@ bin_fill_kernel(const T* __restrict__ grad /*[L,B,C]*/, const float* __restrict_
                 uint32_t bits;
                 bool nz;
                 if constexpr (sizeof(T) == 4) {
-                    const float p = w * (float)gr.v[0];
+                    float p = w * (float)gr.v[0];
+                    if (MODE == 2 && corner == 0) p += tvv;
                     bits = __float_as_uint(p);
                     nz = (bits << 1) != 0u;
                 } else {
@@ -921,8 +971,8 @@ bin_fill_kernel(const T* __restrict__ grad /*[L,B,C]*/, const float* __restrict_
         }
     } else {
         // total variation (gridencoder.cu:505-609): one entry per sample, 8 samples per thread
-        const float w = tv_weight / (float)(2 * D);
         const uint32_t resolution = lv.resolution[level];
+        const float sc = tv.scale_ptr ? *tv.scale_ptr : 1.0f;
 #pragma unroll
         for (uint32_t c8 = 0; c8 < 8; ++c8) {
             const uint32_t s = tile * kTileEntries + c8 * 1024u + tid;
@@ -933,29 +983,9 @@ bin_fill_kernel(const T* __restrict__ grad /*[L,B,C]*/, const float* __restrict_
 #pragma unroll
             for (uint32_t d = 0; d < D; ++d) cell[d] = (uint32_t)floorf(x[d] * scale + (align_corners ? 0.0f : 0.5f));
             const uint32_t here = ix.row(cell);
-            uint32_t nb_row[2 * D];
-            bool nb_ok[2 * D];
-#pragma unroll
-            for (uint32_t d = 0; d < D; ++d) {
-                const uint32_t cur = cell[d];
-                nb_ok[2 * d] = cur < resolution;
-                cell[d] = cur + 1;
-                nb_row[2 * d] = nb_ok[2 * d] ? ix.row(cell) : here;
-                nb_ok[2 * d + 1] = cur > 0;
-                cell[d] = cur - 1;
-                nb_row[2 * d + 1] = nb_ok[2 * d + 1] ? ix.row(cell) : here;
-                cell[d] = cur;
-            }
-            const float* __restrict__ tab = tv_table + (size_t)plan.row0[level];
-            const float centre = tab[here];
-            float nb[2 * D];
-#pragma unroll
-            for (uint32_t k = 0; k < 2 * D; ++k) nb[k] = tab[nb_row[k]];
-            float sum = 0.f, sq = 0.f;
-#pragma unroll
-            for (uint32_t k = 0; k < 2 * D; ++k)      // same order as the reference: +1 then -1 neighbour, axis by axis
-                if (nb_ok[k]) { const float dv = centre - nb[k]; sum += dv; sq += dv * dv; }
-            const float p = w * sum * (1.0f / sqrtf(sq + 1e-9f));
+            const bool inner = fmaxf(fmaxf(fabsf(x[0] - 0.5f), fabsf(x[1] - 0.5f)), fabsf(x[2] - 0.5f)) <= tv.inner01;
+            const float w = tv.scale_ptr ? (inner ? tv.weight : tv.weight_outer) * sc : (inner ? tv.weight : tv.weight_outer);
+            const float p = tv_term(tv.table + (size_t)plan.row0[level], ix, cell, here, resolution, w / (float)(2 * D));
             const uint32_t bits = __float_as_uint(p);
             pm.split(here, e_part[c8], e_rel[c8]);
             e_val[c8] = bits;
@@ -1350,19 +1380,19 @@ BinLayout make_bin_plan(uint32_t Bc, uint32_t C, uint32_t max_level, const int32
     return o;
 }
 
-template <typename T, uint32_t C, bool TV>
-int launch_binned(const T* grad, const float* inputs, const float* tv_table, float tv_weight, T* grad_table, uint32_t B, uint32_t max_level,
+template <typename T, uint32_t C, int MODE>
+int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table, uint32_t B, uint32_t max_level,
                   const int32_t* host_offsets, const LevelTable& lv, uint32_t gridtype, bool align, uint32_t interp, void* workspace,
                   size_t workspace_bytes, hipStream_t s, const char* fn) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)bin_fill_kernel<T, C, TV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 8));
+        (void)hipFuncSetAttribute((const void*)bin_fill_kernel<T, C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 8));
         (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinAccBytes);
         attr_set = true;
     }
     for (uint32_t b0 = 0; b0 < B; b0 += kBinChunk) {
         const uint32_t Bc = B - b0 < kBinChunk ? B - b0 : kBinChunk;
-        const BinLayout lay = make_bin_plan(Bc, C, max_level, host_offsets, TV);
+        const BinLayout lay = make_bin_plan(Bc, C, max_level, host_offsets, MODE == 1);
         N2M_REQUIRE(lay.ok, N2M_EUNSUPPORTED, "%s: table layout not supported by the binned path", fn);
         N2M_REQUIRE(workspace_bytes >= lay.bytes, N2M_EINVAL, "%s: workspace too small (%zu < %zu bytes)", fn, workspace_bytes, lay.bytes);
         uint32_t* level_max = (uint32_t*)workspace;
@@ -1376,8 +1406,8 @@ int launch_binned(const T* grad, const float* inputs, const float* tv_table, flo
         if (B > kBinChunk) {
             N2M_REQUIRE(false, N2M_EUNSUPPORTED, "%s: more than %u samples per call are not supported by the binned path", fn, kBinChunk);
         }
-        bin_fill_kernel<T, C, TV><<<dim3(lay.plan.tiles, max_level), 1024, kTileEntries * 8, s>>>(g, x, tv_table, tv_weight, Bc, lay.plan, lv, gridtype,
-                                                                                                   align, interp, level_max, directory, log);
+        bin_fill_kernel<T, C, MODE><<<dim3(lay.plan.tiles, max_level), 1024, kTileEntries * 8, s>>>(g, x, tv, Bc, lay.plan, lv, gridtype, align, interp,
+                                                                                                     level_max, directory, log);
         N2M_CHECK_LAUNCH();
         const uint32_t items = lay.plan.item_prefix[max_level];
         bin_accumulate_kernel<T, C><<<items < 2048u ? items : 2048u, 1024, kBinAccBytes, s>>>(grad_table, lay.plan, lv, gridtype, align, level_max,
@@ -1538,29 +1568,37 @@ extern "C" uint64_t n2m_grid_binned_workspace_bytes(uint32_t B, uint32_t D, uint
 
 extern "C" int n2m_grid_encode_backward_binned(const void* grad, const float* inputs, const int32_t* host_offsets, void* grad_embeddings,
                                                uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
-                                               uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void* workspace,
-                                               uint64_t workspace_bytes, void* stream) {
+                                               uint32_t gridtype, int align_corners, uint32_t interp, int dtype, const float* tv_embeddings,
+                                               float tv_weight, float tv_weight_outer, float tv_inner01, const float* tv_scale,
+                                               void* workspace, uint64_t workspace_bytes, void* stream) {
     const char* fn = "grid_encode_backward_binned";
     if (int rc = check_dims(fn, D, C, L, max_level, dtype)) return rc;
     N2M_REQUIRE(grad && inputs && host_offsets && grad_embeddings && workspace, N2M_ENULL, "%s: NULL tensor", fn);
     N2M_REQUIRE(D == 3 && ((dtype == N2M_F32 && C == 1) || (dtype == N2M_F16 && C == 2)), N2M_EUNSUPPORTED,
                 "%s: D=3 with fp32 C=1 or fp16 C=2 tables only (use n2m_grid_encode_backward otherwise)", fn);
+    N2M_REQUIRE(!tv_embeddings || (dtype == N2M_F32 && C == 1 && max_level == L), N2M_EUNSUPPORTED,
+                "%s: the fused TV term needs an fp32 C=1 table and max_level == L", fn);
     if (B == 0 || max_level == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const size_t esz = dtype == N2M_F16 ? 2 : 4;
     const LevelTable lv = make_levels(L, S, H);
-    N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (4.0 * D + (double)max_level * C * esz + 2.0 * max_level * (1u << D) * C * esz));
+    const TvParams tv{tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale};
+    N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (4.0 * D + (double)max_level * C * esz + 2.0 * max_level * (1u << D) * C * esz +
+                                             (tv_embeddings ? (double)L * (1 + 2 * D) * 4.0 : 0.0)));
     if (dtype == N2M_F16)
-        return launch_binned<_Float16, 2, false>((const _Float16*)grad, inputs, nullptr, 0.f, (_Float16*)grad_embeddings, B, max_level, host_offsets,
-                                                 lv, gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn);
-    return launch_binned<float, 1, false>((const float*)grad, inputs, nullptr, 0.f, (float*)grad_embeddings, B, max_level, host_offsets, lv,
-                                          gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn);
+        return launch_binned<_Float16, 2, 0>((const _Float16*)grad, inputs, tv, (_Float16*)grad_embeddings, B, max_level, host_offsets, lv, gridtype,
+                                             align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn);
+    if (tv_embeddings)
+        return launch_binned<float, 1, 2>((const float*)grad, inputs, tv, (float*)grad_embeddings, B, max_level, host_offsets, lv, gridtype,
+                                          align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn);
+    return launch_binned<float, 1, 0>((const float*)grad, inputs, tv, (float*)grad_embeddings, B, max_level, host_offsets, lv, gridtype,
+                                      align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn);
 }
 
 extern "C" int n2m_grad_total_variation_binned(const float* inputs, const float* embeddings, float* grad, const int32_t* host_offsets,
-                                               float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
-                                               uint32_t gridtype, int align_corners, void* workspace, uint64_t workspace_bytes,
-                                               void* stream) {
+                                               float weight, float weight_outer, float inner01, const float* weight_scale, uint32_t B,
+                                               uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                               void* workspace, uint64_t workspace_bytes, void* stream) {
     const char* fn = "grad_total_variation_binned";
     if (int rc = check_dims(fn, D, C, L, L, N2M_F32)) return rc;
     N2M_REQUIRE(inputs && embeddings && grad && host_offsets && workspace, N2M_ENULL, "%s: NULL tensor", fn);
@@ -1568,7 +1606,8 @@ extern "C" int n2m_grad_total_variation_binned(const float* inputs, const float*
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const LevelTable lv = make_levels(L, S, H);
+    const TvParams tv{embeddings, weight, weight_outer, inner01, weight_scale};
     N2M_PROF(N2M_K_GRID_TV, s, (double)B * (4.0 * D + (double)L * (1 + 2 * D) * C * 4.0 + (double)L * C * 8.0));
-    return launch_binned<float, 1, true>(nullptr, inputs, embeddings, weight, grad, B, L, host_offsets, lv, gridtype, align_corners != 0, 0u,
-                                         workspace, (size_t)workspace_bytes, s, fn);
+    return launch_binned<float, 1, 1>(nullptr, inputs, tv, grad, B, L, host_offsets, lv, gridtype, align_corners != 0, 0u, workspace,
+                                      (size_t)workspace_bytes, s, fn);
 }

@@ -282,13 +282,52 @@ march_train_wave_kernel(const float* __restrict__ rays_o, const float* __restric
     // t so large that t + dt == t: the serial reference would spin forever) into a bounded loop
     for (uint32_t chunk = 0; chunk < (1u << 20) && t_base < far && kept < budget; ++chunk) {
         // 1. lane j <- T_{base + j}: j sequential applications of the update, in serial fp32 order
-        float t = t_base;
-#pragma unroll 1
-        for (int i = 0; i < 63; ++i) {
-            const float nt = t + n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
-            t = i < lane ? nt : t;
+        float t = t_base, t_next_base;
+        // Constant step (dt_gamma == 0: t += dt_min).  Inside one binade [2^e, 2^(e+1)) every t is a multiple of
+        // u = 2^(e-23); with dt = (m + r) u, |r| < 1/2, the serial update RN(t + dt) is EXACTLY t + m u -- i.e. the
+        // integer m added to t's bit pattern -- so lane j reads T_{base+j} = bits(t_base) + j m in closed form.  Chunks
+        // that leave the binade, and the tie |r| = 1/2 (round-to-even depends on t), take the serial loop below.
+        bool closed_form = false;
+        if (c.dt_gamma == 0.0f) {
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t_base));   // wave-uniform: scalar branch
+            const uint32_t be = b >> 23;                                     // sign 0 and a normal exponent
+            if (be >= 1u && be <= 254u && c.dt_min <= c.dt_max) {
+                const int sh = 23 - ((int)be - 127) + 127;                   // biased exponent of 1/u
+                if (sh >= 1 && sh <= 254) {
+                    const float q = c.dt_min * __uint_as_float((uint32_t)sh << 23);      // dt / u, an exact scaling
+                    const float mq = rintf(q);
+                    if (q < 8388608.0f && mq >= 1.0f && fabsf(q - mq) != 0.5f) {
+                        const uint32_t m = (uint32_t)mq;
+                        const uint32_t last = b + 64u * m;
+                        if ((last >> 23) == be) {
+                            closed_form = true;
+                            t = __uint_as_float(b + (uint32_t)lane * m);
+                            t_next_base = __uint_as_float(last);
+                        }
+                    }
+                }
+            }
         }
-        const float t_next_base = __shfl(t + n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max), 63, 64);   // T_{base+64}
+#ifdef N2M_DEBUG_MARCH
+        if (closed_form) {
+            float ts_ = t_base;
+            for (int i = 0; i < 63; ++i) {
+                const float nt = ts_ + n2m_clampf(ts_ * c.dt_gamma, c.dt_min, c.dt_max);
+                ts_ = i < lane ? nt : ts_;
+            }
+            const float tn_ = __shfl(ts_ + n2m_clampf(ts_ * c.dt_gamma, c.dt_min, c.dt_max), 63, 64);
+            if (ts_ != t || tn_ != t_next_base)
+                printf("T mismatch ray %u chunk %u lane %d: closed %a serial %a next %a %a base %a\n", n, chunk, lane, t, ts_, t_next_base, tn_, t_base);
+        }
+#endif
+        if (!closed_form) {
+#pragma unroll 1
+            for (int i = 0; i < 63; ++i) {
+                const float nt = t + n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+                t = i < lane ? nt : t;
+            }
+            t_next_base = __shfl(t + n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max), 63, 64);   // T_{base+64}
+        }
         // 2. evaluate all candidates of the chunk
         const bool active = t < far;
         LaneEval e;
@@ -327,12 +366,11 @@ march_train_wave_kernel(const float* __restrict__ rays_o, const float* __restric
         if (WRITE && kept_mask) {
             if ((kept_mask >> lane) & 1ull) {
                 const uint32_t rank = (uint32_t)__popcll(kept_mask & ((1ull << lane) - 1ull));
-                const size_t row = out + rank;
+                const size_t row = out + (kept - (uint32_t)__popcll(kept_mask)) + rank;     // samples kept before this chunk + rank in it
                 xyzs[3 * row] = e.cx; xyzs[3 * row + 1] = e.cy; xyzs[3 * row + 2] = e.cz;
                 dirs[3 * row] = c.dx; dirs[3 * row + 1] = c.dy; dirs[3 * row + 2] = c.dz;
                 *reinterpret_cast<float2*>(ts + 2 * row) = make_float2(t + e.dt, e.dt);
             }
-            out += (size_t)__popcll(kept_mask);
         }
         if (done) break;
         t_base = t_next_base;

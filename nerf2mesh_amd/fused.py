@@ -36,6 +36,10 @@ def _encode_backward_lm(grad_lm, x01, emb, enc, max_level):
     Lv, C = enc.num_levels, emb.shape[1]
     g = torch.zeros_like(emb)
     from .gridencoder import binned_backward
+    req = getattr(enc, "tv_request", None)          # set by the trainer: fold the TV gradient into this backward
+    if req is not None and binned_backward(enc, grad_lm, x01, g, max_level, tv=(emb, req["weight"], req["weight_outer"], req["inner01"], req["scale"])):
+        req["done"] = True
+        return g
     if binned_backward(enc, grad_lm, x01, g, max_level):
         return g
     L.call("n2m_grid_encode_backward", _p(grad_lm), _p(x01), _p(emb), _p(enc.offsets), _p(g), B, 3, C, Lv, max_level,

@@ -99,9 +99,10 @@ def _host_offsets(enc):
     return arr
 
 
-def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level):
+def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level, tv=None):
     """grad_embeddings += scatter of grad_lm [L,B,C] through the binned fixed-point kernels (include/n2m_hip.h);
-    returns False when the configuration is not covered (caller uses n2m_grid_encode_backward)."""
+    returns False when the configuration is not covered (caller uses n2m_grid_encode_backward).
+    tv = (embeddings fp32, weight, weight_outer, inner01, scale tensor | None) folds the TV gradient over the same inputs in."""
     B, C = x01.shape[0], grad_embeddings.shape[1]
     if x01.shape[1] != 3 or B > (1 << 19) or not hasattr(enc, "host_offsets"):
         return False
@@ -110,21 +111,25 @@ def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level):
     need = L.lib().n2m_grid_binned_workspace_bytes(B, 3, C, max_level, ho.ctypes.data, dt, 0)
     if need == 0:
         return False
+    if tv is not None and not (dt == L.F32 and C == 1 and max_level == enc.num_levels):
+        return False
     ws = L.workspace(x01.device, need)
+    tv_emb, tv_w, tv_wo, tv_in, tv_scale = tv if tv is not None else (None, 0.0, 0.0, 1.0, None)
     L.call("n2m_grid_encode_backward_binned", _p(grad_lm), _p(x01), ho.ctypes.data, _p(grad_embeddings), B, 3, C, enc.num_levels, max_level,
            float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), enc.interp_id, dt,
-           _p(ws), ws.numel(), L.stream())
+           _p(tv_emb), float(tv_w), float(tv_wo), float(tv_in), _p(tv_scale), _p(ws), ws.numel(), L.stream())
     return True
 
 
-def binned_tv(enc, x01, emb, grad, weight):
+def binned_tv(enc, x01, emb, grad, weight, weight_outer=None, inner01=1.0, scale=None):
     B, C = x01.shape[0], emb.shape[1]
     ho = _host_offsets(enc)
     need = L.lib().n2m_grid_binned_workspace_bytes(B, 3, C, enc.num_levels, ho.ctypes.data, L.F32, 1)
     if need == 0:
         return False
     ws = L.workspace(x01.device, need)
-    L.call("n2m_grad_total_variation_binned", _p(x01), _p(emb), _p(grad), ho.ctypes.data, weight, B, 3, C, enc.num_levels,
+    L.call("n2m_grad_total_variation_binned", _p(x01), _p(emb), _p(grad), ho.ctypes.data, float(weight),
+           float(weight if weight_outer is None else weight_outer), float(inner01), _p(scale), B, 3, C, enc.num_levels,
            float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), _p(ws), ws.numel(),
            L.stream())
     return True

@@ -36,6 +36,8 @@ class Stage0Trainer:
         self.last_num_points = 0
         self.preload = True           # ground-truth images resident on the device, batches gathered from them
         self.images = None
+        self.fused_tv = True          # TV gradient folded into the density encoder's binned backward
+        self._one = torch.ones((), device=device)
         self.fused_loss = True        # losses.photo_loss instead of the torch graph of nerf/utils.py:658-683
         self.pipeline = True          # issue march pass 1 of the next batch one step ahead (results are identical)
         self._next = None
@@ -112,16 +114,29 @@ class Stage0Trainer:
         if opt.adaptive_num_rays and M > 0:                              # nerf/utils.py:796-797
             self.num_rays = max(1, int(round((opt.num_points / M) * self.num_rays)))
 
+        # TV regulariser (nerf/utils.py:812-821 adds it to the unscaled gradients after backward).  Fast path: hand it to the
+        # density encoder's backward, which folds it into its own table scatter pre-multiplied by the loss scale.
+        tv_req = None
+        if opt.lambda_tv > 0 and M > 0 and self.fused_tv and getattr(model, "_can_fuse", lambda: False)() \
+                and model.max_level >= model.encoder.num_levels:
+            scale_t = self.scaler.scale(self._one) if self.scaler.is_enabled() else None      # device scalar, no host sync
+            tv_req = dict(weight=opt.lambda_tv, weight_outer=opt.lambda_tv * (10 if opt.bound > 1 else 1), inner01=0.5 / model.bound,
+                          scale=scale_t, done=False)
+            model.encoder.tv_request = tv_req
         self.scaler.scale(loss).backward()
+        model.encoder.tv_request = None
+        tv_pending = tv_req is None or not tv_req["done"]
 
         xyzs = out["xyzs"]
         if self.sync is None:
             self.scaler.unscale_(self.optimizer)                         # nerf/utils.py:812
-            self._tv(xyzs, 1.0)
+            if tv_pending:
+                self._tv(xyzs, 1.0)
         else:
             # multi-GPU: every rank adds its own TV term (pre-multiplied by the loss scale), then the summed
             # gradients are averaged, then unscaled -- so all ranks see identical gradients and inf flags
-            self._tv(xyzs, self.scaler.get_scale() if self.scaler.is_enabled() else 1.0)
+            if tv_pending:
+                self._tv(xyzs, self.scaler.get_scale() if self.scaler.is_enabled() else 1.0)
             self.sync.all_reduce()
             self.scaler.unscale_(self.optimizer)
         self.scaler.step(self.optimizer)

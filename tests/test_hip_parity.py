@@ -449,7 +449,7 @@ def _binned_backward(be, g, X, offs, ge_out, C, Lv, max_level, S, H, gridtype, a
     assert need > 0
     ws = be["torch"].empty(need, dtype=be["torch"].uint8, device="cuda")
     L.call("n2m_grid_encode_backward_binned", g.data_ptr(), X.data_ptr(), ho.ctypes.data, ge_out.data_ptr(), B, 3, C, Lv, max_level, S, H,
-           gridtype, int(align), interp, dt, ws.data_ptr(), need, L.stream())
+           gridtype, int(align), interp, dt, None, 0.0, 0.0, 1.0, None, ws.data_ptr(), need, L.stream())
 
 
 @pytest.mark.parametrize("C,half,gridtype,align,interp,log2", [
@@ -548,10 +548,48 @@ def test_grad_total_variation_binned(be, oracle):
     need = L.lib().n2m_grid_binned_workspace_bytes(B, 3, 1, 16, ho.ctypes.data, L.F32, 1)
     assert need > 0
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
-    L.call("n2m_grad_total_variation_binned", dev(be, x).data_ptr(), dev(be, emb).data_ptr(), g_h.data_ptr(), ho.ctypes.data, 1e-3, B, 3, 1, 16, S,
-           16, 0, 0, ws.data_ptr(), need, L.stream())
+    L.call("n2m_grad_total_variation_binned", dev(be, x).data_ptr(), dev(be, emb).data_ptr(), g_h.data_ptr(), ho.ctypes.data, 1e-3, 1e-3, 1.0, None,
+           B, 3, 1, 16, S, 16, 0, 0, ws.data_ptr(), need, L.stream())
     oracle.grad_total_variation(x, emb, g_o, offs, 1e-3, S, 16, 0, False)
     np.testing.assert_allclose(g_h.cpu().numpy(), g_o, rtol=1e-4, atol=1e-8)
+    # inner/outer weighting (nerf/utils.py:815-821) and the device-side scale factor == two oracle passes with scaled weights
+    scale = torch.tensor([512.0], device="cuda")
+    g_h2, g_o2 = dev(be, g0), g0.copy()
+    L.call("n2m_grad_total_variation_binned", dev(be, x).data_ptr(), dev(be, emb).data_ptr(), g_h2.data_ptr(), ho.ctypes.data, 1e-3, 1e-2, 0.25,
+           scale.data_ptr(), B, 3, 1, 16, S, 16, 0, 0, ws.data_ptr(), need, L.stream())
+    inner = np.abs(x - 0.5).max(-1) <= 0.25
+    oracle.grad_total_variation(x[inner], emb, g_o2, offs, 1e-3 * 512, S, 16, 0, False)
+    oracle.grad_total_variation(x[~inner], emb, g_o2, offs, 1e-2 * 512, S, 16, 0, False)
+    np.testing.assert_allclose(g_h2.cpu().numpy(), g_o2, rtol=1e-4, atol=1e-7)
+
+
+def test_grid_backward_binned_with_fused_tv(be, oracle):
+    """tv_embeddings != NULL: one call == oracle backward + oracle TV over the same inputs (TV rides on vertex 000's update)."""
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L
+    rng = np.random.default_rng(8)
+    offs, S = lego_offsets(1.0)
+    emb = (rng.random((int(offs[-1]), 1), dtype=np.float32) * 2 - 1) * 1e-2
+    B = 30011
+    x = rng.random((B, 3), dtype=np.float32)
+    x[:3] = [[0, 0, 0], [1, 1, 1], [1.2, 0.5, 0.5]]
+    g = (rng.normal(size=(16, B, 1)) * 1e-3).astype(np.float32)
+    g[:, 100:200] = 0                                             # zero gradient, TV term alone keeps the entry alive
+    ho = np.ascontiguousarray(offs, dtype=np.int32)
+    need = L.lib().n2m_grid_binned_workspace_bytes(B, 3, 1, 16, ho.ctypes.data, L.F32, 0)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(int(offs[-1]), 1, device="cuda")
+    scale = torch.tensor([64.0], device="cuda")
+    L.call("n2m_grid_encode_backward_binned", dev(be, g).data_ptr(), dev(be, x).data_ptr(), ho.ctypes.data, out.data_ptr(), B, 3, 1, 16, 16, S, 16,
+           0, 0, 0, L.F32, dev(be, emb).data_ptr(), 1e-4, 1e-3, 0.3, scale.data_ptr(), ws.data_ptr(), need, L.stream())
+    ref = oracle.grid_encode_backward(g, x, emb, offs, S, 16, 16, None, 0, False, 0)
+    inner = np.abs(x - 0.5).max(-1) <= 0.3
+    oracle.grad_total_variation(x[inner], emb, ref, offs, 1e-4 * 64, S, 16, 0, False)
+    oracle.grad_total_variation(x[~inner], emb, ref, offs, 1e-3 * 64, S, 16, 0, False)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+    # and the TV part is really there: without it the result differs
+    plain = oracle.grid_encode_backward(g, x, emb, offs, S, 16, 16, None, 0, False, 0)
+    assert np.abs(ref - plain).max() > 1e-3 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
