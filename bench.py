@@ -35,6 +35,32 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling is 6290 GB/s
 
 
+# device kernels behind each library entry point, for the PMC traffic lookup
+_DEVICE_KERNELS = {"grid_encode_backward": ("bin_fill_kernel", "bin_accumulate_kernel"), "grid_encode_forward": ("grid_forward3_kernel",),
+                   "mlp_backward": ("field_backward_kernel",), "mlp_forward": ("field_forward_kernel",),
+                   "march_rays_train_count": ("march_train_wave_kernelILb0", "march_train_wave_kernel<false>"),
+                   "march_rays_train_write": ("march_train_wave_kernelILb1", "march_train_wave_kernel<true>")}
+
+
+def pmc_traffic(entry_point):
+    """HBM bytes per launch of `entry_point` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json, made by
+    tools/pmc_traffic.py: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, two separate passes), averaged over the device
+    kernels and table formats behind the entry point.  Counters cannot be read from inside this process, hence the file; None
+    when it is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path) or entry_point not in _DEVICE_KERNELS:
+        return None
+    table = json.load(open(path))
+    per_kernel = {}
+    for name, v in table.items():
+        for key in _DEVICE_KERNELS[entry_point]:
+            if key in name and v.get("fetch_bytes_per_launch") is not None and v.get("write_bytes_per_launch") is not None:
+                per_kernel.setdefault(key.split("IL")[0].split("<")[0], []).append(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
+    if not per_kernel:
+        return None
+    return float(sum(sum(v) / len(v) for v in per_kernel.values()))
+
+
 def cpu_baseline(n_rays=4096, reps=2):
     """One stage-0 iteration's kernels on the host: oracle (C, OpenMP) for march/encode/composite/TV, torch-CPU for the
     MLPs.  Returns dict for the JSON line.  Bounded: ~n_rays rays of the same synthetic workload."""
@@ -149,6 +175,7 @@ def main():
     ap.add_argument("--pretrain", type=int, default=300, help="untimed iterations before warmup so the occupancy grid is pruned")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel hipEvents in the timed region")
+    ap.add_argument("--prof-every", type=int, default=4, help="time every n-th launch of each kernel with hipEvents (1 = all)")
     ap.add_argument("--stage", type=int, default=0, choices=[0, 1], help="0: stage-0 volume rendering (the headline metric); "
                     "1: stage-1 mesh/texture refinement step (BASELINE config 3)")
     ap.add_argument("--unfused", action="store_true", help="A/B: evaluate the MLPs with nn.Linear calls (the reference graph) instead of the fused MFMA kernels")
@@ -190,7 +217,7 @@ def main():
     barrier()
     if not args.no_prof:
         _lib.prof_reset()
-        _lib.prof_enable(True)
+        _lib.prof_enable(args.prof_every)       # hipEvent pairs on every n-th launch of each kernel inside the timed region
     s0, r0 = tr.samples_seen, tr.rays_seen
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -228,7 +255,7 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         k = kernels[dom]
         roof = {"kernel": dom, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (k["GBps"] / HBM_PEAK_GBS) if k["GBps"] else None, "traffic": None,
+                "frac": (k["GBps"] / HBM_PEAK_GBS) if k["GBps"] else None, "traffic": pmc_traffic(dom),
                 "avg_us": k["avg_us"], "algo_bytes_per_launch": k["algo_bytes_per_launch"],
                 "note": "achieved = algorithmic bytes per launch (SURVEY.md 8d; cache hits count) / mean hipEvent duration over the timed region"}
 

@@ -175,7 +175,7 @@ int n2m_grid_encode_backward_bm(const void* grad, const float* inputs, const voi
  *   host_offsets : HOST pointer to the L+1 int32 level offsets (the list gridencoder/grid.py:117-128 builds)
  *   workspace    : device scratch of at least n2m_grid_binned_workspace_bytes(...) bytes, 256-byte aligned; contents
  *                  are undefined on entry and exit, the calls are stream-ordered so one buffer can be shared
- *   B            : at most 2^19 samples per call
+ *   B            : any; batches above 2^19 samples run in passes of 2^19 over the same workspace
  * n2m_grid_binned_workspace_bytes returns 0 when the configuration is not covered (callers then use the generic
  * entry points above). */
 uint64_t n2m_grid_binned_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t max_level,
@@ -241,8 +241,9 @@ enum {
     N2M_K_COMPOSITE_FWD, N2M_K_COMPOSITE_BWD, N2M_K_NEAR_FAR, N2M_K_PACKBITS, N2M_K_MLP_FWD, N2M_K_MLP_BWD,
     N2M_K_RASTER, N2M_K_COUNT
 };
-/* When enabled, every launch of a profiled kernel is bracketed by a hipEvent pair recorded on the launch
- * stream (events come from a fixed pool; launches beyond the pool are counted but not timed). */
+/* on = 1: every launch of a profiled kernel is bracketed by a hipEvent pair recorded on the launch stream; on = n > 1:
+ * every n-th launch of each kernel id (sampled timing, keeps the event overhead out of a timed region); 0: off.
+ * Events come from a fixed pool; launches beyond the pool are counted but not timed. */
 int n2m_prof_enable(int on);
 int n2m_prof_reset(void);
 /* Synchronises the recorded events, then returns the number of timed launches of `kernel_id`, their summed

@@ -116,8 +116,9 @@ def ptr(t):
 
 
 def stream():
+    """Raw hipStream_t of torch's current stream on the current device (the C call behind torch.cuda.current_stream())."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def check_cuda(**tensors):
@@ -132,7 +133,8 @@ def check_cuda(**tensors):
 
 
 def prof_enable(on=True):
-    call("n2m_prof_enable", int(bool(on)))
+    """True/1: time every launch; n > 1: every n-th launch per kernel; False/0: off."""
+    call("n2m_prof_enable", int(on))
 
 
 def prof_reset():

@@ -898,8 +898,8 @@ struct TvParams {
 // entry (the TV cell floor(x*scale+0.5) IS that vertex) -- fp32 C=1 tables.
 template <typename T, uint32_t C, int MODE>
 __global__ void __launch_bounds__(1024)
-bin_fill_kernel(const T* __restrict__ grad /*[L,B,C]*/, const float* __restrict__ inputs, TvParams tv, uint32_t B, BinPlan plan,
-                LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max,
+bin_fill_kernel(const T* __restrict__ grad /*[L,Bstride,C], first sample of this pass*/, const float* __restrict__ inputs, TvParams tv,
+                uint32_t B, uint32_t Bstride, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max,
                 uint32_t* __restrict__ directory, uint64_t* __restrict__ log) {
     constexpr bool TV = MODE == 1;
     constexpr uint32_t D = 3;
@@ -924,7 +924,7 @@ bin_fill_kernel(const T* __restrict__ grad /*[L,B,C]*/, const float* __restrict_
         float x[D] = {2.f, 2.f, 2.f};
         if (s < B) load_point<D>(inputs, s, x);
         if (!outside_unit_cube<D>(x)) {
-            const Row<T, C> gr = Row<T, C>::load(grad + ((size_t)level * B + s) * C);
+            const Row<T, C> gr = Row<T, C>::load(grad + ((size_t)level * Bstride + s) * C);
 #pragma unroll
             for (uint32_t c = 0; c < C; ++c) {
                 const float a = fabsf((float)gr.v[c]);
@@ -1399,14 +1399,10 @@ int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table
         uint32_t* directory = (uint32_t*)((char*)workspace + 256);
         uint64_t* log = (uint64_t*)((char*)workspace + 256 + ((lay.dir_words * 4 + 255) & ~(size_t)255));
         N2M_HIP(hipMemsetAsync(level_max, 0, 256, s));
-        // grad is [L, B, C]: a chunk of samples is a column block, so the kernel gets the full-B pointer arithmetic through
-        // its own B; inputs are offset on the host.  (B <= kBinChunk in training, where this loop runs once.)
-        const T* g = grad;
+        // grad is [L, B, C]: a pass covers the column block b0 .. b0+Bc of every level (level stride = the full B)
+        const T* g = grad ? grad + (size_t)b0 * C : nullptr;
         const float* x = inputs + (size_t)b0 * 3;
-        if (B > kBinChunk) {
-            N2M_REQUIRE(false, N2M_EUNSUPPORTED, "%s: more than %u samples per call are not supported by the binned path", fn, kBinChunk);
-        }
-        bin_fill_kernel<T, C, MODE><<<dim3(lay.plan.tiles, max_level), 1024, kTileEntries * 8, s>>>(g, x, tv, Bc, lay.plan, lv, gridtype, align, interp,
+        bin_fill_kernel<T, C, MODE><<<dim3(lay.plan.tiles, max_level), 1024, kTileEntries * 8, s>>>(g, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp,
                                                                                                      level_max, directory, log);
         N2M_CHECK_LAUNCH();
         const uint32_t items = lay.plan.item_prefix[max_level];
@@ -1560,7 +1556,8 @@ extern "C" int n2m_grad_total_variation(const void* inputs, const void* embeddin
 
 extern "C" uint64_t n2m_grid_binned_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t max_level, const int32_t* host_offsets,
                                                     int dtype, int tv) {
-    if (D != 3 || !host_offsets || B == 0 || B > kBinChunk) return 0;
+    if (D != 3 || !host_offsets || B == 0) return 0;
+    if (B > kBinChunk) B = kBinChunk;           // larger batches run in passes of kBinChunk samples over the same workspace
     if (tv ? !(dtype == N2M_F32 && C == 1) : !((dtype == N2M_F32 && C == 1) || (dtype == N2M_F16 && C == 2))) return 0;
     const BinLayout lay = make_bin_plan(B, C, max_level, host_offsets, tv != 0);
     return lay.ok ? (uint64_t)lay.bytes : 0;

@@ -30,7 +30,8 @@ constexpr int kPool = 16384;
 std::mutex g_mu;
 std::vector<Slot> g_slots;     // events are created lazily and reused after n2m_prof_reset
 int g_used = 0;
-bool g_on = false;
+int g_every = 0;                // 0 = off, 1 = every launch, n = every n-th launch of each kernel id
+uint64_t g_seen[N2M_K_COUNT];
 uint64_t g_untimed[N2M_K_COUNT];
 const char* kNames[N2M_K_COUNT] = {"grid_encode_forward", "grid_encode_backward", "grad_total_variation",
                                    "march_rays_train_count", "march_rays_train_write", "composite_rays_train_forward",
@@ -39,8 +40,9 @@ const char* kNames[N2M_K_COUNT] = {"grid_encode_forward", "grid_encode_backward"
 }  // namespace
 
 N2mProfScope::N2mProfScope(int kernel_id, hipStream_t s, double algo_bytes) : slot(-1), stream(s) {
-    if (!g_on) return;
+    if (g_every == 0) return;
     std::lock_guard<std::mutex> lk(g_mu);
+    if ((g_seen[kernel_id]++ % (uint64_t)g_every) != 0) return;       // sampled timing: keeps the event overhead out of the step
     if (g_used >= kPool) {
         g_untimed[kernel_id]++;
         return;
@@ -62,7 +64,7 @@ N2mProfScope::~N2mProfScope() {
 
 extern "C" int n2m_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_on = on != 0;
+    g_every = on < 0 ? 0 : on;
     return 0;
 }
 
@@ -70,6 +72,7 @@ extern "C" int n2m_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_used = 0;
     memset(g_untimed, 0, sizeof(g_untimed));
+    memset(g_seen, 0, sizeof(g_seen));
     return 0;
 }
 

@@ -104,7 +104,7 @@ def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level, tv=None):
     returns False when the configuration is not covered (caller uses n2m_grid_encode_backward).
     tv = (embeddings fp32, weight, weight_outer, inner01, scale tensor | None) folds the TV gradient over the same inputs in."""
     B, C = x01.shape[0], grad_embeddings.shape[1]
-    if x01.shape[1] != 3 or B > (1 << 19) or not hasattr(enc, "host_offsets"):
+    if x01.shape[1] != 3 or not hasattr(enc, "host_offsets"):
         return False
     dt = _dtype_id(grad_embeddings)
     ho = _host_offsets(enc)
@@ -220,15 +220,7 @@ class GridEncoder(nn.Module):
         emb = self.embeddings.detach().float().contiguous()
         grad = self.embeddings.grad
         if D == 3 and grad.dtype == torch.float32 and grad.is_contiguous():
-            done = 0
-            while done < B:                                   # the binned kernels take at most 2^19 samples per call
-                n = min(B - done, 1 << 19)
-                if not binned_tv(self, inputs[done:done + n], emb, grad, float(weight)):
-                    break
-                done += n
-            if done == B:
+            if binned_tv(self, inputs, emb, grad, float(weight)):
                 return
-            inputs = inputs[done:].contiguous()
-            B -= done
         L.call("n2m_grad_total_variation", _p(inputs), _p(emb), _p(self.embeddings.grad), _p(self.offsets), float(weight), B, D, C,
                Lv, S, int(self.base_resolution), self.gridtype_id, int(bool(self.align_corners)), L.F32, L.stream())

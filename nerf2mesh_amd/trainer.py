@@ -69,7 +69,8 @@ class Stage0Trainer:
 
     def train_step(self):
         opt, model = self.opt, self.model
-        model.train()
+        if not model.training:
+            model.train()
         if self._next is None:
             self._next = self._prepare()
         rays_o, rays_d, images, ticket = self._next

@@ -533,6 +533,28 @@ def test_grid_backward_binned_full_size(be):
                 assert torch.equal(a[sl], b[sl])
 
 
+def test_grid_backward_binned_multi_pass(be):
+    """B > 2^19 runs in passes over one workspace (the stage-1 batch of a 1600x1600 render): same result as the partition kernel."""
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L
+    from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward
+    B = 2 ** 19 + 70001
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(B, 3, device="cuda", generator=gen)
+    enc = GridEncoder(level_dim=2, desired_resolution=2048).cuda()
+    offs = enc.host_offsets
+    grad = (torch.randn(16, B, 2, device="cuda", generator=gen) * 0.05).half()
+    a = torch.zeros(offs[-1], 2, device="cuda", dtype=torch.float16)
+    assert binned_backward(enc, grad, x, a, 16)
+    ref = torch.zeros_like(a)
+    emb = enc.embeddings.detach().half()
+    L.call("n2m_grid_encode_backward", grad.data_ptr(), x.data_ptr(), emb.data_ptr(), enc.offsets.data_ptr(), ref.data_ptr(), B, 3, 2, 16, 16,
+           float(np.log2(enc.per_level_scale)), 16, None, None, 0, 0, 0, L.F16, L.stream())
+    np.testing.assert_allclose(a.float().cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-2, atol=2e-2 * float(ref.float().abs().max()))
+    for l in (0, 7, 15):
+        np.testing.assert_allclose(a[offs[l]:offs[l + 1]].double().sum().item(), grad[l].double().sum().item(), rtol=2e-3, atol=1.0)
+
+
 def test_grad_total_variation_binned(be, oracle):
     torch = be["torch"]
     from nerf2mesh_amd import _lib as L
