@@ -202,6 +202,14 @@ int n2m_grad_total_variation_binned(const float* inputs, const float* embeddings
  * training-step helpers (no reference kernel: the reference composes these from torch ops)
  * ---------------------------------------------------------------------------------------------------- */
 
+/* Rays of a batch of (view, pixel) pairs, get_rays of nerf/utils.py:242-290 for explicit indices plus the ground-truth
+ * gather of nerf/provider.py:330: poses [V,4,4] f32 (camera-to-world), cam [N] / pix [N] int64 (pix = j*W + i),
+ * pinhole intrinsics; rays_d = R * ((i+0.5-cx)/fx, -(j+0.5-cy)/fy, -1) (un-normalised), rays_o = translation;
+ * images [V,H*W,4] f32 with rgba [N,4] out, or both NULL. */
+int n2m_get_rays(const float* poses, const int64_t* cam, const int64_t* pix, uint32_t N, uint32_t H, uint32_t W,
+                 float fx, float fy, float cx, float cy, const float* images, float* rays_o, float* rays_d,
+                 float* rgba, void* stream);
+
 /* Photometric loss head of the stage-0 step in one launch per direction:
  *   pred   = image + (1 - weights_sum) * bg                      nerf/renderer.py:747
  *   target = gt.rgb * gt.a + bg * (1 - gt.a)                     nerf/utils.py:663-664

@@ -34,6 +34,7 @@ SIGNATURES = {
     "n2m_grid_encode_backward_binned": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int,
                                         _vp, _f32, _f32, _f32, _vp, _vp, _u64, _vp],
     "n2m_grad_total_variation_binned": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _vp, _u64, _vp],
+    "n2m_get_rays": [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "n2m_photo_loss_forward": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _u32, _vp, _vp, _vp, _vp],
     "n2m_photo_loss_backward": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _u32, _vp, _vp, _vp, _vp],
     "n2m_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp],

@@ -124,10 +124,19 @@ def preload_images(poses, bx=None, H=LEGO_HW, W=LEGO_HW, focal=LEGO_FOCAL, chunk
 
 def random_batch(poses, images, N, generator=None, H=LEGO_HW, W=LEGO_HW, focal=LEGO_FOCAL):
     """N random pixels over all images with their ground truth gathered from the preloaded set
-    (random_image_batch, nerf/provider.py:302-303 + :330 `torch.gather(images, 1, ...)`)."""
+    (random_image_batch, nerf/provider.py:302-303 + :330 `torch.gather(images, 1, ...)`).  On the GPU the ray construction and
+    the gather are one kernel (n2m_get_rays); rays_from_pixels is the torch statement of the same arithmetic."""
     dev = poses.device
     cam = torch.randint(0, poses.shape[0], (N,), device=dev, generator=generator)
     pix = torch.randint(0, H * W, (N,), device=dev, generator=generator)
+    if dev.type == "cuda" and poses.dtype == torch.float32 and poses.is_contiguous() and images.is_contiguous():
+        from . import _lib as L
+        o = torch.empty(N, 3, device=dev)
+        d = torch.empty(N, 3, device=dev)
+        rgba = torch.empty(N, 4, device=dev)
+        L.call("n2m_get_rays", L.ptr(poses), L.ptr(cam), L.ptr(pix), N, H, W, float(focal), float(focal), W / 2, H / 2, L.ptr(images), L.ptr(o),
+               L.ptr(d), L.ptr(rgba), L.stream())
+        return o, d, rgba
     o, d = rays_from_pixels(poses, cam, pix, H, W, focal)
     return o, d, images[cam, pix]
 

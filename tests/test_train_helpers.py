@@ -36,3 +36,23 @@ def test_photo_loss_matches_torch_graph(N, bg_kind):
     np.testing.assert_allclose(ws.grad.cpu().numpy(), gw.cpu().numpy(), rtol=1e-5, atol=1e-7)
     again = photo_loss(image.detach(), ws.detach(), gt, bg, lam_rgb, lam_mask)
     assert again.item() == got.item(), "fixed summation order: bit-reproducible"
+
+
+def test_get_rays_matches_torch_statement():
+    """n2m_get_rays == synthetic.rays_from_pixels (get_rays of nerf/utils.py:242-290 in torch ops) + images[cam, pix]."""
+    import torch
+    from nerf2mesh_amd import synthetic as S
+    poses = S.make_cameras(7, seed=3).cuda()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    H = W = 96
+    images = torch.rand(7, H * W, 4, device="cuda", generator=g)
+    N = 5003
+    g2 = torch.Generator(device="cuda").manual_seed(5)
+    o, d, rgba = S.random_batch(poses, images, N, g2, H, W, 111.5)
+    g2.manual_seed(5)
+    cam = torch.randint(0, 7, (N,), device="cuda", generator=g2)
+    pix = torch.randint(0, H * W, (N,), device="cuda", generator=g2)
+    ro, rd = S.rays_from_pixels(poses, cam, pix, H, W, 111.5)
+    assert torch.equal(o, ro)
+    np.testing.assert_allclose(d.cpu().numpy(), rd.cpu().numpy(), rtol=2e-6, atol=1e-7)     # same products, fp32 sum order may differ
+    assert torch.equal(rgba, images[cam, pix])
