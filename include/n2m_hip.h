@@ -185,8 +185,10 @@ int n2m_grid_encode_backward_binned(const void* grad, const float* inputs, const
                                     uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
                                     uint32_t interp, int dtype, const float* tv_embeddings, float tv_weight,
                                     float tv_weight_outer, float tv_inner01, const float* tv_scale,
-                                    void* workspace, uint64_t workspace_bytes, void* stream);
-/* tv_embeddings != NULL (fp32 C=1 table, max_level == L) folds grad_total_variation over the same inputs into the
+                                    float* found_inf, void* workspace, uint64_t workspace_bytes, void* stream);
+/* found_inf (device float, may be NULL) is set to 1 when a gradient read or a sum written is not finite (GradScaler's
+ * check, done where the values pass through anyway; never cleared here).
+ * tv_embeddings != NULL (fp32 C=1 table, max_level == L) folds grad_total_variation over the same inputs into the
  * backward: the TV cell floor(x*scale+0.5) is vertex 000 of the interpolation cell, so its term rides on that vertex's
  * update at no extra entry.  TV weighting, here and in n2m_grad_total_variation_binned: `weight` for inputs with
  * |x - 0.5|_inf <= inner01, `weight_outer` for the rest (nerf/utils.py:815-821 runs TV twice, x10 outside the unit box
@@ -224,6 +226,26 @@ int n2m_photo_loss_forward(const float* image, const float* weights_sum, const f
 int n2m_photo_loss_backward(const float* image, const float* weights_sum, const float* gt_rgba, const float* bg,
                             float bg_scalar, float lambda_rgb, float lambda_mask, uint32_t N,
                             const float* grad_loss, float* d_image, float* d_weights_sum, void* stream);
+
+/* Adam + GradScaler for the whole parameter set in two launches (torch.optim.Adam(fused=True) + torch.amp.GradScaler of
+ * main.py:221 / nerf/utils.py:506,1187-1190).  All tensors fp32 and 16-byte aligned, except grad which may be fp16
+ * (grad_is_half) and half_shadow (fp16 copy of the updated parameter, or NULL).  Gradients are still multiplied by *scale
+ * (NULL = 1); nothing is touched when *found_inf != 0; bias [2] = (1 - beta1^t, sqrt(1 - beta2^t)) of this step, kept up to
+ * date by n2m_scaler_update (initialise it to (1 - beta1, sqrt(1 - beta2)) for t = 1). */
+#define N2M_ADAM_MAX 16
+typedef struct {
+    void* param[N2M_ADAM_MAX]; const void* grad[N2M_ADAM_MAX]; void* exp_avg[N2M_ADAM_MAX]; void* exp_avg_sq[N2M_ADAM_MAX];
+    void* half_shadow[N2M_ADAM_MAX];
+    uint32_t numel[N2M_ADAM_MAX]; float lr[N2M_ADAM_MAX]; int32_t grad_is_half[N2M_ADAM_MAX];
+    uint32_t count;
+} N2mAdamDesc;   /* HOST struct */
+int n2m_adam_step(const N2mAdamDesc* desc, double beta1, double beta2, float eps, const float* scale,
+                  const float* found_inf, const float* bias, void* stream);
+/* GradScaler.update() on device scalars (floats): found_inf != 0 -> scale *= backoff, tracker = 0; else step += 1,
+ * tracker += 1 and scale *= growth every growth_interval good steps; found_inf is reset to 0 and bias [2] recomputed (in
+ * double) for the next step.  scale / growth_tracker / step / bias may be NULL. */
+int n2m_scaler_update(float* scale, float* growth_tracker, float* found_inf, float* step, float* bias, double beta1,
+                      double beta2, float growth_factor, float backoff_factor, float growth_interval, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * shencoder   (reference: shencoder/src/shencoder.h:9-10, shencoder/src/bindings.cpp:5-8)

@@ -50,13 +50,14 @@ int n2m_field_forward(const float* xyz, const float* dirs, const float* h1, cons
  *   d_h2 [16, M, 2] f16   LEVEL-major for the C=2 encoder (fp16 like autocast's grad of an fp16 tensor)
  *   d_w_* : fp32, same shapes as the weights, ACCUMULATED into (caller zero-fills or keeps running sums)
  * d_sigma == NULL (colour only) or d_rgb == NULL (density only) skip the corresponding branch and its outputs.
- * Pass already-scaled upstream gradients (GradScaler) as they are. */
+ * Pass already-scaled upstream gradients (GradScaler) as they are.  found_inf (device float, may be NULL) is set to 1 when a
+ * weight-gradient value flushed to HBM is not finite; it is never cleared here. */
 int n2m_field_backward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
                        const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
                        const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs, const float* d_sigma,
                        const float* d_rgb, const float* d_specular, float* d_h1, void* d_h2, float* d_w_sigma0,
                        float* d_w_sigma1, float* d_w_color0, float* d_w_color1, float* d_w_color2, float* d_w_spec0,
-                       float* d_w_spec1, void* stream);
+                       float* d_w_spec1, float* found_inf, void* stream);
 
 #ifdef __cplusplus
 }

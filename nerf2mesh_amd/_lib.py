@@ -32,16 +32,18 @@ SIGNATURES = {
     "n2m_grid_encode_backward_bm": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int, _vp],
     "n2m_grid_binned_workspace_bytes": [_u32, _u32, _u32, _u32, _vp, _int, _int],          # returns uint64 (RESTYPES)
     "n2m_grid_encode_backward_binned": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int,
-                                        _vp, _f32, _f32, _f32, _vp, _vp, _u64, _vp],
+                                        _vp, _f32, _f32, _f32, _vp, _vp, _vp, _u64, _vp],
     "n2m_grad_total_variation_binned": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _vp, _u64, _vp],
     "n2m_get_rays": [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
+    "n2m_adam_step": [_vp, ctypes.c_double, ctypes.c_double, _f32, _vp, _vp, _vp, _vp],
+    "n2m_scaler_update": [_vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp],
     "n2m_photo_loss_forward": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _u32, _vp, _vp, _vp, _vp],
     "n2m_photo_loss_backward": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _u32, _vp, _vp, _vp, _vp],
     "n2m_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp],
     "n2m_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
     # include/n2m_mlp.h
     "n2m_field_forward": [_vp] * 11 + [_u32, _int, _int] + [_vp] * 4,
-    "n2m_field_backward": [_vp] * 11 + [_u32, _int, _int] + [_vp] * 13,
+    "n2m_field_backward": [_vp] * 11 + [_u32, _int, _int] + [_vp] * 14,
     # include/n2m_raster.h
     "n2m_rasterize_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "n2m_rasterize_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp],
@@ -58,6 +60,15 @@ SIGNATURES = {
 RESTYPES = {"n2m_grid_binned_workspace_bytes": _u64}   # everything else returns an int status
 
 F32, F16 = 0, 1
+ADAM_MAX = 16
+
+
+class AdamDesc(ctypes.Structure):
+    """N2mAdamDesc of include/n2m_hip.h."""
+    _fields_ = [("param", _vp * ADAM_MAX), ("grad", _vp * ADAM_MAX), ("exp_avg", _vp * ADAM_MAX), ("exp_avg_sq", _vp * ADAM_MAX),
+                ("half_shadow", _vp * ADAM_MAX), ("numel", _u32 * ADAM_MAX), ("lr", _f32 * ADAM_MAX), ("grad_is_half", _i32 * ADAM_MAX),
+                ("count", _u32)]
+
 
 KERNEL_IDS = {"grid_encode_forward": 0, "grid_encode_backward": 1, "grad_total_variation": 2, "march_rays_train_count": 3,
               "march_rays_train_write": 4, "composite_rays_train_forward": 5, "composite_rays_train_backward": 6,

@@ -900,7 +900,7 @@ template <typename T, uint32_t C, int MODE>
 __global__ void __launch_bounds__(1024)
 bin_fill_kernel(const T* __restrict__ grad /*[L,Bstride,C], first sample of this pass*/, const float* __restrict__ inputs, TvParams tv,
                 uint32_t B, uint32_t Bstride, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max,
-                uint32_t* __restrict__ directory, uint64_t* __restrict__ log) {
+                uint32_t* __restrict__ directory, uint64_t* __restrict__ log, float* __restrict__ found_inf) {
     constexpr bool TV = MODE == 1;
     constexpr uint32_t D = 3;
     extern __shared__ __attribute__((aligned(16))) uint64_t bin_stage[];       // kTileEntries entries, grouped by partition
@@ -929,6 +929,7 @@ bin_fill_kernel(const T* __restrict__ grad /*[L,Bstride,C], first sample of this
             for (uint32_t c = 0; c < C; ++c) {
                 const float a = fabsf((float)gr.v[c]);
                 vmax = fmaxf(vmax, a <= 3.0e38f ? a : 1.0f);             // inf / nan: keep the level alive, they bypass the fixed point
+                if (!(a <= 3.0e38f) && found_inf) *found_inf = 1.0f;     // GradScaler's non-finite check, done where the value is read anyway
             }
             uint32_t cell[D];
             float tvv = 0.0f;
@@ -1063,7 +1064,7 @@ template <typename T, uint32_t C>
 __global__ void __launch_bounds__(1024)
 bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners,
                       const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ directory,
-                      const uint64_t* __restrict__ log) {
+                      const uint64_t* __restrict__ log, float* __restrict__ found_inf) {
     constexpr uint32_t P = BinGeom<C>::P;
     extern __shared__ __attribute__((aligned(16))) unsigned long long bin_acc[];   // P * C
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -1133,6 +1134,7 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
                 const long long a = (long long)bin_acc[rel];
                 if (a != 0) {
                     const float f = (float)a * inv;
+                    if (!(fabsf(f) <= 3.0e38f) && found_inf) *found_inf = 1.0f;
                     if (Gl == 1u) gtab[row] += f;
                     else unsafeAtomicAdd(gtab + row, f);
                 }
@@ -1141,6 +1143,7 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
                 const long long a0 = (long long)bin_acc[rel * 2u], a1 = (long long)bin_acc[rel * 2u + 1u];
                 if ((a0 | a1) != 0) {
                     const float f0 = (float)a0 * inv, f1 = (float)a1 * inv;
+                    if (!(fabsf(f0) <= 65504.0f && fabsf(f1) <= 65504.0f) && found_inf) *found_inf = 1.0f;       // rounds to inf in fp16
                     h2* dst = reinterpret_cast<h2*>(gtab + (size_t)row * 2u);
                     if (Gl == 1u) {
                         h2 o = *dst;
@@ -1383,7 +1386,7 @@ BinLayout make_bin_plan(uint32_t Bc, uint32_t C, uint32_t max_level, const int32
 template <typename T, uint32_t C, int MODE>
 int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table, uint32_t B, uint32_t max_level,
                   const int32_t* host_offsets, const LevelTable& lv, uint32_t gridtype, bool align, uint32_t interp, void* workspace,
-                  size_t workspace_bytes, hipStream_t s, const char* fn) {
+                  size_t workspace_bytes, hipStream_t s, const char* fn, float* found_inf = nullptr) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bin_fill_kernel<T, C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 8));
@@ -1403,11 +1406,11 @@ int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table
         const T* g = grad ? grad + (size_t)b0 * C : nullptr;
         const float* x = inputs + (size_t)b0 * 3;
         bin_fill_kernel<T, C, MODE><<<dim3(lay.plan.tiles, max_level), 1024, kTileEntries * 8, s>>>(g, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp,
-                                                                                                     level_max, directory, log);
+                                                                                                     level_max, directory, log, found_inf);
         N2M_CHECK_LAUNCH();
         const uint32_t items = lay.plan.item_prefix[max_level];
         bin_accumulate_kernel<T, C><<<items < 2048u ? items : 2048u, 1024, kBinAccBytes, s>>>(grad_table, lay.plan, lv, gridtype, align, level_max,
-                                                                                                directory, log);
+                                                                                                directory, log, found_inf);
         N2M_CHECK_LAUNCH();
     }
     return 0;
@@ -1567,7 +1570,7 @@ extern "C" int n2m_grid_encode_backward_binned(const void* grad, const float* in
                                                uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
                                                uint32_t gridtype, int align_corners, uint32_t interp, int dtype, const float* tv_embeddings,
                                                float tv_weight, float tv_weight_outer, float tv_inner01, const float* tv_scale,
-                                               void* workspace, uint64_t workspace_bytes, void* stream) {
+                                               float* found_inf, void* workspace, uint64_t workspace_bytes, void* stream) {
     const char* fn = "grid_encode_backward_binned";
     if (int rc = check_dims(fn, D, C, L, max_level, dtype)) return rc;
     N2M_REQUIRE(grad && inputs && host_offsets && grad_embeddings && workspace, N2M_ENULL, "%s: NULL tensor", fn);
@@ -1584,12 +1587,12 @@ extern "C" int n2m_grid_encode_backward_binned(const void* grad, const float* in
                                              (tv_embeddings ? (double)L * (1 + 2 * D) * 4.0 : 0.0)));
     if (dtype == N2M_F16)
         return launch_binned<_Float16, 2, 0>((const _Float16*)grad, inputs, tv, (_Float16*)grad_embeddings, B, max_level, host_offsets, lv, gridtype,
-                                             align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn);
+                                             align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf);
     if (tv_embeddings)
         return launch_binned<float, 1, 2>((const float*)grad, inputs, tv, (float*)grad_embeddings, B, max_level, host_offsets, lv, gridtype,
-                                          align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn);
+                                          align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf);
     return launch_binned<float, 1, 0>((const float*)grad, inputs, tv, (float*)grad_embeddings, B, max_level, host_offsets, lv, gridtype,
-                                      align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn);
+                                      align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf);
 }
 
 extern "C" int n2m_grad_total_variation_binned(const float* inputs, const float* embeddings, float* grad, const int32_t* host_offsets,

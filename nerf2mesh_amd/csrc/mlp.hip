@@ -126,6 +126,7 @@ struct FieldArgs {
     // backward only
     const float* d_sigma; const float* d_rgb; const float* d_specular;
     float* d_h1; _Float16* d_h2; float* dw[7];
+    float* found_inf;        // set to 1 when a weight gradient is not finite (GradScaler's check), may be NULL
 };
 
 // View direction of sample s as fp16 MLP operands.  normalize_dirs: the march kernel hands out the raw ray direction
@@ -310,12 +311,15 @@ __device__ __forceinline__ void dw_to_lds(float* stage, int in_pad, const f16x (
             }
 }
 // LDS staging -> global fp32 weight gradient [out, in] (nn.Linear layout), undoing the logical column order
-__device__ void dw_flush(float* __restrict__ dW, const float* stage, int in_pad, int out, int in, int k_real, int perm) {
+__device__ void dw_flush(float* __restrict__ dW, const float* stage, int in_pad, int out, int in, int k_real, int perm, float* found_inf) {
     for (int idx = threadIdx.x; idx < out * k_real; idx += blockDim.x) {
         const int m = idx / k_real, k = idx - m * k_real;
         const int c = col_of(perm, k, in);
         const float v = stage[m * in_pad + k];
-        if (c >= 0 && v != 0.f) unsafeAtomicAdd(dW + m * in + c, v);
+        if (c >= 0 && v != 0.f) {
+            unsafeAtomicAdd(dW + m * in + c, v);
+            if (!(fabsf(v) <= 3.0e38f) && found_inf) *found_inf = 1.0f;
+        }
     }
 }
 
@@ -543,7 +547,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         __syncthreads();
         dw_to_lds(stage, in_pad, acc, lane);
         __syncthreads();
-        dw_flush(dW, stage, in_pad, out, in, k_real, perm);
+        dw_flush(dW, stage, in_pad, out, in, k_real, perm, a.found_inf);
         __syncthreads();
     };
     if (DO_DENSITY) {
@@ -609,7 +613,7 @@ extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const flo
                                   const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs, const float* d_sigma,
                                   const float* d_rgb, const float* d_specular, float* d_h1, void* d_h2, float* d_w_sigma0,
                                   float* d_w_sigma1, float* d_w_color0, float* d_w_color1, float* d_w_color2, float* d_w_spec0,
-                                  float* d_w_spec1, void* stream) {
+                                  float* d_w_spec1, float* found_inf, void* stream) {
     const float* w[7] = {w_sigma0, w_sigma1, w_color0, w_color1, w_color2, w_spec0, w_spec1};
     float* dw[7] = {d_w_sigma0, d_w_sigma1, d_w_color0, d_w_color1, d_w_color2, d_w_spec0, d_w_spec1};
     const bool density = d_sigma != nullptr;
@@ -633,7 +637,7 @@ extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const flo
     a.xyz = xyz; a.dirs = dirs; a.h1 = h1; a.h2 = (const _Float16*)h2; a.normalize_dirs = normalize_dirs;
     for (int i = 0; i < 7; ++i) { a.w[i] = w[i]; a.dw[i] = dw[i]; }
     a.M = M; a.shading = shading;
-    a.d_sigma = d_sigma; a.d_rgb = d_rgb; a.d_specular = d_specular; a.d_h1 = d_h1; a.d_h2 = (_Float16*)d_h2;
+    a.d_sigma = d_sigma; a.d_rgb = d_rgb; a.d_specular = d_specular; a.d_h1 = d_h1; a.d_h2 = (_Float16*)d_h2; a.found_inf = found_inf;
     hipStream_t s = (hipStream_t)stream;
     N2M_PROF(N2M_K_MLP_BWD, s, (double)M * (12 + 64 + 4 + 64 + (color ? 64 + 12 + 24 + 64 : 0)));
     const size_t smem = (size_t)BWD_HALVES * 2;

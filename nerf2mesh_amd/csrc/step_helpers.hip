@@ -8,6 +8,8 @@
 // (2) Ray generation for a batch of (view, pixel) pairs with the ground-truth gather (nerf/utils.py:242-290 get_rays +
 // nerf/provider.py:330), ~20 launches in torch.
 // Entry points are declared in include/n2m_hip.h.
+#include <string.h>
+
 #include "n2m_common.hpp"
 
 namespace {
@@ -108,6 +110,113 @@ get_rays_kernel(const float* __restrict__ poses /*[V,4,4]*/, const int64_t* __re
     if (images) *reinterpret_cast<float4*>(rgba + (size_t)n * 4) = *reinterpret_cast<const float4*>(images + ((size_t)v * HW + (size_t)p) * 4);
 }
 
+
+// ------------------------------------------------------------------------------------------------ Adam + loss scaling
+// torch.optim.Adam(fused=True) + GradScaler, restated for this step: ONE launch updates every parameter tensor (fp32 master,
+// exp_avg, exp_avg_sq; gradients fp32 or fp16, still multiplied by the loss scale), skips everything when *found_inf != 0 and
+// can refresh an fp16 shadow copy of a table in the same pass (the colour table is consumed as fp16 by the encoder, grid.py:45).
+// A one-thread kernel then does GradScaler.update() and the step count.  Math as in torch's fused kernel:
+//   g = grad / scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+struct AdamTensors {
+    uint64_t p[N2M_ADAM_MAX], g[N2M_ADAM_MAX], m[N2M_ADAM_MAX], v[N2M_ADAM_MAX], shadow[N2M_ADAM_MAX];
+    uint32_t n[N2M_ADAM_MAX], first_block[N2M_ADAM_MAX + 1];
+    float lr[N2M_ADAM_MAX];
+    uint32_t count, g_half_mask;
+};
+
+__global__ void __launch_bounds__(256)
+adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, float eps, const float* __restrict__ scale,
+            const float* __restrict__ found_inf, const float* __restrict__ bias /*[2]: 1-b1^t, sqrt(1-b2^t) of THIS step*/) {
+    if (found_inf && *found_inf != 0.0f) return;                       // GradScaler: skip the whole step
+    uint32_t k = 0;
+    while (k + 1 < t.count && blockIdx.x >= t.first_block[k + 1]) ++k;
+    const uint32_t i0 = ((blockIdx.x - t.first_block[k]) * 256u + threadIdx.x) * 4u;
+    const uint32_t n = t.n[k];
+    if (i0 >= n) return;
+    const float bc1 = bias[0], bc2_sqrt = bias[1];
+    const float step_size = t.lr[k] / bc1;
+    const float inv_scale = scale ? 1.0f / *scale : 1.0f;
+    float* __restrict__ P = reinterpret_cast<float*>(t.p[k]);
+    float* __restrict__ M = reinterpret_cast<float*>(t.m[k]);
+    float* __restrict__ V = reinterpret_cast<float*>(t.v[k]);
+    _Float16* __restrict__ S = reinterpret_cast<_Float16*>(t.shadow[k]);
+    const bool g_half = (t.g_half_mask >> k) & 1u;
+    float p[4], m[4], v[4], g[4];
+    const bool full = i0 + 4u <= n;                                   // tensors are 16-byte aligned (torch allocations)
+    if (full) {
+        const float4 pp = *reinterpret_cast<const float4*>(P + i0), mm = *reinterpret_cast<const float4*>(M + i0),
+                     vv = *reinterpret_cast<const float4*>(V + i0);
+        p[0] = pp.x; p[1] = pp.y; p[2] = pp.z; p[3] = pp.w;
+        m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
+        v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; v[3] = vv.w;
+        if (g_half) {
+            typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+            const h4v gg = *reinterpret_cast<const h4v*>(reinterpret_cast<const _Float16*>(t.g[k]) + i0);
+            g[0] = (float)gg.x; g[1] = (float)gg.y; g[2] = (float)gg.z; g[3] = (float)gg.w;
+        } else {
+            const float4 gg = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(t.g[k]) + i0);
+            g[0] = gg.x; g[1] = gg.y; g[2] = gg.z; g[3] = gg.w;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+            const bool ok = i0 + e < n;
+            p[e] = ok ? P[i0 + e] : 0.f; m[e] = ok ? M[i0 + e] : 0.f; v[e] = ok ? V[i0 + e] : 0.f;
+            g[e] = !ok ? 0.f : (g_half ? (float)reinterpret_cast<const _Float16*>(t.g[k])[i0 + e] : reinterpret_cast<const float*>(t.g[k])[i0 + e]);
+        }
+    }
+#pragma unroll
+    for (uint32_t e = 0; e < 4; ++e) {
+        const float gr = g[e] * inv_scale;
+        m[e] = beta1 * m[e] + omb1 * gr;              // omb = 1 - beta rounded from double: 1.0f - 0.999f is off by 5e-5 relative
+        v[e] = beta2 * v[e] + omb2 * gr * gr;
+        const float denom = sqrtf(v[e]) / bc2_sqrt + eps;
+        p[e] -= step_size * m[e] / denom;
+    }
+    if (full) {
+        *reinterpret_cast<float4*>(P + i0) = make_float4(p[0], p[1], p[2], p[3]);
+        *reinterpret_cast<float4*>(M + i0) = make_float4(m[0], m[1], m[2], m[3]);
+        *reinterpret_cast<float4*>(V + i0) = make_float4(v[0], v[1], v[2], v[3]);
+        if (S) {
+            typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+            h4v o;
+            o.x = (_Float16)p[0]; o.y = (_Float16)p[1]; o.z = (_Float16)p[2]; o.w = (_Float16)p[3];
+            *reinterpret_cast<h4v*>(S + i0) = o;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e)
+            if (i0 + e < n) { P[i0 + e] = p[e]; M[i0 + e] = m[e]; V[i0 + e] = v[e]; if (S) S[i0 + e] = (_Float16)p[e]; }
+    }
+}
+
+// GradScaler.update() (torch/amp/grad_scaler.py:_amp_update_scale_) + step count + found_inf reset, one thread
+__global__ void scaler_update_kernel(float* scale, float* growth_tracker, float* found_inf, float* step, float* bias, double beta1,
+                                     double beta2, float growth_factor, float backoff_factor, float growth_interval) {
+    if (*found_inf != 0.0f) {
+        if (scale) *scale *= backoff_factor;
+        if (growth_tracker) *growth_tracker = 0.0f;
+    } else {
+        if (step) *step += 1.0f;
+        if (growth_tracker) {
+            const float ok = *growth_tracker + 1.0f;
+            if (ok >= growth_interval) {
+                const float ns = *scale * growth_factor;
+                if (scale && ns <= 3.0e38f) *scale = ns;            // do not grow into inf
+                *growth_tracker = 0.0f;
+            } else {
+                *growth_tracker = ok;
+            }
+        }
+    }
+    *found_inf = 0.0f;
+    if (step && bias) {                       // bias corrections of the NEXT step, in double like torch's host-side arithmetic
+        const double t = (double)*step + 1.0;
+        bias[0] = (float)(1.0 - pow(beta1, t));
+        bias[1] = (float)sqrt(1.0 - pow(beta2, t));
+    }
+}
+
 }  // namespace
 
 extern "C" int n2m_get_rays(const float* poses, const int64_t* cam, const int64_t* pix, uint32_t N, uint32_t H, uint32_t W, float fx, float fy,
@@ -142,6 +251,41 @@ extern "C" int n2m_photo_loss_backward(const float* image, const float* weights_
     hipStream_t s = (hipStream_t)stream;
     photo_loss_backward_kernel<<<n2m_ceil_div(N, 256), 256, 0, s>>>(image, weights_sum, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask, N, grad_loss,
                                                                      d_image, d_weights_sum);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, float eps, const float* scale, const float* found_inf,
+                             const float* bias, void* stream) {
+    N2M_REQUIRE(d != nullptr && bias != nullptr, N2M_ENULL, "adam_step: NULL descriptor / bias");
+    N2M_REQUIRE(d->count >= 1 && d->count <= N2M_ADAM_MAX, N2M_EINVAL, "adam_step: 1..%d tensors per call (got %u)", N2M_ADAM_MAX, d->count);
+    AdamTensors t;
+    memset(&t, 0, sizeof(t));
+    uint32_t blocks = 0;
+    for (uint32_t k = 0; k < d->count; ++k) {
+        N2M_REQUIRE(d->param[k] && d->grad[k] && d->exp_avg[k] && d->exp_avg_sq[k], N2M_ENULL, "adam_step: NULL tensor %u", k);
+        t.p[k] = (uint64_t)d->param[k]; t.g[k] = (uint64_t)d->grad[k]; t.m[k] = (uint64_t)d->exp_avg[k]; t.v[k] = (uint64_t)d->exp_avg_sq[k];
+        t.shadow[k] = (uint64_t)d->half_shadow[k];
+        t.n[k] = d->numel[k];
+        t.lr[k] = d->lr[k];
+        t.first_block[k] = blocks;
+        blocks += n2m_ceil_div(d->numel[k], 1024);
+        if (d->grad_is_half[k]) t.g_half_mask |= 1u << k;
+    }
+    t.first_block[d->count] = blocks;
+    t.count = d->count;
+    if (blocks == 0) return 0;
+    adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(t, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, scale,
+                                                         found_inf, bias);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_scaler_update(float* scale, float* growth_tracker, float* found_inf, float* step, float* bias, double beta1,
+                                 double beta2, float growth_factor, float backoff_factor, float growth_interval, void* stream) {
+    N2M_REQUIRE(found_inf != nullptr, N2M_ENULL, "scaler_update: found_inf is NULL");
+    scaler_update_kernel<<<1, 1, 0, (hipStream_t)stream>>>(scale, growth_tracker, found_inf, step, bias, beta1, beta2, growth_factor,
+                                                           backoff_factor, growth_interval);
     N2M_CHECK_LAUNCH();
     return 0;
 }

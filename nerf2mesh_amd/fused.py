@@ -37,10 +37,17 @@ def _encode_backward_lm(grad_lm, x01, emb, enc, max_level):
     g = torch.zeros_like(emb)
     from .gridencoder import binned_backward
     req = getattr(enc, "tv_request", None)          # set by the trainer: fold the TV gradient into this backward
-    if req is not None and binned_backward(enc, grad_lm, x01, g, max_level, tv=(emb, req["weight"], req["weight_outer"], req["inner01"], req["scale"])):
+    amp = getattr(enc, "amp_request", None)         # set by optim.FusedAdamAMP users: {"found_inf": tensor, "flagged": bool}
+    finf = amp["found_inf"] if amp is not None else None
+    if req is not None and binned_backward(enc, grad_lm, x01, g, max_level, tv=(emb, req["weight"], req["weight_outer"], req["inner01"], req["scale"]),
+                                           found_inf=finf):
         req["done"] = True
+        if amp is not None:
+            amp["flagged"] = True
         return g
-    if binned_backward(enc, grad_lm, x01, g, max_level):
+    if binned_backward(enc, grad_lm, x01, g, max_level, found_inf=finf):
+        if amp is not None:
+            amp["flagged"] = True
         return g
     L.call("n2m_grid_encode_backward", _p(grad_lm), _p(x01), _p(emb), _p(enc.offsets), _p(g), B, 3, C, Lv, max_level,
            float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None, None, enc.gridtype_id, int(bool(enc.align_corners)),
@@ -66,7 +73,7 @@ class _fused_field(Function):
         rgb = spec = h2 = emb2h = None
         ws = [w.float().contiguous() for w in (w0, w1, w2, w3, w4, w5, w6)]
         if want_color:
-            emb2h = emb2.half().contiguous()               # autocast: C even -> fp16 table (gridencoder/grid.py:45)
+            emb2h = net.encoder_color.half_table() if hasattr(net.encoder_color, "half_table") else emb2.half().contiguous()   # grid.py:45
             h2 = _encode_lm(x01, emb2h, net.encoder_color, max_level)
             dirs = dirs.float().contiguous() if shading != 0 else None
             rgb = torch.empty(M, 3, dtype=torch.float32, device=xyz.device)
@@ -107,12 +114,21 @@ class _fused_field(Function):
         for w in ws:
             dws.append(flat[o:o + w.numel()].view_as(w))
             o += w.numel()
+        amp = getattr(net, "amp_request", None)          # optim.FusedAdamAMP: weight-gradient finiteness is checked by the kernel
         L.call("n2m_field_backward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, ctx.normalize_dirs, _p(d_sigma), _p(d_rgb),
-               _p(d_spec), _p(d_h1), _p(d_h2), *[_p(g) for g in dws], L.stream())
+               _p(d_spec), _p(d_h1), _p(d_h2), *[_p(g) for g in dws], _p(amp["found_inf"]) if amp is not None else None, L.stream())
+        if amp is not None:
+            amp["flagged"] = True
         g1 = _encode_backward_lm(d_h1, x01, emb1, net.encoder, max_level) if want_density else None
         g2 = None
         if want_color:
-            g2 = _encode_backward_lm(d_h2, x01, emb2h, net.encoder_color, max_level).float()
+            g2 = _encode_backward_lm(d_h2, x01, emb2h, net.encoder_color, max_level)
+            amp2 = getattr(net.encoder_color, "amp_request", None)
+            if amp2 is not None and amp2.get("keep_half"):
+                amp2["grad_half"] = g2           # the optimizer reads the fp16 gradient directly; autograd gets no fp32 copy
+                g2 = None
+            else:
+                g2 = g2.float()
         if not want_color:
             dws[2:] = [None] * 5
         elif shading == 0:

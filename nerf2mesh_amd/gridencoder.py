@@ -99,7 +99,7 @@ def _host_offsets(enc):
     return arr
 
 
-def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level, tv=None):
+def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level, tv=None, found_inf=None):
     """grad_embeddings += scatter of grad_lm [L,B,C] through the binned fixed-point kernels (include/n2m_hip.h);
     returns False when the configuration is not covered (caller uses n2m_grid_encode_backward).
     tv = (embeddings fp32, weight, weight_outer, inner01, scale tensor | None) folds the TV gradient over the same inputs in."""
@@ -117,7 +117,7 @@ def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level, tv=None):
     tv_emb, tv_w, tv_wo, tv_in, tv_scale = tv if tv is not None else (None, 0.0, 0.0, 1.0, None)
     L.call("n2m_grid_encode_backward_binned", _p(grad_lm), _p(x01), ho.ctypes.data, _p(grad_embeddings), B, 3, C, enc.num_levels, max_level,
            float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), enc.interp_id, dt,
-           _p(tv_emb), float(tv_w), float(tv_wo), float(tv_in), _p(tv_scale), _p(ws), ws.numel(), L.stream())
+           _p(tv_emb), float(tv_w), float(tv_wo), float(tv_in), _p(tv_scale), _p(found_inf), _p(ws), ws.numel(), L.stream())
     return True
 
 
@@ -201,6 +201,18 @@ class GridEncoder(nn.Module):
         out = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, inputs.requires_grad,
                           self.gridtype_id, self.align_corners, self.interp_id, max_level)
         return out.view(prefix + [self.output_dim])
+
+    def half_table(self):
+        """fp16 view of the table as the encoder consumes it under autocast (grid.py:45 casts every call).  The copy is cached and
+        re-made only when the fp32 master changed through torch (version counter); optim.FusedAdamAMP refreshes it in its own
+        update pass and marks it fresh."""
+        emb = self.embeddings
+        sh = getattr(self, "_half_shadow", None)
+        if sh is None or sh.shape != emb.shape or sh.device != emb.device or self._half_version != emb._version:
+            sh = emb.detach().half().contiguous()
+            self._half_shadow = sh
+            self._half_version = emb._version
+        return sh
 
     @torch.no_grad()
     def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):

@@ -1,0 +1,85 @@
+"""Adam + dynamic loss scaling for the whole parameter set in two launches (C ABI: n2m_adam_step / n2m_scaler_update).
+
+Same arithmetic as `torch.optim.Adam(..., fused=True)` driven by `torch.amp.GradScaler` (main.py:221, nerf/utils.py:506,
+1187-1190): gradients are divided by the loss scale inside the update, the whole step is skipped when a gradient is not finite,
+the scale backs off / grows like GradScaler.update().  What differs is where the work happens:
+* ONE kernel updates all tensors (torch: 4 multi-tensor launches + an unscale / inf-check pass over every gradient first);
+* the non-finite check of the two big table gradients and of the MLP weight gradients is done by the kernels that produce them
+  (they set `found_inf`); only gradients that did not come from those kernels are checked with the stock foreach op;
+* the colour table's fp16 working copy is refreshed in the same pass, and its gradient is read as fp16.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+class FusedAdamAMP(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, amp=True, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5,
+                 growth_interval=2000):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        ps = [p for g in self.param_groups for p in g["params"]]
+        if len(ps) > L.ADAM_MAX:
+            raise ValueError(f"FusedAdamAMP handles at most {L.ADAM_MAX} tensors per step (got {len(ps)})")
+        dev = ps[0].device
+        if dev.type != "cuda" or any(p.dtype != torch.float32 or not p.is_contiguous() for p in ps):
+            raise ValueError("FusedAdamAMP needs contiguous fp32 CUDA parameters")
+        self.amp = bool(amp)
+        self.scale = torch.full((), float(init_scale) if amp else 1.0, device=dev)
+        self.growth_tracker = torch.zeros((), device=dev)
+        self.found_inf = torch.zeros((), device=dev)
+        self.step_count = torch.zeros((), device=dev)          # successful steps, on the device (a skipped step does not count)
+        self.growth = (float(growth_factor), float(backoff_factor), float(growth_interval))
+        b1, b2 = betas
+        self.bias = torch.tensor([1.0 - b1, (1.0 - b2) ** 0.5], dtype=torch.float32).to(dev)       # bias corrections of step t = 1
+        self._one = torch.ones((), device=dev)
+        for p in ps:
+            self.state[p] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+        self.shadows = {}          # param -> callable returning the fp16 shadow tensor to refresh (or None)
+        self.half_grads = {}       # param -> callable returning an fp16 gradient produced outside autograd (or None)
+
+    def scale_loss(self, loss):
+        return loss * self.scale if self.amp else loss
+
+    @torch.no_grad()
+    def step(self, flagged=()):
+        """flagged: parameters whose gradients were already checked for inf/nan by the kernels that produced them."""
+        flagged = {id(p) for p in flagged}
+        desc = L.AdamDesc()
+        keep, unchecked, k = [], [], 0
+        for group in self.param_groups:
+            for p in group["params"]:
+                hg = self.half_grads.get(p)
+                g = hg() if hg is not None else None
+                is_half = g is not None
+                if g is None:
+                    g = p.grad
+                if g is None:
+                    continue
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                if id(p) not in flagged:
+                    unchecked.append(g)
+                st = self.state[p]
+                sh = self.shadows.get(p)
+                sh = sh() if sh is not None else None
+                desc.param[k], desc.grad[k] = p.data_ptr(), g.data_ptr()
+                desc.exp_avg[k], desc.exp_avg_sq[k] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                desc.half_shadow[k] = sh.data_ptr() if sh is not None else None
+                desc.numel[k], desc.lr[k], desc.grad_is_half[k] = p.numel(), float(group["lr"]), int(is_half)
+                keep += [g, sh]
+                k += 1
+        if k == 0:
+            return
+        desc.count = k
+        if unchecked and self.amp:
+            for dt in {g.dtype for g in unchecked}:
+                torch._amp_foreach_non_finite_check_and_unscale_([g for g in unchecked if g.dtype == dt], self.found_inf, self._one)
+        b1, b2 = self.param_groups[0]["betas"]
+        s = L.stream()
+        L.call("n2m_adam_step", ctypes.addressof(desc), float(b1), float(b2), float(self.param_groups[0]["eps"]),
+               L.ptr(self.scale) if self.amp else None, L.ptr(self.found_inf), L.ptr(self.bias), s)
+        gf, bf, gi = self.growth
+        L.call("n2m_scaler_update", L.ptr(self.scale) if self.amp else None, L.ptr(self.growth_tracker) if self.amp else None,
+               L.ptr(self.found_inf), L.ptr(self.step_count), L.ptr(self.bias), float(b1), float(b2), gf, bf, gi, s)

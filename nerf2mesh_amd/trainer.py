@@ -23,7 +23,19 @@ class Stage0Trainer:
         self.num_rays = opt.num_rays
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(seed + rank)                  # every rank draws its own rays
-        self.optimizer = torch.optim.Adam(model.get_params(opt.lr), eps=1e-15, fused=(device.type == "cuda"))   # main.py:221
+        # main.py:221 Adam(eps=1e-15) + nerf/utils.py:506 GradScaler.  Single GPU with the fused field: optim.FusedAdamAMP does both
+        # in two launches and takes the inf/nan verdict from the kernels that produce the gradients.
+        self.amp_adam = device.type == "cuda" and world_size == 1 and bool(getattr(opt, "fused_mlp", False)) and not opt.sdf \
+            and getattr(opt, "ind_dim", 0) == 0
+        if self.amp_adam:
+            from .optim import FusedAdamAMP
+            self.optimizer = FusedAdamAMP(model.get_params(opt.lr), eps=1e-15, amp=bool(opt.fp16))
+            encc = model.encoder_color
+            self._amp = {}
+            self.optimizer.shadows[encc.embeddings] = lambda: encc.half_table()
+            self.optimizer.half_grads[encc.embeddings] = lambda: self._amp.get("color", {}).get("grad_half")
+        else:
+            self.optimizer = torch.optim.Adam(model.get_params(opt.lr), eps=1e-15, fused=(device.type == "cuda"))
         iters = opt.iters
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
             self.optimizer, lambda it: 0.01 + 0.99 * (it / 500) if it <= 500 else 0.1 ** ((it - 500) / (iters - 500)))   # main.py:239
@@ -120,28 +132,49 @@ class Stage0Trainer:
         tv_req = None
         if opt.lambda_tv > 0 and M > 0 and self.fused_tv and getattr(model, "_can_fuse", lambda: False)() \
                 and model.max_level >= model.encoder.num_levels:
-            scale_t = self.scaler.scale(self._one) if self.scaler.is_enabled() else None      # device scalar, no host sync
+            if self.amp_adam:
+                scale_t = self.optimizer.scale if self.optimizer.amp else None
+            else:
+                scale_t = self.scaler.scale(self._one) if self.scaler.is_enabled() else None   # device scalar, no host sync
             tv_req = dict(weight=opt.lambda_tv, weight_outer=opt.lambda_tv * (10 if opt.bound > 1 else 1), inner01=0.5 / model.bound,
                           scale=scale_t, done=False)
             model.encoder.tv_request = tv_req
-        self.scaler.scale(loss).backward()
-        model.encoder.tv_request = None
-        tv_pending = tv_req is None or not tv_req["done"]
-
         xyzs = out["xyzs"]
-        if self.sync is None:
-            self.scaler.unscale_(self.optimizer)                         # nerf/utils.py:812
-            if tv_pending:
-                self._tv(xyzs, 1.0)
+        if self.amp_adam:
+            o = self.optimizer
+            self._amp = {"density": dict(found_inf=o.found_inf, flagged=False), "color": dict(found_inf=o.found_inf, flagged=False, keep_half=True),
+                         "mlp": dict(found_inf=o.found_inf, flagged=False)}
+            model.encoder.amp_request, model.encoder_color.amp_request, model.amp_request = self._amp["density"], self._amp["color"], self._amp["mlp"]
+            o.scale_loss(loss).backward()
+            model.encoder.amp_request = model.encoder_color.amp_request = model.amp_request = None
+            model.encoder.tv_request = None
+            if tv_req is None or not tv_req["done"]:
+                self._tv(xyzs, 1.0, scale_tensor=o.scale if o.amp else None)        # gradients are still scaled here
+            flagged = []
+            if self._amp["density"]["flagged"]:
+                flagged.append(model.encoder.embeddings)
+            if self._amp["color"]["flagged"]:
+                flagged.append(model.encoder_color.embeddings)
+            if self._amp["mlp"]["flagged"]:
+                flagged += [p for m in (model.sigma_net, model.color_net, model.specular_net) for p in m.parameters()]
+            o.step(flagged=flagged)
         else:
-            # multi-GPU: every rank adds its own TV term (pre-multiplied by the loss scale), then the summed
-            # gradients are averaged, then unscaled -- so all ranks see identical gradients and inf flags
-            if tv_pending:
-                self._tv(xyzs, self.scaler.get_scale() if self.scaler.is_enabled() else 1.0)
-            self.sync.all_reduce()
-            self.scaler.unscale_(self.optimizer)
-        self.scaler.step(self.optimizer)
-        self.scaler.update()
+            self.scaler.scale(loss).backward()
+            model.encoder.tv_request = None
+            tv_pending = tv_req is None or not tv_req["done"]
+            if self.sync is None:
+                self.scaler.unscale_(self.optimizer)                         # nerf/utils.py:812
+                if tv_pending:
+                    self._tv(xyzs, 1.0)
+            else:
+                # multi-GPU: every rank adds its own TV term (pre-multiplied by the loss scale), then the summed
+                # gradients are averaged, then unscaled -- so all ranks see identical gradients and inf flags
+                if tv_pending:
+                    self._tv(xyzs, self.scaler.get_scale() if self.scaler.is_enabled() else 1.0)
+                self.sync.all_reduce()
+                self.scaler.unscale_(self.optimizer)
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
         self.scheduler.step()
         self.loss_acc += loss.detach()
         if self.pipeline:
@@ -150,10 +183,12 @@ class Stage0Trainer:
             self._next = self._prepare()
         return loss
 
-    def _tv(self, xyzs, scale):
+    def _tv(self, xyzs, scale, scale_tensor=None):
         opt, model = self.opt, self.model
         if opt.lambda_tv <= 0 or xyzs is None or xyzs.shape[0] == 0:
             return
+        if scale_tensor is not None:
+            scale = scale * float(scale_tensor)          # rare path (TV not folded into the backward): one host read-back
         lam = opt.lambda_tv * scale
         if opt.bound > 1:                                                # nerf/utils.py:815-821
             inner = xyzs.abs().amax(dim=-1) <= 1

@@ -449,7 +449,7 @@ def _binned_backward(be, g, X, offs, ge_out, C, Lv, max_level, S, H, gridtype, a
     assert need > 0
     ws = be["torch"].empty(need, dtype=be["torch"].uint8, device="cuda")
     L.call("n2m_grid_encode_backward_binned", g.data_ptr(), X.data_ptr(), ho.ctypes.data, ge_out.data_ptr(), B, 3, C, Lv, max_level, S, H,
-           gridtype, int(align), interp, dt, None, 0.0, 0.0, 1.0, None, ws.data_ptr(), need, L.stream())
+           gridtype, int(align), interp, dt, None, 0.0, 0.0, 1.0, None, None, ws.data_ptr(), need, L.stream())
 
 
 @pytest.mark.parametrize("C,half,gridtype,align,interp,log2", [
@@ -603,7 +603,7 @@ def test_grid_backward_binned_with_fused_tv(be, oracle):
     out = torch.zeros(int(offs[-1]), 1, device="cuda")
     scale = torch.tensor([64.0], device="cuda")
     L.call("n2m_grid_encode_backward_binned", dev(be, g).data_ptr(), dev(be, x).data_ptr(), ho.ctypes.data, out.data_ptr(), B, 3, 1, 16, 16, S, 16,
-           0, 0, 0, L.F32, dev(be, emb).data_ptr(), 1e-4, 1e-3, 0.3, scale.data_ptr(), ws.data_ptr(), need, L.stream())
+           0, 0, 0, L.F32, dev(be, emb).data_ptr(), 1e-4, 1e-3, 0.3, scale.data_ptr(), None, ws.data_ptr(), need, L.stream())
     ref = oracle.grid_encode_backward(g, x, emb, offs, S, 16, 16, None, 0, False, 0)
     inner = np.abs(x - 0.5).max(-1) <= 0.3
     oracle.grad_total_variation(x[inner], emb, ref, offs, 1e-4 * 64, S, 16, 0, False)

@@ -1,0 +1,69 @@
+"""FusedAdamAMP (n2m_adam_step + n2m_scaler_update) against torch.optim.Adam + torch.amp.GradScaler on the same gradients."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fused_adam_amp_matches_torch_adam_and_gradscaler():
+    import torch
+    from nerf2mesh_amd.optim import FusedAdamAMP
+    torch.manual_seed(0)
+    shapes = [(1000, 2), (37,), (64, 35), (5, 1)]                       # an odd tail, a tiny tensor
+    ref = [torch.randn(s, device="cuda").requires_grad_() for s in shapes]
+    mine = [p.detach().clone().requires_grad_() for p in ref]
+    lrs = [1e-2, 1e-2, 1e-3, 1e-2]
+    opt_ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(ref, lrs)], eps=1e-15)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=3)
+    opt = FusedAdamAMP([{"params": [p], "lr": lr} for p, lr in zip(mine, lrs)], eps=1e-15, init_scale=1024.0, growth_interval=3)
+    shadow = mine[0].detach().half()
+    opt.shadows[mine[0]] = lambda: shadow
+    half_grad = {}
+    opt.half_grads[mine[0]] = lambda: half_grad.get("g")
+    for step in range(9):
+        gs = [torch.randn(s, device="cuda") * (10.0 ** (step % 3 - 2)) for s in shapes]      # stays inside fp16 after scaling
+        gs[0] = gs[0].half().float()                                    # representable in fp16: both sides see the same numbers
+        if step == 4:
+            gs[2][3, 3] = float("inf")                                  # GradScaler must skip this step and back off
+        scaler.scale(torch.zeros((), device="cuda"))                    # lazily creates the scale tensor / marks the iteration
+        s_ref, s_mine = scaler.get_scale(), float(opt.scale)
+        assert s_ref == s_mine
+        for p, g in zip(ref, gs):
+            p.grad = g * s_ref
+        scaler.step(opt_ref)
+        scaler.update()
+        for i, (p, g) in enumerate(zip(mine, gs)):
+            if i == 0:
+                p.grad = None
+                half_grad["g"] = (g * s_mine).half()
+            else:
+                p.grad = g * s_mine
+        opt.step(flagged=[mine[0]] if step != 4 else [])               # unflagged tensors go through the stock inf check
+        for a, b in zip(ref, mine):
+            np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+        assert torch.equal(shadow, mine[0].detach().half())
+    assert float(opt.step_count) == 8 and float(opt.found_inf) == 0
+    assert scaler.get_scale() == float(opt.scale)
+    for a, b in zip(ref, mine):
+        st_a, st_b = opt_ref.state[a], opt.state[b]
+        np.testing.assert_allclose(st_b["exp_avg"].cpu().numpy(), st_a["exp_avg"].cpu().numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(st_b["exp_avg_sq"].cpu().numpy(), st_a["exp_avg_sq"].cpu().numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_backward_kernels_raise_found_inf():
+    """The producing kernels flag non-finite gradients (binned table backward: value read / sum written; field backward: dW)."""
+    import torch
+    from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward
+    enc = GridEncoder(level_dim=2, desired_resolution=2048).cuda()
+    B = 5000
+    x = torch.rand(B, 3, device="cuda")
+    g = (torch.randn(16, B, 2, device="cuda") * 0.1).half()
+    out = torch.zeros(enc.host_offsets[-1], 2, device="cuda", dtype=torch.float16)
+    flag = torch.zeros((), device="cuda")
+    assert binned_backward(enc, g, x, out, 16, found_inf=flag) and float(flag) == 0
+    g2 = g.clone(); g2[7, 123, 1] = float("nan")
+    assert binned_backward(enc, g2, x, torch.zeros_like(out), 16, found_inf=flag) and float(flag) == 1
+    flag.zero_()
+    g3 = torch.full_like(g, 60000.0)                                   # finite inputs, sums overflow fp16 at the flush
+    x3 = x[:1].expand(B, 3).contiguous()
+    assert binned_backward(enc, g3, x3, torch.zeros_like(out), 16, found_inf=flag) and float(flag) == 1
