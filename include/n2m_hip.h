@@ -200,6 +200,19 @@ int n2m_grad_total_variation_binned(const float* inputs, const float* embeddings
                                     uint32_t H, uint32_t gridtype, int align_corners, void* workspace,
                                     uint64_t workspace_bytes, void* stream);
 
+/* Both encoders of nerf2mesh's field in one call: the density table (fp32, C=1) and the colour table (fp16, C=2) share
+ * their level geometry and are queried at the same inputs (nerf/network.py:92-108), so the index arithmetic and the partition
+ * sort of the binned backward are done once and two update logs are written.  grad1 [L,B] f32, grad2 [L,B,2] f16, one
+ * host_offsets for both tables; TV (tv_embeddings = the fp32 table) and found_inf as in n2m_grid_encode_backward_binned. */
+uint64_t n2m_grid_binned_pair_workspace_bytes(uint32_t B, uint32_t max_level, const int32_t* host_offsets);
+int n2m_grid_encode_backward_binned_pair(const float* grad1, const void* grad2, const float* inputs,
+                                         const int32_t* host_offsets, float* grad_embeddings1,
+                                         void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level, float S,
+                                         uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                         const float* tv_embeddings, float tv_weight, float tv_weight_outer,
+                                         float tv_inner01, const float* tv_scale, float* found_inf, void* workspace,
+                                         uint64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * training-step helpers (no reference kernel: the reference composes these from torch ops)
  * ---------------------------------------------------------------------------------------------------- */

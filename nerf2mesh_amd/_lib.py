@@ -33,6 +33,9 @@ SIGNATURES = {
     "n2m_grid_binned_workspace_bytes": [_u32, _u32, _u32, _u32, _vp, _int, _int],          # returns uint64 (RESTYPES)
     "n2m_grid_encode_backward_binned": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int,
                                         _vp, _f32, _f32, _f32, _vp, _vp, _vp, _u64, _vp],
+    "n2m_grid_binned_pair_workspace_bytes": [_u32, _u32, _vp],                                  # returns uint64 (RESTYPES)
+    "n2m_grid_encode_backward_binned_pair": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
+                                             _vp, _f32, _f32, _f32, _vp, _vp, _vp, _u64, _vp],
     "n2m_grad_total_variation_binned": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _vp, _u64, _vp],
     "n2m_get_rays": [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "n2m_adam_step": [_vp, ctypes.c_double, ctypes.c_double, _f32, _vp, _vp, _vp, _vp],
@@ -57,7 +60,7 @@ SIGNATURES = {
     "n2m_prof_read": [_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
 }
 
-RESTYPES = {"n2m_grid_binned_workspace_bytes": _u64}   # everything else returns an int status
+RESTYPES = {"n2m_grid_binned_workspace_bytes": _u64, "n2m_grid_binned_pair_workspace_bytes": _u64}   # everything else returns an int status
 
 F32, F16 = 0, 1
 ADAM_MAX = 16
@@ -110,16 +113,32 @@ def call(name, *args):
 _WORKSPACE = {}
 
 
-def workspace(device, nbytes):
-    """Grow-only device scratch shared by the binned grid kernels (stream-ordered, so one buffer per device is enough)."""
+def workspace(device, nbytes, slot=0):
+    """Grow-only device scratch of the binned grid kernels: one buffer per (device, slot); uses on one stream are ordered, so a
+    slot is only needed per concurrently running stream."""
     import torch
-    buf = _WORKSPACE.get(device)
+    key = (device, slot)
+    buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None
-        _WORKSPACE.pop(device, None)
+        _WORKSPACE.pop(key, None)
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
-        _WORKSPACE[device] = buf
+        _WORKSPACE[key] = buf
     return buf
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, slot=1):
+    """A second stream per device for work that may overlap the main stream (created once, high priority is not requested)."""
+    import torch
+    key = (device, slot)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[key] = st
+    return st
 
 
 def ptr(t):

@@ -897,7 +897,7 @@ struct TvParams {
 // MODE 0: backward entries; MODE 1: TV entries only (8 samples per thread); MODE 2: backward + TV folded into vertex 000's
 // entry (the TV cell floor(x*scale+0.5) IS that vertex) -- fp32 C=1 tables.
 template <typename T, uint32_t C, int MODE>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))      // <= 64 VGPRs: two workgroups per CU
 bin_fill_kernel(const T* __restrict__ grad /*[L,Bstride,C], first sample of this pass*/, const float* __restrict__ inputs, TvParams tv,
                 uint32_t B, uint32_t Bstride, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max,
                 uint32_t* __restrict__ directory, uint64_t* __restrict__ log, float* __restrict__ found_inf) {
@@ -1060,12 +1060,179 @@ bin_fill_kernel(const T* __restrict__ grad /*[L,Bstride,C], first sample of this
     for (uint32_t i = tid; i < total; i += 1024) seg[i] = bin_stage[i];
 }
 
-template <typename T, uint32_t C>
+// Both encoders of the field in ONE fill.  nerf2mesh's density (fp32, C=1) and colour (fp16, C=2) tables share their
+// geometry (levels, resolutions, hash, offsets) and are queried at the same points, so cell, weights, rows, partition sort and
+// directory are computed once and two logs are written (same structure, different values).  Measured before this: the
+// front end (loads, index arithmetic, sort) is ~80 % of a fill, the log traffic the rest.  Partitions hold kPairP rows for
+// both tables (C=1 then uses half of its LDS accumulator).  TV (template flag) rides on vertex 000 of the fp32 log.
+constexpr uint32_t kPairP = kBinAccBytes / 16u;      // 4096 rows
+
+template <bool TV>
 __global__ void __launch_bounds__(1024)
+bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Float16* __restrict__ grad2 /*[L,Bstride,2]*/,
+                     const float* __restrict__ inputs, TvParams tv, uint32_t B, uint32_t Bstride, BinPlan plan, LevelTable lv,
+                     uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max /*[2][32]*/,
+                     uint32_t* __restrict__ directory, uint64_t* __restrict__ log1, uint64_t* __restrict__ log2,
+                     float* __restrict__ found_inf) {
+    constexpr uint32_t D = 3;
+    constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
+    extern __shared__ __attribute__((aligned(16))) uint64_t bin_stage[];
+    __shared__ uint32_t cnt[kMaxPartsPerLevel];
+    __shared__ uint32_t wave_tot[16], wave_max[2][16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t tile = blockIdx.x, level = blockIdx.y;
+    const uint32_t parts = plan.parts[level], size = plan.size[level];
+    for (uint32_t i = tid; i < parts; i += 1024) cnt[i] = 0;
+    __syncthreads();
+
+    const float scale = lv.scale[level];
+    const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
+    const PartMap pm(parts, 0, kLog2P, !ix.hashed && parts > 1u);
+    uint32_t e_pr[8], e_v1[8], e_v2[8], e_slot[8];        // e_pr = partition << 16 | row in partition (rel < 4096, parts <= 2048)
+    uint32_t vmask = 0;
+    float vmax1 = 0.0f, vmax2 = 0.0f;
+
+    const uint32_t s = tile * 1024u + tid;
+    float x[D] = {2.f, 2.f, 2.f};
+    if (s < B) load_point<D>(inputs, s, x);
+    if (!outside_unit_cube<D>(x)) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const float g1 = grad1[(size_t)level * Bstride + s];
+        const h2 g2 = *reinterpret_cast<const h2*>(grad2 + ((size_t)level * Bstride + s) * 2);
+        const float g2x = (float)g2.x, g2y = (float)g2.y;
+        const float a1 = fabsf(g1), a2 = fmaxf(fabsf(g2x), fabsf(g2y));
+        vmax1 = a1 <= 3.0e38f ? a1 : 1.0f;
+        vmax2 = a2 <= 3.0e38f ? a2 : 1.0f;           // nan: fmaxf drops it, the half2 check below catches it
+        if ((!(a1 <= 3.0e38f) || !(fabsf(g2x) <= 3.0e38f) || !(fabsf(g2y) <= 3.0e38f)) && found_inf) *found_inf = 1.0f;
+        if (!(fabsf(g2x) <= 3.0e38f) || !(fabsf(g2y) <= 3.0e38f)) vmax2 = fmaxf(vmax2, 1.0f);
+        uint32_t cell[D];
+        float frac[D], dfrac[D];
+        locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
+        float tvv = 0.0f;
+        if constexpr (TV) {
+            const bool inner = fmaxf(fmaxf(fabsf(x[0] - 0.5f), fabsf(x[1] - 0.5f)), fabsf(x[2] - 0.5f)) <= tv.inner01;
+            float w = (inner ? tv.weight : tv.weight_outer);
+            if (tv.scale_ptr) w *= *tv.scale_ptr;
+            tvv = tv_term(tv.table + (size_t)plan.row0[level], ix, cell, ix.row(cell), lv.resolution[level], w / (float)(2 * D));
+            const float a = fabsf(tvv);
+            vmax1 += a <= 3.0e38f ? a : 1.0f;
+        }
+        // per-axis terms of the row index, hoisted (hashed power-of-two table / dense table without wrap / generic)
+        const bool fast_hash = ix.hashed && ix.pow2, fast_dense = !ix.hashed && !ix.wrap;
+        uint32_t tx[2], ty[2], tz[2];
+        if (fast_hash) {
+            tx[0] = cell[0]; tx[1] = cell[0] + 1u;
+            ty[0] = cell[1] * kPrimes[1]; ty[1] = ty[0] + kPrimes[1];
+            tz[0] = cell[2] * kPrimes[2]; tz[1] = tz[0] + kPrimes[2];
+        } else {
+            tx[0] = cell[0]; tx[1] = cell[0] + 1u;
+            ty[0] = cell[1] * ix.stride[1]; ty[1] = ty[0] + ix.stride[1];
+            tz[0] = cell[2] * ix.stride[2]; tz[1] = tz[0] + ix.stride[2];
+        }
+        const float wx[2] = {1 - frac[0], frac[0]}, wy[2] = {1 - frac[1], frac[1]}, wz[2] = {1 - frac[2], frac[2]};
+#pragma unroll
+        for (uint32_t corner = 0; corner < 8; ++corner) {
+            const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
+            uint32_t row;
+            if (fast_hash) row = (tx[i] ^ ty[j] ^ tz[k]) & ix.mask;
+            else if (fast_dense) row = tx[i] + ty[j] + tz[k];
+            else {
+                const uint32_t v[D] = {cell[0] + i, cell[1] + j, cell[2] + k};
+                row = ix.row(v);
+            }
+            const float w = (wx[i] * wy[j]) * wz[k];                     // forward's association
+            float p1 = w * g1;
+            if (TV && corner == 0) p1 += tvv;
+            h2 p2;
+            p2.x = (_Float16)(w * g2x);
+            p2.y = (_Float16)(w * g2y);
+            e_v1[corner] = __float_as_uint(p1);
+            e_v2[corner] = __builtin_bit_cast(uint32_t, p2);
+            uint32_t part_, rel_;
+            pm.split(row, part_, rel_);
+            e_pr[corner] = (part_ << 16) | rel_;
+            if (((e_v1[corner] << 1) | (e_v2[corner] & 0x7FFF7FFFu)) != 0u) vmask |= 1u << corner;
+        }
+    }
+
+    // level maxima of both tables: workgroup reduction, one conditional atomicMax each (see bin_fill_kernel)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        vmax1 = fmaxf(vmax1, __shfl_xor(vmax1, o, 64));
+        vmax2 = fmaxf(vmax2, __shfl_xor(vmax2, o, 64));
+    }
+    if (lane == 0) { wave_max[0][wid] = __float_as_uint(vmax1); wave_max[1][wid] = __float_as_uint(vmax2); }
+
+    if (parts == 1u) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) {
+            const bool v = (vmask >> c) & 1u;
+            const unsigned long long m = __ballot(v);
+            uint32_t base = 0;
+            if (lane == 0 && m) base = atomicAdd(&cnt[0], (uint32_t)__popcll(m));
+            base = __shfl(base, 0, 64);
+            e_slot[c] = base + (uint32_t)__popcll(m & below);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c)
+            if ((vmask >> c) & 1u) e_slot[c] = atomicAdd(&cnt[e_pr[c] >> 16], 1u);
+    }
+    __syncthreads();
+    if (tid < 2u) {
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) m = max(m, wave_max[tid][w]);
+        uint32_t* dst = level_max + tid * kMaxLevels + level;
+        if (m > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, m);
+    }
+
+    const uint32_t i0 = 2u * tid, i1 = i0 + 1u;
+    const uint32_t a0 = i0 < parts ? cnt[i0] : 0u, a1c = i1 < parts ? cnt[i1] : 0u;
+    const uint32_t incl = n2m_wave_scan_add_u32(a0 + a1c, (int)lane);
+    if (lane == 63u) wave_tot[wid] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; ++w) {
+        const uint32_t t = wave_tot[w];
+        if (w < wid) woff += t;
+        total += t;
+    }
+    const uint32_t excl = woff + incl - (a0 + a1c);
+    uint32_t* __restrict__ dir = directory + plan.dir_base[level] + (size_t)tile * (parts + 1u);
+    if (i0 < parts) { cnt[i0] = excl; dir[i0] = excl; }
+    if (i1 < parts) { cnt[i1] = excl + a0; dir[i1] = excl + a0; }
+    if (tid == 0) dir[parts] = total;
+    __syncthreads();
+
+#pragma unroll
+    for (uint32_t c = 0; c < 8; ++c)
+        if ((vmask >> c) & 1u) {
+            e_slot[c] += cnt[e_pr[c] >> 16];                       // position in the sorted tile
+            bin_stage[e_slot[c]] = ((uint64_t)(e_pr[c] & 0xFFFFu) << 32) | e_v1[c];
+        }
+    __syncthreads();
+    const size_t seg = ((size_t)level * plan.tiles + tile) * kTileEntries;
+    for (uint32_t i = tid; i < total; i += 1024) log1[seg + i] = bin_stage[i];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t c = 0; c < 8; ++c)
+        if ((vmask >> c) & 1u) bin_stage[e_slot[c]] = ((uint64_t)(e_pr[c] & 0xFFFFu) << 32) | e_v2[c];
+    __syncthreads();
+    for (uint32_t i = tid; i < total; i += 1024) log2[seg + i] = bin_stage[i];
+}
+
+// P = table rows per partition; SUB = consecutive partitions one work item accumulates (their runs are adjacent in the
+// partition-sorted tiles, so they stream as one run): LDS accumulator SUB * P * C * 8 bytes.  SUB = 2 lets the fp32 table, whose
+// rows are half as wide, keep 8192-row items on the 4096-row partition structure it shares with the fp16 table.
+template <typename T, uint32_t C, uint32_t P, uint32_t SUB>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners,
                       const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ directory,
                       const uint64_t* __restrict__ log, float* __restrict__ found_inf) {
-    constexpr uint32_t P = BinGeom<C>::P;
+    constexpr uint32_t kLog2P = 31u - __builtin_clz(P);
     extern __shared__ __attribute__((aligned(16))) unsigned long long bin_acc[];   // P * C
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t total_items = plan.item_prefix[plan.levels];
@@ -1077,16 +1244,22 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
         if (vm == 0u) continue;                                             // no non-zero finite update in this level
         const uint32_t Gl = plan.groups[level];
         const uint32_t local = item - plan.item_prefix[level];
-        const uint32_t part = local / Gl, grp = local - part * Gl;
+        const uint32_t part0 = (local / Gl) * SUB, grp = local - (local / Gl) * Gl;
         const uint32_t parts = plan.parts[level], size = plan.size[level];
+        const uint32_t part_end = min(part0 + SUB, parts);                   // this item owns partitions part0 .. part_end-1
         const Indexer<3> ix(size, lv.resolution[level], gridtype, align_corners);
         const bool interleaved = !ix.hashed && parts > 1u;                  // same rule as bin_fill_kernel
         const uint32_t row0 = plan.row0[level];
-        const PartMap pm(parts, part, BinGeom<C>::kLog2P, interleaved);
+        const PartMap pm(parts, part0, kLog2P, interleaved);
         const uint32_t n_blocks = (size + 15u) >> 4;
-        const uint32_t my_blocks = interleaved ? (part < n_blocks ? (n_blocks - part + parts - 1) / parts : 0u)
-                                               : min(P / 16u, n_blocks - min(n_blocks, part * (P / 16u)));
-        const uint32_t rows_here = my_blocks << 4;
+        auto rows_of = [&](uint32_t part) {
+            const uint32_t my_blocks = interleaved ? (part < n_blocks ? (n_blocks - part + parts - 1) / parts : 0u)
+                                                   : min(P / 16u, n_blocks - min(n_blocks, part * (P / 16u)));
+            return my_blocks << 4;
+        };
+        auto global_row = [&](uint32_t u, uint32_t rel) {                    // table row of entry `rel` of partition part0 + u
+            return interleaved ? ((((rel >> 4) * parts + part0 + u) << 4) | (rel & 15u)) : (((part0 + u) << kLog2P) + rel);
+        };
 
         // unit = 2^-ex with |v| * 2^ex < 2^38 for every finite v of the level
         int ex = 37 - ((int)((vm >> 23) & 255u) - 127);
@@ -1094,24 +1267,27 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
         const float scale = __uint_as_float((uint32_t)(ex + 127) << 23);
         const float inv = __uint_as_float((uint32_t)(127 - ex) << 23);
 
-        for (uint32_t i = tid; i < rows_here * C; i += 1024) bin_acc[i] = 0ull;
+        for (uint32_t i = tid; i < SUB * P * C; i += 1024) bin_acc[i] = 0ull;
         __syncthreads();
 
         T* __restrict__ gtab = grad_table + (size_t)row0 * C;
         const uint32_t* __restrict__ dir_l = directory + plan.dir_base[level];
         for (uint32_t t = grp + wid * Gl; t < plan.tiles; t += 16u * Gl) {   // one wave per tile run
             const uint32_t* __restrict__ dir = dir_l + (size_t)t * (parts + 1u);
-            const uint32_t off = dir[part], end = dir[part + 1u];
+            const uint32_t off = dir[part0], end = dir[part_end];
+            const uint32_t mid = SUB > 1u && part0 + 1u < part_end ? dir[part0 + 1u] : end;      // first entry of the second partition
             const uint64_t* __restrict__ seg = log + ((size_t)level * plan.tiles + t) * kTileEntries;
             for (uint32_t i = off + lane; i < end; i += 64u) {
                 const uint64_t e = seg[i];
-                const uint32_t rel = (uint32_t)(e >> 32), bits = (uint32_t)e;
+                const uint32_t u = (SUB > 1u && i >= mid) ? 1u : 0u;
+                const uint32_t rel0 = (uint32_t)(e >> 32), bits = (uint32_t)e;
+                const uint32_t rel = rel0 + u * P;                            // slot in this item's accumulator
                 if constexpr (sizeof(T) == 4) {
                     const float v = __uint_as_float(bits);
                     if (fabsf(v) <= 3.0e38f)
                         __hip_atomic_fetch_add(&bin_acc[rel], (unsigned long long)to_fixed(v, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else
-                        unsafeAtomicAdd(gtab + pm.global_row(rel), v);          // inf / nan propagate as they are
+                        unsafeAtomicAdd(gtab + global_row(u, rel0), v);          // inf / nan propagate as they are
                 } else {
                     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                     const h2 p = __builtin_bit_cast(h2, bits);
@@ -1120,15 +1296,17 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
                         if (v0 != 0.f) __hip_atomic_fetch_add(&bin_acc[rel * 2u], (unsigned long long)to_fixed(v0, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (v1 != 0.f) __hip_atomic_fetch_add(&bin_acc[rel * 2u + 1u], (unsigned long long)to_fixed(v1, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else {
-                        (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gtab + (size_t)pm.global_row(rel) * 2u), p);
+                        (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gtab + (size_t)global_row(u, rel0) * 2u), p);
                     }
                 }
             }
         }
         __syncthreads();
 
-        for (uint32_t rel = tid; rel < rows_here; rel += 1024) {
-            const uint32_t row = pm.global_row(rel);
+        for (uint32_t rel = tid; rel < SUB * P; rel += 1024) {
+            const uint32_t u = rel >> kLog2P, rel0 = rel & (P - 1u);
+            if (part0 + u >= part_end || rel0 >= rows_of(part0 + u)) continue;
+            const uint32_t row = global_row(u, rel0);
             if (row >= size) continue;
             if constexpr (sizeof(T) == 4) {
                 const long long a = (long long)bin_acc[rel];
@@ -1345,11 +1523,11 @@ struct BinLayout {
     bool ok;
 };
 
-BinLayout make_bin_plan(uint32_t Bc, uint32_t C, uint32_t max_level, const int32_t* host_offsets, bool tv) {
+BinLayout make_bin_plan(uint32_t Bc, uint32_t C, uint32_t max_level, const int32_t* host_offsets, bool tv, uint32_t P = 0, uint32_t logs = 1) {
     BinLayout o{};
     o.ok = max_level >= 1 && max_level <= kMaxLevels && (C == 1 || C == 2);
     if (!o.ok) return o;
-    const uint32_t P = kBinAccBytes / (8u * C);
+    if (P == 0) P = kBinAccBytes / (8u * C);
     const uint32_t per_tile = tv ? kTileEntries : 1024u;                     // samples per tile
     const uint32_t tiles = (Bc + per_tile - 1) / per_tile;
     o.plan.tiles = tiles;
@@ -1378,7 +1556,7 @@ BinLayout make_bin_plan(uint32_t Bc, uint32_t C, uint32_t max_level, const int32
     o.plan.item_prefix[max_level] = items;
     o.dir_words = dir;
     o.log_entries = (size_t)max_level * tiles * kTileEntries;
-    o.bytes = 256 + ((dir * 4 + 255) & ~(size_t)255) + o.log_entries * 8;
+    o.bytes = 256 + ((dir * 4 + 255) & ~(size_t)255) + (size_t)logs * o.log_entries * 8;
     if (dir >= (1ull << 32)) o.ok = false;
     return o;
 }
@@ -1390,7 +1568,7 @@ int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bin_fill_kernel<T, C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 8));
-        (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinAccBytes);
+        (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<T, C, BinGeom<C>::P, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinAccBytes);
         attr_set = true;
     }
     for (uint32_t b0 = 0; b0 < B; b0 += kBinChunk) {
@@ -1409,8 +1587,67 @@ int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table
                                                                                                      level_max, directory, log, found_inf);
         N2M_CHECK_LAUNCH();
         const uint32_t items = lay.plan.item_prefix[max_level];
-        bin_accumulate_kernel<T, C><<<items < 2048u ? items : 2048u, 1024, kBinAccBytes, s>>>(grad_table, lay.plan, lv, gridtype, align, level_max,
+        bin_accumulate_kernel<T, C, BinGeom<C>::P, 1><<<items < 2048u ? items : 2048u, 1024, kBinAccBytes, s>>>(grad_table, lay.plan, lv, gridtype, align, level_max,
                                                                                                 directory, log, found_inf);
+        N2M_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+
+int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* inputs, TvParams tv, float* table1, _Float16* table2, uint32_t B,
+                       uint32_t max_level, const int32_t* host_offsets, const LevelTable& lv, uint32_t gridtype, bool align, uint32_t interp,
+                       void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn, float* found_inf) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 8));
+        (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 8));
+        (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<float, 1, kPairP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
+        (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<_Float16, 2, kPairP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
+        attr_set = true;
+    }
+    for (uint32_t b0 = 0; b0 < B; b0 += kBinChunk) {
+        const uint32_t Bc = B - b0 < kBinChunk ? B - b0 : kBinChunk;
+        const BinLayout lay = make_bin_plan(Bc, 2, max_level, host_offsets, false, kPairP, 2);
+        N2M_REQUIRE(lay.ok, N2M_EUNSUPPORTED, "%s: table layout not supported by the binned path", fn);
+        N2M_REQUIRE(workspace_bytes >= lay.bytes, N2M_EINVAL, "%s: workspace too small (%zu < %zu bytes)", fn, workspace_bytes, lay.bytes);
+        uint32_t* level_max = (uint32_t*)workspace;                                  // [2][32]
+        uint32_t* directory = (uint32_t*)((char*)workspace + 256);
+        uint64_t* log1 = (uint64_t*)((char*)workspace + 256 + ((lay.dir_words * 4 + 255) & ~(size_t)255));
+        uint64_t* log2 = log1 + lay.log_entries;
+        N2M_HIP(hipMemsetAsync(level_max, 0, 256, s));
+        const float* g1 = grad1 + (size_t)b0;
+        const _Float16* g2 = grad2 + (size_t)b0 * 2;
+        const float* x = inputs + (size_t)b0 * 3;
+        const dim3 grid(lay.plan.tiles, max_level);
+        if (tv.table)
+            bin_fill_pair_kernel<true><<<grid, 1024, kTileEntries * 8, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
+                                                                             directory, log1, log2, found_inf);
+        else
+            bin_fill_pair_kernel<false><<<grid, 1024, kTileEntries * 8, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
+                                                                              directory, log1, log2, found_inf);
+        N2M_CHECK_LAUNCH();
+        const uint32_t items = lay.plan.item_prefix[max_level];
+        const uint32_t nb = items < 4096u ? items : 4096u;
+        // the fp32 table accumulates two partitions per work item: same item count and LDS bytes as on its own 8192-row structure
+        BinPlan plan1 = lay.plan;
+        uint32_t items1 = 0;
+        for (uint32_t l = 0; l < max_level; ++l) {
+            const uint32_t pairs = (plan1.parts[l] + 1u) / 2u;
+            const uint64_t per_item = (uint64_t)8 * Bc / pairs;
+            uint32_t g = (uint32_t)((per_item + 65535u) / 65536u);
+            g = g < 1u ? 1u : (g > 64u ? 64u : g);
+            g = g > plan1.tiles ? plan1.tiles : g;
+            plan1.groups[l] = g;
+            plan1.item_prefix[l] = items1;
+            items1 += pairs * g;
+        }
+        plan1.item_prefix[max_level] = items1;
+        bin_accumulate_kernel<float, 1, kPairP, 2><<<items1 < 4096u ? items1 : 4096u, 1024, kPairP * 16, s>>>(table1, plan1, lv, gridtype, align, level_max,
+                                                                                                             directory, log1, found_inf);
+        N2M_CHECK_LAUNCH();
+        bin_accumulate_kernel<_Float16, 2, kPairP, 1><<<nb, 1024, kPairP * 16, s>>>(table2, lay.plan, lv, gridtype, align, level_max + kMaxLevels, directory,
+                                                                                  log2, found_inf);
         N2M_CHECK_LAUNCH();
     }
     return 0;
@@ -1610,4 +1847,32 @@ extern "C" int n2m_grad_total_variation_binned(const float* inputs, const float*
     N2M_PROF(N2M_K_GRID_TV, s, (double)B * (4.0 * D + (double)L * (1 + 2 * D) * C * 4.0 + (double)L * C * 8.0));
     return launch_binned<float, 1, 1>(nullptr, inputs, tv, grad, B, L, host_offsets, lv, gridtype, align_corners != 0, 0u, workspace,
                                       (size_t)workspace_bytes, s, fn);
+}
+
+extern "C" uint64_t n2m_grid_binned_pair_workspace_bytes(uint32_t B, uint32_t max_level, const int32_t* host_offsets) {
+    if (!host_offsets || B == 0) return 0;
+    if (B > kBinChunk) B = kBinChunk;
+    const BinLayout lay = make_bin_plan(B, 2, max_level, host_offsets, false, kPairP, 2);
+    return lay.ok ? (uint64_t)lay.bytes : 0;
+}
+
+extern "C" int n2m_grid_encode_backward_binned_pair(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
+                                                    float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
+                                                    float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                                    const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
+                                                    const float* tv_scale, float* found_inf, void* workspace, uint64_t workspace_bytes,
+                                                    void* stream) {
+    const char* fn = "grid_encode_backward_binned_pair";
+    if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
+    N2M_REQUIRE(grad1 && grad2 && inputs && host_offsets && grad_embeddings1 && grad_embeddings2 && workspace, N2M_ENULL, "%s: NULL tensor", fn);
+    N2M_REQUIRE(!tv_embeddings || max_level == L, N2M_EUNSUPPORTED, "%s: the fused TV term needs max_level == L", fn);
+    if (B == 0 || max_level == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const LevelTable lv = make_levels(L, S, H);
+    const TvParams tv{tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale};
+    // algorithmic bytes of BOTH encoders' backward + the TV stencil reads
+    N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (12.0 + (double)max_level * (4 + 4) + 2.0 * max_level * 8 * (4 + 4) +
+                                             (tv_embeddings ? (double)L * 7 * 4.0 : 0.0)));
+    return launch_binned_pair(grad1, (const _Float16*)grad2, inputs, tv, grad_embeddings1, (_Float16*)grad_embeddings2, B, max_level, host_offsets, lv,
+                              gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf);
 }

@@ -13,6 +13,8 @@ from torch.autograd import Function
 from . import _lib as L
 
 _p = L.ptr
+PAIR_BACKWARD = True            # one shared fill for the two tables when their geometry is identical
+CONCURRENT_BACKWARD = False     # A/B switch: run the two table backward passes on two streams (measured: no gain, the kernels already fill the chip)
 SHADING = {"diffuse": 0, "full": 1, "specular": 2}
 
 
@@ -31,7 +33,7 @@ def _encode_lm(x01, emb, enc, max_level):
     return out
 
 
-def _encode_backward_lm(grad_lm, x01, emb, enc, max_level):
+def _encode_backward_lm(grad_lm, x01, emb, enc, max_level, ws_slot=0):
     B = x01.shape[0]
     Lv, C = enc.num_levels, emb.shape[1]
     g = torch.zeros_like(emb)
@@ -40,12 +42,12 @@ def _encode_backward_lm(grad_lm, x01, emb, enc, max_level):
     amp = getattr(enc, "amp_request", None)         # set by optim.FusedAdamAMP users: {"found_inf": tensor, "flagged": bool}
     finf = amp["found_inf"] if amp is not None else None
     if req is not None and binned_backward(enc, grad_lm, x01, g, max_level, tv=(emb, req["weight"], req["weight_outer"], req["inner01"], req["scale"]),
-                                           found_inf=finf):
+                                           found_inf=finf, ws_slot=ws_slot):
         req["done"] = True
         if amp is not None:
             amp["flagged"] = True
         return g
-    if binned_backward(enc, grad_lm, x01, g, max_level, found_inf=finf):
+    if binned_backward(enc, grad_lm, x01, g, max_level, found_inf=finf, ws_slot=ws_slot):
         if amp is not None:
             amp["flagged"] = True
         return g
@@ -53,6 +55,25 @@ def _encode_backward_lm(grad_lm, x01, emb, enc, max_level):
            float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None, None, enc.gridtype_id, int(bool(enc.align_corners)),
            enc.interp_id, L.F16 if emb.dtype == torch.float16 else L.F32, L.stream())
     return g
+
+
+def _encode_backward_pair(d_h1, d_h2, x01, emb1, emb2h, net, max_level):
+    """(g1, g2) through the shared-fill kernel, or (None, None) when it does not apply."""
+    from .gridencoder import binned_backward_pair
+    enc1, enc2 = net.encoder, net.encoder_color
+    g1, g2 = torch.zeros_like(emb1), torch.zeros_like(emb2h)
+    req = getattr(enc1, "tv_request", None)
+    amp1, amp2 = getattr(enc1, "amp_request", None), getattr(enc2, "amp_request", None)
+    finf = amp1["found_inf"] if amp1 is not None else (amp2["found_inf"] if amp2 is not None else None)
+    tv = (emb1, req["weight"], req["weight_outer"], req["inner01"], req["scale"]) if req is not None else None
+    if not binned_backward_pair(enc1, enc2, d_h1, d_h2, x01, g1, g2, max_level, tv=tv, found_inf=finf):
+        return None, None
+    if req is not None:
+        req["done"] = True
+    for amp in (amp1, amp2):
+        if amp is not None and finf is amp["found_inf"]:
+            amp["flagged"] = True
+    return g1, g2
 
 
 class _fused_field(Function):
@@ -119,10 +140,26 @@ class _fused_field(Function):
                _p(d_spec), _p(d_h1), _p(d_h2), *[_p(g) for g in dws], _p(amp["found_inf"]) if amp is not None else None, L.stream())
         if amp is not None:
             amp["flagged"] = True
-        g1 = _encode_backward_lm(d_h1, x01, emb1, net.encoder, max_level) if want_density else None
-        g2 = None
+        # both tables: one shared fill when their geometry is identical (it is for nerf2mesh), else one backward per table
+        g1 = g2 = None
+        if want_density and want_color and PAIR_BACKWARD:
+            g1, g2 = _encode_backward_pair(d_h1, d_h2, x01, emb1, emb2h, net, max_level)
+        if g1 is None:
+            side = L.side_stream(dev) if (want_density and want_color and CONCURRENT_BACKWARD) else None
+            if want_color and side is not None:
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    g2 = _encode_backward_lm(d_h2, x01, emb2h, net.encoder_color, max_level, ws_slot=1)
+                for t_ in (g2, d_h2, x01, emb2h):
+                    t_.record_stream(side)
+            g1 = _encode_backward_lm(d_h1, x01, emb1, net.encoder, max_level) if want_density else None
+            if want_color:
+                if side is not None:
+                    torch.cuda.current_stream().wait_stream(side)
+                else:
+                    g2 = _encode_backward_lm(d_h2, x01, emb2h, net.encoder_color, max_level)
         if want_color:
-            g2 = _encode_backward_lm(d_h2, x01, emb2h, net.encoder_color, max_level)
             amp2 = getattr(net.encoder_color, "amp_request", None)
             if amp2 is not None and amp2.get("keep_half"):
                 amp2["grad_half"] = g2           # the optimizer reads the fp16 gradient directly; autograd gets no fp32 copy

@@ -99,7 +99,7 @@ def _host_offsets(enc):
     return arr
 
 
-def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level, tv=None, found_inf=None):
+def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level, tv=None, found_inf=None, ws_slot=0):
     """grad_embeddings += scatter of grad_lm [L,B,C] through the binned fixed-point kernels (include/n2m_hip.h);
     returns False when the configuration is not covered (caller uses n2m_grid_encode_backward).
     tv = (embeddings fp32, weight, weight_outer, inner01, scale tensor | None) folds the TV gradient over the same inputs in."""
@@ -113,11 +113,40 @@ def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level, tv=None, foun
         return False
     if tv is not None and not (dt == L.F32 and C == 1 and max_level == enc.num_levels):
         return False
-    ws = L.workspace(x01.device, need)
+    ws = L.workspace(x01.device, need, ws_slot)
     tv_emb, tv_w, tv_wo, tv_in, tv_scale = tv if tv is not None else (None, 0.0, 0.0, 1.0, None)
     L.call("n2m_grid_encode_backward_binned", _p(grad_lm), _p(x01), ho.ctypes.data, _p(grad_embeddings), B, 3, C, enc.num_levels, max_level,
            float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), enc.interp_id, dt,
            _p(tv_emb), float(tv_w), float(tv_wo), float(tv_in), _p(tv_scale), _p(found_inf), _p(ws), ws.numel(), L.stream())
+    return True
+
+
+def same_geometry(a, b):
+    """Two encoders index their tables identically (levels, resolutions, hash/tiled, offsets): their backward can share one fill."""
+    return (list(a.host_offsets) == list(b.host_offsets) and a.per_level_scale == b.per_level_scale and a.base_resolution == b.base_resolution
+            and a.gridtype_id == b.gridtype_id and bool(a.align_corners) == bool(b.align_corners) and a.interp_id == b.interp_id
+            and a.input_dim == b.input_dim == 3)
+
+
+def binned_backward_pair(enc1, enc2, grad1_lm, grad2_lm, x01, g1, g2, max_level, tv=None, found_inf=None):
+    """Both table gradients (g1 fp32 C=1, g2 fp16 C=2, zero-filled or running sums) from one shared fill
+    (n2m_grid_encode_backward_binned_pair); False when not applicable."""
+    if not (g1.dtype == torch.float32 and g1.shape[1] == 1 and g2.dtype == torch.float16 and g2.shape[1] == 2):
+        return False
+    if not (hasattr(enc1, "host_offsets") and hasattr(enc2, "host_offsets") and same_geometry(enc1, enc2)):
+        return False
+    if tv is not None and max_level != enc1.num_levels:
+        return False
+    B = x01.shape[0]
+    ho = _host_offsets(enc1)
+    need = L.lib().n2m_grid_binned_pair_workspace_bytes(B, max_level, ho.ctypes.data)
+    if need == 0:
+        return False
+    ws = L.workspace(x01.device, need)
+    tv_emb, tv_w, tv_wo, tv_in, tv_scale = tv if tv is not None else (None, 0.0, 0.0, 1.0, None)
+    L.call("n2m_grid_encode_backward_binned_pair", _p(grad1_lm), _p(grad2_lm), _p(x01), ho.ctypes.data, _p(g1), _p(g2), B, enc1.num_levels,
+           max_level, float(np.log2(enc1.per_level_scale)), int(enc1.base_resolution), enc1.gridtype_id, int(bool(enc1.align_corners)),
+           enc1.interp_id, _p(tv_emb), float(tv_w), float(tv_wo), float(tv_in), _p(tv_scale), _p(found_inf), _p(ws), ws.numel(), L.stream())
     return True
 
 

@@ -555,6 +555,39 @@ def test_grid_backward_binned_multi_pass(be):
         np.testing.assert_allclose(a[offs[l]:offs[l + 1]].double().sum().item(), grad[l].double().sum().item(), rtol=2e-3, atol=1.0)
 
 
+@pytest.mark.parametrize("with_tv", [False, True])
+def test_grid_backward_binned_pair_equals_two_calls(be, with_tv):
+    """One shared fill for the density (fp32 C=1) and colour (fp16 C=2) tables == the two single-table calls: the sums are exact
+    fixed-point sums of the same products, so hashed levels agree bit for bit and the split dense levels to atomic-order noise."""
+    torch = be["torch"]
+    from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward, binned_backward_pair
+    B = 100003
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.rand(B, 3, device="cuda", generator=gen)
+    x[5] = 1.0; x[6, 1] = -0.01
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    e2 = GridEncoder(level_dim=2, desired_resolution=2048).cuda()
+    offs = e1.host_offsets
+    d1 = torch.randn(16, B, 1, device="cuda", generator=gen) * (torch.rand(1, B, 1, device="cuda", generator=gen) < 0.7)
+    d2 = (torch.randn(16, B, 2, device="cuda", generator=gen) * (torch.rand(1, B, 1, device="cuda", generator=gen) < 0.7)).half()
+    emb1 = e1.embeddings.detach().float().contiguous()
+    scale = torch.tensor(128.0, device="cuda")
+    tv = (emb1, 1e-3, 1e-2, 0.3, scale) if with_tv else None
+    a1 = torch.zeros(offs[-1], 1, device="cuda"); a2 = torch.zeros(offs[-1], 2, device="cuda", dtype=torch.float16)
+    flag = torch.zeros((), device="cuda")
+    assert binned_backward_pair(e1, e2, d1, d2, x, a1, a2, 16, tv=tv, found_inf=flag) and float(flag) == 0
+    b1 = torch.zeros_like(a1); b2 = torch.zeros_like(a2)
+    assert binned_backward(e1, d1, x, b1, 16, tv=tv) and binned_backward(e2, d2, x, b2, 16)
+    np.testing.assert_allclose(a1.cpu().numpy(), b1.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(b1.abs().max()))
+    np.testing.assert_allclose(a2.float().cpu().numpy(), b2.float().cpu().numpy(), rtol=2e-3, atol=2e-3 * float(b2.float().abs().max()))
+    for l in range(16):
+        if offs[l + 1] - offs[l] == 2 ** 19:
+            sl = slice(offs[l], offs[l + 1])
+            assert torch.equal(a1[sl], b1[sl]) and torch.equal(a2[sl], b2[sl])
+    d2n = d2.clone(); d2n[3, 17, 0] = float("inf")
+    assert binned_backward_pair(e1, e2, d1, d2n, x, torch.zeros_like(a1), torch.zeros_like(a2), 16, found_inf=flag) and float(flag) == 1
+
+
 def test_grad_total_variation_binned(be, oracle):
     torch = be["torch"]
     from nerf2mesh_amd import _lib as L
