@@ -308,25 +308,14 @@ march_train_wave_kernel(const float* __restrict__ rays_o, const float* __restric
                 }
             }
         }
-#ifdef N2M_DEBUG_MARCH
-        if (closed_form) {
-            float ts_ = t_base;
-            for (int i = 0; i < 63; ++i) {
-                const float nt = ts_ + n2m_clampf(ts_ * c.dt_gamma, c.dt_min, c.dt_max);
-                ts_ = i < lane ? nt : ts_;
-            }
-            const float tn_ = __shfl(ts_ + n2m_clampf(ts_ * c.dt_gamma, c.dt_min, c.dt_max), 63, 64);
-            if (ts_ != t || tn_ != t_next_base)
-                printf("T mismatch ray %u chunk %u lane %d: closed %a serial %a next %a %a base %a\n", n, chunk, lane, t, ts_, t_next_base, tn_, t_base);
-        }
-#endif
         if (!closed_form) {
 #pragma unroll 1
             for (int i = 0; i < 63; ++i) {
                 const float nt = t + n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
                 t = i < lane ? nt : t;
             }
-            t_next_base = __shfl(t + n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max), 63, 64);   // T_{base+64}
+            t_next_base = __uint_as_float((uint32_t)__builtin_amdgcn_readlane(
+                (int)__float_as_uint(t + n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max)), 63));   // T_{base+64}
         }
         // 2. evaluate all candidates of the chunk
         const bool active = t < far;
@@ -355,7 +344,8 @@ march_train_wave_kernel(const float* __restrict__ rays_o, const float* __restric
                 if (kept >= budget) { done = true; break; }
                 cur += (int)run;
             } else {
-                const float tt = __shfl(e.tt, cur, 64);
+                // cur is wave-uniform: v_readlane with a scalar lane index instead of an LDS-pipe ds_bpermute round trip
+                const float tt = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(e.tt), __builtin_amdgcn_readfirstlane(cur)));
                 const unsigned long long later = cur >= 63 ? 0ull : (~0ull << (cur + 1));
                 const unsigned long long reach = __ballot(t >= tt) & later;
                 if (reach) cur = (int)__ffsll((long long)reach) - 1;
