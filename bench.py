@@ -192,6 +192,7 @@ def main():
         if rank == 0:
             print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    local = local % torch.cuda.device_count()          # ranks beyond the visible GPUs share devices (gloo test runs only)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     _lib.lib()

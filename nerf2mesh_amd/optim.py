@@ -39,8 +39,10 @@ class FusedAdamAMP(torch.optim.Optimizer):
         self.shadows = {}          # param -> callable returning the fp16 shadow tensor to refresh (or None)
         self.half_grads = {}       # param -> callable returning an fp16 gradient produced outside autograd (or None)
 
-    def scale_loss(self, loss):
-        return loss * self.scale if self.amp else loss
+    def scale_loss(self, loss, world=1):
+        """loss * scale / world: with gradients SUMMED over `world` ranks the update sees their mean."""
+        f = (self.scale / world if world > 1 else self.scale) if self.amp else (1.0 / world if world > 1 else None)
+        return loss if f is None else loss * f
 
     @torch.no_grad()
     def step(self, flagged=()):

@@ -68,6 +68,30 @@ class GradSync:
                 p.grad.copy_(self.bucket[off:off + n].view_as(p.grad)).mul_(inv)
                 off += n
 
+    @torch.no_grad()
+    def all_reduce_sum(self, big, small):
+        """In-place SUM over ranks of explicit tensors: every tensor of `big` gets its own collective in its own dtype (an fp16
+        gradient travels as fp16: half the bytes over xGMI), the tensors of `small` ride together in one flat fp32 bucket.  No
+        averaging here -- the caller folds 1/world into the loss scale, which saves a pass over the tables."""
+        if self.world <= 1:
+            return
+        works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for t in big if t is not None]
+        small = [t for t in small if t is not None]
+        n = sum(t.numel() for t in small)
+        if n:
+            if self.bucket is None or self.bucket.numel() < n:
+                self.bucket = torch.zeros(n, dtype=torch.float32, device=small[0].device)
+            flat = self.bucket[:n]
+            torch.cat([t.reshape(-1).float() for t in small], out=flat)
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        if n:
+            off = 0
+            for t in small:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+
     def grad_bytes(self):
         return sum(p.numel() for p in self.params) * 4
 
@@ -100,8 +124,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # N2M_DIST_BACKEND=gloo lets the whole multi-rank trainer run on a box with fewer GPUs than ranks (test use)
+            backend = os.environ.get("N2M_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local

@@ -25,8 +25,7 @@ class Stage0Trainer:
         self.gen.manual_seed(seed + rank)                  # every rank draws its own rays
         # main.py:221 Adam(eps=1e-15) + nerf/utils.py:506 GradScaler.  Single GPU with the fused field: optim.FusedAdamAMP does both
         # in two launches and takes the inf/nan verdict from the kernels that produce the gradients.
-        self.amp_adam = device.type == "cuda" and world_size == 1 and bool(getattr(opt, "fused_mlp", False)) and not opt.sdf \
-            and getattr(opt, "ind_dim", 0) == 0
+        self.amp_adam = device.type == "cuda" and bool(getattr(opt, "fused_mlp", False)) and not opt.sdf and getattr(opt, "ind_dim", 0) == 0
         if self.amp_adam:
             from .optim import FusedAdamAMP
             self.optimizer = FusedAdamAMP(model.get_params(opt.lr), eps=1e-15, amp=bool(opt.fp16))
@@ -133,7 +132,9 @@ class Stage0Trainer:
         if opt.lambda_tv > 0 and M > 0 and self.fused_tv and getattr(model, "_can_fuse", lambda: False)() \
                 and model.max_level >= model.encoder.num_levels:
             if self.amp_adam:
-                scale_t = self.optimizer.scale if self.optimizer.amp else None
+                # gradients are summed over ranks and carry scale / world (see scale_loss): the TV term must carry the same factor
+                scale_t = (self.optimizer.scale if self.world == 1 else self.optimizer.scale / self.world) if self.optimizer.amp else \
+                    (None if self.world == 1 else self._one / self.world)
             else:
                 scale_t = self.scaler.scale(self._one) if self.scaler.is_enabled() else None   # device scalar, no host sync
             tv_req = dict(weight=opt.lambda_tv, weight_outer=opt.lambda_tv * (10 if opt.bound > 1 else 1), inner01=0.5 / model.bound,
@@ -145,18 +146,25 @@ class Stage0Trainer:
             self._amp = {"density": dict(found_inf=o.found_inf, flagged=False), "color": dict(found_inf=o.found_inf, flagged=False, keep_half=True),
                          "mlp": dict(found_inf=o.found_inf, flagged=False)}
             model.encoder.amp_request, model.encoder_color.amp_request, model.amp_request = self._amp["density"], self._amp["color"], self._amp["mlp"]
-            o.scale_loss(loss).backward()
+            o.scale_loss(loss, self.world).backward()
             model.encoder.amp_request = model.encoder_color.amp_request = model.amp_request = None
             model.encoder.tv_request = None
             if tv_req is None or not tv_req["done"]:
-                self._tv(xyzs, 1.0, scale_tensor=o.scale if o.amp else None)        # gradients are still scaled here
+                self._tv(xyzs, 1.0 / self.world, scale_tensor=o.scale if o.amp else None)        # gradients are still scaled here
             flagged = []
-            if self._amp["density"]["flagged"]:
-                flagged.append(model.encoder.embeddings)
-            if self._amp["color"]["flagged"]:
-                flagged.append(model.encoder_color.embeddings)
-            if self._amp["mlp"]["flagged"]:
-                flagged += [p for m in (model.sigma_net, model.color_net, model.specular_net) for p in m.parameters()]
+            if self.sync is not None:
+                # one SUM all-reduce per table gradient (the colour one stays fp16: half the bytes) + one small bucket; the reduced
+                # gradients are then checked for inf/nan like any others (a sum of finite fp16 values can overflow)
+                mlp = [p.grad for m in (model.sigma_net, model.color_net, model.specular_net) for p in m.parameters()]
+                self.sync.all_reduce_sum([model.encoder.embeddings.grad, self._amp["color"].get("grad_half"), model.encoder_color.embeddings.grad],
+                                         mlp + [o.found_inf])
+            else:
+                if self._amp["density"]["flagged"]:
+                    flagged.append(model.encoder.embeddings)
+                if self._amp["color"]["flagged"]:
+                    flagged.append(model.encoder_color.embeddings)
+                if self._amp["mlp"]["flagged"]:
+                    flagged += [p for m in (model.sigma_net, model.color_net, model.specular_net) for p in m.parameters()]
             o.step(flagged=flagged)
         else:
             self.scaler.scale(loss).backward()

@@ -55,6 +55,15 @@ def _worker(rank, world, port, q):
         model.w1.grad[0, 0] = float("inf")
     sync.all_reduce()
     ok &= bool(torch.isinf(model.w1.grad[0, 0]))
+    # explicit-tensor SUM (the FusedAdamAMP path): own collective per big tensor in its own dtype, flat bucket for the rest
+    big32 = torch.full((1 << 16,), float(rank + 1))
+    big16 = torch.full((1 << 16, 2), float(rank + 1), dtype=torch.float16)
+    small = [torch.full((7, 3), float(rank)), torch.zeros(()) + (1.0 if rank == 1 else 0.0), None]
+    p16 = big16.data_ptr()
+    sync.all_reduce_sum([big32, big16, None], small)
+    tot = sum(range(1, world + 1))
+    ok &= bool((big32 == tot).all()) and bool((big16 == tot).all()) and big16.dtype == torch.float16 and big16.data_ptr() == p16
+    ok &= bool((small[0] == sum(range(world))).all()) and float(small[1]) == 1.0
     # identical jitter for the replicated occupancy refresh
     GradSync.sync_rng_for_grid_update(48)
     r = torch.rand(4)
