@@ -1,0 +1,52 @@
+"""End-to-end training steps on the GPU for the BASELINE configurations beyond the lego -O recipe: large-bound cascades
+(config 4: `--bound 16`, 5 cascades, inner/outer TV split) and the SDF variant (config 5: NeuS alpha, 7 density evaluations per
+sample for the normals, eikonal loss, progressive levels, contraction).  They assert that the whole path runs through the HIP
+kernels, stays finite and learns; parity of the individual kernels is covered elsewhere."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(**kw):
+    import torch
+    from nerf2mesh_amd import synthetic
+    from nerf2mesh_amd.network import NeRFNetwork
+    from nerf2mesh_amd.options import make_options
+    from nerf2mesh_amd.trainer import Stage0Trainer
+    torch.manual_seed(0)
+    opt = make_options(O=True, iters=2000, **kw)
+    tr = Stage0Trainer(NeRFNetwork(opt), opt, synthetic.make_cameras(12, seed=0), torch.device("cuda", 0), seed=0)
+    tr.mark_untrained()
+    return tr
+
+
+def _run(tr, steps):
+    import torch
+    losses = [float(tr.train_step().detach()) for _ in range(steps)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)), losses
+    return losses
+
+
+def test_bound16_cascades_fused_path_learns():
+    tr = _trainer(bound=16, dt_gamma=1 / 256, fused_mlp=True)
+    assert tr.model.cascade == 5 and tr.amp_adam
+    losses = _run(tr, 120)
+    assert np.mean(losses[-20:]) < 0.6 * np.mean(losses[:10]), (losses[:10], losses[-20:])
+    assert tr.last_num_points > 0 and float(tr.model.density_bitfield.float().sum()) > 0
+
+
+def test_bound16_unfused_reference_graph_learns():
+    tr = _trainer(bound=16, dt_gamma=1 / 256, fused_mlp=False)
+    assert not tr.amp_adam
+    losses = _run(tr, 120)                                               # the LR ramps up over the first 500 steps (main.py:239)
+    assert np.mean(losses[-10:]) < 0.8 * np.mean(losses[:10]), (losses[:10], losses[-10:])
+
+
+def test_sdf_stage0_steps_run_and_learn():
+    tr = _trainer(bound=1, dt_gamma=0, sdf=True, fused_mlp=True)       # sdf keeps the nn.Linear graph (_can_fuse is False)
+    assert tr.opt.progressive_level and not tr.amp_adam
+    losses = _run(tr, 60)
+    assert tr.model.max_level < 16                                      # progressive levels active (nerf/utils.py:654-655)
+    assert np.mean(losses[-10:]) < np.mean(losses[:10]), (losses[:10], losses[-10:])
