@@ -35,30 +35,28 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling is 6290 GB/s
 
 
-# device kernels behind each library entry point, for the PMC traffic lookup
-_DEVICE_KERNELS = {"grid_encode_backward": ("bin_fill_kernel", "bin_accumulate_kernel"), "grid_encode_forward": ("grid_forward3_kernel",),
-                   "mlp_backward": ("field_backward_kernel",), "mlp_forward": ("field_forward_kernel",),
-                   "march_rays_train_count": ("march_train_wave_kernelILb0", "march_train_wave_kernel<false>"),
-                   "march_rays_train_write": ("march_train_wave_kernelILb1", "march_train_wave_kernel<true>")}
+# device kernels behind each library entry point, for the PMC traffic lookup: (substrings of the kernel names, how their
+# per-launch byte counts combine into one call of the entry point)
+_DEVICE_KERNELS = {"grid_encode_backward": (("bin_fill_pair_kernel", "bin_accumulate_kernel"), "sum"),     # one call = fill + both accumulates
+                   "grid_encode_forward": (("grid_forward3_kernel",), "mean"),                               # one call per table
+                   "mlp_backward": (("field_backward_kernel",), "mean"), "mlp_forward": (("field_forward_kernel",), "mean"),
+                   "march_rays_train_count": (("march_train_wave_kernelILb0", "march_train_wave_kernel<false>"), "mean"),
+                   "march_rays_train_write": (("march_train_wave_kernelILb1", "march_train_wave_kernel<true>"), "mean")}
 
 
 def pmc_traffic(entry_point):
-    """HBM bytes per launch of `entry_point` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json, made by
-    tools/pmc_traffic.py: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, two separate passes), averaged over the device
-    kernels and table formats behind the entry point.  Counters cannot be read from inside this process, hence the file; None
-    when it is absent."""
+    """HBM-side bytes per call of `entry_point` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json, made by
+    tools/pmc_traffic.py: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, two separate passes) over the device kernels
+    behind the entry point.  Counters cannot be read from inside this process, hence the file; None when it is absent."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
     if not os.path.exists(path) or entry_point not in _DEVICE_KERNELS:
         return None
-    table = json.load(open(path))
-    per_kernel = {}
-    for name, v in table.items():
-        for key in _DEVICE_KERNELS[entry_point]:
-            if key in name and v.get("fetch_bytes_per_launch") is not None and v.get("write_bytes_per_launch") is not None:
-                per_kernel.setdefault(key.split("IL")[0].split("<")[0], []).append(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
-    if not per_kernel:
+    keys, how = _DEVICE_KERNELS[entry_point]
+    vals = [v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for name, v in json.load(open(path)).items()
+            if any(k in name for k in keys) and v.get("fetch_bytes_per_launch") is not None and v.get("write_bytes_per_launch") is not None]
+    if not vals:
         return None
-    return float(sum(sum(v) / len(v) for v in per_kernel.values()))
+    return float(sum(vals) if how == "sum" else sum(vals) / len(vals))
 
 
 def cpu_baseline(n_rays=4096, reps=2):
