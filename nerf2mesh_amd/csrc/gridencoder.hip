@@ -1072,11 +1072,15 @@ __global__ void __launch_bounds__(1024)
 bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Float16* __restrict__ grad2 /*[L,Bstride,2]*/,
                      const float* __restrict__ inputs, TvParams tv, uint32_t B, uint32_t Bstride, BinPlan plan, LevelTable lv,
                      uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max /*[2][32]*/,
-                     uint32_t* __restrict__ directory, uint64_t* __restrict__ log1, uint64_t* __restrict__ log2,
-                     float* __restrict__ found_inf) {
+                     uint32_t* __restrict__ directory, uint16_t* __restrict__ log_rel, uint32_t* __restrict__ log_v1,
+                     uint32_t* __restrict__ log_v2, float* __restrict__ found_inf) {
     constexpr uint32_t D = 3;
     constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
+    // the logs are structure-of-arrays: row-in-partition as u16 (shared by both tables) + one 4-byte value array per table =
+    // 10 bytes per update pair instead of 2 x 8; staged through LDS so that every array is written as one contiguous run
     extern __shared__ __attribute__((aligned(16))) uint64_t bin_stage[];
+    uint32_t* stage_v = reinterpret_cast<uint32_t*>(bin_stage);                       // kTileEntries x u32
+    uint16_t* stage_rel = reinterpret_cast<uint16_t*>(stage_v + kTileEntries);        // kTileEntries x u16
     __shared__ uint32_t cnt[kMaxPartsPerLevel];
     __shared__ uint32_t wave_tot[16], wave_max[2][16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -1211,27 +1215,35 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
     for (uint32_t c = 0; c < 8; ++c)
         if ((vmask >> c) & 1u) {
             e_slot[c] += cnt[e_pr[c] >> 16];                       // position in the sorted tile
-            bin_stage[e_slot[c]] = ((uint64_t)(e_pr[c] & 0xFFFFu) << 32) | e_v1[c];
+            stage_v[e_slot[c]] = e_v1[c];
+            stage_rel[e_slot[c]] = (uint16_t)(e_pr[c] & 0xFFFFu);
         }
     __syncthreads();
     const size_t seg = ((size_t)level * plan.tiles + tile) * kTileEntries;
-    for (uint32_t i = tid; i < total; i += 1024) log1[seg + i] = bin_stage[i];
+    for (uint32_t i = tid; i < total; i += 1024) log_v1[seg + i] = stage_v[i];
+    {   // rows as u32 pairs (seg is even, a trailing odd entry is padded with whatever follows in LDS: never read back)
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(stage_rel);
+        uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(log_rel + seg);
+        for (uint32_t i = tid; i < (total + 1u) / 2u; i += 1024) dst[i] = src[i];
+    }
     __syncthreads();
 #pragma unroll
     for (uint32_t c = 0; c < 8; ++c)
-        if ((vmask >> c) & 1u) bin_stage[e_slot[c]] = ((uint64_t)(e_pr[c] & 0xFFFFu) << 32) | e_v2[c];
+        if ((vmask >> c) & 1u) stage_v[e_slot[c]] = e_v2[c];
     __syncthreads();
-    for (uint32_t i = tid; i < total; i += 1024) log2[seg + i] = bin_stage[i];
+    for (uint32_t i = tid; i < total; i += 1024) log_v2[seg + i] = stage_v[i];
 }
 
 // P = table rows per partition; SUB = consecutive partitions one work item accumulates (their runs are adjacent in the
 // partition-sorted tiles, so they stream as one run): LDS accumulator SUB * P * C * 8 bytes.  SUB = 2 lets the fp32 table, whose
 // rows are half as wide, keep 8192-row items on the 4096-row partition structure it shares with the fp16 table.
-template <typename T, uint32_t C, uint32_t P, uint32_t SUB>
+// SOA: entries come as (u16 row-in-partition, u32 value) arrays (the shared-fill logs) instead of packed u64.
+template <typename T, uint32_t C, uint32_t P, uint32_t SUB, bool SOA = false>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners,
                       const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ directory,
-                      const uint64_t* __restrict__ log, float* __restrict__ found_inf) {
+                      const uint64_t* __restrict__ log, float* __restrict__ found_inf, const uint16_t* __restrict__ log_rel = nullptr,
+                      const uint32_t* __restrict__ log_val = nullptr) {
     constexpr uint32_t kLog2P = 31u - __builtin_clz(P);
     extern __shared__ __attribute__((aligned(16))) unsigned long long bin_acc[];   // P * C
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -1276,11 +1288,18 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
             const uint32_t* __restrict__ dir = dir_l + (size_t)t * (parts + 1u);
             const uint32_t off = dir[part0], end = dir[part_end];
             const uint32_t mid = SUB > 1u && part0 + 1u < part_end ? dir[part0 + 1u] : end;      // first entry of the second partition
-            const uint64_t* __restrict__ seg = log + ((size_t)level * plan.tiles + t) * kTileEntries;
+            const size_t seg0 = ((size_t)level * plan.tiles + t) * kTileEntries;
             for (uint32_t i = off + lane; i < end; i += 64u) {
-                const uint64_t e = seg[i];
+                uint32_t rel0, bits;
+                if constexpr (SOA) {
+                    rel0 = log_rel[seg0 + i];
+                    bits = log_val[seg0 + i];
+                } else {
+                    const uint64_t e = log[seg0 + i];
+                    rel0 = (uint32_t)(e >> 32);
+                    bits = (uint32_t)e;
+                }
                 const uint32_t u = (SUB > 1u && i >= mid) ? 1u : 0u;
-                const uint32_t rel0 = (uint32_t)(e >> 32), bits = (uint32_t)e;
                 const uint32_t rel = rel0 + u * P;                            // slot in this item's accumulator
                 if constexpr (sizeof(T) == 4) {
                     const float v = __uint_as_float(bits);
@@ -1602,30 +1621,31 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 8));
         (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 8));
-        (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<float, 1, kPairP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
-        (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<_Float16, 2, kPairP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
+        (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<float, 1, kPairP, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
+        (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<_Float16, 2, kPairP, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
         attr_set = true;
     }
     for (uint32_t b0 = 0; b0 < B; b0 += kBinChunk) {
         const uint32_t Bc = B - b0 < kBinChunk ? B - b0 : kBinChunk;
-        const BinLayout lay = make_bin_plan(Bc, 2, max_level, host_offsets, false, kPairP, 2);
+        const BinLayout lay = make_bin_plan(Bc, 2, max_level, host_offsets, false, kPairP, 2);     // 2 x 8 B per entry >= the 10 B used
         N2M_REQUIRE(lay.ok, N2M_EUNSUPPORTED, "%s: table layout not supported by the binned path", fn);
         N2M_REQUIRE(workspace_bytes >= lay.bytes, N2M_EINVAL, "%s: workspace too small (%zu < %zu bytes)", fn, workspace_bytes, lay.bytes);
         uint32_t* level_max = (uint32_t*)workspace;                                  // [2][32]
         uint32_t* directory = (uint32_t*)((char*)workspace + 256);
-        uint64_t* log1 = (uint64_t*)((char*)workspace + 256 + ((lay.dir_words * 4 + 255) & ~(size_t)255));
-        uint64_t* log2 = log1 + lay.log_entries;
+        uint32_t* log_v1 = (uint32_t*)((char*)workspace + 256 + ((lay.dir_words * 4 + 255) & ~(size_t)255));
+        uint32_t* log_v2 = log_v1 + lay.log_entries;
+        uint16_t* log_rel = (uint16_t*)(log_v2 + lay.log_entries);
         N2M_HIP(hipMemsetAsync(level_max, 0, 256, s));
         const float* g1 = grad1 + (size_t)b0;
         const _Float16* g2 = grad2 + (size_t)b0 * 2;
         const float* x = inputs + (size_t)b0 * 3;
         const dim3 grid(lay.plan.tiles, max_level);
         if (tv.table)
-            bin_fill_pair_kernel<true><<<grid, 1024, kTileEntries * 8, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
-                                                                             directory, log1, log2, found_inf);
+            bin_fill_pair_kernel<true><<<grid, 1024, kTileEntries * 6, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
+                                                                             directory, log_rel, log_v1, log_v2, found_inf);
         else
-            bin_fill_pair_kernel<false><<<grid, 1024, kTileEntries * 8, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
-                                                                              directory, log1, log2, found_inf);
+            bin_fill_pair_kernel<false><<<grid, 1024, kTileEntries * 6, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
+                                                                              directory, log_rel, log_v1, log_v2, found_inf);
         N2M_CHECK_LAUNCH();
         const uint32_t items = lay.plan.item_prefix[max_level];
         const uint32_t nb = items < 4096u ? items : 4096u;
@@ -1643,11 +1663,11 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
             items1 += pairs * g;
         }
         plan1.item_prefix[max_level] = items1;
-        bin_accumulate_kernel<float, 1, kPairP, 2><<<items1 < 4096u ? items1 : 4096u, 1024, kPairP * 16, s>>>(table1, plan1, lv, gridtype, align, level_max,
-                                                                                                             directory, log1, found_inf);
+        bin_accumulate_kernel<float, 1, kPairP, 2, true><<<items1 < 4096u ? items1 : 4096u, 1024, kPairP * 16, s>>>(
+            table1, plan1, lv, gridtype, align, level_max, directory, nullptr, found_inf, log_rel, log_v1);
         N2M_CHECK_LAUNCH();
-        bin_accumulate_kernel<_Float16, 2, kPairP, 1><<<nb, 1024, kPairP * 16, s>>>(table2, lay.plan, lv, gridtype, align, level_max + kMaxLevels, directory,
-                                                                                  log2, found_inf);
+        bin_accumulate_kernel<_Float16, 2, kPairP, 1, true><<<nb, 1024, kPairP * 16, s>>>(table2, lay.plan, lv, gridtype, align, level_max + kMaxLevels,
+                                                                                        directory, nullptr, found_inf, log_rel, log_v2);
         N2M_CHECK_LAUNCH();
     }
     return 0;
