@@ -200,6 +200,14 @@ int n2m_grad_total_variation_binned(const float* inputs, const float* embeddings
                                     uint32_t H, uint32_t gridtype, int align_corners, void* workspace,
                                     uint64_t workspace_bytes, void* stream);
 
+/* Forward of both field encoders in one launch (same inputs, same level geometry): embeddings1 [rows,1] f32 -> outputs1 [L,B]
+ * f32, embeddings2 [rows,2] f16 -> outputs2 [L,B,2] f16, level-major; bit-identical to two n2m_grid_encode_forward calls.
+ * Levels >= max_level are not written. */
+int n2m_grid_encode_forward_pair(const float* inputs, const float* embeddings1, const void* embeddings2,
+                                 const int32_t* offsets, float* outputs1, void* outputs2, uint32_t B, uint32_t L,
+                                 uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                 uint32_t interp, void* stream);
+
 /* Both encoders of nerf2mesh's field in one call: the density table (fp32, C=1) and the colour table (fp16, C=2) share
  * their level geometry and are queried at the same inputs (nerf/network.py:92-108), so the index arithmetic and the partition
  * sort of the binned backward are done once and two update logs are written.  grad1 [L,B] f32, grad2 [L,B,2] f16, one

@@ -417,6 +417,111 @@ __device__ __forceinline__ void atomic_add_row(float* dst, const float* v, uint3
 }
 
 // one thread per (sample, level): scatter w * grad into the 2^D rows
+// Both tables of the field in one forward: the density (fp32 C=1) and colour (fp16 C=2) encoders share geometry and inputs
+// (nerf/network.py:92-108), so cell, weights and row indices are derived once and each vertex pair is fetched from both tables.
+// Same arithmetic and rounding points as grid_forward3_kernel per table: outputs are bit-identical to two single calls.
+// Level-major outputs out1 [L,B] f32, out2 [L,B,2] f16.
+__global__ void __launch_bounds__(256)
+grid_forward3_pair_kernel(const float* __restrict__ inputs, const float* __restrict__ table1, const _Float16* __restrict__ table2,
+                          const int32_t* __restrict__ offsets, float* __restrict__ out1, _Float16* __restrict__ out2, uint32_t B,
+                          uint32_t max_level, LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t n_tiles) {
+    constexpr uint32_t D = 3;
+    const uint32_t level = blockIdx.x / n_tiles, tile = blockIdx.x - level * n_tiles;
+    if (level >= max_level) return;
+    const uint32_t b = tile * 256 + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t row0 = (uint32_t)offsets[level];
+    const uint32_t size = (uint32_t)offsets[level + 1] - row0;
+    const float scale = lv.scale[level];
+    const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
+    const float* __restrict__ t1 = table1 + (size_t)row0;
+    const _Float16* __restrict__ t2 = table2 + (size_t)row0 * 2;
+    float* o1 = out1 + (size_t)level * B + b;
+    _Float16* o2 = out2 + ((size_t)level * B + b) * 2;
+
+    float x[D];
+    load_point<D>(inputs, b, x);
+    if (outside_unit_cube<D>(x)) {
+        *o1 = 0.0f;
+        Row<_Float16, 2> z;
+        z.v[0] = z.v[1] = (_Float16)0;
+        z.store(o2);
+        return;
+    }
+    uint32_t cell[D];
+    float frac[D], dfrac[D];
+    locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
+
+    Row<float, 1> g1[8];
+    Row<_Float16, 2> g2[8];
+    const bool dense = !ix.hashed && !ix.wrap;
+    if (dense) {
+        const uint32_t base = cell[0] + cell[1] * ix.stride[1] + cell[2] * ix.stride[2];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t r = base + ((q & 1u) ? ix.stride[1] : 0u) + ((q & 2u) ? ix.stride[2] : 0u);
+            const RowPair<float, 1> p1 = load_pair<float, 1>(t1 + (size_t)r);
+            const RowPair<_Float16, 2> p2 = load_pair<_Float16, 2>(t2 + (size_t)r * 2);
+            g1[2 * q] = p1.lo; g1[2 * q + 1] = p1.hi;
+            g2[2 * q] = p2.lo; g2[2 * q + 1] = p2.hi;
+        }
+    } else if (ix.hashed && ix.pow2) {
+        const uint32_t hy0 = cell[1] * kPrimes[1], hy1 = hy0 + kPrimes[1], hz0 = cell[2] * kPrimes[2], hz1 = hz0 + kPrimes[2];
+        const bool x_even = (cell[0] & 1u) == 0u;
+        uint32_t rx[4], rx1[4];
+        RowPair<float, 1> p1[4];
+        RowPair<_Float16, 2> p2[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t h = ((q & 1u) ? hy1 : hy0) ^ ((q & 2u) ? hz1 : hz0);
+            rx[q] = (cell[0] ^ h) & ix.mask;
+            rx1[q] = ((cell[0] + 1u) ^ h) & ix.mask;
+            p1[q] = load_pair<float, 1>(t1 + (size_t)(rx[q] & ~1u));
+            p2[q] = load_pair<_Float16, 2>(t2 + (size_t)(rx[q] & ~1u) * 2);
+        }
+        Row<float, 1> e1[4];
+        Row<_Float16, 2> e2[4];
+        if (!x_even) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                e1[q] = Row<float, 1>::load(t1 + (size_t)rx1[q]);
+                e2[q] = Row<_Float16, 2>::load(t2 + (size_t)rx1[q] * 2);
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const bool odd_row = (rx[q] & 1u) != 0u;
+            g1[2 * q] = odd_row ? p1[q].hi : p1[q].lo;
+            g1[2 * q + 1] = x_even ? (odd_row ? p1[q].lo : p1[q].hi) : e1[q];
+            g2[2 * q] = odd_row ? p2[q].hi : p2[q].lo;
+            g2[2 * q + 1] = x_even ? (odd_row ? p2[q].lo : p2[q].hi) : e2[q];
+        }
+    } else {
+#pragma unroll
+        for (uint32_t corner = 0; corner < 8; ++corner) {
+            const uint32_t v[D] = {cell[0] + (corner & 1u), cell[1] + ((corner >> 1) & 1u), cell[2] + (corner >> 2)};
+            const uint32_t r = ix.row(v);
+            g1[corner] = Row<float, 1>::load(t1 + (size_t)r);
+            g2[corner] = Row<_Float16, 2>::load(t2 + (size_t)r * 2);
+        }
+    }
+    float a1 = 0.0f;
+    _Float16 a2[2] = {(_Float16)0, (_Float16)0};
+#pragma unroll
+    for (uint32_t corner = 0; corner < 8; ++corner) {   // corner bit 0 = x, bit 1 = y, bit 2 = z: the reference's order
+        float w = 1.0f;
+#pragma unroll
+        for (uint32_t d = 0; d < D; ++d) w *= (corner & (1u << d)) ? frac[d] : 1 - frac[d];
+        accum(a1, w, g1[corner].v[0]);
+        accum(a2[0], w, g2[corner].v[0]);
+        accum(a2[1], w, g2[corner].v[1]);
+    }
+    *o1 = a1;
+    Row<_Float16, 2> r2;
+    r2.v[0] = a2[0]; r2.v[1] = a2[1];
+    r2.store(o2);
+}
+
 template <typename T, uint32_t D, uint32_t C, bool SAMPLE_MAJOR>
 __global__ void __launch_bounds__(256)
 grid_backward_kernel(const T* __restrict__ grad, const float* __restrict__ inputs, const int32_t* __restrict__ offsets,
@@ -1895,4 +2000,22 @@ extern "C" int n2m_grid_encode_backward_binned_pair(const float* grad1, const vo
                                              (tv_embeddings ? (double)L * 7 * 4.0 : 0.0)));
     return launch_binned_pair(grad1, (const _Float16*)grad2, inputs, tv, grad_embeddings1, (_Float16*)grad_embeddings2, B, max_level, host_offsets, lv,
                               gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf);
+}
+
+extern "C" int n2m_grid_encode_forward_pair(const float* inputs, const float* embeddings1, const void* embeddings2, const int32_t* offsets,
+                                            float* outputs1, void* outputs2, uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                            uint32_t gridtype, int align_corners, uint32_t interp, void* stream) {
+    const char* fn = "grid_encode_forward_pair";
+    if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
+    N2M_REQUIRE(inputs && embeddings1 && embeddings2 && offsets && outputs1 && outputs2, N2M_ENULL, "%s: NULL tensor", fn);
+    if (B == 0 || max_level == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const LevelTable lv = make_levels(L, S, H);
+    // algorithmic bytes of both encoders' forward (588 B/sample each at L = 16)
+    N2M_PROF(N2M_K_GRID_FWD, s, (double)B * (12.0 + (double)max_level * 8 * (4 + 4) + (double)max_level * (4 + 4)));
+    const uint32_t n_tiles = n2m_ceil_div(B, 256);
+    grid_forward3_pair_kernel<<<n_tiles * max_level, 256, 0, s>>>(inputs, embeddings1, (const _Float16*)embeddings2, offsets, outputs1,
+                                                                 (_Float16*)outputs2, B, max_level, lv, gridtype, align_corners != 0, interp, n_tiles);
+    N2M_CHECK_LAUNCH();
+    return 0;
 }

@@ -13,6 +13,7 @@ from torch.autograd import Function
 from . import _lib as L
 
 _p = L.ptr
+PAIR_FORWARD = True             # one forward launch for the two tables when their geometry is identical
 PAIR_BACKWARD = True            # one shared fill for the two tables when their geometry is identical
 CONCURRENT_BACKWARD = False     # A/B switch: run the two table backward passes on two streams (measured: no gain, the kernels already fill the chip)
 SHADING = {"diffuse": 0, "full": 1, "specular": 2}
@@ -31,6 +32,22 @@ def _encode_lm(x01, emb, enc, max_level):
            float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None, enc.gridtype_id, int(bool(enc.align_corners)), enc.interp_id,
            L.F16 if emb.dtype == torch.float16 else L.F32, L.stream())
     return out
+
+
+def _encode_lm_pair(x01, emb1, emb2h, net, max_level):
+    """(h1 [L,B,1] f32, h2 [L,B,2] f16) from one launch when the two encoders share their geometry, else None."""
+    from .gridencoder import same_geometry
+    e1, e2 = net.encoder, net.encoder_color
+    if not (PAIR_FORWARD and emb1.dtype == torch.float32 and emb1.shape[1] == 1 and emb2h.dtype == torch.float16 and emb2h.shape[1] == 2
+            and hasattr(e1, "host_offsets") and hasattr(e2, "host_offsets") and same_geometry(e1, e2)):
+        return None
+    B, Lv = x01.shape[0], e1.num_levels
+    mk = torch.empty if max_level >= Lv else torch.zeros
+    h1 = mk(Lv, B, 1, device=x01.device, dtype=torch.float32)
+    h2 = mk(Lv, B, 2, device=x01.device, dtype=torch.float16)
+    L.call("n2m_grid_encode_forward_pair", _p(x01), _p(emb1), _p(emb2h), _p(e1.offsets), _p(h1), _p(h2), B, Lv, max_level,
+           float(np.log2(e1.per_level_scale)), int(e1.base_resolution), e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, L.stream())
+    return h1, h2
 
 
 def _encode_backward_lm(grad_lm, x01, emb, enc, max_level, ws_slot=0):
@@ -85,17 +102,21 @@ class _fused_field(Function):
         bound, max_level = float(net.bound), int(min(net.max_level, net.encoder.num_levels))
         x01 = (xyz + bound) / (2 * bound)
         sigma = h1 = None
-        if want_density:
-            emb1 = emb1.float().contiguous()
-            h1 = _encode_lm(x01, emb1, net.encoder, max_level)
-            sigma = torch.empty(M, dtype=torch.float32, device=xyz.device)
-        else:
-            emb1 = None
         rgb = spec = h2 = emb2h = None
-        ws = [w.float().contiguous() for w in (w0, w1, w2, w3, w4, w5, w6)]
+        emb1 = emb1.float().contiguous() if want_density else None
         if want_color:
             emb2h = net.encoder_color.half_table() if hasattr(net.encoder_color, "half_table") else emb2.half().contiguous()   # grid.py:45
-            h2 = _encode_lm(x01, emb2h, net.encoder_color, max_level)
+        both = _encode_lm_pair(x01, emb1, emb2h, net, max_level) if (want_density and want_color) else None
+        if both is not None:
+            h1, h2 = both
+        if want_density:
+            if h1 is None:
+                h1 = _encode_lm(x01, emb1, net.encoder, max_level)
+            sigma = torch.empty(M, dtype=torch.float32, device=xyz.device)
+        ws = [w.float().contiguous() for w in (w0, w1, w2, w3, w4, w5, w6)]
+        if want_color:
+            if h2 is None:
+                h2 = _encode_lm(x01, emb2h, net.encoder_color, max_level)
             dirs = dirs.float().contiguous() if shading != 0 else None
             rgb = torch.empty(M, 3, dtype=torch.float32, device=xyz.device)
             spec = torch.empty(M, 3, dtype=torch.float32, device=xyz.device) if shading != 0 else None

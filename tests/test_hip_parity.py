@@ -401,6 +401,32 @@ def test_grid_encode_backward(be, oracle, D, C, half, gridtype, align, interp):
             np.testing.assert_allclose(got2, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
 
 
+def test_grid_encode_forward_pair_is_bit_identical_to_two_calls(be):
+    """n2m_grid_encode_forward_pair == two n2m_grid_encode_forward calls (fp32 C=1 + fp16 C=2 tables of identical geometry)."""
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L
+    from nerf2mesh_amd.gridencoder import GridEncoder
+    for gridtype, align, interp in (("hash", False, "linear"), ("tiled", True, "smoothstep")):
+        e1 = GridEncoder(level_dim=1, desired_resolution=2048, gridtype=gridtype, align_corners=align, interpolation=interp).cuda()
+        e2 = GridEncoder(level_dim=2, desired_resolution=2048, gridtype=gridtype, align_corners=align, interpolation=interp).cuda()
+        with torch.no_grad():
+            e1.embeddings.uniform_(-1, 1); e2.embeddings.uniform_(-1, 1)
+        emb1, emb2 = e1.embeddings.detach().contiguous(), e2.embeddings.detach().half().contiguous()
+        B = 70001
+        x = torch.rand(B, 3, device="cuda")
+        x[0] = 0.0; x[1] = 1.0; x[2, 1] = 1.001
+        S = float(np.log2(e1.per_level_scale))
+        for ml in (16, 7):
+            h1 = torch.full((16, B, 1), 3.0, device="cuda"); h2 = torch.full((16, B, 2), 3.0, device="cuda", dtype=torch.float16)
+            L.call("n2m_grid_encode_forward_pair", x.data_ptr(), emb1.data_ptr(), emb2.data_ptr(), e1.offsets.data_ptr(), h1.data_ptr(), h2.data_ptr(),
+                   B, 16, ml, S, 16, e1.gridtype_id, int(align), e1.interp_id, L.stream())
+            r1 = torch.full_like(h1, 3.0); r2 = torch.full_like(h2, 3.0)
+            for emb, out, C, dt in ((emb1, r1, 1, L.F32), (emb2, r2, 2, L.F16)):
+                L.call("n2m_grid_encode_forward", x.data_ptr(), emb.data_ptr(), e1.offsets.data_ptr(), out.data_ptr(), B, 3, C, 16, ml, S, 16, None,
+                       e1.gridtype_id, int(align), e1.interp_id, dt, L.stream())
+            assert torch.equal(h1, r1) and torch.equal(h2.view(torch.int16), r2.view(torch.int16))
+
+
 def test_grid_backward_linearity_full_size(be):
     """Size-independent property at the BASELINE size (B = 2^18, lego tables): backward is linear in grad and
     sum(grad_embeddings) == sum_b sum_l grad[b,l] (the 8 interpolation weights of a sample sum to 1)."""
