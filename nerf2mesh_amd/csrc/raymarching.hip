@@ -324,34 +324,41 @@ march_train_wave_kernel(const float* __restrict__ rays_o, const float* __restric
         if (active) e = eval_candidate(c, t);
         const unsigned long long active_mask = __ballot(active);             // a prefix of the lanes (T increases)
         const unsigned long long keep_mask = __ballot(active && e.keep);
-        // 3. resolve the visited subsequence
+        // 3. resolve the visited subsequence.  Everything in this loop is wave-uniform (ballots, lane indices, counters); the
+        // values are pinned to SGPRs with readfirstlane so that the loop runs on the scalar unit with scalar branches instead of
+        // per-lane VALU compares under exec masks.
         unsigned long long kept_mask = 0ull;
         int cur = 0;
         bool done = false;
+        const uint32_t budget_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)budget);
+        uint32_t kept_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)kept);
         if (pending) {
             const unsigned long long reach = __ballot(t >= pending_tt);
             if (reach == 0ull) cur = 64;                                     // whole chunk lies inside the skipped voxel
             else { cur = (int)__ffsll((long long)reach) - 1; pending = false; }
         }
+        cur = __builtin_amdgcn_readfirstlane(cur);
         while (cur < 64) {
             if (!((active_mask >> cur) & 1ull)) { done = true; break; }      // T_cur >= far
             if ((keep_mask >> cur) & 1ull) {
                 const unsigned long long stop = ~keep_mask >> cur;           // first lane >= cur that is not kept
                 const uint32_t run = stop ? (uint32_t)__ffsll((long long)stop) - 1u : (uint32_t)(64 - cur);
-                const uint32_t take = min(run, budget - kept);
+                const uint32_t take = min(run, budget_s - kept_s);
                 kept_mask |= (take >= 64u ? ~0ull : ((1ull << take) - 1ull)) << cur;
-                kept += take;
-                if (kept >= budget) { done = true; break; }
+                kept_s += take;
+                if (kept_s >= budget_s) { done = true; break; }
                 cur += (int)run;
             } else {
-                // cur is wave-uniform: v_readlane with a scalar lane index instead of an LDS-pipe ds_bpermute round trip
-                const float tt = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(e.tt), __builtin_amdgcn_readfirstlane(cur)));
+                // v_readlane with a scalar lane index instead of an LDS-pipe ds_bpermute round trip
+                const float tt = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(e.tt), cur));
                 const unsigned long long later = cur >= 63 ? 0ull : (~0ull << (cur + 1));
                 const unsigned long long reach = __ballot(t >= tt) & later;
                 if (reach) cur = (int)__ffsll((long long)reach) - 1;
                 else { pending = true; pending_tt = tt; cur = 64; }
             }
+            cur = __builtin_amdgcn_readfirstlane(cur);
         }
+        kept = kept_s;
         // 4. emit
         if (WRITE && kept_mask) {
             if ((kept_mask >> lane) & 1ull) {
