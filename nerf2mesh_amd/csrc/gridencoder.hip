@@ -1389,10 +1389,21 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
 
         T* __restrict__ gtab = grad_table + (size_t)row0 * C;
         const uint32_t* __restrict__ dir_l = directory + plan.dir_base[level];
-        for (uint32_t t = grp + wid * Gl; t < plan.tiles; t += 16u * Gl) {   // one wave per tile run
+        // one wave per tile run.  The wave first fetches the directory entries of ALL its tiles in one parallel load (lane j <-
+        // its j-th tile), then walks them with readlane: one dependent global-load round trip per item instead of one per tile.
+        const uint32_t my_tiles = (plan.tiles > grp + wid * Gl) ? (plan.tiles - (grp + wid * Gl) + 16u * Gl - 1u) / (16u * Gl) : 0u;   // <= 64
+        uint32_t d_off = 0, d_mid = 0, d_end = 0;
+        if (lane < my_tiles) {
+            const uint32_t t = grp + wid * Gl + lane * 16u * Gl;
             const uint32_t* __restrict__ dir = dir_l + (size_t)t * (parts + 1u);
-            const uint32_t off = dir[part0], end = dir[part_end];
-            const uint32_t mid = SUB > 1u && part0 + 1u < part_end ? dir[part0 + 1u] : end;      // first entry of the second partition
+            d_off = dir[part0];
+            d_end = dir[part_end];
+            d_mid = SUB > 1u && part0 + 1u < part_end ? dir[part0 + 1u] : d_end;
+        }
+        for (uint32_t j = 0; j < my_tiles; ++j) {
+            const uint32_t t = grp + wid * Gl + j * 16u * Gl;
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)d_off, j), end = (uint32_t)__builtin_amdgcn_readlane((int)d_end, j);
+            const uint32_t mid = (uint32_t)__builtin_amdgcn_readlane((int)d_mid, j);      // first entry of the second partition
             const size_t seg0 = ((size_t)level * plan.tiles + t) * kTileEntries;
             for (uint32_t i = off + lane; i < end; i += 64u) {
                 uint32_t rel0, bits;
