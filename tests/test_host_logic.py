@@ -72,3 +72,25 @@ def test_scene_and_gt():
     # Morton helper agrees with its definition
     c = torch.tensor([[1, 0, 0], [0, 1, 0], [0, 0, 1], [127, 127, 127]])
     assert S.morton3D_torch(c).tolist() == [1, 2, 4, 2 ** 21 - 1]
+
+
+def test_uniform_laplacian_matches_dense_operator_and_its_gradient():
+    """trainer.UniformLaplacian (nerf/utils.py:176-221) == mean || D^-1 A v - v ||^2 built densely; the custom backward (the
+    neighbour sum is self-adjoint on a symmetric edge list) must equal autograd's."""
+    import torch
+    from nerf2mesh_amd.trainer import UniformLaplacian
+    torch.manual_seed(0)
+    faces = torch.tensor([[0, 1, 2], [0, 2, 3], [0, 3, 4], [1, 2, 5], [2, 3, 5], [3, 4, 5]])
+    V = 6
+    v = torch.randn(V, 3, dtype=torch.float64, requires_grad=True)
+    A = torch.zeros(V, V, dtype=torch.float64)
+    for f in faces.tolist():
+        for a, b in ((0, 1), (1, 2), (2, 0)):
+            A[f[a], f[b]] = A[f[b], f[a]] = 1
+    ref = (((A @ v) / A.sum(1, keepdim=True) - v) ** 2).sum(-1).mean()
+    g_ref, = torch.autograd.grad(ref, v)
+    lap = UniformLaplacian(faces, V)
+    lap.inv_deg = lap.inv_deg.double()
+    got = lap(v)
+    g_got, = torch.autograd.grad(got, v)
+    assert torch.allclose(got, ref, rtol=1e-12) and torch.allclose(g_got, g_ref, rtol=1e-10, atol=1e-12)
