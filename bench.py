@@ -128,13 +128,14 @@ def bench_stage1(args, rank, world, device):
     opt = make_options(O=True, bound=1, dt_gamma=0, stage=1, fused_mlp=not args.unfused)
     v, f = synthetic.scene_mesh(300000)
     tr = Stage1Trainer(NeRFNetwork(opt), opt, synthetic.make_cameras(100, seed=0), v, f, device, rank=rank, world_size=world)
+    tr.preload()                     # rays + ground truth of all views on the device, as the reference's --preload
     for _ in range(args.warmup):
         tr.train_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     if not args.no_prof:
-        _lib.prof_reset(); _lib.prof_enable(True)
+        _lib.prof_reset(); _lib.prof_enable(args.prof_every)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.train_step()

@@ -288,15 +288,23 @@ class Stage1Trainer:
         self.view_cache = {}          # per view: rays + ground-truth RGBA, resident in HBM like the reference's --preload
         self.covered_seen = 0
 
+    def _view(self, v):
+        if v not in self.view_cache:
+            rays_o, rays_d = synthetic.rays_from_pixels(self.poses, torch.full_like(self.pix, v), self.pix, self.H, self.W)
+            self.view_cache[v] = (rays_o, rays_d, synthetic.render_gt(rays_o, rays_d, self.boxes))
+        return self.view_cache[v]
+
+    def preload(self):
+        """Rays + ground truth of every view of this rank resident on the device before training (the reference's --preload)."""
+        for v in self.views:
+            self._view(v)
+
     def train_step(self):
         opt, model = self.opt, self.model
         model.train()
         v = self.views[self.global_step % len(self.views)]
         self.global_step += 1
-        if v not in self.view_cache:
-            rays_o, rays_d = synthetic.rays_from_pixels(self.poses, torch.full_like(self.pix, v), self.pix, self.H, self.W)
-            self.view_cache[v] = (rays_o, rays_d, synthetic.render_gt(rays_o, rays_d, self.boxes))
-        rays_o, rays_d, rgba = self.view_cache[v]
+        rays_o, rays_d, rgba = self._view(v)
         bg = torch.rand(self.H * self.W, 3, device=self.device, generator=self.gen)
         gt_mask = rgba[:, 3:]
         gt_rgb = rgba[:, :3] * gt_mask + bg * (1 - gt_mask)
