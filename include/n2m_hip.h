@@ -175,7 +175,7 @@ int n2m_grid_encode_backward_bm(const void* grad, const float* inputs, const voi
  *   host_offsets : HOST pointer to the L+1 int32 level offsets (the list gridencoder/grid.py:117-128 builds)
  *   workspace    : device scratch of at least n2m_grid_binned_workspace_bytes(...) bytes, 256-byte aligned; contents
  *                  are undefined on entry and exit, the calls are stream-ordered so one buffer can be shared
- *   B            : any; batches above 2^19 samples run in passes of 2^19 over the same workspace
+ *   B            : any; batches above 2^20 samples run in passes of 2^20 over the same workspace
  * n2m_grid_binned_workspace_bytes returns 0 when the configuration is not covered (callers then use the generic
  * entry points above). */
 uint64_t n2m_grid_binned_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t max_level,

@@ -939,7 +939,7 @@ grid_backward_lds_kernel(const T* __restrict__ grad /*[L,B,C]*/, const float* __
 constexpr uint32_t kBinAccBytes = 65536;          // LDS accumulator per accumulate workgroup (two workgroups per CU)
 constexpr uint32_t kTileEntries = 8192;           // 1024 threads x 8 entries per tile and level
 constexpr uint32_t kMaxPartsPerLevel = 2048;      // LDS counters of bin_fill_kernel
-constexpr uint32_t kBinChunk = 1u << 19;          // samples per pass over the workspace
+constexpr uint32_t kBinChunk = 1u << 20;          // samples per pass over the workspace (a stage-1 frame shades ~0.65 M pixels)
 
 struct BinPlan {
     uint32_t row0[kMaxLevels], size[kMaxLevels], parts[kMaxLevels], groups[kMaxLevels];

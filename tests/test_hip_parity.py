@@ -560,11 +560,11 @@ def test_grid_backward_binned_full_size(be):
 
 
 def test_grid_backward_binned_multi_pass(be):
-    """B > 2^19 runs in passes over one workspace (the stage-1 batch of a 1600x1600 render): same result as the partition kernel."""
+    """B > 2^20 runs in passes over one workspace: same result as the partition kernel."""
     torch = be["torch"]
     from nerf2mesh_amd import _lib as L
     from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward
-    B = 2 ** 19 + 70001
+    B = 2 ** 20 + 70001
     gen = torch.Generator(device="cuda").manual_seed(3)
     x = torch.rand(B, 3, device="cuda", generator=gen)
     enc = GridEncoder(level_dim=2, desired_resolution=2048).cuda()
