@@ -69,28 +69,40 @@ class GradSync:
                 off += n
 
     @torch.no_grad()
-    def all_reduce_sum(self, big, small):
-        """In-place SUM over ranks of explicit tensors: every tensor of `big` gets its own collective in its own dtype (an fp16
-        gradient travels as fp16: half the bytes over xGMI), the tensors of `small` ride together in one flat fp32 bucket.  No
-        averaging here -- the caller folds 1/world into the loss scale, which saves a pass over the tables."""
+    def all_reduce_sum_begin(self, big, small):
+        """Issue the in-place SUM over ranks of explicit tensors and return a token for all_reduce_sum_end: every tensor of `big`
+        gets its own collective in its own dtype (an fp16 gradient travels as fp16: half the bytes over xGMI), the tensors of
+        `small` ride together in one flat fp32 bucket.  No averaging here -- the caller folds 1/world into the loss scale, which
+        saves a pass over the tables.  Work enqueued on the current stream between begin and end overlaps the collectives."""
         if self.world <= 1:
-            return
+            return None
         works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for t in big if t is not None]
         small = [t for t in small if t is not None]
         n = sum(t.numel() for t in small)
+        flat = None
         if n:
             if self.bucket is None or self.bucket.numel() < n:
                 self.bucket = torch.zeros(n, dtype=torch.float32, device=small[0].device)
             flat = self.bucket[:n]
             torch.cat([t.reshape(-1).float() for t in small], out=flat)
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return works, small, flat
+
+    @torch.no_grad()
+    def all_reduce_sum_end(self, token):
+        if token is None:
+            return
+        works, small, flat = token
         for w in works:
             w.wait()
-        if n:
+        if flat is not None:
             off = 0
             for t in small:
                 t.copy_(flat[off:off + t.numel()].view_as(t))
                 off += t.numel()
+
+    def all_reduce_sum(self, big, small):
+        self.all_reduce_sum_end(self.all_reduce_sum_begin(big, small))
 
     def grad_bytes(self):
         return sum(p.numel() for p in self.params) * 4

@@ -156,8 +156,13 @@ class Stage0Trainer:
                 # one SUM all-reduce per table gradient (the colour one stays fp16: half the bytes) + one small bucket; the reduced
                 # gradients are then checked for inf/nan like any others (a sum of finite fp16 values can overflow)
                 mlp = [p.grad for m in (model.sigma_net, model.color_net, model.specular_net) for p in m.parameters()]
-                self.sync.all_reduce_sum([model.encoder.embeddings.grad, self._amp["color"].get("grad_half"), model.encoder_color.embeddings.grad],
-                                         mlp + [o.found_inf])
+                token = self.sync.all_reduce_sum_begin([model.encoder.embeddings.grad, self._amp["color"].get("grad_half"),
+                                                        model.encoder_color.embeddings.grad], mlp + [o.found_inf])
+                # the next batch's ray generation and march pass 1 read neither gradients nor parameters: enqueue them now so that they
+                # run while the collectives are in flight (not on occupancy-refresh steps, which need the updated parameters first)
+                if self.pipeline and self.global_step % opt.update_extra_interval != 0:
+                    self._next = self._prepare()
+                self.sync.all_reduce_sum_end(token)
             else:
                 if self._amp["density"]["flagged"]:
                     flagged.append(model.encoder.embeddings)
@@ -185,7 +190,7 @@ class Stage0Trainer:
             self.scaler.update()
         self.scheduler.step()
         self.loss_acc += loss.detach()
-        if self.pipeline:
+        if self.pipeline and self._next is None:
             # everything the next step needs before its sample count is known goes into the queue now, behind this step's
             # optimizer update (same order as the reference: refresh -> batch -> march), so the GPU never drains at the read-back
             self._next = self._prepare()
