@@ -222,6 +222,18 @@ int n2m_grid_encode_backward_binned_pair(const float* grad1, const void* grad2, 
                                          uint64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * freqencoder   (reference: freqencoder/src/freqencoder.h:6-10, freqencoder/src/bindings.cpp:5-8)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* freqencoder.h:7  freq_encode_forward   kernel freqencoder.cu:30-61.  inputs [B,D] f32 -> outputs [B,C] f32,
+ * C = D + 2*deg*D: the input, then per frequency f: sin(2^f x) and sin(2^f x + pi/2). */
+int n2m_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                            float* outputs, void* stream);
+/* freqencoder.h:10  freq_encode_backward   kernel freqencoder.cu:66-94.  grad, outputs [B,C] -> grad_inputs [B,D] (written). */
+int n2m_freq_encode_backward(const float* grad, const float* outputs, uint32_t B, uint32_t D, uint32_t deg,
+                             uint32_t C, float* grad_inputs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * training-step helpers (no reference kernel: the reference composes these from torch ops)
  * ---------------------------------------------------------------------------------------------------- */
 

@@ -38,6 +38,8 @@ SIGNATURES = {
     "n2m_grid_encode_backward_binned_pair": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
                                              _vp, _f32, _f32, _f32, _vp, _vp, _vp, _u64, _vp],
     "n2m_grad_total_variation_binned": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _vp, _u64, _vp],
+    "n2m_freq_encode_forward": [_vp, _u32, _u32, _u32, _u32, _vp, _vp],
+    "n2m_freq_encode_backward": [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp],
     "n2m_get_rays": [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "n2m_adam_step": [_vp, ctypes.c_double, ctypes.c_double, _f32, _vp, _vp, _vp, _vp],
     "n2m_scaler_update": [_vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp],

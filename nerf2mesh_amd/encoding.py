@@ -1,4 +1,4 @@
-"""Encoder factory with the reference's names (encoding.py:71-106): None / frequency_torch / sh / hashgrid / tiledgrid."""
+"""Encoder factory with the reference's names (encoding.py:71-106): None / frequency_torch / frequency / sh / hashgrid / tiledgrid."""
 import torch
 import torch.nn as nn
 
@@ -36,8 +36,11 @@ def get_encoder(encoding, input_dim=3, multires=6, degree=4, num_levels=16, leve
                           log2_hashmap_size=log2_hashmap_size, desired_resolution=desired_resolution,
                           gridtype="hash" if encoding == "hashgrid" else "tiled", align_corners=align_corners,
                           interpolation=interpolation)
-    elif encoding in ("frequency", "hashgrid_tcnn"):
-        raise NotImplementedError(f"encoding '{encoding}' is outside this build's scope (SURVEY.md section 2, rows 12 and 24)")
+    elif encoding == "frequency":
+        from .freqencoder import FreqEncoder
+        enc = FreqEncoder(input_dim=input_dim, degree=multires)                # encoding.py:84-86
+    elif encoding == "hashgrid_tcnn":
+        raise NotImplementedError("encoding 'hashgrid_tcnn' is outside this build's scope (SURVEY.md section 2, row 24: tiny-cuda-nn)")
     else:
         raise NotImplementedError("Unknown encoding mode, choose from [None, frequency_torch, sh, hashgrid, tiledgrid]")
     return enc, enc.output_dim

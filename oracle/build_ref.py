@@ -18,6 +18,7 @@ Outputs (python extension modules taking CPU torch tensors, same function table 
   oracle/_ref/_ref_raymarching.so   <- raymarching/src/{raymarching.cu,bindings.cpp}
   oracle/_ref/_ref_gridencoder.so   <- gridencoder/src/{gridencoder.cu,bindings.cpp}
   oracle/_ref/_ref_shencoder.so     <- shencoder/src/{shencoder.cu,bindings.cpp}
+  oracle/_ref/_ref_freqencoder.so   <- freqencoder/src/{freqencoder.cu,bindings.cpp}
 
 `oracle/_ref/` is git-ignored (binaries only) but travels to the GPU box with the snapshot.
 Used by: tests/ (to pin oracle/n2m_oracle.c), tests/golden/make_golden.py (fixture generation).
@@ -38,6 +39,7 @@ EXTS = {
     "_ref_raymarching": ("raymarching", "raymarching.cu"),
     "_ref_gridencoder": ("gridencoder", "gridencoder.cu"),
     "_ref_shencoder": ("shencoder", "shencoder.cu"),
+    "_ref_freqencoder": ("freqencoder", "freqencoder.cu"),
 }
 
 _LAUNCH = re.compile(r"(\w+(?:<[^<>;]*>)?)\s*<<<(.*?)>>>\s*\((.*?)\);", re.S)
@@ -91,12 +93,21 @@ def build(force: bool = False, verbose: bool = True) -> bool:
 
 
 def load():
-    """Import the three modules (after `import torch`). Returns (raymarching, gridencoder, shencoder)."""
+    """Import the modules (after `import torch`). Returns (raymarching, gridencoder, shencoder)."""
     import importlib
     import torch  # noqa: F401  (must be loaded before the extension modules)
     if OUT not in sys.path:
         sys.path.insert(0, OUT)
-    return tuple(importlib.import_module(n) for n in EXTS)
+    return tuple(importlib.import_module(n) for n in ("_ref_raymarching", "_ref_gridencoder", "_ref_shencoder"))
+
+
+def load_freq():
+    """The reference's freqencoder module (freqencoder/src/freqencoder.cu) compiled for the host."""
+    import importlib
+    import torch  # noqa: F401
+    if OUT not in sys.path:
+        sys.path.insert(0, OUT)
+    return importlib.import_module("_ref_freqencoder")
 
 
 if __name__ == "__main__":

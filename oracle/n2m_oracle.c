@@ -763,3 +763,38 @@ void n2m_oracle_sh_encode_backward(const float* grad, const float* inputs, uint3
         grad_inputs[t] = acc;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * freqencoder (freqencoder/src/freqencoder.cu:30-94): outputs [B, C], C = D + 2*deg*D: column block 0 is the input, block
+ * 1 + 2f is sin(2^f x), block 2 + 2f is sin(2^f x + pi/2) (the reference's cosine, :58-60; __sinf there, sinf here).
+ * backward (:66-94): d/dx = g_self + sum_f 2^f (g_sin cos - g_cos sin), using the stored outputs. */
+void n2m_oracle_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs) {
+    const float PI_F = 3.141592653589793f;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < (int64_t)B * C; ++t) {
+        const uint32_t b = (uint32_t)(t / C), c = (uint32_t)(t - (int64_t)b * C);
+        const float* in = inputs + (size_t)b * D;
+        if (c < D) { outputs[t] = in[c]; continue; }
+        const uint32_t col = c / D - 1, d = c % D, freq = col / 2;
+        const float phase_shift = (float)(col % 2) * (PI_F / 2);
+        outputs[t] = sinf(scalbnf(in[d], (int)freq) + phase_shift);
+    }
+    (void)deg;
+}
+
+void n2m_oracle_freq_encode_backward(const float* grad, const float* outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                                     float* grad_inputs) {
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < (int64_t)B * D; ++t) {
+        const uint32_t b = (uint32_t)(t / D), d = (uint32_t)(t - (int64_t)b * D);
+        const float* g = grad + (size_t)b * C;
+        const float* o = outputs + (size_t)b * C;
+        float result = g[d];
+        g += D; o += D;
+        for (uint32_t f = 0; f < deg; ++f) {
+            result += scalbnf(1.0f, (int)f) * (g[d] * o[D + d] - g[D + d] * o[d]);
+            g += 2 * D; o += 2 * D;
+        }
+        grad_inputs[t] = result;
+    }
+}

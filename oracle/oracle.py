@@ -276,6 +276,24 @@ def sh_encode_backward(grad, inputs, degree, dy_dx, grad_inputs=None):
     return grad_inputs
 
 
+def freq_encode_forward(inputs, degree):
+    """[B,D] -> [B, D + 2*degree*D] (freqencoder/freq.py:15-37)."""
+    inputs = _c(inputs, np.float32)
+    B, D = inputs.shape
+    C = D + 2 * degree * D
+    out = np.empty((B, C), np.float32)
+    _call("freq_encode_forward", _p(inputs), _u32(B), _u32(D), _u32(degree), _u32(C), _p(out))
+    return out
+
+
+def freq_encode_backward(grad, outputs, D, degree):
+    grad, outputs = _c(grad, np.float32), _c(outputs, np.float32)
+    B, C = outputs.shape
+    gi = np.zeros((B, D), np.float32)
+    _call("freq_encode_backward", _p(grad), _p(outputs), _u32(B), _u32(D), _u32(degree), _u32(C), _p(gi))
+    return gi
+
+
 # ------------------------------------------------------------------------------------------- stage-1 raster
 
 def rasterize(pos, tri, H, W):

@@ -43,6 +43,7 @@ inline void ref_launch(dim3 grid, dim3 block, Body&& body) {
 using std::min;
 using std::max;
 inline float __expf(float x) { return expf(x); }
+inline float __sinf(float x) { return sinf(x); }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 
 // half types: c10::Half carries IEEE binary16 storage with float arithmetic + round-to-nearest-even on

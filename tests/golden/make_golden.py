@@ -31,6 +31,23 @@ def save(name, **arrays):
     print(name, {k: v.shape for k, v in arrays.items()})
 
 
+# ------------------------------------------------------------------------------------------------ freqencoder
+fq = build_ref.load_freq()
+rng_f = np.random.default_rng(2025)          # own stream: this section can be regenerated alone (--only-freq)
+xf = (rng_f.normal(size=(64, 3)) * 2).astype(np.float32)
+arr = {"inputs": xf}
+for deg in (1, 4, 6):
+    C = 3 + 2 * deg * 3
+    out = np.zeros((64, C), np.float32)
+    fq.freq_encode_forward(t(xf), 64, 3, deg, C, t(out))
+    g = rng_f.normal(size=(64, C)).astype(np.float32)
+    gi = np.zeros((64, 3), np.float32)
+    fq.freq_encode_backward(t(g), t(out), 64, 3, deg, C, t(gi))
+    arr[f"out{deg}"], arr[f"grad{deg}"], arr[f"grad_inputs{deg}"] = out, g, gi
+save("freq", **arr)
+if "--only-freq" in sys.argv:
+    sys.exit(0)
+
 rng = np.random.default_rng(2024)
 
 # ---------------------------------------------------------------------------------------------- raymarching

@@ -74,6 +74,7 @@ REFERENCE_TABLES = {   # raymarching/src/bindings.cpp:5-20, gridencoder/src/bind
                          "composite_rays_train_backward": 17, "march_rays": 19, "composite_rays": 12},
     "_gridencoder": {"grid_encode_forward": 15, "grid_encode_backward": 17, "grad_total_variation": 13},
     "_shencoder": {"sh_encode_forward": 6, "sh_encode_backward": 7},
+    "_freqencoder": {"freq_encode_forward": 6, "freq_encode_backward": 7},      # freqencoder/src/bindings.cpp:5-8
 }
 
 
@@ -92,7 +93,7 @@ def test_backend_shims_have_the_reference_function_tables():
 def test_shim_signatures_match_reference_headers():
     """Parameter counts above are the ones of the reference's C++ prototypes."""
     for pkg, hdr, mod in (("raymarching", "raymarching.h", "_raymarching_mob"), ("gridencoder", "gridencoder.h", "_gridencoder"),
-                          ("shencoder", "shencoder.h", "_shencoder")):
+                          ("shencoder", "shencoder.h", "_shencoder"), ("freqencoder", "freqencoder.h", "_freqencoder")):
         src = open(f"/root/reference/{pkg}/src/{hdr}").read()
         for fn, nargs in REFERENCE_TABLES[mod].items():
             m = re.search(r"void\s+" + fn + r"\s*\((.*?)\)\s*;", src, flags=re.S)

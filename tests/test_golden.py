@@ -68,6 +68,15 @@ def test_oracle_sh(oracle):
         np.testing.assert_allclose(dy, g[f"dy{deg}"], rtol=2e-6, atol=6e-5)
 
 
+def test_oracle_freq(oracle):
+    g = load("freq")
+    for deg in (1, 4, 6):
+        out = oracle.freq_encode_forward(g["inputs"], deg)
+        assert np.array_equal(out.view(np.uint32), g[f"out{deg}"].view(np.uint32))
+        gi = oracle.freq_encode_backward(g[f"grad{deg}"], g[f"out{deg}"], 3, deg)
+        assert np.array_equal(gi.view(np.uint32), g[f"grad_inputs{deg}"].view(np.uint32))
+
+
 # ------------------------------------------------------------------------------------------------------- GPU: HIP
 @pytest.fixture(scope="module")
 def hip():
@@ -147,3 +156,19 @@ def test_hip_sh(hip):
         sh.sh_encode_forward(dev(hip, g["inputs"]), out, 64, 3, deg, dy)
         np.testing.assert_allclose(out.cpu().numpy(), g[f"out{deg}"], rtol=0, atol=4e-6)
         np.testing.assert_allclose(dy.cpu().numpy(), g[f"dy{deg}"], rtol=4e-6, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_freq(hip):
+    """fp32 tolerance: device sinf vs the host libm behind the fixtures (<= 2 ulp of values in [-1, 1]); the backward is a few
+    multiply-adds of those values in the reference's order."""
+    torch, g = hip["torch"], load("freq")
+    import _freqencoder as fq
+    for deg in (1, 4, 6):
+        C = 3 + 2 * deg * 3
+        out = torch.empty(64, C, device="cuda")
+        fq.freq_encode_forward(dev(hip, g["inputs"]), 64, 3, deg, C, out)
+        np.testing.assert_allclose(out.cpu().numpy(), g[f"out{deg}"], rtol=0, atol=3e-7)
+        gi = torch.empty(64, 3, device="cuda")
+        fq.freq_encode_backward(dev(hip, g[f"grad{deg}"]), dev(hip, g[f"out{deg}"]), 64, 3, deg, C, gi)
+        np.testing.assert_allclose(gi.cpu().numpy(), g[f"grad_inputs{deg}"], rtol=1e-5, atol=1e-5)

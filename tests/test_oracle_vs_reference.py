@@ -304,6 +304,34 @@ def test_sh_encode(oracle, ref, degree):
     assert np.array_equal(gi.numpy().view(np.uint32), ogi.view(np.uint32))
 
 
+@pytest.mark.parametrize("degree", [1, 4, 6, 10])
+def test_freq_encode(oracle, degree):
+    """freqencoder.cu:30-94 on the host (its __sinf maps to sinf in the shim) == the oracle, bit for bit, forward and backward."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import build_ref
+    if not build_ref.available():
+        pytest.skip("oracle/_ref not built")
+    fq = build_ref.load_freq()
+    rng = np.random.default_rng(9)
+    B, D = 300, 3
+    C = D + 2 * degree * D
+    x = (rng.normal(size=(B, D)) * 3).astype(np.float32)
+    out = t(np.zeros((B, C), np.float32))
+    fq.freq_encode_forward(t(x), B, D, degree, C, out)
+    oo = oracle.freq_encode_forward(x, degree)
+    assert np.array_equal(out.numpy().view(np.uint32), oo.view(np.uint32))
+    g = rng.normal(size=(B, C)).astype(np.float32)
+    gi = t(np.zeros((B, D), np.float32))
+    fq.freq_encode_backward(t(g), out, B, D, degree, C, gi)
+    ogi = oracle.freq_encode_backward(g, oo, D, degree)
+    assert np.array_equal(gi.numpy().view(np.uint32), ogi.view(np.uint32))
+    # independent property: the columns really are sin / cos of 2^f x
+    f = min(degree - 1, 3)
+    np.testing.assert_allclose(oo[:, D + 2 * f * D:D + (2 * f + 1) * D], np.sin(x.astype(np.float64) * 2 ** f), atol=2e-6)
+    np.testing.assert_allclose(oo[:, D + (2 * f + 1) * D:D + (2 * f + 2) * D], np.cos(x.astype(np.float64) * 2 ** f), atol=4e-6)
+
+
 def test_sh_orthonormality(oracle):
     # independent property: Monte-Carlo orthonormality of the basis on the sphere (SURVEY.md section 4)
     rng = np.random.default_rng(8)
