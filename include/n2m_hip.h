@@ -64,6 +64,9 @@ int n2m_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, voi
 /* raymarching.h:11  packbits   kernel raymarching.cu:267-289.
  * grid [N*8] fp32, bitfield [N] u8: bit i of byte n  <=>  grid[8n+i] > density_thresh  (strict, LSB first). */
 int n2m_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream);
+/* New: packbits with the threshold read from device memory, so that the occupancy refresh (threshold = min(mean density,
+ * density_thresh), nerf/renderer.py:1142-1145) needs no host read-back of the mean. */
+int n2m_packbits_dev(const float* grid, uint32_t N, const float* density_thresh, uint8_t* bitfield, void* stream);
 
 /* raymarching.h:12  flatten_rays   kernel raymarching.cu:303-319.
  * rays [N,2] = (offset,count); res [M] int32: res[offset .. offset+count) = n.  Other entries untouched. */

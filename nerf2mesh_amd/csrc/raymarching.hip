@@ -82,7 +82,9 @@ __global__ void morton_invert_kernel(const int32_t* __restrict__ indices, uint32
 }
 
 // One lane packs 4 output bytes from 32 floats read as 8 x float4 (128 B per lane, 8 KiB per wave-iteration).
-__global__ void packbits_kernel(const float* __restrict__ grid, uint32_t N, float thresh, uint8_t* __restrict__ bitfield) {
+__global__ void packbits_kernel(const float* __restrict__ grid, uint32_t N, float thresh, uint8_t* __restrict__ bitfield,
+                                const float* __restrict__ thresh_dev = nullptr) {
+    if (thresh_dev) thresh = *thresh_dev;
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;   // index of a group of 4 output bytes
     const uint32_t nq = N >> 2;
     if (q < nq) {
@@ -106,7 +108,9 @@ __global__ void packbits_kernel(const float* __restrict__ grid, uint32_t N, floa
     }
 }
 
-__global__ void packbits_bytes_kernel(const float* __restrict__ grid, uint32_t N, float thresh, uint8_t* __restrict__ bitfield) {
+__global__ void packbits_bytes_kernel(const float* __restrict__ grid, uint32_t N, float thresh, uint8_t* __restrict__ bitfield,
+                                      const float* __restrict__ thresh_dev = nullptr) {
+    if (thresh_dev) thresh = *thresh_dev;
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     uint32_t bits = 0;
@@ -760,6 +764,18 @@ extern "C" int n2m_packbits(const float* grid, uint32_t N, float density_thresh,
     const bool aligned = (((uintptr_t)grid & 15u) == 0) && (((uintptr_t)bitfield & 3u) == 0);
     if (aligned) packbits_kernel<<<n2m_ceil_div((uint64_t)(N >> 2) + 1, 256), 256, 0, s>>>(grid, N, density_thresh, bitfield);
     else packbits_bytes_kernel<<<n2m_ceil_div(N, 256), 256, 0, s>>>(grid, N, density_thresh, bitfield);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_packbits_dev(const float* grid, uint32_t N, const float* density_thresh, uint8_t* bitfield, void* stream) {
+    N2M_NOTNULL(grid); N2M_NOTNULL(bitfield); N2M_NOTNULL(density_thresh);
+    if (N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    N2M_PROF(N2M_K_PACKBITS, s, 33.0 * N);
+    const bool aligned = (((uintptr_t)grid & 15u) == 0) && (((uintptr_t)bitfield & 3u) == 0);
+    if (aligned) packbits_kernel<<<n2m_ceil_div((uint64_t)(N >> 2) + 1, 256), 256, 0, s>>>(grid, N, 0.f, bitfield, density_thresh);
+    else packbits_bytes_kernel<<<n2m_ceil_div(N, 256), 256, 0, s>>>(grid, N, 0.f, bitfield, density_thresh);
     N2M_CHECK_LAUNCH();
     return 0;
 }

@@ -81,7 +81,10 @@ def packbits(grid, thresh, bitfield=None):
     N = grid.numel() // 8
     if bitfield is None:
         bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
-    L.call("n2m_packbits", _p(grid), N, float(thresh), _p(bitfield), L.stream())
+    if torch.is_tensor(thresh):        # threshold computed on the device: no host read-back (n2m_packbits_dev)
+        L.call("n2m_packbits_dev", _p(grid), N, _p(thresh.float().contiguous()), _p(bitfield), L.stream())
+    else:
+        L.call("n2m_packbits", _p(grid), N, float(thresh), _p(bitfield), L.stream())
     return bitfield
 
 

@@ -35,6 +35,15 @@ def contract(xyzs):
 
 
 class NeRFRenderer(nn.Module):
+    @property
+    def mean_density(self):
+        t = getattr(self, "_mean_density_t", None)
+        return float(t) if t is not None else 0.0
+
+    @mean_density.setter
+    def mean_density(self, v):
+        self._mean_density_t = None if v == 0 else torch.tensor(float(v))
+
     def __init__(self, opt):
         super().__init__()
         self.opt = opt
@@ -203,9 +212,10 @@ class NeRFRenderer(nn.Module):
             tmp_grid[cas] = sigmas.float()
         valid = (self.density_grid >= 0) & (tmp_grid >= 0)
         self.density_grid.copy_(torch.where(valid, torch.maximum(self.density_grid * decay, tmp_grid), self.density_grid))
-        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        # mean and threshold stay on the device (the reference reads the mean back every refresh, :1142): no queue drain
+        self._mean_density_t = torch.mean(self.density_grid.clamp(min=0))
         self.iter_density += 1
-        density_thresh = min(self.mean_density, self.density_thresh)
+        density_thresh = self._mean_density_t.clamp(max=self.density_thresh)
         self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
 
     @torch.no_grad()

@@ -58,6 +58,9 @@ def test_morton_packbits_flatten(be, oracle):
         bf = torch.zeros(n_floats // 8, dtype=torch.uint8, device="cuda")
         rm.packbits(dev(be, grid), n_floats // 8, 0.5, bf)
         assert np.array_equal(bf.cpu().numpy(), oracle.packbits(grid, 0.5))
+        from nerf2mesh_amd import raymarching as R                      # threshold from device memory: same bits
+        bf2 = R.packbits(dev(be, grid), torch.tensor(0.5, device="cuda"))
+        assert torch.equal(bf2, bf)
     rays = np.array([[0, 3], [3, 0], [3, 70], [73, 1]], np.int32)
     res = torch.zeros(74, dtype=torch.int32, device="cuda")
     rm.flatten_rays(dev(be, rays), 4, 74, res)
