@@ -59,12 +59,14 @@ def pmc_traffic(entry_point):
     return float(sum(vals) if how == "sum" else sum(vals) / len(vals))
 
 
-def cpu_baseline(n_rays=4096, reps=2):
+def cpu_baseline(n_rays=32768, reps=4, threads=None):
     """One stage-0 iteration's kernels on the host: oracle (C, OpenMP) for march/encode/composite/TV, torch-CPU for the
-    MLPs.  Returns dict for the JSON line.  Bounded: ~n_rays rays of the same synthetic workload."""
+    MLPs.  Returns dict for the JSON line.  Bounded: ~n_rays rays of the same synthetic workload.
+    threads: OpenMP/torch threads (shared runtime).  Default min(cores, 32): with all 256 hardware threads of the GPU box the
+    fork/join cost of the many small parallel regions made the same code 40x slower (measured 3.3 k vs 610 k samples/s)."""
     from oracle import oracle as orc
     from nerf2mesh_amd import synthetic as S
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32) if threads is None else int(threads)
     torch.set_num_threads(cores)
     poses = S.make_cameras(100, seed=0)
     grid = S.scene_density_grid(H=128)
