@@ -1171,6 +1171,7 @@ bin_fill_kernel(const T* __restrict__ grad /*[L,Bstride,C], first sample of this
 // front end (loads, index arithmetic, sort) is ~80 % of a fill, the log traffic the rest.  Partitions hold kPairP rows for
 // both tables (C=1 then uses half of its LDS accumulator).  TV (template flag) rides on vertex 000 of the fp32 log.
 constexpr uint32_t kPairP = kBinAccBytes / 16u;      // 4096 rows
+constexpr uint32_t kPairTilesPerWg = 4;              // tiles one fill workgroup walks (next tile's inputs prefetched)
 
 template <bool TV>
 __global__ void __launch_bounds__(1024)
@@ -1181,87 +1182,170 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
                      uint32_t* __restrict__ log_v2, float* __restrict__ found_inf) {
     constexpr uint32_t D = 3;
     constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
-    // the logs are structure-of-arrays: row-in-partition as u16 (shared by both tables) + one 4-byte value array per table =
-    // 10 bytes per update pair instead of 2 x 8; staged through LDS so that every array is written as one contiguous run
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    // The logs are structure-of-arrays: row-in-partition as u16 (shared by both tables) + one 4-byte value array per table =
+    // 10 bytes per update pair instead of 2 x 8; staged through LDS so that every array is written as one contiguous run.
+    // SQ counters showed the waves of this kernel parked on barriers / s_waitcnt 55 % of the time (one workgroup per CU, seven
+    // barriers per tile): a workgroup therefore walks several tiles of its level, requests the next tile's inputs before it
+    // works on the current one, stages all three arrays at once and double-buffers the partition counters -- four barriers
+    // per tile.
     extern __shared__ __attribute__((aligned(16))) uint64_t bin_stage[];
-    uint32_t* stage_v = reinterpret_cast<uint32_t*>(bin_stage);                       // kTileEntries x u32
-    uint16_t* stage_rel = reinterpret_cast<uint16_t*>(stage_v + kTileEntries);        // kTileEntries x u16
-    __shared__ uint32_t cnt[kMaxPartsPerLevel];
+    uint32_t* stage_v1 = reinterpret_cast<uint32_t*>(bin_stage);                      // kTileEntries x u32
+    uint32_t* stage_v2 = stage_v1 + kTileEntries;                                    // kTileEntries x u32
+    uint16_t* stage_rel = reinterpret_cast<uint16_t*>(stage_v2 + kTileEntries);       // kTileEntries x u16
+    __shared__ uint32_t cnt2[2][kMaxPartsPerLevel];
     __shared__ uint32_t wave_tot[16], wave_max[2][16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    const uint32_t tile = blockIdx.x, level = blockIdx.y;
+    const uint32_t level = blockIdx.y;
     const uint32_t parts = plan.parts[level], size = plan.size[level];
-    for (uint32_t i = tid; i < parts; i += 1024) cnt[i] = 0;
-    __syncthreads();
+    for (uint32_t i = tid; i < parts; i += 1024) { cnt2[0][i] = 0; cnt2[1][i] = 0; }
 
     const float scale = lv.scale[level];
     const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
     const PartMap pm(parts, 0, kLog2P, !ix.hashed && parts > 1u);
-    uint32_t e_pr[8], e_v1[8], e_v2[8], e_slot[8];        // e_pr = partition << 16 | row in partition (rel < 4096, parts <= 2048)
-    uint32_t vmask = 0;
+    const bool fast_hash = ix.hashed && ix.pow2, fast_dense = !ix.hashed && !ix.wrap;
     float vmax1 = 0.0f, vmax2 = 0.0f;
 
-    const uint32_t s = tile * 1024u + tid;
-    float x[D] = {2.f, 2.f, 2.f};
-    if (s < B) load_point<D>(inputs, s, x);
-    if (!outside_unit_cube<D>(x)) {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const float g1 = grad1[(size_t)level * Bstride + s];
-        const h2 g2 = *reinterpret_cast<const h2*>(grad2 + ((size_t)level * Bstride + s) * 2);
-        const float g2x = (float)g2.x, g2y = (float)g2.y;
-        const float a1 = fabsf(g1), a2 = fmaxf(fabsf(g2x), fabsf(g2y));
-        vmax1 = a1 <= 3.0e38f ? a1 : 1.0f;
-        vmax2 = a2 <= 3.0e38f ? a2 : 1.0f;           // nan: fmaxf drops it, the half2 check below catches it
-        if ((!(a1 <= 3.0e38f) || !(fabsf(g2x) <= 3.0e38f) || !(fabsf(g2y) <= 3.0e38f)) && found_inf) *found_inf = 1.0f;
-        if (!(fabsf(g2x) <= 3.0e38f) || !(fabsf(g2y) <= 3.0e38f)) vmax2 = fmaxf(vmax2, 1.0f);
-        uint32_t cell[D];
-        float frac[D], dfrac[D];
-        locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
-        float tvv = 0.0f;
-        if constexpr (TV) {
-            const bool inner = fmaxf(fmaxf(fabsf(x[0] - 0.5f), fabsf(x[1] - 0.5f)), fabsf(x[2] - 0.5f)) <= tv.inner01;
-            float w = (inner ? tv.weight : tv.weight_outer);
-            if (tv.scale_ptr) w *= *tv.scale_ptr;
-            tvv = tv_term(tv.table + (size_t)plan.row0[level], ix, cell, ix.row(cell), lv.resolution[level], w / (float)(2 * D));
-            const float a = fabsf(tvv);
-            vmax1 += a <= 3.0e38f ? a : 1.0f;
+    // inputs of the first tile
+    uint32_t tile = blockIdx.x;
+    float nx[D] = {2.f, 2.f, 2.f}, ng1 = 0.0f;
+    h2 ng2 = {(_Float16)0, (_Float16)0};
+    auto request = [&](uint32_t t) {
+        const uint32_t s = t * 1024u + tid;
+        nx[0] = nx[1] = nx[2] = 2.f;
+        if (t < plan.tiles && s < B) {
+            load_point<D>(inputs, s, nx);
+            ng1 = grad1[(size_t)level * Bstride + s];
+            ng2 = *reinterpret_cast<const h2*>(grad2 + ((size_t)level * Bstride + s) * 2);
         }
-        // per-axis terms of the row index, hoisted (hashed power-of-two table / dense table without wrap / generic)
-        const bool fast_hash = ix.hashed && ix.pow2, fast_dense = !ix.hashed && !ix.wrap;
-        uint32_t tx[2], ty[2], tz[2];
-        if (fast_hash) {
-            tx[0] = cell[0]; tx[1] = cell[0] + 1u;
-            ty[0] = cell[1] * kPrimes[1]; ty[1] = ty[0] + kPrimes[1];
-            tz[0] = cell[2] * kPrimes[2]; tz[1] = tz[0] + kPrimes[2];
-        } else {
-            tx[0] = cell[0]; tx[1] = cell[0] + 1u;
-            ty[0] = cell[1] * ix.stride[1]; ty[1] = ty[0] + ix.stride[1];
-            tz[0] = cell[2] * ix.stride[2]; tz[1] = tz[0] + ix.stride[2];
-        }
-        const float wx[2] = {1 - frac[0], frac[0]}, wy[2] = {1 - frac[1], frac[1]}, wz[2] = {1 - frac[2], frac[2]};
-#pragma unroll
-        for (uint32_t corner = 0; corner < 8; ++corner) {
-            const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
-            uint32_t row;
-            if (fast_hash) row = (tx[i] ^ ty[j] ^ tz[k]) & ix.mask;
-            else if (fast_dense) row = tx[i] + ty[j] + tz[k];
-            else {
-                const uint32_t v[D] = {cell[0] + i, cell[1] + j, cell[2] + k};
-                row = ix.row(v);
+    };
+    request(tile);
+    __syncthreads();
+
+    for (uint32_t it = 0; tile < plan.tiles; tile += gridDim.x, ++it) {
+        uint32_t* cnt = cnt2[it & 1u];
+        uint32_t* cnt_next = cnt2[(it & 1u) ^ 1u];
+        float x[D] = {nx[0], nx[1], nx[2]};
+        const float g1 = ng1;
+        const h2 g2 = ng2;
+        request(tile + gridDim.x);                       // next tile's inputs are in flight while this one is processed
+
+        uint32_t e_pr[8], e_v1[8], e_v2[8], e_slot[8];    // e_pr = partition << 16 | row in partition (rel < 4096, parts <= 2048)
+        uint32_t vmask = 0;
+        if (!outside_unit_cube<D>(x)) {
+            const float g2x = (float)g2.x, g2y = (float)g2.y;
+            const float a1 = fabsf(g1), a2 = fmaxf(fabsf(g2x), fabsf(g2y));
+            vmax1 = fmaxf(vmax1, a1 <= 3.0e38f ? a1 : 1.0f);
+            vmax2 = fmaxf(vmax2, a2 <= 3.0e38f ? a2 : 1.0f);           // nan: fmaxf drops it, the check below catches it
+            const bool bad2 = !(fabsf(g2x) <= 3.0e38f) || !(fabsf(g2y) <= 3.0e38f);
+            if ((!(a1 <= 3.0e38f) || bad2) && found_inf) *found_inf = 1.0f;
+            if (bad2) vmax2 = fmaxf(vmax2, 1.0f);
+            uint32_t cell[D];
+            float frac[D], dfrac[D];
+            locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
+            float tvv = 0.0f;
+            if constexpr (TV) {
+                const bool inner = fmaxf(fmaxf(fabsf(x[0] - 0.5f), fabsf(x[1] - 0.5f)), fabsf(x[2] - 0.5f)) <= tv.inner01;
+                float w = (inner ? tv.weight : tv.weight_outer);
+                if (tv.scale_ptr) w *= *tv.scale_ptr;
+                tvv = tv_term(tv.table + (size_t)plan.row0[level], ix, cell, ix.row(cell), lv.resolution[level], w / (float)(2 * D));
+                const float a = fabsf(tvv);
+                vmax1 = fmaxf(vmax1, (a1 <= 3.0e38f ? a1 : 1.0f) + (a <= 3.0e38f ? a : 1.0f));       // |w*g + tv| <= |g| + |tv|
             }
-            const float w = (wx[i] * wy[j]) * wz[k];                     // forward's association
-            float p1 = w * g1;
-            if (TV && corner == 0) p1 += tvv;
-            h2 p2;
-            p2.x = (_Float16)(w * g2x);
-            p2.y = (_Float16)(w * g2y);
-            e_v1[corner] = __float_as_uint(p1);
-            e_v2[corner] = __builtin_bit_cast(uint32_t, p2);
-            uint32_t part_, rel_;
-            pm.split(row, part_, rel_);
-            e_pr[corner] = (part_ << 16) | rel_;
-            if (((e_v1[corner] << 1) | (e_v2[corner] & 0x7FFF7FFFu)) != 0u) vmask |= 1u << corner;
+            // per-axis terms of the row index, hoisted (hashed power-of-two table / dense table without wrap / generic)
+            uint32_t tx[2], ty[2], tz[2];
+            if (fast_hash) {
+                tx[0] = cell[0]; tx[1] = cell[0] + 1u;
+                ty[0] = cell[1] * kPrimes[1]; ty[1] = ty[0] + kPrimes[1];
+                tz[0] = cell[2] * kPrimes[2]; tz[1] = tz[0] + kPrimes[2];
+            } else {
+                tx[0] = cell[0]; tx[1] = cell[0] + 1u;
+                ty[0] = cell[1] * ix.stride[1]; ty[1] = ty[0] + ix.stride[1];
+                tz[0] = cell[2] * ix.stride[2]; tz[1] = tz[0] + ix.stride[2];
+            }
+            const float wx[2] = {1 - frac[0], frac[0]}, wy[2] = {1 - frac[1], frac[1]}, wz[2] = {1 - frac[2], frac[2]};
+#pragma unroll
+            for (uint32_t corner = 0; corner < 8; ++corner) {
+                const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
+                uint32_t row;
+                if (fast_hash) row = (tx[i] ^ ty[j] ^ tz[k]) & ix.mask;
+                else if (fast_dense) row = tx[i] + ty[j] + tz[k];
+                else {
+                    const uint32_t v[D] = {cell[0] + i, cell[1] + j, cell[2] + k};
+                    row = ix.row(v);
+                }
+                const float w = (wx[i] * wy[j]) * wz[k];                     // forward's association
+                float p1 = w * g1;
+                if (TV && corner == 0) p1 += tvv;
+                h2 p2;
+                p2.x = (_Float16)(w * g2x);
+                p2.y = (_Float16)(w * g2y);
+                e_v1[corner] = __float_as_uint(p1);
+                e_v2[corner] = __builtin_bit_cast(uint32_t, p2);
+                uint32_t part_, rel_;
+                pm.split(row, part_, rel_);
+                e_pr[corner] = (part_ << 16) | rel_;
+                if (((e_v1[corner] << 1) | (e_v2[corner] & 0x7FFF7FFFu)) != 0u) vmask |= 1u << corner;
+            }
         }
+
+        // slot of every entry inside its partition's run of this tile
+        if (parts == 1u) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c) {
+                const bool v = (vmask >> c) & 1u;
+                const unsigned long long m = __ballot(v);
+                uint32_t base = 0;
+                if (lane == 0 && m) base = atomicAdd(&cnt[0], (uint32_t)__popcll(m));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                e_slot[c] = base + (uint32_t)__popcll(m & below);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c)
+                if ((vmask >> c) & 1u) e_slot[c] = atomicAdd(&cnt[e_pr[c] >> 16], 1u);
+        }
+        __syncthreads();                                                     // (1) counters complete
+
+        const uint32_t i0 = 2u * tid, i1 = i0 + 1u;
+        const uint32_t a0 = i0 < parts ? cnt[i0] : 0u, a1c = i1 < parts ? cnt[i1] : 0u;
+        const uint32_t incl = n2m_wave_scan_add_u32(a0 + a1c, (int)lane);
+        if (lane == 63u) wave_tot[wid] = incl;
+        __syncthreads();                                                     // (2) wave totals
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) {
+            const uint32_t t = wave_tot[w];
+            if (w < wid) woff += t;
+            total += t;
+        }
+        const uint32_t excl = woff + incl - (a0 + a1c);
+        uint32_t* __restrict__ dir = directory + plan.dir_base[level] + (size_t)tile * (parts + 1u);
+        if (i0 < parts) { cnt[i0] = excl; dir[i0] = excl; }
+        if (i1 < parts) { cnt[i1] = excl + a0; dir[i1] = excl + a0; }
+        if (tid == 0) dir[parts] = total;
+        __syncthreads();                                                     // (3) run starts in place
+
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c)
+            if ((vmask >> c) & 1u) {
+                const uint32_t pos = cnt[e_pr[c] >> 16] + e_slot[c];         // position in the sorted tile
+                stage_v1[pos] = e_v1[c];
+                stage_v2[pos] = e_v2[c];
+                stage_rel[pos] = (uint16_t)(e_pr[c] & 0xFFFFu);
+            }
+        for (uint32_t i = tid; i < parts; i += 1024) cnt_next[i] = 0;        // the other counter set, for the next tile
+        __syncthreads();                                                     // (4) tile staged (and next counters clean)
+
+        const size_t seg = ((size_t)level * plan.tiles + tile) * kTileEntries;
+        for (uint32_t i = tid; i < total; i += 1024) { log_v1[seg + i] = stage_v1[i]; log_v2[seg + i] = stage_v2[i]; }
+        {   // rows as u32 pairs (seg is even; a trailing odd entry drags one stale u16 along: never read back)
+            const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(stage_rel);
+            uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(log_rel + seg);
+            for (uint32_t i = tid; i < (total + 1u) / 2u; i += 1024) dst[i] = src[i];
+        }
+        // no barrier here: the next tile writes the stage only after its barrier (3), which every thread reaches after this copy
     }
 
     // level maxima of both tables: workgroup reduction, one conditional atomicMax each (see bin_fill_kernel)
@@ -1271,23 +1355,6 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
         vmax2 = fmaxf(vmax2, __shfl_xor(vmax2, o, 64));
     }
     if (lane == 0) { wave_max[0][wid] = __float_as_uint(vmax1); wave_max[1][wid] = __float_as_uint(vmax2); }
-
-    if (parts == 1u) {
-        const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-        for (uint32_t c = 0; c < 8; ++c) {
-            const bool v = (vmask >> c) & 1u;
-            const unsigned long long m = __ballot(v);
-            uint32_t base = 0;
-            if (lane == 0 && m) base = atomicAdd(&cnt[0], (uint32_t)__popcll(m));
-            base = __shfl(base, 0, 64);
-            e_slot[c] = base + (uint32_t)__popcll(m & below);
-        }
-    } else {
-#pragma unroll
-        for (uint32_t c = 0; c < 8; ++c)
-            if ((vmask >> c) & 1u) e_slot[c] = atomicAdd(&cnt[e_pr[c] >> 16], 1u);
-    }
     __syncthreads();
     if (tid < 2u) {
         uint32_t m = 0;
@@ -1296,47 +1363,6 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
         uint32_t* dst = level_max + tid * kMaxLevels + level;
         if (m > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, m);
     }
-
-    const uint32_t i0 = 2u * tid, i1 = i0 + 1u;
-    const uint32_t a0 = i0 < parts ? cnt[i0] : 0u, a1c = i1 < parts ? cnt[i1] : 0u;
-    const uint32_t incl = n2m_wave_scan_add_u32(a0 + a1c, (int)lane);
-    if (lane == 63u) wave_tot[wid] = incl;
-    __syncthreads();
-    uint32_t woff = 0, total = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < 16; ++w) {
-        const uint32_t t = wave_tot[w];
-        if (w < wid) woff += t;
-        total += t;
-    }
-    const uint32_t excl = woff + incl - (a0 + a1c);
-    uint32_t* __restrict__ dir = directory + plan.dir_base[level] + (size_t)tile * (parts + 1u);
-    if (i0 < parts) { cnt[i0] = excl; dir[i0] = excl; }
-    if (i1 < parts) { cnt[i1] = excl + a0; dir[i1] = excl + a0; }
-    if (tid == 0) dir[parts] = total;
-    __syncthreads();
-
-#pragma unroll
-    for (uint32_t c = 0; c < 8; ++c)
-        if ((vmask >> c) & 1u) {
-            e_slot[c] += cnt[e_pr[c] >> 16];                       // position in the sorted tile
-            stage_v[e_slot[c]] = e_v1[c];
-            stage_rel[e_slot[c]] = (uint16_t)(e_pr[c] & 0xFFFFu);
-        }
-    __syncthreads();
-    const size_t seg = ((size_t)level * plan.tiles + tile) * kTileEntries;
-    for (uint32_t i = tid; i < total; i += 1024) log_v1[seg + i] = stage_v[i];
-    {   // rows as u32 pairs (seg is even, a trailing odd entry is padded with whatever follows in LDS: never read back)
-        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(stage_rel);
-        uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(log_rel + seg);
-        for (uint32_t i = tid; i < (total + 1u) / 2u; i += 1024) dst[i] = src[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t c = 0; c < 8; ++c)
-        if ((vmask >> c) & 1u) stage_v[e_slot[c]] = e_v2[c];
-    __syncthreads();
-    for (uint32_t i = tid; i < total; i += 1024) log_v2[seg + i] = stage_v[i];
 }
 
 // P = table rows per partition; SUB = consecutive partitions one work item accumulates (their runs are adjacent in the
@@ -1735,8 +1761,8 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
                        void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn, float* found_inf) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 8));
-        (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 8));
+        (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
+        (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
         (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<float, 1, kPairP, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
         (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<_Float16, 2, kPairP, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
         attr_set = true;
@@ -1755,12 +1781,12 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         const float* g1 = grad1 + (size_t)b0;
         const _Float16* g2 = grad2 + (size_t)b0 * 2;
         const float* x = inputs + (size_t)b0 * 3;
-        const dim3 grid(lay.plan.tiles, max_level);
+        const dim3 grid((lay.plan.tiles + kPairTilesPerWg - 1) / kPairTilesPerWg, max_level);     // each workgroup walks ~kPairTilesPerWg tiles
         if (tv.table)
-            bin_fill_pair_kernel<true><<<grid, 1024, kTileEntries * 6, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
+            bin_fill_pair_kernel<true><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
                                                                              directory, log_rel, log_v1, log_v2, found_inf);
         else
-            bin_fill_pair_kernel<false><<<grid, 1024, kTileEntries * 6, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
+            bin_fill_pair_kernel<false><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
                                                                               directory, log_rel, log_v1, log_v2, found_inf);
         N2M_CHECK_LAUNCH();
         const uint32_t items = lay.plan.item_prefix[max_level];
