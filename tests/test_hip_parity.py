@@ -617,6 +617,38 @@ def test_grid_backward_binned_pair_equals_two_calls(be, with_tv):
     assert binned_backward_pair(e1, e2, d1, d2n, x, torch.zeros_like(a1), torch.zeros_like(a2), 16, found_inf=flag) and float(flag) == 1
 
 
+@pytest.mark.parametrize("B,max_level", [(5, 16), (1025, 7), (40000, 1)])
+def test_grid_backward_binned_pair_edge_cases(be, oracle, B, max_level):
+    """Shared-fill backward vs the oracle on tiny / ragged batches and truncated level ranges; all-zero gradients leave the tables
+    untouched; levels >= max_level are never written."""
+    torch = be["torch"]
+    from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward_pair
+    rng = np.random.default_rng(B)
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    e2 = GridEncoder(level_dim=2, desired_resolution=2048).cuda()
+    offs = np.asarray(e1.host_offsets, np.int32)
+    S = float(np.log2(e1.per_level_scale))
+    x = rng.random((B, 3), dtype=np.float32)
+    x[0] = [1.0, 0.0, 0.5]
+    d1 = rng.normal(size=(16, B, 1)).astype(np.float32)
+    d2 = rng.normal(size=(16, B, 2)).astype(np.float16)
+    pre1 = (rng.normal(size=(int(offs[-1]), 1)) * 0.01).astype(np.float32)
+    pre2 = (rng.normal(size=(int(offs[-1]), 2)) * 0.01).astype(np.float16)
+    a1, a2 = dev(be, pre1.copy()), dev(be, pre2.copy())
+    assert binned_backward_pair(e1, e2, dev(be, d1), dev(be, d2), dev(be, x), a1, a2, max_level)
+    o1 = oracle.grid_encode_backward(d1, x, np.zeros_like(pre1), offs, S, 16, max_level)
+    o2 = oracle.grid_encode_backward(d2, x, np.zeros_like(pre2), offs, S, 16, max_level)
+    np.testing.assert_allclose(a1.cpu().numpy() - pre1, o1, rtol=1e-4, atol=1e-5 * max(np.abs(o1).max(), 1e-6))
+    got2 = a2.cpu().numpy().astype(np.float32) - pre2.astype(np.float32)
+    np.testing.assert_allclose(got2, o2.astype(np.float32), rtol=3e-2, atol=3e-2 * max(np.abs(o2).max(), 1e-3))
+    top = int(offs[max_level])
+    assert np.array_equal(a1.cpu().numpy()[top:], pre1[top:]) and np.array_equal(a2.cpu().numpy()[top:], pre2[top:])
+    z1, z2 = dev(be, pre1.copy()), dev(be, pre2.copy())
+    assert binned_backward_pair(e1, e2, torch.zeros(16, B, 1, device="cuda"), torch.zeros(16, B, 2, device="cuda", dtype=torch.float16), dev(be, x),
+                                z1, z2, max_level)
+    assert np.array_equal(z1.cpu().numpy(), pre1) and np.array_equal(z2.cpu().numpy(), pre2)
+
+
 def test_grad_total_variation_binned(be, oracle):
     torch = be["torch"]
     from nerf2mesh_amd import _lib as L
