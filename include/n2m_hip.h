@@ -209,7 +209,10 @@ int n2m_grad_total_variation_binned(const float* inputs, const float* embeddings
 int n2m_grid_encode_forward_pair(const float* inputs, const float* embeddings1, const void* embeddings2,
                                  const int32_t* offsets, float* outputs1, void* outputs2, uint32_t B, uint32_t L,
                                  uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
-                                 uint32_t interp, void* stream);
+                                 uint32_t interp, float in_scale, float in_offset, void* stream);
+/* in_scale / in_offset (here and in the pair backward): the kernels read x * in_scale + in_offset, i.e. (1, 0) for inputs already
+ * in [0,1], or (1/(2*bound), 0.5) to consume the renderer's points in [-bound, bound] directly -- for a power-of-two bound that is
+ * bit-identical to grid.py:156's (x + bound) / (2 * bound) and saves two elementwise passes per call. */
 
 /* Both encoders of nerf2mesh's field in one call: the density table (fp32, C=1) and the colour table (fp16, C=2) share
  * their level geometry and are queried at the same inputs (nerf/network.py:92-108), so the index arithmetic and the partition
@@ -221,8 +224,8 @@ int n2m_grid_encode_backward_binned_pair(const float* grad1, const void* grad2, 
                                          void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level, float S,
                                          uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                                          const float* tv_embeddings, float tv_weight, float tv_weight_outer,
-                                         float tv_inner01, const float* tv_scale, float* found_inf, void* workspace,
-                                         uint64_t workspace_bytes, void* stream);
+                                         float tv_inner01, const float* tv_scale, float* found_inf, float in_scale,
+                                         float in_offset, void* workspace, uint64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * freqencoder   (reference: freqencoder/src/freqencoder.h:6-10, freqencoder/src/bindings.cpp:5-8)

@@ -424,7 +424,8 @@ __device__ __forceinline__ void atomic_add_row(float* dst, const float* v, uint3
 __global__ void __launch_bounds__(256)
 grid_forward3_pair_kernel(const float* __restrict__ inputs, const float* __restrict__ table1, const _Float16* __restrict__ table2,
                           const int32_t* __restrict__ offsets, float* __restrict__ out1, _Float16* __restrict__ out2, uint32_t B,
-                          uint32_t max_level, LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t n_tiles) {
+                          uint32_t max_level, LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t n_tiles,
+                          float in_scale, float in_offset) {
     constexpr uint32_t D = 3;
     const uint32_t level = blockIdx.x / n_tiles, tile = blockIdx.x - level * n_tiles;
     if (level >= max_level) return;
@@ -441,6 +442,8 @@ grid_forward3_pair_kernel(const float* __restrict__ inputs, const float* __restr
 
     float x[D];
     load_point<D>(inputs, b, x);
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) x[d] = x[d] * in_scale + in_offset;     // (1, 0) = inputs already in [0,1]; see n2m_hip.h
     if (outside_unit_cube<D>(x)) {
         *o1 = 0.0f;
         Row<_Float16, 2> z;
@@ -1179,7 +1182,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
                      const float* __restrict__ inputs, TvParams tv, uint32_t B, uint32_t Bstride, BinPlan plan, LevelTable lv,
                      uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max /*[2][32]*/,
                      uint32_t* __restrict__ directory, uint16_t* __restrict__ log_rel, uint32_t* __restrict__ log_v1,
-                     uint32_t* __restrict__ log_v2, float* __restrict__ found_inf) {
+                     uint32_t* __restrict__ log_v2, float* __restrict__ found_inf, float in_scale, float in_offset) {
     constexpr uint32_t D = 3;
     constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -1215,6 +1218,8 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
         nx[0] = nx[1] = nx[2] = 2.f;
         if (t < plan.tiles && s < B) {
             load_point<D>(inputs, s, nx);
+#pragma unroll
+            for (uint32_t d = 0; d < D; ++d) nx[d] = nx[d] * in_scale + in_offset;
             ng1 = grad1[(size_t)level * Bstride + s];
             ng2 = *reinterpret_cast<const h2*>(grad2 + ((size_t)level * Bstride + s) * 2);
         }
@@ -1758,7 +1763,8 @@ int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table
 
 int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* inputs, TvParams tv, float* table1, _Float16* table2, uint32_t B,
                        uint32_t max_level, const int32_t* host_offsets, const LevelTable& lv, uint32_t gridtype, bool align, uint32_t interp,
-                       void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn, float* found_inf) {
+                       void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn, float* found_inf, float in_scale,
+                       float in_offset) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
@@ -1784,10 +1790,10 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         const dim3 grid((lay.plan.tiles + kPairTilesPerWg - 1) / kPairTilesPerWg, max_level);     // each workgroup walks ~kPairTilesPerWg tiles
         if (tv.table)
             bin_fill_pair_kernel<true><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
-                                                                             directory, log_rel, log_v1, log_v2, found_inf);
+                                                                             directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset);
         else
             bin_fill_pair_kernel<false><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
-                                                                              directory, log_rel, log_v1, log_v2, found_inf);
+                                                                              directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset);
         N2M_CHECK_LAUNCH();
         const uint32_t items = lay.plan.item_prefix[max_level];
         const uint32_t nb = items < 4096u ? items : 4096u;
@@ -2022,8 +2028,8 @@ extern "C" int n2m_grid_encode_backward_binned_pair(const float* grad1, const vo
                                                     float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
                                                     float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                                                     const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
-                                                    const float* tv_scale, float* found_inf, void* workspace, uint64_t workspace_bytes,
-                                                    void* stream) {
+                                                    const float* tv_scale, float* found_inf, float in_scale, float in_offset, void* workspace,
+                                                    uint64_t workspace_bytes, void* stream) {
     const char* fn = "grid_encode_backward_binned_pair";
     if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
     N2M_REQUIRE(grad1 && grad2 && inputs && host_offsets && grad_embeddings1 && grad_embeddings2 && workspace, N2M_ENULL, "%s: NULL tensor", fn);
@@ -2036,12 +2042,13 @@ extern "C" int n2m_grid_encode_backward_binned_pair(const float* grad1, const vo
     N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (12.0 + (double)max_level * (4 + 4) + 2.0 * max_level * 8 * (4 + 4) +
                                              (tv_embeddings ? (double)L * 7 * 4.0 : 0.0)));
     return launch_binned_pair(grad1, (const _Float16*)grad2, inputs, tv, grad_embeddings1, (_Float16*)grad_embeddings2, B, max_level, host_offsets, lv,
-                              gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf);
+                              gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf, in_scale, in_offset);
 }
 
 extern "C" int n2m_grid_encode_forward_pair(const float* inputs, const float* embeddings1, const void* embeddings2, const int32_t* offsets,
                                             float* outputs1, void* outputs2, uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H,
-                                            uint32_t gridtype, int align_corners, uint32_t interp, void* stream) {
+                                            uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
+                                            void* stream) {
     const char* fn = "grid_encode_forward_pair";
     if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
     N2M_REQUIRE(inputs && embeddings1 && embeddings2 && offsets && outputs1 && outputs2, N2M_ENULL, "%s: NULL tensor", fn);
@@ -2052,7 +2059,8 @@ extern "C" int n2m_grid_encode_forward_pair(const float* inputs, const float* em
     N2M_PROF(N2M_K_GRID_FWD, s, (double)B * (12.0 + (double)max_level * 8 * (4 + 4) + (double)max_level * (4 + 4)));
     const uint32_t n_tiles = n2m_ceil_div(B, 256);
     grid_forward3_pair_kernel<<<n_tiles * max_level, 256, 0, s>>>(inputs, embeddings1, (const _Float16*)embeddings2, offsets, outputs1,
-                                                                 (_Float16*)outputs2, B, max_level, lv, gridtype, align_corners != 0, interp, n_tiles);
+                                                                 (_Float16*)outputs2, B, max_level, lv, gridtype, align_corners != 0, interp, n_tiles,
+                                                                 in_scale, in_offset);
     N2M_CHECK_LAUNCH();
     return 0;
 }

@@ -34,8 +34,17 @@ def _encode_lm(x01, emb, enc, max_level):
     return out
 
 
-def _encode_lm_pair(x01, emb1, emb2h, net, max_level):
-    """(h1 [L,B,1] f32, h2 [L,B,2] f16) from one launch when the two encoders share their geometry, else None."""
+def _affine(bound):
+    """(scale, offset) with x01 = x * scale + offset, when that is bit-identical to grid.py:156's (x + bound) / (2 * bound): bound a
+    power of two (every bound nerf2mesh uses).  None otherwise: the caller then materialises x01 with torch."""
+    import math
+    m, _ = math.frexp(float(bound))
+    return (1.0 / (2.0 * float(bound)), 0.5) if m == 0.5 else None
+
+
+def _encode_lm_pair(x01, emb1, emb2h, net, max_level, in_affine=(1.0, 0.0)):
+    """(h1 [L,B,1] f32, h2 [L,B,2] f16) from one launch when the two encoders share their geometry, else None.
+    in_affine: the kernel reads x01 * scale + offset (pass the raw points and _affine(bound) to skip the torch normalisation)."""
     from .gridencoder import same_geometry
     e1, e2 = net.encoder, net.encoder_color
     if not (PAIR_FORWARD and emb1.dtype == torch.float32 and emb1.shape[1] == 1 and emb2h.dtype == torch.float16 and emb2h.shape[1] == 2
@@ -46,7 +55,8 @@ def _encode_lm_pair(x01, emb1, emb2h, net, max_level):
     h1 = mk(Lv, B, 1, device=x01.device, dtype=torch.float32)
     h2 = mk(Lv, B, 2, device=x01.device, dtype=torch.float16)
     L.call("n2m_grid_encode_forward_pair", _p(x01), _p(emb1), _p(emb2h), _p(e1.offsets), _p(h1), _p(h2), B, Lv, max_level,
-           float(np.log2(e1.per_level_scale)), int(e1.base_resolution), e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, L.stream())
+           float(np.log2(e1.per_level_scale)), int(e1.base_resolution), e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id,
+           float(in_affine[0]), float(in_affine[1]), L.stream())
     return h1, h2
 
 
@@ -74,7 +84,7 @@ def _encode_backward_lm(grad_lm, x01, emb, enc, max_level, ws_slot=0):
     return g
 
 
-def _encode_backward_pair(d_h1, d_h2, x01, emb1, emb2h, net, max_level):
+def _encode_backward_pair(d_h1, d_h2, x01, emb1, emb2h, net, max_level, in_affine=(1.0, 0.0)):
     """(g1, g2) through the shared-fill kernel, or (None, None) when it does not apply."""
     from .gridencoder import binned_backward_pair
     enc1, enc2 = net.encoder, net.encoder_color
@@ -83,7 +93,7 @@ def _encode_backward_pair(d_h1, d_h2, x01, emb1, emb2h, net, max_level):
     amp1, amp2 = getattr(enc1, "amp_request", None), getattr(enc2, "amp_request", None)
     finf = amp1["found_inf"] if amp1 is not None else (amp2["found_inf"] if amp2 is not None else None)
     tv = (emb1, req["weight"], req["weight_outer"], req["inner01"], req["scale"]) if req is not None else None
-    if not binned_backward_pair(enc1, enc2, d_h1, d_h2, x01, g1, g2, max_level, tv=tv, found_inf=finf):
+    if not binned_backward_pair(enc1, enc2, d_h1, d_h2, x01, g1, g2, max_level, tv=tv, found_inf=finf, in_affine=in_affine):
         return None, None
     if req is not None:
         req["done"] = True
@@ -100,15 +110,24 @@ class _fused_field(Function):
         xyz = xyz.float().contiguous()
         M = xyz.shape[0]
         bound, max_level = float(net.bound), int(min(net.max_level, net.encoder.num_levels))
-        x01 = (xyz + bound) / (2 * bound)
+        aff = _affine(bound)
+        x01 = None                                        # materialised only for the code paths that need [0,1] points
         sigma = h1 = None
         rgb = spec = h2 = emb2h = None
         emb1 = emb1.float().contiguous() if want_density else None
         if want_color:
             emb2h = net.encoder_color.half_table() if hasattr(net.encoder_color, "half_table") else emb2.half().contiguous()   # grid.py:45
-        both = _encode_lm_pair(x01, emb1, emb2h, net, max_level) if (want_density and want_color) else None
+        both = None
+        if want_density and want_color:
+            if aff is not None:
+                both = _encode_lm_pair(xyz, emb1, emb2h, net, max_level, aff)      # normalisation folded into the kernel
+            else:
+                x01 = (xyz + bound) / (2 * bound)
+                both = _encode_lm_pair(x01, emb1, emb2h, net, max_level)
         if both is not None:
             h1, h2 = both
+        elif x01 is None:
+            x01 = (xyz + bound) / (2 * bound)
         if want_density:
             if h1 is None:
                 h1 = _encode_lm(x01, emb1, net.encoder, max_level)
@@ -124,6 +143,7 @@ class _fused_field(Function):
                _p(spec), L.stream())
         ctx.net, ctx.shading, ctx.want_color, ctx.max_level, ctx.want_density = net, shading, want_color, max_level, want_density
         ctx.normalize_dirs = int(normalize_dirs)
+        ctx.bound = bound
         ctx.save_for_backward(xyz, dirs, x01, h1, h2, emb1, emb2h, *ws)
         if not want_color:
             return sigma
@@ -163,9 +183,17 @@ class _fused_field(Function):
             amp["flagged"] = True
         # both tables: one shared fill when their geometry is identical (it is for nerf2mesh), else one backward per table
         g1 = g2 = None
+        aff = _affine(ctx.bound)
         if want_density and want_color and PAIR_BACKWARD:
-            g1, g2 = _encode_backward_pair(d_h1, d_h2, x01, emb1, emb2h, net, max_level)
+            if x01 is None and aff is not None:
+                g1, g2 = _encode_backward_pair(d_h1, d_h2, xyz, emb1, emb2h, net, max_level, aff)
+            else:
+                if x01 is None:
+                    x01 = (xyz + ctx.bound) / (2 * ctx.bound)
+                g1, g2 = _encode_backward_pair(d_h1, d_h2, x01, emb1, emb2h, net, max_level)
         if g1 is None:
+            if x01 is None:
+                x01 = (xyz + ctx.bound) / (2 * ctx.bound)
             side = L.side_stream(dev) if (want_density and want_color and CONCURRENT_BACKWARD) else None
             if want_color and side is not None:
                 main = torch.cuda.current_stream()

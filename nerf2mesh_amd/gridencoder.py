@@ -128,7 +128,7 @@ def same_geometry(a, b):
             and a.input_dim == b.input_dim == 3)
 
 
-def binned_backward_pair(enc1, enc2, grad1_lm, grad2_lm, x01, g1, g2, max_level, tv=None, found_inf=None):
+def binned_backward_pair(enc1, enc2, grad1_lm, grad2_lm, x01, g1, g2, max_level, tv=None, found_inf=None, in_affine=(1.0, 0.0)):
     """Both table gradients (g1 fp32 C=1, g2 fp16 C=2, zero-filled or running sums) from one shared fill
     (n2m_grid_encode_backward_binned_pair); False when not applicable."""
     if not (g1.dtype == torch.float32 and g1.shape[1] == 1 and g2.dtype == torch.float16 and g2.shape[1] == 2):
@@ -146,7 +146,8 @@ def binned_backward_pair(enc1, enc2, grad1_lm, grad2_lm, x01, g1, g2, max_level,
     tv_emb, tv_w, tv_wo, tv_in, tv_scale = tv if tv is not None else (None, 0.0, 0.0, 1.0, None)
     L.call("n2m_grid_encode_backward_binned_pair", _p(grad1_lm), _p(grad2_lm), _p(x01), ho.ctypes.data, _p(g1), _p(g2), B, enc1.num_levels,
            max_level, float(np.log2(enc1.per_level_scale)), int(enc1.base_resolution), enc1.gridtype_id, int(bool(enc1.align_corners)),
-           enc1.interp_id, _p(tv_emb), float(tv_w), float(tv_wo), float(tv_in), _p(tv_scale), _p(found_inf), _p(ws), ws.numel(), L.stream())
+           enc1.interp_id, _p(tv_emb), float(tv_w), float(tv_wo), float(tv_in), _p(tv_scale), _p(found_inf), float(in_affine[0]),
+           float(in_affine[1]), _p(ws), ws.numel(), L.stream())
     return True
 
 

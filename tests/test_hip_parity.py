@@ -422,12 +422,22 @@ def test_grid_encode_forward_pair_is_bit_identical_to_two_calls(be):
         for ml in (16, 7):
             h1 = torch.full((16, B, 1), 3.0, device="cuda"); h2 = torch.full((16, B, 2), 3.0, device="cuda", dtype=torch.float16)
             L.call("n2m_grid_encode_forward_pair", x.data_ptr(), emb1.data_ptr(), emb2.data_ptr(), e1.offsets.data_ptr(), h1.data_ptr(), h2.data_ptr(),
-                   B, 16, ml, S, 16, e1.gridtype_id, int(align), e1.interp_id, L.stream())
+                   B, 16, ml, S, 16, e1.gridtype_id, int(align), e1.interp_id, 1.0, 0.0, L.stream())
             r1 = torch.full_like(h1, 3.0); r2 = torch.full_like(h2, 3.0)
             for emb, out, C, dt in ((emb1, r1, 1, L.F32), (emb2, r2, 2, L.F16)):
                 L.call("n2m_grid_encode_forward", x.data_ptr(), emb.data_ptr(), e1.offsets.data_ptr(), out.data_ptr(), B, 3, C, 16, ml, S, 16, None,
                        e1.gridtype_id, int(align), e1.interp_id, dt, L.stream())
             assert torch.equal(h1, r1) and torch.equal(h2.view(torch.int16), r2.view(torch.int16))
+            # raw points in [-bound, bound] + in-kernel (x * 1/(2 bound) + 0.5) == torch's (x + bound) / (2 bound), bit for bit
+            for bound in (1.0, 2.0, 16.0):
+                raw = (x * 2 - 1) * bound
+                x01t = (raw + bound) / (2 * bound)
+                a1 = torch.full_like(h1, 3.0); a2 = torch.full_like(h2, 3.0); b1 = torch.full_like(h1, 3.0); b2 = torch.full_like(h2, 3.0)
+                L.call("n2m_grid_encode_forward_pair", raw.data_ptr(), emb1.data_ptr(), emb2.data_ptr(), e1.offsets.data_ptr(), a1.data_ptr(),
+                       a2.data_ptr(), B, 16, ml, S, 16, e1.gridtype_id, int(align), e1.interp_id, 1.0 / (2 * bound), 0.5, L.stream())
+                L.call("n2m_grid_encode_forward_pair", x01t.data_ptr(), emb1.data_ptr(), emb2.data_ptr(), e1.offsets.data_ptr(), b1.data_ptr(),
+                       b2.data_ptr(), B, 16, ml, S, 16, e1.gridtype_id, int(align), e1.interp_id, 1.0, 0.0, L.stream())
+                assert torch.equal(a1, b1) and torch.equal(a2.view(torch.int16), b2.view(torch.int16))
 
 
 def test_grid_backward_linearity_full_size(be):
