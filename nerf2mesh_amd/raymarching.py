@@ -138,6 +138,18 @@ def march_rays_train(rays_o, rays_d, bound, contract, density_bitfield, C, H, ne
                                    max_steps, noises)
 
 
+_ZERO_CACHE = {}
+
+
+def _zeros_like_cached(ref, n):
+    """A persistent all-zero fp32 buffer of at least n elements on ref's device (never written by anyone)."""
+    z = _ZERO_CACHE.get(ref.device)
+    if z is None or z.numel() < n:
+        z = torch.zeros(int(n * 1.5) + 1024, dtype=torch.float32, device=ref.device)
+        _ZERO_CACHE[ref.device] = z
+    return z
+
+
 class _composite_rays_train(Function):
     @staticmethod
     def forward(ctx, sigmas, rgbs, ts, rays, T_thresh=1e-4, alpha_mode=False):
@@ -153,15 +165,21 @@ class _composite_rays_train(Function):
                int(bool(alpha_mode)), _p(weights), _p(weights_sum), _p(depth), _p(image), L.stream())
         ctx.save_for_backward(sigmas, rgbs, ts, rays, weights_sum, depth, image)
         ctx.cfg = (M, N, float(T_thresh), int(bool(alpha_mode)))
+        ctx.set_materialize_grads(False)      # unused outputs (weights, depth in the plain rgb loss) arrive as None, not as fresh zero tensors
         return weights, weights_sum, depth, image
 
     @staticmethod
     def backward(ctx, grad_weights, grad_weights_sum, grad_depth, grad_image):
         sigmas, rgbs, ts, rays, weights_sum, depth, image = ctx.saved_tensors
         M, N, T_thresh, alpha_mode = ctx.cfg
-        gw, gws, gd, gi = (_f32c(g) for g in (grad_weights, grad_weights_sum, grad_depth, grad_image))
-        grad_sigmas = torch.zeros_like(sigmas)
-        grad_rgbs = torch.zeros_like(rgbs)
+        zeros = _zeros_like_cached(sigmas, max(M, 3 * N))          # stands in for every gradient that is None (read-only)
+        gw = _f32c(grad_weights) if grad_weights is not None else zeros[:M]
+        gws = _f32c(grad_weights_sum) if grad_weights_sum is not None else zeros[:N]
+        gd = _f32c(grad_depth) if grad_depth is not None else zeros[:N]
+        gi = _f32c(grad_image) if grad_image is not None else zeros[:3 * N].view(N, 3)
+        both = torch.zeros(M, 4, dtype=torch.float32, device=sigmas.device)      # one fill for the two outputs
+        grad_sigmas = both.view(-1)[:M]
+        grad_rgbs = both.view(-1)[M:].view(M, 3)
         L.call("n2m_composite_rays_train_backward", _p(gw), _p(gws), _p(gd), _p(gi), _p(sigmas), _p(rgbs), _p(ts), _p(rays),
                _p(weights_sum), _p(depth), _p(image), M, N, T_thresh, alpha_mode, _p(grad_sigmas), _p(grad_rgbs), L.stream())
         return grad_sigmas, grad_rgbs, None, None, None, None
