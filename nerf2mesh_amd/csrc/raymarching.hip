@@ -231,10 +231,14 @@ __device__ __forceinline__ LaneEval eval_candidate(const MarchCtx& c, float t) {
     const float z = n2m_clampf(c.oz + t * c.dz, -c.bound, c.bound);
     const float dt = n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
     const float mag = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-    const int lp = level_from_exponent(mag, c.Cf);
-    const int ld = level_from_exponent((dt * c.Hf) * 0.5f, c.Cf);
-    const int level = lp > ld ? lp : ld;
-    const float mip_bound = fminf(scalbnf(1.0f, level), c.bound);
+    int level = 0;
+    float mip_bound = fminf(1.0f, c.bound);              // level 0: min(2^0, bound)
+    if (c.Cf > 1.0f) {                                    // one cascade (bound <= 1): level is min(C-1, .) = 0 whatever the exponents say
+        const int lp = level_from_exponent(mag, c.Cf);
+        const int ld = level_from_exponent((dt * c.Hf) * 0.5f, c.Cf);
+        level = lp > ld ? lp : ld;
+        mip_bound = fminf(scalbnf(1.0f, level), c.bound);
+    }
     const float mip_rbound = 1.0f / mip_bound;
     float cx = x, cy = y, cz = z;
     const bool outside = c.contract && mag > 1.0f;
