@@ -214,6 +214,14 @@ int n2m_grid_encode_forward_pair(const float* inputs, const float* embeddings1, 
  * in [0,1], or (1/(2*bound), 0.5) to consume the renderer's points in [-bound, bound] directly -- for a power-of-two bound that is
  * bit-identical to grid.py:156's (x + bound) / (2 * bound) and saves two elementwise passes per call. */
 
+/* n2m_grid_encode_forward_pair on a PACKED copy of the two tables: packed [rows] of 8 bytes {fp32 density feature, 2 x fp16 colour
+ * features}, 16-byte aligned.  One L2 line then serves both encoders' gather of a vertex pair (the forward is bound by line traffic,
+ * not by bytes used).  Outputs are bit-identical to the pair call.  n2m_adam_step keeps such a copy fresh (shadow modes 2 and 3). */
+int n2m_grid_encode_forward_packed(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1,
+                                   void* outputs2, uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                   uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
+                                   void* stream);
+
 /* Both encoders of nerf2mesh's field in one call: the density table (fp32, C=1) and the colour table (fp16, C=2) share
  * their level geometry and are queried at the same inputs (nerf/network.py:92-108), so the index arithmetic and the partition
  * sort of the binned backward are done once and two update logs are written.  grad1 [L,B] f32, grad2 [L,B,2] f16, one
@@ -276,6 +284,8 @@ typedef struct {
     void* param[N2M_ADAM_MAX]; const void* grad[N2M_ADAM_MAX]; void* exp_avg[N2M_ADAM_MAX]; void* exp_avg_sq[N2M_ADAM_MAX];
     void* half_shadow[N2M_ADAM_MAX];
     uint32_t numel[N2M_ADAM_MAX]; float lr[N2M_ADAM_MAX]; int32_t grad_is_half[N2M_ADAM_MAX];
+    int32_t shadow_mode[N2M_ADAM_MAX];   /* 1: half_shadow is a plain fp16 copy; 2: parameter is a [rows,1] fp32 table, written to column 0
+                                            of a packed table (8 B rows); 3: parameter is a [rows,2] table, written as half2 to column 1 */
     uint32_t count;
 } N2mAdamDesc;   /* HOST struct */
 int n2m_adam_step(const N2mAdamDesc* desc, double beta1, double beta2, float eps, const float* scale,

@@ -35,6 +35,7 @@ SIGNATURES = {
     "n2m_grid_encode_backward_binned": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _int,
                                         _vp, _f32, _f32, _f32, _vp, _vp, _vp, _u64, _vp],
     "n2m_grid_encode_forward_pair": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _f32, _f32, _vp],
+    "n2m_grid_encode_forward_packed": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _f32, _f32, _vp],
     "n2m_grid_binned_pair_workspace_bytes": [_u32, _u32, _vp],                                  # returns uint64 (RESTYPES)
     "n2m_grid_encode_backward_binned_pair": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
                                              _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _vp, _u64, _vp],
@@ -74,7 +75,7 @@ class AdamDesc(ctypes.Structure):
     """N2mAdamDesc of include/n2m_hip.h."""
     _fields_ = [("param", _vp * ADAM_MAX), ("grad", _vp * ADAM_MAX), ("exp_avg", _vp * ADAM_MAX), ("exp_avg_sq", _vp * ADAM_MAX),
                 ("half_shadow", _vp * ADAM_MAX), ("numel", _u32 * ADAM_MAX), ("lr", _f32 * ADAM_MAX), ("grad_is_half", _i32 * ADAM_MAX),
-                ("count", _u32)]
+                ("shadow_mode", _i32 * ADAM_MAX), ("count", _u32)]
 
 
 KERNEL_IDS = {"grid_encode_forward": 0, "grid_encode_backward": 1, "grad_total_variation": 2, "march_rays_train_count": 3,

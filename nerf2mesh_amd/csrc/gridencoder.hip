@@ -417,6 +417,106 @@ __device__ __forceinline__ void atomic_add_row(float* dst, const float* v, uint3
 }
 
 // one thread per (sample, level): scatter w * grad into the 2^D rows
+// The same forward on a PACKED table: row r = 8 bytes {fp32 density feature, 2 x fp16 colour features}.  The gathers of this
+// kernel move one 64-byte line from L2 per vertex pair to use 8 bytes of it; with the two tables interleaved the same line
+// serves both encoders, i.e. half the line traffic for the pair (the packed copy is kept fresh by the optimizer's update pass,
+// n2m_adam_step shadow modes 2/3).  Arithmetic and outputs are identical to grid_forward3_pair_kernel.
+__global__ void __launch_bounds__(256)
+grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __restrict__ packed, const int32_t* __restrict__ offsets,
+                            float* __restrict__ out1, _Float16* __restrict__ out2, uint32_t B, uint32_t max_level, LevelTable lv,
+                            uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t n_tiles, float in_scale, float in_offset) {
+    constexpr uint32_t D = 3;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const uint32_t level = blockIdx.x / n_tiles, tile = blockIdx.x - level * n_tiles;
+    if (level >= max_level) return;
+    const uint32_t b = tile * 256 + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t row0 = (uint32_t)offsets[level];
+    const uint32_t size = (uint32_t)offsets[level + 1] - row0;
+    const float scale = lv.scale[level];
+    const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
+    const uint2* __restrict__ tab = packed + (size_t)row0;
+    float* o1 = out1 + (size_t)level * B + b;
+    _Float16* o2 = out2 + ((size_t)level * B + b) * 2;
+
+    float x[D];
+    load_point<D>(inputs, b, x);
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) x[d] = x[d] * in_scale + in_offset;
+    if (outside_unit_cube<D>(x)) {
+        *o1 = 0.0f;
+        Row<_Float16, 2> z;
+        z.v[0] = z.v[1] = (_Float16)0;
+        z.store(o2);
+        return;
+    }
+    uint32_t cell[D];
+    float frac[D], dfrac[D];
+    locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
+
+    uint2 g[8];                                           // packed rows of the 8 vertices
+    const bool dense = !ix.hashed && !ix.wrap;
+    if (dense) {
+        const uint32_t base = cell[0] + cell[1] * ix.stride[1] + cell[2] * ix.stride[2];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t r = base + ((q & 1u) ? ix.stride[1] : 0u) + ((q & 2u) ? ix.stride[2] : 0u);
+            if ((r & 1u) == 0u) {                        // rows r, r+1 share one aligned 16-byte slot
+                const uint4 v = *reinterpret_cast<const uint4*>(tab + r);
+                g[2 * q] = make_uint2(v.x, v.y); g[2 * q + 1] = make_uint2(v.z, v.w);
+            } else {
+                g[2 * q] = tab[r]; g[2 * q + 1] = tab[r + 1u];
+            }
+        }
+    } else if (ix.hashed && ix.pow2) {
+        const uint32_t hy0 = cell[1] * kPrimes[1], hy1 = hy0 + kPrimes[1], hz0 = cell[2] * kPrimes[2], hz1 = hz0 + kPrimes[2];
+        const bool x_even = (cell[0] & 1u) == 0u;
+        uint32_t rx[4], rx1[4];
+        uint4 pr[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t h = ((q & 1u) ? hy1 : hy0) ^ ((q & 2u) ? hz1 : hz0);
+            rx[q] = (cell[0] ^ h) & ix.mask;
+            rx1[q] = ((cell[0] + 1u) ^ h) & ix.mask;
+            pr[q] = *reinterpret_cast<const uint4*>(tab + (rx[q] & ~1u));
+        }
+        uint2 extra[4];
+        if (!x_even) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) extra[q] = tab[rx1[q]];
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const bool odd_row = (rx[q] & 1u) != 0u;
+            const uint2 lo = make_uint2(pr[q].x, pr[q].y), hi = make_uint2(pr[q].z, pr[q].w);
+            g[2 * q] = odd_row ? hi : lo;
+            g[2 * q + 1] = x_even ? (odd_row ? lo : hi) : extra[q];
+        }
+    } else {
+#pragma unroll
+        for (uint32_t corner = 0; corner < 8; ++corner) {
+            const uint32_t v[D] = {cell[0] + (corner & 1u), cell[1] + ((corner >> 1) & 1u), cell[2] + (corner >> 2)};
+            g[corner] = tab[ix.row(v)];
+        }
+    }
+    float a1 = 0.0f;
+    _Float16 a2[2] = {(_Float16)0, (_Float16)0};
+#pragma unroll
+    for (uint32_t corner = 0; corner < 8; ++corner) {   // corner bit 0 = x, bit 1 = y, bit 2 = z: the reference's order
+        float w = 1.0f;
+#pragma unroll
+        for (uint32_t d = 0; d < D; ++d) w *= (corner & (1u << d)) ? frac[d] : 1 - frac[d];
+        const h2 c2 = __builtin_bit_cast(h2, g[corner].y);
+        accum(a1, w, __uint_as_float(g[corner].x));
+        accum(a2[0], w, c2.x);
+        accum(a2[1], w, c2.y);
+    }
+    *o1 = a1;
+    Row<_Float16, 2> r2;
+    r2.v[0] = a2[0]; r2.v[1] = a2[1];
+    r2.store(o2);
+}
+
 // Both tables of the field in one forward: the density (fp32 C=1) and colour (fp16 C=2) encoders share geometry and inputs
 // (nerf/network.py:92-108), so cell, weights and row indices are derived once and each vertex pair is fetched from both tables.
 // Same arithmetic and rounding points as grid_forward3_kernel per table: outputs are bit-identical to two single calls.
@@ -2061,6 +2161,25 @@ extern "C" int n2m_grid_encode_forward_pair(const float* inputs, const float* em
     grid_forward3_pair_kernel<<<n_tiles * max_level, 256, 0, s>>>(inputs, embeddings1, (const _Float16*)embeddings2, offsets, outputs1,
                                                                  (_Float16*)outputs2, B, max_level, lv, gridtype, align_corners != 0, interp, n_tiles,
                                                                  in_scale, in_offset);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_grid_encode_forward_packed(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1, void* outputs2,
+                                              uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
+                                              int align_corners, uint32_t interp, float in_scale, float in_offset, void* stream) {
+    const char* fn = "grid_encode_forward_packed";
+    if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
+    N2M_REQUIRE(inputs && packed && offsets && outputs1 && outputs2, N2M_ENULL, "%s: NULL tensor", fn);
+    N2M_REQUIRE(((uintptr_t)packed & 15u) == 0, N2M_EINVAL, "%s: the packed table must be 16-byte aligned", fn);
+    if (B == 0 || max_level == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const LevelTable lv = make_levels(L, S, H);
+    N2M_PROF(N2M_K_GRID_FWD, s, (double)B * (12.0 + (double)max_level * 8 * (4 + 4) + (double)max_level * (4 + 4)));
+    const uint32_t n_tiles = n2m_ceil_div(B, 256);
+    grid_forward3_packed_kernel<<<n_tiles * max_level, 256, 0, s>>>(inputs, (const uint2*)packed, offsets, outputs1, (_Float16*)outputs2, B,
+                                                                   max_level, lv, gridtype, align_corners != 0, interp, n_tiles, in_scale,
+                                                                   in_offset);
     N2M_CHECK_LAUNCH();
     return 0;
 }

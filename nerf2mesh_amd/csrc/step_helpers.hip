@@ -121,8 +121,40 @@ struct AdamTensors {
     uint64_t p[N2M_ADAM_MAX], g[N2M_ADAM_MAX], m[N2M_ADAM_MAX], v[N2M_ADAM_MAX], shadow[N2M_ADAM_MAX];
     uint32_t n[N2M_ADAM_MAX], first_block[N2M_ADAM_MAX + 1];
     float lr[N2M_ADAM_MAX];
+    uint8_t shadow_mode[N2M_ADAM_MAX];
     uint32_t count, g_half_mask;
 };
+
+// refresh the working copy of elements i0 .. i0+cnt-1 (cnt <= 4): plain fp16 copy, or one column of a packed table whose rows
+// are 8 bytes {fp32 from a [rows,1] table, half2 from a [rows,2] table}
+__device__ __forceinline__ void shadow_store(_Float16* S, uint32_t mode, uint32_t i0, const float (&p)[4], uint32_t cnt) {
+    if (mode == 2u) {
+        float* F = reinterpret_cast<float*>(S);
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e)
+            if (e < cnt) F[(size_t)(i0 + e) * 2u] = p[e];
+    } else if (mode == 3u) {                               // i0 is a multiple of 4: elements (2r, 2r+1) are row r
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        uint32_t* U = reinterpret_cast<uint32_t*>(S);
+#pragma unroll
+        for (uint32_t e = 0; e < 4; e += 2) {
+            if (e + 1 < cnt) {
+                h2v o;
+                o.x = (_Float16)p[e]; o.y = (_Float16)p[e + 1];
+                U[(size_t)((i0 + e) >> 1) * 2u + 1u] = __builtin_bit_cast(uint32_t, o);
+            }
+        }
+    } else if (cnt == 4u) {
+        typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+        h4v o;
+        o.x = (_Float16)p[0]; o.y = (_Float16)p[1]; o.z = (_Float16)p[2]; o.w = (_Float16)p[3];
+        *reinterpret_cast<h4v*>(S + i0) = o;
+    } else {
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e)
+            if (e < cnt) S[i0 + e] = (_Float16)p[e];
+    }
+}
 
 __global__ void __launch_bounds__(256)
 adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, float eps, const float* __restrict__ scale,
@@ -140,6 +172,7 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
     float* __restrict__ M = reinterpret_cast<float*>(t.m[k]);
     float* __restrict__ V = reinterpret_cast<float*>(t.v[k]);
     _Float16* __restrict__ S = reinterpret_cast<_Float16*>(t.shadow[k]);
+    const uint32_t smode = t.shadow_mode[k];
     const bool g_half = (t.g_half_mask >> k) & 1u;
     float p[4], m[4], v[4], g[4];
     const bool full = i0 + 4u <= n;                                   // tensors are 16-byte aligned (torch allocations)
@@ -177,16 +210,12 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
         *reinterpret_cast<float4*>(P + i0) = make_float4(p[0], p[1], p[2], p[3]);
         *reinterpret_cast<float4*>(M + i0) = make_float4(m[0], m[1], m[2], m[3]);
         *reinterpret_cast<float4*>(V + i0) = make_float4(v[0], v[1], v[2], v[3]);
-        if (S) {
-            typedef _Float16 h4v __attribute__((ext_vector_type(4)));
-            h4v o;
-            o.x = (_Float16)p[0]; o.y = (_Float16)p[1]; o.z = (_Float16)p[2]; o.w = (_Float16)p[3];
-            *reinterpret_cast<h4v*>(S + i0) = o;
-        }
+        if (S) shadow_store(S, smode, i0, p, 4u);
     } else {
 #pragma unroll
         for (uint32_t e = 0; e < 4; ++e)
-            if (i0 + e < n) { P[i0 + e] = p[e]; M[i0 + e] = m[e]; V[i0 + e] = v[e]; if (S) S[i0 + e] = (_Float16)p[e]; }
+            if (i0 + e < n) { P[i0 + e] = p[e]; M[i0 + e] = m[e]; V[i0 + e] = v[e]; }
+        if (S) shadow_store(S, smode, i0, p, n - i0);
     }
 }
 
@@ -271,6 +300,8 @@ extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, f
         t.first_block[k] = blocks;
         blocks += n2m_ceil_div(d->numel[k], 1024);
         if (d->grad_is_half[k]) t.g_half_mask |= 1u << k;
+        t.shadow_mode[k] = (uint8_t)(d->half_shadow[k] ? (d->shadow_mode[k] ? d->shadow_mode[k] : 1) : 0);
+        N2M_REQUIRE(t.shadow_mode[k] <= 3 && !(t.shadow_mode[k] == 3 && (d->numel[k] & 1u)), N2M_EINVAL, "adam_step: bad shadow mode for tensor %u", k);
     }
     t.first_block[d->count] = blocks;
     t.count = d->count;

@@ -13,6 +13,7 @@ from torch.autograd import Function
 from . import _lib as L
 
 _p = L.ptr
+PACKED_FORWARD = True           # gather both tables from one packed copy (8-byte rows) when the network provides it
 PAIR_FORWARD = True             # one forward launch for the two tables when their geometry is identical
 PAIR_BACKWARD = True            # one shared fill for the two tables when their geometry is identical
 CONCURRENT_BACKWARD = False     # A/B switch: run the two table backward passes on two streams (measured: no gain, the kernels already fill the chip)
@@ -60,6 +61,19 @@ def _encode_lm_pair(x01, emb1, emb2h, net, max_level, in_affine=(1.0, 0.0)):
     return h1, h2
 
 
+def _encode_lm_packed(x, packed, net, max_level, in_affine):
+    """_encode_lm_pair from the packed copy of the two tables (network.packed_tables)."""
+    e1 = net.encoder
+    B, Lv = x.shape[0], e1.num_levels
+    mk = torch.empty if max_level >= Lv else torch.zeros
+    h1 = mk(Lv, B, 1, device=x.device, dtype=torch.float32)
+    h2 = mk(Lv, B, 2, device=x.device, dtype=torch.float16)
+    L.call("n2m_grid_encode_forward_packed", _p(x), _p(packed), _p(e1.offsets), _p(h1), _p(h2), B, Lv, max_level,
+           float(np.log2(e1.per_level_scale)), int(e1.base_resolution), e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id,
+           float(in_affine[0]), float(in_affine[1]), L.stream())
+    return h1, h2
+
+
 def _encode_backward_lm(grad_lm, x01, emb, enc, max_level, ws_slot=0):
     B = x01.shape[0]
     Lv, C = enc.num_levels, emb.shape[1]
@@ -85,10 +99,12 @@ def _encode_backward_lm(grad_lm, x01, emb, enc, max_level, ws_slot=0):
 
 
 def _encode_backward_pair(d_h1, d_h2, x01, emb1, emb2h, net, max_level, in_affine=(1.0, 0.0)):
+    # emb2h may be None (packed forward): only its shape / dtype are needed here
     """(g1, g2) through the shared-fill kernel, or (None, None) when it does not apply."""
     from .gridencoder import binned_backward_pair
     enc1, enc2 = net.encoder, net.encoder_color
-    g1, g2 = torch.zeros_like(emb1), torch.zeros_like(emb2h)
+    g1 = torch.zeros_like(emb1)
+    g2 = torch.zeros_like(emb2h) if emb2h is not None else torch.zeros(emb1.shape[0], 2, dtype=torch.float16, device=emb1.device)
     req = getattr(enc1, "tv_request", None)
     amp1, amp2 = getattr(enc1, "amp_request", None), getattr(enc2, "amp_request", None)
     finf = amp1["found_inf"] if amp1 is not None else (amp2["found_inf"] if amp2 is not None else None)
@@ -115,10 +131,13 @@ class _fused_field(Function):
         sigma = h1 = None
         rgb = spec = h2 = emb2h = None
         emb1 = emb1.float().contiguous() if want_density else None
-        if want_color:
-            emb2h = net.encoder_color.half_table() if hasattr(net.encoder_color, "half_table") else emb2.half().contiguous()   # grid.py:45
         both = None
-        if want_density and want_color:
+        packed = net.packed_tables() if (PACKED_FORWARD and want_density and want_color and aff is not None and hasattr(net, "packed_tables")) else None
+        if packed is not None:
+            both = _encode_lm_packed(xyz, packed, net, max_level, aff)
+        elif want_color:
+            emb2h = net.encoder_color.half_table() if hasattr(net.encoder_color, "half_table") else emb2.half().contiguous()   # grid.py:45
+        if both is None and want_density and want_color:
             if aff is not None:
                 both = _encode_lm_pair(xyz, emb1, emb2h, net, max_level, aff)      # normalisation folded into the kernel
             else:
@@ -194,6 +213,8 @@ class _fused_field(Function):
         if g1 is None:
             if x01 is None:
                 x01 = (xyz + ctx.bound) / (2 * ctx.bound)
+            if want_color and emb2h is None:
+                emb2h = net.encoder_color.half_table()
             side = L.side_stream(dev) if (want_density and want_color and CONCURRENT_BACKWARD) else None
             if want_color and side is not None:
                 main = torch.cuda.current_stream()

@@ -56,6 +56,27 @@ class NeRFNetwork(NeRFRenderer):
         if self.opt.sdf:
             self.register_parameter("variance", nn.Parameter(torch.tensor(0.3, dtype=torch.float32)))
 
+    def packed_tables(self):
+        """[rows, 2] fp32 tensor whose 8-byte rows are {density feature fp32, colour features 2 x fp16}: the layout
+        n2m_grid_encode_forward_packed gathers from (one L2 line per vertex pair for both encoders).  Rebuilt when either table
+        changed through torch (version counters); optim.FusedAdamAMP refreshes it in its own update pass.  None when the two
+        encoders do not share their geometry."""
+        e1, e2 = self.encoder, self.encoder_color
+        a, b = e1.embeddings, e2.embeddings
+        if a.shape[1] != 1 or b.shape[1] != 2 or a.shape[0] != b.shape[0] or not a.is_cuda:
+            return None
+        key = (a._version, b._version, a.data_ptr(), b.data_ptr())
+        if getattr(self, "_packed_key", None) != key or getattr(self, "_packed", None) is None:
+            from .gridencoder import same_geometry
+            if not same_geometry(e1, e2):
+                return None
+            with torch.no_grad():
+                pk = torch.empty(a.shape[0], 2, dtype=torch.float32, device=a.device)
+                pk[:, 0] = a.detach()[:, 0]
+                pk.view(torch.float16)[:, 2:] = b.detach().half()
+            self._packed, self._packed_key = pk, key
+        return self._packed
+
     def _can_fuse(self, c=None):
         return bool(getattr(self.opt, "fused_mlp", False)) and c is None and not self.opt.sdf and x_is_cuda(self)
 

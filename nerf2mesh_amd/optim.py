@@ -36,7 +36,8 @@ class FusedAdamAMP(torch.optim.Optimizer):
         self._one = torch.ones((), device=dev)
         for p in ps:
             self.state[p] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
-        self.shadows = {}          # param -> callable returning the fp16 shadow tensor to refresh (or None)
+        self.shadows = {}          # param -> callable returning the working copy to refresh: a tensor (plain fp16 copy), (tensor, mode)
+                                   # with mode 2 / 3 = column of a packed table (N2mAdamDesc.shadow_mode), or None
         self.half_grads = {}       # param -> callable returning an fp16 gradient produced outside autograd (or None)
 
     def scale_loss(self, loss, world=1):
@@ -66,10 +67,14 @@ class FusedAdamAMP(torch.optim.Optimizer):
                 st = self.state[p]
                 sh = self.shadows.get(p)
                 sh = sh() if sh is not None else None
+                mode = 1
+                if isinstance(sh, tuple):
+                    sh, mode = sh
                 desc.param[k], desc.grad[k] = p.data_ptr(), g.data_ptr()
                 desc.exp_avg[k], desc.exp_avg_sq[k] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                 desc.half_shadow[k] = sh.data_ptr() if sh is not None else None
                 desc.numel[k], desc.lr[k], desc.grad_is_half[k] = p.numel(), float(group["lr"]), int(is_half)
+                desc.shadow_mode[k] = int(mode) if sh is not None else 0
                 keep += [g, sh]
                 k += 1
         if k == 0:

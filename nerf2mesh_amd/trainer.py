@@ -29,9 +29,22 @@ class Stage0Trainer:
         if self.amp_adam:
             from .optim import FusedAdamAMP
             self.optimizer = FusedAdamAMP(model.get_params(opt.lr), eps=1e-15, amp=bool(opt.fp16))
-            encc = model.encoder_color
+            enc, encc = model.encoder, model.encoder_color
             self._amp = {}
-            self.optimizer.shadows[encc.embeddings] = lambda: encc.half_table()
+
+            def shadow_density():          # column 0 of the packed table the forward gathers from (None: no packed table)
+                pk = model.packed_tables()
+                return (pk, 2) if pk is not None else None
+
+            def shadow_color():            # column 1 of the packed table, else the plain fp16 copy
+                pk = model.packed_tables()
+                if pk is None:
+                    return encc.half_table()
+                encc._half_version = -1    # the plain fp16 copy is not refreshed any more: rebuild it on next use
+                return (pk, 3)
+
+            self.optimizer.shadows[enc.embeddings] = shadow_density
+            self.optimizer.shadows[encc.embeddings] = shadow_color
             self.optimizer.half_grads[encc.embeddings] = lambda: self._amp.get("color", {}).get("grad_half")
         else:
             self.optimizer = torch.optim.Adam(model.get_params(opt.lr), eps=1e-15, fused=(device.type == "cuda"))

@@ -428,6 +428,14 @@ def test_grid_encode_forward_pair_is_bit_identical_to_two_calls(be):
                 L.call("n2m_grid_encode_forward", x.data_ptr(), emb.data_ptr(), e1.offsets.data_ptr(), out.data_ptr(), B, 3, C, 16, ml, S, 16, None,
                        e1.gridtype_id, int(align), e1.interp_id, dt, L.stream())
             assert torch.equal(h1, r1) and torch.equal(h2.view(torch.int16), r2.view(torch.int16))
+            # packed copy of the two tables (8-byte rows): same outputs
+            pk = torch.empty(emb1.shape[0], 2, device="cuda")
+            pk[:, 0] = emb1[:, 0]
+            pk.view(torch.float16)[:, 2:] = emb2
+            p1 = torch.full_like(h1, 3.0); p2 = torch.full_like(h2, 3.0)
+            L.call("n2m_grid_encode_forward_packed", x.data_ptr(), pk.data_ptr(), e1.offsets.data_ptr(), p1.data_ptr(), p2.data_ptr(), B, 16, ml, S,
+                   16, e1.gridtype_id, int(align), e1.interp_id, 1.0, 0.0, L.stream())
+            assert torch.equal(p1, r1) and torch.equal(p2.view(torch.int16), r2.view(torch.int16))
             # raw points in [-bound, bound] + in-kernel (x * 1/(2 bound) + 0.5) == torch's (x + bound) / (2 bound), bit for bit
             for bound in (1.0, 2.0, 16.0):
                 raw = (x * 2 - 1) * bound

@@ -50,6 +50,26 @@ def test_fused_adam_amp_matches_torch_adam_and_gradscaler():
         np.testing.assert_allclose(st_b["exp_avg_sq"].cpu().numpy(), st_a["exp_avg_sq"].cpu().numpy(), rtol=1e-5, atol=1e-9)
 
 
+def test_adam_refreshes_packed_table_columns():
+    """Shadow modes 2 / 3 of n2m_adam_step: the updated fp32 [rows,1] table lands in column 0 and the fp16 image of the [rows,2] table
+    in column 1 of a packed [rows] x 8-byte table (what n2m_grid_encode_forward_packed gathers from)."""
+    import torch
+    from nerf2mesh_amd.optim import FusedAdamAMP
+    torch.manual_seed(1)
+    rows = 1027
+    a = torch.randn(rows, 1, device="cuda").requires_grad_()
+    b = torch.randn(rows, 2, device="cuda").requires_grad_()
+    pk = torch.zeros(rows, 2, device="cuda")
+    opt = FusedAdamAMP([{"params": [a]}, {"params": [b]}], lr=1e-2, eps=1e-15, amp=False)
+    opt.shadows[a] = lambda: (pk, 2)
+    opt.shadows[b] = lambda: (pk, 3)
+    for _ in range(3):
+        a.grad, b.grad = torch.randn_like(a), torch.randn_like(b)
+        opt.step()
+    assert torch.equal(pk[:, 0], a.detach()[:, 0])
+    assert torch.equal(pk.view(torch.float16)[:, 2:], b.detach().half())
+
+
 def test_backward_kernels_raise_found_inf():
     """The producing kernels flag non-finite gradients (binned table backward: value read / sum written; field backward: dW)."""
     import torch
