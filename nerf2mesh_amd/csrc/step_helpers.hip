@@ -122,6 +122,7 @@ struct AdamTensors {
     uint32_t n[N2M_ADAM_MAX], first_block[N2M_ADAM_MAX + 1];
     float lr[N2M_ADAM_MAX];
     uint8_t shadow_mode[N2M_ADAM_MAX];
+    int8_t partner[N2M_ADAM_MAX];     // mode-3 tensor: index of the mode-2 tensor packed into the same table (updated by the same threads), or -1
     uint32_t count, g_half_mask;
 };
 
@@ -206,16 +207,48 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
         const float denom = sqrtf(v[e]) / bc2_sqrt + eps;
         p[e] -= step_size * m[e] / denom;
     }
+    const int pk = t.partner[k];
     if (full) {
         *reinterpret_cast<float4*>(P + i0) = make_float4(p[0], p[1], p[2], p[3]);
         *reinterpret_cast<float4*>(M + i0) = make_float4(m[0], m[1], m[2], m[3]);
         *reinterpret_cast<float4*>(V + i0) = make_float4(v[0], v[1], v[2], v[3]);
-        if (S) shadow_store(S, smode, i0, p, 4u);
+        if (S && pk < 0) shadow_store(S, smode, i0, p, 4u);
     } else {
 #pragma unroll
         for (uint32_t e = 0; e < 4; ++e)
             if (i0 + e < n) { P[i0 + e] = p[e]; M[i0 + e] = m[e]; V[i0 + e] = v[e]; }
-        if (S) shadow_store(S, smode, i0, p, n - i0);
+        if (S && pk < 0) shadow_store(S, smode, i0, p, n - i0);
+    }
+    if (pk >= 0) {
+        // this [rows,2] tensor shares a packed table with the [rows,1] tensor `pk`: the same thread updates rows r0, r0+1 of that
+        // tensor too and writes the two complete 8-byte packed rows with one 16-byte store (separate column writes at an 8-byte
+        // stride cost 22 us more, measured)
+        const uint32_t r0 = i0 >> 1, n1 = t.n[pk];
+        float* __restrict__ P1 = reinterpret_cast<float*>(t.p[pk]);
+        float* __restrict__ M1 = reinterpret_cast<float*>(t.m[pk]);
+        float* __restrict__ V1 = reinterpret_cast<float*>(t.v[pk]);
+        const bool g1_half = (t.g_half_mask >> pk) & 1u;
+        const float step1 = t.lr[pk] / bc1;
+        float q[2] = {0.f, 0.f};
+#pragma unroll
+        for (uint32_t e = 0; e < 2; ++e) {
+            if (r0 + e >= n1) continue;
+            const float gr = (g1_half ? (float)reinterpret_cast<const _Float16*>(t.g[pk])[r0 + e] : reinterpret_cast<const float*>(t.g[pk])[r0 + e]) * inv_scale;
+            const float m1 = beta1 * M1[r0 + e] + omb1 * gr;
+            const float v1 = beta2 * V1[r0 + e] + omb2 * gr * gr;
+            q[e] = P1[r0 + e] - step1 * m1 / (sqrtf(v1) / bc2_sqrt + eps);
+            P1[r0 + e] = q[e]; M1[r0 + e] = m1; V1[r0 + e] = v1;
+        }
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        h2v c0, c1;
+        c0.x = (_Float16)p[0]; c0.y = (_Float16)p[1]; c1.x = (_Float16)p[2]; c1.y = (_Float16)p[3];
+        uint32_t* U = reinterpret_cast<uint32_t*>(S) + (size_t)r0 * 2u;
+        if (full && r0 + 2u <= n1)
+            *reinterpret_cast<uint4*>(U) = make_uint4(__float_as_uint(q[0]), __builtin_bit_cast(uint32_t, c0), __float_as_uint(q[1]), __builtin_bit_cast(uint32_t, c1));
+        else {
+            if (i0 + 1u < n) { U[1] = __builtin_bit_cast(uint32_t, c0); if (r0 < n1) U[0] = __float_as_uint(q[0]); }
+            if (i0 + 3u < n) { U[3] = __builtin_bit_cast(uint32_t, c1); if (r0 + 1u < n1) U[2] = __float_as_uint(q[1]); }
+        }
     }
 }
 
@@ -302,6 +335,24 @@ extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, f
         if (d->grad_is_half[k]) t.g_half_mask |= 1u << k;
         t.shadow_mode[k] = (uint8_t)(d->half_shadow[k] ? (d->shadow_mode[k] ? d->shadow_mode[k] : 1) : 0);
         N2M_REQUIRE(t.shadow_mode[k] <= 3 && !(t.shadow_mode[k] == 3 && (d->numel[k] & 1u)), N2M_EINVAL, "adam_step: bad shadow mode for tensor %u", k);
+    }
+    // a [rows,1] tensor (mode 2) and a [rows,2] tensor (mode 3) writing columns of the SAME packed table are updated together by the
+    // threads of the second one: complete 8-byte rows, coalesced.  The first tensor then gets no blocks of its own.
+    for (uint32_t k = 0; k < d->count; ++k) t.partner[k] = -1;
+    for (uint32_t k = 0; k < d->count; ++k) {
+        if (t.shadow_mode[k] != 3) continue;
+        for (uint32_t j = 0; j < d->count; ++j)
+            if (t.shadow_mode[j] == 2 && d->half_shadow[j] == d->half_shadow[k] && d->numel[k] == 2 * d->numel[j] && ((uintptr_t)d->half_shadow[k] & 15u) == 0) {
+                t.partner[k] = (int8_t)j;
+                break;
+            }
+    }
+    blocks = 0;
+    for (uint32_t k = 0; k < d->count; ++k) {
+        bool is_partner = false;
+        for (uint32_t j = 0; j < d->count; ++j) is_partner |= t.partner[j] == (int8_t)k;
+        t.first_block[k] = blocks;
+        if (!is_partner) blocks += n2m_ceil_div(d->numel[k], 1024);
     }
     t.first_block[d->count] = blocks;
     t.count = d->count;

@@ -60,12 +60,17 @@ def test_adam_refreshes_packed_table_columns():
     a = torch.randn(rows, 1, device="cuda").requires_grad_()
     b = torch.randn(rows, 2, device="cuda").requires_grad_()
     pk = torch.zeros(rows, 2, device="cuda")
-    opt = FusedAdamAMP([{"params": [a]}, {"params": [b]}], lr=1e-2, eps=1e-15, amp=False)
+    ra, rb = a.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    ref = torch.optim.Adam([{"params": [ra], "lr": 1e-2}, {"params": [rb], "lr": 3e-3}], eps=1e-15)
+    opt = FusedAdamAMP([{"params": [a], "lr": 1e-2}, {"params": [b], "lr": 3e-3}], lr=1e-2, eps=1e-15, amp=False)
     opt.shadows[a] = lambda: (pk, 2)
     opt.shadows[b] = lambda: (pk, 3)
     for _ in range(3):
         a.grad, b.grad = torch.randn_like(a), torch.randn_like(b)
-        opt.step()
+        ra.grad, rb.grad = a.grad.clone(), b.grad.clone()
+        opt.step(); ref.step()
+    # the two tensors are updated by the same threads (complete packed rows per store): both must still follow torch's Adam
+    assert torch.allclose(a, ra, rtol=1e-5, atol=1e-7) and torch.allclose(b, rb, rtol=1e-5, atol=1e-7)
     assert torch.equal(pk[:, 0], a.detach()[:, 0])
     assert torch.equal(pk.view(torch.float16)[:, 2:], b.detach().half())
 
