@@ -273,6 +273,7 @@ def march_rays_train_finish(t):
     M = int(t.host_count[0])
     rays_o = t.keep[0]
     dev = rays_o.device
+    torch.cuda.current_stream(dev).wait_event(t.event)      # pass 1 may have been issued on another stream
     xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
     dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
     ts = torch.empty(M, 2, dtype=torch.float32, device=dev)

@@ -64,6 +64,7 @@ class Stage0Trainer:
         self._one = torch.ones((), device=device)
         self.fused_loss = True        # losses.photo_loss instead of the torch graph of nerf/utils.py:658-683
         self.pipeline = True          # issue march pass 1 of the next batch one step ahead (results are identical)
+        self.overlap_march = True     # ... on a second stream, next to this step's backward + optimizer kernels (single-rank path)
         self._next = None
 
     def mark_untrained(self):
@@ -90,6 +91,24 @@ class Stage0Trainer:
         rays_o, rays_d, images = self.batch()
         ticket = model.march_ahead(rays_o, rays_d, dt_gamma=opt.dt_gamma, perturb=True, max_steps=opt.max_steps) if self.pipeline else None
         return rays_o, rays_d, images, ticket
+
+    def _prepare_overlapped(self):
+        """_prepare() on the side stream.  The next batch's ray generation and march pass 1 read only the camera set and the occupancy
+        bit field, so they may run NEXT TO this step's backward and Adam kernels: the count pass is latency-bound (a wave per ray,
+        ~6 GB/s) and leaves the memory system to them.  Ordering: the side stream starts behind everything already queued on the main
+        stream (covers an occupancy refresh), the main stream picks the results up through the ticket's event
+        (march_rays_train_finish).  The random streams are consumed in the same order as in the serial schedule, so results are identical."""
+        from . import _lib as L
+        main = torch.cuda.current_stream(self.device)
+        side = L.side_stream(self.device, slot=2)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            nxt = self._prepare()
+        rays_o, rays_d, images, ticket = nxt
+        for t in (rays_o, rays_d, images, ticket.rays, ticket.counter, ticket.noises) + tuple(ticket.keep):
+            if torch.is_tensor(t):
+                t.record_stream(main)          # allocated on the side stream, consumed on the main one
+        return nxt
 
     def train_step(self):
         opt, model = self.opt, self.model
@@ -159,6 +178,9 @@ class Stage0Trainer:
             self._amp = {"density": dict(found_inf=o.found_inf, flagged=False), "color": dict(found_inf=o.found_inf, flagged=False, keep_half=True),
                          "mlp": dict(found_inf=o.found_inf, flagged=False)}
             model.encoder.amp_request, model.encoder_color.amp_request, model.amp_request = self._amp["density"], self._amp["color"], self._amp["mlp"]
+            if self.overlap_march and self.pipeline and self.sync is None and torch.device(self.device).type == "cuda" \
+                    and self.global_step % opt.update_extra_interval != 0:
+                self._next = self._prepare_overlapped()
             o.scale_loss(loss, self.world).backward()
             model.encoder.amp_request = model.encoder_color.amp_request = model.amp_request = None
             model.encoder.tv_request = None
