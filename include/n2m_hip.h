@@ -225,7 +225,10 @@ int n2m_grid_encode_forward_packed(const float* inputs, const void* packed, cons
 /* Both encoders of nerf2mesh's field in one call: the density table (fp32, C=1) and the colour table (fp16, C=2) share
  * their level geometry and are queried at the same inputs (nerf/network.py:92-108), so the index arithmetic and the partition
  * sort of the binned backward are done once and two update logs are written.  grad1 [L,B] f32, grad2 [L,B,2] f16, one
- * host_offsets for both tables; TV (tv_embeddings = the fp32 table) and found_inf as in n2m_grid_encode_backward_binned. */
+ * host_offsets for both tables; TV (tv_embeddings = the fp32 table) and found_inf as in n2m_grid_encode_backward_binned.
+ * overwrite = 0: the sums are added onto grad_embeddings1/2 (zero-filled by the caller, or running sums) like the reference's
+ * atomicAdd (gridencoder.cu:324-334); overwrite = 1: the call DEFINES both tables completely (all host_offsets[L] rows, zeros
+ * included) -- no zero-fill beforehand and no read-modify-write in the flush. */
 uint64_t n2m_grid_binned_pair_workspace_bytes(uint32_t B, uint32_t max_level, const int32_t* host_offsets);
 int n2m_grid_encode_backward_binned_pair(const float* grad1, const void* grad2, const float* inputs,
                                          const int32_t* host_offsets, float* grad_embeddings1,
@@ -233,7 +236,8 @@ int n2m_grid_encode_backward_binned_pair(const float* grad1, const void* grad2, 
                                          uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                                          const float* tv_embeddings, float tv_weight, float tv_weight_outer,
                                          float tv_inner01, const float* tv_scale, float* found_inf, float in_scale,
-                                         float in_offset, void* workspace, uint64_t workspace_bytes, void* stream);
+                                         float in_offset, int overwrite, void* workspace, uint64_t workspace_bytes,
+                                         void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * freqencoder   (reference: freqencoder/src/freqencoder.h:6-10, freqencoder/src/bindings.cpp:5-8)

@@ -1276,6 +1276,97 @@ bin_fill_kernel(const T* __restrict__ grad /*[L,Bstride,C], first sample of this
 constexpr uint32_t kPairP = kBinAccBytes / 16u;      // 4096 rows
 constexpr uint32_t kPairTilesPerWg = 4;              // tiles one fill workgroup walks (next tile's inputs prefetched)
 
+// Entries of one sample in one level for bin_fill_pair_kernel.  IMODE 1: hashed power-of-two table, 2: dense table without wrap,
+// 0: generic Indexer::row.  ILV: interleaved partition map (dense levels spanning several partitions); IMODE 0 asks the PartMap.
+// In the two fast modes the per-axis terms of the row index are hoisted, and the six TV neighbours reuse them: +1 neighbours ARE
+// corners 100 / 010 / 001, -1 neighbours cost one subtraction each (was: seven generic Indexer::row calls per sample and level).
+struct PairCtx {
+    TvParams tv; const float* tv_tab; float scale; uint32_t resolution; bool align_corners; uint32_t interp;
+};
+
+template <bool TV, int IMODE, bool ILV>
+__device__ __forceinline__ uint32_t pair_entries(const PairCtx& cx, const Indexer<3>& ix, const PartMap& pm, const float (&x)[3], float g1,
+                                                 float g2x, float g2y, float a1, float& vmax1, uint32_t (&e_pr)[8], uint32_t (&e_v1)[8],
+                                                 uint32_t (&e_v2)[8]) {
+    constexpr uint32_t D = 3;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    uint32_t cell[D];
+    float frac[D], dfrac[D];
+    locate<D>(x, cx.scale, cx.align_corners, cx.interp, cell, frac, dfrac);
+    const uint32_t sy = IMODE == 1 ? kPrimes[1] : ix.stride[1], sz = IMODE == 1 ? kPrimes[2] : ix.stride[2];
+    const uint32_t tx[2] = {cell[0], cell[0] + 1u};
+    const uint32_t ty0 = cell[1] * sy, tz0 = cell[2] * sz;
+    const uint32_t ty[2] = {ty0, ty0 + sy}, tz[2] = {tz0, tz0 + sz};
+    auto comb = [&](uint32_t a, uint32_t b, uint32_t c) { return IMODE == 1 ? ((a ^ b ^ c) & ix.mask) : (a + b + c); };
+    uint32_t rows[8];
+#pragma unroll
+    for (uint32_t corner = 0; corner < 8; ++corner) {
+        const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
+        if constexpr (IMODE != 0) rows[corner] = comb(tx[i], ty[j], tz[k]);
+        else {
+            const uint32_t v[D] = {cell[0] + i, cell[1] + j, cell[2] + k};
+            rows[corner] = ix.row(v);
+        }
+    }
+    float tvv = 0.0f;
+    if constexpr (TV) {
+        const bool inner = fmaxf(fmaxf(fabsf(x[0] - 0.5f), fabsf(x[1] - 0.5f)), fabsf(x[2] - 0.5f)) <= cx.tv.inner01;
+        float w = (inner ? cx.tv.weight : cx.tv.weight_outer);
+        if (cx.tv.scale_ptr) w *= *cx.tv.scale_ptr;
+        w /= (float)(2 * D);
+        if constexpr (IMODE == 0) tvv = tv_term(cx.tv_tab, ix, cell, rows[0], cx.resolution, w);
+        else {
+            // gridencoder.cu:505-609, neighbours in the reference's order: +x -x +y -y +z -z; out-of-grid ones are skipped
+            const float* __restrict__ tab = cx.tv_tab;
+            const uint32_t nb_row[6] = {rows[1], comb(tx[0] - 1u, ty[0], tz[0]), rows[2], comb(tx[0], ty[0] - sy, tz[0]),
+                                        rows[4], comb(tx[0], ty[0], tz[0] - sz)};
+            const bool nb_ok[6] = {cell[0] < cx.resolution, cell[0] > 0u, cell[1] < cx.resolution, cell[1] > 0u,
+                                   cell[2] < cx.resolution, cell[2] > 0u};
+            const float centre = tab[rows[0]];
+            float nb[6];
+#pragma unroll
+            for (uint32_t k = 0; k < 6; ++k) nb[k] = tab[nb_ok[k] ? nb_row[k] : rows[0]];
+            float sum = 0.f, sq = 0.f;
+#pragma unroll
+            for (uint32_t k = 0; k < 6; ++k)
+                if (nb_ok[k]) { const float dv = centre - nb[k]; sum += dv; sq += dv * dv; }
+            tvv = w * sum * (1.0f / sqrtf(sq + 1e-9f));
+        }
+        const float a = fabsf(tvv);
+        vmax1 = fmaxf(vmax1, (a1 <= 3.0e38f ? a1 : 1.0f) + (a <= 3.0e38f ? a : 1.0f));       // |w*g + tv| <= |g| + |tv|
+    }
+    const float wx[2] = {1 - frac[0], frac[0]}, wy[2] = {1 - frac[1], frac[1]}, wz[2] = {1 - frac[2], frac[2]};
+    uint32_t vmask = 0;
+#pragma unroll
+    for (uint32_t corner = 0; corner < 8; ++corner) {
+        const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
+        const float w = (wx[i] * wy[j]) * wz[k];                     // forward's association
+        float p1 = w * g1;
+        if (TV && corner == 0) p1 += tvv;
+        h2 p2;
+        p2.x = (_Float16)(w * g2x);
+        p2.y = (_Float16)(w * g2y);
+        e_v1[corner] = __float_as_uint(p1);
+        e_v2[corner] = __builtin_bit_cast(uint32_t, p2);
+        uint32_t part_, rel_;
+        const uint32_t row = rows[corner];
+        if constexpr (IMODE == 0) pm.split(row, part_, rel_);
+        else if constexpr (ILV) {
+            const uint32_t blk = row >> 4;
+            const uint32_t q = __umulhi(blk, pm.magic);
+            part_ = blk - q * pm.parts;
+            rel_ = (q << 4) | (row & 15u);
+        } else {
+            part_ = row >> pm.log2p;
+            rel_ = row & ((1u << pm.log2p) - 1u);
+        }
+        e_pr[corner] = (part_ << 16) | rel_;
+        if (((e_v1[corner] << 1) | (e_v2[corner] & 0x7FFF7FFFu)) != 0u) vmask |= 1u << corner;
+    }
+    return vmask;
+}
+
+
 template <bool TV>
 __global__ void __launch_bounds__(1024)
 bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Float16* __restrict__ grad2 /*[L,Bstride,2]*/,
@@ -1345,53 +1436,12 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
             const bool bad2 = !(fabsf(g2x) <= 3.0e38f) || !(fabsf(g2y) <= 3.0e38f);
             if ((!(a1 <= 3.0e38f) || bad2) && found_inf) *found_inf = 1.0f;
             if (bad2) vmax2 = fmaxf(vmax2, 1.0f);
-            uint32_t cell[D];
-            float frac[D], dfrac[D];
-            locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
-            float tvv = 0.0f;
-            if constexpr (TV) {
-                const bool inner = fmaxf(fmaxf(fabsf(x[0] - 0.5f), fabsf(x[1] - 0.5f)), fabsf(x[2] - 0.5f)) <= tv.inner01;
-                float w = (inner ? tv.weight : tv.weight_outer);
-                if (tv.scale_ptr) w *= *tv.scale_ptr;
-                tvv = tv_term(tv.table + (size_t)plan.row0[level], ix, cell, ix.row(cell), lv.resolution[level], w / (float)(2 * D));
-                const float a = fabsf(tvv);
-                vmax1 = fmaxf(vmax1, (a1 <= 3.0e38f ? a1 : 1.0f) + (a <= 3.0e38f ? a : 1.0f));       // |w*g + tv| <= |g| + |tv|
-            }
-            // per-axis terms of the row index, hoisted (hashed power-of-two table / dense table without wrap / generic)
-            uint32_t tx[2], ty[2], tz[2];
-            if (fast_hash) {
-                tx[0] = cell[0]; tx[1] = cell[0] + 1u;
-                ty[0] = cell[1] * kPrimes[1]; ty[1] = ty[0] + kPrimes[1];
-                tz[0] = cell[2] * kPrimes[2]; tz[1] = tz[0] + kPrimes[2];
-            } else {
-                tx[0] = cell[0]; tx[1] = cell[0] + 1u;
-                ty[0] = cell[1] * ix.stride[1]; ty[1] = ty[0] + ix.stride[1];
-                tz[0] = cell[2] * ix.stride[2]; tz[1] = tz[0] + ix.stride[2];
-            }
-            const float wx[2] = {1 - frac[0], frac[0]}, wy[2] = {1 - frac[1], frac[1]}, wz[2] = {1 - frac[2], frac[2]};
-#pragma unroll
-            for (uint32_t corner = 0; corner < 8; ++corner) {
-                const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
-                uint32_t row;
-                if (fast_hash) row = (tx[i] ^ ty[j] ^ tz[k]) & ix.mask;
-                else if (fast_dense) row = tx[i] + ty[j] + tz[k];
-                else {
-                    const uint32_t v[D] = {cell[0] + i, cell[1] + j, cell[2] + k};
-                    row = ix.row(v);
-                }
-                const float w = (wx[i] * wy[j]) * wz[k];                     // forward's association
-                float p1 = w * g1;
-                if (TV && corner == 0) p1 += tvv;
-                h2 p2;
-                p2.x = (_Float16)(w * g2x);
-                p2.y = (_Float16)(w * g2y);
-                e_v1[corner] = __float_as_uint(p1);
-                e_v2[corner] = __builtin_bit_cast(uint32_t, p2);
-                uint32_t part_, rel_;
-                pm.split(row, part_, rel_);
-                e_pr[corner] = (part_ << 16) | rel_;
-                if (((e_v1[corner] << 1) | (e_v2[corner] & 0x7FFF7FFFu)) != 0u) vmask |= 1u << corner;
-            }
+            const PairCtx cx{tv, tv.table ? tv.table + (size_t)plan.row0[level] : nullptr, scale, lv.resolution[level], align_corners, interp};
+            // one straight-line body per index mode (wave-uniform per level) instead of three-way branches around every row
+            if (fast_hash) vmask = pair_entries<TV, 1, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, e_v1, e_v2);
+            else if (fast_dense && parts > 1u) vmask = pair_entries<TV, 2, true>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, e_v1, e_v2);
+            else if (fast_dense) vmask = pair_entries<TV, 2, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, e_v1, e_v2);
+            else vmask = pair_entries<TV, 0, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, e_v1, e_v2);
         }
 
         // slot of every entry inside its partition's run of this tile
@@ -1479,9 +1529,14 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)
 bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners,
                       const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ directory,
                       const uint64_t* __restrict__ log, float* __restrict__ found_inf, const uint16_t* __restrict__ log_rel = nullptr,
-                      const uint32_t* __restrict__ log_val = nullptr) {
+                      const uint32_t* __restrict__ log_val = nullptr, bool overwrite = false) {
+    // overwrite: the gradient table holds no earlier sums.  Partitions owned by one workgroup (Gl == 1) are then STORED in full,
+    // zeros included -- no read-modify-write round trips in the flush (measured: eight dependent load-add-store steps per item were
+    // a third of this kernel) and no zero-fill of the table before the call; levels split over several groups still add
+    // atomically onto rows the launcher has cleared.
     constexpr uint32_t kLog2P = 31u - __builtin_clz(P);
     extern __shared__ __attribute__((aligned(16))) unsigned long long bin_acc[];   // P * C
+    __shared__ uint32_t nonfinite_seen;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t total_items = plan.item_prefix[plan.levels];
 
@@ -1489,8 +1544,9 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
         uint32_t level = 0;
         while (item >= plan.item_prefix[level + 1]) ++level;
         const uint32_t vm = level_max[level];
-        if (vm == 0u) continue;                                             // no non-zero finite update in this level
         const uint32_t Gl = plan.groups[level];
+        const bool store_all = overwrite && Gl == 1u;
+        if (vm == 0u && !store_all) continue;                               // no non-zero finite update in this level
         const uint32_t local = item - plan.item_prefix[level];
         const uint32_t part0 = (local / Gl) * SUB, grp = local - (local / Gl) * Gl;
         const uint32_t parts = plan.parts[level], size = plan.size[level];
@@ -1516,6 +1572,7 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
         const float inv = __uint_as_float((uint32_t)(127 - ex) << 23);
 
         for (uint32_t i = tid; i < SUB * P * C; i += 1024) bin_acc[i] = 0ull;
+        if (tid == 0) nonfinite_seen = 0u;
         __syncthreads();
 
         T* __restrict__ gtab = grad_table + (size_t)row0 * C;
@@ -1531,43 +1588,65 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
             d_end = dir[part_end];
             d_mid = SUB > 1u && part0 + 1u < part_end ? dir[part0 + 1u] : d_end;
         }
-        for (uint32_t j = 0; j < my_tiles; ++j) {
-            const uint32_t t = grp + wid * Gl + j * 16u * Gl;
-            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)d_off, j), end = (uint32_t)__builtin_amdgcn_readlane((int)d_end, j);
-            const uint32_t mid = (uint32_t)__builtin_amdgcn_readlane((int)d_mid, j);      // first entry of the second partition
-            const size_t seg0 = ((size_t)level * plan.tiles + t) * kTileEntries;
-            for (uint32_t i = off + lane; i < end; i += 64u) {
-                uint32_t rel0, bits;
-                if constexpr (SOA) {
-                    rel0 = log_rel[seg0 + i];
-                    bits = log_val[seg0 + i];
-                } else {
-                    const uint64_t e = log[seg0 + i];
-                    rel0 = (uint32_t)(e >> 32);
-                    bits = (uint32_t)e;
-                }
-                const uint32_t u = (SUB > 1u && i >= mid) ? 1u : 0u;
-                const uint32_t rel = rel0 + u * P;                            // slot in this item's accumulator
-                if constexpr (sizeof(T) == 4) {
-                    const float v = __uint_as_float(bits);
-                    if (fabsf(v) <= 3.0e38f)
-                        __hip_atomic_fetch_add(&bin_acc[rel], (unsigned long long)to_fixed(v, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else
-                        unsafeAtomicAdd(gtab + global_row(u, rel0), v);          // inf / nan propagate as they are
-                } else {
-                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                    const h2 p = __builtin_bit_cast(h2, bits);
-                    const float v0 = (float)p.x, v1 = (float)p.y;
-                    if (fabsf(v0) <= 3.0e38f && fabsf(v1) <= 3.0e38f) {
-                        if (v0 != 0.f) __hip_atomic_fetch_add(&bin_acc[rel * 2u], (unsigned long long)to_fixed(v0, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (v1 != 0.f) __hip_atomic_fetch_add(&bin_acc[rel * 2u + 1u], (unsigned long long)to_fixed(v1, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // walk(body): body(rel0, u, bits) for every entry of this item's runs
+        auto walk = [&](auto&& body) {
+            for (uint32_t j = 0; j < (vm != 0u ? my_tiles : 0u); ++j) {
+                const uint32_t t = grp + wid * Gl + j * 16u * Gl;
+                const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)d_off, j), end = (uint32_t)__builtin_amdgcn_readlane((int)d_end, j);
+                const uint32_t mid = (uint32_t)__builtin_amdgcn_readlane((int)d_mid, j);      // first entry of the second partition
+                const size_t seg0 = ((size_t)level * plan.tiles + t) * kTileEntries;
+                for (uint32_t i = off + lane; i < end; i += 64u) {
+                    uint32_t rel0, bits;
+                    if constexpr (SOA) {
+                        rel0 = log_rel[seg0 + i];
+                        bits = log_val[seg0 + i];
                     } else {
-                        (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gtab + (size_t)global_row(u, rel0) * 2u), p);
+                        const uint64_t e = log[seg0 + i];
+                        rel0 = (uint32_t)(e >> 32);
+                        bits = (uint32_t)e;
                     }
+                    body(rel0, (SUB > 1u && i >= mid) ? 1u : 0u, bits);
                 }
             }
-        }
+        };
+        // inf / nan entries bypass the fixed-point sum and go to the table as they are.  When the flush STORES its rows (store_all)
+        // that has to happen after the flush: the first walk only notes that there are any, a second walk (never taken in a healthy
+        // run) adds them onto the stored sums.
+        auto bypass = [&](uint32_t rel0, uint32_t u, uint32_t bits) {
+            if constexpr (sizeof(T) == 4) unsafeAtomicAdd(gtab + global_row(u, rel0), __uint_as_float(bits));
+            else {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gtab + (size_t)global_row(u, rel0) * 2u),
+                                                                __builtin_bit_cast(h2, bits));
+            }
+        };
+        auto finite = [&](uint32_t bits) {
+            if constexpr (sizeof(T) == 4) return fabsf(__uint_as_float(bits)) <= 3.0e38f;
+            else {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 p = __builtin_bit_cast(h2, bits);
+                return fabsf((float)p.x) <= 3.0e38f && fabsf((float)p.y) <= 3.0e38f;
+            }
+        };
+        walk([&](uint32_t rel0, uint32_t u, uint32_t bits) {
+            const uint32_t rel = rel0 + u * P;                            // slot in this item's accumulator
+            if (!finite(bits)) {
+                if (store_all) nonfinite_seen = 1u;
+                else bypass(rel0, u, bits);
+                return;
+            }
+            if constexpr (sizeof(T) == 4) {
+                __hip_atomic_fetch_add(&bin_acc[rel], (unsigned long long)to_fixed(__uint_as_float(bits), scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 p = __builtin_bit_cast(h2, bits);
+                const float v0 = (float)p.x, v1 = (float)p.y;
+                if (v0 != 0.f) __hip_atomic_fetch_add(&bin_acc[rel * 2u], (unsigned long long)to_fixed(v0, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (v1 != 0.f) __hip_atomic_fetch_add(&bin_acc[rel * 2u + 1u], (unsigned long long)to_fixed(v1, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        });
         __syncthreads();
+        const bool second_walk = store_all && nonfinite_seen != 0u;       // read here: the next item resets the flag before ITS first barrier
 
         for (uint32_t rel = tid; rel < SUB * P; rel += 1024) {
             const uint32_t u = rel >> kLog2P, rel0 = rel & (P - 1u);
@@ -1576,20 +1655,26 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
             if (row >= size) continue;
             if constexpr (sizeof(T) == 4) {
                 const long long a = (long long)bin_acc[rel];
-                if (a != 0) {
+                if (a != 0 || store_all) {
                     const float f = (float)a * inv;
                     if (!(fabsf(f) <= 3.0e38f) && found_inf) *found_inf = 1.0f;
-                    if (Gl == 1u) gtab[row] += f;
+                    if (store_all) gtab[row] = f;
+                    else if (Gl == 1u) gtab[row] += f;
                     else unsafeAtomicAdd(gtab + row, f);
                 }
             } else {
                 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                 const long long a0 = (long long)bin_acc[rel * 2u], a1 = (long long)bin_acc[rel * 2u + 1u];
-                if ((a0 | a1) != 0) {
+                if ((a0 | a1) != 0 || store_all) {
                     const float f0 = (float)a0 * inv, f1 = (float)a1 * inv;
                     if (!(fabsf(f0) <= 65504.0f && fabsf(f1) <= 65504.0f) && found_inf) *found_inf = 1.0f;       // rounds to inf in fp16
                     h2* dst = reinterpret_cast<h2*>(gtab + (size_t)row * 2u);
-                    if (Gl == 1u) {
+                    if (store_all) {
+                        h2 o;
+                        o.x = (_Float16)f0;          // == (half)(0 + f): the sum below starts from +0
+                        o.y = (_Float16)f1;
+                        *dst = o;
+                    } else if (Gl == 1u) {
                         h2 o = *dst;
                         o.x = (_Float16)((float)o.x + f0);
                         o.y = (_Float16)((float)o.y + f1);
@@ -1604,6 +1689,11 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
             }
         }
         __syncthreads();
+        if (second_walk) {
+            __threadfence();                                               // the stores above before the atomics below
+            walk([&](uint32_t rel0, uint32_t u, uint32_t bits) { if (!finite(bits)) bypass(rel0, u, bits); });
+            __syncthreads();
+        }
     }
 }
 
@@ -1864,7 +1954,7 @@ int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table
 int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* inputs, TvParams tv, float* table1, _Float16* table2, uint32_t B,
                        uint32_t max_level, const int32_t* host_offsets, const LevelTable& lv, uint32_t gridtype, bool align, uint32_t interp,
                        void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn, float* found_inf, float in_scale,
-                       float in_offset) {
+                       float in_offset, bool overwrite, uint32_t L) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
@@ -1884,6 +1974,7 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         uint32_t* log_v2 = log_v1 + lay.log_entries;
         uint16_t* log_rel = (uint16_t*)(log_v2 + lay.log_entries);
         N2M_HIP(hipMemsetAsync(level_max, 0, 256, s));
+        const bool ow = overwrite && b0 == 0;                 // later passes add onto the first one's sums
         const float* g1 = grad1 + (size_t)b0;
         const _Float16* g2 = grad2 + (size_t)b0 * 2;
         const float* x = inputs + (size_t)b0 * 3;
@@ -1911,11 +2002,30 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
             items1 += pairs * g;
         }
         plan1.item_prefix[max_level] = items1;
+        if (ow) {
+            // rows the accumulate kernels will not store themselves: levels split over several groups (they add atomically) -- the small
+            // dense levels at the front, cleared as ONE range per table (a single-group level inside it is simply stored over) -- and
+            // the levels >= max_level
+            auto clear = [&](const BinPlan& pl, void* table, size_t row_bytes) -> int {
+                size_t lo = SIZE_MAX, hi = 0;
+                for (uint32_t l = 0; l < max_level; ++l)
+                    if (pl.groups[l] > 1u) {
+                        lo = lo < pl.row0[l] ? lo : pl.row0[l];
+                        hi = hi > (size_t)pl.row0[l] + pl.size[l] ? hi : (size_t)pl.row0[l] + pl.size[l];
+                    }
+                if (hi > lo) N2M_HIP(hipMemsetAsync((char*)table + lo * row_bytes, 0, (hi - lo) * row_bytes, s));
+                const size_t t0 = (size_t)host_offsets[max_level], t1 = (size_t)host_offsets[L];
+                if (t1 > t0) N2M_HIP(hipMemsetAsync((char*)table + t0 * row_bytes, 0, (t1 - t0) * row_bytes, s));
+                return 0;
+            };
+            if (int rc = clear(plan1, table1, sizeof(float))) return rc;
+            if (int rc = clear(lay.plan, table2, 2u * sizeof(_Float16))) return rc;
+        }
         bin_accumulate_kernel<float, 1, kPairP, 2, true><<<items1 < 4096u ? items1 : 4096u, 1024, kPairP * 16, s>>>(
-            table1, plan1, lv, gridtype, align, level_max, directory, nullptr, found_inf, log_rel, log_v1);
+            table1, plan1, lv, gridtype, align, level_max, directory, nullptr, found_inf, log_rel, log_v1, ow);
         N2M_CHECK_LAUNCH();
         bin_accumulate_kernel<_Float16, 2, kPairP, 1, true><<<nb, 1024, kPairP * 16, s>>>(table2, lay.plan, lv, gridtype, align, level_max + kMaxLevels,
-                                                                                        directory, nullptr, found_inf, log_rel, log_v2);
+                                                                                        directory, nullptr, found_inf, log_rel, log_v2, ow);
         N2M_CHECK_LAUNCH();
     }
     return 0;
@@ -2128,21 +2238,27 @@ extern "C" int n2m_grid_encode_backward_binned_pair(const float* grad1, const vo
                                                     float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
                                                     float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                                                     const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
-                                                    const float* tv_scale, float* found_inf, float in_scale, float in_offset, void* workspace,
-                                                    uint64_t workspace_bytes, void* stream) {
+                                                    const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
+                                                    void* workspace, uint64_t workspace_bytes, void* stream) {
     const char* fn = "grid_encode_backward_binned_pair";
     if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
     N2M_REQUIRE(grad1 && grad2 && inputs && host_offsets && grad_embeddings1 && grad_embeddings2 && workspace, N2M_ENULL, "%s: NULL tensor", fn);
     N2M_REQUIRE(!tv_embeddings || max_level == L, N2M_EUNSUPPORTED, "%s: the fused TV term needs max_level == L", fn);
-    if (B == 0 || max_level == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (B == 0 || max_level == 0) {
+        if (overwrite && host_offsets[L] > 0) {
+            N2M_HIP(hipMemsetAsync(grad_embeddings1, 0, (size_t)host_offsets[L] * sizeof(float), s));
+            N2M_HIP(hipMemsetAsync(grad_embeddings2, 0, (size_t)host_offsets[L] * 2u * sizeof(_Float16), s));
+        }
+        return 0;
+    }
     const LevelTable lv = make_levels(L, S, H);
     const TvParams tv{tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale};
     // algorithmic bytes of BOTH encoders' backward + the TV stencil reads
     N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (12.0 + (double)max_level * (4 + 4) + 2.0 * max_level * 8 * (4 + 4) +
                                              (tv_embeddings ? (double)L * 7 * 4.0 : 0.0)));
     return launch_binned_pair(grad1, (const _Float16*)grad2, inputs, tv, grad_embeddings1, (_Float16*)grad_embeddings2, B, max_level, host_offsets, lv,
-                              gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf, in_scale, in_offset);
+                              gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf, in_scale, in_offset, overwrite != 0, L);
 }
 
 extern "C" int n2m_grid_encode_forward_pair(const float* inputs, const float* embeddings1, const void* embeddings2, const int32_t* offsets,

@@ -103,13 +103,13 @@ def _encode_backward_pair(d_h1, d_h2, x01, emb1, emb2h, net, max_level, in_affin
     """(g1, g2) through the shared-fill kernel, or (None, None) when it does not apply."""
     from .gridencoder import binned_backward_pair
     enc1, enc2 = net.encoder, net.encoder_color
-    g1 = torch.zeros_like(emb1)
-    g2 = torch.zeros_like(emb2h) if emb2h is not None else torch.zeros(emb1.shape[0], 2, dtype=torch.float16, device=emb1.device)
+    g1 = torch.empty_like(emb1)                        # overwrite mode: the kernels define every row, no zero-fill
+    g2 = torch.empty(emb1.shape[0], 2, dtype=torch.float16, device=emb1.device)
     req = getattr(enc1, "tv_request", None)
     amp1, amp2 = getattr(enc1, "amp_request", None), getattr(enc2, "amp_request", None)
     finf = amp1["found_inf"] if amp1 is not None else (amp2["found_inf"] if amp2 is not None else None)
     tv = (emb1, req["weight"], req["weight_outer"], req["inner01"], req["scale"]) if req is not None else None
-    if not binned_backward_pair(enc1, enc2, d_h1, d_h2, x01, g1, g2, max_level, tv=tv, found_inf=finf, in_affine=in_affine):
+    if not binned_backward_pair(enc1, enc2, d_h1, d_h2, x01, g1, g2, max_level, tv=tv, found_inf=finf, in_affine=in_affine, overwrite=True):
         return None, None
     if req is not None:
         req["done"] = True

@@ -128,9 +128,10 @@ def same_geometry(a, b):
             and a.input_dim == b.input_dim == 3)
 
 
-def binned_backward_pair(enc1, enc2, grad1_lm, grad2_lm, x01, g1, g2, max_level, tv=None, found_inf=None, in_affine=(1.0, 0.0)):
-    """Both table gradients (g1 fp32 C=1, g2 fp16 C=2, zero-filled or running sums) from one shared fill
-    (n2m_grid_encode_backward_binned_pair); False when not applicable."""
+def binned_backward_pair(enc1, enc2, grad1_lm, grad2_lm, x01, g1, g2, max_level, tv=None, found_inf=None, in_affine=(1.0, 0.0), overwrite=False):
+    """Both table gradients (g1 fp32 C=1, g2 fp16 C=2) from one shared fill (n2m_grid_encode_backward_binned_pair); False when not
+    applicable.  overwrite=False: added onto g1 / g2 (zero-filled or running sums); True: g1 / g2 may be uninitialised, the call
+    defines every row."""
     if not (g1.dtype == torch.float32 and g1.shape[1] == 1 and g2.dtype == torch.float16 and g2.shape[1] == 2):
         return False
     if not (hasattr(enc1, "host_offsets") and hasattr(enc2, "host_offsets") and same_geometry(enc1, enc2)):
@@ -138,6 +139,10 @@ def binned_backward_pair(enc1, enc2, grad1_lm, grad2_lm, x01, g1, g2, max_level,
     if tv is not None and max_level != enc1.num_levels:
         return False
     B = x01.shape[0]
+    if B == 0:
+        if overwrite:
+            g1.zero_(); g2.zero_()
+        return True
     ho = _host_offsets(enc1)
     need = L.lib().n2m_grid_binned_pair_workspace_bytes(B, max_level, ho.ctypes.data)
     if need == 0:
@@ -147,7 +152,7 @@ def binned_backward_pair(enc1, enc2, grad1_lm, grad2_lm, x01, g1, g2, max_level,
     L.call("n2m_grid_encode_backward_binned_pair", _p(grad1_lm), _p(grad2_lm), _p(x01), ho.ctypes.data, _p(g1), _p(g2), B, enc1.num_levels,
            max_level, float(np.log2(enc1.per_level_scale)), int(enc1.base_resolution), enc1.gridtype_id, int(bool(enc1.align_corners)),
            enc1.interp_id, _p(tv_emb), float(tv_w), float(tv_wo), float(tv_in), _p(tv_scale), _p(found_inf), float(in_affine[0]),
-           float(in_affine[1]), _p(ws), ws.numel(), L.stream())
+           float(in_affine[1]), int(bool(overwrite)), _p(ws), ws.numel(), L.stream())
     return True
 
 

@@ -667,6 +667,46 @@ def test_grid_backward_binned_pair_edge_cases(be, oracle, B, max_level):
     assert np.array_equal(z1.cpu().numpy(), pre1) and np.array_equal(z2.cpu().numpy(), pre2)
 
 
+@pytest.mark.parametrize("B,max_level,with_tv", [(100003, 16, True), (1025, 7, False), (0, 16, False), (2 ** 20 + 70001, 16, False)])
+def test_grid_backward_binned_pair_overwrite_mode(be, B, max_level, with_tv):
+    """overwrite=1 on garbage-filled tables == overwrite=0 on zero-filled ones: bit for bit where one workgroup owns a partition
+    (the 2^19-row levels), to atomic-order noise on the split dense levels; rows of levels >= max_level come back as zeros; a
+    non-finite gradient reaches the same rows in both modes (second walk after the stores) and raises found_inf."""
+    torch = be["torch"]
+    from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward_pair
+    gen = torch.Generator(device="cuda").manual_seed(B + max_level)
+    x = torch.rand(B, 3, device="cuda", generator=gen)
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    e2 = GridEncoder(level_dim=2, desired_resolution=2048).cuda()
+    offs = e1.host_offsets
+    d1 = torch.randn(16, B, 1, device="cuda", generator=gen) * (torch.rand(1, B, 1, device="cuda", generator=gen) < 0.7)
+    d2 = (torch.randn(16, B, 2, device="cuda", generator=gen) * (torch.rand(1, B, 1, device="cuda", generator=gen) < 0.7)).half()
+    if B > 100:
+        d1[2, 40, 0] = float("inf"); d2[5, 77, 1] = float("nan")
+    tv = (e1.embeddings.detach().float().contiguous(), 1e-3, 1e-2, 0.3, torch.tensor(128.0, device="cuda")) if with_tv else None
+    z1 = torch.zeros(offs[-1], 1, device="cuda"); z2 = torch.zeros(offs[-1], 2, device="cuda", dtype=torch.float16)
+    w1 = torch.full_like(z1, 123.0); w2 = torch.full_like(z2, -7.0)
+    f0, f1 = torch.zeros((), device="cuda"), torch.zeros((), device="cuda")
+    assert binned_backward_pair(e1, e2, d1, d2, x, z1, z2, max_level, tv=tv, found_inf=f0)
+    assert binned_backward_pair(e1, e2, d1, d2, x, w1, w2, max_level, tv=tv, found_inf=f1, overwrite=True)
+    assert float(f0) == float(f1) == (1.0 if B > 100 else 0.0)
+    a1, b1 = z1.cpu().numpy(), w1.cpu().numpy()
+    a2, b2 = z2.float().cpu().numpy(), w2.float().cpu().numpy()
+    assert np.array_equal(np.isfinite(a1), np.isfinite(b1)) and np.array_equal(np.isfinite(a2), np.isfinite(b2))
+    if B > 100:
+        assert not np.isfinite(a1).all() and not np.isfinite(a2).all()
+    fin1, fin2 = np.isfinite(a1), np.isfinite(a2)
+    np.testing.assert_allclose(b1[fin1], a1[fin1], rtol=1e-5, atol=1e-6 * max(float(np.abs(a1[fin1]).max()), 1e-30))
+    np.testing.assert_allclose(b2[fin2], a2[fin2], rtol=2e-3, atol=2e-3 * max(float(np.abs(a2[fin2]).max()), 1e-30))
+    for l in range(max_level if B else 0):
+        if offs[l + 1] - offs[l] == 2 ** 19 and B <= 2 ** 20:
+            sl = slice(offs[l], offs[l + 1])
+            ok = fin1[sl].all(-1) & fin2[sl].all(-1)        # a row hit by an inf/nan also takes its finite part in atomic order
+            assert np.array_equal(a1[sl][ok], b1[sl][ok]) and np.array_equal(a2[sl][ok], b2[sl][ok])
+    top = offs[max_level] if B else 0
+    assert not b1[top:].any() and not b2[top:].any()
+
+
 def test_grad_total_variation_binned(be, oracle):
     torch = be["torch"]
     from nerf2mesh_amd import _lib as L

@@ -31,4 +31,4 @@ if "--cprofile" in sys.argv:
     for i in range(200): tr.train_step()
     pr.disable(); torch.cuda.synchronize()
     st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
-    st.sort_stats("cumulative").print_stats(60)
+    st.sort_stats("cumulative").print_stats(170)
