@@ -89,8 +89,11 @@ int n2m_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
                          int32_t* rays, int32_t* counter, const float* noises, void* stream);
 
 /* raymarching.h:15  composite_rays_train_forward   kernel raymarching.cu:500-578.
- * sigmas [M], rgbs [M,3], ts [M,2], rays [N,2] -> weights [M] (caller zero-fills; entries after an early
- * stop are left untouched), weights_sum [N], depth [N], image [N,3]. */
+ * sigmas [M], rgbs [M,3], ts [M,2], rays [N,2] -> weights [M], weights_sum [N], depth [N], image [N,3].
+ * weights: every sample of a ray's (offset, count) range inside [0,M) is written -- zero after the early stop, and a
+ * ray cut off by M (skipped like :521) zeroes its part.  The reference zero-fills instead (raymarching.py:262); a caller
+ * whose ranges tile [0,M), as march_rays_train's do, can skip that, any other caller zero-fills as before.  The same
+ * holds for grad_sigmas / grad_rgbs of the backward. */
 int n2m_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* ts,
                                      const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
                                      int alpha_mode, float* weights, float* weights_sum, float* depth,

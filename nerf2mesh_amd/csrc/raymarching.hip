@@ -587,12 +587,20 @@ composite_train_fwd_kernel(const float* __restrict__ sigmas, const float* __rest
     if (n >= N) return;
     const uint32_t off = (uint32_t)rays[2 * n], cnt = (uint32_t)rays[2 * n + 1];
     float r = 0, g = 0, b = 0, ws = 0, d = 0;
+    // Every sample of the ray's range that lies inside [0, M) is WRITTEN (zero after the early stop; a ray cut off by M -- the
+    // reference's kernel returns for it, raymarching.cu:513 -- zeroes its part), so a caller whose rays tile [0, M), as those of
+    // march_rays_train do, need not clear `weights` first.
     if (cnt != 0 && off + cnt <= M) {
         float carry_T = 1.0f;
+        bool stopped = false;
         for (uint32_t base = 0; base < cnt; base += 64) {
             const uint32_t k = base + lane;
             const bool valid = k < cnt;
             const size_t i = (size_t)off + k;
+            if (stopped) {
+                if (valid) weights[i] = 0.f;
+                continue;
+            }
             float alpha = 0.f, tmid = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
             if (valid) {
                 const float2 tt = *reinterpret_cast<const float2*>(ts + 2 * i);
@@ -610,12 +618,14 @@ composite_train_fwd_kernel(const float* __restrict__ sigmas, const float* __rest
             const int last = stop ? (int)__ffsll((long long)stop) - 1 : 63;
             const bool live = valid && lane <= last;
             const float w = live ? alpha * T_before : 0.f;
-            if (live) weights[i] = w;
+            if (valid) weights[i] = w;
             r += w * cr; g += w * cg; b += w * cb; ws += w; d += w * tmid;
-            if (stop) break;
-            carry_T = __shfl(T_after, 63, 64);
+            if (stop) stopped = true;
+            else carry_T = __shfl(T_after, 63, 64);
         }
         r = n2m_wave_sum(r); g = n2m_wave_sum(g); b = n2m_wave_sum(b); ws = n2m_wave_sum(ws); d = n2m_wave_sum(d);
+    } else if (cnt != 0 && off < M) {
+        for (uint32_t i = off + (uint32_t)lane; i < M; i += 64) weights[i] = 0.f;
     }
     if (lane == 0) {
         weights_sum[n] = ws;
@@ -635,15 +645,27 @@ composite_train_bwd_kernel(const float* __restrict__ grad_weights, const float* 
     const int lane = threadIdx.x & 63;
     if (n >= N) return;
     const uint32_t off = (uint32_t)rays[2 * n], cnt = (uint32_t)rays[2 * n + 1];
-    if (cnt == 0 || off + cnt > M) return;
+    if (cnt == 0) return;
+    if (off + cnt > M) {          // cut off by M: no gradient; like the forward, the part inside [0, M) is written (zeros)
+        for (uint32_t i = off + (uint32_t)lane; i < M; i += 64) {
+            grad_sigmas[i] = 0.f;
+            grad_rgbs[3 * (size_t)i] = 0.f; grad_rgbs[3 * (size_t)i + 1] = 0.f; grad_rgbs[3 * (size_t)i + 2] = 0.f;
+        }
+        return;
+    }
     const float gi0 = grad_image[3 * n], gi1 = grad_image[3 * n + 1], gi2 = grad_image[3 * n + 2];
     const float gws = grad_weights_sum[n], gd = grad_depth[n];
     const float rF = image[3 * n], gF = image[3 * n + 1], bF = image[3 * n + 2], wsF = weights_sum[n], dF = depth[n];
     float carry_T = 1.0f, r0 = 0, g0 = 0, b0 = 0, ws0 = 0, d0 = 0;   // running sums before this chunk
+    bool stopped = false;
     for (uint32_t base = 0; base < cnt; base += 64) {
         const uint32_t k = base + lane;
         const bool valid = k < cnt;
         const size_t i = (size_t)off + k;
+        if (stopped) {
+            if (valid) { grad_sigmas[i] = 0.f; grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f; }
+            continue;
+        }
         float alpha = 0.f, tmid = 0.f, dt = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, gw = 0.f;
         if (valid) {
             const float2 tt = *reinterpret_cast<const float2*>(ts + 2 * i);
@@ -673,8 +695,10 @@ composite_train_bwd_kernel(const float* __restrict__ grad_weights, const float* 
             grad_sigmas[i] = scale * (gi0 * (T_after * cr - (rF - r)) + gi1 * (T_after * cg - (gF - g)) +
                                       gi2 * (T_after * cb - (bF - b)) + (gws + gw) * (T_after - (wsF - ws)) +
                                       gd * (T_after * tmid - (dF - d)));
+        } else if (valid) {
+            grad_sigmas[i] = 0.f; grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f;
         }
-        if (stop) break;
+        if (stop) { stopped = true; continue; }
         carry_T = __shfl(T_after, 63, 64);
         r0 = __shfl(r, 63, 64); g0 = __shfl(g, 63, 64); b0 = __shfl(b, 63, 64);
         ws0 = __shfl(ws, 63, 64); d0 = __shfl(d, 63, 64);

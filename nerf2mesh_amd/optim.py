@@ -45,6 +45,15 @@ class FusedAdamAMP(torch.optim.Optimizer):
         f = (self.scale / world if world > 1 else self.scale) if self.amp else (1.0 / world if world > 1 else None)
         return loss if f is None else loss * f
 
+    def backward(self, loss, world=1):
+        """scale_loss(loss, world).backward() without materialising the product: the factor goes in as the seed gradient (a device
+        scalar), which the loss head's backward kernel reads by pointer -- two small launches fewer per step."""
+        f = (self.scale / world if world > 1 else self.scale) if self.amp else (self._one / world if world > 1 else None)
+        if f is None:
+            loss.backward()
+        else:
+            loss.backward(gradient=f.to(loss.dtype).reshape(loss.shape))
+
     @torch.no_grad()
     def step(self, flagged=()):
         """flagged: parameters whose gradients were already checked for inf/nan by the kernels that produced them."""

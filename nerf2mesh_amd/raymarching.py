@@ -152,43 +152,47 @@ def _zeros_like_cached(ref, n):
 
 class _composite_rays_train(Function):
     @staticmethod
-    def forward(ctx, sigmas, rgbs, ts, rays, T_thresh=1e-4, alpha_mode=False):
+    def forward(ctx, sigmas, rgbs, ts, rays, T_thresh=1e-4, alpha_mode=False, rays_tile_samples=False):
         sigmas, rgbs, ts = _f32c(sigmas), _f32c(rgbs), _f32c(ts)
         rays = rays.contiguous()
         M, N = sigmas.shape[0], rays.shape[0]
         dev = sigmas.device
-        weights = torch.zeros(M, dtype=torch.float32, device=dev)   # samples after an early stop keep weight 0
+        # the kernels write every sample inside a ray's range (zeros after the early stop); the fill is only for samples no ray owns
+        mk = torch.empty if rays_tile_samples else torch.zeros
+        weights = mk(M, dtype=torch.float32, device=dev)
         weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
         image = torch.empty(N, 3, dtype=torch.float32, device=dev)
         L.call("n2m_composite_rays_train_forward", _p(sigmas), _p(rgbs), _p(ts), _p(rays), M, N, float(T_thresh),
                int(bool(alpha_mode)), _p(weights), _p(weights_sum), _p(depth), _p(image), L.stream())
         ctx.save_for_backward(sigmas, rgbs, ts, rays, weights_sum, depth, image)
-        ctx.cfg = (M, N, float(T_thresh), int(bool(alpha_mode)))
+        ctx.cfg = (M, N, float(T_thresh), int(bool(alpha_mode)), bool(rays_tile_samples))
         ctx.set_materialize_grads(False)      # unused outputs (weights, depth in the plain rgb loss) arrive as None, not as fresh zero tensors
         return weights, weights_sum, depth, image
 
     @staticmethod
     def backward(ctx, grad_weights, grad_weights_sum, grad_depth, grad_image):
         sigmas, rgbs, ts, rays, weights_sum, depth, image = ctx.saved_tensors
-        M, N, T_thresh, alpha_mode = ctx.cfg
+        M, N, T_thresh, alpha_mode, tiled = ctx.cfg
         zeros = _zeros_like_cached(sigmas, max(M, 3 * N))          # stands in for every gradient that is None (read-only)
         gw = _f32c(grad_weights) if grad_weights is not None else zeros[:M]
         gws = _f32c(grad_weights_sum) if grad_weights_sum is not None else zeros[:N]
         gd = _f32c(grad_depth) if grad_depth is not None else zeros[:N]
         gi = _f32c(grad_image) if grad_image is not None else zeros[:3 * N].view(N, 3)
-        both = torch.zeros(M, 4, dtype=torch.float32, device=sigmas.device)      # one fill for the two outputs
+        both = (torch.empty if tiled else torch.zeros)(M, 4, dtype=torch.float32, device=sigmas.device)      # one buffer for the two outputs
         grad_sigmas = both.view(-1)[:M]
         grad_rgbs = both.view(-1)[M:].view(M, 3)
         L.call("n2m_composite_rays_train_backward", _p(gw), _p(gws), _p(gd), _p(gi), _p(sigmas), _p(rgbs), _p(ts), _p(rays),
                _p(weights_sum), _p(depth), _p(image), M, N, T_thresh, alpha_mode, _p(grad_sigmas), _p(grad_rgbs), L.stream())
-        return grad_sigmas, grad_rgbs, None, None, None, None
+        return grad_sigmas, grad_rgbs, None, None, None, None, None
 
 
-def composite_rays_train(sigmas, rgbs, ts, rays, T_thresh=1e-4, alpha_mode=False):
+def composite_rays_train(sigmas, rgbs, ts, rays, T_thresh=1e-4, alpha_mode=False, rays_tile_samples=False):
     """Front-to-back compositing of packed samples; differentiable in sigmas and rgbs (raymarching.py:248-305).
-    Returns weights [M], weights_sum [N], depth [N], image [N,3]."""
-    return _composite_rays_train.apply(sigmas, rgbs, ts, rays, T_thresh, alpha_mode)
+    Returns weights [M], weights_sum [N], depth [N], image [N,3].
+    rays_tile_samples (not in the reference signature): the (offset, count) ranges of `rays` cover [0, M) without gaps -- true for the
+    output of march_rays_train -- so the outputs need no zero-fill."""
+    return _composite_rays_train.apply(sigmas, rgbs, ts, rays, T_thresh, alpha_mode, rays_tile_samples)
 
 
 @torch.no_grad()

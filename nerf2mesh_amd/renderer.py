@@ -141,7 +141,8 @@ class NeRFRenderer(nn.Module):
                 car = self.opt.cos_anneal_ratio
                 iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - car) + F.relu(-true_cos) * car)
                 sigmas = self._sdf_to_alpha(sigmas, iter_cos, ts[:, 1])
-            weights, weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, ts, rays, T_thresh, self.opt.sdf)
+            weights, weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, ts, rays, T_thresh, self.opt.sdf,
+                                                                                  rays_tile_samples=True)   # our marcher's ranges tile [0, M)
             results.update(num_points=xyzs.shape[0], xyzs=xyzs, speculars=speculars, weights=weights, weights_sum=weights_sum)
         else:
             weights_sum = torch.zeros(N, dtype=torch.float32, device=device)

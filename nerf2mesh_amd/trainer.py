@@ -54,7 +54,8 @@ class Stage0Trainer:
         self.scaler = torch.amp.GradScaler("cuda", enabled=bool(opt.fp16) and device.type == "cuda")
         self.sync = GradSync(model, world_size) if world_size > 1 else None
         self.boxes = synthetic.boxes(device)
-        self.loss_acc = torch.zeros((), device=device)
+        self._loss_sum = torch.zeros((), device=device)
+        self._loss_pending = []
         self.samples_seen = 0
         self.rays_seen = 0
         self.last_num_points = 0
@@ -66,6 +67,14 @@ class Stage0Trainer:
         self.pipeline = True          # issue march pass 1 of the next batch one step ahead (results are identical)
         self.overlap_march = True     # ... on a second stream, next to this step's backward + optimizer kernels (single-rank path)
         self._next = None
+
+    @property
+    def loss_acc(self):
+        """Sum of the training losses so far (device scalar)."""
+        if self._loss_pending:
+            self._loss_sum = self._loss_sum + torch.stack(self._loss_pending).sum()
+            self._loss_pending = []
+        return self._loss_sum
 
     def mark_untrained(self):
         if self.opt.mark_untrained:
@@ -181,7 +190,7 @@ class Stage0Trainer:
             if self.overlap_march and self.pipeline and self.sync is None and torch.device(self.device).type == "cuda" \
                     and self.global_step % opt.update_extra_interval != 0:
                 self._next = self._prepare_overlapped()
-            o.scale_loss(loss, self.world).backward()
+            o.backward(loss, self.world)
             model.encoder.amp_request = model.encoder_color.amp_request = model.amp_request = None
             model.encoder.tv_request = None
             if tv_req is None or not tv_req["done"]:
@@ -224,7 +233,9 @@ class Stage0Trainer:
             self.scaler.step(self.optimizer)
             self.scaler.update()
         self.scheduler.step()
-        self.loss_acc += loss.detach()
+        self._loss_pending.append(loss.detach())       # summed lazily (loss_acc): no per-step add kernel
+        if len(self._loss_pending) >= 1024:
+            _ = self.loss_acc
         if self.pipeline and self._next is None:
             # everything the next step needs before its sample count is known goes into the queue now, behind this step's
             # optimizer update (same order as the reference: refresh -> batch -> march), so the GPU never drains at the read-back

@@ -192,10 +192,10 @@ def test_composite_train(be, oracle, alpha_mode):
     counts = rng.integers(0, 200, N).astype(np.int32)
     counts[:5] = 0
     counts[10] = 1024
+    counts[-1] = 37
     offs = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int32)
     rays = np.stack([offs, counts], 1).astype(np.int32)
-    M = int(counts.sum())
-    rays[7] = [M - 2, 10]                      # overflowing ray -> zeros (guard raymarching.cu:521)
+    M = int(counts.sum()) - 3                  # the last ray overflows the sample buffer -> zeros (guard raymarching.cu:521)
     sig = (rng.random(M) * (1.0 if alpha_mode else 60.0)).astype(np.float32)
     sig[offs[10]:offs[10] + 1024] *= 0.002      # a long, thin ray: many chunks before the early stop
     if alpha_mode:
@@ -213,14 +213,22 @@ def test_composite_train(be, oracle, alpha_mode):
     # relative error itself, the wave tree sum less; 2e-4 covers the worst (1024-sample) ray
     np.testing.assert_allclose(dp.cpu().numpy(), odp, rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(im.cpu().numpy(), oim, **tol)
-    # samples after the early stop are untouched in both (exact zeros), up to threshold ties
+    # samples after the early stop are exact zeros in both, up to threshold ties
     assert np.mean((w.cpu().numpy() == 0) != (ow == 0)) < 1e-4
+    # the kernel writes every sample of every ray range (these rays tile [0, M)): no zero-fill needed beforehand
+    w2 = torch.full((M,), 7.0, device="cuda")
+    rm.composite_rays_train_forward(dev(be, sig), dev(be, rgb), dev(be, ts), dev(be, rays), M, N, 1e-4, alpha_mode, w2, ws, dp, im)
+    assert torch.equal(w, w2)
     gw, gws, gd, gi = (rng.normal(size=M).astype(np.float32), rng.normal(size=N).astype(np.float32),
                        rng.normal(size=N).astype(np.float32), rng.normal(size=(N, 3)).astype(np.float32))
     gs = torch.zeros(M, device="cuda"); gr = torch.zeros(M, 3, device="cuda")
     rm.composite_rays_train_backward(dev(be, gw), dev(be, gws), dev(be, gd), dev(be, gi), dev(be, sig), dev(be, rgb), dev(be, ts),
                                      dev(be, rays), dev(be, ows), dev(be, odp), dev(be, oim), M, N, 1e-4, alpha_mode, gs, gr)
     ogs, ogr = oracle.composite_rays_train_backward(gw, gws, gd, gi, sig, rgb, ts, rays, ows, odp, oim, 1e-4, alpha_mode)
+    gs2 = torch.full((M,), -3.0, device="cuda"); gr2 = torch.full((M, 3), 5.0, device="cuda")
+    rm.composite_rays_train_backward(dev(be, gw), dev(be, gws), dev(be, gd), dev(be, gi), dev(be, sig), dev(be, rgb), dev(be, ts),
+                                     dev(be, rays), dev(be, ows), dev(be, odp), dev(be, oim), M, N, 1e-4, alpha_mode, gs2, gr2)
+    assert torch.equal(gs, gs2) and torch.equal(gr, gr2)
     np.testing.assert_allclose(gr.cpu().numpy(), ogr, rtol=2e-5, atol=2e-6)
     # grad_sigma subtracts nearly equal suffix sums: absolute tolerance scaled to the magnitudes involved
     scale = np.abs(ogs).max()
