@@ -284,7 +284,7 @@ int n2m_photo_loss_backward(const float* image, const float* weights_sum, const 
 /* Adam + GradScaler for the whole parameter set in two launches (torch.optim.Adam(fused=True) + torch.amp.GradScaler of
  * main.py:221 / nerf/utils.py:506,1187-1190).  All tensors fp32 and 16-byte aligned, except grad which may be fp16
  * (grad_is_half) and half_shadow (fp16 copy of the updated parameter, or NULL).  Gradients are still multiplied by *scale
- * (NULL = 1); nothing is touched when *found_inf != 0; bias [2] = (1 - beta1^t, sqrt(1 - beta2^t)) of this step, kept up to
+ * (NULL = 1); no parameter or moment is touched when *found_inf != 0; bias [2] = (1 - beta1^t, sqrt(1 - beta2^t)) of this step, kept up to
  * date by n2m_scaler_update (initialise it to (1 - beta1, sqrt(1 - beta2)) for t = 1). */
 #define N2M_ADAM_MAX 16
 typedef struct {
@@ -293,6 +293,8 @@ typedef struct {
     uint32_t numel[N2M_ADAM_MAX]; float lr[N2M_ADAM_MAX]; int32_t grad_is_half[N2M_ADAM_MAX];
     int32_t shadow_mode[N2M_ADAM_MAX];   /* 1: half_shadow is a plain fp16 copy; 2: parameter is a [rows,1] fp32 table, written to column 0
                                             of a packed table (8 B rows); 3: parameter is a [rows,2] table, written as half2 to column 1 */
+    int32_t clear_grad[N2M_ADAM_MAX];    /* 1: the (fp32) gradient is set to zero once read -- also when the step is skipped -- so that a
+                                            producer adding into a persistent buffer needs no zero-fill launch of its own */
     uint32_t count;
 } N2mAdamDesc;   /* HOST struct */
 int n2m_adam_step(const N2mAdamDesc* desc, double beta1, double beta2, float eps, const float* scale,

@@ -75,7 +75,7 @@ class AdamDesc(ctypes.Structure):
     """N2mAdamDesc of include/n2m_hip.h."""
     _fields_ = [("param", _vp * ADAM_MAX), ("grad", _vp * ADAM_MAX), ("exp_avg", _vp * ADAM_MAX), ("exp_avg_sq", _vp * ADAM_MAX),
                 ("half_shadow", _vp * ADAM_MAX), ("numel", _u32 * ADAM_MAX), ("lr", _f32 * ADAM_MAX), ("grad_is_half", _i32 * ADAM_MAX),
-                ("shadow_mode", _i32 * ADAM_MAX), ("count", _u32)]
+                ("shadow_mode", _i32 * ADAM_MAX), ("clear_grad", _i32 * ADAM_MAX), ("count", _u32)]
 
 
 KERNEL_IDS = {"grid_encode_forward": 0, "grid_encode_backward": 1, "grad_total_variation": 2, "march_rays_train_count": 3,

@@ -1373,7 +1373,8 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
                      const float* __restrict__ inputs, TvParams tv, uint32_t B, uint32_t Bstride, BinPlan plan, LevelTable lv,
                      uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max /*[2][32]*/,
                      uint32_t* __restrict__ directory, uint16_t* __restrict__ log_rel, uint32_t* __restrict__ log_v1,
-                     uint32_t* __restrict__ log_v2, float* __restrict__ found_inf, float in_scale, float in_offset) {
+                     uint32_t* __restrict__ log_v2, float* __restrict__ found_inf, float in_scale, float in_offset,
+                     float* __restrict__ clear1, _Float16* __restrict__ clear2, uint32_t clear_mask1, uint32_t clear_mask2) {
     constexpr uint32_t D = 3;
     constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -1393,6 +1394,16 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
     const uint32_t level = blockIdx.y;
     const uint32_t parts = plan.parts[level], size = plan.size[level];
     for (uint32_t i = tid; i < parts; i += 1024) { cnt2[0][i] = 0; cnt2[1][i] = 0; }
+    // overwrite mode: levels whose partitions are split over several accumulate groups receive atomics and must start from zero;
+    // this kernel is ordered before the accumulates, so its workgroups clear them (a slice each) instead of two extra memset launches
+    if ((clear_mask1 | clear_mask2) >> level & 1u) {
+        const uint32_t per = (size + gridDim.x - 1) / gridDim.x, lo = min(size, blockIdx.x * per), hi = min(size, lo + per);
+        const size_t r0 = plan.row0[level];
+        if (clear_mask1 >> level & 1u)
+            for (uint32_t i = lo + tid; i < hi; i += 1024) clear1[r0 + i] = 0.0f;
+        if (clear_mask2 >> level & 1u)
+            for (uint32_t i = lo + tid; i < hi; i += 1024) reinterpret_cast<uint32_t*>(clear2)[r0 + i] = 0u;
+    }
 
     const float scale = lv.scale[level];
     const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
@@ -1978,19 +1989,9 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         const float* g1 = grad1 + (size_t)b0;
         const _Float16* g2 = grad2 + (size_t)b0 * 2;
         const float* x = inputs + (size_t)b0 * 3;
-        const dim3 grid((lay.plan.tiles + kPairTilesPerWg - 1) / kPairTilesPerWg, max_level);     // each workgroup walks ~kPairTilesPerWg tiles
-        if (tv.table)
-            bin_fill_pair_kernel<true><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
-                                                                             directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset);
-        else
-            bin_fill_pair_kernel<false><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
-                                                                              directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset);
-        N2M_CHECK_LAUNCH();
-        const uint32_t items = lay.plan.item_prefix[max_level];
-        const uint32_t nb = items < 4096u ? items : 4096u;
         // the fp32 table accumulates two partitions per work item: same item count and LDS bytes as on its own 8192-row structure
         BinPlan plan1 = lay.plan;
-        uint32_t items1 = 0;
+        uint32_t items1 = 0, cm1 = 0, cm2 = 0;
         for (uint32_t l = 0; l < max_level; ++l) {
             const uint32_t pairs = (plan1.parts[l] + 1u) / 2u;
             const uint64_t per_item = (uint64_t)8 * Bc / pairs;
@@ -2000,27 +2001,27 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
             plan1.groups[l] = g;
             plan1.item_prefix[l] = items1;
             items1 += pairs * g;
+            if (ow && g > 1u) cm1 |= 1u << l;                      // levels that add atomically: cleared by the fill kernel
+            if (ow && lay.plan.groups[l] > 1u) cm2 |= 1u << l;
         }
         plan1.item_prefix[max_level] = items1;
-        if (ow) {
-            // rows the accumulate kernels will not store themselves: levels split over several groups (they add atomically) -- the small
-            // dense levels at the front, cleared as ONE range per table (a single-group level inside it is simply stored over) -- and
-            // the levels >= max_level
-            auto clear = [&](const BinPlan& pl, void* table, size_t row_bytes) -> int {
-                size_t lo = SIZE_MAX, hi = 0;
-                for (uint32_t l = 0; l < max_level; ++l)
-                    if (pl.groups[l] > 1u) {
-                        lo = lo < pl.row0[l] ? lo : pl.row0[l];
-                        hi = hi > (size_t)pl.row0[l] + pl.size[l] ? hi : (size_t)pl.row0[l] + pl.size[l];
-                    }
-                if (hi > lo) N2M_HIP(hipMemsetAsync((char*)table + lo * row_bytes, 0, (hi - lo) * row_bytes, s));
-                const size_t t0 = (size_t)host_offsets[max_level], t1 = (size_t)host_offsets[L];
-                if (t1 > t0) N2M_HIP(hipMemsetAsync((char*)table + t0 * row_bytes, 0, (t1 - t0) * row_bytes, s));
-                return 0;
-            };
-            if (int rc = clear(plan1, table1, sizeof(float))) return rc;
-            if (int rc = clear(lay.plan, table2, 2u * sizeof(_Float16))) return rc;
+        if (ow && max_level < L) {                                  // levels the call does not touch
+            const size_t t0 = (size_t)host_offsets[max_level], t1 = (size_t)host_offsets[L];
+            N2M_HIP(hipMemsetAsync(table1 + t0, 0, (t1 - t0) * sizeof(float), s));
+            N2M_HIP(hipMemsetAsync(table2 + t0 * 2u, 0, (t1 - t0) * 2u * sizeof(_Float16), s));
         }
+        const dim3 grid((lay.plan.tiles + kPairTilesPerWg - 1) / kPairTilesPerWg, max_level);     // each workgroup walks ~kPairTilesPerWg tiles
+        if (tv.table)
+            bin_fill_pair_kernel<true><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
+                                                                             directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset, ow ? table1 : nullptr,
+                                                                             ow ? table2 : nullptr, cm1, cm2);
+        else
+            bin_fill_pair_kernel<false><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
+                                                                              directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset, ow ? table1 : nullptr,
+                                                                             ow ? table2 : nullptr, cm1, cm2);
+        N2M_CHECK_LAUNCH();
+        const uint32_t items = lay.plan.item_prefix[max_level];
+        const uint32_t nb = items < 4096u ? items : 4096u;
         bin_accumulate_kernel<float, 1, kPairP, 2, true><<<items1 < 4096u ? items1 : 4096u, 1024, kPairP * 16, s>>>(
             table1, plan1, lv, gridtype, align, level_max, directory, nullptr, found_inf, log_rel, log_v1, ow);
         N2M_CHECK_LAUNCH();

@@ -123,7 +123,7 @@ struct AdamTensors {
     float lr[N2M_ADAM_MAX];
     uint8_t shadow_mode[N2M_ADAM_MAX];
     int8_t partner[N2M_ADAM_MAX];     // mode-3 tensor: index of the mode-2 tensor packed into the same table (updated by the same threads), or -1
-    uint32_t count, g_half_mask;
+    uint32_t count, g_half_mask, clear_mask;    // clear_mask: fp32 gradients this launch resets to zero once consumed
 };
 
 // refresh the working copy of elements i0 .. i0+cnt-1 (cnt <= 4): plain fp16 copy, or one column of a packed table whose rows
@@ -160,12 +160,17 @@ __device__ __forceinline__ void shadow_store(_Float16* S, uint32_t mode, uint32_
 __global__ void __launch_bounds__(256)
 adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, float eps, const float* __restrict__ scale,
             const float* __restrict__ found_inf, const float* __restrict__ bias /*[2]: 1-b1^t, sqrt(1-b2^t) of THIS step*/) {
-    if (found_inf && *found_inf != 0.0f) return;                       // GradScaler: skip the whole step
     uint32_t k = 0;
     while (k + 1 < t.count && blockIdx.x >= t.first_block[k + 1]) ++k;
     const uint32_t i0 = ((blockIdx.x - t.first_block[k]) * 256u + threadIdx.x) * 4u;
     const uint32_t n = t.n[k];
     if (i0 >= n) return;
+    const bool clear_g = (t.clear_mask >> k) & 1u;                     // consume-and-clear: the producer accumulates into a persistent buffer
+    if (found_inf && *found_inf != 0.0f) {                             // GradScaler: skip the whole step (the gradients are still consumed)
+        if (clear_g)
+            for (uint32_t e = 0; e < 4u && i0 + e < n; ++e) reinterpret_cast<float*>(t.g[k])[i0 + e] = 0.0f;
+        return;
+    }
     const float bc1 = bias[0], bc2_sqrt = bias[1];
     const float step_size = t.lr[k] / bc1;
     const float inv_scale = scale ? 1.0f / *scale : 1.0f;
@@ -208,6 +213,8 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
         p[e] -= step_size * m[e] / denom;
     }
     const int pk = t.partner[k];
+    if (clear_g)
+        for (uint32_t e = 0; e < 4u && i0 + e < n; ++e) reinterpret_cast<float*>(t.g[k])[i0 + e] = 0.0f;
     if (full) {
         *reinterpret_cast<float4*>(P + i0) = make_float4(p[0], p[1], p[2], p[3]);
         *reinterpret_cast<float4*>(M + i0) = make_float4(m[0], m[1], m[2], m[3]);
@@ -333,6 +340,7 @@ extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, f
         t.first_block[k] = blocks;
         blocks += n2m_ceil_div(d->numel[k], 1024);
         if (d->grad_is_half[k]) t.g_half_mask |= 1u << k;
+        if (d->clear_grad[k] && !d->grad_is_half[k]) t.clear_mask |= 1u << k;
         t.shadow_mode[k] = (uint8_t)(d->half_shadow[k] ? (d->shadow_mode[k] ? d->shadow_mode[k] : 1) : 0);
         N2M_REQUIRE(t.shadow_mode[k] <= 3 && !(t.shadow_mode[k] == 3 && (d->numel[k] & 1u)), N2M_EINVAL, "adam_step: bad shadow mode for tensor %u", k);
     }

@@ -190,12 +190,23 @@ class _fused_field(Function):
             d_h2 = torch.empty(16, M, 2, dtype=torch.float16, device=dev)
         else:
             d_rgb = d_spec = None
-        flat = torch.zeros(sum(w.numel() for w in ws), dtype=torch.float32, device=dev)      # one fill for the seven dW
+        amp = getattr(net, "amp_request", None)          # optim.FusedAdamAMP: weight-gradient finiteness is checked by the kernel
+        n_flat = sum(w.numel() for w in ws)
+        persistent = amp is not None and amp.get("persistent_dw", False)
+        if persistent:
+            # the seven dW live in one buffer that is all-zero between steps: the kernel adds into it, the optimizer reads it through
+            # ext_grads and its Adam kernel clears it again -- no fill launch, no AccumulateGrad nodes
+            flat = getattr(net, "_dw_flat", None)
+            if flat is None or flat.numel() != n_flat or flat.device != dev:
+                flat = net._dw_flat = torch.zeros(n_flat, dtype=torch.float32, device=dev)
+        else:
+            flat = torch.zeros(n_flat, dtype=torch.float32, device=dev)      # one fill for the seven dW
         dws, o = [], 0
         for w in ws:
             dws.append(flat[o:o + w.numel()].view_as(w))
             o += w.numel()
-        amp = getattr(net, "amp_request", None)          # optim.FusedAdamAMP: weight-gradient finiteness is checked by the kernel
+        if persistent:
+            amp["dw_flat"], amp["dw_views"] = flat, list(dws)
         L.call("n2m_field_backward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, ctx.normalize_dirs, _p(d_sigma), _p(d_rgb),
                _p(d_spec), _p(d_h1), _p(d_h2), *[_p(g) for g in dws], _p(amp["found_inf"]) if amp is not None else None, L.stream())
         if amp is not None:
@@ -236,7 +247,9 @@ class _fused_field(Function):
                 g2 = None
             else:
                 g2 = g2.float()
-        if not want_color:
+        if persistent:
+            dws = [None] * 7
+        elif not want_color:
             dws[2:] = [None] * 5
         elif shading == 0:
             dws[5:] = [None] * 2

@@ -39,6 +39,8 @@ class FusedAdamAMP(torch.optim.Optimizer):
         self.shadows = {}          # param -> callable returning the working copy to refresh: a tensor (plain fp16 copy), (tensor, mode)
                                    # with mode 2 / 3 = column of a packed table (N2mAdamDesc.shadow_mode), or None
         self.half_grads = {}       # param -> callable returning an fp16 gradient produced outside autograd (or None)
+        self.ext_grads = {}        # param -> callable returning an fp32 gradient that lives in a PERSISTENT buffer its producer adds into
+                                   # (or None): the Adam kernel zeroes it after reading, so the producer needs no zero-fill launch
 
     def scale_loss(self, loss, world=1):
         """loss * scale / world: with gradients SUMMED over `world` ranks the update sees their mean."""
@@ -65,11 +67,17 @@ class FusedAdamAMP(torch.optim.Optimizer):
                 hg = self.half_grads.get(p)
                 g = hg() if hg is not None else None
                 is_half = g is not None
+                clear = False
+                if g is None:
+                    eg = self.ext_grads.get(p)
+                    g = eg() if eg is not None else None
+                    clear = g is not None
                 if g is None:
                     g = p.grad
                 if g is None:
                     continue
                 if not g.is_contiguous():
+                    assert not clear, "a persistent gradient buffer must be contiguous"
                     g = g.contiguous()
                 if id(p) not in flagged:
                     unchecked.append(g)
@@ -84,6 +92,7 @@ class FusedAdamAMP(torch.optim.Optimizer):
                 desc.half_shadow[k] = sh.data_ptr() if sh is not None else None
                 desc.numel[k], desc.lr[k], desc.grad_is_half[k] = p.numel(), float(group["lr"]), int(is_half)
                 desc.shadow_mode[k] = int(mode) if sh is not None else 0
+                desc.clear_grad[k] = int(clear and g.is_contiguous())
                 keep += [g, sh]
                 k += 1
         if k == 0:

@@ -46,6 +46,9 @@ class Stage0Trainer:
             self.optimizer.shadows[enc.embeddings] = shadow_density
             self.optimizer.shadows[encc.embeddings] = shadow_color
             self.optimizer.half_grads[encc.embeddings] = lambda: self._amp.get("color", {}).get("grad_half")
+            self._mlp_params = [p for m in (model.sigma_net, model.color_net, model.specular_net) for p in m.parameters()]
+            for i, p in enumerate(self._mlp_params):   # the fused field backward adds the seven dW into one persistent buffer (fused._fused_field)
+                self.optimizer.ext_grads[p] = lambda i=i: (self._amp.get("mlp", {}).get("dw_views") or [None] * 7)[i]
         else:
             self.optimizer = torch.optim.Adam(model.get_params(opt.lr), eps=1e-15, fused=(device.type == "cuda"))
         iters = opt.iters
@@ -185,7 +188,7 @@ class Stage0Trainer:
         if self.amp_adam:
             o = self.optimizer
             self._amp = {"density": dict(found_inf=o.found_inf, flagged=False), "color": dict(found_inf=o.found_inf, flagged=False, keep_half=True),
-                         "mlp": dict(found_inf=o.found_inf, flagged=False)}
+                         "mlp": dict(found_inf=o.found_inf, flagged=False, persistent_dw=len(self._mlp_params) == 7)}
             model.encoder.amp_request, model.encoder_color.amp_request, model.amp_request = self._amp["density"], self._amp["color"], self._amp["mlp"]
             if self.overlap_march and self.pipeline and self.sync is None and torch.device(self.device).type == "cuda" \
                     and self.global_step % opt.update_extra_interval != 0:
@@ -199,7 +202,7 @@ class Stage0Trainer:
             if self.sync is not None:
                 # one SUM all-reduce per table gradient (the colour one stays fp16: half the bytes) + one small bucket; the reduced
                 # gradients are then checked for inf/nan like any others (a sum of finite fp16 values can overflow)
-                mlp = [p.grad for m in (model.sigma_net, model.color_net, model.specular_net) for p in m.parameters()]
+                mlp = [self._amp["mlp"]["dw_flat"]] if "dw_flat" in self._amp["mlp"] else [p.grad for p in self._mlp_params]
                 token = self.sync.all_reduce_sum_begin([model.encoder.embeddings.grad, self._amp["color"].get("grad_half"),
                                                         model.encoder_color.embeddings.grad], mlp + [o.found_inf])
                 # the next batch's ray generation and march pass 1 read neither gradients nor parameters: enqueue them now so that they
@@ -213,7 +216,7 @@ class Stage0Trainer:
                 if self._amp["color"]["flagged"]:
                     flagged.append(model.encoder_color.embeddings)
                 if self._amp["mlp"]["flagged"]:
-                    flagged += [p for m in (model.sigma_net, model.color_net, model.specular_net) for p in m.parameters()]
+                    flagged += self._mlp_params
             o.step(flagged=flagged)
         else:
             self.scaler.scale(loss).backward()

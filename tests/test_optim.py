@@ -92,3 +92,31 @@ def test_backward_kernels_raise_found_inf():
     g3 = torch.full_like(g, 60000.0)                                   # finite inputs, sums overflow fp16 at the flush
     x3 = x[:1].expand(B, 3).contiguous()
     assert binned_backward(enc, g3, x3, torch.zeros_like(out), 16, found_inf=flag) and float(flag) == 1
+
+
+def test_adam_consumes_and_clears_persistent_gradients():
+    """ext_grads: a gradient living in a persistent buffer is read by the Adam kernel and left all-zero for the producer's next
+    accumulation -- also on a skipped (found_inf) step -- while the update itself equals torch's."""
+    import torch
+    from nerf2mesh_amd.optim import FusedAdamAMP
+    torch.manual_seed(3)
+    a = torch.randn(1001, 3, device="cuda").requires_grad_()
+    b = torch.randn(64, 64, device="cuda").requires_grad_()
+    ra, rb = a.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    ref = torch.optim.Adam([ra, rb], lr=1e-2, eps=1e-15)
+    opt = FusedAdamAMP([a, b], lr=1e-2, eps=1e-15, amp=True, init_scale=4.0)
+    flat = torch.zeros(a.numel() + b.numel(), device="cuda")
+    va, vb = flat[:a.numel()].view_as(a), flat[a.numel():].view_as(b)
+    opt.ext_grads[a] = lambda: va
+    opt.ext_grads[b] = lambda: vb
+    for it in range(3):
+        ga, gb = torch.randn_like(a), torch.randn_like(b)
+        va += ga * 4.0; vb += gb * 4.0                       # the producer adds (scaled gradients) into the all-zero buffer
+        ra.grad, rb.grad = ga, gb
+        opt.step(); ref.step()
+        assert not flat.any()
+    assert torch.allclose(a, ra, rtol=1e-5, atol=1e-7) and torch.allclose(b, rb, rtol=1e-5, atol=1e-7)
+    before = a.detach().clone()
+    va += float("inf")
+    opt.step()                                               # non-finite: step skipped, scale backed off, buffer still cleared
+    assert not flat.any() and torch.equal(a.detach(), before) and float(opt.scale) == 2.0
