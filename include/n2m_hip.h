@@ -87,6 +87,13 @@ int n2m_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
                          int contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                          const float* nears, const float* fars, float* xyzs, float* dirs, float* ts,
                          int32_t* rays, int32_t* counter, const float* noises, void* stream);
+/* Pass 2 alone, into sample buffers of max_points rows: a ray whose (offset, count) range does not fit is not written
+ * (the reference's `if (point_index + num_steps > M) return`, raymarching.cu:417).  With it the write pass can be queued
+ * before the host has read the sample count back: buffers sized from the previous batch, exact re-run on overflow. */
+int n2m_march_rays_train_write(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, int contract,
+                               float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                               const float* nears, const float* fars, float* xyzs, float* dirs, float* ts,
+                               const int32_t* rays, const float* noises, uint32_t max_points, void* stream);
 
 /* raymarching.h:15  composite_rays_train_forward   kernel raymarching.cu:500-578.
  * sigmas [M], rgbs [M,3], ts [M,2], rays [N,2] -> weights [M], weights_sum [N], depth [N], image [N,3].

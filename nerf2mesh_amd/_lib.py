@@ -21,6 +21,7 @@ SIGNATURES = {
     "n2m_packbits_dev": [_vp, _u32, _vp, _vp, _vp],
     "n2m_flatten_rays": [_vp, _u32, _u32, _vp, _vp],
     "n2m_march_rays_train": [_vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "n2m_march_rays_train_write": [_vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     "n2m_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _int, _vp, _vp, _vp, _vp, _vp],
     "n2m_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _int, _vp, _vp, _vp],
     "n2m_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -135,13 +136,14 @@ def workspace(device, nbytes, slot=0):
 _SIDE_STREAMS = {}
 
 
-def side_stream(device, slot=1):
-    """A second stream per device for work that may overlap the main stream (created once, high priority is not requested)."""
+def side_stream(device, slot=1, priority=0):
+    """A second stream per device for work that may overlap the main stream (created once).  priority > 0 asks for the lowest
+    priority the device offers: its workgroups are dispatched only into slots the main stream leaves free."""
     import torch
     key = (device, slot)
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        st = torch.cuda.Stream(device=device, priority=int(os.environ.get("N2M_SIDE_PRIO", priority)))
         _SIDE_STREAMS[key] = st
     return st
 

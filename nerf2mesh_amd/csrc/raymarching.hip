@@ -266,7 +266,7 @@ march_train_wave_kernel(const float* __restrict__ rays_o, const float* __restric
                         float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                         const float* __restrict__ nears, const float* __restrict__ fars, float* __restrict__ xyzs,
                         float* __restrict__ dirs, float* __restrict__ ts, int32_t* __restrict__ rays,
-                        const float* __restrict__ noises) {
+                        const float* __restrict__ noises, uint32_t max_points) {
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);      // one wave per ray, 4 rays per workgroup
     const int lane = threadIdx.x & 63;
     if (n >= N) return;
@@ -277,7 +277,7 @@ march_train_wave_kernel(const float* __restrict__ rays_o, const float* __restric
     if (WRITE) {
         out = (size_t)(uint32_t)rays[2 * n];
         budget = (uint32_t)rays[2 * n + 1];
-        if (budget == 0) return;
+        if (budget == 0 || out + budget > (size_t)max_points) return;     // does not fit the sample buffers (raymarching.cu:417)
     }
     const float far = fars[n];
     float t_base = nears[n];
@@ -389,7 +389,7 @@ march_train_kernel(const float* __restrict__ rays_o, const float* __restrict__ r
                    float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                    const float* __restrict__ nears, const float* __restrict__ fars, float* __restrict__ xyzs,
                    float* __restrict__ dirs, float* __restrict__ ts, int32_t* __restrict__ rays,
-                   const float* __restrict__ noises) {
+                   const float* __restrict__ noises, uint32_t max_points) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     MarchCtx c;
@@ -399,6 +399,7 @@ march_train_kernel(const float* __restrict__ rays_o, const float* __restrict__ r
     if (WRITE) {
         const uint32_t off = (uint32_t)rays[2 * n];
         budget = (uint32_t)rays[2 * n + 1];
+        if ((size_t)off + budget > (size_t)max_points) return;
         px = xyzs + 3 * (size_t)off; pd = dirs + 3 * (size_t)off; pt = ts + 2 * (size_t)off;
     }
     const float far = fars[n];
@@ -816,10 +817,10 @@ extern "C" int n2m_flatten_rays(const int32_t* rays, uint32_t N, uint32_t M, int
     return 0;
 }
 
-extern "C" int n2m_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
-                                    int contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
-                                    const float* nears, const float* fars, float* xyzs, float* dirs, float* ts,
-                                    int32_t* rays, int32_t* counter, const float* noises, void* stream) {
+static int march_rays_train_impl(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                                 int contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                 const float* nears, const float* fars, float* xyzs, float* dirs, float* ts,
+                                 int32_t* rays, int32_t* counter, const float* noises, uint32_t max_points, void* stream) {
     N2M_NOTNULL(rays_o); N2M_NOTNULL(rays_d); N2M_NOTNULL(grid); N2M_NOTNULL(nears); N2M_NOTNULL(fars);
     N2M_NOTNULL(rays); N2M_NOTNULL(noises);
     N2M_REQUIRE(C >= 1 && H >= 1 && H <= 1024 && max_steps >= 1, N2M_EINVAL,
@@ -835,11 +836,11 @@ extern "C" int n2m_march_rays_train(const float* rays_o, const float* rays_d, co
             if (serial_march())
                 march_train_kernel<false><<<n2m_ceil_div(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
                                                                              max_steps, N, C, H, nears, fars, nullptr, nullptr,
-                                                                             nullptr, rays, noises);
+                                                                             nullptr, rays, noises, max_points);
             else
                 march_train_wave_kernel<false><<<n2m_ceil_div(N, 4), 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0,
                                                                                   dt_gamma, max_steps, N, C, H, nears, fars, nullptr,
-                                                                                  nullptr, nullptr, rays, noises);
+                                                                                  nullptr, nullptr, rays, noises, max_points);
             N2M_CHECK_LAUNCH();
         }
         const int rc = run_exclusive_scan(RayOffsetsOp{rays, counter}, N, s);
@@ -850,14 +851,33 @@ extern "C" int n2m_march_rays_train(const float* rays_o, const float* rays_d, co
         if (serial_march())
             march_train_kernel<true><<<n2m_ceil_div(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
                                                                         max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
-                                                                        noises);
+                                                                        noises, max_points);
         else
             march_train_wave_kernel<true><<<n2m_ceil_div(N, 4), 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
                                                                              max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
-                                                                             noises);
+                                                                             noises, max_points);
         N2M_CHECK_LAUNCH();
     }
     return 0;
+}
+
+extern "C" int n2m_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                                    int contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                    const float* nears, const float* fars, float* xyzs, float* dirs, float* ts,
+                                    int32_t* rays, int32_t* counter, const float* noises, void* stream) {
+    return march_rays_train_impl(rays_o, rays_d, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
+                                 counter, noises, 0xFFFFFFFFu, stream);
+}
+
+// Pass 2 into sample buffers of max_points rows: a ray whose range does not fit is not written (the reference's guard, :417).
+// Lets a caller issue the write pass BEFORE it has read the sample count back (buffers sized from the previous batch).
+extern "C" int n2m_march_rays_train_write(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                                          int contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                          const float* nears, const float* fars, float* xyzs, float* dirs, float* ts,
+                                          const int32_t* rays, const float* noises, uint32_t max_points, void* stream) {
+    N2M_NOTNULL(xyzs);
+    return march_rays_train_impl(rays_o, rays_d, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears, fars, xyzs, dirs, ts,
+                                 const_cast<int32_t*>(rays), nullptr, noises, max_points, stream);
 }
 
 extern "C" int n2m_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* ts,

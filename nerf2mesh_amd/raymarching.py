@@ -242,12 +242,15 @@ def compact_alive(rays_alive):
 # enqueues pass 1 and an asynchronous copy of the counter into pinned host memory; `march_rays_train_finish` waits for
 # that copy only (an event, normally long complete) and enqueues pass 2.  Results are identical to march_rays_train.
 class MarchTicket:
-    __slots__ = ("args", "rays", "counter", "noises", "host_count", "event", "keep")
+    __slots__ = ("args", "rays", "counter", "noises", "host_count", "event", "keep", "spec", "cap")
 
 
 @torch.no_grad()
 def march_rays_train_begin(rays_o, rays_d, bound, contract, density_bitfield, C, H, nears, fars, perturb=False, dt_gamma=0,
-                           max_steps=1024, noises=None):
+                           max_steps=1024, noises=None, expect_points=0):
+    """Pass 1 (count + offset scan) of march_rays_train, with the sample count on its way to the host; march_rays_train_finish
+    completes the call.  expect_points > 0: pass 2 is queued right behind it into buffers of that many rows (n2m_march_rays_train_write
+    skips rays that do not fit), so that finish() only has to slice them -- unless the batch turned out larger, then it re-runs."""
     rays_o = _f32c(_dev(rays_o)).view(-1, 3)
     rays_d = _f32c(_dev(rays_d)).view(-1, 3)
     bits = _dev(density_bitfield).contiguous()
@@ -266,6 +269,12 @@ def march_rays_train_begin(rays_o, rays_d, bound, contract, density_bitfield, C,
     L.call("n2m_march_rays_train", *t.args, None, None, None, _p(t.rays), _p(t.counter), _p(t.noises), L.stream())
     t.host_count = torch.empty(1, dtype=torch.int32, pin_memory=True)
     t.host_count.copy_(t.counter, non_blocking=True)
+    t.spec, t.cap = None, int(expect_points)
+    if t.cap > 0 and N > 0:
+        buf = torch.empty(t.cap, 8, dtype=torch.float32, device=dev)       # one allocation: xyzs | dirs | ts
+        xyzs, dirs, ts = buf.view(-1)[:3 * t.cap].view(-1, 3), buf.view(-1)[3 * t.cap:6 * t.cap].view(-1, 3), buf.view(-1)[6 * t.cap:].view(-1, 2)
+        L.call("n2m_march_rays_train_write", *t.args, _p(xyzs), _p(dirs), _p(ts), _p(t.rays), _p(t.noises), t.cap, L.stream())
+        t.spec = (xyzs, dirs, ts)
     t.event = torch.cuda.Event()
     t.event.record()
     return t
@@ -277,7 +286,10 @@ def march_rays_train_finish(t):
     M = int(t.host_count[0])
     rays_o = t.keep[0]
     dev = rays_o.device
-    torch.cuda.current_stream(dev).wait_event(t.event)      # pass 1 may have been issued on another stream
+    torch.cuda.current_stream(dev).wait_event(t.event)      # pass 1 (and a speculative pass 2) may have been issued on another stream
+    if t.spec is not None and M <= t.cap:
+        xyzs, dirs, ts = t.spec
+        return xyzs[:M], dirs[:M], ts[:M], t.rays
     xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
     dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
     ts = torch.empty(M, 2, dtype=torch.float32, device=dev)

@@ -6,6 +6,8 @@ One iteration = [every 16th: occupancy refresh] -> sample rays -> render (march,
 + specular reg) -> scaled backward -> [multi-GPU: gradient all-reduce] -> unscale -> in-place TV gradient -> Adam -> LR step.
 Rays come from nerf2mesh_amd.synthetic (no dataset ships with the container); everything stays on the device.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -69,6 +71,7 @@ class Stage0Trainer:
         self.fused_loss = True        # losses.photo_loss instead of the torch graph of nerf/utils.py:658-683
         self.pipeline = True          # issue march pass 1 of the next batch one step ahead (results are identical)
         self.overlap_march = True     # ... on a second stream, next to this step's backward + optimizer kernels (single-rank path)
+        self.early_march = os.environ.get("N2M_EARLY", "1") == "1"
         self._next = None
 
     @property
@@ -101,7 +104,11 @@ class Stage0Trainer:
                 self.sync.sync_rng_for_grid_update(self.global_step)
             model.update_extra_state()
         rays_o, rays_d, images = self.batch()
-        ticket = model.march_ahead(rays_o, rays_d, dt_gamma=opt.dt_gamma, perturb=True, max_steps=opt.max_steps) if self.pipeline else None
+        # sample buffers for the speculative write pass: a quarter above the last batch (adaptive_num_rays steers M towards
+        # opt.num_points, nerf/utils.py:796-797); a batch that still does not fit is re-marched exactly by finish()
+        expect = 0 if self.last_num_points <= 0 else ((int(1.25 * max(self.last_num_points, 1024)) + 1023) // 1024) * 1024
+        ticket = model.march_ahead(rays_o, rays_d, dt_gamma=opt.dt_gamma, perturb=True, max_steps=opt.max_steps,
+                                   expect_points=expect) if self.pipeline else None
         return rays_o, rays_d, images, ticket
 
     def _prepare_overlapped(self):
@@ -117,7 +124,7 @@ class Stage0Trainer:
         with torch.cuda.stream(side):
             nxt = self._prepare()
         rays_o, rays_d, images, ticket = nxt
-        for t in (rays_o, rays_d, images, ticket.rays, ticket.counter, ticket.noises) + tuple(ticket.keep):
+        for t in (rays_o, rays_d, images, ticket.rays, ticket.counter, ticket.noises) + tuple(ticket.keep) + tuple(ticket.spec or ()):
             if torch.is_tensor(t):
                 t.record_stream(main)          # allocated on the side stream, consumed on the main one
         return nxt
@@ -140,6 +147,23 @@ class Stage0Trainer:
         if opt.progressive_level:
             model.max_level = 4 + int(12 * min(1, self.global_step / (0.5 * opt.iters)))
         shading = "diffuse" if (self.global_step < opt.diffuse_step or opt.diffuse_only) else "full"
+
+        adapted = False
+        if self.overlap_march and self.early_march and self.pipeline and self.amp_adam and self.sync is None and ticket is not None \
+                and torch.device(self.device).type == "cuda" and self.global_step % opt.update_extra_interval != 0:
+            # The sample count of THIS batch is all the next batch waits for (adaptive_num_rays): read it now and put the next
+            # batch's ray generation + march on the side stream before this step's own kernels are queued.  They then run beside
+            # the forward pass instead of queueing up behind the field backward (one wave per SIMD, it shares the chip with nobody),
+            # the count is back long before the host needs it, and the host stays a step tail ahead of the GPU.  Same draws from
+            # the same generators in the same order as the serial schedule (bg_color above, then the batch): identical results.
+            from . import raymarching
+            ticket = raymarching.march_rays_train_finish(ticket)
+            M0 = ticket[0].shape[0]
+            self.last_num_points = M0
+            if opt.adaptive_num_rays and M0 > 0:                             # nerf/utils.py:796-797
+                self.num_rays = max(1, int(round((opt.num_points / M0) * self.num_rays)))
+            adapted = True
+            self._next = self._prepare_overlapped()
 
         out = model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, shading=shading, dt_gamma=opt.dt_gamma,
                            max_steps=opt.max_steps, ticket=ticket, blend_bg=not self.fused_loss)
@@ -167,7 +191,7 @@ class Stage0Trainer:
         self.last_num_points = M
         self.samples_seen += M
         self.rays_seen += N
-        if opt.adaptive_num_rays and M > 0:                              # nerf/utils.py:796-797
+        if opt.adaptive_num_rays and M > 0 and not adapted:              # nerf/utils.py:796-797
             self.num_rays = max(1, int(round((opt.num_points / M) * self.num_rays)))
 
         # TV regulariser (nerf/utils.py:812-821 adds it to the unscaled gradients after backward).  Fast path: hand it to the
@@ -191,7 +215,7 @@ class Stage0Trainer:
                          "mlp": dict(found_inf=o.found_inf, flagged=False, persistent_dw=len(self._mlp_params) == 7)}
             model.encoder.amp_request, model.encoder_color.amp_request, model.amp_request = self._amp["density"], self._amp["color"], self._amp["mlp"]
             if self.overlap_march and self.pipeline and self.sync is None and torch.device(self.device).type == "cuda" \
-                    and self.global_step % opt.update_extra_interval != 0:
+                    and self.global_step % opt.update_extra_interval != 0 and self._next is None:
                 self._next = self._prepare_overlapped()
             o.backward(loss, self.world)
             model.encoder.amp_request = model.encoder_color.amp_request = model.amp_request = None

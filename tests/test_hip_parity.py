@@ -162,6 +162,17 @@ def test_march_split_form_equals_single_call(be, oracle, scene):
     assert ref[0].shape[0] > 1000
     for x, y in zip(ref, got):
         assert torch.equal(x, y)
+    # speculative write pass (n2m_march_rays_train_write into buffers of expect_points rows, queued before the count is known):
+    # large enough -> finish() slices them; too small -> rays that do not fit are skipped by the kernel and finish() re-marches
+    M = ref[0].shape[0]
+    for cap, spec_used in ((M + 100, True), (M, True), (M - 1, False), (64, False)):
+        ticket = R.march_rays_train_begin(*a, True, 1 / 256, 1024, dev(be, noises), expect_points=cap)
+        canary = ticket.spec[0].new_full((1,), 0)            # keeps the buffers alive; over-capacity rays must not be written
+        got = R.march_rays_train_finish(ticket)
+        assert (got[0].data_ptr() == ticket.spec[0].data_ptr()) == spec_used
+        for x, y in zip(ref, got):
+            assert torch.equal(x, y)
+        del canary
 
 
 def test_march_counter_base_and_repeatability(be, oracle, scene):
