@@ -146,6 +146,14 @@ __device__ __forceinline__ void accum(_Float16& acc, float w, _Float16 g) {
     acc = (_Float16)((float)acc + (float)p);
 }
 
+// (__half)(w * g) of the reference's backward (gridencoder.cu:326): the fp32 product is ROUNDED to fp32, then to half.  Without the
+// barrier the compiler selects v_fma_mixlo_f16, which rounds the exact product once -- a different half in ~2^-14 of the cases.
+__device__ __forceinline__ _Float16 half_product(float w, float g) {
+    float p = w * g;
+    asm volatile("" : "+v"(p));
+    return (_Float16)p;
+}
+
 template <uint32_t D>
 __device__ __forceinline__ bool outside_unit_cube(const float (&x)[D]) {
     bool oob = false;
@@ -662,8 +670,8 @@ grid_backward_kernel(const T* __restrict__ grad, const float* __restrict__ input
 #pragma unroll
             for (uint32_t c = 0; c < C; c += 2) {
                 h2 val;
-                val.x = (_Float16)(w * (float)gr.v[c]);
-                val.y = (_Float16)(w * (float)gr.v[c + 1]);
+                val.x = half_product(w, (float)gr.v[c]);
+                val.y = half_product(w, (float)gr.v[c + 1]);
                 (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(dst + c), val);
             }
         } else {
@@ -1168,8 +1176,8 @@ bin_fill_kernel(const T* __restrict__ grad /*[L,Bstride,C], first sample of this
                 } else {
                     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                     h2 p;
-                    p.x = (_Float16)(w * (float)gr.v[0]);
-                    p.y = (_Float16)(w * (float)gr.v[1]);
+                    p.x = half_product(w, (float)gr.v[0]);
+                    p.y = half_product(w, (float)gr.v[1]);
                     bits = __builtin_bit_cast(uint32_t, p);
                     nz = (bits & 0x7FFF7FFFu) != 0u;
                 }
@@ -1275,6 +1283,7 @@ bin_fill_kernel(const T* __restrict__ grad /*[L,Bstride,C], first sample of this
 // both tables (C=1 then uses half of its LDS accumulator).  TV (template flag) rides on vertex 000 of the fp32 log.
 constexpr uint32_t kPairP = kBinAccBytes / 16u;      // 4096 rows
 constexpr uint32_t kPairTilesPerWg = 4;              // tiles one fill workgroup walks (next tile's inputs prefetched)
+constexpr uint32_t kPairMergeLevels = 9;             // levels (from the coarsest) whose same-cell runs of consecutive samples are merged
 
 // Entries of one sample in one level for bin_fill_pair_kernel.  IMODE 1: hashed power-of-two table, 2: dense table without wrap,
 // 0: generic Indexer::row.  ILV: interleaved partition map (dense levels spanning several partitions); IMODE 0 asks the PartMap.
@@ -1285,12 +1294,10 @@ struct PairCtx {
 };
 
 template <bool TV, int IMODE, bool ILV>
-__device__ __forceinline__ uint32_t pair_entries(const PairCtx& cx, const Indexer<3>& ix, const PartMap& pm, const float (&x)[3], float g1,
-                                                 float g2x, float g2y, float a1, float& vmax1, uint32_t (&e_pr)[8], uint32_t (&e_v1)[8],
-                                                 uint32_t (&e_v2)[8]) {
+__device__ __forceinline__ void pair_entries(const PairCtx& cx, const Indexer<3>& ix, const PartMap& pm, const float (&x)[3], float g1,
+                                             float g2x, float g2y, float a1, float& vmax1, uint32_t (&e_pr)[8], float (&f1)[8],
+                                             float (&f2x)[8], float (&f2y)[8], uint32_t (&cell)[3]) {
     constexpr uint32_t D = 3;
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    uint32_t cell[D];
     float frac[D], dfrac[D];
     locate<D>(x, cx.scale, cx.align_corners, cx.interp, cell, frac, dfrac);
     const uint32_t sy = IMODE == 1 ? kPrimes[1] : ix.stride[1], sz = IMODE == 1 ? kPrimes[2] : ix.stride[2];
@@ -1336,18 +1343,15 @@ __device__ __forceinline__ uint32_t pair_entries(const PairCtx& cx, const Indexe
         vmax1 = fmaxf(vmax1, (a1 <= 3.0e38f ? a1 : 1.0f) + (a <= 3.0e38f ? a : 1.0f));       // |w*g + tv| <= |g| + |tv|
     }
     const float wx[2] = {1 - frac[0], frac[0]}, wy[2] = {1 - frac[1], frac[1]}, wz[2] = {1 - frac[2], frac[2]};
-    uint32_t vmask = 0;
 #pragma unroll
     for (uint32_t corner = 0; corner < 8; ++corner) {
         const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
         const float w = (wx[i] * wy[j]) * wz[k];                     // forward's association
         float p1 = w * g1;
         if (TV && corner == 0) p1 += tvv;
-        h2 p2;
-        p2.x = (_Float16)(w * g2x);
-        p2.y = (_Float16)(w * g2y);
-        e_v1[corner] = __float_as_uint(p1);
-        e_v2[corner] = __builtin_bit_cast(uint32_t, p2);
+        f1[corner] = p1;
+        f2x[corner] = (float)half_product(w, g2x);                   // each product rounded to half like the reference (:326)
+        f2y[corner] = (float)half_product(w, g2y);
         uint32_t part_, rel_;
         const uint32_t row = rows[corner];
         if constexpr (IMODE == 0) pm.split(row, part_, rel_);
@@ -1361,11 +1365,48 @@ __device__ __forceinline__ uint32_t pair_entries(const PairCtx& cx, const Indexe
             rel_ = row & ((1u << pm.log2p) - 1u);
         }
         e_pr[corner] = (part_ << 16) | rel_;
-        if (((e_v1[corner] << 1) | (e_v2[corner] & 0x7FFF7FFFu)) != 0u) vmask |= 1u << corner;
     }
-    return vmask;
 }
 
+// Samples that follow each other along a ray fall into the SAME cell of a coarse level (a 2^18-sample batch of the lego scene:
+// ~16 per cell at level 0, still ~2 at level 8), i.e. they update the same eight rows.  Lanes are consecutive samples, so such a
+// run of lanes is reduced to ONE entry per vertex before anything is sorted, logged or accumulated: a segmented inclusive scan
+// over the 16-lane DPP rows (row_shr 1, 2, 4, 8), the last lane of a run keeps the sums.  Halves the update log of the whole
+// batch.  The partial sums are fp32 (table 2: of the half-rounded products), rounded once more when the entry is packed.
+__device__ __forceinline__ float dpp_row_shr(float v, int d) {      // value of lane - d inside the 16-lane row, 0 beyond its start
+    int r;
+    const int i = __float_as_int(v);
+    switch (d) {
+        case 1: r = __builtin_amdgcn_update_dpp(0, i, 0x111, 0xF, 0xF, true); break;
+        case 2: r = __builtin_amdgcn_update_dpp(0, i, 0x112, 0xF, 0xF, true); break;
+        case 4: r = __builtin_amdgcn_update_dpp(0, i, 0x114, 0xF, 0xF, true); break;
+        default: r = __builtin_amdgcn_update_dpp(0, i, 0x118, 0xF, 0xF, true); break;
+    }
+    return __int_as_float(r);
+}
+// returns false for lanes whose entries were handed to a later lane of their run
+__device__ __forceinline__ bool merge_runs(bool inside, const uint32_t (&cell)[3], float (&f1)[8], float (&f2x)[8], float (&f2y)[8], uint32_t lane) {
+    const uint32_t key0 = inside ? cell[0] : 0xFFFFFFFFu;           // an outside lane never matches (and carries zeros)
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)key0, 0x111, 0xF, 0xF, false);
+    const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)cell[1], 0x111, 0xF, 0xF, false);
+    const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)cell[2], 0x111, 0xF, 0xF, false);
+    const bool same = inside && (lane & 15u) != 0u && p0 == key0 && p1 == cell[1] && p2 == cell[2];
+    const unsigned long long heads = __ballot(!same);               // bit i: lane i starts a run
+    const unsigned long long upto = heads & (~0ull >> (63u - lane));
+    const uint32_t dist = lane - (63u - (uint32_t)__builtin_clzll(upto));   // lanes between this one and the head of its run
+    const bool last = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
+    if (__builtin_popcountll(heads) == 64) return true;              // no run anywhere in this wave (wave-uniform)
+#pragma unroll
+    for (int d = 1; d <= 8; d <<= 1) {
+        const bool take = dist >= (uint32_t)d;
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) {
+            const float a = dpp_row_shr(f1[c], d), b = dpp_row_shr(f2x[c], d), e = dpp_row_shr(f2y[c], d);
+            if (take) { f1[c] += a; f2x[c] += b; f2y[c] += e; }
+        }
+    }
+    return last;
+}
 
 template <bool TV>
 __global__ void __launch_bounds__(1024)
@@ -1374,7 +1415,8 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
                      uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max /*[2][32]*/,
                      uint32_t* __restrict__ directory, uint16_t* __restrict__ log_rel, uint32_t* __restrict__ log_v1,
                      uint32_t* __restrict__ log_v2, float* __restrict__ found_inf, float in_scale, float in_offset,
-                     float* __restrict__ clear1, _Float16* __restrict__ clear2, uint32_t clear_mask1, uint32_t clear_mask2) {
+                     float* __restrict__ clear1, _Float16* __restrict__ clear2, uint32_t clear_mask1, uint32_t clear_mask2,
+                     uint32_t merge_levels) {
     constexpr uint32_t D = 3;
     constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -1438,8 +1480,13 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
         request(tile + gridDim.x);                       // next tile's inputs are in flight while this one is processed
 
         uint32_t e_pr[8], e_v1[8], e_v2[8], e_slot[8];    // e_pr = partition << 16 | row in partition (rel < 4096, parts <= 2048)
+        float f1[8], f2x[8], f2y[8];
+        uint32_t cell[D] = {0u, 0u, 0u};
         uint32_t vmask = 0;
-        if (!outside_unit_cube<D>(x)) {
+        const bool inside = !outside_unit_cube<D>(x);
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) { f1[c] = 0.f; f2x[c] = 0.f; f2y[c] = 0.f; e_pr[c] = 0u; }
+        if (inside) {
             const float g2x = (float)g2.x, g2y = (float)g2.y;
             const float a1 = fabsf(g1), a2 = fmaxf(fabsf(g2x), fabsf(g2y));
             vmax1 = fmaxf(vmax1, a1 <= 3.0e38f ? a1 : 1.0f);
@@ -1449,10 +1496,32 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
             if (bad2) vmax2 = fmaxf(vmax2, 1.0f);
             const PairCtx cx{tv, tv.table ? tv.table + (size_t)plan.row0[level] : nullptr, scale, lv.resolution[level], align_corners, interp};
             // one straight-line body per index mode (wave-uniform per level) instead of three-way branches around every row
-            if (fast_hash) vmask = pair_entries<TV, 1, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, e_v1, e_v2);
-            else if (fast_dense && parts > 1u) vmask = pair_entries<TV, 2, true>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, e_v1, e_v2);
-            else if (fast_dense) vmask = pair_entries<TV, 2, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, e_v1, e_v2);
-            else vmask = pair_entries<TV, 0, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, e_v1, e_v2);
+            if (fast_hash) pair_entries<TV, 1, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell);
+            else if (fast_dense && parts > 1u) pair_entries<TV, 2, true>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell);
+            else if (fast_dense) pair_entries<TV, 2, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell);
+            else pair_entries<TV, 0, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell);
+        }
+        bool keep = inside;
+        if (level < merge_levels) {                                    // block-uniform
+            keep = merge_runs(inside, cell, f1, f2x, f2y, lane) && inside;
+            if (keep) {                                                  // a run's sum can exceed every one of its terms
+                float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                for (uint32_t c = 0; c < 8; ++c) { m1 = fmaxf(m1, fabsf(f1[c])); m2 = fmaxf(m2, fmaxf(fabsf(f2x[c]), fabsf(f2y[c]))); }
+                vmax1 = fmaxf(vmax1, m1 <= 3.0e38f ? m1 : 1.0f);
+                vmax2 = fmaxf(vmax2, m2 <= 65504.0f ? m2 : 65504.0f);
+                // a sum of finite terms that leaves the range of its type: the reference's half atomicAdd overflows on it just the same
+                if ((!(m1 <= 3.0e38f) || !(m2 <= 65504.0f)) && found_inf) *found_inf = 1.0f;
+            }
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) {
+            h2 p2;
+            p2.x = (_Float16)f2x[c];
+            p2.y = (_Float16)f2y[c];
+            e_v1[c] = __float_as_uint(f1[c]);
+            e_v2[c] = __builtin_bit_cast(uint32_t, p2);
+            if (keep && ((e_v1[c] << 1) | (e_v2[c] & 0x7FFF7FFFu)) != 0u) vmask |= 1u << c;
         }
 
         // slot of every entry inside its partition's run of this tile
@@ -2010,15 +2079,16 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
             N2M_HIP(hipMemsetAsync(table1 + t0, 0, (t1 - t0) * sizeof(float), s));
             N2M_HIP(hipMemsetAsync(table2 + t0 * 2u, 0, (t1 - t0) * 2u * sizeof(_Float16), s));
         }
+        static const uint32_t merge_levels = getenv("N2M_BIN_MERGE_LEVELS") ? (uint32_t)atoi(getenv("N2M_BIN_MERGE_LEVELS")) : kPairMergeLevels;
         const dim3 grid((lay.plan.tiles + kPairTilesPerWg - 1) / kPairTilesPerWg, max_level);     // each workgroup walks ~kPairTilesPerWg tiles
         if (tv.table)
             bin_fill_pair_kernel<true><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
                                                                              directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset, ow ? table1 : nullptr,
-                                                                             ow ? table2 : nullptr, cm1, cm2);
+                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels);
         else
             bin_fill_pair_kernel<false><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
                                                                               directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset, ow ? table1 : nullptr,
-                                                                             ow ? table2 : nullptr, cm1, cm2);
+                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels);
         N2M_CHECK_LAUNCH();
         const uint32_t items = lay.plan.item_prefix[max_level];
         const uint32_t nb = items < 4096u ? items : 4096u;

@@ -646,7 +646,7 @@ def test_grid_backward_binned_pair_equals_two_calls(be, with_tv):
     assert binned_backward(e1, d1, x, b1, 16, tv=tv) and binned_backward(e2, d2, x, b2, 16)
     np.testing.assert_allclose(a1.cpu().numpy(), b1.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(b1.abs().max()))
     np.testing.assert_allclose(a2.float().cpu().numpy(), b2.float().cpu().numpy(), rtol=2e-3, atol=2e-3 * float(b2.float().abs().max()))
-    for l in range(16):
+    for l in range(9, 16):                           # below level 9 the shared fill merges same-cell runs first (fp32 partial sums)
         if offs[l + 1] - offs[l] == 2 ** 19:
             sl = slice(offs[l], offs[l + 1])
             assert torch.equal(a1[sl], b1[sl]) and torch.equal(a2[sl], b2[sl])
@@ -724,6 +724,51 @@ def test_grid_backward_binned_pair_overwrite_mode(be, B, max_level, with_tv):
             assert np.array_equal(a1[sl][ok], b1[sl][ok]) and np.array_equal(a2[sl][ok], b2[sl][ok])
     top = offs[max_level] if B else 0
     assert not b1[top:].any() and not b2[top:].any()
+
+
+@pytest.mark.parametrize("with_tv", [False, True])
+def test_grid_backward_binned_pair_merges_runs_along_rays(be, oracle, with_tv):
+    """Consecutive samples of a ray share their cell on the coarse levels; the shared fill reduces such runs of lanes to one entry per
+    vertex (segmented DPP scan) before sorting.  Inputs: points marching along rays, 5..40 per ray, so that runs start and end
+    anywhere in the 16-lane rows.  Checked against the oracle (no merging) for both tables, and for run-to-run bit-reproducibility."""
+    torch = be["torch"]
+    from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward_pair
+    rng = np.random.default_rng(21)
+    pts = []
+    while sum(len(p) for p in pts) < 30000:
+        o = rng.random(3) * 0.6 + 0.2
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        n = int(rng.integers(5, 41))
+        t = np.arange(n)[:, None] * 0.0017 * rng.uniform(0.5, 2.0)
+        pts.append((o + t * d).astype(np.float32))
+    x = np.clip(np.concatenate(pts), -0.05, 1.05).astype(np.float32)          # a few leave the cube: they break runs
+    B = x.shape[0]
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    e2 = GridEncoder(level_dim=2, desired_resolution=2048).cuda()
+    offs = np.asarray(e1.host_offsets, np.int32)
+    S = float(np.log2(e1.per_level_scale))
+    d1 = rng.normal(size=(16, B, 1)).astype(np.float32)
+    d2 = rng.normal(size=(16, B, 2)).astype(np.float16)
+    emb1 = ((rng.random((int(offs[-1]), 1), dtype=np.float32) * 2 - 1) * 1e-2)
+    tv = (dev(be, emb1), 1e-3, 1e-3, 1.0, None) if with_tv else None
+    outs = []
+    for _ in range(2):
+        a1 = torch.full((int(offs[-1]), 1), 9.0, device="cuda"); a2 = torch.full((int(offs[-1]), 2), 9.0, device="cuda", dtype=torch.float16)
+        assert binned_backward_pair(e1, e2, dev(be, d1), dev(be, d2), dev(be, x), a1, a2, 16, tv=tv, overwrite=True)
+        outs.append((a1, a2))
+    for l in range(16):                                  # single-owner partitions: identical bits run to run
+        if offs[l + 1] - offs[l] == 2 ** 19:
+            sl = slice(int(offs[l]), int(offs[l + 1]))
+            assert torch.equal(outs[0][0][sl], outs[1][0][sl]) and torch.equal(outs[0][1][sl], outs[1][1][sl])
+    o1 = oracle.grid_encode_backward(d1, x, np.zeros((int(offs[-1]), 1), np.float32), offs, S, 16, 16)
+    if with_tv:
+        oracle.grad_total_variation(x, emb1, o1, offs, 1e-3, S, 16, 0, False)
+    o2 = oracle.grid_encode_backward(d2, x, np.zeros((int(offs[-1]), 2), np.float16), offs, S, 16, 16)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), o1, rtol=1e-4, atol=1e-5 * np.abs(o1).max())
+    np.testing.assert_allclose(outs[0][1].float().cpu().numpy(), o2.astype(np.float32), rtol=3e-2, atol=3e-2 * np.abs(o2).max())
+    for l in (0, 3, 8, 15):                              # column sums: nothing lost or counted twice by the merge
+        sl = slice(int(offs[l]), int(offs[l + 1]))
+        np.testing.assert_allclose(outs[0][0][sl].double().sum().item(), o1[sl].astype(np.float64).sum(), rtol=1e-4, atol=1e-4 * np.abs(d1[l]).sum())
 
 
 def test_grad_total_variation_binned(be, oracle):
