@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured floa
 # device kernels behind each library entry point, for the PMC traffic lookup: (substrings of the kernel names, how their
 # per-launch byte counts combine into one call of the entry point)
 _DEVICE_KERNELS = {"grid_encode_backward": (("bin_fill_pair_kernel", "bin_accumulate_kernel"), "sum"),     # one call = fill + both accumulates
-                   "grid_encode_forward": (("grid_forward3_pair_kernel",), "sum"),                           # one call = both tables
+                   "grid_encode_forward": (("grid_forward3_packed_kernel",), "sum"),                         # one call = both tables (packed copy)
                    "mlp_backward": (("field_backward_kernel",), "mean"), "mlp_forward": (("field_forward_kernel",), "mean"),
                    "march_rays_train_count": (("march_train_wave_kernelILb0", "march_train_wave_kernel<false>"), "mean"),
                    "march_rays_train_write": (("march_train_wave_kernelILb1", "march_train_wave_kernel<true>"), "mean")}

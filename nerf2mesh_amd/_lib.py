@@ -143,7 +143,7 @@ def side_stream(device, slot=1, priority=0):
     key = (device, slot)
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device, priority=int(os.environ.get("N2M_SIDE_PRIO", priority)))
+        st = torch.cuda.Stream(device=device, priority=int(priority))
         _SIDE_STREAMS[key] = st
     return st
 

@@ -261,15 +261,12 @@ __device__ __forceinline__ LaneEval eval_candidate(const MarchCtx& c, float t) {
 }
 
 template <bool WRITE>
-__global__ void __launch_bounds__(256)
-march_train_wave_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
+__device__ __forceinline__ void march_train_one_ray(uint32_t n, int lane, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                        const uint8_t* __restrict__ grid,
                         float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                         const float* __restrict__ nears, const float* __restrict__ fars, float* __restrict__ xyzs,
                         float* __restrict__ dirs, float* __restrict__ ts, int32_t* __restrict__ rays,
                         const float* __restrict__ noises, uint32_t max_points) {
-    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);      // one wave per ray, 4 rays per workgroup
-    const int lane = threadIdx.x & 63;
-    if (n >= N) return;
     MarchCtx c;
     march_ctx_init(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, 0.0f, grid, bound, contract, dt_gamma, max_steps, C, H);
     uint32_t budget = max_steps;
@@ -381,6 +378,23 @@ march_train_wave_kernel(const float* __restrict__ rays_o, const float* __restric
         t_base = t_next_base;
     }
     if (!WRITE && lane == 0) rays[2 * n + 1] = (int32_t)kept;
+}
+
+// One wave per ray, four waves per workgroup; a workgroup walks rays blockIdx.x*4 + wave, += 4*gridDim.x.  With a grid that covers N
+// this is one ray per wave; a SMALLER grid turns the kernel into a few resident waves per SIMD that work through the batch beside
+// whatever else is running (the pass is queued on a second stream next to the training step's own kernels; a full-size grid
+// slows an MFMA kernel it overlaps ~3.7x, measured -- but see march_grid: capping it cost more than it saved).
+template <bool WRITE>
+__global__ void __launch_bounds__(256)
+march_train_wave_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
+                        float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                        const float* __restrict__ nears, const float* __restrict__ fars, float* __restrict__ xyzs,
+                        float* __restrict__ dirs, float* __restrict__ ts, int32_t* __restrict__ rays,
+                        const float* __restrict__ noises, uint32_t max_points) {
+    const int lane = threadIdx.x & 63;
+    for (uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6); n < N; n += gridDim.x * 4)
+        march_train_one_ray<WRITE>(n, lane, rays_o, rays_d, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
+                                   noises, max_points);
 }
 
 template <bool WRITE>
@@ -817,6 +831,15 @@ extern "C" int n2m_flatten_rays(const int32_t* rays, uint32_t N, uint32_t M, int
     return 0;
 }
 
+// workgroups of the wave marcher: one ray per wave, or N2M_MARCH_GRID_CAP workgroups walking the batch (see the kernel)
+static uint32_t march_grid(uint32_t N) {
+    // measurement switch: capping the grid did not pay on MI355X (256 / 512 / 1024 / 2048 workgroups: 1.21 / 1.05 / 0.99 / 0.97 ms per
+    // training step against 0.98 uncapped) -- the overlapped pass then ends up on the critical path
+    static const uint32_t cap = getenv("N2M_MARCH_GRID_CAP") ? (uint32_t)atoi(getenv("N2M_MARCH_GRID_CAP")) : 0u;
+    const uint32_t full = n2m_ceil_div(N, 4);
+    return cap && cap < full ? cap : full;
+}
+
 static int march_rays_train_impl(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                                  int contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                  const float* nears, const float* fars, float* xyzs, float* dirs, float* ts,
@@ -838,7 +861,7 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
                                                                              max_steps, N, C, H, nears, fars, nullptr, nullptr,
                                                                              nullptr, rays, noises, max_points);
             else
-                march_train_wave_kernel<false><<<n2m_ceil_div(N, 4), 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0,
+                march_train_wave_kernel<false><<<march_grid(N), 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0,
                                                                                   dt_gamma, max_steps, N, C, H, nears, fars, nullptr,
                                                                                   nullptr, nullptr, rays, noises, max_points);
             N2M_CHECK_LAUNCH();
@@ -853,7 +876,7 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
                                                                         max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
                                                                         noises, max_points);
         else
-            march_train_wave_kernel<true><<<n2m_ceil_div(N, 4), 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
+            march_train_wave_kernel<true><<<march_grid(N), 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
                                                                              max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
                                                                              noises, max_points);
         N2M_CHECK_LAUNCH();

@@ -71,7 +71,7 @@ class Stage0Trainer:
         self.fused_loss = True        # losses.photo_loss instead of the torch graph of nerf/utils.py:658-683
         self.pipeline = True          # issue march pass 1 of the next batch one step ahead (results are identical)
         self.overlap_march = True     # ... on a second stream, next to this step's backward + optimizer kernels (single-rank path)
-        self.early_march = os.environ.get("N2M_EARLY", "1") == "1"
+        self.early_march = True       # ... and already at the start of the step (A/B switch; measured equal to issuing it before the backward)
         self._next = None
 
     @property
