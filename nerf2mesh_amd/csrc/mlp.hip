@@ -52,6 +52,7 @@ constexpr int ALL_W_HALVES = O_P0T + 32 * P_P0T;
 constexpr int TILE_PITCH = 68;                                   // per-wave transpose tiles [32 samples][64 + 4]
 constexpr int TILE_HALVES = 32 * TILE_PITCH;
 constexpr int BWD_HALVES = ALL_W_HALVES + 4 * 2 * TILE_HALVES;   // 4 waves x (X tile + dY tile)
+constexpr int BWD_PC_HALVES = ALL_W_HALVES + 4 * 4 * TILE_HALVES; // producer/consumer form: 4 pairs x 2 buffers x (X tile + dY tile)
 
 // logical input feature k -> column of the nn.Linear weight (or -1 for padding)
 __device__ __forceinline__ int col_color0(int k) { return k < 32 ? 3 + k : (k < 35 ? k - 32 : -1); }
@@ -92,24 +93,41 @@ __device__ __forceinline__ f16x zero16() {
     return z;
 }
 
-// regs 4q..4q+3 of an accumulator -> fp16 fragment, with ReLU (the next layer's B operand for K-block q)
+// regs 4q..4q+3 of an accumulator -> fp16 fragment, with ReLU (the next layer's B operand for K-block q).
+// Packed forms: two conversions are one v_cvt_pk_f16_f32; ReLU on the half BIT PATTERNS is a signed 16-bit max with 0 (negative
+// halves, -0 included, are negative integers; NaN passes through like torch's relu); the backward's "activation was positive" test
+// is the sign smear of the negated pattern.  7 VALU instructions per pair of values became 2 (forward) / 4 (backward mask).
+typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
+typedef short s2v_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u2v_t __attribute__((ext_vector_type(2)));
+typedef float f2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk(float a, float b) {
+    const f2v_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2v_t));       // one fptrunc <2 x float>: v_cvt_pk_f16_f32
+}
+__device__ __forceinline__ uint32_t relu_pk(uint32_t hh) {
+    const s2v_t z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2v_t, hh), z));
+}
+__device__ __forceinline__ uint32_t positive_mask(uint32_t relu_out) {     // 0xFFFF per half that is > 0 (input: a ReLU output, never negative)
+    const s2v_t z = {0, 0};
+    return __builtin_bit_cast(uint32_t, (z - __builtin_bit_cast(s2v_t, relu_out)) >> 15);
+}
 template <int Q>
 __device__ __forceinline__ h4 relu_pack(const f16x& d) {
-    h4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const _Float16 v = (_Float16)d[4 * Q + i];
-        r[i] = v > (_Float16)0 ? v : (_Float16)0;
-    }
-    return r;
+    u2v_t r;
+    r.x = relu_pk(cvt_pk(d[4 * Q], d[4 * Q + 1]));
+    r.y = relu_pk(cvt_pk(d[4 * Q + 2], d[4 * Q + 3]));
+    return __builtin_bit_cast(h4, r);
 }
 // gradient fragment: round to fp16 and apply the ReLU mask of the forward fragment
 template <int Q>
 __device__ __forceinline__ h4 mask_pack(const f16x& d, const h4& fwd) {
-    h4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = fwd[i] > (_Float16)0 ? (_Float16)d[4 * Q + i] : (_Float16)0;
-    return r;
+    const u2v_t f = __builtin_bit_cast(u2v_t, fwd);
+    u2v_t r;
+    r.x = cvt_pk(d[4 * Q], d[4 * Q + 1]) & positive_mask(f.x);
+    r.y = cvt_pk(d[4 * Q + 2], d[4 * Q + 3]) & positive_mask(f.y);
+    return __builtin_bit_cast(h4, r);
 }
 
 __device__ __forceinline__ float sigmoid_h(float pre_acc) {
@@ -565,6 +583,271 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
+// Producer / consumer form of the backward: eight waves per workgroup = four PAIRS.  The producer wave of a pair runs the forward
+// recompute and the activation-gradient chain of its 32-sample tile and, stage by stage, leaves the (X, dY) tiles of one layer in
+// LDS; the consumer wave holds the fp32 weight-gradient accumulators (224 registers) and contracts them over the samples one stage
+// behind (two tile buffers per pair, ONE workgroup barrier per stage).  Neither role needs more than 256 registers, so two waves
+// share a SIMD and each hides the other's MFMA -> convert -> MFMA dependency stalls -- the single-wave kernel above spends 40 % of its
+// cycles in issue stalls with nobody to switch to.  Same arithmetic in the same order per tile: results are bit-identical per
+// accumulator; only the order in which tiles reach an accumulator (hence fp32 rounding of dW) differs with the tile-to-wave map.
+template <bool DO_DENSITY, bool DO_COLOR>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) field_backward_pc_kernel(FieldArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    if (DO_DENSITY) {
+        stage_w(lds + O_S0, P_S0, a.w[0], 32, 19, 32, 24, PERM_SIGMA0);
+        stage_w(lds + O_S1, P_S1, a.w[1], 1, 32, 32, 32, PERM_PLAIN);
+        stage_wt(lds + O_S1T, P_S1T, a.w[1], 1, 32, 32, 8, PERM_PLAIN);
+        stage_wt(lds + O_S0T, P_S0T, a.w[0], 32, 19, 32, 32, PERM_SIGMA0);
+    }
+    if (DO_COLOR) {
+        stage_w(lds + O_C0, P_C0, a.w[2], 64, 35, 64, 40, PERM_COLOR0);
+        stage_w(lds + O_C1, P_C1, a.w[3], 64, 64, 64, 64, PERM_PLAIN);
+        stage_w(lds + O_C2, P_C2, a.w[4], 6, 64, 32, 64, PERM_PLAIN);
+        stage_wt(lds + O_C2T, P_C2T, a.w[4], 6, 64, 64, 8, PERM_PLAIN);
+        stage_wt(lds + O_C1T, P_C1T, a.w[3], 64, 64, 64, 64, PERM_PLAIN);
+        stage_wt(lds + O_C0T, P_C0T, a.w[2], 64, 35, 64, 64, PERM_COLOR0);
+        if (a.shading != 0) {
+            stage_w(lds + O_P0, P_P0, a.w[5], 32, 6, 32, 8, PERM_PLAIN);
+            stage_w(lds + O_P1, P_P1, a.w[6], 3, 32, 32, 32, PERM_PLAIN);
+            stage_wt(lds + O_P1T, P_P1T, a.w[6], 3, 32, 32, 8, PERM_PLAIN);
+            stage_wt(lds + O_P0T, P_P0T, a.w[5], 32, 6, 32, 32, PERM_PLAIN);
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, n = lane & 31, g = lane >> 5, wid = threadIdx.x >> 6;
+    const int pair = wid & 3;
+    const bool producer = wid < 4;
+    // stage st of the pair uses buffer st & 1: X tile then dY tile
+    _Float16* const tbase = lds + ALL_W_HALVES + pair * 4 * TILE_HALVES;
+    auto TX = [&](uint32_t st) { return tbase + (st & 1u) * 2 * TILE_HALVES; };
+    auto TY = [&](uint32_t st) { return tbase + (st & 1u) * 2 * TILE_HALVES + TILE_HALVES; };
+    const uint32_t n_tiles = (a.M + 31) / 32;
+    const size_t Mz = a.M;
+    uint32_t st = 0;                 // running stage counter, identical in both waves of a pair
+
+    // weight-gradient accumulators, fp32, live for the whole launch
+    f16x gS0[1][1] = {{zero16()}}, gS1[1][1] = {{zero16()}};
+    f16x gC0[2][2], gC1[2][2], gC2[1][2], gP0[1][1] = {{zero16()}}, gP1[1][1] = {{zero16()}};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { gC0[i][j] = zero16(); gC1[i][j] = zero16(); gC2[0][j] = zero16(); }
+
+    if (producer)
+    for (uint32_t base = blockIdx.x * 4; base < n_tiles; base += gridDim.x * 4) {
+        const uint32_t tile = base + pair;      // may lie beyond the last tile: all lanes invalid, the stages still run (barriers)
+        const uint32_t s = tile * 32 + n;
+        const bool valid = s < a.M;
+        if (DO_DENSITY) {   // --------------------------------------------------------------------------- density net
+            h4 b0[3];
+            load_density_inputs(a, s, valid, g, b0);
+            f16x d = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) d = MFMA(ld_a(lds + O_S0, P_S0, 0, kb, lane), b0[kb], d);
+            const h4 b1[4] = {relu_pack<0>(d), relu_pack<1>(d), relu_pack<2>(d), relu_pack<3>(d)};
+            f16x o = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) o = MFMA(ld_a(lds + O_S1, P_S1, 0, kb, lane), b1[kb], o);
+            // trunc_exp backward: g * exp(clamp(x, -15, 15)) (activation.py:13-17), then into the fp16 Linear backward
+            h4 dy1 = zero4();
+            if (valid && g == 0) {
+                const float pre = (float)(_Float16)o[0];
+                dy1[0] = (_Float16)(a.d_sigma[s] * expf(fminf(fmaxf(pre, -15.f), 15.f)));
+            }
+            // stage S1: dW1 = dy1^T x H1
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) { tile_put(TX(st), kb, b1[kb], lane); tile_put(TY(st), kb, kb == 0 ? dy1 : zero4(), lane); }
+            __syncthreads(); ++st;
+            // dH1 = W1^T dy1, masked
+            const f16x dh = MFMA(ld_a(lds + O_S1T, P_S1T, 0, 0, lane), dy1, zero16());
+            const h4 dy0[4] = {mask_pack<0>(dh, b1[0]), mask_pack<1>(dh, b1[1]), mask_pack<2>(dh, b1[2]), mask_pack<3>(dh, b1[3])};
+            // stage S0
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) { tile_put(TY(st), kb, dy0[kb], lane); tile_put(TX(st), kb, kb < 3 ? b0[kb] : zero4(), lane); }
+            __syncthreads(); ++st;
+            // dX0 = W0^T dH1 : rows 0..15 are d h1 -> level-major [16][M] fp32 (values carry fp16 precision like autocast)
+            f16x dx = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) dx = MFMA(ld_a(lds + O_S0T, P_S0T, 0, kb, lane), dy0[kb], dx);
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int row = 8 * (r >> 2) + 4 * g + (r & 3);
+                    a.d_h1[(size_t)row * Mz + s] = (float)(_Float16)dx[r];
+                }
+            }
+        }
+        if (DO_COLOR) {   // ---------------------------------------------------------------------------- colour + specular
+            h4 b0[5];
+            load_color_inputs(a, s, valid, g, b0);
+            f16x d1[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int kb = 0; kb < 5; ++kb) d1[mb] = MFMA(ld_a(lds + O_C0, P_C0, mb, kb, lane), b0[kb], d1[mb]);
+            const h4 b1[8] = {relu_pack<0>(d1[0]), relu_pack<1>(d1[0]), relu_pack<2>(d1[0]), relu_pack<3>(d1[0]),
+                              relu_pack<0>(d1[1]), relu_pack<1>(d1[1]), relu_pack<2>(d1[1]), relu_pack<3>(d1[1])};
+            f16x d2[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) d2[mb] = MFMA(ld_a(lds + O_C1, P_C1, mb, kb, lane), b1[kb], d2[mb]);
+            const h4 b2[8] = {relu_pack<0>(d2[0]), relu_pack<1>(d2[0]), relu_pack<2>(d2[0]), relu_pack<3>(d2[0]),
+                              relu_pack<0>(d2[1]), relu_pack<1>(d2[1]), relu_pack<2>(d2[1]), relu_pack<3>(d2[1])};
+            f16x d3 = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) d3 = MFMA(ld_a(lds + O_C2, P_C2, 0, kb, lane), b2[kb], d3);
+            const float q0 = sigmoid_h(d3[0]), q1 = sigmoid_h(d3[1]), q2 = sigmoid_h(d3[2]), q3 = sigmoid_h(d3[3]);
+
+            // upstream gradients (g = 0 lanes own sample s)
+            float gr = 0.f, gg = 0.f, gb = 0.f, es0 = 0.f, es1 = 0.f, es2 = 0.f;
+            if (valid && g == 0) {
+                gr = a.d_rgb[(size_t)s * 3]; gg = a.d_rgb[(size_t)s * 3 + 1]; gb = a.d_rgb[(size_t)s * 3 + 2];
+                if (a.d_specular && a.shading != 0) {
+                    es0 = a.d_specular[(size_t)s * 3]; es1 = a.d_specular[(size_t)s * 3 + 1]; es2 = a.d_specular[(size_t)s * 3 + 2];
+                }
+            }
+            float dq0 = 0.f, dq1 = 0.f, dq2 = 0.f, dq3 = 0.f;   // d geo rows 0..3 (g = 0) / rows 4,5 in dq0,dq1 (g = 1)
+            if (a.shading == 0) { dq0 = gr; dq1 = gg; dq2 = gb; }
+            else {
+                h4 bp = zero4();
+                if (g == 0) {
+                    if (valid) load_dir(a, s, bp);
+                    bp[3] = (_Float16)q3;
+                } else { bp[0] = (_Float16)q0; bp[1] = (_Float16)q1; }
+                const f16x p1 = MFMA(ld_a(lds + O_P0, P_P0, 0, 0, lane), bp, zero16());
+                const h4 bq[4] = {relu_pack<0>(p1), relu_pack<1>(p1), relu_pack<2>(p1), relu_pack<3>(p1)};
+                f16x p2 = zero16();
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) p2 = MFMA(ld_a(lds + O_P1, P_P1, 0, kb, lane), bq[kb], p2);
+                const float s0 = sigmoid_h(p2[0]), s1 = sigmoid_h(p2[1]), s2 = sigmoid_h(p2[2]);
+                float ts0 = es0, ts1 = es1, ts2 = es2;          // d loss / d specular, total
+                if (a.shading == 2) { ts0 += gr; ts1 += gg; ts2 += gb; }
+                else {   // clamp backward passes the gradient where 0 <= x <= 1
+                    const float t0 = (float)(_Float16)(s0 + q0), t1 = (float)(_Float16)(s1 + q1), t2 = (float)(_Float16)(s2 + q2);
+                    const float p0g = (t0 >= 0.f && t0 <= 1.f) ? gr : 0.f, p1g = (t1 >= 0.f && t1 <= 1.f) ? gg : 0.f,
+                                p2g = (t2 >= 0.f && t2 <= 1.f) ? gb : 0.f;
+                    ts0 += p0g; ts1 += p1g; ts2 += p2g;
+                    dq0 = p0g; dq1 = p1g; dq2 = p2g;
+                }
+                h4 dsp = zero4();                                // d specular_net output (pre-sigmoid), rows 0..2
+                if (g == 0) {
+                    dsp[0] = (_Float16)(ts0 * s0 * (1.f - s0)); dsp[1] = (_Float16)(ts1 * s1 * (1.f - s1)); dsp[2] = (_Float16)(ts2 * s2 * (1.f - s2));
+                }
+                // stage P1
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) { tile_put(TX(st), kb, bq[kb], lane); tile_put(TY(st), kb, kb == 0 ? dsp : zero4(), lane); }
+                __syncthreads(); ++st;
+                const f16x dhp = MFMA(ld_a(lds + O_P1T, P_P1T, 0, 0, lane), dsp, zero16());
+                const h4 dyp[4] = {mask_pack<0>(dhp, bq[0]), mask_pack<1>(dhp, bq[1]), mask_pack<2>(dhp, bq[2]), mask_pack<3>(dhp, bq[3])};
+                // stage P0
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) { tile_put(TY(st), kb, dyp[kb], lane); tile_put(TX(st), kb, kb == 0 ? bp : zero4(), lane); }
+                __syncthreads(); ++st;
+                f16x dxp = zero16();
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) dxp = MFMA(ld_a(lds + O_P0T, P_P0T, 0, kb, lane), dyp[kb], dxp);
+                // rows 3 (g=0, reg 3), 4 and 5 (g=1, regs 0,1) are d feat
+                if (g == 0) dq3 = (float)(_Float16)dxp[3];
+                else { dq0 = (float)(_Float16)dxp[0]; dq1 = (float)(_Float16)dxp[1]; }
+            }
+            // through the sigmoid of color_net's output
+            h4 dc = zero4();
+            if (g == 0) {
+                dc[0] = (_Float16)(dq0 * q0 * (1.f - q0)); dc[1] = (_Float16)(dq1 * q1 * (1.f - q1));
+                dc[2] = (_Float16)(dq2 * q2 * (1.f - q2)); dc[3] = (_Float16)(dq3 * q3 * (1.f - q3));
+            } else { dc[0] = (_Float16)(dq0 * q0 * (1.f - q0)); dc[1] = (_Float16)(dq1 * q1 * (1.f - q1)); }
+            if (!valid) dc = zero4();
+            // layer 3: dW = dc^T x H2 ; dH2 = W3^T dc
+            // stage C2
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) tile_put(TX(st), kb, b2[kb], lane);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) tile_put(TY(st), kb, kb == 0 ? dc : zero4(), lane);
+            __syncthreads(); ++st;
+            f16x e2[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) e2[mb] = MFMA(ld_a(lds + O_C2T, P_C2T, mb, 0, lane), dc, zero16());
+            const h4 dy2[8] = {mask_pack<0>(e2[0], b2[0]), mask_pack<1>(e2[0], b2[1]), mask_pack<2>(e2[0], b2[2]), mask_pack<3>(e2[0], b2[3]),
+                               mask_pack<0>(e2[1], b2[4]), mask_pack<1>(e2[1], b2[5]), mask_pack<2>(e2[1], b2[6]), mask_pack<3>(e2[1], b2[7])};
+            // layer 2: dW = dy2^T x H1 ; dH1 = W2^T dy2
+            // stage C1
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) { tile_put(TX(st), kb, b1[kb], lane); tile_put(TY(st), kb, dy2[kb], lane); }
+            __syncthreads(); ++st;
+            f16x e1[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) e1[mb] = MFMA(ld_a(lds + O_C1T, P_C1T, mb, kb, lane), dy2[kb], e1[mb]);
+            const h4 dy1[8] = {mask_pack<0>(e1[0], b1[0]), mask_pack<1>(e1[0], b1[1]), mask_pack<2>(e1[0], b1[2]), mask_pack<3>(e1[0], b1[3]),
+                               mask_pack<0>(e1[1], b1[4]), mask_pack<1>(e1[1], b1[5]), mask_pack<2>(e1[1], b1[6]), mask_pack<3>(e1[1], b1[7])};
+            // layer 1: dW = dy1^T x X0 ; d h2 = rows 0..31 of W1^T dy1
+            // stage C0
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) { tile_put(TY(st), kb, dy1[kb], lane); tile_put(TX(st), kb, kb < 5 ? b0[kb] : zero4(), lane); }
+            __syncthreads(); ++st;
+            f16x e0 = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) e0 = MFMA(ld_a(lds + O_C0T, P_C0T, 0, kb, lane), dy1[kb], e0);
+            if (valid) {   // rows (2l, 2l+1) = level l of the C=2 encoder -> [16][M][2] fp16
+                typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int row = 8 * (r >> 2) + 4 * g + (r & 3);      // even
+                    h2v v;
+                    v.x = (_Float16)e0[r]; v.y = (_Float16)e0[r + 1];
+                    *reinterpret_cast<h2v*>(a.d_h2 + ((size_t)(row >> 1) * Mz + s) * 2) = v;
+                }
+            }
+        }
+    }
+
+    else
+    for (uint32_t base = blockIdx.x * 4; base < n_tiles; base += gridDim.x * 4) {
+        // consumer: one barrier per stage (the pair's producer has filled buffer st & 1 by then), then the sample contraction
+        if (DO_DENSITY) {
+            __syncthreads(); dw_tile<1, 1>(gS1, TY(st), TX(st), lane); ++st;
+            __syncthreads(); dw_tile<1, 1>(gS0, TY(st), TX(st), lane); ++st;
+        }
+        if (DO_COLOR) {
+            if (a.shading != 0) {
+                __syncthreads(); dw_tile<1, 1>(gP1, TY(st), TX(st), lane); ++st;
+                __syncthreads(); dw_tile<1, 1>(gP0, TY(st), TX(st), lane); ++st;
+            }
+            __syncthreads(); dw_tile<1, 2>(gC2, TY(st), TX(st), lane); ++st;
+            __syncthreads(); dw_tile<2, 2>(gC1, TY(st), TX(st), lane); ++st;
+            __syncthreads(); dw_tile<2, 2>(gC0, TY(st), TX(st), lane); ++st;
+        }
+    }
+
+    // ---------------------------------------------------------------------------- reduce dW: registers -> LDS -> HBM
+    __syncthreads();
+    float* stage = reinterpret_cast<float*>(lds);        // weights are dead now; 64 x 64 floats fit in the weight area
+    auto reduce = [&](auto& acc, int out_pad, int in_pad, float* dW, int out, int in, int k_real, int perm) {
+        for (int i = threadIdx.x; i < out_pad * in_pad; i += blockDim.x) stage[i] = 0.f;
+        __syncthreads();
+        if (!producer) dw_to_lds(stage, in_pad, acc, lane);
+        __syncthreads();
+        dw_flush(dW, stage, in_pad, out, in, k_real, perm, a.found_inf);
+        __syncthreads();
+    };
+    if (DO_DENSITY) {
+        reduce(gS1, 32, 32, a.dw[1], 1, 32, 32, PERM_PLAIN);
+        reduce(gS0, 32, 32, a.dw[0], 32, 19, 19, PERM_SIGMA0);
+    }
+    if (DO_COLOR) {
+        reduce(gC2, 32, 64, a.dw[4], 6, 64, 64, PERM_PLAIN);
+        reduce(gC1, 64, 64, a.dw[3], 64, 64, 64, PERM_PLAIN);
+        reduce(gC0, 64, 64, a.dw[2], 64, 35, 35, PERM_COLOR0);
+        if (a.shading != 0) {
+            reduce(gP1, 32, 32, a.dw[6], 3, 32, 32, PERM_PLAIN);
+            reduce(gP0, 32, 32, a.dw[5], 32, 6, 6, PERM_PLAIN);
+        }
+    }
+}
+
 int check_field(const char* fn, const float* xyz, const float* h1, const float* const* w, bool density, int shading) {
     N2M_REQUIRE(shading >= 0 && shading <= 2, N2M_EINVAL, "%s: shading must be 0 (diffuse), 1 (full) or 2 (specular)", fn);
     N2M_REQUIRE(xyz, N2M_ENULL, "%s: xyz is NULL", fn);
@@ -631,6 +914,9 @@ extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const flo
         (void)hipFuncSetAttribute((const void*)field_backward_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_HALVES * 2);
         (void)hipFuncSetAttribute((const void*)field_backward_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_HALVES * 2);
         (void)hipFuncSetAttribute((const void*)field_backward_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_HALVES * 2);
+        (void)hipFuncSetAttribute((const void*)field_backward_pc_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_PC_HALVES * 2);
+        (void)hipFuncSetAttribute((const void*)field_backward_pc_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_PC_HALVES * 2);
+        (void)hipFuncSetAttribute((const void*)field_backward_pc_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_PC_HALVES * 2);
         attr_set = true;
     }
     FieldArgs a{};
@@ -640,6 +926,15 @@ extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const flo
     a.d_sigma = d_sigma; a.d_rgb = d_rgb; a.d_specular = d_specular; a.d_h1 = d_h1; a.d_h2 = (_Float16*)d_h2; a.found_inf = found_inf;
     hipStream_t s = (hipStream_t)stream;
     N2M_PROF(N2M_K_MLP_BWD, s, (double)M * (12 + 64 + 4 + 64 + (color ? 64 + 12 + 24 + 64 : 0)));
+    static const bool single_wave = getenv("N2M_FIELD_BWD_SINGLE") != nullptr;     // A/B switch: the one-wave-per-SIMD kernel
+    if (!single_wave) {
+        const size_t smem = (size_t)BWD_PC_HALVES * 2;
+        if (color && density) field_backward_pc_kernel<true, true><<<persistent_grid(M), 512, smem, s>>>(a);
+        else if (color) field_backward_pc_kernel<false, true><<<persistent_grid(M), 512, smem, s>>>(a);
+        else field_backward_pc_kernel<true, false><<<persistent_grid(M), 512, smem, s>>>(a);
+        N2M_CHECK_LAUNCH();
+        return 0;
+    }
     const size_t smem = (size_t)BWD_HALVES * 2;
     if (color && density) field_backward_kernel<true, true><<<persistent_grid(M), 256, smem, s>>>(a);
     else if (color) field_backward_kernel<false, true><<<persistent_grid(M), 256, smem, s>>>(a);
