@@ -242,7 +242,7 @@ def compact_alive(rays_alive):
 # enqueues pass 1 and an asynchronous copy of the counter into pinned host memory; `march_rays_train_finish` waits for
 # that copy only (an event, normally long complete) and enqueues pass 2.  Results are identical to march_rays_train.
 class MarchTicket:
-    __slots__ = ("args", "rays", "counter", "noises", "host_count", "event", "keep", "spec", "cap")
+    __slots__ = ("args", "rays", "counter", "noises", "host_count", "event", "done", "keep", "spec", "cap")
 
 
 @torch.no_grad()
@@ -269,14 +269,16 @@ def march_rays_train_begin(rays_o, rays_d, bound, contract, density_bitfield, C,
     L.call("n2m_march_rays_train", *t.args, None, None, None, _p(t.rays), _p(t.counter), _p(t.noises), L.stream())
     t.host_count = torch.empty(1, dtype=torch.int32, pin_memory=True)
     t.host_count.copy_(t.counter, non_blocking=True)
-    t.spec, t.cap = None, int(expect_points)
+    t.event = torch.cuda.Event()                       # the HOST waits for this one: the count is all it needs to go on
+    t.event.record()
+    t.spec, t.cap, t.done = None, int(expect_points), t.event
     if t.cap > 0 and N > 0:
         buf = torch.empty(t.cap, 8, dtype=torch.float32, device=dev)       # one allocation: xyzs | dirs | ts
         xyzs, dirs, ts = buf.view(-1)[:3 * t.cap].view(-1, 3), buf.view(-1)[3 * t.cap:6 * t.cap].view(-1, 3), buf.view(-1)[6 * t.cap:].view(-1, 2)
         L.call("n2m_march_rays_train_write", *t.args, _p(xyzs), _p(dirs), _p(ts), _p(t.rays), _p(t.noises), t.cap, L.stream())
         t.spec = (xyzs, dirs, ts)
-    t.event = torch.cuda.Event()
-    t.event.record()
+        t.done = torch.cuda.Event()                    # the consuming STREAM waits for this one (speculative pass 2 finished)
+        t.done.record()
     return t
 
 
@@ -286,7 +288,7 @@ def march_rays_train_finish(t):
     M = int(t.host_count[0])
     rays_o = t.keep[0]
     dev = rays_o.device
-    torch.cuda.current_stream(dev).wait_event(t.event)      # pass 1 (and a speculative pass 2) may have been issued on another stream
+    torch.cuda.current_stream(dev).wait_event(t.done)       # pass 1 (and a speculative pass 2) may have been issued on another stream
     if t.spec is not None and M <= t.cap:
         xyzs, dirs, ts = t.spec
         return xyzs[:M], dirs[:M], ts[:M], t.rays
