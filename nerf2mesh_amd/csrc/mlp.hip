@@ -199,6 +199,8 @@ __device__ __forceinline__ void load_color_inputs(const FieldArgs& a, uint32_t s
 // ================================================================================================== forward
 template <bool DO_DENSITY, bool DO_COLOR>
 __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
+    // These kernels run beside the next batch's marcher (second stream): their waves win the SIMD's issue arbitration
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     if (DO_DENSITY) {
         stage_w(lds + O_S0, P_S0, a.w[0], 32, 19, 32, 24, PERM_SIGMA0);
@@ -592,6 +594,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 // accumulator; only the order in which tiles reach an accumulator (hence fp32 rounding of dW) differs with the tile-to-wave map.
 template <bool DO_DENSITY, bool DO_COLOR>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) field_backward_pc_kernel(FieldArgs a) {
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     if (DO_DENSITY) {
         stage_w(lds + O_S0, P_S0, a.w[0], 32, 19, 32, 24, PERM_SIGMA0);
