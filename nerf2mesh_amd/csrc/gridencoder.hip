@@ -1416,7 +1416,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
                      uint32_t* __restrict__ directory, uint16_t* __restrict__ log_rel, uint32_t* __restrict__ log_v1,
                      uint32_t* __restrict__ log_v2, float* __restrict__ found_inf, float in_scale, float in_offset,
                      float* __restrict__ clear1, _Float16* __restrict__ clear2, uint32_t clear_mask1, uint32_t clear_mask2,
-                     uint32_t merge_levels) {
+                     uint32_t merge_levels, uint32_t groups_x) {
     constexpr uint32_t D = 3;
     constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -1433,13 +1433,25 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
     __shared__ uint32_t cnt2[2][kMaxPartsPerLevel];
     __shared__ uint32_t wave_tot[16], wave_max[2][16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    const uint32_t level = blockIdx.y;
+    // (tile group, level) of this workgroup.  Plain: blockIdx = (group, level).  XCD-aware (groups_x != 0, 1-D grid): workgroups are
+    // dealt round-robin to the 8 XCDs; XCD x works through the levels x, 15-x, ... one after the other (coarse paired with fine:
+    // equal work per XCD), so the table a level's TV stencil reads from (2 MB) stays in that XCD's 4 MB L2.
+    uint32_t level = blockIdx.y, group = blockIdx.x, n_groups = gridDim.x;
+    if (groups_x != 0u) {
+        const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+        const uint32_t slot = k / groups_x;                          // which of this XCD's levels
+        group = k - slot * groups_x;
+        n_groups = groups_x;
+        const uint32_t pairi = xcd + 8u * (slot >> 1);               // levels come in pairs (p, L-1-p)
+        level = (slot & 1u) ? pairi : plan.levels - 1u - pairi;
+        if (level >= plan.levels || pairi > plan.levels - 1u - pairi || ((slot & 1u) && pairi == plan.levels - 1u - pairi)) return;
+    }
     const uint32_t parts = plan.parts[level], size = plan.size[level];
     for (uint32_t i = tid; i < parts; i += 1024) { cnt2[0][i] = 0; cnt2[1][i] = 0; }
     // overwrite mode: levels whose partitions are split over several accumulate groups receive atomics and must start from zero;
     // this kernel is ordered before the accumulates, so its workgroups clear them (a slice each) instead of two extra memset launches
     if ((clear_mask1 | clear_mask2) >> level & 1u) {
-        const uint32_t per = (size + gridDim.x - 1) / gridDim.x, lo = min(size, blockIdx.x * per), hi = min(size, lo + per);
+        const uint32_t per = (size + n_groups - 1) / n_groups, lo = min(size, group * per), hi = min(size, lo + per);
         const size_t r0 = plan.row0[level];
         if (clear_mask1 >> level & 1u)
             for (uint32_t i = lo + tid; i < hi; i += 1024) clear1[r0 + i] = 0.0f;
@@ -1454,7 +1466,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
     float vmax1 = 0.0f, vmax2 = 0.0f;
 
     // inputs of the first tile
-    uint32_t tile = blockIdx.x;
+    uint32_t tile = group;
     float nx[D] = {2.f, 2.f, 2.f}, ng1 = 0.0f;
     h2 ng2 = {(_Float16)0, (_Float16)0};
     auto request = [&](uint32_t t) {
@@ -1471,13 +1483,13 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
     request(tile);
     __syncthreads();
 
-    for (uint32_t it = 0; tile < plan.tiles; tile += gridDim.x, ++it) {
+    for (uint32_t it = 0; tile < plan.tiles; tile += n_groups, ++it) {
         uint32_t* cnt = cnt2[it & 1u];
         uint32_t* cnt_next = cnt2[(it & 1u) ^ 1u];
         float x[D] = {nx[0], nx[1], nx[2]};
         const float g1 = ng1;
         const h2 g2 = ng2;
-        request(tile + gridDim.x);                       // next tile's inputs are in flight while this one is processed
+        request(tile + n_groups);                        // next tile's inputs are in flight while this one is processed
 
         uint32_t e_pr[8], e_v1[8], e_v2[8], e_slot[8];    // e_pr = partition << 16 | row in partition (rel < 4096, parts <= 2048)
         float f1[8], f2x[8], f2y[8];
@@ -2080,15 +2092,22 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
             N2M_HIP(hipMemsetAsync(table2 + t0 * 2u, 0, (t1 - t0) * 2u * sizeof(_Float16), s));
         }
         static const uint32_t merge_levels = getenv("N2M_BIN_MERGE_LEVELS") ? (uint32_t)atoi(getenv("N2M_BIN_MERGE_LEVELS")) : kPairMergeLevels;
-        const dim3 grid((lay.plan.tiles + kPairTilesPerWg - 1) / kPairTilesPerWg, max_level);     // each workgroup walks ~kPairTilesPerWg tiles
+        static const bool xcd_map = getenv("N2M_FILL_NO_XCD") == nullptr;       // A/B switch; measured 332 -> 311 us for fill + accumulates
+        dim3 grid((lay.plan.tiles + kPairTilesPerWg - 1) / kPairTilesPerWg, max_level);           // each workgroup walks ~kPairTilesPerWg tiles
+        uint32_t groups_x = 0;
+        if (xcd_map) {           // 1-D grid: 8 XCDs x ceil(levels / 8) level slots (rounded to pairs) x groups
+            groups_x = grid.x;
+            const uint32_t slots = 2u * ((max_level + 15u) / 16u);
+            grid = dim3(8u * slots * groups_x, 1);
+        }
         if (tv.table)
             bin_fill_pair_kernel<true><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
                                                                              directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset, ow ? table1 : nullptr,
-                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels);
+                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x);
         else
             bin_fill_pair_kernel<false><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
                                                                               directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset, ow ? table1 : nullptr,
-                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels);
+                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x);
         N2M_CHECK_LAUNCH();
         const uint32_t items = lay.plan.item_prefix[max_level];
         const uint32_t nb = items < 4096u ? items : 4096u;
