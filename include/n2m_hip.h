@@ -236,6 +236,9 @@ int n2m_grid_encode_forward_packed(const float* inputs, const void* packed, cons
  * their level geometry and are queried at the same inputs (nerf/network.py:92-108), so the index arithmetic and the partition
  * sort of the binned backward are done once and two update logs are written.  grad1 [L,B] f32, grad2 [L,B,2] f16, one
  * host_offsets for both tables; TV (tv_embeddings = the fp32 table) and found_inf as in n2m_grid_encode_backward_binned.
+ * Entries of consecutive samples that fall into the same cell of a coarse level (samples along a ray do) are summed in fp32 before
+ * they enter the exact fixed-point sum -- the log halves; the result differs from the unmerged sum by the rounding of those
+ * partial sums (fp16 table: of sums of the half-rounded products), far below the order noise of the reference's atomics.
  * overwrite = 0: the sums are added onto grad_embeddings1/2 (zero-filled by the caller, or running sums) like the reference's
  * atomicAdd (gridencoder.cu:324-334); overwrite = 1: the call DEFINES both tables completely (all host_offsets[L] rows, zeros
  * included) -- no zero-fill beforehand and no read-modify-write in the flush. */
