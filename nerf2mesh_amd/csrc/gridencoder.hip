@@ -433,6 +433,7 @@ __global__ void __launch_bounds__(256)
 grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __restrict__ packed, const int32_t* __restrict__ offsets,
                             float* __restrict__ out1, _Float16* __restrict__ out2, uint32_t B, uint32_t max_level, LevelTable lv,
                             uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t n_tiles, float in_scale, float in_offset) {
+    __builtin_amdgcn_s_setprio(3);      // runs beside the next batch's marcher (second stream): win the issue arbitration
     constexpr uint32_t D = 3;
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const uint32_t level = blockIdx.x / n_tiles, tile = blockIdx.x - level * n_tiles;
@@ -1417,6 +1418,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
                      uint32_t* __restrict__ log_v2, float* __restrict__ found_inf, float in_scale, float in_offset,
                      float* __restrict__ clear1, _Float16* __restrict__ clear2, uint32_t clear_mask1, uint32_t clear_mask2,
                      uint32_t merge_levels, uint32_t groups_x) {
+    __builtin_amdgcn_s_setprio(3);
     constexpr uint32_t D = 3;
     constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
