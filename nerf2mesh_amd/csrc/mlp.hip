@@ -110,8 +110,11 @@ __device__ __forceinline__ uint32_t relu_pk(uint32_t hh) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2v_t, hh), z));
 }
 __device__ __forceinline__ uint32_t positive_mask(uint32_t relu_out) {     // 0xFFFF per half that is > 0 (input: a ReLU output, never negative)
-    const s2v_t z = {0, 0};
-    return __builtin_bit_cast(uint32_t, (z - __builtin_bit_cast(s2v_t, relu_out)) >> 15);
+    // sign smear of the negated pattern, two packed instructions (written in C++ the compiler turns it back into two compares, two
+    // selects and a permute); op_sel_hi:[0,1] feeds the shift count 15 to both halves
+    uint32_t m;
+    asm("v_pk_sub_i16 %0, 0, %1\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=v"(m) : "v"(relu_out));
+    return m;
 }
 template <int Q>
 __device__ __forceinline__ h4 relu_pack(const f16x& d) {
