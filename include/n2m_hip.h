@@ -305,6 +305,8 @@ typedef struct {
                                             of a packed table (8 B rows); 3: parameter is a [rows,2] table, written as half2 to column 1 */
     int32_t clear_grad[N2M_ADAM_MAX];    /* 1: the (fp32) gradient is set to zero once read -- also when the step is skipped -- so that a
                                             producer adding into a persistent buffer needs no zero-fill launch of its own */
+    int32_t slot[N2M_ADAM_MAX];          /* 0: bias corrections bias[0..1] (one step count for all tensors); s in 1..N2M_ADAM_MAX: this
+                                            tensor's own count, corrections bias[2s..2s+1] (n2m_scaler_update_slots) */
     uint32_t count;
 } N2mAdamDesc;   /* HOST struct */
 int n2m_adam_step(const N2mAdamDesc* desc, double beta1, double beta2, float eps, const float* scale,
@@ -314,6 +316,12 @@ int n2m_adam_step(const N2mAdamDesc* desc, double beta1, double beta2, float eps
  * double) for the next step.  scale / growth_tracker / step / bias may be NULL. */
 int n2m_scaler_update(float* scale, float* growth_tracker, float* found_inf, float* step, float* bias, double beta1,
                       double beta2, float growth_factor, float backoff_factor, float growth_interval, void* stream);
+/* The same with one step count per tensor slot, as torch.optim.Adam counts (state[p]["step"]: a parameter that receives its first
+ * gradient late starts its bias corrections at t = 1).  steps [1 + N2M_ADAM_MAX] and bias [1 + N2M_ADAM_MAX][2], slot 0 = the
+ * global count; participants: bit s-1 set = slot s took part in this step.  Initialise every bias row to (1-beta1, sqrt(1-beta2)). */
+int n2m_scaler_update_slots(float* scale, float* growth_tracker, float* found_inf, float* steps, float* bias,
+                            uint32_t participants, double beta1, double beta2, float growth_factor, float backoff_factor,
+                            float growth_interval, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * shencoder   (reference: shencoder/src/shencoder.h:9-10, shencoder/src/bindings.cpp:5-8)

@@ -122,6 +122,7 @@ struct AdamTensors {
     uint32_t n[N2M_ADAM_MAX], first_block[N2M_ADAM_MAX + 1];
     float lr[N2M_ADAM_MAX];
     uint8_t shadow_mode[N2M_ADAM_MAX];
+    uint8_t slot[N2M_ADAM_MAX];       // 0: bias[0..1] (one step count for everything); s > 0: bias[2s..2s+1], this tensor's own count
     int8_t partner[N2M_ADAM_MAX];     // mode-3 tensor: index of the mode-2 tensor packed into the same table (updated by the same threads), or -1
     uint32_t count, g_half_mask, clear_mask;    // clear_mask: fp32 gradients this launch resets to zero once consumed
 };
@@ -171,7 +172,7 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
             for (uint32_t e = 0; e < 4u && i0 + e < n; ++e) reinterpret_cast<float*>(t.g[k])[i0 + e] = 0.0f;
         return;
     }
-    const float bc1 = bias[0], bc2_sqrt = bias[1];
+    const float bc1 = bias[2u * t.slot[k]], bc2_sqrt = bias[2u * t.slot[k] + 1u];
     const float step_size = t.lr[k] / bc1;
     const float inv_scale = scale ? 1.0f / *scale : 1.0f;
     float* __restrict__ P = reinterpret_cast<float*>(t.p[k]);
@@ -235,7 +236,8 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
         float* __restrict__ M1 = reinterpret_cast<float*>(t.m[pk]);
         float* __restrict__ V1 = reinterpret_cast<float*>(t.v[pk]);
         const bool g1_half = (t.g_half_mask >> pk) & 1u;
-        const float step1 = t.lr[pk] / bc1;
+        const float bc1p = bias[2u * t.slot[pk]], bc2p_sqrt = bias[2u * t.slot[pk] + 1u];      // the partner tensor's own step count
+        const float step1 = t.lr[pk] / bc1p;
         float q[2] = {0.f, 0.f};
 #pragma unroll
         for (uint32_t e = 0; e < 2; ++e) {
@@ -243,7 +245,7 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
             const float gr = (g1_half ? (float)reinterpret_cast<const _Float16*>(t.g[pk])[r0 + e] : reinterpret_cast<const float*>(t.g[pk])[r0 + e]) * inv_scale;
             const float m1 = beta1 * M1[r0 + e] + omb1 * gr;
             const float v1 = beta2 * V1[r0 + e] + omb2 * gr * gr;
-            q[e] = P1[r0 + e] - step1 * m1 / (sqrtf(v1) / bc2_sqrt + eps);
+            q[e] = P1[r0 + e] - step1 * m1 / (sqrtf(v1) / bc2p_sqrt + eps);
             P1[r0 + e] = q[e]; M1[r0 + e] = m1; V1[r0 + e] = v1;
         }
         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -342,6 +344,8 @@ extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, f
         if (d->grad_is_half[k]) t.g_half_mask |= 1u << k;
         if (d->clear_grad[k] && !d->grad_is_half[k]) t.clear_mask |= 1u << k;
         t.shadow_mode[k] = (uint8_t)(d->half_shadow[k] ? (d->shadow_mode[k] ? d->shadow_mode[k] : 1) : 0);
+        N2M_REQUIRE(d->slot[k] >= 0 && d->slot[k] <= N2M_ADAM_MAX, N2M_EINVAL, "adam_step: slot of tensor %u out of range", k);
+        t.slot[k] = (uint8_t)d->slot[k];
         N2M_REQUIRE(t.shadow_mode[k] <= 3 && !(t.shadow_mode[k] == 3 && (d->numel[k] & 1u)), N2M_EINVAL, "adam_step: bad shadow mode for tensor %u", k);
     }
     // a [rows,1] tensor (mode 2) and a [rows,2] tensor (mode 3) writing columns of the SAME packed table are updated together by the
@@ -367,6 +371,49 @@ extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, f
     if (blocks == 0) return 0;
     adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(t, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, scale,
                                                          found_inf, bias);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+// The same with one step count PER TENSOR SLOT (torch.optim.Adam keeps `state[p]["step"]` per parameter: a parameter that gets its
+// first gradient late -- nerf2mesh's specular head after `diffuse_step` -- starts its bias corrections at t = 1).  Thread 0 does the
+// scaler bookkeeping and the global count (slot 0), thread s the count and the next-step corrections of slot s.
+__global__ void scaler_update_slots_kernel(float* scale, float* growth_tracker, float* found_inf, float* steps /*[1+MAX]*/,
+                                           float* bias /*[1+MAX][2]*/, uint32_t participants, double beta1, double beta2,
+                                           float growth_factor, float backoff_factor, float growth_interval) {
+    const uint32_t s = threadIdx.x;
+    const bool ok = *found_inf == 0.0f;
+    __syncthreads();                                  // everyone has read the verdict before thread 0 clears it
+    if (s == 0) {
+        if (!ok) {
+            if (scale) *scale *= backoff_factor;
+            if (growth_tracker) *growth_tracker = 0.0f;
+        } else if (growth_tracker) {
+            const float g = *growth_tracker + 1.0f;
+            if (g >= growth_interval) {
+                const float ns = *scale * growth_factor;
+                if (scale && ns <= 3.0e38f) *scale = ns;            // do not grow into inf
+                *growth_tracker = 0.0f;
+            } else {
+                *growth_tracker = g;
+            }
+        }
+        *found_inf = 0.0f;
+    }
+    if (s <= N2M_ADAM_MAX) {
+        if (ok && (s == 0 || ((participants >> (s - 1u)) & 1u))) steps[s] += 1.0f;
+        const double t = (double)steps[s] + 1.0;      // corrections of this slot's NEXT step, in double like torch's host arithmetic
+        bias[2u * s] = (float)(1.0 - pow(beta1, t));
+        bias[2u * s + 1u] = (float)sqrt(1.0 - pow(beta2, t));
+    }
+}
+
+extern "C" int n2m_scaler_update_slots(float* scale, float* growth_tracker, float* found_inf, float* steps, float* bias,
+                                       uint32_t participants, double beta1, double beta2, float growth_factor, float backoff_factor,
+                                       float growth_interval, void* stream) {
+    N2M_REQUIRE(found_inf != nullptr && steps != nullptr && bias != nullptr, N2M_ENULL, "scaler_update_slots: NULL found_inf / steps / bias");
+    scaler_update_slots_kernel<<<1, 64, 0, (hipStream_t)stream>>>(scale, growth_tracker, found_inf, steps, bias, participants, beta1, beta2,
+                                                                  growth_factor, backoff_factor, growth_interval);
     N2M_CHECK_LAUNCH();
     return 0;
 }

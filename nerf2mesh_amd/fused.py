@@ -206,7 +206,10 @@ class _fused_field(Function):
             dws.append(flat[o:o + w.numel()].view_as(w))
             o += w.numel()
         if persistent:
-            amp["dw_flat"], amp["dw_views"] = flat, list(dws)
+            # weights whose gradient this call does not produce stay out of the optimizer step (torch: grad is None), so that their
+            # Adam step count starts when they first train -- the specular head after opt.diffuse_step
+            live = [want_density] * 2 + [want_color] * 3 + [want_color and shading != 0] * 2
+            amp["dw_flat"], amp["dw_views"] = flat, [g if ok else None for g, ok in zip(dws, live)]
         L.call("n2m_field_backward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, ctx.normalize_dirs, _p(d_sigma), _p(d_rgb),
                _p(d_spec), _p(d_h1), _p(d_h2), *[_p(g) for g in dws], _p(amp["found_inf"]) if amp is not None else None, L.stream())
         if amp is not None:

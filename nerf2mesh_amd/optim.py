@@ -29,10 +29,14 @@ class FusedAdamAMP(torch.optim.Optimizer):
         self.scale = torch.full((), float(init_scale) if amp else 1.0, device=dev)
         self.growth_tracker = torch.zeros((), device=dev)
         self.found_inf = torch.zeros((), device=dev)
-        self.step_count = torch.zeros((), device=dev)          # successful steps, on the device (a skipped step does not count)
+        # successful steps on the device (a skipped step does not count): [0] all steps, [1 + i] those parameter i took part in --
+        # torch.optim.Adam counts per parameter, so a parameter whose first gradient comes late starts its bias corrections at t = 1
+        self.steps = torch.zeros(1 + L.ADAM_MAX, device=dev)
+        self.step_count = self.steps[0]
         self.growth = (float(growth_factor), float(backoff_factor), float(growth_interval))
         b1, b2 = betas
-        self.bias = torch.tensor([1.0 - b1, (1.0 - b2) ** 0.5], dtype=torch.float32).to(dev)       # bias corrections of step t = 1
+        self.bias = torch.tensor([[1.0 - b1, (1.0 - b2) ** 0.5]] * (1 + L.ADAM_MAX), dtype=torch.float32).to(dev)   # corrections of step t = 1, per slot
+        self._slot = {p: 1 + i for i, p in enumerate(ps)}
         self._one = torch.ones((), device=dev)
         for p in ps:
             self.state[p] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
@@ -61,7 +65,7 @@ class FusedAdamAMP(torch.optim.Optimizer):
         """flagged: parameters whose gradients were already checked for inf/nan by the kernels that produced them."""
         flagged = {id(p) for p in flagged}
         desc = L.AdamDesc()
-        keep, unchecked, k = [], [], 0
+        keep, unchecked, k, participants = [], [], 0, 0
         for group in self.param_groups:
             for p in group["params"]:
                 hg = self.half_grads.get(p)
@@ -93,6 +97,8 @@ class FusedAdamAMP(torch.optim.Optimizer):
                 desc.numel[k], desc.lr[k], desc.grad_is_half[k] = p.numel(), float(group["lr"]), int(is_half)
                 desc.shadow_mode[k] = int(mode) if sh is not None else 0
                 desc.clear_grad[k] = int(clear and g.is_contiguous())
+                desc.slot[k] = self._slot[p]
+                participants |= 1 << (self._slot[p] - 1)
                 keep += [g, sh]
                 k += 1
         if k == 0:
@@ -106,5 +112,5 @@ class FusedAdamAMP(torch.optim.Optimizer):
         L.call("n2m_adam_step", ctypes.addressof(desc), float(b1), float(b2), float(self.param_groups[0]["eps"]),
                L.ptr(self.scale) if self.amp else None, L.ptr(self.found_inf), L.ptr(self.bias), s)
         gf, bf, gi = self.growth
-        L.call("n2m_scaler_update", L.ptr(self.scale) if self.amp else None, L.ptr(self.growth_tracker) if self.amp else None,
-               L.ptr(self.found_inf), L.ptr(self.step_count), L.ptr(self.bias), float(b1), float(b2), gf, bf, gi, s)
+        L.call("n2m_scaler_update_slots", L.ptr(self.scale) if self.amp else None, L.ptr(self.growth_tracker) if self.amp else None,
+               L.ptr(self.found_inf), L.ptr(self.steps), L.ptr(self.bias), participants, float(b1), float(b2), gf, bf, gi, s)

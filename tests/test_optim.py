@@ -120,3 +120,23 @@ def test_adam_consumes_and_clears_persistent_gradients():
     va += float("inf")
     opt.step()                                               # non-finite: step skipped, scale backed off, buffer still cleared
     assert not flat.any() and torch.equal(a.detach(), before) and float(opt.scale) == 2.0
+
+
+def test_adam_counts_steps_per_parameter():
+    """A parameter that gets its first gradient late starts its bias corrections at t = 1, like torch.optim.Adam's per-parameter
+    state["step"] (nerf2mesh's specular head trains only after opt.diffuse_step)."""
+    import torch
+    from nerf2mesh_amd.optim import FusedAdamAMP
+    torch.manual_seed(5)
+    a = torch.randn(513, 2, device="cuda").requires_grad_()
+    c = torch.randn(64, 32, device="cuda").requires_grad_()
+    ra, rc = a.detach().clone().requires_grad_(), c.detach().clone().requires_grad_()
+    ref = torch.optim.Adam([ra, rc], lr=1e-2, eps=1e-15)
+    opt = FusedAdamAMP([a, c], lr=1e-2, eps=1e-15, amp=False)
+    for it in range(7):
+        a.grad = torch.randn_like(a); ra.grad = a.grad.clone()
+        if it >= 3:                                           # c joins at the fourth step
+            c.grad = torch.randn_like(c); rc.grad = c.grad.clone()
+        opt.step(); ref.step()
+    assert torch.allclose(a, ra, rtol=1e-5, atol=1e-7) and torch.allclose(c, rc, rtol=1e-5, atol=1e-7)
+    assert float(opt.steps[0]) == 7 and float(opt.steps[1]) == 7 and float(opt.steps[2]) == 4
