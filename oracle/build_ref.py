@@ -89,6 +89,11 @@ def build(force: bool = False, verbose: bool = True) -> bool:
                         "-lc10", "-ltorch_cpu", "-ltorch", "-ltorch_python"], check=True)
         os.remove(obj_cu)
         os.remove(obj_b)
+    # the reference's Python callers of this path, byte-compiled (oracle/_ref/pyref): what the GPU box imports instead of the checkout
+    if os.path.dirname(HERE) not in sys.path:
+        sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import ref_python
+    ref_python.compile_pyref(verbose=verbose)
     return True
 
 

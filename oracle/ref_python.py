@@ -1,0 +1,199 @@
+"""TEST INFRASTRUCTURE ONLY -- runs the reference's UNCHANGED Python callers (nerf/renderer.py, nerf/network.py,
+raymarching/raymarching.py, gridencoder/grid.py, shencoder/sphere_harmonics.py, encoding.py, activation.py) so that the
+caller-level restatement in nerf2mesh_amd/{renderer,network}.py and the drop-in `_backend` modules can be checked against them.
+
+Where the Python comes from:
+  * this container: the sources where they lie under /root/reference (never copied);
+  * the GPU box (no /root/reference): `oracle/_ref/pyref/` = the same files byte-compiled by `compile_pyref()` below
+    (`py_compile`, sourceless `.pyc`, git-ignored like the `.so` files next to them; the compiled form travels, the sources do not).
+
+Which kernels sit under the wrappers (`backend=`):
+  * "ref": oracle/_ref/_ref_*.so -- the reference's own .cu kernels compiled for the host (oracle/build_ref.py); CPU tensors, fp32
+    (torch.cuda.amp.autocast disables itself without a device); `Tensor.cuda` is patched to the identity for the
+    duration of a call because the wrappers hard-code `.cuda()` (raymarching/raymarching.py:34-35 ...);
+  * "hip": nerf2mesh_amd/backends/_{raymarching_mob,gridencoder,shencoder,freqencoder}.py over libn2m_hip.so -- the product's drop-in
+    boundary; device tensors.
+Both function tables can live in one process: `use_backend()` swaps the `_backend` global of the three wrapper modules.
+
+Modules the reference imports at module scope but that this path never calls (cv2, trimesh, nvdiffrast, ... SURVEY 8b) are
+registered as empty stubs; `nvdiffrast.torch` resolves to the HIP facade when backend == "hip".
+"""
+import contextlib
+import importlib
+import os
+import py_compile
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFERENCE = os.environ.get("N2M_REFERENCE", "/root/reference")
+PYREF = os.path.join(HERE, "_ref", "pyref")
+
+# reference files on this path (relative to the checkout) -> compiled for the GPU box
+PY_FILES = [
+    "activation.py", "encoding.py", "meshutils.py",
+    "raymarching/__init__.py", "raymarching/raymarching.py",
+    "gridencoder/__init__.py", "gridencoder/grid.py",
+    "shencoder/__init__.py", "shencoder/sphere_harmonics.py",
+    "freqencoder/__init__.py", "freqencoder/freq.py",
+    "nerf/renderer.py", "nerf/network.py", "nerf/utils.py",
+]
+
+_STUBS = ["cv2", "mcubes", "trimesh", "xatlas", "pymeshlab", "imageio", "tensorboardX", "torch_ema", "lpips", "pytorch3d",
+          "pytorch3d.structures", "pytorch3d.loss", "dearpygui", "dearpygui.dearpygui", "torch_scatter"]
+
+
+def compile_pyref(verbose=False) -> bool:
+    """Byte-compile the reference's Python files of this path into oracle/_ref/pyref (sourceless layout). False without a checkout."""
+    if not os.path.isdir(REFERENCE):
+        return False
+    for rel in PY_FILES:
+        src = os.path.join(REFERENCE, rel)
+        dst = os.path.join(PYREF, rel + "c")
+        if os.path.exists(dst) and os.path.getmtime(dst) > os.path.getmtime(src):
+            continue
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        py_compile.compile(src, cfile=dst, dfile=rel, doraise=True)
+        if verbose:
+            print(f"[oracle/_ref] pyref: {rel}")
+    # `nerf` has no __init__.py in the reference (namespace package): nothing to compile for it
+    return True
+
+
+def root():
+    """Directory to put on sys.path: the checkout when present, else the byte-compiled copy. None when neither exists."""
+    if os.path.isdir(REFERENCE):
+        return REFERENCE
+    if os.path.exists(os.path.join(PYREF, "nerf", "renderer.pyc")):
+        return PYREF
+    return None
+
+
+def available() -> bool:
+    return root() is not None
+
+
+def _stub(name):
+    if name in sys.modules:
+        return sys.modules[name]
+    m = types.ModuleType(name)
+    m.__path__ = []          # lets `import a.b` resolve through sys.modules
+    m.__n2m_stub__ = True
+    sys.modules[name] = m
+    if "." in name:
+        parent, child = name.rsplit(".", 1)
+        setattr(_stub(parent), child, m)
+    return m
+
+
+def _install_stubs():
+    for n in _STUBS:
+        _stub(n)
+    sys.modules["torch_ema"].ExponentialMovingAverage = type("ExponentialMovingAverage", (), {})
+    sys.modules["pytorch3d.structures"].Meshes = type("Meshes", (), {})
+    for fn in ("mesh_laplacian_smoothing", "mesh_normal_consistency", "mesh_edge_loss"):
+        setattr(sys.modules["pytorch3d.loss"], fn, None)
+    sys.modules["lpips"].LPIPS = type("LPIPS", (), {})
+
+
+_BACKENDS = {}
+_state = {"loaded": False}
+
+
+def _backend_tables(kind):
+    """(raymarching, gridencoder, shencoder, freqencoder) function tables of one kind."""
+    if kind in _BACKENDS:
+        return _BACKENDS[kind]
+    if kind == "ref":
+        from oracle import build_ref
+        if not build_ref.available():
+            assert build_ref.build(verbose=False), "oracle/_ref is not built and /root/reference is absent"
+        rm, ge, sh = build_ref.load()
+        fq = build_ref.load_freq()
+    elif kind == "hip":
+        from nerf2mesh_amd import backends
+        bdir = backends.path()
+
+        def imp(n):
+            spec = importlib.util.spec_from_file_location("n2m_hip" + n, os.path.join(bdir, n + ".py"))
+            m = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(m)
+            return m
+        rm, ge, sh, fq = (imp(n) for n in ("_raymarching_mob", "_gridencoder", "_shencoder", "_freqencoder"))
+    else:
+        raise ValueError(kind)
+    _BACKENDS[kind] = (rm, ge, sh, fq)
+    return _BACKENDS[kind]
+
+
+def load(backend="ref"):
+    """Import the unchanged reference modules; returns a namespace with `.network` (nerf.network), `.renderer`, `.utils`,
+    `.raymarching`, `.grid`.  `backend` selects the kernels under the wrappers (see module docstring)."""
+    r = root()
+    assert r is not None, "neither /root/reference nor oracle/_ref/pyref is present"
+    import torch  # noqa: F401
+    if not _state["loaded"]:
+        _install_stubs()
+        _stub("nvdiffrast")
+        _stub("nvdiffrast.torch")
+        rm, ge, sh, fq = _backend_tables(backend)
+        # the wrappers' `import _raymarching_mob as _backend` seam (raymarching/raymarching.py:9-12 etc.)
+        sys.modules["_raymarching_mob"], sys.modules["_gridencoder"] = rm, ge
+        sys.modules["_shencoder"], sys.modules["_freqencoder"] = sh, fq
+        if r not in sys.path:
+            sys.path.insert(0, r)
+        _state["loaded"] = True
+    ns = types.SimpleNamespace()
+    ns.raymarching = importlib.import_module("raymarching.raymarching")
+    ns.grid = importlib.import_module("gridencoder.grid")
+    ns.sh = importlib.import_module("shencoder.sphere_harmonics")
+    ns.freq = importlib.import_module("freqencoder.freq")
+    # nerf/utils.py:45-52 decorates two colour-space helpers (not on this path) with torch.jit.script, which wants source text:
+    # with the byte-compiled copy the decorator is the identity for the duration of the import
+    import torch.jit
+    script = torch.jit.script
+    if r == PYREF:
+        torch.jit.script = lambda fn, *a, **k: fn
+    try:
+        ns.utils = importlib.import_module("nerf.utils")
+        ns.renderer = importlib.import_module("nerf.renderer")
+        ns.network = importlib.import_module("nerf.network")
+    finally:
+        torch.jit.script = script
+    use_backend(backend)
+    return ns
+
+
+def use_backend(kind):
+    """Point the reference wrappers' `_backend` globals at the "ref" (CPU, reference kernels) or "hip" (libn2m_hip.so) tables;
+    with "hip", nerf/renderer.py's `dr` (nvdiffrast.torch, :15) becomes the HIP facade."""
+    rm, ge, sh, fq = _backend_tables(kind)
+    sys.modules["raymarching.raymarching"]._backend = rm
+    sys.modules["gridencoder.grid"]._backend = ge
+    sys.modules["shencoder.sphere_harmonics"]._backend = sh
+    sys.modules["freqencoder.freq"]._backend = fq
+    if kind == "hip":
+        sys.modules["nerf.renderer"].dr = importlib.import_module("nerf2mesh_amd.raster")
+
+
+@contextlib.contextmanager
+def cpu_mode():
+    """`Tensor.cuda()` / `Module.cuda()` -> identity while the reference Python runs on CPU tensors over the "ref" tables
+    (test-only patch)."""
+    import torch
+    t_cuda, m_cuda = torch.Tensor.cuda, torch.nn.Module.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    try:
+        yield
+    finally:
+        torch.Tensor.cuda, torch.nn.Module.cuda = t_cuda, m_cuda
+
+
+def reference_opt(**kw):
+    """The `opt` fields NeRFNetwork / NeRFRenderer read (nerf/renderer.py:68-168, nerf/network.py:57-79), main.py defaults."""
+    d = dict(bound=1.0, contract=False, grid_size=128, min_near=0.05, density_thresh=10, ind_num=500, ind_dim=0, cuda_ray=True,
+             trainable_density_grid=False, stage=0, gui=False, tcnn=False, sdf=False, fp16=False, lr=1e-2,
+             normal_anneal_epsilon=1e-4, cos_anneal_ratio=1.0, lambda_density=0, workspace="", mesh="", ckpt="scratch")
+    d.update(kw)
+    return types.SimpleNamespace(**d)
