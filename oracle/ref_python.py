@@ -86,9 +86,22 @@ def _stub(name):
     return m
 
 
+# installed in this image but not necessarily on every box: imported for real when present, stubbed otherwise
+_OPTIONAL = {"matplotlib": [], "matplotlib.pyplot": [], "sklearn": [], "sklearn.neighbors": ["NearestNeighbors"], "scipy": [],
+             "scipy.ndimage": ["binary_dilation", "binary_erosion"], "tqdm": ["tqdm", "trange"], "rich": [], "rich.console": ["Console"],
+             "packaging": [], "packaging.version": []}
+
+
 def _install_stubs():
     for n in _STUBS:
         _stub(n)
+    for n, names in _OPTIONAL.items():
+        try:
+            importlib.import_module(n)
+        except Exception:
+            m = _stub(n)
+            for a in names:
+                setattr(m, a, None)
     sys.modules["torch_ema"].ExponentialMovingAverage = type("ExponentialMovingAverage", (), {})
     sys.modules["pytorch3d.structures"].Meshes = type("Meshes", (), {})
     for fn in ("mesh_laplacian_smoothing", "mesh_normal_consistency", "mesh_edge_loss"):

@@ -32,10 +32,11 @@ GOLD = os.path.join(HERE, "golden")
 
 # fp32 tolerances (GPU HIP kernels + rocBLAS GEMMs vs CPU reference kernels + MKL GEMMs; composite sums of ~250 terms)
 TOL = {
-    "nerf": dict(grid=2e-5, image=5e-5, depth=2e-4, grad=2e-4, normal=None, flips=4),
+    # density = exp(h), |h| <= ~12: the relative error of the density is the absolute error of an fp32 dot product of that size
+    "nerf": dict(grid=1e-4, image=1e-5, depth=3e-5, grad=2e-4, normal=None, flips=2),      # measured: 3e-5, 9e-7, 2.6e-6, 4.6e-5, 0
     # SDF: normals are central differences with eps = 1e-4 (nerf/network.py:143-154): a 1e-7 difference of two densities is
-    # amplified 5000x, and the alpha derived from them feeds every output
-    "sdf": dict(grid=2e-4, image=2e-3, depth=5e-3, grad=2e-2, normal=2e-2, flips=16),
+    # amplified 5000x, and the alpha derived from them feeds every output; grid density = sigmoid(-sdf * s) * s with s = e^5 = 148
+    "sdf": dict(grid=2e-3, image=5e-5, depth=1e-4, grad=2e-2, normal=1e-3, flips=4),      # measured: 3.6e-4, 2.4e-6, 3.8e-6, 3.4e-3, 3.5e-5, 0
 }
 
 
@@ -49,45 +50,54 @@ def relmax(a, b):
 
 
 def compare(out, fx, tol, what):
-    """`out` = run_case() result with the fixture's bit field used for the march; `fx` = committed fixture."""
-    # ---- A12 mark_untrained_grid: integer decision per cell (fp compares of exactly representable products may differ by an ulp
-    # between matmul implementations only for cells ON a frustum plane; none are here)
-    assert np.array_equal(out["untrained"], fx["untrained"]), f"{what}: untrained-cell mask differs"
+    """`out` = run_case() result with the fixture's bit field used for the march; `fx` = committed fixture.
+    Every check is evaluated; the measured errors are printed (pytest -s / failure report) and all violations raised together."""
+    bad, rows = [], []
+
+    def check(name, err, limit, exact=False):
+        rows.append(f"  {name:44s} {'==' if exact else 'err'} {err:.3g}  (limit {limit:.3g})")
+        if not err <= limit:
+            bad.append(f"{name}: {err:.3g} > {limit:.3g}")
+
+    # ---- A12 mark_untrained_grid: an integer decision per cell
+    check("untrained-cell mask: differing cells", float((np.unpackbits(out["untrained"]) != np.unpackbits(fx["untrained"])).sum()), 0, True)
     # ---- A12 update_extra_state
     grid = out["density_grid"].reshape(-1)
     sub = grid[::int(fx["density_grid_stride"])]
-    assert int((grid < 0).sum()) == int(fx["density_grid_neg"])
+    check("density_grid: cells < 0", abs(int((grid < 0).sum()) - int(fx["density_grid_neg"])), 0, True)
     err = np.abs(sub - fx["density_grid_sub"]) / np.maximum(np.abs(fx["density_grid_sub"]), 1e-3)
-    assert err.max() <= tol["grid"], f"{what}: density_grid rel err {err.max():.3g}"
-    assert abs(float(out["mean_density"]) - float(fx["mean_density"])) <= 1e-5 * abs(float(fx["mean_density"]))
+    check("density_grid rel err (floor 1e-3)", float(err.max()), tol["grid"])
+    check("mean_density rel err", abs(float(out["mean_density"]) - float(fx["mean_density"])) / abs(float(fx["mean_density"])), tol["grid"])
     # bit field: exact, except cells whose density sits within the grid tolerance of the threshold (an fp decision, not an integer one)
     mine, ref = np.unpackbits(out["density_bitfield"], bitorder="little"), np.unpackbits(fx["density_bitfield"], bitorder="little")
     flips = np.flatnonzero(mine != ref)
-    thr = min(float(fx["mean_density"]), 10.0 if "sdf" not in what else 0.001)
-    assert flips.size <= tol["flips"], f"{what}: {flips.size} occupancy bits differ"
-    assert np.all(np.abs(grid[flips] - thr) <= 10 * tol["grid"] * thr), f"{what}: occupancy bits differ away from the threshold"
+    thr = min(float(fx["mean_density"]), 0.001 if "sdf" in what else 10.0)
+    check("density_bitfield: differing bits", float(flips.size), tol["flips"], True)
+    if flips.size:
+        check("  their |density - threshold| / threshold", float((np.abs(grid[flips] - thr) / thr).max()), 2 * tol["grid"])
     # ---- A2/A3 through render(): integer outputs exact (same bit field), fp outputs to tolerance
-    assert int(out["num_points"]) == int(fx["num_points"]), f"{what}: num_points {out['num_points']} != {fx['num_points']}"
-    assert np.array_equal(out["xyzs_head"], fx["xyzs_head"]), f"{what}: sample positions differ"
+    check("num_points", abs(int(out["num_points"]) - int(fx["num_points"])), 0, True)
+    check("sample positions: differing values", float((out["xyzs_head"] != fx["xyzs_head"]).sum()), 0, True)
     for key, t in (("image", tol["image"]), ("weights_sum", tol["image"]), ("depth", tol["depth"]), ("eval_image", tol["image"]),
                    ("eval_depth", tol["depth"])):
-        d = np.abs(out[key] - fx[key]).max()
-        assert d <= t, f"{what}: {key} abs err {d:.3g} > {t}"
+        check(f"{key} abs err", float(np.abs(out[key] - fx[key]).max()), t)
     if tol["normal"] is not None:
-        d = relmax(out["normal_head"], fx["normal_head"])
-        assert d <= tol["normal"], f"{what}: normals rel err {d:.3g}"
-    assert abs(float(out["loss"]) - float(fx["loss"])) <= 10 * tol["image"] * abs(float(fx["loss"]))
+        check("normals rel-to-max err", relmax(out["normal_head"], fx["normal_head"]), tol["normal"])
+    check("loss rel err", abs(float(out["loss"]) - float(fx["loss"])) / abs(float(fx["loss"])), 10 * tol["image"])
     # ---- backward through composite, heads, encoders
-    for key in fx:
+    for key in sorted(fx):
         if key.startswith("grad.") or key.startswith("grad_head."):
-            assert key in out, f"{what}: no gradient for {key}"
-            d = relmax(out[key], fx[key])
-            assert d <= tol["grad"], f"{what}: {key} rel-to-max err {d:.3g}"
+            if key not in out:
+                bad.append(f"no gradient for {key}")
+                continue
+            check(f"{key} rel-to-max err", relmax(out[key], fx[key]), tol["grad"])
         elif key.startswith("grad_sum."):
-            assert abs(out[key] - fx[key]) <= tol["grad"] * fx[key], f"{what}: {key}"
+            check(f"{key} rel err", abs(out[key] - fx[key]) / fx[key], tol["grad"])
         elif key.startswith("grad_nnz."):
             # rows whose gradient is exactly zero are rows no sample touched: an index statement
-            assert abs(int(out[key]) - int(fx[key])) <= 1e-4 * int(fx[key]), f"{what}: {key} {out[key]} vs {fx[key]}"
+            check(f"{key}: differing count", abs(int(out[key]) - int(fx[key])), 1e-4 * int(fx[key]), True)
+    print(f"\n{what} vs tests/golden fixture:\n" + "\n".join(rows))
+    assert not bad, f"{what}:\n  " + "\n  ".join(bad)
     return int(flips.size)
 
 
