@@ -95,6 +95,11 @@ int n2m_march_rays_train_write(const float* rays_o, const float* rays_d, const u
                                const float* nears, const float* fars, float* xyzs, float* dirs, float* ts,
                                const int32_t* rays, const float* noises, uint32_t max_points, void* stream);
 
+/* Diagnostics.  march_rays_train resolves which candidates a ray visits with a wave-wide prefix maximum whose result is provably the
+ * serial chain's whenever its check passes; a ray that fails the check is re-marched with the serial resolution.  Returns in *out
+ * the number of such rays (count passes) since the previous call and resets it.  Synchronises the device. */
+int n2m_march_fallback_count(uint32_t* out);
+
 /* raymarching.h:15  composite_rays_train_forward   kernel raymarching.cu:500-578.
  * sigmas [M], rgbs [M,3], ts [M,2], rays [N,2] -> weights [M], weights_sum [N], depth [N], image [N,3].
  * weights: every sample of a ray's (offset, count) range inside [0,M) is written -- zero after the early stop, and a

@@ -22,6 +22,7 @@ SIGNATURES = {
     "n2m_flatten_rays": [_vp, _u32, _u32, _vp, _vp],
     "n2m_march_rays_train": [_vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_march_rays_train_write": [_vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "n2m_march_fallback_count": [_vp],
     "n2m_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _int, _vp, _vp, _vp, _vp, _vp],
     "n2m_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _int, _vp, _vp, _vp],
     "n2m_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

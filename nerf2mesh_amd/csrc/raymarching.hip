@@ -260,13 +260,31 @@ __device__ __forceinline__ LaneEval eval_candidate(const MarchCtx& c, float t) {
     return e;
 }
 
+// rays whose parallel resolution failed its check and were redone serially (diagnostics: n2m_march_fallback_count)
+__device__ unsigned int g_march_fallbacks;
+
+// Inclusive prefix maximum across the wave on the DPP network (no LDS pipe): Hillis-Steele inside each row of 16 lanes
+// (row_shr 1/2/4/8), then lane 15 of rows 0/2 into rows 1/3 (row_bcast:15) and lane 31 into rows 2/3 (row_bcast:31).
+__device__ __forceinline__ float wave_scan_max_dpp(float v) {
+    const int ninf = (int)0xff800000u;
+#define N2M_DPP_MAX(ctrl, rows) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), (ctrl), (rows), 0xf, false)))
+    N2M_DPP_MAX(0x111, 0xf);   // row_shr:1
+    N2M_DPP_MAX(0x112, 0xf);   // row_shr:2
+    N2M_DPP_MAX(0x114, 0xf);   // row_shr:4
+    N2M_DPP_MAX(0x118, 0xf);   // row_shr:8
+    N2M_DPP_MAX(0x142, 0xa);   // row_bcast:15 -> rows 1, 3
+    N2M_DPP_MAX(0x143, 0xc);   // row_bcast:31 -> rows 2, 3
+#undef N2M_DPP_MAX
+    return v;
+}
+
 template <bool WRITE>
 __device__ __forceinline__ void march_train_one_ray(uint32_t n, int lane, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                         const uint8_t* __restrict__ grid,
                         float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                         const float* __restrict__ nears, const float* __restrict__ fars, float* __restrict__ xyzs,
                         float* __restrict__ dirs, float* __restrict__ ts, int32_t* __restrict__ rays,
-                        const float* __restrict__ noises, uint32_t max_points) {
+                        const float* __restrict__ noises, uint32_t max_points, bool force_serial) {
     MarchCtx c;
     march_ctx_init(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, 0.0f, grid, bound, contract, dt_gamma, max_steps, C, H);
     uint32_t budget = max_steps;
@@ -277,12 +295,22 @@ __device__ __forceinline__ void march_train_one_ray(uint32_t n, int lane, const 
         if (budget == 0 || out + budget > (size_t)max_points) return;     // does not fit the sample buffers (raymarching.cu:417)
     }
     const float far = fars[n];
-    float t_base = nears[n];
-    t_base += n2m_clampf(t_base * dt_gamma, c.dt_min, c.dt_max) * noises[n];
-
+    const float t_start = nears[n] + n2m_clampf(nears[n] * dt_gamma, c.dt_min, c.dt_max) * noises[n];
+    // Resolution of the visited subsequence, two ways.  PARALLEL (first attempt): the serial chain keeps an occupied candidate j
+    // unless a VISITED empty candidate i < j jumps over it, i.e. has exit time tt_i > T_j.  If no empty candidate at all -- visited
+    // or not -- has tt_i > T_j for any later occupied j (a prefix maximum over the lanes, carried across chunks), the chain never
+    // skips an occupied candidate and visits every one of them (induction over the chain: an empty candidate jumps to the first
+    // T_k >= tt_i and everything in between is empty by the condition), so the kept set is exactly the occupied candidates, cut by
+    // the sample budget and by `far`: no serial loop.  The condition only fails when rounding pushes a voxel's exit time past a
+    // candidate that already lies in the next, occupied voxel (~1e-4 per empty->occupied crossing); the ray is then redone from
+    // its start with the SERIAL resolution (the exact chain state is not tracked by the parallel form).
+    bool serial = force_serial;
+restart_ray:
+    float t_base = t_start;
     uint32_t kept = 0;
     bool pending = false;      // an empty voxel's exit time lies beyond the previous chunk
     float pending_tt = 0.f;
+    float carry_tt = -INFINITY; // parallel form: largest exit time of any empty candidate in earlier chunks
     // a ray can only end by t >= far or by the sample budget; the chunk cap turns a non-advancing t (far = inf with
     // t so large that t + dt == t: the serial reference would spin forever) into a bounded loop
     for (uint32_t chunk = 0; chunk < (1u << 20) && t_base < far && kept < budget; ++chunk) {
@@ -329,14 +357,32 @@ __device__ __forceinline__ void march_train_one_ray(uint32_t n, int lane, const 
         if (active) e = eval_candidate(c, t);
         const unsigned long long active_mask = __ballot(active);             // a prefix of the lanes (T increases)
         const unsigned long long keep_mask = __ballot(active && e.keep);
-        // 3. resolve the visited subsequence.  Everything in this loop is wave-uniform (ballots, lane indices, counters); the
-        // values are pinned to SGPRs with readfirstlane so that the loop runs on the scalar unit with scalar branches instead of
-        // per-lane VALU compares under exec masks.
         unsigned long long kept_mask = 0ull;
-        int cur = 0;
         bool done = false;
         const uint32_t budget_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)budget);
         uint32_t kept_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)kept);
+        if (!serial) {
+            // 3a. parallel resolution (see above)
+            const float incl = wave_scan_max_dpp((active && !e.keep) ? e.tt : -INFINITY);
+            // exclusive form: lane j sees the maximum over lanes < j and over the earlier chunks (wave_shr:1, lane 0 keeps `old`)
+            const float before = fmaxf(carry_tt, __int_as_float(__builtin_amdgcn_update_dpp((int)0xff800000u, __float_as_int(incl), 0x138, 0xf, 0xf, false)));
+            if (__ballot(active && e.keep && t < before) != 0ull) {
+                if (!WRITE && lane == 0) atomicAdd(&g_march_fallbacks, 1u);
+                serial = true;
+                goto restart_ray;
+            }
+            carry_tt = fmaxf(carry_tt, __uint_as_float((uint32_t)__builtin_amdgcn_readlane(__float_as_int(incl), 63)));
+            const uint32_t room = budget_s - kept_s;
+            kept_mask = keep_mask;
+            if ((uint32_t)__popcll(keep_mask) > room)      // sample budget: the first `room` occupied candidates
+                kept_mask = __ballot(active && e.keep && (uint32_t)__popcll(keep_mask & ((1ull << lane) - 1ull)) < room);
+            kept_s += (uint32_t)__popcll(kept_mask);
+            done = kept_s >= budget_s || active_mask != ~0ull;        // budget spent, or some T_j >= far lies in this chunk
+        } else {
+        // 3b. serial resolution.  Everything in this loop is wave-uniform (ballots, lane indices, counters); the
+        // values are pinned to SGPRs with readfirstlane so that the loop runs on the scalar unit with scalar branches instead of
+        // per-lane VALU compares under exec masks.
+        int cur = 0;
         if (pending) {
             const unsigned long long reach = __ballot(t >= pending_tt);
             if (reach == 0ull) cur = 64;                                     // whole chunk lies inside the skipped voxel
@@ -362,6 +408,7 @@ __device__ __forceinline__ void march_train_one_ray(uint32_t n, int lane, const 
                 else { pending = true; pending_tt = tt; cur = 64; }
             }
             cur = __builtin_amdgcn_readfirstlane(cur);
+        }
         }
         kept = kept_s;
         // 4. emit
@@ -390,11 +437,11 @@ march_train_wave_kernel(const float* __restrict__ rays_o, const float* __restric
                         float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                         const float* __restrict__ nears, const float* __restrict__ fars, float* __restrict__ xyzs,
                         float* __restrict__ dirs, float* __restrict__ ts, int32_t* __restrict__ rays,
-                        const float* __restrict__ noises, uint32_t max_points) {
+                        const float* __restrict__ noises, uint32_t max_points, bool force_serial) {
     const int lane = threadIdx.x & 63;
     for (uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6); n < N; n += gridDim.x * 4)
         march_train_one_ray<WRITE>(n, lane, rays_o, rays_d, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
-                                   noises, max_points);
+                                   noises, max_points, force_serial);
 }
 
 template <bool WRITE>
@@ -831,6 +878,11 @@ extern "C" int n2m_flatten_rays(const int32_t* rays, uint32_t N, uint32_t M, int
     return 0;
 }
 
+static bool serial_resolve() {   // A/B switch: N2M_MARCH_RESOLVE=serial keeps the scalar-loop resolution of the visited subsequence for every ray
+    static const bool v = getenv("N2M_MARCH_RESOLVE") != nullptr && getenv("N2M_MARCH_RESOLVE")[0] == 's';
+    return v;
+}
+
 // workgroups of the wave marcher: one ray per wave, or N2M_MARCH_GRID_CAP workgroups walking the batch (see the kernel)
 static uint32_t march_grid(uint32_t N) {
     // measurement switch: capping the grid did not pay on MI355X (256 / 512 / 1024 / 2048 workgroups: 1.21 / 1.05 / 0.99 / 0.97 ms per
@@ -863,7 +915,7 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
             else
                 march_train_wave_kernel<false><<<march_grid(N), 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0,
                                                                                   dt_gamma, max_steps, N, C, H, nears, fars, nullptr,
-                                                                                  nullptr, nullptr, rays, noises, max_points);
+                                                                                  nullptr, nullptr, rays, noises, max_points, serial_resolve());
             N2M_CHECK_LAUNCH();
         }
         const int rc = run_exclusive_scan(RayOffsetsOp{rays, counter}, N, s);
@@ -878,9 +930,20 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
         else
             march_train_wave_kernel<true><<<march_grid(N), 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
                                                                              max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
-                                                                             noises, max_points);
+                                                                             noises, max_points, serial_resolve());
         N2M_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+// Diagnostics: number of rays (count passes only) whose prefix-maximum resolution failed its exactness check and that were re-marched
+// with the serial resolution since the last call; resets the counter.  Synchronises the device.
+extern "C" int n2m_march_fallback_count(uint32_t* out) {
+    N2M_NOTNULL(out);
+    unsigned int v = 0, zero = 0;
+    N2M_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_march_fallbacks), sizeof(v)));
+    N2M_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_march_fallbacks), &zero, sizeof(zero)));
+    *out = v;
     return 0;
 }
 

@@ -21,7 +21,7 @@ def be():
     _lib.lib()                       # raises if the HIP library is missing: no silent fallback
     backends.install()
     import _raymarching_mob, _gridencoder, _shencoder
-    return {"rm": _raymarching_mob, "ge": _gridencoder, "sh": _shencoder, "torch": torch}
+    return {"rm": _raymarching_mob, "ge": _gridencoder, "sh": _shencoder, "torch": torch, "L": _lib}
 
 
 def dev(be, a):
@@ -143,6 +143,29 @@ def test_march_rays_train_bit_exact(be, oracle, scene, cfg):
         return
     assert orr[:, 1].sum() > 1000
     assert bits_equal(hx, ox) and bits_equal(hd, od) and bits_equal(ht, ot)
+
+
+def test_march_parallel_resolution_falls_back_exactly(be, oracle, scene):
+    """Random 30 % occupancy = hundreds of empty->occupied crossings per ray: some exit times round past a candidate of the next,
+    occupied voxel, the prefix-maximum check fails and the ray is re-marched serially.  Results stay bit-exact and the fallback is taken."""
+    import ctypes
+    rng = np.random.default_rng(11)
+    H = 128
+    bits = oracle.packbits((rng.random((1, H ** 3)) < 0.3).astype(np.float32) * 50, 10.0)
+    N = 60000
+    o, d = make_rays(scene, N, seed=21)
+    nears, fars = oracle.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.05)
+    noises = rng.random(N).astype(np.float32)
+    cnt = ctypes.c_uint32(0)
+    be["L"].call("n2m_march_fallback_count", ctypes.addressof(cnt))       # reset
+    for dt_gamma in (0.0, 1 / 256):
+        hx, hd, ht, hr = _hip_march_train(be, o, d, bits, 1.0, False, dt_gamma, 1024, 1, H, nears, fars, noises)
+        ox, od, ot, orr = oracle.march_rays_train(o, d, 1.0, False, bits, 1, H, nears, fars, noises, dt_gamma, 1024)
+        assert np.array_equal(hr, orr)
+        assert bits_equal(hx, ox) and bits_equal(ht, ot)
+        be["L"].call("n2m_march_fallback_count", ctypes.addressof(cnt))
+        print(f"dt_gamma {dt_gamma}: {cnt.value} of {N} rays took the serial fallback, {int(orr[:, 1].sum())} samples")
+        assert 0 < cnt.value < N // 4
 
 
 def test_march_split_form_equals_single_call(be, oracle, scene):
