@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--prof-every", type=int, default=4, help="time every n-th launch of each kernel with hipEvents (1 = all)")
     ap.add_argument("--stage", type=int, default=0, choices=[0, 1], help="0: stage-0 volume rendering (the headline metric); "
                     "1: stage-1 mesh/texture refinement step (BASELINE config 3)")
+    ap.add_argument("--autograd", action="store_true", help="A/B: drive the step through torch.autograd (trainer.Stage0Trainer) instead of the step "
+                    "executor (engine.Stage0Engine): same kernels, same arguments, more host time")
     ap.add_argument("--unfused", action="store_true", help="A/B: evaluate the MLPs with nn.Linear calls (the reference graph) instead of the fused MFMA kernels")
     args = ap.parse_args()
 
@@ -205,7 +207,9 @@ def main():
     opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=not args.unfused)   # scripts/runall_syn.sh:1
     model = NeRFNetwork(opt)
     poses = synthetic.make_cameras(100, seed=0)
-    tr = Stage0Trainer(model, opt, poses, device, rank=rank, world_size=world, seed=0)
+    from nerf2mesh_amd.engine import Stage0Engine
+    use_engine = not args.autograd and not args.unfused
+    tr = (Stage0Engine if use_engine else Stage0Trainer)(model, opt, poses, device, rank=rank, world_size=world, seed=0)
     tr.mark_untrained()
 
     def barrier():
@@ -281,7 +285,8 @@ def main():
         "config": {"workload": "nerf_synthetic/lego stage-0 -O --bound 1 --dt_gamma 0, 800x800 x 100 synthetic views, "
                                "num_points target 2^18/GPU (adaptive num_rays), occupancy refresh every 16 steps",
                    "parallelism": f"dp{world} (rays sharded, grad all-reduce)" if world > 1 else "single GPU",
-                   "mlp": "nn.Linear (unfused)" if args.unfused else "fused MFMA field kernels", "pretrain_steps": args.pretrain, "samples_per_step_per_gpu": samples / args.steps / world,
+                   "mlp": "nn.Linear (unfused)" if args.unfused else "fused MFMA field kernels",
+                   "driver": "engine.Stage0Engine (fixed launch sequence)" if use_engine else "trainer.Stage0Trainer (torch.autograd)", "pretrain_steps": args.pretrain, "samples_per_step_per_gpu": samples / args.steps / world,
                    "rays_per_step_per_gpu": rays / args.steps / world, "params": 18367240},
         "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "psnr_view0_quarter_res": psnr,
         "loss_mean": float(tr.loss_acc / max(tr.global_step, 1)),

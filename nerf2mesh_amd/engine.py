@@ -1,0 +1,390 @@
+"""Stage-0 step executor: the iteration of trainer.Stage0Trainer's fast path (lego recipe: fused field, packed tables, fused loss, TV
+folded into the table backward, FusedAdamAMP) issued as a FIXED sequence of C-ABI launches on preallocated buffers.
+
+Why it exists: with the kernels of this package a training step is ~0.7 ms of GPU work, and the same step driven through
+torch.autograd (custom Functions, ~50 tensor allocations, AccumulateGrad, LambdaLR, optimizer hooks) costs the host ~0.85 ms -- the
+step was HOST-bound (tools/cpu_bound.py).  The executor keeps PyTorch for what the task statement keeps it for -- device memory,
+streams, the random generators and torch.distributed -- and does the rest itself:
+
+  prepare (side stream, for batch i+1):  randint cam/pix -> n2m_get_rays -> n2m_near_far_from_aabb -> rand noises ->
+        n2m_march_rays_train pass 1 (count + offset scan) -> count to pinned memory + event -> n2m_march_rays_train_write (speculative)
+  step (main stream, batch i):  rand background -> [wait count] -> n2m_grid_encode_forward_packed -> n2m_field_forward ->
+        n2m_composite_rays_train_forward -> n2m_photo_loss_forward/backward -> n2m_composite_rays_train_backward -> n2m_field_backward ->
+        n2m_grid_encode_backward_binned_pair (+TV) -> [world > 1: SUM all-reduce of the fixed gradient buffers] -> n2m_adam_step ->
+        n2m_scaler_update_slots
+
+Same kernels, same arguments, same random draws in the same order as Stage0Trainer: the two produce the same parameters
+(tests/test_engine.py).  What the reference does per iteration is cited there (nerf/utils.py:628-823,1152-1190, main.py:221-241).
+Configurations outside the fast path (SDF, individual codes, unfused MLPs, bound > 1 without the packed tables) stay on Stage0Trainer.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import raymarching, synthetic
+from .fused import SHADING, _affine
+from .gridencoder import _host_offsets, same_geometry
+from .optim import FusedAdamAMP
+
+_p = L.ptr
+
+
+def lr_lambda(it, iters):
+    """main.py:239: 0.01 -> 1 over the first 500 iterations, then 0.1 ** ((it - 500) / (iters - 500))."""
+    return 0.01 + 0.99 * (it / 500) if it <= 500 else 0.1 ** ((it - 500) / (iters - 500))
+
+
+class _RayBufs:
+    """Per-batch ray-side tensors (two sets alternate: batch i+1 is produced while batch i is consumed)."""
+
+    def __init__(self, cap, dev):
+        self.cap = cap
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        self.o, self.d, self.rgba = f(cap, 3), f(cap, 3), f(cap, 4)
+        self.nears, self.fars = f(cap), f(cap)
+        self.rays = torch.empty(cap, 2, dtype=torch.int32, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.host_count = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        self.count_ready = torch.cuda.Event()
+        self.written = torch.cuda.Event()
+        self.samples = None          # [cap_m, 8] fp32: xyzs | dirs | ts (speculative write pass)
+        self.cap_m = 0
+        self.N = 0
+        self.noises = None
+        self.cam = self.pix = None
+        self.args = None
+        self.refreshed = False
+
+
+class Stage0Engine:
+    def __init__(self, model, opt, poses, device, rank=0, world_size=1, seed=0):
+        self.model, self.opt, self.device = model.to(device), opt, torch.device(device)
+        dev = self.device
+        assert dev.type == "cuda", "the step executor drives HIP kernels: no CPU path"
+        if not self.supported(model, opt):
+            raise ValueError("Stage0Engine covers the fused lego-style recipe (fused_mlp, fp16, no SDF / individual codes, power-of-two "
+                             "bound, shared encoder geometry); use trainer.Stage0Trainer for other configurations")
+        L.lib()
+        self.poses = poses.to(dev).float().contiguous()
+        self.rank, self.world = rank, world_size
+        self.global_step = 0
+        self.num_rays = opt.num_rays
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed + rank)
+        self.optimizer = FusedAdamAMP(model.get_params(opt.lr), eps=1e-15, amp=True)
+        self.images = None
+        self.boxes = synthetic.boxes(dev)
+        self.samples_seen = self.rays_seen = 0
+        self.last_num_points = 0
+        self._loss_pending, self._loss_sum = [], torch.zeros((), device=dev)
+        self.sync = None
+        if world_size > 1:
+            from .parallel import GradSync
+            self.sync = GradSync(model, world_size)
+        self.side = L.side_stream(dev, slot=2)
+        self.overlap = True                   # next batch on the side stream (False: everything on the main stream, same results)
+
+        e1, e2 = model.encoder, model.encoder_color
+        self.rows = e1.embeddings.shape[0]
+        self.Lv = e1.num_levels
+        self.S = float(np.log2(e1.per_level_scale))
+        self.H0 = int(e1.base_resolution)
+        self.ho = _host_offsets(e1)
+        self.aff = _affine(float(model.bound))
+        self.mlp_params = [p for m in (model.sigma_net, model.color_net, model.specular_net) for p in m.parameters()]
+        assert len(self.mlp_params) == 7
+        # persistent gradient buffers: both table gradients are fully rewritten by every backward (overwrite mode); the seven dW live
+        # in one flat buffer that is all-zero between steps (the field backward adds into it, the Adam kernel clears it)
+        self.g1 = torch.empty(self.rows, 1, dtype=torch.float32, device=dev)
+        self.g2 = torch.empty(self.rows, 2, dtype=torch.float16, device=dev)
+        self.dw = torch.zeros(sum(p.numel() for p in self.mlp_params), dtype=torch.float32, device=dev)
+        self.dw_views, o = [], 0
+        for p in self.mlp_params:
+            self.dw_views.append(self.dw[o:o + p.numel()])
+            o += p.numel()
+        self._desc = {}
+        self._bufs = [None, None]
+        self._cur = 0
+        self._work_cap = (0, 0)
+        self._next = None
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._loss = torch.empty(1, dtype=torch.float32, device=dev)
+        self._seed = None
+        self._aabb = None
+
+    # ------------------------------------------------------------------------------------------------ configuration
+    @staticmethod
+    def supported(model, opt):
+        e1, e2 = model.encoder, model.encoder_color
+        return (bool(getattr(opt, "fused_mlp", False)) and bool(opt.fp16) and not opt.sdf and getattr(opt, "ind_dim", 0) == 0
+                and _affine(float(model.bound)) is not None and same_geometry(e1, e2) and e1.embeddings.shape[1] == 1
+                and e2.embeddings.shape[1] == 2 and not getattr(opt, "progressive_level", False) and opt.lambda_entropy <= 0
+                and opt.patch_size == 1 and model.max_level >= e1.num_levels)
+
+    @property
+    def loss_acc(self):
+        if self._loss_pending:
+            self._loss_sum = self._loss_sum + torch.stack(self._loss_pending).sum()
+            self._loss_pending = []
+        return self._loss_sum
+
+    def mark_untrained(self):
+        if self.opt.mark_untrained:
+            f = synthetic.LEGO_FOCAL
+            self.model.mark_untrained_grid(self.poses, (f, f, synthetic.LEGO_HW / 2, synthetic.LEGO_HW / 2))
+
+    # ------------------------------------------------------------------------------------------------------ buffers
+    def _ray_bufs(self, N):
+        self._cur ^= 1
+        b = self._bufs[self._cur]
+        if b is None or b.cap < N:
+            b = self._bufs[self._cur] = _RayBufs(max(int(N * 1.5), 8192), self.device)
+        return b
+
+    def _sample_bufs(self, b, cap_m):
+        if b.samples is None or b.cap_m < cap_m:
+            b.cap_m = int(cap_m)
+            b.samples = torch.empty(b.cap_m * 8, dtype=torch.float32, device=self.device)
+        c = b.cap_m
+        s = b.samples
+        return s[:3 * c], s[3 * c:6 * c], s[6 * c:]
+
+    def _work(self, M, N):
+        """Step-local buffers, grow-only (level-major feature layouts are [16, M] with the step's own M as the stride)."""
+        cm, cn = self._work_cap
+        if M > cm or N > cn:
+            cm, cn = max(cm, int(M * 1.25) + 1024), max(cn, int(N * 1.5) + 1024)
+            dev = self.device
+            f = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+            w = self._w = {}
+            w["h1"], w["d_h1"] = f(16 * cm), f(16 * cm)
+            w["h2"] = torch.empty(32 * cm, dtype=torch.float16, device=dev)
+            w["d_h2"] = torch.empty(32 * cm, dtype=torch.float16, device=dev)
+            w["sigma"], w["rgb"], w["spec"], w["weights"], w["d_sr"] = f(cm), f(3 * cm), f(3 * cm), f(cm), f(4 * cm)
+            w["d_spec"] = f(3 * cm)
+            w["ws"], w["depth"], w["image"], w["d_image"], w["d_ws"], w["bg"] = f(cn), f(cn), f(3 * cn), f(3 * cn), f(cn), f(3 * cn)
+            w["partial"] = f((cn + 255) // 256 + 1)
+            w["zeros"] = torch.zeros(max(cm, 3 * cn), dtype=torch.float32, device=dev)
+            self._work_cap = (cm, cn)
+        return self._w
+
+    # ------------------------------------------------------------------------------------------------- next batch
+    def _prepare(self):
+        """Occupancy refresh on every 16th step (nerf/utils.py:1155-1156), then the next batch: rays, near/far, march pass 1, the count
+        on its way to the host, speculative pass 2.  Same draws, same order as Stage0Trainer._prepare."""
+        opt, model, dev = self.opt, self.model, self.device
+        refreshed = self.global_step % opt.update_extra_interval == 0
+        if refreshed:
+            if self.sync is not None:
+                self.sync.sync_rng_for_grid_update(self.global_step)
+            model.update_extra_state()
+        if self.images is None:
+            self.images = synthetic.preload_images(self.poses, self.boxes)
+        N = int(self.num_rays)
+        b = self._ray_bufs(N)
+        b.N, b.refreshed = N, refreshed
+        H = W = synthetic.LEGO_HW
+        f = float(synthetic.LEGO_FOCAL)
+        b.cam = torch.randint(0, self.poses.shape[0], (N,), device=dev, generator=self.gen)
+        b.pix = torch.randint(0, H * W, (N,), device=dev, generator=self.gen)
+        s = L.stream()
+        L.call("n2m_get_rays", _p(self.poses), _p(b.cam), _p(b.pix), N, H, W, f, f, W / 2, H / 2, _p(self.images), _p(b.o), _p(b.d), _p(b.rgba), s)
+        if self._aabb is None or self._aabb is not model.aabb_train:
+            self._aabb = model.aabb_train
+        L.call("n2m_near_far_from_aabb", _p(b.o), _p(b.d), _p(self._aabb), N, float(model.min_near), _p(b.nears), _p(b.fars), s)
+        b.noises = torch.rand(N, dtype=torch.float32, device=dev)
+        bits = model.density_bitfield
+        b.args = (_p(b.o), _p(b.d), _p(bits), float(model.real_bound), int(bool(opt.contract)), float(opt.dt_gamma), int(opt.max_steps), N,
+                  int(model.cascade), int(model.grid_size), _p(b.nears), _p(b.fars))
+        b.bits = bits
+        b.counter.zero_()
+        L.call("n2m_march_rays_train", *b.args, None, None, None, _p(b.rays), _p(b.counter), _p(b.noises), s)
+        b.host_count.copy_(b.counter, non_blocking=True)
+        b.count_ready.record()
+        expect = 0 if self.last_num_points <= 0 else ((int(1.25 * max(self.last_num_points, 1024)) + 1023) // 1024) * 1024
+        b.spec = False
+        if expect > 0:
+            x, d, t = self._sample_bufs(b, expect)
+            L.call("n2m_march_rays_train_write", *b.args, _p(x), _p(d), _p(t), _p(b.rays), _p(b.noises), b.cap_m, s)
+            b.spec = True
+        b.written.record()
+        return b
+
+    def _prepare_side(self):
+        main = torch.cuda.current_stream(self.device)
+        if not self.overlap:
+            return self._prepare()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            b = self._prepare()
+        for t in (b.cam, b.pix, b.noises):
+            t.record_stream(main)
+        return b
+
+    def _finish(self, b):
+        """Sample count of batch b on the host; sample tensors (the speculative ones, or an exact re-march when they did not fit)."""
+        b.count_ready.synchronize()
+        M = int(b.host_count[0])
+        torch.cuda.current_stream(self.device).wait_event(b.written)
+        if M > 0 and not (b.spec and M <= b.cap_m):
+            x, d, t = self._sample_bufs(b, ((int(1.25 * M) + 1023) // 1024) * 1024)
+            L.call("n2m_march_rays_train_write", *b.args, _p(x), _p(d), _p(t), _p(b.rays), _p(b.noises), b.cap_m, L.stream())
+        return M
+
+    # ------------------------------------------------------------------------------------------------------- Adam
+    def _adam_desc(self, full):
+        """The N2mAdamDesc of this model (pointers are fixed for the life of the engine); `full`: the specular head takes part."""
+        d = self._desc.get(full)
+        if d is not None:
+            return d
+        o, model = self.optimizer, self.model
+        pk = model.packed_tables()
+        assert pk is not None
+        self._packed = pk
+        desc = L.AdamDesc()
+        params = [p for g in o.param_groups for p in g["params"]]
+        grads = {model.encoder.embeddings: (self.g1, 0, 0, (pk, 2)), model.encoder_color.embeddings: (self.g2, 1, 0, (pk, 3))}
+        for i, p in enumerate(self.mlp_params):
+            grads[p] = (self.dw_views[i], 0, 1, None)
+        live = set(params[:2]) | set(self.mlp_params[:5]) | (set(self.mlp_params[5:]) if full else set())
+        k, participants, groups = 0, 0, []
+        group_of = {p: gi for gi, g in enumerate(o.param_groups) for p in g["params"]}
+        for p in params:
+            if p not in live:
+                continue
+            groups.append(group_of[p])
+            g, is_half, clear, sh = grads[p]
+            st = o.state[p]
+            desc.param[k], desc.grad[k] = p.data_ptr(), g.data_ptr()
+            desc.exp_avg[k], desc.exp_avg_sq[k] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            desc.half_shadow[k] = sh[0].data_ptr() if sh is not None else None
+            desc.shadow_mode[k] = sh[1] if sh is not None else 0
+            desc.numel[k], desc.grad_is_half[k], desc.clear_grad[k] = p.numel(), is_half, clear
+            desc.slot[k] = o._slot[p]
+            participants |= 1 << (o._slot[p] - 1)
+            k += 1
+        desc.count = k
+        d = self._desc[full] = (desc, participants, groups)
+        return d
+
+    def _optimizer_step(self, full, lr_factor):
+        o = self.optimizer
+        desc, participants, groups = self._adam_desc(full)
+        for k, gi in enumerate(groups):
+            desc.lr[k] = float(o.param_groups[gi]["initial_lr"]) * lr_factor
+        b1, b2 = o.param_groups[0]["betas"]
+        s = L.stream()
+        L.call("n2m_adam_step", ctypes.addressof(desc), float(b1), float(b2), float(o.param_groups[0]["eps"]), _p(o.scale), _p(o.found_inf),
+               _p(o.bias), s)
+        gf, bf, gi = o.growth
+        L.call("n2m_scaler_update_slots", _p(o.scale), _p(o.growth_tracker), _p(o.found_inf), _p(o.steps), _p(o.bias), participants,
+               float(b1), float(b2), gf, bf, gi, s)
+        nxt = lr_lambda(self.global_step, self.opt.iters)          # like LambdaLR.step(): param_groups carry the NEXT step's rate
+        for group in o.param_groups:
+            group["lr"] = float(group["initial_lr"]) * nxt
+
+    # ------------------------------------------------------------------------------------------------------- step
+    @torch.no_grad()
+    def train_step(self):
+        opt, model, dev = self.opt, self.model, self.device
+        if not model.training:
+            model.train()
+        for g in self.optimizer.param_groups:
+            g.setdefault("initial_lr", g["lr"])
+        if self._next is None:
+            self._next = self._prepare()
+        b = self._next
+        self._next = None
+        self.global_step += 1
+        N = b.N
+        random_bg = opt.background != "white"
+        if random_bg:
+            bg = torch.rand(N, 3, device=dev, generator=self.gen)
+        shading = SHADING["diffuse" if (self.global_step < opt.diffuse_step or opt.diffuse_only) else "full"]
+        refresh_next = self.global_step % opt.update_extra_interval == 0
+
+        M = self._finish(b)
+        self.last_num_points = M
+        if opt.adaptive_num_rays and M > 0:                                  # nerf/utils.py:796-797
+            self.num_rays = max(1, int(round((opt.num_points / M) * self.num_rays)))
+        if not refresh_next:
+            self._next = self._prepare_side()        # beside this step's kernels: it reads only the cameras and the occupancy bit field
+        self.samples_seen += M
+        self.rays_seen += N
+
+        w = self._work(max(M, 1), N)
+        s = L.stream()
+        c = b.cap_m
+        xyzs = dirs = ts = None
+        if M > 0:
+            xyzs, dirs, ts = b.samples[:3 * c], b.samples[3 * c:6 * c], b.samples[6 * c:]
+        o = self.optimizer
+        pk = model.packed_tables()
+        sw = self.mlp_params
+        e1 = model.encoder
+        # ---- forward
+        if M > 0:
+            L.call("n2m_grid_encode_forward_packed", _p(xyzs), _p(pk), _p(e1.offsets), _p(w["h1"]), _p(w["h2"]), M, self.Lv, self.Lv, self.S,
+                   self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, float(self.aff[0]), float(self.aff[1]), s)
+            L.call("n2m_field_forward", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 1,
+                   _p(w["sigma"]), _p(w["rgb"]), _p(w["spec"]) if shading != 0 else None, s)
+        L.call("n2m_composite_rays_train_forward", _p(w["sigma"]), _p(w["rgb"]), _p(ts), _p(b.rays), M, N, 1e-4, 0, _p(w["weights"]), _p(w["ws"]),
+               _p(w["depth"]), _p(w["image"]), s)
+        bg_t, bg_s = (bg, 0.0) if random_bg else (None, 1.0)
+        lam_rgb, lam_mask = float(opt.lambda_rgb), float(max(opt.lambda_mask, 0.0))
+        L.call("n2m_photo_loss_forward", _p(w["image"]), _p(w["ws"]), _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask, N, _p(w["partial"]),
+               _p(self._ticket), _p(self._loss), s)
+        loss = self._loss.clone().view(())
+        # ---- backward (seed gradient = loss scale [/ world]: gradients are SUMMED over ranks)
+        seed = o.scale if self.world == 1 else o.scale / self.world
+        if M > 0:
+            L.call("n2m_photo_loss_backward", _p(w["image"]), _p(w["ws"]), _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask, N, _p(seed),
+                   _p(w["d_image"]), _p(w["d_ws"]), s)
+            z = w["zeros"]
+            d_sigma, d_rgb = w["d_sr"][:M], w["d_sr"][M:4 * M]
+            L.call("n2m_composite_rays_train_backward", _p(z), _p(w["d_ws"]), _p(z), _p(w["d_image"]), _p(w["sigma"]), _p(w["rgb"]), _p(ts),
+                   _p(b.rays), _p(w["ws"]), _p(w["depth"]), _p(w["image"]), M, N, 1e-4, 0, _p(d_sigma), _p(d_rgb), s)
+            d_spec = None
+            if shading != 0 and opt.lambda_specular > 0:
+                # + lambda_specular * mean_m sum_c spec^2 (nerf/utils.py:735-737): d/dspec = 2 lambda / M * spec, times the seed
+                spec_m = w["spec"][:3 * M]
+                loss = loss + opt.lambda_specular * (spec_m * spec_m).sum() / M
+                d_spec = w["d_spec"][:3 * M]
+                torch.mul(spec_m, seed * (2.0 * opt.lambda_specular / M), out=d_spec)
+            L.call("n2m_field_backward", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 1,
+                   _p(d_sigma), _p(d_rgb), _p(d_spec), _p(w["d_h1"]), _p(w["d_h2"]), *[_p(g) for g in self.dw_views], _p(o.found_inf), s)
+            need = L.lib().n2m_grid_binned_pair_workspace_bytes(M, self.Lv, self.ho.ctypes.data)
+            ws = L.workspace(dev, need)
+            tv = opt.lambda_tv > 0
+            L.call("n2m_grid_encode_backward_binned_pair", _p(w["d_h1"]), _p(w["d_h2"]), _p(xyzs), self.ho.ctypes.data, _p(self.g1), _p(self.g2), M,
+                   self.Lv, self.Lv, self.S, self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id,
+                   _p(e1.embeddings) if tv else None, float(opt.lambda_tv), float(opt.lambda_tv * (10 if opt.bound > 1 else 1)),
+                   float(0.5 / model.bound), _p(seed) if tv else None, _p(o.found_inf), float(self.aff[0]), float(self.aff[1]), 1, _p(ws),
+                   ws.numel(), s)
+        else:
+            # no sample in the batch: every gradient is zero (the reduction below still takes part on every rank)
+            self.g1.zero_()
+            self.g2.zero_()
+        # ---- [multi-GPU] one SUM all-reduce per fixed gradient buffer (the colour table's stays fp16) + the small bucket
+        if self.sync is not None:
+            token = self.sync.all_reduce_sum_begin([self.g1, self.g2], [self.dw, o.found_inf])
+            self.sync.all_reduce_sum_end(token)
+        # ---- Adam + loss-scale bookkeeping, LR schedule (main.py:239)
+        self._lr_step(shading != 0)
+        self._loss_pending.append(loss.detach())
+        if len(self._loss_pending) >= 1024:
+            _ = self.loss_acc
+        if self._next is None:
+            self._next = self._prepare()          # refresh steps: behind the optimizer update, like the reference (refresh -> batch -> march)
+        return loss
+
+    def _lr_step(self, full):
+        if full is not None:
+            self._optimizer_step(full, lr_lambda(self.global_step - 1, self.opt.iters))
+
+    @torch.no_grad()
+    def eval_psnr(self, cam=0, downscale=4):
+        from .trainer import Stage0Trainer
+        return Stage0Trainer.eval_psnr(self, cam, downscale)

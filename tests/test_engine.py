@@ -1,0 +1,75 @@
+"""The step executor (nerf2mesh_amd/engine.py) against the autograd-driven trainer it replaces on the fast path: same kernels, same
+arguments, same random draws -> same parameters.  What one iteration does follows nerf/utils.py:628-823,1152-1190 and main.py:221-241
+(see trainer.Stage0Trainer, whose own parity tests are tests/test_mlp_parity.py, tests/test_optim.py, tests/test_configs.py)."""
+import numpy as np
+import pytest
+import torch
+
+
+def _run(cls, steps, **over):
+    from nerf2mesh_amd import synthetic
+    from nerf2mesh_amd.network import NeRFNetwork
+    from nerf2mesh_amd.options import make_options
+    torch.manual_seed(0)
+    opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=True, **over)
+    dev = torch.device("cuda", 0)
+    tr = cls(NeRFNetwork(opt), opt, synthetic.make_cameras(6, seed=0), dev, seed=0)
+    tr.mark_untrained()
+    losses = [float(tr.train_step()) for _ in range(steps)]
+    torch.cuda.synchronize()
+    return tr, losses
+
+
+@pytest.mark.gpu
+def test_engine_reproduces_the_autograd_trainer():
+    from nerf2mesh_amd.engine import Stage0Engine
+    from nerf2mesh_amd.trainer import Stage0Trainer
+    steps = 40                              # crosses two occupancy refreshes (16, 32) and the diffuse -> full switch
+    a, la = _run(Stage0Trainer, steps, diffuse_step=24)
+    b, lb = _run(Stage0Engine, steps, diffuse_step=24)
+    assert a.samples_seen == b.samples_seen and a.rays_seen == b.rays_seen, "same batches, same sample counts"
+    assert a.num_rays == b.num_rays
+    np.testing.assert_allclose(la, lb, rtol=2e-4, atol=1e-7)
+    # Parameters: Adam divides by sqrt(v), so rows whose gradient is rounding noise (float atomics of the weight gradients and of the
+    # three smallest dense levels sum in arrival order) move by +-lr whatever the noise says -- two runs of the SAME driver differ
+    # there too.  The yardstick is therefore a second run of the trainer: the executor must be as close to it as it is to itself.
+    a2, _ = _run(Stage0Trainer, steps, diffuse_step=24)
+
+    def rel(p, q):
+        return ((p - q).norm() / p.norm().clamp_min(1e-30)).item()
+    for (n, p), (_, q), (_, r) in zip(a.model.named_parameters(), b.model.named_parameters(), a2.model.named_parameters()):
+        d_te, d_tt = rel(p, q), rel(p, r)
+        print(f"{n:36s} trainer-vs-engine {d_te:.3g}   trainer-vs-trainer {d_tt:.3g}")
+        assert d_te <= 10 * d_tt + 2e-4, f"{n}: executor differs from the trainer by {d_te:.3g}, two trainer runs differ by {d_tt:.3g}"
+    occ = lambda t: np.unpackbits(t.model.density_bitfield.cpu().numpy())
+    assert (occ(a) != occ(b)).mean() <= max(3 * (occ(a) != occ(a2)).mean(), 1e-4)
+    sa, sb = a.optimizer, b.optimizer
+    assert torch.equal(sa.scale, sb.scale) and torch.equal(sa.steps, sb.steps)
+    for g, h in zip(sa.param_groups, sb.param_groups):
+        assert abs(g["lr"] - h["lr"]) <= 1e-12 * max(g["lr"], 1e-30)
+
+
+@pytest.mark.gpu
+def test_engine_serial_schedule_equals_overlapped():
+    """overlap=False (next batch on the main stream) is the same computation in a different order of issue."""
+    from nerf2mesh_amd.engine import Stage0Engine
+
+    class Serial(Stage0Engine):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.overlap = False
+    a, la = _run(Stage0Engine, 20)
+    b, lb = _run(Serial, 20)
+    assert a.samples_seen == b.samples_seen
+    np.testing.assert_allclose(la, lb, rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_engine_rejects_configurations_outside_the_fast_path():
+    from nerf2mesh_amd import synthetic
+    from nerf2mesh_amd.engine import Stage0Engine
+    from nerf2mesh_amd.network import NeRFNetwork
+    from nerf2mesh_amd.options import make_options
+    opt = make_options(O=True, bound=1, dt_gamma=0, sdf=True, fused_mlp=True)
+    with pytest.raises(ValueError):
+        Stage0Engine(NeRFNetwork(opt), opt, synthetic.make_cameras(4, seed=0), torch.device("cuda", 0))
