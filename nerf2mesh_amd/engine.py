@@ -37,7 +37,9 @@ def lr_lambda(it, iters):
 
 
 class _RayBufs:
-    """Per-batch ray-side tensors (two sets alternate: batch i+1 is produced while batch i is consumed)."""
+    """Per-batch ray-side tensors.  Three sets rotate: batch i+1 is produced on the side stream while batch i is consumed; `consumed`
+    (the main-stream marker of the step AFTER the one that read the set) is what the next producer of the set waits for on the host,
+    which also keeps the host from running more than two steps ahead of the GPU."""
 
     def __init__(self, cap, dev):
         self.cap = cap
@@ -48,7 +50,8 @@ class _RayBufs:
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.host_count = torch.empty(1, dtype=torch.int32, pin_memory=True)
         self.count_ready = torch.cuda.Event()
-        self.written = torch.cuda.Event()
+        self.consumed = None
+        self.loss = torch.empty(1, dtype=torch.float32, device=dev)
         self.samples = None          # [cap_m, 8] fp32: xyzs | dirs | ts (speculative write pass)
         self.cap_m = 0
         self.N = 0
@@ -105,12 +108,13 @@ class Stage0Engine:
             self.dw_views.append(self.dw[o:o + p.numel()])
             o += p.numel()
         self._desc = {}
-        self._bufs = [None, None]
+        self._bufs = [None, None, None]
+        self._marker = self._prev = None
         self._cur = 0
+
         self._work_cap = (0, 0)
         self._next = None
         self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._loss = torch.empty(1, dtype=torch.float32, device=dev)
         self._seed = None
         self._aabb = None
 
@@ -125,9 +129,6 @@ class Stage0Engine:
 
     @property
     def loss_acc(self):
-        if self._loss_pending:
-            self._loss_sum = self._loss_sum + torch.stack(self._loss_pending).sum()
-            self._loss_pending = []
         return self._loss_sum
 
     def mark_untrained(self):
@@ -137,8 +138,11 @@ class Stage0Engine:
 
     # ------------------------------------------------------------------------------------------------------ buffers
     def _ray_bufs(self, N):
-        self._cur ^= 1
+        self._cur = (self._cur + 1) % len(self._bufs)
         b = self._bufs[self._cur]
+        if b is not None and b.consumed is not None:
+            b.consumed.synchronize()          # the step that read this set has finished on the GPU
+            b.consumed = None
         if b is None or b.cap < N:
             b = self._bufs[self._cur] = _RayBufs(max(int(N * 1.5), 8192), self.device)
         return b
@@ -203,20 +207,17 @@ class Stage0Engine:
         L.call("n2m_march_rays_train", *b.args, None, None, None, _p(b.rays), _p(b.counter), _p(b.noises), s)
         b.host_count.copy_(b.counter, non_blocking=True)
         b.count_ready.record()
-        expect = 0 if self.last_num_points <= 0 else ((int(1.25 * max(self.last_num_points, 1024)) + 1023) // 1024) * 1024
-        b.spec = False
-        if expect > 0:
-            x, d, t = self._sample_bufs(b, expect)
-            L.call("n2m_march_rays_train_write", *b.args, _p(x), _p(d), _p(t), _p(b.rays), _p(b.noises), b.cap_m, s)
-            b.spec = True
-        b.written.record()
         return b
 
     def _prepare_side(self):
+        """_prepare() on the side stream (rays, near/far, march pass 1, count to the host)."""
         main = torch.cuda.current_stream(self.device)
         if not self.overlap:
             return self._prepare()
-        self.side.wait_stream(main)
+        # Behind everything already queued on the main stream: the pass then starts together with the next step and runs beside its
+        # forward kernels.  (Letting it run further ahead was measured slower: its small launches queue up behind the field backward,
+        # whose workgroups own every CU, and the march then lands on the table backward.)
+        self.side.wait_event(self._marker)
         with torch.cuda.stream(self.side):
             b = self._prepare()
         for t in (b.cam, b.pix, b.noises):
@@ -224,12 +225,13 @@ class Stage0Engine:
         return b
 
     def _finish(self, b):
-        """Sample count of batch b on the host; sample tensors (the speculative ones, or an exact re-march when they did not fit)."""
+        """Sample count of batch b on the host, then pass 2 (the write pass) on the MAIN stream into buffers that fit.  The host has
+        waited for the event behind the offset scan, so the main stream needs no cross-stream dependency on the side stream (a
+        barrier packet there cost the step ~25 us of idle queue, measured); with the prefix-maximum marcher the pass is ~25 us."""
         b.count_ready.synchronize()
         M = int(b.host_count[0])
-        torch.cuda.current_stream(self.device).wait_event(b.written)
-        if M > 0 and not (b.spec and M <= b.cap_m):
-            x, d, t = self._sample_bufs(b, ((int(1.25 * M) + 1023) // 1024) * 1024)
+        if M > 0:
+            x, d, t = self._sample_bufs(b, ((int(1.25 * M) + 1023) // 1024) * 1024 if b.cap_m < M else b.cap_m)
             L.call("n2m_march_rays_train_write", *b.args, _p(x), _p(d), _p(t), _p(b.rays), _p(b.noises), b.cap_m, L.stream())
         return M
 
@@ -305,6 +307,15 @@ class Stage0Engine:
         shading = SHADING["diffuse" if (self.global_step < opt.diffuse_step or opt.diffuse_only) else "full"]
         refresh_next = self.global_step % opt.update_extra_interval == 0
 
+        # ONE event per step on the main stream (an event record is a marker packet the queue idles ~6 us behind, measured; a second
+        # one between the table backward and Adam cost as much again).  It is behind everything of the previous step, so it serves as
+        # the side stream's go-ahead for the next batch AND as "the previous batch's buffers are free".
+        b.count_ready.synchronize()
+        self._marker = torch.cuda.Event()
+        self._marker.record()
+        if self._prev is not None:
+            self._prev.consumed = self._marker
+        self._prev = b
         M = self._finish(b)
         self.last_num_points = M
         if opt.adaptive_num_rays and M > 0:                                  # nerf/utils.py:796-797
@@ -335,8 +346,8 @@ class Stage0Engine:
         bg_t, bg_s = (bg, 0.0) if random_bg else (None, 1.0)
         lam_rgb, lam_mask = float(opt.lambda_rgb), float(max(opt.lambda_mask, 0.0))
         L.call("n2m_photo_loss_forward", _p(w["image"]), _p(w["ws"]), _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask, N, _p(w["partial"]),
-               _p(self._ticket), _p(self._loss), s)
-        loss = self._loss.clone().view(())
+               _p(self._ticket), _p(b.loss), s)
+        loss = b.loss.view(())                 # lives in the batch's buffer set: valid until the set is reused three steps later
         # ---- backward (seed gradient = loss scale [/ world]: gradients are SUMMED over ranks)
         seed = o.scale if self.world == 1 else o.scale / self.world
         if M > 0:
@@ -373,9 +384,7 @@ class Stage0Engine:
             self.sync.all_reduce_sum_end(token)
         # ---- Adam + loss-scale bookkeeping, LR schedule (main.py:239)
         self._lr_step(shading != 0)
-        self._loss_pending.append(loss.detach())
-        if len(self._loss_pending) >= 1024:
-            _ = self.loss_acc
+        self._loss_sum += loss.view(())        # running sum on the device (the value itself lives in a rotating buffer)
         if self._next is None:
             self._next = self._prepare()          # refresh steps: behind the optimizer update, like the reference (refresh -> batch -> march)
         return loss
