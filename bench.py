@@ -190,11 +190,24 @@ def main():
     from nerf2mesh_amd.parallel import init_from_env
     from nerf2mesh_amd.trainer import Stage0Trainer
 
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher -- one rank per GPU under torch.distributed.run, exactly
+        # the command the driver uses (the JSON line then reports n_gpus = the rank count that actually ran)
+        n_dev = torch.cuda.device_count()
+        shared = os.environ.get("N2M_DIST_BACKEND") == "gloo"        # test mode: ranks may share a device over gloo
+        if n_dev < args.gpus and not shared:
+            sys.exit(f"[bench] --gpus {args.gpus} but only {n_dev} GPU(s) are visible: refusing to measure fewer ranks than asked for")
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     rank, world, local = init_from_env()
     if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+        sys.exit(f"[bench] launched with WORLD_SIZE={world} but --gpus {args.gpus}: the two must agree")
     local = local % torch.cuda.device_count()          # ranks beyond the visible GPUs share devices (gloo test runs only)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -284,7 +297,7 @@ def main():
         "rays_per_sec": rays / dt,
         "config": {"workload": "nerf_synthetic/lego stage-0 -O --bound 1 --dt_gamma 0, 800x800 x 100 synthetic views, "
                                "num_points target 2^18/GPU (adaptive num_rays), occupancy refresh every 16 steps",
-                   "parallelism": f"dp{world} (rays sharded, grad all-reduce)" if world > 1 else "single GPU",
+                   "parallelism": f"dp{world} (rays sharded, grad all-reduce over {dist.get_backend()})" if world > 1 else "single GPU",
                    "mlp": "nn.Linear (unfused)" if args.unfused else "fused MFMA field kernels",
                    "driver": "engine.Stage0Engine (fixed launch sequence)" if use_engine else "trainer.Stage0Trainer (torch.autograd)", "pretrain_steps": args.pretrain, "samples_per_step_per_gpu": samples / args.steps / world,
                    "rays_per_step_per_gpu": rays / args.steps / world, "params": 18367240},

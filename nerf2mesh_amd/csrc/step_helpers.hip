@@ -335,6 +335,10 @@ extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, f
     uint32_t blocks = 0;
     for (uint32_t k = 0; k < d->count; ++k) {
         N2M_REQUIRE(d->param[k] && d->grad[k] && d->exp_avg[k] && d->exp_avg_sq[k], N2M_ENULL, "adam_step: NULL tensor %u", k);
+        // the kernel moves float4 / half4 vectors; gfx950 global accesses need element (dword / half-pair) alignment only, so views at
+        // any element offset of a flat gradient buffer are fine (tests/test_optim.py drives a 12-byte-offset view) -- but not less
+        N2M_REQUIRE((((uintptr_t)d->param[k] | (uintptr_t)d->grad[k] | (uintptr_t)d->exp_avg[k] | (uintptr_t)d->exp_avg_sq[k]) & 3u) == 0,
+                    N2M_EINVAL, "adam_step: tensor %u is not 4-byte aligned (param/grad/exp_avg/exp_avg_sq)", k);
         t.p[k] = (uint64_t)d->param[k]; t.g[k] = (uint64_t)d->grad[k]; t.m[k] = (uint64_t)d->exp_avg[k]; t.v[k] = (uint64_t)d->exp_avg_sq[k];
         t.shadow[k] = (uint64_t)d->half_shadow[k];
         t.n[k] = d->numel[k];

@@ -238,10 +238,11 @@ class Stage0Engine:
     # ------------------------------------------------------------------------------------------------------- Adam
     def _adam_desc(self, full):
         """The N2mAdamDesc of this model (pointers are fixed for the life of the engine); `full`: the specular head takes part."""
-        d = self._desc.get(full)
+        o, model = self.optimizer, self.model
+        key = (full, getattr(o, "state_epoch", 0))
+        d = self._desc.get(key)
         if d is not None:
             return d
-        o, model = self.optimizer, self.model
         pk = model.packed_tables()
         assert pk is not None
         self._packed = pk
@@ -268,7 +269,7 @@ class Stage0Engine:
             participants |= 1 << (o._slot[p] - 1)
             k += 1
         desc.count = k
-        d = self._desc[full] = (desc, participants, groups)
+        d = self._desc[key] = (desc, participants, groups)
         return d
 
     def _optimizer_step(self, full, lr_factor):

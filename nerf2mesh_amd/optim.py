@@ -46,6 +46,32 @@ class FusedAdamAMP(torch.optim.Optimizer):
         self.ext_grads = {}        # param -> callable returning an fp32 gradient that lives in a PERSISTENT buffer its producer adds into
                                    # (or None): the Adam kernel zeroes it after reading, so the producer needs no zero-fill launch
 
+    def state_dict(self):
+        """torch's optimizer state (exp_avg / exp_avg_sq per parameter, param_groups) + what torch keeps in state[p]["step"] and in a
+        separate GradScaler: per-slot step counts, loss scale, growth tracker.  A resumed run continues its bias corrections and its
+        loss scale where the saved one stopped (the reference saves optimizer and scaler state side by side, nerf/utils.py:1336-1350)."""
+        sd = super().state_dict()
+        sd["n2m_amp"] = {"steps": self.steps.detach().cpu().clone(), "scale": float(self.scale), "growth_tracker": float(self.growth_tracker),
+                         "amp": self.amp, "growth": self.growth}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        extra = state_dict.pop("n2m_amp", None)
+        super().load_state_dict(state_dict)
+        if extra is not None:
+            self.steps.copy_(extra["steps"].to(self.steps.device))
+            self.scale.fill_(extra["scale"])
+            self.growth_tracker.fill_(extra["growth_tracker"])
+            self.growth = tuple(extra.get("growth", self.growth))
+            # bias corrections of the NEXT step of every slot, like n2m_scaler_update_slots leaves them (double arithmetic)
+            b1, b2 = self.param_groups[0]["betas"]
+            t = self.steps.double().cpu() + 1
+            bias = torch.stack([1.0 - torch.tensor(b1, dtype=torch.float64) ** t, (1.0 - torch.tensor(b2, dtype=torch.float64) ** t).sqrt()], dim=1)
+            self.bias.copy_(bias.float().to(self.bias.device))
+        self.found_inf.zero_()
+        self.state_epoch = getattr(self, "state_epoch", 0) + 1      # the moment tensors were replaced: cached N2mAdamDesc pointers are stale
+
     def scale_loss(self, loss, world=1):
         """loss * scale / world: with gradients SUMMED over `world` ranks the update sees their mean."""
         f = (self.scale / world if world > 1 else self.scale) if self.amp else (1.0 / world if world > 1 else None)

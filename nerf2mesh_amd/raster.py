@@ -133,18 +133,19 @@ def antialias_construct_topology_hash(tri):
     return table
 
 
-_topology_cache = {}
+_topology_cache = {}      # id(tri) -> (weakref to tri, version, table): an entry dies with its tensor, so a new tensor that lands on a
+                          # freed one's address (same face count after remeshing) can never pick up the stale edge table
 
 
 def _topology(tri):
-    key = (tri.data_ptr(), tri._version, tri.shape[0])
-    t = _topology_cache.get(key)
-    if t is None:
-        if len(_topology_cache) > 8:
-            _topology_cache.clear()
-        t = antialias_construct_topology_hash(tri)
-        _topology_cache[key] = t
-    return t
+    import weakref
+    key = id(tri)
+    hit = _topology_cache.get(key)
+    if hit is not None and hit[0]() is tri and hit[1] == tri._version:
+        return hit[2]
+    table = antialias_construct_topology_hash(tri)
+    _topology_cache[key] = (weakref.ref(tri, lambda _r, k=key: _topology_cache.pop(k, None)), tri._version, table)
+    return table
 
 
 class _antialias(Function):

@@ -354,6 +354,10 @@ class Stage1Trainer:
         model.init_stage1(vertices, triangles)
         params = model.get_params(opt.lr) + [{"params": model.vertices_offsets, "lr": opt.lr_vert, "weight_decay": 0}]
         self.optimizer = torch.optim.Adam(params, eps=1e-15, fused=(device.type == "cuda"))
+        iters = opt.iters
+        # main.py:239 applies the same schedule to both stages: 0.01 -> 1 over 500 iterations, then 0.1 ** ((it - 500) / (iters - 500))
+        self.scheduler = torch.optim.lr_scheduler.LambdaLR(
+            self.optimizer, lambda it: 0.01 + 0.99 * (it / 500) if it <= 500 else 0.1 ** ((it - 500) / (iters - 500)))
         self.scaler = torch.amp.GradScaler("cuda", enabled=bool(opt.fp16))
         self.sync = GradSync(model, world_size) if world_size > 1 else None
         self.boxes = synthetic.boxes(device)
@@ -387,7 +391,8 @@ class Stage1Trainer:
         gt_mask = rgba[:, 3:]
         gt_rgb = rgba[:, :3] * gt_mask + bg * (1 - gt_mask)
         self.optimizer.zero_grad(set_to_none=True)
-        out = model.render_stage1(rays_o, rays_d, self.mvps[v], self.H, self.W, bg_color=bg, shading="full")
+        shading = "diffuse" if opt.diffuse_only else "full"                  # nerf/utils.py:669-672 (diffuse_step only gates stage 0)
+        out = model.render_stage1(rays_o, rays_d, self.mvps[v], self.H, self.W, bg_color=bg, shading=shading)
         loss = opt.lambda_rgb * F.mse_loss(out["image"], gt_rgb, reduction="none").mean(-1)
         if opt.lambda_mask > 0:
             loss = loss + opt.lambda_mask * F.mse_loss(out["weights_sum"].view(-1), gt_mask.view(-1), reduction="none")
@@ -396,11 +401,18 @@ class Stage1Trainer:
         loss = loss.mean()
         if opt.lambda_lap > 0:
             loss = loss + opt.lambda_lap * self.laplacian(model.vertices + model.vertices_offsets)
-        if opt.lambda_offsets > 0:
-            loss = loss + opt.lambda_offsets * (model.vertices_offsets ** 2).sum(-1).mean()
+        if opt.lambda_offsets > 0:                                           # nerf/utils.py:772-789
+            off = model.vertices_offsets
+            if opt.bound > 1:       # inner mesh (cascade 0) + 0.1 x the outer cascades' meshes
+                n_in = int(model.v_cumsum[1])
+                loss_offsets = (off[:n_in] ** 2).sum(-1).mean() + 0.1 * (off[n_in:] ** 2).sum(-1).mean()
+            else:
+                loss_offsets = (off ** 2).sum(-1).mean()
+            loss = loss + opt.lambda_offsets * loss_offsets
         self.scaler.scale(loss).backward()
         if self.sync is not None:
             self.sync.all_reduce()
         self.scaler.step(self.optimizer)
         self.scaler.update()
+        self.scheduler.step()
         return loss

@@ -140,3 +140,43 @@ def test_adam_counts_steps_per_parameter():
         opt.step(); ref.step()
     assert torch.allclose(a, ra, rtol=1e-5, atol=1e-7) and torch.allclose(c, rc, rtol=1e-5, atol=1e-7)
     assert float(opt.steps[0]) == 7 and float(opt.steps[1]) == 7 and float(opt.steps[2]) == 4
+
+
+def test_state_dict_round_trip_resumes_bias_corrections_and_loss_scale():
+    """Checkpoint / resume (the reference saves optimizer + scaler state, nerf/utils.py:1336-1350): a FusedAdamAMP restored from
+    state_dict() continues exactly like the one that kept running -- moments, per-slot step counts (bias corrections), loss scale,
+    growth tracker -- also for a parameter that joined late."""
+    import io
+    import torch
+    from nerf2mesh_amd.optim import FusedAdamAMP
+    torch.manual_seed(1)
+    shapes = [(512, 2), (64, 35), (32, 6)]
+
+    def make(src=None):
+        ps = [(torch.randn(s, device="cuda") if src is None else src[i].detach().clone()).requires_grad_() for i, s in enumerate(shapes)]
+        return ps, FusedAdamAMP([{"params": [p], "lr": 1e-2} for p in ps], eps=1e-15, init_scale=256.0, growth_interval=2)
+
+    def step(ps, opt, k, late=True):
+        g = torch.Generator(device="cuda").manual_seed(100 + k)
+        for i, p in enumerate(ps):
+            p.grad = None if (i == 2 and not late) else torch.randn(p.shape, device="cuda", generator=g) * float(opt.scale)
+        if k == 2:
+            ps[0].grad[0, 0] = float("inf")              # one skipped step: the scale backs off
+        opt.step()
+
+    a, oa = make()
+    for k in range(5):
+        step(a, oa, k, late=k >= 3)                      # the third tensor gets its first gradient at k = 3
+    buf = io.BytesIO()
+    torch.save(oa.state_dict(), buf)
+    buf.seek(0)
+    b, ob = make(src=a)
+    ob.load_state_dict(torch.load(buf, weights_only=False))
+    assert float(ob.scale) == float(oa.scale) and torch.equal(ob.steps, oa.steps) and float(ob.growth_tracker) == float(oa.growth_tracker)
+    assert torch.allclose(ob.bias, oa.bias, rtol=1e-6, atol=0)
+    for k in range(5, 9):
+        step(a, oa, k)
+        step(b, ob, k)
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+    assert float(ob.scale) == float(oa.scale) and torch.equal(ob.steps, oa.steps)

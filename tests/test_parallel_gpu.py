@@ -12,9 +12,36 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_two_ranks_stay_bit_identical_and_learn():
+@pytest.mark.parametrize("driver", ["trainer", "engine"])
+def test_two_ranks_stay_bit_identical_and_learn(driver):
     env = dict(os.environ, N2M_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "tools", "dist_check.py"), "40"]
+           "--master-port", "29517" if driver == "trainer" else "29519", os.path.join(ROOT, "tools", "dist_check.py"), "40", driver]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DIST_CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_spawns_the_ranks_it_is_asked_for():
+    """`python bench.py --gpus 2` with no launcher around it re-executes itself under torch.distributed.run: the JSON line says
+    n_gpus = 2 and names the backend the ranks really used (here gloo, two ranks on the one GPU of the test box)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(N2M_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--pretrain", "20",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "gloo" in d["config"]["parallelism"]
+    assert d["config"]["samples_per_step_per_gpu"] > 1e5 and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_refuses_a_rank_count_it_cannot_run():
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "N2M_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

@@ -18,6 +18,10 @@ def test_render_stage1_and_step(fused):
     dev = torch.device("cuda")
     v, f = S.scene_mesh(20000)
     tr = Stage1Trainer(NeRFNetwork(opt), opt, S.make_cameras(6, seed=0), v, f, dev, H=200, W=200)
+    assert abs(tr.optimizer.param_groups[0]["lr"] - 0.01 * opt.lr) < 1e-12          # main.py:239: the schedule starts at 1 % of lr
+    for _ in range(500):
+        tr.scheduler.step()               # past the warm-up, so that a dozen steps are enough to see the loss move
+    assert abs(tr.optimizer.param_groups[0]["lr"] - opt.lr) < 1e-9
     losses = [float(tr.train_step().detach()) for _ in range(12)]
     m = tr.model
     assert m.vertices_offsets.grad is not None and m.vertices_offsets.grad.abs().sum() > 0, "no gradient reached the vertices"

@@ -14,12 +14,17 @@ from nerf2mesh_amd.parallel import init_from_env
 from nerf2mesh_amd.trainer import Stage0Trainer
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+ENGINE = len(sys.argv) > 2 and sys.argv[2] == "engine"       # the step executor instead of the autograd trainer
 rank, world, local = init_from_env()
 device = torch.device("cuda", local % torch.cuda.device_count())
 torch.cuda.set_device(device)
 torch.manual_seed(0)
 opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=True)
-tr = Stage0Trainer(NeRFNetwork(opt), opt, synthetic.make_cameras(100, seed=0), device, rank=rank, world_size=world, seed=0)
+if ENGINE:
+    from nerf2mesh_amd.engine import Stage0Engine
+    tr = Stage0Engine(NeRFNetwork(opt), opt, synthetic.make_cameras(100, seed=0), device, rank=rank, world_size=world, seed=0)
+else:
+    tr = Stage0Trainer(NeRFNetwork(opt), opt, synthetic.make_cameras(100, seed=0), device, rank=rank, world_size=world, seed=0)
 tr.mark_untrained()
 losses = [float(tr.train_step()) for _ in range(steps)]
 torch.cuda.synchronize()
@@ -35,7 +40,7 @@ if world > 1:
 first, last = sum(losses[:5]) / 5, sum(losses[-5:]) / 5
 ok = ok and last < first
 if rank == 0:
-    print(f"DIST_CHECK {'OK' if ok else 'FAILED'} world={world} steps={steps} loss {first:.5f} -> {last:.5f} digest={[float(x) for x in digest]}")
+    print(f"DIST_CHECK {'OK' if ok else 'FAILED'} driver={type(tr).__name__} world={world} steps={steps} loss {first:.5f} -> {last:.5f} digest={[float(x) for x in digest]}")
 if world > 1:
     dist.destroy_process_group()
 sys.exit(0 if ok else 1)
