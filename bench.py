@@ -38,25 +38,31 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured floa
 # device kernels behind each library entry point, for the PMC traffic lookup: (substrings of the kernel names, how their
 # per-launch byte counts combine into one call of the entry point)
 _DEVICE_KERNELS = {"grid_encode_backward": (("bin_fill_pair_kernel", "bin_accumulate_kernel"), "sum"),     # one call = fill + both accumulates
-                   "grid_encode_forward": (("grid_forward3_packed_kernel",), "sum"),                         # one call = both tables (packed copy)
+                   "grid_encode_forward_packed": (("grid_forward3_packed_kernel",), "sum"),                  # one call = both tables (packed copy)
+                   "adam_step": (("adam_kernel",), "sum"),
                    "mlp_backward": (("field_backward_kernel",), "mean"), "mlp_forward": (("field_forward_kernel",), "mean"),
                    "march_rays_train_count": (("march_train_wave_kernelILb0", "march_train_wave_kernel<false>"), "mean"),
                    "march_rays_train_write": (("march_train_wave_kernelILb1", "march_train_wave_kernel<true>"), "mean")}
 
 
 def pmc_traffic(entry_point):
-    """HBM-side bytes per call of `entry_point` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json, made by
-    tools/pmc_traffic.py: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, two separate passes) over the device kernels
-    behind the entry point.  Counters cannot be read from inside this process, hence the file; None when it is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path) or entry_point not in _DEVICE_KERNELS:
-        return None
+    """(bytes, source) -- memory-side bytes per call of `entry_point` from the newest committed rocprofv3 --pmc passes
+    (profiles/r*_pmc_traffic.json, made by tools/pmc_traffic.py in separate FETCH_SIZE / WRITE_SIZE passes over this same bench
+    command) summed over the device kernels behind the entry point.  Counters cannot be read from inside the timed process, hence
+    the file; (None, reason) when no file names the kernels this build launches.  The figure is an UPPER BOUND on HBM traffic:
+    FETCH_SIZE is doubled per the gfx950 correction of MI355X_MICROARCH.md (calibrated there on wide coalesced reads, not on 8/16-byte
+    gathers) and both counters include requests the Infinity Cache serves."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    if not files or entry_point not in _DEVICE_KERNELS:
+        return None, "no profiles/r*_pmc_traffic.json"
+    path = files[-1]
     keys, how = _DEVICE_KERNELS[entry_point]
     vals = [v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for name, v in json.load(open(path)).items()
             if any(k in name for k in keys) and v.get("fetch_bytes_per_launch") is not None and v.get("write_bytes_per_launch") is not None]
     if not vals:
-        return None
-    return float(sum(vals) if how == "sum" else sum(vals) / len(vals))
+        return None, f"{os.path.basename(path)} has no kernel of {entry_point}"
+    return float(sum(vals) if how == "sum" else sum(vals) / len(vals)), f"profiles/{os.path.basename(path)} (upper bound: FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included)"
 
 
 def cpu_baseline(n_rays=32768, reps=4, threads=None):
@@ -261,22 +267,26 @@ def main():
 
     kernels = {}
     if not args.no_prof:
-        for name in ("grid_encode_forward", "grid_encode_backward", "grad_total_variation", "march_rays_train_count",
+        for name in ("grid_encode_forward_packed", "grid_encode_forward", "grid_encode_backward", "grad_total_variation", "march_rays_train_count",
                      "march_rays_train_write", "composite_rays_train_forward", "composite_rays_train_backward",
-                     "near_far_from_aabb", "packbits", "mlp_forward", "mlp_backward"):
+                     "near_far_from_aabb", "packbits", "mlp_forward", "mlp_backward", "adam_step"):
             n, ms, by = _lib.prof_read(name)
             if n:
                 kernels[name] = {"launches": n, "avg_us": 1e3 * ms / n, "algo_bytes_per_launch": by / n,
                                  "GBps": (by / n) / (ms / n * 1e-3) / 1e9 if ms > 0 else None,
-                                 "ms_per_step": ms / args.steps}
-    roof = None
-    if kernels:
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        k = kernels[dom]
-        roof = {"kernel": dom, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (k["GBps"] / HBM_PEAK_GBS) if k["GBps"] else None, "traffic": pmc_traffic(dom),
+                                 "ms_per_step": ms * max(args.prof_every, 1) / args.steps}       # every prof_every-th launch is timed
+    def roofline_of(name):
+        k = kernels[name]
+        traffic, source = pmc_traffic(name)
+        return {"kernel": name, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (k["GBps"] / HBM_PEAK_GBS) if k["GBps"] else None, "traffic": traffic, "traffic_source": source,
                 "avg_us": k["avg_us"], "algo_bytes_per_launch": k["algo_bytes_per_launch"],
                 "note": "achieved = algorithmic bytes per launch (SURVEY.md 8d; cache hits count) / mean hipEvent duration over the timed region"}
+    roof = roof_lookup = None
+    if kernels:
+        roof = roofline_of(max(kernels, key=lambda k: kernels[k]["ms_per_step"]))          # the dominant entry point of the step
+        if "grid_encode_forward_packed" in kernels:
+            roof_lookup = roofline_of("grid_encode_forward_packed")                          # north_star's hash-grid lookup (training launches only)
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -301,7 +311,7 @@ def main():
                    "mlp": "nn.Linear (unfused)" if args.unfused else "fused MFMA field kernels",
                    "driver": "engine.Stage0Engine (fixed launch sequence)" if use_engine else "trainer.Stage0Trainer (torch.autograd)", "pretrain_steps": args.pretrain, "samples_per_step_per_gpu": samples / args.steps / world,
                    "rays_per_step_per_gpu": rays / args.steps / world, "params": 18367240},
-        "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "psnr_view0_quarter_res": psnr,
+        "roofline": roof, "roofline_lookup": roof_lookup, "kernels": kernels, "cpu_baseline": cpu, "psnr_view0_quarter_res": psnr,
         "loss_mean": float(tr.loss_acc / max(tr.global_step, 1)),
     }
     print(json.dumps(line))

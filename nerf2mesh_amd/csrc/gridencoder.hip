@@ -432,11 +432,31 @@ __device__ __forceinline__ void atomic_add_row(float* dst, const float* v, uint3
 __global__ void __launch_bounds__(256)
 grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __restrict__ packed, const int32_t* __restrict__ offsets,
                             float* __restrict__ out1, _Float16* __restrict__ out2, uint32_t B, uint32_t max_level, LevelTable lv,
-                            uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t n_tiles, float in_scale, float in_offset) {
+                            uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t n_tiles, float in_scale, float in_offset,
+                            uint32_t xcd_group) {
     __builtin_amdgcn_s_setprio(3);      // runs beside the next batch's marcher (second stream): win the issue arbitration
     constexpr uint32_t D = 3;
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const uint32_t level = blockIdx.x / n_tiles, tile = blockIdx.x - level * n_tiles;
+    uint32_t level, tile;
+    if (xcd_group == 0u) {
+        level = blockIdx.x / n_tiles;
+        tile = blockIdx.x - level * n_tiles;
+    } else {
+        // XCD groups (max_level == 16).  Workgroup b runs on XCD b % 8 (observed dispatch rule; a wrong guess costs speed only).  The
+        // kernel is bound by the L2s' request rate (tools/fwd_lab.hip: random 16-byte gathers from an L2-resident table run at 256 G
+        // loads/s = 128 channels x 1 per clock, L1-resident at 800 G/s), so every level must stay spread over several L2s -- but each
+        // L2 that works on a level also pulls that level's whole 4 MB table through the fabric.  g = 4 XCDs per level is the measured
+        // optimum: group k = xcd / 4 owns eight levels (pairs p, 15 - p: coarse with fine) and walks them one after the other, its four
+        // XCDs splitting the tiles.  67.8 -> 65.3 us stand-alone (8 XCDs per level -> 4; 2: 69.1, 1: 73.2).
+        const uint32_t g = xcd_group, groups = 8u / g, per_group = 16u / groups;
+        const uint32_t xcd = blockIdx.x & 7u, k = xcd / g, j = xcd - k * g, i = blockIdx.x >> 3;
+        const uint32_t tiles_per_xcd = (n_tiles + g - 1u) / g;
+        const uint32_t li = i / tiles_per_xcd;
+        tile = (i - li * tiles_per_xcd) * g + j;
+        if (li >= per_group || tile >= n_tiles) return;
+        const uint32_t pair = k + groups * (li >> 1);
+        level = (li & 1u) ? 15u - pair : pair;
+    }
     if (level >= max_level) return;
     const uint32_t b = tile * 256 + threadIdx.x;
     if (b >= B) return;
@@ -470,12 +490,10 @@ grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __res
 #pragma unroll
         for (uint32_t q = 0; q < 4; ++q) {
             const uint32_t r = base + ((q & 1u) ? ix.stride[1] : 0u) + ((q & 2u) ? ix.stride[2] : 0u);
-            if ((r & 1u) == 0u) {                        // rows r, r+1 share one aligned 16-byte slot
-                const uint4 v = *reinterpret_cast<const uint4*>(tab + r);
-                g[2 * q] = make_uint2(v.x, v.y); g[2 * q + 1] = make_uint2(v.z, v.w);
-            } else {
-                g[2 * q] = tab[r]; g[2 * q + 1] = tab[r + 1u];
-            }
+            // rows r, r+1 are adjacent: ONE 16-byte load at an 8-byte-aligned address (gfx950 global loads need dword alignment only;
+            // for odd r it used to be two 8-byte loads = two requests at the L1): 67.8 -> 63.9 us stand-alone
+            const uint4 v = *reinterpret_cast<const uint4 __attribute__((aligned(8)))*>(tab + r);
+            g[2 * q] = make_uint2(v.x, v.y); g[2 * q + 1] = make_uint2(v.z, v.w);
         }
     } else if (ix.hashed && ix.pow2) {
         const uint32_t hy0 = cell[1] * kPrimes[1], hy1 = hy0 + kPrimes[1], hz0 = cell[2] * kPrimes[2], hz1 = hz0 + kPrimes[2];
@@ -2387,11 +2405,15 @@ extern "C" int n2m_grid_encode_forward_packed(const float* inputs, const void* p
     if (B == 0 || max_level == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const LevelTable lv = make_levels(L, S, H);
-    N2M_PROF(N2M_K_GRID_FWD, s, (double)B * (12.0 + (double)max_level * 8 * (4 + 4) + (double)max_level * (4 + 4)));
+    // algorithmic bytes of both encoders' forward (588 B/sample each at L = 16, one 12-byte input read shared)
+    N2M_PROF(N2M_K_GRID_FWD_PACKED, s, (double)B * (12.0 + (double)max_level * 8 * (4 + 4) + (double)max_level * (4 + 4)));
     const uint32_t n_tiles = n2m_ceil_div(B, 256);
-    grid_forward3_packed_kernel<<<n_tiles * max_level, 256, 0, s>>>(inputs, (const uint2*)packed, offsets, outputs1, (_Float16*)outputs2, B,
-                                                                   max_level, lv, gridtype, align_corners != 0, interp, n_tiles, in_scale,
-                                                                   in_offset);
+    static const uint32_t xg_env = getenv("N2M_FWD_XCD_GROUP") ? (uint32_t)atoi(getenv("N2M_FWD_XCD_GROUP")) : 4u;     // A/B switch: 0 = level-major grid
+    const uint32_t xg = (max_level == 16u && (xg_env == 1u || xg_env == 2u || xg_env == 4u)) ? xg_env : 0u;
+    const uint32_t blocks = xg ? 8u * (16u / (8u / xg)) * n2m_ceil_div(n_tiles, xg) : n_tiles * max_level;
+    grid_forward3_packed_kernel<<<blocks, 256, 0, s>>>(inputs, (const uint2*)packed, offsets, outputs1, (_Float16*)outputs2, B,
+                                                       max_level, lv, gridtype, align_corners != 0, interp, n_tiles, in_scale,
+                                                       in_offset, xg);
     N2M_CHECK_LAUNCH();
     return 0;
 }

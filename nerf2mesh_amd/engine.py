@@ -37,9 +37,8 @@ def lr_lambda(it, iters):
 
 
 class _RayBufs:
-    """Per-batch ray-side tensors.  Three sets rotate: batch i+1 is produced on the side stream while batch i is consumed; `consumed`
-    (the main-stream marker of the step AFTER the one that read the set) is what the next producer of the set waits for on the host,
-    which also keeps the host from running more than two steps ahead of the GPU."""
+    """Per-batch ray-side tensors.  Three sets rotate: while step i consumes batch i, batch i+1 waits for its turn and batch i+2 is
+    produced on the side stream (behind the marker in front of Adam(i), i.e. after the last kernel that read batch i-1's set)."""
 
     def __init__(self, cap, dev):
         self.cap = cap
@@ -50,7 +49,8 @@ class _RayBufs:
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.host_count = torch.empty(1, dtype=torch.int32, pin_memory=True)
         self.count_ready = torch.cuda.Event()
-        self.consumed = None
+        self.index = 0
+        self.M = None                # sample count once the host has read it
         self.loss = torch.empty(1, dtype=torch.float32, device=dev)
         self.samples = None          # [cap_m, 8] fp32: xyzs | dirs | ts (speculative write pass)
         self.cap_m = 0
@@ -74,8 +74,12 @@ class Stage0Engine:
         self.rank, self.world = rank, world_size
         self.global_step = 0
         self.num_rays = opt.num_rays
-        self.gen = torch.Generator(device=dev)
+        # three independent streams (pixel choice, background, march jitter): which batch a number goes to then does not depend on how
+        # far ahead batches are prepared, so this executor and Stage0Trainer consume identical draws (rank r: its own rays)
+        self.gen, self.gen_bg, self.gen_noise = (torch.Generator(device=dev) for _ in range(3))
         self.gen.manual_seed(seed + rank)
+        self.gen_bg.manual_seed(seed + rank + 7919)
+        self.gen_noise.manual_seed(seed + rank + 104729)
         self.optimizer = FusedAdamAMP(model.get_params(opt.lr), eps=1e-15, amp=True)
         self.images = None
         self.boxes = synthetic.boxes(dev)
@@ -109,11 +113,14 @@ class Stage0Engine:
             o += p.numel()
         self._desc = {}
         self._bufs = [None, None, None]
-        self._marker = self._prev = None
+        self._marker = None
+        self._last = None                     # the newest prepared batch
+        self._queue = []                      # prepared batches, oldest first (steady state: the next one and the one after)
+        self._prepared = 0                    # index (1-based) of the newest prepared batch
+        self.depth = 2                        # batches prepared ahead of the running step
         self._cur = 0
 
         self._work_cap = (0, 0)
-        self._next = None
         self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self._seed = None
         self._aabb = None
@@ -140,9 +147,6 @@ class Stage0Engine:
     def _ray_bufs(self, N):
         self._cur = (self._cur + 1) % len(self._bufs)
         b = self._bufs[self._cur]
-        if b is not None and b.consumed is not None:
-            b.consumed.synchronize()          # the step that read this set has finished on the GPU
-            b.consumed = None
         if b is None or b.cap < N:
             b = self._bufs[self._cur] = _RayBufs(max(int(N * 1.5), 8192), self.device)
         return b
@@ -175,30 +179,30 @@ class Stage0Engine:
         return self._w
 
     # ------------------------------------------------------------------------------------------------- next batch
-    def _prepare(self):
-        """Occupancy refresh on every 16th step (nerf/utils.py:1155-1156), then the next batch: rays, near/far, march pass 1, the count
-        on its way to the host, speculative pass 2.  Same draws, same order as Stage0Trainer._prepare."""
+    def _refresh(self):
+        """Occupancy refresh (every 16th step, nerf/utils.py:1155-1156): reads the parameters, so it runs on the main stream behind the
+        optimizer update of the step before."""
+        if self.sync is not None:
+            self.sync.sync_rng_for_grid_update(self.global_step)
+        self.model.update_extra_state()
+
+    def _prepare(self, N):
+        """Batch of N rays: pixel choice, rays + ground truth, near/far, march pass 1 (count + offset scan), count on its way to the host.
+        Reads the cameras, the images and the occupancy bit field only."""
         opt, model, dev = self.opt, self.model, self.device
-        refreshed = self.global_step % opt.update_extra_interval == 0
-        if refreshed:
-            if self.sync is not None:
-                self.sync.sync_rng_for_grid_update(self.global_step)
-            model.update_extra_state()
         if self.images is None:
             self.images = synthetic.preload_images(self.poses, self.boxes)
-        N = int(self.num_rays)
         b = self._ray_bufs(N)
-        b.N, b.refreshed = N, refreshed
+        b.N, b.M = N, None
         H = W = synthetic.LEGO_HW
         f = float(synthetic.LEGO_FOCAL)
         b.cam = torch.randint(0, self.poses.shape[0], (N,), device=dev, generator=self.gen)
         b.pix = torch.randint(0, H * W, (N,), device=dev, generator=self.gen)
         s = L.stream()
         L.call("n2m_get_rays", _p(self.poses), _p(b.cam), _p(b.pix), N, H, W, f, f, W / 2, H / 2, _p(self.images), _p(b.o), _p(b.d), _p(b.rgba), s)
-        if self._aabb is None or self._aabb is not model.aabb_train:
-            self._aabb = model.aabb_train
+        self._aabb = model.aabb_train
         L.call("n2m_near_far_from_aabb", _p(b.o), _p(b.d), _p(self._aabb), N, float(model.min_near), _p(b.nears), _p(b.fars), s)
-        b.noises = torch.rand(N, dtype=torch.float32, device=dev)
+        b.noises = torch.rand(N, dtype=torch.float32, device=dev, generator=self.gen_noise)
         bits = model.density_bitfield
         b.args = (_p(b.o), _p(b.d), _p(bits), float(model.real_bound), int(bool(opt.contract)), float(opt.dt_gamma), int(opt.max_steps), N,
                   int(model.cascade), int(model.grid_size), _p(b.nears), _p(b.fars))
@@ -209,27 +213,53 @@ class Stage0Engine:
         b.count_ready.record()
         return b
 
-    def _prepare_side(self):
-        """_prepare() on the side stream (rays, near/far, march pass 1, count to the host)."""
-        main = torch.cuda.current_stream(self.device)
-        if not self.overlap:
-            return self._prepare()
-        # Behind everything already queued on the main stream: the pass then starts together with the next step and runs beside its
-        # forward kernels.  (Letting it run further ahead was measured slower: its small launches queue up behind the field backward,
-        # whose workgroups own every CU, and the march then lands on the table backward.)
-        self.side.wait_event(self._marker)
-        with torch.cuda.stream(self.side):
-            b = self._prepare()
-        for t in (b.cam, b.pix, b.noises):
-            t.record_stream(main)
-        return b
+    def _count(self, b):
+        """Sample count of batch b on the host (waits for the event behind its offset scan; normally long complete)."""
+        if b.M is None:
+            b.count_ready.synchronize()
+            b.M = int(b.host_count[0])
+        return b.M
+
+    def _fill_pipeline(self):
+        """Prepare batches until `depth` of them wait in the queue.  Batch j takes its ray count from batch j-1's sample count
+        (adaptive num_rays, nerf/utils.py:796-797) and, when (j-1) % 16 == 0, follows an occupancy refresh that needs step j-1's
+        parameter update: such a batch cannot be prepared early -- it is issued on the main stream behind that step.  Every other batch
+        is issued on the side stream behind the marker in front of the running step's Adam kernel: its count pass then runs beside
+        the optimizer update (a streaming kernel that leaves the ALUs idle) instead of beside the forward lookup, and its count is on
+        the host a whole step before it is needed."""
+        opt = self.opt
+        while len(self._queue) < self.depth:
+            j = self._prepared + 1
+            need_refresh = (j - 1) % opt.update_extra_interval == 0
+            if need_refresh and j - 1 > self.global_step:
+                break                                   # its refresh waits for a step that is not queued yet
+            prev = self._last                           # batch j-1 (still queued, or the one the running step consumes)
+            if prev is not None:                        # N(j) from M(j-1)
+                M = self._count(prev)
+                if opt.adaptive_num_rays and M > 0:
+                    self.num_rays = max(1, int(round((opt.num_points / M) * prev.N)))
+            N = int(self.num_rays)
+            if need_refresh or not self.overlap or self._marker is None:
+                if need_refresh:
+                    self._refresh()
+                b = self._prepare(N)
+            else:
+                self.side.wait_event(self._marker)
+                with torch.cuda.stream(self.side):
+                    b = self._prepare(N)
+                main = torch.cuda.current_stream(self.device)
+                for t in (b.cam, b.pix, b.noises):
+                    t.record_stream(main)
+            b.index = j
+            self._prepared = j
+            self._last = b
+            self._queue.append(b)
 
     def _finish(self, b):
-        """Sample count of batch b on the host, then pass 2 (the write pass) on the MAIN stream into buffers that fit.  The host has
-        waited for the event behind the offset scan, so the main stream needs no cross-stream dependency on the side stream (a
-        barrier packet there cost the step ~25 us of idle queue, measured); with the prefix-maximum marcher the pass is ~25 us."""
-        b.count_ready.synchronize()
-        M = int(b.host_count[0])
+        """Pass 2 (the write pass) of batch b on the MAIN stream into buffers that fit its count.  The host has waited for the event
+        behind the offset scan, so the main stream needs no cross-stream dependency on the side stream (a barrier packet there cost
+        the step ~25 us of idle queue, measured); with the prefix-maximum marcher the pass is ~25 us."""
+        M = self._count(b)
         if M > 0:
             x, d, t = self._sample_bufs(b, ((int(1.25 * M) + 1023) // 1024) * 1024 if b.cap_m < M else b.cap_m)
             L.call("n2m_march_rays_train_write", *b.args, _p(x), _p(d), _p(t), _p(b.rays), _p(b.noises), b.cap_m, L.stream())
@@ -296,33 +326,18 @@ class Stage0Engine:
             model.train()
         for g in self.optimizer.param_groups:
             g.setdefault("initial_lr", g["lr"])
-        if self._next is None:
-            self._next = self._prepare()
-        b = self._next
-        self._next = None
+        if not self._queue:
+            self._fill_pipeline()
+        b = self._queue.pop(0)
         self.global_step += 1
+        assert b.index == self.global_step
         N = b.N
         random_bg = opt.background != "white"
         if random_bg:
-            bg = torch.rand(N, 3, device=dev, generator=self.gen)
+            bg = torch.rand(N, 3, device=dev, generator=self.gen_bg)
         shading = SHADING["diffuse" if (self.global_step < opt.diffuse_step or opt.diffuse_only) else "full"]
-        refresh_next = self.global_step % opt.update_extra_interval == 0
-
-        # ONE event per step on the main stream (an event record is a marker packet the queue idles ~6 us behind, measured; a second
-        # one between the table backward and Adam cost as much again).  It is behind everything of the previous step, so it serves as
-        # the side stream's go-ahead for the next batch AND as "the previous batch's buffers are free".
-        b.count_ready.synchronize()
-        self._marker = torch.cuda.Event()
-        self._marker.record()
-        if self._prev is not None:
-            self._prev.consumed = self._marker
-        self._prev = b
         M = self._finish(b)
         self.last_num_points = M
-        if opt.adaptive_num_rays and M > 0:                                  # nerf/utils.py:796-797
-            self.num_rays = max(1, int(round((opt.num_points / M) * self.num_rays)))
-        if not refresh_next:
-            self._next = self._prepare_side()        # beside this step's kernels: it reads only the cameras and the occupancy bit field
         self.samples_seen += M
         self.rays_seen += N
 
@@ -383,11 +398,14 @@ class Stage0Engine:
         if self.sync is not None:
             token = self.sync.all_reduce_sum_begin([self.g1, self.g2], [self.dw, o.found_inf])
             self.sync.all_reduce_sum_end(token)
+        # ONE event per step on the main stream (an event record is a marker packet the queue idles ~6 us behind, measured): behind the
+        # last kernel that reads this batch's buffers and in front of the optimizer update -- the side stream's go-ahead
+        self._marker = torch.cuda.Event()
+        self._marker.record()
         # ---- Adam + loss-scale bookkeeping, LR schedule (main.py:239)
         self._lr_step(shading != 0)
         self._loss_sum += loss.view(())        # running sum on the device (the value itself lives in a rotating buffer)
-        if self._next is None:
-            self._next = self._prepare()          # refresh steps: behind the optimizer update, like the reference (refresh -> batch -> march)
+        self._fill_pipeline()
         return loss
 
     def _lr_step(self, full):

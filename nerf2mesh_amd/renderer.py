@@ -89,7 +89,7 @@ class NeRFRenderer(nn.Module):
 
     # ------------------------------------------------------------------------------------------ stage 0
     @torch.no_grad()
-    def march_ahead(self, rays_o, rays_d, dt_gamma=0, perturb=True, max_steps=1024, cam_near_far=None, expect_points=0):
+    def march_ahead(self, rays_o, rays_d, dt_gamma=0, perturb=True, max_steps=1024, cam_near_far=None, expect_points=0, noises=None):
         """Enqueue near/far + march pass 1 for a FUTURE training batch (they read only the occupancy bit field) and return a
         ticket for render(..., ticket=...).  Lets the training loop keep the GPU queue full across the sample-count read-back."""
         rays_o = rays_o.contiguous().view(-1, 3)
@@ -99,7 +99,8 @@ class NeRFRenderer(nn.Module):
             nears = torch.maximum(nears, cam_near_far[:, 0])
             fars = torch.minimum(fars, cam_near_far[:, 1])
         return raymarching.march_rays_train_begin(rays_o, rays_d, self.real_bound, self.opt.contract, self.density_bitfield, self.cascade,
-                                                  self.grid_size, nears, fars, perturb, dt_gamma, max_steps, expect_points=expect_points)
+                                                  self.grid_size, nears, fars, perturb, dt_gamma, max_steps, noises=noises,
+                                                  expect_points=expect_points)
 
     def render(self, rays_o, rays_d, index=None, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-4,
                cam_near_far=None, shading="full", ticket=None, blend_bg=True, **kwargs):

@@ -23,8 +23,13 @@ class Stage0Trainer:
         self.rank, self.world = rank, world_size
         self.global_step = 0
         self.num_rays = opt.num_rays
+        # every rank draws its own rays.  Pixel choice, background and march jitter come from three independent
+        # streams, so a driver that prepares batches further ahead (engine.Stage0Engine) consumes identical numbers per batch
         self.gen = torch.Generator(device=device)
-        self.gen.manual_seed(seed + rank)                  # every rank draws its own rays
+        self.gen.manual_seed(seed + rank)
+        self.gen_bg, self.gen_noise = torch.Generator(device=device), torch.Generator(device=device)
+        self.gen_bg.manual_seed(seed + rank + 7919)
+        self.gen_noise.manual_seed(seed + rank + 104729)
         # main.py:221 Adam(eps=1e-15) + nerf/utils.py:506 GradScaler.  Single GPU with the fused field: optim.FusedAdamAMP does both
         # in two launches and takes the inf/nan verdict from the kernels that produce the gradients.
         self.amp_adam = device.type == "cuda" and bool(getattr(opt, "fused_mlp", False)) and not opt.sdf and getattr(opt, "ind_dim", 0) == 0
@@ -107,8 +112,9 @@ class Stage0Trainer:
         # sample buffers for the speculative write pass: a quarter above the last batch (adaptive_num_rays steers M towards
         # opt.num_points, nerf/utils.py:796-797); a batch that still does not fit is re-marched exactly by finish()
         expect = 0 if self.last_num_points <= 0 else ((int(1.25 * max(self.last_num_points, 1024)) + 1023) // 1024) * 1024
+        noises = torch.rand(rays_o.shape[0], dtype=torch.float32, device=rays_o.device, generator=self.gen_noise) if self.pipeline else None
         ticket = model.march_ahead(rays_o, rays_d, dt_gamma=opt.dt_gamma, perturb=True, max_steps=opt.max_steps,
-                                   expect_points=expect) if self.pipeline else None
+                                   expect_points=expect, noises=noises) if self.pipeline else None
         return rays_o, rays_d, images, ticket
 
     def _prepare_overlapped(self):
@@ -140,7 +146,7 @@ class Stage0Trainer:
         self.global_step += 1
         self.optimizer.zero_grad(set_to_none=True)
         N = rays_o.shape[0]
-        bg_color = 1 if opt.background == "white" else torch.rand(N, 3, device=self.device, generator=self.gen)
+        bg_color = 1 if opt.background == "white" else torch.rand(N, 3, device=self.device, generator=self.gen_bg)
         if opt.sdf:
             opt.cos_anneal_ratio = min(1, self.global_step / (0.5 * opt.iters))
             opt.normal_anneal_epsilon = 1e-1 * (1 - min(0.999, self.global_step / (0.5 * opt.iters)))

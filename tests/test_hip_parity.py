@@ -739,7 +739,10 @@ def test_grid_backward_binned_pair_overwrite_mode(be, B, max_level, with_tv):
         assert not np.isfinite(a1).all() and not np.isfinite(a2).all()
     fin1, fin2 = np.isfinite(a1), np.isfinite(a2)
     np.testing.assert_allclose(b1[fin1], a1[fin1], rtol=1e-5, atol=1e-6 * max(float(np.abs(a1[fin1]).max()), 1e-30))
-    np.testing.assert_allclose(b2[fin2], a2[fin2], rtol=2e-3, atol=2e-3 * max(float(np.abs(a2[fin2]).max()), 1e-30))
+    # fp16 table, levels split over tile groups: up to 64 groups x passes partial sums reach a row as fp16 atomics, each rounding to
+    # half an fp16 ulp (2^-11 relative) in arrival order -- both runs carry that noise: |diff| up to ~sqrt(128) * 2^-11 * |row| typical,
+    # 128 * 2^-11 worst.  (2e-3 * max, the earlier bar, is ~3 sigma of that for the 2^20-sample case and failed 4 runs in 12.)
+    np.testing.assert_allclose(b2[fin2], a2[fin2], rtol=2e-3, atol=1e-2 * max(float(np.abs(a2[fin2]).max()), 1e-30))
     for l in range(max_level if B else 0):
         if offs[l + 1] - offs[l] == 2 ** 19 and B <= 2 ** 20:
             sl = slice(offs[l], offs[l + 1])

@@ -13,5 +13,8 @@ for path in sys.argv[1:]:
         if d.get("roofline"):
             r = d["roofline"]
             print(f"   roofline: {r['kernel']} {r['achieved']:.0f} GB/s = {100*r['frac']:.1f}% of {r['peak']:.0f}")
+        if d.get("roofline_lookup"):
+            r = d["roofline_lookup"]
+            print(f"   lookup:   {r['kernel']} {r['achieved']:.0f} GB/s = {100*r['frac']:.1f}% of {r['peak']:.0f}  ({r['avg_us']:.1f} us)")
         if d.get("cpu_baseline"):
             print("   cpu:", d["cpu_baseline"])
