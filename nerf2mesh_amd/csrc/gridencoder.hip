@@ -1645,7 +1645,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)
 bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners,
                       const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ directory,
                       const uint64_t* __restrict__ log, float* __restrict__ found_inf, const uint16_t* __restrict__ log_rel = nullptr,
-                      const uint32_t* __restrict__ log_val = nullptr, bool overwrite = false) {
+                      const uint32_t* __restrict__ log_val = nullptr, bool overwrite = false, uint32_t dbg = 0) {
     // overwrite: the gradient table holds no earlier sums.  Partitions owned by one workgroup (Gl == 1) are then STORED in full,
     // zeros included -- no read-modify-write round trips in the flush (measured: eight dependent load-add-store steps per item were
     // a third of this kernel) and no zero-fill of the table before the call; levels split over several groups still add
@@ -1687,14 +1687,12 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
         const float scale = __uint_as_float((uint32_t)(ex + 127) << 23);
         const float inv = __uint_as_float((uint32_t)(127 - ex) << 23);
 
-        for (uint32_t i = tid; i < SUB * P * C; i += 1024) bin_acc[i] = 0ull;
-        if (tid == 0) nonfinite_seen = 0u;
-        __syncthreads();
-
         T* __restrict__ gtab = grad_table + (size_t)row0 * C;
         const uint32_t* __restrict__ dir_l = directory + plan.dir_base[level];
         // one wave per tile run.  The wave first fetches the directory entries of ALL its tiles in one parallel load (lane j <-
         // its j-th tile), then walks them with readlane: one dependent global-load round trip per item instead of one per tile.
+        // The loads are issued BEFORE the accumulator is cleared, so that their latency hides behind the LDS stores and the barrier
+        // (the per-item skeleton -- clear, directory, barriers -- is 25-30 us of each accumulate launch, tools/acc_lab.sh).
         const uint32_t my_tiles = (plan.tiles > grp + wid * Gl) ? (plan.tiles - (grp + wid * Gl) + 16u * Gl - 1u) / (16u * Gl) : 0u;   // <= 64
         uint32_t d_off = 0, d_mid = 0, d_end = 0;
         if (lane < my_tiles) {
@@ -1704,6 +1702,9 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
             d_end = dir[part_end];
             d_mid = SUB > 1u && part0 + 1u < part_end ? dir[part0 + 1u] : d_end;
         }
+        for (uint32_t i = tid; i < SUB * P * C; i += 1024) bin_acc[i] = 0ull;
+        if (tid == 0) nonfinite_seen = 0u;
+        __syncthreads();
         // walk(body): body(rel0, u, bits) for every entry of this item's runs
         auto walk = [&](auto&& body) {
             for (uint32_t j = 0; j < (vm != 0u ? my_tiles : 0u); ++j) {
@@ -1714,8 +1715,11 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
                 for (uint32_t i = off + lane; i < end; i += 64u) {
                     uint32_t rel0, bits;
                     if constexpr (SOA) {
+                        if (dbg & 4u) { rel0 = i & (P - 1u); bits = 0x3f800000u; }
+                        else {
                         rel0 = log_rel[seg0 + i];        // (streaming-load hints here measured 5 us slower)
                         bits = log_val[seg0 + i];
+                        }
                     } else {
                         const uint64_t e = log[seg0 + i];
                         rel0 = (uint32_t)(e >> 32);
@@ -1746,6 +1750,7 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
         };
         walk([&](uint32_t rel0, uint32_t u, uint32_t bits) {
             const uint32_t rel = rel0 + u * P;                            // slot in this item's accumulator
+            if (dbg & 1u) { if (bits == 0x12345u) bin_acc[rel] = 1; return; }
             if (!finite(bits)) {
                 if (store_all) nonfinite_seen = 1u;
                 else bypass(rel0, u, bits);
@@ -1764,7 +1769,7 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
         __syncthreads();
         const bool second_walk = store_all && nonfinite_seen != 0u;       // read here: the next item resets the flag before ITS first barrier
 
-        for (uint32_t rel = tid; rel < SUB * P; rel += 1024) {
+        for (uint32_t rel = tid; rel < ((dbg & 2u) ? 0u : SUB * P); rel += 1024) {
             const uint32_t u = rel >> kLog2P, rel0 = rel & (P - 1u);
             if (part0 + u >= part_end || rel0 >= rows_of(part0 + u)) continue;
             const uint32_t row = global_row(u, rel0);
@@ -2135,11 +2140,12 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         N2M_CHECK_LAUNCH();
         const uint32_t items = lay.plan.item_prefix[max_level];
         const uint32_t nb = items < 4096u ? items : 4096u;
+        static const uint32_t acc_dbg = getenv("N2M_ACC_DEBUG") ? (uint32_t)atoi(getenv("N2M_ACC_DEBUG")) : 0u;   // measurement switches (wrong results)
         bin_accumulate_kernel<float, 1, kPairP, 2, true><<<items1 < 4096u ? items1 : 4096u, 1024, kPairP * 16, s>>>(
-            table1, plan1, lv, gridtype, align, level_max, directory, nullptr, found_inf, log_rel, log_v1, ow);
+            table1, plan1, lv, gridtype, align, level_max, directory, nullptr, found_inf, log_rel, log_v1, ow, acc_dbg);
         N2M_CHECK_LAUNCH();
         bin_accumulate_kernel<_Float16, 2, kPairP, 1, true><<<nb, 1024, kPairP * 16, s>>>(table2, lay.plan, lv, gridtype, align, level_max + kMaxLevels,
-                                                                                        directory, nullptr, found_inf, log_rel, log_v2, ow);
+                                                                                        directory, nullptr, found_inf, log_rel, log_v2, ow, acc_dbg);
         N2M_CHECK_LAUNCH();
     }
     return 0;

@@ -650,6 +650,46 @@ void n2m_oracle_grid_encode_backward_bm(const void* grad, const float* inputs, c
     grid_backward_impl(grad, inputs, emb, offsets, grad_emb, B, D, C, L, max_level, S, H, NULL, NULL, gridtype, align_corners, interp, dtype == 1, 1);
 }
 
+/* Exact-sum form of the table backward, for tight parity bars on kernels that do NOT follow the reference's (order-dependent)
+ * summation: per row and channel, the sum IN DOUBLE of the terms the reference adds -- for half tables each term is first rounded
+ * like the reference rounds it, (__half)(w * grad) with the product rounded to fp32 in between (gridencoder.cu:326); for fp32
+ * tables the fp32 product -- plus the sum of their magnitudes (for rounding bounds) and the number of terms.  Same traversal as
+ * grid_backward_impl; level-major grad [L,B,C]. */
+void n2m_oracle_grid_encode_backward_exact(const void* grad, const float* inputs, const int32_t* offsets, double* sum, double* abs_sum,
+                                           uint32_t* count, uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S,
+                                           uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype) {
+    const int is_half = dtype == 1;
+    (void)L;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t lv = 0; lv < (int64_t)max_level; ++lv) {
+        const uint32_t level = (uint32_t)lv;
+        const level_geom g = level_setup(offsets, level, S, H);
+        for (uint32_t b = 0; b < B; ++b) {
+            const float* x = inputs + (size_t)b * D;
+            if (out_of_unit_cube(x, D)) continue;
+            uint32_t cell[N2M_MAX_D], v[N2M_MAX_D];
+            float frac[N2M_MAX_D], dfrac[N2M_MAX_D];
+            locate(x, D, g.scale, align_corners, interp, cell, frac, dfrac);
+            const size_t gb = (size_t)level * B * C + (size_t)b * C;
+            for (uint32_t corner = 0; corner < (1u << D); ++corner) {
+                float w = 1.0f;
+                for (uint32_t d = 0; d < D; ++d) {
+                    if (corner & (1u << d)) { w *= frac[d]; v[d] = cell[d] + 1; }
+                    else { w *= 1 - frac[d]; v[d] = cell[d]; }
+                }
+                const size_t row = (size_t)(g.offset + vertex_row(v, D, gridtype, align_corners, g.size, g.resolution)) * C;
+                for (uint32_t c = 0; c < C; ++c) {
+                    volatile float p = is_half ? w * h2f(((const uint16_t*)grad)[gb + c]) : w * ((const float*)grad)[gb + c];
+                    const double t = is_half ? (double)h2f(f2h(p)) : (double)p;
+                    sum[row + c] += t;
+                    abs_sum[row + c] += t < 0 ? -t : t;
+                    if (t != 0.0) count[row + c] += 1;
+                }
+            }
+        }
+    }
+}
+
 /* gridencoder.cu:505-609, fp32 tables only (the reference's half path ends in an empty atomicAdd stub,
  * gridencoder.cu:22-26, and grid.py:170 runs TV with autocast disabled). */
 void n2m_oracle_grad_total_variation(const float* inputs, const float* emb, float* grad, const int32_t* offsets,

@@ -238,6 +238,23 @@ def grid_encode_backward(grad, inputs, emb, offsets, S, H, max_level=None, dy_dx
     return (grad_emb, grad_inputs) if dy_dx is not None else grad_emb
 
 
+def grid_encode_backward_exact(grad, inputs, offsets, S, H, C, is_half, max_level=None, gridtype=0, align_corners=False, interp=0):
+    """(sum, abs_sum, count) per table entry [rows, C]: the double-precision sum of exactly the terms the reference's backward adds
+    (half tables: each term rounded to half like gridencoder.cu:326), the sum of their magnitudes and their number.  grad is level-major
+    [L, B, C] in the table's dtype.  For parity bars on kernels whose summation order differs from the reference's."""
+    inputs, offsets = _c(inputs, np.float32), _c(offsets, np.int32)
+    grad = np.ascontiguousarray(grad, dtype=np.float16 if is_half else np.float32)
+    B, D = inputs.shape
+    L = offsets.shape[0] - 1
+    max_level = L if max_level is None else min(max_level, L)
+    rows = int(offsets[-1])
+    total, mag = np.zeros((rows, C), np.float64), np.zeros((rows, C), np.float64)
+    cnt = np.zeros((rows, C), np.uint32)
+    _call("grid_encode_backward_exact", _p(grad), _p(inputs), _p(offsets), _p(total), _p(mag), _p(cnt), _u32(B), _u32(D), _u32(C), _u32(L),
+          _u32(max_level), _f32(S), _u32(H), _u32(gridtype), ctypes.c_int(int(align_corners)), _u32(interp), ctypes.c_int(1 if is_half else 0))
+    return total, mag, cnt
+
+
 def grad_total_variation(inputs, emb, grad, offsets, weight, S, H, gridtype=0, align_corners=False):
     """In place on `grad` (fp32, C-contiguous)."""
     inputs, emb, offsets = _c(inputs, np.float32), _c(emb, np.float32), _c(offsets, np.int32)

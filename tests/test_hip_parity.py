@@ -919,3 +919,98 @@ def test_error_behaviour(be):
         ge.grid_encode_forward(x.cpu(), emb, offs, out, 8, 3, 3, 1, 1, 0.5, 16, None, 0, False, 0)
     with pytest.raises(RuntimeError, match="contiguous"):
         ge.grid_encode_forward(x.t().contiguous().t(), emb, offs, out, 8, 3, 3, 1, 1, 0.5, 16, None, 0, False, 0)
+
+
+def _half_ulp(v):
+    """Spacing of fp16 at |v| (subnormal spacing 2^-24 below 2^-14)."""
+    a = np.abs(v)
+    e = np.floor(np.log2(np.maximum(a, 2.0 ** -14)))
+    return np.exp2(e - 10)
+
+
+@pytest.mark.parametrize("with_tv", [False, True])
+def test_binned_pair_backward_is_the_exact_sum_at_full_batch(be, oracle, scene, with_tv):
+    """B = 2^18 samples of the marcher (ray-ordered, so the run merge is active), lego tables, both table gradients from the shared
+    binned backward.  The kernel claims: every term is rounded exactly like the reference rounds it ((half)(w * g) for the fp16 table,
+    gridencoder.cu:326), then summed EXACTLY (64-bit fixed point), then rounded once.  So each entry must equal the double-precision
+    sum of the reference's terms (oracle.grid_encode_backward_exact) up to
+      * the final rounding: half an ulp of the result (fp16 table) / 2^-24 relative (fp32 table),
+      * on merged levels (0..8): one rounding of every merged run's partial sum to the entry type: <= 2^-11 (fp16) / 2^-23 (fp32) of the sum
+        of the magnitudes of the row's terms,
+      * the fixed-point unit: 2^-38 of the level's largest term, half a unit per term.
+    The reference's own order-dependent result (serial half adds) is farther from that sum than this bound -- asserted at the end."""
+    torch = be["torch"]
+    from nerf2mesh_amd import raymarching, synthetic as S
+    from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward_pair
+    B = 2 ** 18
+    poses = S.make_cameras(64, seed=1).cuda()
+    bits = raymarching.packbits(S.scene_density_grid(H=128, device="cuda"), 10.0)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    xs, n = [], 0
+    while n < B:
+        o, d = S.random_rays(poses, 32768, g)
+        nears, fars = raymarching.near_far_from_aabb(o, d, torch.tensor([-1, -1, -1, 1, 1, 1.0], device="cuda"), 0.05)
+        xyzs = raymarching.march_rays_train(o, d, 1.0, False, bits, 1, 128, nears, fars, True, 0.0, 1024)[0]
+        xs.append(xyzs); n += xyzs.shape[0]
+    x_t = ((torch.cat(xs)[:B] + 1) / 2).contiguous()
+    x = x_t.cpu().numpy()
+    rng = np.random.default_rng(8)
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    e2 = GridEncoder(level_dim=2, desired_resolution=2048).cuda()
+    offs = np.asarray(e1.host_offsets, np.int32)
+    Sl = float(np.log2(e1.per_level_scale))
+    rows = int(offs[-1])
+    # gradient magnitudes like a training step's: a few large, most small, some exactly zero (early-stopped samples)
+    d1 = (rng.standard_normal((16, B, 1)) * np.exp(rng.normal(-6, 2, (1, B, 1))) * (rng.random((1, B, 1)) < 0.8)).astype(np.float32)
+    d2 = (rng.standard_normal((16, B, 2)) * np.exp(rng.normal(-6, 2, (1, B, 1))) * (rng.random((1, B, 1)) < 0.8) * 128).astype(np.float16)
+    emb1 = ((rng.random((rows, 1), dtype=np.float32) * 2 - 1) * 1e-2)
+    tv_w = 1e-4
+    tv = (dev(be, emb1), tv_w, tv_w, 1.0, None) if with_tv else None
+    a1 = torch.zeros(rows, 1, device="cuda"); a2 = torch.zeros(rows, 2, device="cuda", dtype=torch.float16)
+    assert binned_backward_pair(e1, e2, dev(be, d1), dev(be, d2), x_t, a1, a2, 16, tv=tv)
+    h1, h2 = a1.cpu().numpy().astype(np.float64), a2.float().cpu().numpy().astype(np.float64)
+
+    ex1, mag1, cnt1 = oracle.grid_encode_backward_exact(d1, x, offs, Sl, 16, 1, False)
+    ex2, mag2, cnt2 = oracle.grid_encode_backward_exact(d2, x, offs, Sl, 16, 2, True)
+    tv_ref = np.zeros((rows, 1), np.float32)
+    if with_tv:
+        oracle.grad_total_variation(x, emb1, tv_ref, offs, tv_w, Sl, 16, 0, False)
+        ex1 = ex1 + tv_ref.astype(np.float64)
+    level_of = np.repeat(np.arange(16), np.diff(offs))
+    lmax1 = np.array([np.abs(d1[l]).max() for l in range(16)], np.float64)[level_of][:, None] + (np.abs(tv_ref).max() if with_tv else 0.0)
+    lmax2 = np.array([np.abs(d2[l].astype(np.float32)).max() for l in range(16)], np.float64)[level_of][:, None]
+    merged = (level_of < 9)[:, None].astype(np.float64)
+    # small dense levels are split over G tile groups (make_bin_plan: ceil(8 B / partitions / 65536)); each group's partial sum is rounded
+    # to the table's type and ADDED with a float atomic, which rounds the running sum again: (G + 1) roundings of at most the magnitude sum
+    sizes = np.diff(offs).astype(np.int64)
+    parts = -(-((sizes + 15) >> 4) // (4096 // 16))
+    G = np.clip(-(-(8 * B // parts) // 65536), 1, 64)
+    split = np.where(G > 1, G + 1, 0).astype(np.float64)[level_of][:, None]
+
+    bound2 = 0.5 * _half_ulp(ex2) * 1.002 + (merged + split) * 2.0 ** -11 * mag2 + cnt2 * 2.0 ** -38 * lmax2
+    err2 = np.abs(h2 - ex2)
+    worst2 = (err2 / np.maximum(bound2, 1e-300))[cnt2 > 0].max()
+    # fp32 table.  Final conversion of the fixed-point sum: 2^-24 relative; merged runs: up to 16 fp32 adds per entry; TV: the term
+    # rides on vertex 000's product (one more fp32 add per sample) and is an fp32 expression whose association differs from the
+    # oracle's ((w * sum) * r vs w * (sum * r)); every sample's term is at most sqrt(6)/6 * weight (Cauchy-Schwarz on the six
+    # differences), and at most `pairs` samples reach a row
+    bound1 = 2.0 ** -23 * np.abs(ex1) + (merged * 16 + split) * 2.0 ** -24 * mag1 + (cnt1 + 1) * 2.0 ** -38 * lmax1
+    if with_tv:
+        pairs = oracle.grid_encode_backward_exact(np.ones((16, B, 1), np.float32), x, offs, Sl, 16, 1, False)[2].astype(np.float64)
+        tv_each = tv_w * np.sqrt(6.0) / 6.0
+        bound1 = bound1 + pairs * tv_each * (8 + 16 * merged) * 2.0 ** -24 + 2.0 ** -23 * mag1 + pairs * 2.0 ** -38 * (lmax1 + tv_each)
+    err1 = np.abs(h1 - ex1)
+    touched1 = (cnt1 > 0) | (np.abs(tv_ref) > 0)
+    worst1 = (err1 / np.maximum(bound1, 1e-300))[touched1].max()
+    per_level2 = [float((err2 / np.maximum(bound2, 1e-300))[(level_of == l)[:, None] & (cnt2 > 0)].max()) for l in range(16)]
+    per_level1 = [float((err1 / np.maximum(bound1, 1e-300))[(level_of == l)[:, None] & touched1].max()) for l in range(16)]
+    print(f"tv={with_tv}: fp16 table worst err/bound {worst2:.3f} ({int((cnt2 > 0).sum())} entries), fp32 table {worst1:.3f} ({int(touched1.sum())} entries)")
+    print("   per level fp16:", " ".join(f"{v:.2f}" for v in per_level2))
+    print("   per level fp32:", " ".join(f"{v:.2f}" for v in per_level1))
+    assert worst2 <= 1.0, f"fp16 table gradient is not the exact sum of the reference's half-rounded terms (err/bound {worst2:.3f})"
+    assert worst1 <= 1.0, f"fp32 table gradient off its bound (err/bound {worst1:.3f})"
+    assert not h2[cnt2 == 0].any() and not h1[~touched1].any()
+    # and the reference's own summation order is farther from the exact sum than we are: its result is one draw of that rounding noise
+    ref2 = oracle.grid_encode_backward(d2, x, np.zeros((rows, 2), np.float16), offs, Sl, 16, 16).astype(np.float64)
+    sel = cnt2 > 8
+    assert np.abs(h2 - ex2)[sel].sum() < np.abs(ref2 - ex2)[sel].sum()
