@@ -152,3 +152,69 @@ def test_fused_training_matches_unfused_loss_curve():
             acc.append(float(tr.train_step()))
         losses.append(np.mean(acc[-10:]))
     assert abs(losses[0] - losses[1]) / losses[0] < 0.10, losses
+
+
+@pytest.mark.parametrize("shading", ["diffuse", "full"])
+def test_fused_field_is_no_farther_from_fp32_truth_than_the_reference_fp16_graph(shading):
+    """Ground truth = the same network in fp32 (autocast off: fp32 tables, fp32 nn.Linear).  The reference's `-O` graph (fp16 autocast,
+    nerf/renderer.py:721-722) is one fp16 approximation of it, the fused MFMA kernels another (fp16 operands, fp32 accumulate, fp32
+    weight-gradient sums).  Per output and per gradient tensor the fused error must not exceed 1.5 x the autocast graph's error (+ a
+    floor of a few fp16 ulps of the tensor's scale): a biased gradient or a wrong rounding point would show up here, where a
+    comparison of the two fp16 versions with wide bars does not see it."""
+    import torch
+    ref, fused = make_nets()
+    M = 16384 + 3
+    x, d = samples(M, seed=11)
+    g = torch.Generator(device="cuda").manual_seed(12)
+    cs, cc, cp = torch.randn(M, device="cuda", generator=g), torch.randn(M, 3, device="cuda", generator=g), torch.randn(M, 3, device="cuda", generator=g)
+    scale = 128.0
+
+    def run(net, mode):
+        for p in net.parameters():
+            p.grad = None
+        if mode == "autocast":
+            with torch.autocast("cuda", dtype=torch.float16):
+                s, c, p = net(x, d, None, shading)
+        else:
+            s, c, p = net(x, d, None, shading)            # fp32 graph (ref net), or the fused kernels (fused net)
+        l = (torch.log1p(s.float()) * cs).sum() + (c.float() * cc).sum()
+        if p is not None:
+            l = l + 0.3 * (p.float() * cp).sum()
+        (l * scale / M).backward()
+        outs = {"sigma": s.detach().float(), "rgb": c.detach().float()}
+        if p is not None:
+            outs["specular"] = p.detach().float()
+        grads = {n: q.grad.detach().float().clone() for n, q in net.named_parameters() if q.grad is not None}
+        return outs, grads
+
+    truth_o, truth_g = run(ref, "fp32")
+    auto_o, auto_g = run(ref, "autocast")
+    fuse_o, fuse_g = run(fused, "fused")
+    rows = []
+    for name in truth_o:
+        t = truth_o[name]
+        if name == "sigma":                      # exp(): compare relative errors
+            ea = ((auto_o[name] - t).abs() / t.abs().clamp(min=1e-3)).mean().item()
+            ef = ((fuse_o[name] - t).abs() / t.abs().clamp(min=1e-3)).mean().item()
+            floor = 2.0 ** -11
+        else:
+            ea, ef = (auto_o[name] - t).abs().mean().item(), (fuse_o[name] - t).abs().mean().item()
+            floor = 2.0 ** -12
+        rows.append((name, ea, ef, floor))
+    for name, t in truth_g.items():
+        assert name in fuse_g and name in auto_g, name
+        den = t.abs().max().item() + 1e-30
+        if "embeddings" in name:                 # tables: mean error over the touched entries, relative to the largest entry
+            m = t != 0
+            ea = ((auto_g[name] - t).abs()[m].mean() / den).item()
+            ef = ((fuse_g[name] - t).abs()[m].mean() / den).item()
+        else:
+            ea, ef = ((auto_g[name] - t).abs().max() / den).item(), ((fuse_g[name] - t).abs().max() / den).item()
+        rows.append(("d " + name, ea, ef, 2.0 ** -11))
+    print()
+    bad = []
+    for name, ea, ef, floor in rows:
+        print(f"  {name:34s} autocast-vs-fp32 {ea:.3e}   fused-vs-fp32 {ef:.3e}   ratio {ef / max(ea, 1e-30):.2f}")
+        if not ef <= 1.5 * ea + floor:
+            bad.append(name)
+    assert not bad, f"fused field farther from the fp32 truth than 1.5 x the reference's fp16 graph: {bad}"
