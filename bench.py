@@ -159,17 +159,29 @@ def bench_stage1(args, rank, world, device):
     if rank == 0:
         px = 800 * 800 * args.steps * world
         kernels = {}
-        for name in ("rasterize", "mlp_forward", "mlp_backward", "grid_encode_forward", "grid_encode_backward"):
+        for name in ("rasterize", "rasterize_backward", "interpolate_forward", "interpolate_backward", "antialias_forward", "antialias_backward",
+                     "mlp_forward", "mlp_backward", "grid_encode_forward", "grid_encode_backward"):
             n, ms, by = _lib.prof_read(name)
             if n:
-                kernels[name] = {"launches": n, "avg_us": 1e3 * ms / n, "ms_per_step": ms / args.steps}
+                gbps = (by / n) / (ms / n * 1e-3) / 1e9 if ms > 0 else None
+                kernels[name] = {"launches": n, "avg_us": 1e3 * ms / n, "ms_per_step": ms * max(args.prof_every, 1) / args.steps,
+                                 "algo_bytes_per_launch": by / n, "GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS if gbps else None}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
+        roof = None
+        if dom:
+            k = kernels[dom]
+            roof = {"kernel": dom, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["frac_of_hbm_peak"],
+                    "traffic": None, "avg_us": k["avg_us"], "algo_bytes_per_launch": k["algo_bytes_per_launch"],
+                    "note": "algorithmic bytes per SURVEY.md 8d (raster ops: every pixel counted as covered = upper bound)"}
         print(json.dumps({"metric": "stage1_train_pixels_per_sec", "value": px / dt, "unit": "output pixels/s (800x800 views, rendered at 1600x1600)",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 raster, f16 autocast shading",
                           "data": "synthetic", "config": {"workload": f"nerf_synthetic/lego stage-1 -O --bound 1: {f.shape[0]} faces, "
                                                                        f"{v.shape[0]} vertices, ssaa 2, refine error tracking on",
-                                                          "parallelism": f"views sharded over {world} GPU(s)"},
-                          "kernels": kernels}))
+                                                          "parallelism": f"views sharded over {world} GPU(s)",
+                                                          "parity": "UNPINNED: nvdiffrast is not under /root/reference; the HIP rasterize/interpolate/antialias "
+                                                                    "are validated against closed forms and the scalar oracle (tests/test_raster_*.py)"},
+                          "roofline": roof, "kernels": kernels}))
     if world > 1:
         dist.destroy_process_group()
 

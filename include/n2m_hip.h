@@ -350,7 +350,8 @@ int n2m_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, u
 enum {
     N2M_K_GRID_FWD = 0, N2M_K_GRID_BWD, N2M_K_GRID_TV, N2M_K_MARCH_COUNT, N2M_K_MARCH_WRITE,
     N2M_K_COMPOSITE_FWD, N2M_K_COMPOSITE_BWD, N2M_K_NEAR_FAR, N2M_K_PACKBITS, N2M_K_MLP_FWD, N2M_K_MLP_BWD,
-    N2M_K_RASTER, N2M_K_GRID_FWD_PACKED /* the training lookup: both field tables from the packed copy */, N2M_K_ADAM, N2M_K_COUNT
+    N2M_K_RASTER, N2M_K_GRID_FWD_PACKED /* the training lookup: both field tables from the packed copy */, N2M_K_ADAM,
+    N2M_K_INTERP_FWD, N2M_K_INTERP_BWD, N2M_K_AA_FWD, N2M_K_AA_BWD, N2M_K_RASTER_BWD, N2M_K_COUNT
 };
 /* on = 1: every launch of a profiled kernel is bracketed by a hipEvent pair recorded on the launch stream; on = n > 1:
  * every n-th launch of each kernel id (sampled timing, keeps the event overhead out of a timed region); 0: off.

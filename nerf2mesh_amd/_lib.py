@@ -84,7 +84,8 @@ class AdamDesc(ctypes.Structure):
 KERNEL_IDS = {"grid_encode_forward": 0, "grid_encode_backward": 1, "grad_total_variation": 2, "march_rays_train_count": 3,
               "march_rays_train_write": 4, "composite_rays_train_forward": 5, "composite_rays_train_backward": 6,
               "near_far_from_aabb": 7, "packbits": 8, "mlp_forward": 9, "mlp_backward": 10, "rasterize": 11,
-              "grid_encode_forward_packed": 12, "adam_step": 13}
+              "grid_encode_forward_packed": 12, "adam_step": 13,
+              "interpolate_forward": 14, "interpolate_backward": 15, "antialias_forward": 16, "antialias_backward": 17, "rasterize_backward": 18}
 
 _lib = None
 

@@ -497,6 +497,7 @@ extern "C" int n2m_rasterize_backward(const float* pos, const int32_t* tri, cons
                                       uint32_t F, uint32_t H, uint32_t W, float* grad_pos, void* stream) {
     (void)F;
     N2M_NOTNULL(pos); N2M_NOTNULL(tri); N2M_NOTNULL(rast); N2M_NOTNULL(d_rast); N2M_NOTNULL(grad_pos);
+    N2M_PROF(N2M_K_RASTER_BWD, (hipStream_t)stream, 32.0 * H * W + 16.0 * V);
     raster_backward_kernel<<<n2m_ceil_div((uint64_t)H * W, 256), 256, 0, (hipStream_t)stream>>>(pos, tri, rast, d_rast, V, H, W, grad_pos);
     N2M_CHECK_LAUNCH();
     return 0;
@@ -506,6 +507,8 @@ extern "C" int n2m_interpolate_forward(const float* attr, const float* rast, con
                                        uint32_t H, uint32_t W, float* out, void* stream) {
     N2M_NOTNULL(attr); N2M_NOTNULL(rast); N2M_NOTNULL(tri); N2M_NOTNULL(out);
     N2M_REQUIRE(A >= 1, N2M_EINVAL, "interpolate: attribute count must be >= 1");
+    // 16 hw (rast) + covered * (12 + 12 A) + 4 A hw (out); the host does not know the covered count: every pixel is counted as covered (upper bound)
+    N2M_PROF(N2M_K_INTERP_FWD, (hipStream_t)stream, (double)H * W * (16.0 + 12.0 + 12.0 * A + 4.0 * A));
     interpolate_forward_kernel<<<n2m_ceil_div((uint64_t)H * W, 256), 256, 0, (hipStream_t)stream>>>(attr, rast, tri, V, F, A, H * W, out);
     N2M_CHECK_LAUNCH();
     return 0;
@@ -515,6 +518,7 @@ extern "C" int n2m_interpolate_backward(const float* attr, const float* rast, co
                                         uint32_t F, uint32_t A, uint32_t H, uint32_t W, float* grad_attr, float* grad_rast,
                                         void* stream) {
     N2M_NOTNULL(attr); N2M_NOTNULL(rast); N2M_NOTNULL(tri); N2M_NOTNULL(d_out);
+    N2M_PROF(N2M_K_INTERP_BWD, (hipStream_t)stream, (double)H * W * (16.0 + 12.0 + 12.0 * A + 4.0 * A + (grad_attr ? 12.0 * A : 0.0) + (grad_rast ? 16.0 : 0.0)));
     interpolate_backward_kernel<<<n2m_ceil_div((uint64_t)H * W, 256), 256, 0, (hipStream_t)stream>>>(attr, rast, tri, d_out, V, F, A, H * W,
                                                                                                   grad_attr, grad_rast);
     N2M_CHECK_LAUNCH();
@@ -542,6 +546,7 @@ extern "C" int n2m_antialias_forward(const float* color, const float* rast, cons
     N2M_NOTNULL(color); N2M_NOTNULL(rast); N2M_NOTNULL(pos); N2M_NOTNULL(tri); N2M_NOTNULL(table); N2M_NOTNULL(out);
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)H * W * C;
+    N2M_PROF(N2M_K_AA_FWD, s, (double)H * W * (8.0 * C + 16.0));          // SURVEY 8d (silhouette-pixel edge fetches not counted)
     copy_kernel<<<n2m_ceil_div(n, 256), 256, 0, s>>>(color, out, n);
     antialias_forward_kernel<<<n2m_ceil_div((uint64_t)H * W, 256), 256, 0, s>>>(color, rast, pos, tri, reinterpret_cast<const Edge*>(table),
                                                                               capacity, V, C, H, W, out);
@@ -558,6 +563,7 @@ extern "C" int n2m_antialias_backward(const float* color, const float* rast, con
     N2M_NOTNULL(grad_color);
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)H * W * C;
+    N2M_PROF(N2M_K_AA_BWD, s, (double)H * W * (12.0 * C + 16.0));
     copy_kernel<<<n2m_ceil_div(n, 256), 256, 0, s>>>(d_out, grad_color, n);     // identity part of the operator
     antialias_backward_kernel<<<n2m_ceil_div((uint64_t)H * W, 256), 256, 0, s>>>(color, rast, pos, tri, reinterpret_cast<const Edge*>(table),
                                                                                capacity, d_out, V, C, H, W, pos_gradient_boost, grad_color,

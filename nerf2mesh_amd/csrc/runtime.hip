@@ -36,7 +36,8 @@ uint64_t g_untimed[N2M_K_COUNT];
 const char* kNames[N2M_K_COUNT] = {"grid_encode_forward", "grid_encode_backward", "grad_total_variation",
                                    "march_rays_train_count", "march_rays_train_write", "composite_rays_train_forward",
                                    "composite_rays_train_backward", "near_far_from_aabb", "packbits", "mlp_forward",
-                                   "mlp_backward", "rasterize", "grid_encode_forward_packed", "adam_step"};
+                                   "mlp_backward", "rasterize", "grid_encode_forward_packed", "adam_step",
+                                   "interpolate_forward", "interpolate_backward", "antialias_forward", "antialias_backward", "rasterize_backward"};
 }  // namespace
 
 N2mProfScope::N2mProfScope(int kernel_id, hipStream_t s, double algo_bytes) : slot(-1), stream(s) {
