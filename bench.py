@@ -199,6 +199,9 @@ def main():
                     "1: stage-1 mesh/texture refinement step (BASELINE config 3)")
     ap.add_argument("--autograd", action="store_true", help="A/B: drive the step through torch.autograd (trainer.Stage0Trainer) instead of the step "
                     "executor (engine.Stage0Engine): same kernels, same arguments, more host time")
+    ap.add_argument("--recipe", default="lego", choices=["lego", "sdf", "garden"], help="lego: the headline config (BASELINE configs[1]); sdf: "
+                    "`--sdf` stage 0 (config 5: NeuS alpha, 7 density evaluations per sample, eikonal loss); garden: `--bound 16 --dt_gamma 1/256`, "
+                    "5 cascades, inner/outer TV split (config 4's recipe on the synthetic scene).  The last two run on trainer.Stage0Trainer")
     ap.add_argument("--unfused", action="store_true", help="A/B: evaluate the MLPs with nn.Linear calls (the reference graph) instead of the fused MFMA kernels")
     args = ap.parse_args()
 
@@ -235,11 +238,14 @@ def main():
         return bench_stage1(args, rank, world, device)
 
     torch.manual_seed(0)                                           # seed_everything(0), identical init on every rank
-    opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=not args.unfused)   # scripts/runall_syn.sh:1
+    recipes = {"lego": dict(bound=1, dt_gamma=0),                                    # scripts/runall_syn.sh:1
+               "sdf": dict(bound=1, dt_gamma=0, sdf=True),                            # scripts/runall_syn_sdf.sh:1
+               "garden": dict(bound=16, dt_gamma=1 / 256)}                            # scripts/runall_360.sh (bound 16, default dt_gamma)
+    opt = make_options(O=True, iters=30000, fused_mlp=not args.unfused, **recipes[args.recipe])
     model = NeRFNetwork(opt)
     poses = synthetic.make_cameras(100, seed=0)
     from nerf2mesh_amd.engine import Stage0Engine
-    use_engine = not args.autograd and not args.unfused
+    use_engine = not args.autograd and not args.unfused and Stage0Engine.supported(model, opt)
     tr = (Stage0Engine if use_engine else Stage0Trainer)(model, opt, poses, device, rank=rank, world_size=world, seed=0)
     tr.mark_untrained()
 
@@ -317,8 +323,10 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 march/composite, f16 autocast encode+MLP (reference -O recipe)", "data": "synthetic",
         "rays_per_sec": rays / dt,
-        "config": {"workload": "nerf_synthetic/lego stage-0 -O --bound 1 --dt_gamma 0, 800x800 x 100 synthetic views, "
-                               "num_points target 2^18/GPU (adaptive num_rays), occupancy refresh every 16 steps",
+        "config": {"workload": {"lego": "nerf_synthetic/lego stage-0 -O --bound 1 --dt_gamma 0",
+                                "sdf": "nerf_synthetic/lego --sdf stage-0 -O --bound 1 --dt_gamma 0 (NeuS alpha, finite-difference normals, eikonal loss)",
+                                "garden": "mip-360-style stage-0 -O --bound 16 --dt_gamma 1/256 (5 cascades, inner/outer TV) on the synthetic scene"}[args.recipe]
+                               + ", 800x800 x 100 synthetic views, num_points target 2^18/GPU (adaptive num_rays), occupancy refresh every 16 steps",
                    "parallelism": f"dp{world} (rays sharded, grad all-reduce over {dist.get_backend()})" if world > 1 else "single GPU",
                    "mlp": "nn.Linear (unfused)" if args.unfused else "fused MFMA field kernels",
                    "driver": "engine.Stage0Engine (fixed launch sequence)" if use_engine else "trainer.Stage0Trainer (torch.autograd)", "pretrain_steps": args.pretrain, "samples_per_step_per_gpu": samples / args.steps / world,

@@ -31,8 +31,9 @@ extern "C" {
 #endif
 
 /* Forward.  xyz [M,3] f32 (grid-bound coordinates, as fed to the encoders), dirs [M,3] f32 (may be NULL when
- * shading == 0; unit vectors, or with normalize_dirs != 0 the raw ray directions march_rays_train hands out, which are
- * then normalised on load exactly like safe_normalize, nerf/renderer.py:704), h1 [16,M] f32 (density features, LEVEL-major as n2m_grid_encode_forward writes them), h2 [16,M,2] f16
+ * shading == 0; unit vectors, or with bit 0 of normalize_dirs set the raw ray directions march_rays_train hands out, which are
+ * then normalised on load exactly like safe_normalize, nerf/renderer.py:704; bit 1 of normalize_dirs selects the SDF head: sigma is the
+ * fp16 output of sigma_net as it is, `h[..., 0].float()` of nerf/network.py:100-101, instead of trunc_exp of it -- forward and backward), h1 [16,M] f32 (density features, LEVEL-major as n2m_grid_encode_forward writes them), h2 [16,M,2] f16
  * (colour features, level-major; may be NULL
  * when rgb == NULL: density-only evaluation as in update_extra_state).
  * Outputs: sigma [M] f32; rgb [M,3] f32 and specular [M,3] f32 (either may be NULL; specular is not written for

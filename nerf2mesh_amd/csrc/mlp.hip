@@ -143,6 +143,7 @@ struct FieldArgs {
     const float* xyz; const float* dirs; const float* h1; const _Float16* h2;
     const float* w[7];       // sigma0, sigma1, color0, color1, color2, spec0, spec1
     uint32_t M; int shading; int normalize_dirs;
+    int raw_density;         // SDF head: sigma = the fp16 Linear output as it is (nerf/network.py:100-101), no trunc_exp
     float* sigma; float* rgb; float* specular;
     // backward only
     const float* d_sigma; const float* d_rgb; const float* d_specular;
@@ -236,7 +237,7 @@ __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
             f16x o = zero16();
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) o = MFMA(ld_a(lds + O_S1, P_S1, 0, kb, lane), b1[kb], o);
-            if (valid && g == 0) a.sigma[s] = expf((float)(_Float16)o[0]);
+            if (valid && g == 0) a.sigma[s] = a.raw_density ? (float)(_Float16)o[0] : expf((float)(_Float16)o[0]);
         }
         if (DO_COLOR) {   // ---- colour: [h2 | xyz] -> 64 -> 64 -> 6 -> sigmoid ; specular: [d | feat] -> 32 -> 3 -> sigmoid
             h4 b0[5];
@@ -403,7 +404,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             h4 dy1 = zero4();
             if (valid && g == 0) {
                 const float pre = (float)(_Float16)o[0];
-                dy1[0] = (_Float16)(a.d_sigma[s] * expf(fminf(fmaxf(pre, -15.f), 15.f)));
+                dy1[0] = a.raw_density ? (_Float16)a.d_sigma[s] : (_Float16)(a.d_sigma[s] * expf(fminf(fmaxf(pre, -15.f), 15.f)));
             }
             // dW1 = dy1^T x H1
             wave_lds_fence();
@@ -659,7 +660,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             h4 dy1 = zero4();
             if (valid && g == 0) {
                 const float pre = (float)(_Float16)o[0];
-                dy1[0] = (_Float16)(a.d_sigma[s] * expf(fminf(fmaxf(pre, -15.f), 15.f)));
+                dy1[0] = a.raw_density ? (_Float16)a.d_sigma[s] : (_Float16)(a.d_sigma[s] * expf(fminf(fmaxf(pre, -15.f), 15.f)));
             }
             // stage S1: dW1 = dy1^T x H1
 #pragma unroll
@@ -884,7 +885,7 @@ extern "C" int n2m_field_forward(const float* xyz, const float* dirs, const floa
     }
     if (M == 0) return 0;
     FieldArgs a{};
-    a.xyz = xyz; a.dirs = dirs; a.h1 = h1; a.h2 = (const _Float16*)h2; a.normalize_dirs = normalize_dirs;
+    a.xyz = xyz; a.dirs = dirs; a.h1 = h1; a.h2 = (const _Float16*)h2; a.normalize_dirs = normalize_dirs & 1; a.raw_density = (normalize_dirs >> 1) & 1;
     for (int i = 0; i < 7; ++i) a.w[i] = w[i];
     a.M = M; a.shading = shading; a.sigma = sigma; a.rgb = rgb; a.specular = specular;
     hipStream_t s = (hipStream_t)stream;
@@ -926,7 +927,7 @@ extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const flo
         attr_set = true;
     }
     FieldArgs a{};
-    a.xyz = xyz; a.dirs = dirs; a.h1 = h1; a.h2 = (const _Float16*)h2; a.normalize_dirs = normalize_dirs;
+    a.xyz = xyz; a.dirs = dirs; a.h1 = h1; a.h2 = (const _Float16*)h2; a.normalize_dirs = normalize_dirs & 1; a.raw_density = (normalize_dirs >> 1) & 1;
     for (int i = 0; i < 7; ++i) { a.w[i] = w[i]; a.dw[i] = dw[i]; }
     a.M = M; a.shading = shading;
     a.d_sigma = d_sigma; a.d_rgb = d_rgb; a.d_specular = d_specular; a.d_h1 = d_h1; a.d_h2 = (_Float16*)d_h2; a.found_inf = found_inf;

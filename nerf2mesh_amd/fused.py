@@ -80,6 +80,8 @@ def _encode_backward_lm(grad_lm, x01, emb, enc, max_level, ws_slot=0):
     g = torch.zeros_like(emb)
     from .gridencoder import binned_backward
     req = getattr(enc, "tv_request", None)          # set by the trainer: fold the TV gradient into this backward
+    if req is not None and (req.get("done") or (req.get("rows") is not None and req["rows"] != B)):
+        req = None                                  # already folded in, or a different batch of points (SDF: the finite-difference offsets)
     amp = getattr(enc, "amp_request", None)         # set by optim.FusedAdamAMP users: {"found_inf": tensor, "flagged": bool}
     finf = amp["found_inf"] if amp is not None else None
     if req is not None and binned_backward(enc, grad_lm, x01, g, max_level, tv=(emb, req["weight"], req["weight_outer"], req["inner01"], req["scale"]),
@@ -106,6 +108,8 @@ def _encode_backward_pair(d_h1, d_h2, x01, emb1, emb2h, net, max_level, in_affin
     g1 = torch.empty_like(emb1)                        # overwrite mode: the kernels define every row, no zero-fill
     g2 = torch.empty(emb1.shape[0], 2, dtype=torch.float16, device=emb1.device)
     req = getattr(enc1, "tv_request", None)
+    if req is not None and (req.get("done") or (req.get("rows") is not None and req["rows"] != x01.shape[0])):
+        req = None
     amp1, amp2 = getattr(enc1, "amp_request", None), getattr(enc2, "amp_request", None)
     finf = amp1["found_inf"] if amp1 is not None else (amp2["found_inf"] if amp2 is not None else None)
     tv = (emb1, req["weight"], req["weight_outer"], req["inner01"], req["scale"]) if req is not None else None
@@ -158,10 +162,11 @@ class _fused_field(Function):
             dirs = dirs.float().contiguous() if shading != 0 else None
             rgb = torch.empty(M, 3, dtype=torch.float32, device=xyz.device)
             spec = torch.empty(M, 3, dtype=torch.float32, device=xyz.device) if shading != 0 else None
-        L.call("n2m_field_forward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, int(normalize_dirs), _p(sigma), _p(rgb),
+        flags = int(bool(normalize_dirs)) | (2 if getattr(net.opt, "sdf", False) else 0)      # bit 1: SDF head, sigma = raw fp16 output
+        L.call("n2m_field_forward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, flags, _p(sigma), _p(rgb),
                _p(spec), L.stream())
         ctx.net, ctx.shading, ctx.want_color, ctx.max_level, ctx.want_density = net, shading, want_color, max_level, want_density
-        ctx.normalize_dirs = int(normalize_dirs)
+        ctx.normalize_dirs = flags
         ctx.bound = bound
         ctx.save_for_backward(xyz, dirs, x01, h1, h2, emb1, emb2h, *ws)
         if not want_color:
@@ -209,7 +214,8 @@ class _fused_field(Function):
             # weights whose gradient this call does not produce stay out of the optimizer step (torch: grad is None), so that their
             # Adam step count starts when they first train -- the specular head after opt.diffuse_step
             live = [want_density] * 2 + [want_color] * 3 + [want_color and shading != 0] * 2
-            amp["dw_flat"], amp["dw_views"] = flat, [g if ok else None for g, ok in zip(dws, live)]
+            prev = amp.get("dw_views") or [None] * 7        # an earlier backward call of the same step (SDF: field + normals) keeps its weights live
+            amp["dw_flat"], amp["dw_views"] = flat, [g if (ok or pv is not None) else None for g, ok, pv in zip(dws, live, prev)]
         L.call("n2m_field_backward", _p(xyz), _p(dirs), _p(h1), _p(h2), *[_p(w) for w in ws], M, shading, ctx.normalize_dirs, _p(d_sigma), _p(d_rgb),
                _p(d_spec), _p(d_h1), _p(d_h2), *[_p(g) for g in dws], _p(amp["found_inf"]) if amp is not None else None, L.stream())
         if amp is not None:

@@ -250,9 +250,11 @@ class GridEncoder(nn.Module):
         return sh
 
     @torch.no_grad()
-    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
+    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000, scale=None):
         """Adds the TV gradient of the cells containing `inputs` into embeddings.grad, in place, in fp32
-        (grid.py:170-192).  Call after backward (and after GradScaler.unscale_) and before optimizer.step."""
+        (grid.py:170-192).  Call after backward (and after GradScaler.unscale_) and before optimizer.step.
+        scale (not in the reference signature): a device scalar the term is multiplied by inside the kernel -- the loss scale, when the
+        gradients are still scaled -- so that the caller needs no host read of it."""
         D, C = self.input_dim, self.embeddings.shape[1]
         Lv = self.offsets.shape[0] - 1
         S = float(np.log2(self.per_level_scale))
@@ -267,7 +269,9 @@ class GridEncoder(nn.Module):
         emb = self.embeddings.detach().float().contiguous()
         grad = self.embeddings.grad
         if D == 3 and grad.dtype == torch.float32 and grad.is_contiguous():
-            if binned_tv(self, inputs, emb, grad, float(weight)):
+            if binned_tv(self, inputs, emb, grad, float(weight), scale=scale):
                 return
+        if scale is not None:
+            weight = float(weight) * float(scale)            # scatter fallback (table formats the binned path does not cover): host read
         L.call("n2m_grad_total_variation", _p(inputs), _p(emb), _p(self.embeddings.grad), _p(self.offsets), float(weight), B, D, C,
                Lv, S, int(self.base_resolution), self.gridtype_id, int(bool(self.align_corners)), L.F32, L.stream())

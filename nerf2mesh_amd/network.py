@@ -78,7 +78,8 @@ class NeRFNetwork(NeRFRenderer):
         return self._packed
 
     def _can_fuse(self, c=None):
-        return bool(getattr(self.opt, "fused_mlp", False)) and c is None and not self.opt.sdf and x_is_cuda(self)
+        # SDF: the fused kernels return the raw fp16 sigma_net output (flag bit 1); progressive levels go through max_level
+        return bool(getattr(self.opt, "fused_mlp", False)) and c is None and x_is_cuda(self)
 
     def forward(self, x, d, c=None, shading="full", raw_dirs=False):
         """raw_dirs: `d` are un-normalised ray directions (only valid when _can_fuse(c): the kernel normalises on load)."""
@@ -93,7 +94,7 @@ class NeRFNetwork(NeRFRenderer):
     def density(self, x):
         if self._can_fuse() and not x.requires_grad:
             from .fused import fused_density
-            return {"sigma": fused_density(self, x.reshape(-1, 3)).view(x.shape[:-1])}
+            return {"sigma": fused_density(self, x.reshape(-1, 3)).view(x.shape[:-1])}     # trunc_exp(.) or, SDF, the raw output
         h = self.encoder(x, bound=self.bound, max_level=self.max_level)
         h = self.sigma_net(torch.cat([x, h], dim=-1))
         sigma = h[..., 0].float() if self.opt.sdf else trunc_exp(h[..., 0])
@@ -118,15 +119,17 @@ class NeRFNetwork(NeRFRenderer):
         return self.encoder.embeddings.device
 
     def normal(self, x, epsilon=1e-4):
-        """Central finite differences of the density/SDF: 6 extra density() evaluations (nerf/network.py:143-154)."""
-        comps = []
+        """Central finite differences of the density/SDF: 6 extra density() evaluations (nerf/network.py:143-154) -- here ONE call on
+        the six offset copies stacked into a [6M, 3] batch (same points, same clamp, same arithmetic per point; one encode + one MLP
+        launch forward and backward instead of six)."""
+        M = x.shape[0]
+        off = torch.zeros(6, 1, 3, device=x.device, dtype=x.dtype)
         for axis in range(3):
-            off = torch.zeros(1, 3, device=x.device)
-            off[0, axis] = epsilon
-            pos = self.density((x + off).clamp(-self.bound, self.bound))["sigma"]
-            neg = self.density((x - off).clamp(-self.bound, self.bound))["sigma"]
-            comps.append(0.5 * (pos - neg) / epsilon)
-        return torch.stack(comps, dim=-1)
+            off[2 * axis, 0, axis] = epsilon
+            off[2 * axis + 1, 0, axis] = -epsilon
+        pts = (x.unsqueeze(0) + off).clamp(-self.bound, self.bound).reshape(6 * M, 3)
+        s = self.density(pts)["sigma"].view(6, M)
+        return torch.stack([0.5 * (s[0] - s[1]) / epsilon, 0.5 * (s[2] - s[3]) / epsilon, 0.5 * (s[4] - s[5]) / epsilon], dim=-1)
 
     def geo_feat(self, x, c=None):
         h = self.encoder_color(x, bound=self.bound, max_level=self.max_level)

@@ -32,7 +32,7 @@ class Stage0Trainer:
         self.gen_noise.manual_seed(seed + rank + 104729)
         # main.py:221 Adam(eps=1e-15) + nerf/utils.py:506 GradScaler.  Single GPU with the fused field: optim.FusedAdamAMP does both
         # in two launches and takes the inf/nan verdict from the kernels that produce the gradients.
-        self.amp_adam = device.type == "cuda" and bool(getattr(opt, "fused_mlp", False)) and not opt.sdf and getattr(opt, "ind_dim", 0) == 0
+        self.amp_adam = device.type == "cuda" and bool(getattr(opt, "fused_mlp", False)) and bool(opt.fp16) and getattr(opt, "ind_dim", 0) == 0
         if self.amp_adam:
             from .optim import FusedAdamAMP
             self.optimizer = FusedAdamAMP(model.get_params(opt.lr), eps=1e-15, amp=bool(opt.fp16))
@@ -211,8 +211,10 @@ class Stage0Trainer:
                     (None if self.world == 1 else self._one / self.world)
             else:
                 scale_t = self.scaler.scale(self._one) if self.scaler.is_enabled() else None   # device scalar, no host sync
+            # rows: only the backward call over THIS batch's M samples folds the term in (SDF evaluates the density encoder a second time
+            # on the 6 M finite-difference offsets)
             tv_req = dict(weight=opt.lambda_tv, weight_outer=opt.lambda_tv * (10 if opt.bound > 1 else 1), inner01=0.5 / model.bound,
-                          scale=scale_t, done=False)
+                          scale=scale_t, done=False, rows=M)
             model.encoder.tv_request = tv_req
         xyzs = out["xyzs"]
         if self.amp_adam:
@@ -276,18 +278,18 @@ class Stage0Trainer:
         return loss
 
     def _tv(self, xyzs, scale, scale_tensor=None):
+        """Stand-alone TV pass (TV not folded into the backward: progressive levels, bound > 1 on the unfused path).  scale_tensor: the
+        loss scale as a device scalar, multiplied in by the kernel (no host read-back)."""
         opt, model = self.opt, self.model
         if opt.lambda_tv <= 0 or xyzs is None or xyzs.shape[0] == 0:
             return
-        if scale_tensor is not None:
-            scale = scale * float(scale_tensor)          # rare path (TV not folded into the backward): one host read-back
         lam = opt.lambda_tv * scale
         if opt.bound > 1:                                                # nerf/utils.py:815-821
             inner = xyzs.abs().amax(dim=-1) <= 1
-            model.encoder.grad_total_variation(lam, xyzs[inner].contiguous(), model.bound)
-            model.encoder.grad_total_variation(lam * 10, xyzs[~inner].contiguous(), model.bound)
+            model.encoder.grad_total_variation(lam, xyzs[inner].contiguous(), model.bound, scale=scale_tensor)
+            model.encoder.grad_total_variation(lam * 10, xyzs[~inner].contiguous(), model.bound, scale=scale_tensor)
         else:
-            model.encoder.grad_total_variation(lam, xyzs, model.bound)
+            model.encoder.grad_total_variation(lam, xyzs, model.bound, scale=scale_tensor)
 
     @torch.no_grad()
     def eval_psnr(self, cam=0, downscale=4):

@@ -197,31 +197,39 @@ def test_unchanged_reference_python_over_the_hip_backend(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [False, True])
-def test_fp16_recipe_tracks_the_reference_python_on_the_same_device(fused):
+@pytest.mark.parametrize("name,fused", [("nerf", False), ("nerf", True), ("sdf", False), ("sdf", True)])
+def test_fp16_recipe_tracks_the_reference_python_on_the_same_device(name, fused):
     """`-O` (fp16 autocast): unchanged reference Python over the HIP backend vs the restated renderer, unfused (same torch graph:
-    integer outputs exact, fp outputs within fp16 GEMM re-association) and fused MFMA field (fp16 activations, fp32 accumulate)."""
-    fx = fixture("nerf")
-    ref = _reference_on_hip(False, fp16=True)
-    a = RC.run_case(ref, lambda m, poses, intr: m.mark_untrained_grid(RC.dataset_stub(poses, intr)), "meshgrid", "cuda",
-                    bitfield_override=fx["density_bitfield"])
+    integer outputs exact, fp outputs within fp16 GEMM re-association) and fused MFMA field (fp16 activations, fp32 accumulate; SDF:
+    raw-sdf head + the six finite-difference evaluations as one stacked call)."""
+    sdf = name == "sdf"
+    fx = fixture(name)
+    ref = _reference_on_hip(sdf, fp16=True)
+    mark_ref = lambda m, poses, intr: m.mark_untrained_grid(RC.dataset_stub(poses, intr))
+    a = RC.run_case(ref, mark_ref, "meshgrid", "cuda", sdf=sdf, bitfield_override=fx["density_bitfield"])
     del ref
-    mine = _ours(False, fp16=True, fused=fused)
-    b = RC.run_case(mine, _ours_mark, "morton", "cuda", bitfield_override=fx["density_bitfield"])
+    mine = _ours(sdf, fp16=True, fused=fused)
+    b = RC.run_case(mine, _ours_mark, "morton", "cuda", sdf=sdf, bitfield_override=fx["density_bitfield"])
     assert int(a["num_points"]) == int(b["num_points"]) == int(fx["num_points"])
     assert np.array_equal(a["xyzs_head"], b["xyzs_head"])
     # the fp16 density differs from the fp32 fixture by ~1e-3 relative: bits may flip near the threshold only
     for r in (a, b):
         bits, ref_bits = np.unpackbits(r["density_bitfield"]), np.unpackbits(fx["density_bitfield"])
-        assert (bits != ref_bits).mean() < 2e-4
-    tol_img = 4e-3 if fused else 2e-3
+        assert (bits != ref_bits).mean() < (2e-3 if sdf else 2e-4)
+    # SDF: alpha comes from finite differences (eps = 1e-4) of an fp16-rounded sdf -- differences of a few fp16 ulps divided by 2e-4:
+    # the reference's own fp16 image is far from the fp32 fixture, so only the two fp16 paths are compared with each other, loosely
+    tol_img = (8e-2 if sdf else 4e-3) if fused else (5e-2 if sdf else 2e-3)
+    rows = []
     for key in ("image", "weights_sum", "eval_image"):
-        d = np.abs(a[key] - b[key]).max()
-        assert d <= tol_img, f"{key}: {d:.3g}"
-        # and both stay near the fp32 reference
-        assert np.abs(a[key] - fx[key]).max() <= 2e-2 and np.abs(b[key] - fx[key]).max() <= 2e-2
+        d = float(np.abs(a[key] - b[key]).mean() if sdf else np.abs(a[key] - b[key]).max())
+        rows.append(f"  {key}: reference-fp16 vs ours {d:.3g} (limit {tol_img}); vs fp32 fixture: {np.abs(a[key] - fx[key]).max():.3g} / {np.abs(b[key] - fx[key]).max():.3g}")
+        assert d <= tol_img, rows[-1]
+        if not sdf:      # and both stay near the fp32 reference
+            assert np.abs(a[key] - fx[key]).max() <= 2e-2 and np.abs(b[key] - fx[key]).max() <= 2e-2
     for key in a:
         if key.startswith("grad.") or key.startswith("grad_head."):
             ea, eb = relmax(a[key], fx[key]), relmax(b[key], fx[key])
+            rows.append(f"  {key}: vs fp32 fixture, reference-fp16 {ea:.3g}, ours {eb:.3g}")
             # the restated/fused path must be no farther from the fp32 truth than the reference's own fp16 graph (x1.5 + floor)
-            assert eb <= 1.5 * ea + 2e-3, f"{key}: ours {eb:.3g} vs reference-fp16 {ea:.3g} (both vs fp32 fixture)"
+            assert eb <= 1.5 * ea + (5e-2 if sdf else 2e-3), rows[-1]
+    print(f"\n{name} fused={fused}\n" + "\n".join(rows))

@@ -1,15 +1,19 @@
 #!/bin/bash
-# Round-end measurement set (run on the GPU box from the repo root): PMC traffic passes, kernel-trace stats, default bench lines.
-# Outputs land in gpurun_out/; copy what is to be kept into profiles/.
+# Measurement set of a round (run on the GPU box from the repo root): PMC traffic passes, kernel-trace stats + one step's timeline,
+# default bench lines (stage 0, stage 1).  Outputs land in gpurun_out/<tag>/; copy what is to be kept into profiles/.
+#   tools/collect_profiles.sh r02
 set -u
-R=$(pwd); TAG=${1:-v9}
+R=$(pwd); TAG=${1:-r02}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --pretrain 200 --warmup 5 --steps 20 --no-prof --no-cpu-baseline"
+rm -rf /tmp/pmc_f /tmp/pmc_w /tmp/prof_s
+# counters in their own passes, with --kernel-trace only (no other trace domains)
 timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- $B > /tmp/pf.log 2>&1
 timeout 250 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- $B > /tmp/pw.log 2>&1
-python $R/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $R/gpurun_out/r01_pmc_traffic_$TAG.json > /tmp/pt.log 2>&1; tail -3 /tmp/pt.log
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -- python $R/bench.py --no-cpu-baseline --no-prof --pretrain 300 --warmup 20 --steps 200 > $R/gpurun_out/bench_prof_$TAG.json 2>/tmp/ps.log
-cp $(find /tmp/prof_s -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r01_step_kernel_stats_$TAG.csv
+python $R/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $O/${TAG}_pmc_traffic.json > $O/pmc_traffic.txt 2>&1; head -12 $O/pmc_traffic.txt
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -- python $R/bench.py --no-cpu-baseline --no-prof --pretrain 300 --warmup 20 --steps 200 > $O/bench_under_rocprof.json 2>/tmp/ps.log
+cp $(find /tmp/prof_s -name "*kernel_stats.csv" | head -1) $O/${TAG}_step_kernel_stats.csv
+python $R/tools/step_timeline.py $(find /tmp/prof_s -name "*kernel_trace.csv" | head -1) > $O/${TAG}_step_timeline.txt
 cd $R
-python bench.py > gpurun_out/r01_bench_$TAG.json 2>gpurun_out/bench_$TAG.err; tail -c 400 gpurun_out/r01_bench_$TAG.json
-python bench.py --stage 1 --no-cpu-baseline > gpurun_out/r01_bench_${TAG}_stage1.json 2>/dev/null; tail -c 300 gpurun_out/r01_bench_${TAG}_stage1.json
+python bench.py > $O/${TAG}_bench.json 2>$O/bench.err; python tools/show_bench.py $O/${TAG}_bench.json
+python bench.py --stage 1 --no-cpu-baseline > $O/${TAG}_bench_stage1.json 2>/dev/null; tail -c 300 $O/${TAG}_bench_stage1.json
