@@ -256,6 +256,17 @@ int n2m_grid_encode_backward_binned_pair(const float* grad1, const void* grad2, 
                                          float tv_inner01, const float* tv_scale, float* found_inf, float in_scale,
                                          float in_offset, int overwrite, void* workspace, uint64_t workspace_bytes,
                                          void* stream);
+/* The same for ONE half of the levels (max_level == L == 16 only): half = 1 -> levels 8..15, half = 2 -> levels 0..7; the two calls
+ * together equal the full call bit for bit (levels are independent).  For callers that exchange the table gradients between GPUs: the
+ * rows of the fine half are final after the first call, their collective can run while the second call computes (engine.py). */
+int n2m_grid_encode_backward_binned_pair_half(const float* grad1, const void* grad2, const float* inputs,
+                                         const int32_t* host_offsets, float* grad_embeddings1,
+                                         void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level, float S,
+                                         uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                         const float* tv_embeddings, float tv_weight, float tv_weight_outer,
+                                         float tv_inner01, const float* tv_scale, float* found_inf, float in_scale,
+                                         float in_offset, int overwrite, void* workspace, uint64_t workspace_bytes,
+                                         void* stream, int half);
 
 /* ------------------------------------------------------------------------------------------------------
  * freqencoder   (reference: freqencoder/src/freqencoder.h:6-10, freqencoder/src/bindings.cpp:5-8)

@@ -1435,7 +1435,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
                      uint32_t* __restrict__ directory, uint16_t* __restrict__ log_rel, uint32_t* __restrict__ log_v1,
                      uint32_t* __restrict__ log_v2, float* __restrict__ found_inf, float in_scale, float in_offset,
                      float* __restrict__ clear1, _Float16* __restrict__ clear2, uint32_t clear_mask1, uint32_t clear_mask2,
-                     uint32_t merge_levels, uint32_t groups_x) {
+                     uint32_t merge_levels, uint32_t groups_x, uint32_t slot_begin) {
     __builtin_amdgcn_s_setprio(3);
     constexpr uint32_t D = 3;
     constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
@@ -1459,8 +1459,9 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
     uint32_t level = blockIdx.y, group = blockIdx.x, n_groups = gridDim.x;
     if (groups_x != 0u) {
         const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
-        const uint32_t slot = k / groups_x;                          // which of this XCD's levels
-        group = k - slot * groups_x;
+        const uint32_t ls = k / groups_x;
+        const uint32_t slot = slot_begin + ls;                       // which of this XCD's levels (a launch may cover a range of slots)
+        group = k - ls * groups_x;
         n_groups = groups_x;
         const uint32_t pairi = xcd + 8u * (slot >> 1);               // levels come in pairs (p, L-1-p)
         level = (slot & 1u) ? pairi : plan.levels - 1u - pairi;
@@ -2075,7 +2076,7 @@ int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table
 int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* inputs, TvParams tv, float* table1, _Float16* table2, uint32_t B,
                        uint32_t max_level, const int32_t* host_offsets, const LevelTable& lv, uint32_t gridtype, bool align, uint32_t interp,
                        void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn, float* found_inf, float in_scale,
-                       float in_offset, bool overwrite, uint32_t L) {
+                       float in_offset, bool overwrite, uint32_t L, int half = 0) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
@@ -2100,8 +2101,12 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         const _Float16* g2 = grad2 + (size_t)b0 * 2;
         const float* x = inputs + (size_t)b0 * 3;
         // the fp32 table accumulates two partitions per work item: same item count and LDS bytes as on its own 8192-row structure
-        BinPlan plan1 = lay.plan;
-        uint32_t items1 = 0, cm1 = 0, cm2 = 0;
+        // half != 0 (max_level == 16, XCD-aware fill): this call covers the levels of ONE fill slot only -- 1: levels 8..15 (slot 0),
+        // 2: levels 0..7 (slot 1).  A caller that exchanges gradients between GPUs issues the fine half first and starts its collective
+        // on those table rows while the coarse half is still being computed (nerf2mesh_amd/engine.py, multi-rank path).
+        auto in_half = [&](uint32_t l) { return half == 0 || (half == 1 ? l >= 8u : l < 8u); };
+        BinPlan plan1 = lay.plan, plan2 = lay.plan;
+        uint32_t items1 = 0, items2 = 0, cm1 = 0, cm2 = 0;
         for (uint32_t l = 0; l < max_level; ++l) {
             const uint32_t pairs = (plan1.parts[l] + 1u) / 2u;
             const uint64_t per_item = (uint64_t)8 * Bc / pairs;
@@ -2110,11 +2115,15 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
             g = g > plan1.tiles ? plan1.tiles : g;
             plan1.groups[l] = g;
             plan1.item_prefix[l] = items1;
+            plan2.item_prefix[l] = items2;
+            if (!in_half(l)) continue;                              // no work items for the levels of the other half
             items1 += pairs * g;
+            items2 += lay.plan.parts[l] * lay.plan.groups[l];
             if (ow && g > 1u) cm1 |= 1u << l;                      // levels that add atomically: cleared by the fill kernel
             if (ow && lay.plan.groups[l] > 1u) cm2 |= 1u << l;
         }
         plan1.item_prefix[max_level] = items1;
+        plan2.item_prefix[max_level] = items2;
         if (ow && max_level < L) {                                  // levels the call does not touch
             const size_t t0 = (size_t)host_offsets[max_level], t1 = (size_t)host_offsets[L];
             N2M_HIP(hipMemsetAsync(table1 + t0, 0, (t1 - t0) * sizeof(float), s));
@@ -2123,28 +2132,31 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         static const uint32_t merge_levels = getenv("N2M_BIN_MERGE_LEVELS") ? (uint32_t)atoi(getenv("N2M_BIN_MERGE_LEVELS")) : kPairMergeLevels;
         static const bool xcd_map = getenv("N2M_FILL_NO_XCD") == nullptr;       // A/B switch; measured 332 -> 311 us for fill + accumulates
         dim3 grid((lay.plan.tiles + kPairTilesPerWg - 1) / kPairTilesPerWg, max_level);           // each workgroup walks ~kPairTilesPerWg tiles
-        uint32_t groups_x = 0;
+        uint32_t groups_x = 0, slot_begin = 0;
+        N2M_REQUIRE(half == 0 || (xcd_map && max_level == 16u && (half == 1 || half == 2)), N2M_EUNSUPPORTED,
+                    "%s: level halves need max_level == 16 and the XCD-aware fill", fn);
         if (xcd_map) {           // 1-D grid: 8 XCDs x ceil(levels / 8) level slots (rounded to pairs) x groups
             groups_x = grid.x;
-            const uint32_t slots = 2u * ((max_level + 15u) / 16u);
+            uint32_t slots = 2u * ((max_level + 15u) / 16u);
+            if (half != 0) { slot_begin = (uint32_t)half - 1u; slots = 1u; }
             grid = dim3(8u * slots * groups_x, 1);
         }
         if (tv.table)
             bin_fill_pair_kernel<true><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
                                                                              directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset, ow ? table1 : nullptr,
-                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x);
+                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin);
         else
             bin_fill_pair_kernel<false><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
                                                                               directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset, ow ? table1 : nullptr,
-                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x);
+                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin);
         N2M_CHECK_LAUNCH();
-        const uint32_t items = lay.plan.item_prefix[max_level];
+        const uint32_t items = items2;
         const uint32_t nb = items < 4096u ? items : 4096u;
         static const uint32_t acc_dbg = getenv("N2M_ACC_DEBUG") ? (uint32_t)atoi(getenv("N2M_ACC_DEBUG")) : 0u;   // measurement switches (wrong results)
         bin_accumulate_kernel<float, 1, kPairP, 2, true><<<items1 < 4096u ? items1 : 4096u, 1024, kPairP * 16, s>>>(
             table1, plan1, lv, gridtype, align, level_max, directory, nullptr, found_inf, log_rel, log_v1, ow, acc_dbg);
         N2M_CHECK_LAUNCH();
-        bin_accumulate_kernel<_Float16, 2, kPairP, 1, true><<<nb, 1024, kPairP * 16, s>>>(table2, lay.plan, lv, gridtype, align, level_max + kMaxLevels,
+        bin_accumulate_kernel<_Float16, 2, kPairP, 1, true><<<nb, 1024, kPairP * 16, s>>>(table2, plan2, lv, gridtype, align, level_max + kMaxLevels,
                                                                                         directory, nullptr, found_inf, log_rel, log_v2, ow, acc_dbg);
         N2M_CHECK_LAUNCH();
     }
@@ -2354,19 +2366,49 @@ extern "C" uint64_t n2m_grid_binned_pair_workspace_bytes(uint32_t B, uint32_t ma
     return lay.ok ? (uint64_t)lay.bytes : 0;
 }
 
+static int binned_pair_entry(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
+                             float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
+                             float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                             const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
+                             const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
+                             void* workspace, uint64_t workspace_bytes, void* stream, int half);
+
 extern "C" int n2m_grid_encode_backward_binned_pair(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
                                                     float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
                                                     float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                                                     const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
                                                     const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
                                                     void* workspace, uint64_t workspace_bytes, void* stream) {
+    return binned_pair_entry(grad1, grad2, inputs, host_offsets, grad_embeddings1, grad_embeddings2, B, L, max_level, S, H, gridtype, align_corners,
+                             interp, tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale, found_inf, in_scale, in_offset, overwrite,
+                             workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int n2m_grid_encode_backward_binned_pair_half(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
+                                                         float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
+                                                         float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                                         const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
+                                                         const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
+                                                         void* workspace, uint64_t workspace_bytes, void* stream, int half) {
+    N2M_REQUIRE(half == 1 || half == 2, N2M_EINVAL, "grid_encode_backward_binned_pair_half: half must be 1 (levels 8..15) or 2 (levels 0..7)");
+    return binned_pair_entry(grad1, grad2, inputs, host_offsets, grad_embeddings1, grad_embeddings2, B, L, max_level, S, H, gridtype, align_corners,
+                             interp, tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale, found_inf, in_scale, in_offset, overwrite,
+                             workspace, workspace_bytes, stream, half);
+}
+
+static int binned_pair_entry(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
+                             float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
+                             float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                             const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
+                             const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
+                             void* workspace, uint64_t workspace_bytes, void* stream, int half) {
     const char* fn = "grid_encode_backward_binned_pair";
     if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
     N2M_REQUIRE(grad1 && grad2 && inputs && host_offsets && grad_embeddings1 && grad_embeddings2 && workspace, N2M_ENULL, "%s: NULL tensor", fn);
     N2M_REQUIRE(!tv_embeddings || max_level == L, N2M_EUNSUPPORTED, "%s: the fused TV term needs max_level == L", fn);
     hipStream_t s = (hipStream_t)stream;
     if (B == 0 || max_level == 0) {
-        if (overwrite && host_offsets[L] > 0) {
+        if (overwrite && host_offsets[L] > 0 && half != 2) {
             N2M_HIP(hipMemsetAsync(grad_embeddings1, 0, (size_t)host_offsets[L] * sizeof(float), s));
             N2M_HIP(hipMemsetAsync(grad_embeddings2, 0, (size_t)host_offsets[L] * 2u * sizeof(_Float16), s));
         }
@@ -2374,11 +2416,12 @@ extern "C" int n2m_grid_encode_backward_binned_pair(const float* grad1, const vo
     }
     const LevelTable lv = make_levels(L, S, H);
     const TvParams tv{tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale};
-    // algorithmic bytes of BOTH encoders' backward + the TV stencil reads
-    N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (12.0 + (double)max_level * (4 + 4) + 2.0 * max_level * 8 * (4 + 4) +
-                                             (tv_embeddings ? (double)L * 7 * 4.0 : 0.0)));
+    // algorithmic bytes of BOTH encoders' backward + the TV stencil reads (a half call: its eight levels)
+    const double lvls = half ? 8.0 : (double)max_level;
+    N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (12.0 + lvls * (4 + 4) + 2.0 * lvls * 8 * (4 + 4) + (tv_embeddings ? lvls * 7 * 4.0 : 0.0)));
     return launch_binned_pair(grad1, (const _Float16*)grad2, inputs, tv, grad_embeddings1, (_Float16*)grad_embeddings2, B, max_level, host_offsets, lv,
-                              gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf, in_scale, in_offset, overwrite != 0, L);
+                              gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf, in_scale, in_offset, overwrite != 0, L,
+                              half);
 }
 
 extern "C" int n2m_grid_encode_forward_pair(const float* inputs, const float* embeddings1, const void* embeddings2, const int32_t* offsets,

@@ -91,6 +91,7 @@ class Stage0Engine:
             from .parallel import GradSync
             self.sync = GradSync(model, world_size)
         self.side = L.side_stream(dev, slot=2)
+        self.split_backward = True            # multi-rank: table backward in two level halves, the first half's all-reduce under the second
         self.overlap = True                   # next batch on the side stream (False: everything on the main stream, same results)
 
         e1, e2 = model.encoder, model.encoder_color
@@ -366,6 +367,7 @@ class Stage0Engine:
         loss = b.loss.view(())                 # lives in the batch's buffer set: valid until the set is reused three steps later
         # ---- backward (seed gradient = loss scale [/ world]: gradients are SUMMED over ranks)
         seed = o.scale if self.world == 1 else o.scale / self.world
+        early = None
         if M > 0:
             L.call("n2m_photo_loss_backward", _p(w["image"]), _p(w["ws"]), _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask, N, _p(seed),
                    _p(w["d_image"]), _p(w["d_ws"]), s)
@@ -385,18 +387,34 @@ class Stage0Engine:
             need = L.lib().n2m_grid_binned_pair_workspace_bytes(M, self.Lv, self.ho.ctypes.data)
             ws = L.workspace(dev, need)
             tv = opt.lambda_tv > 0
-            L.call("n2m_grid_encode_backward_binned_pair", _p(w["d_h1"]), _p(w["d_h2"]), _p(xyzs), self.ho.ctypes.data, _p(self.g1), _p(self.g2), M,
-                   self.Lv, self.Lv, self.S, self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id,
-                   _p(e1.embeddings) if tv else None, float(opt.lambda_tv), float(opt.lambda_tv * (10 if opt.bound > 1 else 1)),
-                   float(0.5 / model.bound), _p(seed) if tv else None, _p(o.found_inf), float(self.aff[0]), float(self.aff[1]), 1, _p(ws),
-                   ws.numel(), s)
+            bwd_args = (_p(w["d_h1"]), _p(w["d_h2"]), _p(xyzs), self.ho.ctypes.data, _p(self.g1), _p(self.g2), M,
+                        self.Lv, self.Lv, self.S, self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id,
+                        _p(e1.embeddings) if tv else None, float(opt.lambda_tv), float(opt.lambda_tv * (10 if opt.bound > 1 else 1)),
+                        float(0.5 / model.bound), _p(seed) if tv else None, _p(o.found_inf), float(self.aff[0]), float(self.aff[1]), 1, _p(ws),
+                        ws.numel(), s)
+            if self.sync is not None and self.split_backward and self.Lv == 16:
+                # multi-GPU: the table backward in two halves of the levels.  The rows of the fine half (levels 8..15: 68 % of the
+                # bytes) are final after the first call; their SUM all-reduce runs on the collective stream while the coarse half is
+                # still being computed, so most of the exchange hides behind the backward's own tail (at 0.75 ms per step
+                # a 49 MB all-reduce no longer is the "< 4 %" the survey estimated at 26 ms per step)
+                split = int(self.ho[8])
+                L.call("n2m_grid_encode_backward_binned_pair_half", *bwd_args, 1)
+                early = self.sync.all_reduce_sum_begin([self.g1[split:], self.g2[split:]], [])
+                L.call("n2m_grid_encode_backward_binned_pair_half", *bwd_args, 2)
+            else:
+                L.call("n2m_grid_encode_backward_binned_pair", *bwd_args)
         else:
             # no sample in the batch: every gradient is zero (the reduction below still takes part on every rank)
             self.g1.zero_()
             self.g2.zero_()
         # ---- [multi-GPU] one SUM all-reduce per fixed gradient buffer (the colour table's stays fp16) + the small bucket
         if self.sync is not None:
-            token = self.sync.all_reduce_sum_begin([self.g1, self.g2], [self.dw, o.found_inf])
+            if early is not None:
+                split = int(self.ho[8])
+                token = self.sync.all_reduce_sum_begin([self.g1[:split], self.g2[:split]], [self.dw, o.found_inf])
+                self.sync.all_reduce_sum_end(early)
+            else:
+                token = self.sync.all_reduce_sum_begin([self.g1, self.g2], [self.dw, o.found_inf])
             self.sync.all_reduce_sum_end(token)
         # ONE event per step on the main stream (an event record is a marker packet the queue idles ~6 us behind, measured): behind the
         # last kernel that reads this batch's buffers and in front of the optimizer update -- the side stream's go-ahead

@@ -81,7 +81,7 @@ class GradSync:
         n = sum(t.numel() for t in small)
         flat = None
         if n:
-            if self.bucket is None or self.bucket.numel() < n:
+            if self.bucket is None or self.bucket.numel() < n or self.bucket.device != small[0].device:
                 self.bucket = torch.zeros(n, dtype=torch.float32, device=small[0].device)
             flat = self.bucket[:n]
             torch.cat([t.reshape(-1).float() for t in small], out=flat)

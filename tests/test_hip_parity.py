@@ -1014,3 +1014,49 @@ def test_binned_pair_backward_is_the_exact_sum_at_full_batch(be, oracle, scene, 
     ref2 = oracle.grid_encode_backward(d2, x, np.zeros((rows, 2), np.float16), offs, Sl, 16, 16).astype(np.float64)
     sel = cnt2 > 8
     assert np.abs(h2 - ex2)[sel].sum() < np.abs(ref2 - ex2)[sel].sum()
+
+
+def test_binned_pair_backward_in_two_level_halves_equals_the_full_call(be):
+    """n2m_grid_encode_backward_binned_pair_half: levels 8..15 then 0..7 == the full call (levels are independent): bit for bit on
+    the single-owner (2^19-row) levels and the TV term included; the split dense levels 0..3 carry float-atomic order noise in both."""
+    import ctypes
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L
+    from nerf2mesh_amd.gridencoder import GridEncoder, _host_offsets
+    B = 70001
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(B, 3, device="cuda", generator=g) * 2 - 1
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    ho = _host_offsets(e1)
+    rows = int(ho[-1])
+    d1 = torch.randn(16, B, device="cuda", generator=g)
+    d2 = torch.randn(16, B, 2, device="cuda", generator=g).half()
+    emb = (torch.rand(rows, 1, device="cuda", generator=g) - 0.5) * 1e-2
+    scale = torch.tensor(64.0, device="cuda")
+    need = L.lib().n2m_grid_binned_pair_workspace_bytes(B, 16, ho.ctypes.data)
+    ws = L.workspace(torch.device("cuda"), need)
+    outs = []
+    for mode in ("full", "halves"):
+        g1 = torch.full((rows, 1), 5.0, device="cuda"); g2 = torch.full((rows, 2), 5.0, device="cuda", dtype=torch.float16)
+        finf = torch.zeros((), device="cuda")
+        args = (L.ptr(d1), L.ptr(d2), L.ptr(x), ho.ctypes.data, L.ptr(g1), L.ptr(g2), B, 16, 16, float(np.log2(e1.per_level_scale)), 16, 0, 0, 0,
+                L.ptr(emb), 1e-4, 1e-4, 1.0, L.ptr(scale), L.ptr(finf), 0.5, 0.5, 1, L.ptr(ws), ws.numel(), L.stream())
+        if mode == "full":
+            L.call("n2m_grid_encode_backward_binned_pair", *args)
+        else:
+            L.call("n2m_grid_encode_backward_binned_pair_half", *args, 1)
+            hi = (g1[int(ho[8]):].clone(), g2[int(ho[8]):].clone())            # final after the first call
+            assert bool((g1[:int(ho[8])] == 5.0).all())                         # the other half is untouched so far
+            L.call("n2m_grid_encode_backward_binned_pair_half", *args, 2)
+            assert torch.equal(hi[0], g1[int(ho[8]):]) and torch.equal(hi[1], g2[int(ho[8]):])
+        outs.append((g1, g2))
+    (a1, a2), (b1, b2) = outs
+    for l in range(16):
+        sl = slice(int(ho[l]), int(ho[l + 1]))
+        if ho[l + 1] - ho[l] == 2 ** 19 or l >= 4:
+            assert torch.equal(a1[sl], b1[sl]) and torch.equal(a2[sl], b2[sl]), f"level {l}"
+        else:
+            np.testing.assert_allclose(b1[sl].cpu().numpy(), a1[sl].cpu().numpy(), rtol=1e-5, atol=1e-6 * float(a1[sl].abs().max()))
+            np.testing.assert_allclose(b2[sl].float().cpu().numpy(), a2[sl].float().cpu().numpy(), rtol=2e-3, atol=1e-2 * float(a2[sl].float().abs().max()))
+    with pytest.raises(RuntimeError):
+        L.call("n2m_grid_encode_backward_binned_pair_half", *args, 3)
