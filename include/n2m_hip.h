@@ -307,6 +307,17 @@ int n2m_photo_loss_backward(const float* image, const float* weights_sum, const 
                             float bg_scalar, float lambda_rgb, float lambda_mask, uint32_t N,
                             const float* grad_loss, float* d_image, float* d_weights_sum, void* stream);
 
+/* Training fast path: n2m_composite_rays_train_forward -> n2m_photo_loss_forward -> n2m_photo_loss_backward ->
+ * n2m_composite_rays_train_backward as ONE launch (density mode, the plain rgb + mask loss: no gradient into weights or depth).
+ * A wave composites its ray, forms the ray's loss term and gradients and runs the backward scan right away (the seed gradient
+ * *grad_loss / N does not depend on the loss value).  grad_sigmas [M] / grad_rgbs [M,3] are bit-identical to the four-call chain
+ * (every sample of a ray's range is written); weights_sum [N] and image [N,3] (colour before the background blend) may be NULL;
+ * partial: ceil(N/16) floats scratch; ticket: one zero uint32 (left zero); loss [1] = the mean over rays; loss_sum (may be NULL) += loss. */
+int n2m_composite_loss_train(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays, uint32_t M, uint32_t N,
+                             float T_thresh, const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask,
+                             const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas, float* grad_rgbs, float* partial,
+                             uint32_t* ticket, float* loss, float* loss_sum, void* stream);
+
 /* Adam + GradScaler for the whole parameter set in two launches (torch.optim.Adam(fused=True) + torch.amp.GradScaler of
  * main.py:221 / nerf/utils.py:506,1187-1190).  All tensors fp32 and 16-byte aligned, except grad which may be fp16
  * (grad_is_half) and half_shadow (fp16 copy of the updated parameter, or NULL).  Gradients are still multiplied by *scale

@@ -767,6 +767,162 @@ composite_train_bwd_kernel(const float* __restrict__ grad_weights, const float* 
     }
 }
 
+// Compositing + photometric loss head + their backward in ONE launch (training fast path, nerf2mesh_amd/engine.py).  The loss of a ray
+// needs only that ray's composited colour and opacity, and its seed gradient (the loss scale / N) does not depend on the loss VALUE,
+// so a wave can composite its ray forward (composite_train_fwd_kernel's arithmetic, sample weights not stored), form the ray's loss
+// term and gradients (photo_loss_forward/backward_kernel's arithmetic: background blend nerf/renderer.py:747, target nerf/utils.py:
+// 663-664, MSE + mask MSE :679-683) and run the backward scan (composite_train_bwd_kernel's arithmetic) while the ray's samples are
+// still in cache.  Replaces four launches and the [N]-sized round trips between them; gradients are bit-identical to the four-kernel
+// chain, the loss value differs by its summation order only (per-workgroup partials, summed in index order by the last workgroup).
+// 16 waves per workgroup, one ray per wave: same-address atomics retire one per ~11 ns (tools/atomic_bench.hip), so the arrival ticket
+// must be taken by ~N/16 workgroups, not N/4 (measured: 80 us with 4-ray workgroups at N = 15 k, the ticket chain alone)
+__global__ void __launch_bounds__(1024)
+composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ ts,
+                            const int32_t* __restrict__ rays, uint32_t M, uint32_t N, float T_thresh, const float* __restrict__ gt,
+                            const float* __restrict__ bg, float bg_scalar, float lambda_rgb, float lambda_mask,
+                            const float* __restrict__ grad_loss, float* __restrict__ weights_sum, float* __restrict__ image,
+                            float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs, float* __restrict__ partial,
+                            uint32_t* __restrict__ ticket, float* __restrict__ loss, float* __restrict__ loss_sum) {
+    __shared__ float wave_loss[16];
+    __shared__ bool last_block;
+    const uint32_t wid = threadIdx.x >> 6, n = blockIdx.x * 16 + wid;
+    const int lane = threadIdx.x & 63;
+    float l_ray = 0.0f;
+    if (n < N) {
+        const uint32_t off = (uint32_t)rays[2 * n], cnt = (uint32_t)rays[2 * n + 1];
+        const bool whole = cnt != 0 && off + cnt <= M;
+        // ---- forward
+        float rF = 0, gF = 0, bF = 0, wsF = 0;
+        if (whole) {
+            float carry_T = 1.0f;
+            for (uint32_t base = 0; base < cnt; base += 64) {
+                const uint32_t k = base + lane;
+                const bool valid = k < cnt;
+                const size_t i = (size_t)off + k;
+                float alpha = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+                if (valid) {
+                    const float2 tt = *reinterpret_cast<const float2*>(ts + 2 * i);
+                    alpha = 1.0f - expf(-sigmas[i] * tt.y);
+                    cr = rgbs[3 * i]; cg = rgbs[3 * i + 1]; cb = rgbs[3 * i + 2];
+                }
+                const float incl = n2m_wave_scan_mul(1.0f - alpha, lane);
+                float excl = __shfl_up(incl, 1, 64);
+                if (lane == 0) excl = 1.0f;
+                const float T_before = carry_T * excl, T_after = carry_T * incl;
+                const unsigned long long stop = __ballot(valid && T_after < T_thresh);
+                const int last = stop ? (int)__ffsll((long long)stop) - 1 : 63;
+                const float w = (valid && lane <= last) ? alpha * T_before : 0.f;
+                rF += w * cr; gF += w * cg; bF += w * cb; wsF += w;
+                if (stop) break;
+                carry_T = __shfl(T_after, 63, 64);
+            }
+            rF = n2m_wave_sum(rF); gF = n2m_wave_sum(gF); bF = n2m_wave_sum(bF); wsF = n2m_wave_sum(wsF);
+        }
+        // ---- loss term of the ray and its gradients (wave-uniform)
+        const float4 gtv = *reinterpret_cast<const float4*>(gt + (size_t)n * 4);
+        const float a = gtv.w;
+        const float gc[3] = {gtv.x, gtv.y, gtv.z}, pc[3] = {rF, gF, bF};
+        const float gscale = *grad_loss / (float)N;
+        float gi[3];
+        const float m = wsF - a;
+        float gws = gscale * lambda_mask * 2.0f * m;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float bgc = bg ? bg[(size_t)n * 3 + c] : bg_scalar;
+            const float target = gc[c] * a + bgc * (1.0f - a);
+            const float pred = pc[c] + (1.0f - wsF) * bgc;
+            const float e = pred - target;
+            gi[c] = gscale * lambda_rgb * (2.0f * e / 3.0f);
+            gws -= gi[c] * bgc;
+            if (c == 0) l_ray = e * e; else l_ray += e * e;
+        }
+        l_ray = lambda_rgb * (l_ray / 3.0f) + lambda_mask * (m * m);
+        if (lane == 0) {
+            if (weights_sum) weights_sum[n] = wsF;
+            if (image) { image[3 * n] = rF; image[3 * n + 1] = gF; image[3 * n + 2] = bF; }
+        }
+        // ---- backward
+        if (cnt != 0 && !whole) {                       // cut off by M: no gradient, the part inside [0, M) is zeroed
+            for (uint32_t i = off + (uint32_t)lane; i < M; i += 64) {
+                grad_sigmas[i] = 0.f;
+                grad_rgbs[3 * (size_t)i] = 0.f; grad_rgbs[3 * (size_t)i + 1] = 0.f; grad_rgbs[3 * (size_t)i + 2] = 0.f;
+            }
+        } else if (whole) {
+            float carry_T = 1.0f, r0 = 0, g0 = 0, b0 = 0, ws0 = 0;
+            bool stopped = false;
+            for (uint32_t base = 0; base < cnt; base += 64) {
+                const uint32_t k = base + lane;
+                const bool valid = k < cnt;
+                const size_t i = (size_t)off + k;
+                if (stopped) {
+                    if (valid) { grad_sigmas[i] = 0.f; grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f; }
+                    continue;
+                }
+                float alpha = 0.f, dt = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+                if (valid) {
+                    const float2 tt = *reinterpret_cast<const float2*>(ts + 2 * i);
+                    alpha = 1.0f - expf(-sigmas[i] * tt.y);
+                    dt = tt.y;
+                    cr = rgbs[3 * i]; cg = rgbs[3 * i + 1]; cb = rgbs[3 * i + 2];
+                }
+                const float incl = n2m_wave_scan_mul(1.0f - alpha, lane);
+                float excl = __shfl_up(incl, 1, 64);
+                if (lane == 0) excl = 1.0f;
+                const float T_before = carry_T * excl, T_after = carry_T * incl;
+                const unsigned long long stop = __ballot(valid && T_after < T_thresh);
+                const int last = stop ? (int)__ffsll((long long)stop) - 1 : 63;
+                const bool live = valid && lane <= last;
+                const float w = live ? alpha * T_before : 0.f;
+                const float r = r0 + n2m_wave_scan_add(w * cr, lane);
+                const float g = g0 + n2m_wave_scan_add(w * cg, lane);
+                const float b = b0 + n2m_wave_scan_add(w * cb, lane);
+                const float ws = ws0 + n2m_wave_scan_add(w, lane);
+                if (live) {
+                    grad_rgbs[3 * i] = gi[0] * w; grad_rgbs[3 * i + 1] = gi[1] * w; grad_rgbs[3 * i + 2] = gi[2] * w;
+                    // composite_train_bwd_kernel's expression with grad_weights = grad_depth = 0 (their terms are exact zeros there)
+                    grad_sigmas[i] = dt * (gi[0] * (T_after * cr - (rF - r)) + gi[1] * (T_after * cg - (gF - g)) +
+                                           gi[2] * (T_after * cb - (bF - b)) + (gws + 0.f) * (T_after - (wsF - ws)) + 0.f * 0.f);
+                } else if (valid) {
+                    grad_sigmas[i] = 0.f; grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f;
+                }
+                if (stop) { stopped = true; continue; }
+                carry_T = __shfl(T_after, 63, 64);
+                r0 = __shfl(r, 63, 64); g0 = __shfl(g, 63, 64); b0 = __shfl(b, 63, 64); ws0 = __shfl(ws, 63, 64);
+            }
+        }
+    }
+    // ---- loss value: per-workgroup partial, the last workgroup to arrive sums them in index order (reproducible)
+    if (lane == 0) wave_loss[wid] = l_ray;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float p = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) p += wave_loss[q];
+        partial[blockIdx.x] = p;
+        __threadfence();
+        last_block = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last_block) {
+        __threadfence();
+        float sum = 0.0f;
+        for (uint32_t i = threadIdx.x; i < gridDim.x; i += 1024) sum += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sum = n2m_wave_sum(sum);
+        __syncthreads();
+        if (lane == 0) wave_loss[wid] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot += wave_loss[q];
+            const float v = tot / (float)N;
+            *loss = v;
+            if (loss_sum) *loss_sum += v;
+            *ticket = 0;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------- compositing (inference)
 
 __global__ void composite_infer_kernel(uint32_t n_alive, uint32_t n_step, float T_thresh, bool alpha_mode,
@@ -977,6 +1133,24 @@ extern "C" int n2m_composite_rays_train_forward(const float* sigmas, const float
     N2M_PROF(N2M_K_COMPOSITE_FWD, s, 28.0 * M + 28.0 * N);
     composite_train_fwd_kernel<<<n2m_ceil_div(N, 4), 256, 0, s>>>(sigmas, rgbs, ts, rays, M, N, T_thresh, alpha_mode != 0,
                                                                    weights, weights_sum, depth, image);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+// Training fast path: compositing, loss head and both backward passes of n2m_composite_rays_train_forward/backward +
+// n2m_photo_loss_forward/backward in one launch (density mode; no grad_weights / grad_depth: the plain rgb + mask loss).
+extern "C" int n2m_composite_loss_train(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays, uint32_t M, uint32_t N,
+                                        float T_thresh, const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb,
+                                        float lambda_mask, const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas,
+                                        float* grad_rgbs, float* partial, uint32_t* ticket, float* loss, float* loss_sum, void* stream) {
+    N2M_NOTNULL(rays); N2M_NOTNULL(gt_rgba); N2M_NOTNULL(grad_loss); N2M_NOTNULL(partial); N2M_NOTNULL(ticket); N2M_NOTNULL(loss);
+    if (M > 0) { N2M_NOTNULL(sigmas); N2M_NOTNULL(rgbs); N2M_NOTNULL(ts); N2M_NOTNULL(grad_sigmas); N2M_NOTNULL(grad_rgbs); }
+    if (N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    N2M_PROF(N2M_K_COMPOSITE_FWD, s, 28.0 * M + 28.0 * N + 44.0 * M + 48.0 * N);     // forward + backward of SURVEY 8d, one launch
+    composite_loss_train_kernel<<<n2m_ceil_div(N, 16), 1024, 0, s>>>(sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar, lambda_rgb,
+                                                                    lambda_mask, grad_loss, weights_sum, image, grad_sigmas, grad_rgbs, partial,
+                                                                    ticket, loss, loss_sum);
     N2M_CHECK_LAUNCH();
     return 0;
 }

@@ -49,6 +49,8 @@ class _RayBufs:
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.host_count = torch.empty(1, dtype=torch.int32, pin_memory=True)
         self.count_ready = torch.cuda.Event()
+        self.written = torch.cuda.Event()
+        self.spec = False
         self.index = 0
         self.M = None                # sample count once the host has read it
         self.loss = torch.empty(1, dtype=torch.float32, device=dev)
@@ -85,7 +87,7 @@ class Stage0Engine:
         self.boxes = synthetic.boxes(dev)
         self.samples_seen = self.rays_seen = 0
         self.last_num_points = 0
-        self._loss_pending, self._loss_sum = [], torch.zeros((), device=dev)
+        self._loss_pending, self._loss_sum = [], torch.zeros(1, device=dev)
         self.sync = None
         if world_size > 1:
             from .parallel import GradSync
@@ -174,7 +176,7 @@ class Stage0Engine:
             w["sigma"], w["rgb"], w["spec"], w["weights"], w["d_sr"] = f(cm), f(3 * cm), f(3 * cm), f(cm), f(4 * cm)
             w["d_spec"] = f(3 * cm)
             w["ws"], w["depth"], w["image"], w["d_image"], w["d_ws"], w["bg"] = f(cn), f(cn), f(3 * cn), f(3 * cn), f(cn), f(3 * cn)
-            w["partial"] = f((cn + 255) // 256 + 1)
+            w["partial"] = f((cn + 3) // 4 + 1)
             w["zeros"] = torch.zeros(max(cm, 3 * cn), dtype=torch.float32, device=dev)
             self._work_cap = (cm, cn)
         return self._w
@@ -204,6 +206,9 @@ class Stage0Engine:
         self._aabb = model.aabb_train
         L.call("n2m_near_far_from_aabb", _p(b.o), _p(b.d), _p(self._aabb), N, float(model.min_near), _p(b.nears), _p(b.fars), s)
         b.noises = torch.rand(N, dtype=torch.float32, device=dev, generator=self.gen_noise)
+        # the random background of the batch (nerf/utils.py:649-652): drawn here, off the main stream; gen_bg is its own stream of
+        # numbers, so batch j gets the j-th draw exactly as in Stage0Trainer
+        b.bg = torch.rand(N, 3, device=dev, generator=self.gen_bg) if opt.background != "white" else None
         bits = model.density_bitfield
         b.args = (_p(b.o), _p(b.d), _p(bits), float(model.real_bound), int(bool(opt.contract)), float(opt.dt_gamma), int(opt.max_steps), N,
                   int(model.cascade), int(model.grid_size), _p(b.nears), _p(b.fars))
@@ -212,6 +217,17 @@ class Stage0Engine:
         L.call("n2m_march_rays_train", *b.args, None, None, None, _p(b.rays), _p(b.counter), _p(b.noises), s)
         b.host_count.copy_(b.counter, non_blocking=True)
         b.count_ready.record()
+        # speculative pass 2 right behind it, into buffers a quarter above the last batch (adaptive num_rays steers M towards
+        # opt.num_points): a ray that does not fit is skipped like raymarching.cu:417 and _finish() re-marches the batch exactly.  With
+        # batches prepared two ahead the pass has finished a whole step before its samples are read, so the consumer normally needs no
+        # cross-stream wait at all (an event that has already fired is not waited for)
+        b.spec = False
+        expect = 0 if self.last_num_points <= 0 else ((int(1.25 * max(self.last_num_points, 1024)) + 1023) // 1024) * 1024
+        if expect > 0:
+            x, d, t = self._sample_bufs(b, expect)
+            L.call("n2m_march_rays_train_write", *b.args, _p(x), _p(d), _p(t), _p(b.rays), _p(b.noises), b.cap_m, s)
+            b.spec = True
+            b.written.record()
         return b
 
     def _count(self, b):
@@ -249,19 +265,22 @@ class Stage0Engine:
                 with torch.cuda.stream(self.side):
                     b = self._prepare(N)
                 main = torch.cuda.current_stream(self.device)
-                for t in (b.cam, b.pix, b.noises):
-                    t.record_stream(main)
+                for t in (b.cam, b.pix, b.noises, b.bg):
+                    if t is not None:
+                        t.record_stream(main)
             b.index = j
             self._prepared = j
             self._last = b
             self._queue.append(b)
 
     def _finish(self, b):
-        """Pass 2 (the write pass) of batch b on the MAIN stream into buffers that fit its count.  The host has waited for the event
-        behind the offset scan, so the main stream needs no cross-stream dependency on the side stream (a barrier packet there cost
-        the step ~25 us of idle queue, measured); with the prefix-maximum marcher the pass is ~25 us."""
+        """Samples of batch b: the speculative pass 2 of _prepare() when the count fits its buffers (the normal case), else an exact
+        pass 2 on the main stream (the host has waited for the event behind the offset scan, so no cross-stream dependency is needed)."""
         M = self._count(b)
-        if M > 0:
+        if M > 0 and b.spec and M <= b.cap_m:
+            if not b.written.query():
+                torch.cuda.current_stream(self.device).wait_event(b.written)
+        elif M > 0:
             x, d, t = self._sample_bufs(b, ((int(1.25 * M) + 1023) // 1024) * 1024 if b.cap_m < M else b.cap_m)
             L.call("n2m_march_rays_train_write", *b.args, _p(x), _p(d), _p(t), _p(b.rays), _p(b.noises), b.cap_m, L.stream())
         return M
@@ -333,9 +352,8 @@ class Stage0Engine:
         self.global_step += 1
         assert b.index == self.global_step
         N = b.N
-        random_bg = opt.background != "white"
-        if random_bg:
-            bg = torch.rand(N, 3, device=dev, generator=self.gen_bg)
+        random_bg = b.bg is not None
+        bg = b.bg
         shading = SHADING["diffuse" if (self.global_step < opt.diffuse_step or opt.diffuse_only) else "full"]
         M = self._finish(b)
         self.last_num_points = M
@@ -358,28 +376,23 @@ class Stage0Engine:
                    self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, float(self.aff[0]), float(self.aff[1]), s)
             L.call("n2m_field_forward", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 1,
                    _p(w["sigma"]), _p(w["rgb"]), _p(w["spec"]) if shading != 0 else None, s)
-        L.call("n2m_composite_rays_train_forward", _p(w["sigma"]), _p(w["rgb"]), _p(ts), _p(b.rays), M, N, 1e-4, 0, _p(w["weights"]), _p(w["ws"]),
-               _p(w["depth"]), _p(w["image"]), s)
         bg_t, bg_s = (bg, 0.0) if random_bg else (None, 1.0)
         lam_rgb, lam_mask = float(opt.lambda_rgb), float(max(opt.lambda_mask, 0.0))
-        L.call("n2m_photo_loss_forward", _p(w["image"]), _p(w["ws"]), _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask, N, _p(w["partial"]),
-               _p(self._ticket), _p(b.loss), s)
-        loss = b.loss.view(())                 # lives in the batch's buffer set: valid until the set is reused three steps later
-        # ---- backward (seed gradient = loss scale [/ world]: gradients are SUMMED over ranks)
+        # ---- compositing + loss head + both backward passes: one launch (seed gradient = loss scale [/ world]: gradients are SUMMED over ranks)
         seed = o.scale if self.world == 1 else o.scale / self.world
         early = None
+        d_sigma, d_rgb = w["d_sr"][:max(M, 1)], w["d_sr"][max(M, 1):4 * max(M, 1)]
+        L.call("n2m_composite_loss_train", _p(w["sigma"]), _p(w["rgb"]), _p(ts), _p(b.rays), M, N, 1e-4, _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask,
+               _p(seed), None, None, _p(d_sigma), _p(d_rgb), _p(w["partial"]), _p(self._ticket), _p(b.loss), _p(self._loss_sum), s)
+        loss = b.loss.view(())                 # lives in the batch's buffer set: valid until the set is reused three steps later
+        spec_loss = None
         if M > 0:
-            L.call("n2m_photo_loss_backward", _p(w["image"]), _p(w["ws"]), _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask, N, _p(seed),
-                   _p(w["d_image"]), _p(w["d_ws"]), s)
-            z = w["zeros"]
-            d_sigma, d_rgb = w["d_sr"][:M], w["d_sr"][M:4 * M]
-            L.call("n2m_composite_rays_train_backward", _p(z), _p(w["d_ws"]), _p(z), _p(w["d_image"]), _p(w["sigma"]), _p(w["rgb"]), _p(ts),
-                   _p(b.rays), _p(w["ws"]), _p(w["depth"]), _p(w["image"]), M, N, 1e-4, 0, _p(d_sigma), _p(d_rgb), s)
             d_spec = None
             if shading != 0 and opt.lambda_specular > 0:
                 # + lambda_specular * mean_m sum_c spec^2 (nerf/utils.py:735-737): d/dspec = 2 lambda / M * spec, times the seed
                 spec_m = w["spec"][:3 * M]
-                loss = loss + opt.lambda_specular * (spec_m * spec_m).sum() / M
+                spec_loss = opt.lambda_specular * (spec_m * spec_m).sum() / M
+                loss = loss + spec_loss
                 d_spec = w["d_spec"][:3 * M]
                 torch.mul(spec_m, seed * (2.0 * opt.lambda_specular / M), out=d_spec)
             L.call("n2m_field_backward", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 1,
@@ -422,7 +435,8 @@ class Stage0Engine:
         self._marker.record()
         # ---- Adam + loss-scale bookkeeping, LR schedule (main.py:239)
         self._lr_step(shading != 0)
-        self._loss_sum += loss.view(())        # running sum on the device (the value itself lives in a rotating buffer)
+        if spec_loss is not None:
+            self._loss_sum += spec_loss        # the photometric part was added by the loss kernel itself
         self._fill_pipeline()
         return loss
 

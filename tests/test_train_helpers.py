@@ -56,3 +56,44 @@ def test_get_rays_matches_torch_statement():
     assert torch.equal(o, ro)
     np.testing.assert_allclose(d.cpu().numpy(), rd.cpu().numpy(), rtol=2e-6, atol=1e-7)     # same products, fp32 sum order may differ
     assert torch.equal(rgba, images[cam, pix])
+
+
+@pytest.mark.parametrize("bg_kind", ["white", "random"])
+def test_fused_composite_loss_equals_the_four_kernel_chain(bg_kind):
+    """n2m_composite_loss_train == composite forward -> photo loss forward/backward -> composite backward (the chain whose parts are
+    checked against the oracle / the torch graph elsewhere): gradients, opacities and colours bit for bit; the loss value up to its
+    summation order.  Rays: the marcher's own output on the synthetic scene (ranges tile [0, M)), plus empty rays and early stops."""
+    import torch
+    from nerf2mesh_amd import _lib as L, raymarching, synthetic as S
+    from nerf2mesh_amd.losses import photo_loss
+    dev = torch.device("cuda")
+    poses = S.make_cameras(16, seed=2).to(dev)
+    bits = raymarching.packbits(S.scene_density_grid(H=128, device=dev), 10.0)
+    g = torch.Generator(device=dev).manual_seed(9)
+    o, d = S.random_rays(poses, 6000, g)
+    nears, fars = raymarching.near_far_from_aabb(o, d, torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev), 0.05)
+    xyzs, dirs, ts, rays = raymarching.march_rays_train(o, d, 1.0, False, bits, 1, 128, nears, fars, True, 0.0, 1024)
+    M, N = xyzs.shape[0], o.shape[0]
+    assert M > 20000 and int((rays[:, 1] == 0).sum()) > 0
+    sig = (torch.rand(M, device=dev, generator=g) * 60).requires_grad_()          # dense enough for early stops
+    rgb = torch.rand(M, 3, device=dev, generator=g).requires_grad_()
+    gt = torch.rand(N, 4, device=dev, generator=g)
+    gt[: N // 3, 3] = 0
+    bg = 1 if bg_kind == "white" else torch.rand(N, 3, device=dev, generator=g)
+    scale = torch.tensor(512.0, device=dev)
+    w, ws, dp, im = raymarching.composite_rays_train(sig, rgb, ts, rays, 1e-4, False, rays_tile_samples=True)
+    loss = photo_loss(im, ws, gt, bg, 1.0, 0.1)
+    loss.backward(gradient=scale)
+    d_sr = torch.empty(4 * M, device=dev)
+    out_ws, out_im = torch.empty(N, device=dev), torch.empty(N, 3, device=dev)
+    partial = torch.empty((N + 3) // 4, device=dev)
+    ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+    lv, lsum = torch.zeros(1, device=dev), torch.full((1,), 2.0, device=dev)
+    bg_t = bg if torch.is_tensor(bg) else None
+    L.call("n2m_composite_loss_train", L.ptr(sig.detach()), L.ptr(rgb.detach()), L.ptr(ts), L.ptr(rays), M, N, 1e-4, L.ptr(gt), L.ptr(bg_t),
+           1.0 if bg_t is None else 0.0, 1.0, 0.1, L.ptr(scale), L.ptr(out_ws), L.ptr(out_im), L.ptr(d_sr[:M]), L.ptr(d_sr[M:]), L.ptr(partial),
+           L.ptr(ticket), L.ptr(lv), L.ptr(lsum), L.stream())
+    assert torch.equal(out_ws, ws.detach()) and torch.equal(out_im, im.detach())
+    assert torch.equal(d_sr[:M], sig.grad) and torch.equal(d_sr[M:].view(M, 3), rgb.grad)
+    np.testing.assert_allclose(lv.item(), loss.item(), rtol=5e-6)
+    assert abs(lsum.item() - (2.0 + lv.item())) < 1e-6 and int(ticket) == 0
