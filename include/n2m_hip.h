@@ -292,6 +292,13 @@ int n2m_get_rays(const float* poses, const int64_t* cam, const int64_t* pix, uin
                  float fx, float fy, float cx, float cy, const float* images, float* rays_o, float* rays_d,
                  float* rgba, void* stream);
 
+/* A whole training batch from ONE tensor of uniforms [N,6] in [0,1): view = floor(u0 V), pixel = floor(u1 H W) (random pixels over
+ * random views, nerf/provider.py:302-303, nerf/utils.py:271), rays + ground truth as n2m_get_rays, near/far as n2m_near_far_from_aabb,
+ * march jitter noises [N] = u2, random background bg [N,3] = u3..u5 (may be NULL), and *counter = 0 (may be NULL).  H*W < 2^24. */
+int n2m_batch_rays(const float* poses, const float* uniforms, uint32_t V, uint32_t N, uint32_t H, uint32_t W, float fx, float fy, float cx,
+                   float cy, const float* images, const float* aabb, float min_near, float* rays_o, float* rays_d, float* rgba,
+                   float* nears, float* fars, float* noises, float* bg, int32_t* counter, void* stream);
+
 /* Photometric loss head of the stage-0 step in one launch per direction:
  *   pred   = image + (1 - weights_sum) * bg                      nerf/renderer.py:747
  *   target = gt.rgb * gt.a + bg * (1 - gt.a)                     nerf/utils.py:663-664

@@ -25,18 +25,16 @@ constexpr float kSqrt3 = 1.7320508075688772f;
 
 // ------------------------------------------------------------------------------------------- small kernels
 
-__global__ void near_far_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                const float* __restrict__ aabb, uint32_t N, float min_near,
-                                float* __restrict__ nears, float* __restrict__ fars) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// slab test of one ray (raymarching.cu:91-145): (near, far), both FLT_MAX on a miss
+__device__ __forceinline__ void near_far_of(const float (&o)[3], const float (&d)[3], const float* __restrict__ aabb, float min_near,
+                                            float& near, float& far) {
     float tn = 0.f, tf = 0.f;
     bool hit = true;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         if (!hit) break;
-        const float inv = 1.0f / rays_d[3 * n + a];
-        const float org = rays_o[3 * n + a];
+        const float inv = 1.0f / d[a];
+        const float org = o[a];
         float lo = (aabb[a] - org) * inv, hi = (aabb[a + 3] - org) * inv;
         if (lo > hi) { const float t = lo; lo = hi; hi = t; }
         if (a == 0) { tn = lo; tf = hi; continue; }
@@ -44,10 +42,52 @@ __global__ void near_far_kernel(const float* __restrict__ rays_o, const float* _
         if (lo > tn) tn = lo;
         if (hi < tf) tf = hi;
     }
-    if (!hit) { nears[n] = FLT_MAX; fars[n] = FLT_MAX; return; }
+    if (!hit) { near = FLT_MAX; far = FLT_MAX; return; }
     if (tn < min_near) tn = min_near;
-    nears[n] = tn;
-    fars[n] = tf;
+    near = tn;
+    far = tf;
+}
+
+__global__ void near_far_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                const float* __restrict__ aabb, uint32_t N, float min_near,
+                                float* __restrict__ nears, float* __restrict__ fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float o[3] = {rays_o[3 * n], rays_o[3 * n + 1], rays_o[3 * n + 2]}, d[3] = {rays_d[3 * n], rays_d[3 * n + 1], rays_d[3 * n + 2]};
+    near_far_of(o, d, aabb, min_near, nears[n], fars[n]);
+}
+
+// A whole training batch from ONE tensor of uniforms u [N,6] in [0,1): view = floor(u0 V), pixel = floor(u1 H W) (random_image_batch,
+// nerf/provider.py:302-303 + get_rays with N random pixels, nerf/utils.py:271), rays exactly as n2m_get_rays builds them
+// (nerf/utils.py:242-290), ground-truth gather (nerf/provider.py:330), near/far exactly as n2m_near_far_from_aabb, march jitter u2,
+// random background u3..u5 (nerf/utils.py:649-652); also clears the marcher's sample counter.  Seven small launches of the step's
+// side stream become one (they ran 7-13 us EACH beside the optimizer update and delayed the march behind them).
+__global__ void __launch_bounds__(256)
+batch_rays_kernel(const float* __restrict__ poses /*[V,4,4]*/, const float* __restrict__ u /*[N,6]*/, uint32_t V, uint32_t N, uint32_t W,
+                  uint32_t HW, float fx, float fy, float cx, float cy, const float* __restrict__ images /*[V,HW,4]*/,
+                  const float* __restrict__ aabb, float min_near, float* __restrict__ rays_o, float* __restrict__ rays_d,
+                  float* __restrict__ rgba, float* __restrict__ nears, float* __restrict__ fars, float* __restrict__ noises,
+                  float* __restrict__ bg, int32_t* __restrict__ counter) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n == 0 && counter) counter[0] = 0;
+    if (n >= N) return;
+    const float* __restrict__ un = u + (size_t)n * 6;
+    const uint32_t v = min(V - 1u, (uint32_t)(un[0] * (float)V)), p = min(HW - 1u, (uint32_t)(un[1] * (float)HW));
+    const float i = (float)(p % W) + 0.5f, j = (float)(p / W) + 0.5f;
+    const float d0 = (i - cx) / fx, d1 = -(j - cy) / fy, d2 = -1.0f;
+    const float* __restrict__ P = poses + (size_t)v * 16;
+    float o[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        d[k] = (d0 * P[4 * k] + d1 * P[4 * k + 1]) + d2 * P[4 * k + 2];
+        o[k] = P[4 * k + 3];
+        rays_d[(size_t)n * 3 + k] = d[k];
+        rays_o[(size_t)n * 3 + k] = o[k];
+    }
+    *reinterpret_cast<float4*>(rgba + (size_t)n * 4) = *reinterpret_cast<const float4*>(images + ((size_t)v * HW + (size_t)p) * 4);
+    near_far_of(o, d, aabb, min_near, nears[n], fars[n]);
+    noises[n] = un[2];
+    if (bg) { bg[(size_t)n * 3] = un[3]; bg[(size_t)n * 3 + 1] = un[4]; bg[(size_t)n * 3 + 2] = un[5]; }
 }
 
 __global__ void sph_from_ray_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, float radius,
@@ -973,6 +1013,19 @@ extern "C" int n2m_near_far_from_aabb(const float* rays_o, const float* rays_d, 
     hipStream_t s = (hipStream_t)stream;
     N2M_PROF(N2M_K_NEAR_FAR, s, 32.0 * N);
     near_far_kernel<<<n2m_ceil_div(N, 256), 256, 0, s>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_batch_rays(const float* poses, const float* uniforms, uint32_t V, uint32_t N, uint32_t H, uint32_t W, float fx, float fy,
+                              float cx, float cy, const float* images, const float* aabb, float min_near, float* rays_o, float* rays_d,
+                              float* rgba, float* nears, float* fars, float* noises, float* bg, int32_t* counter, void* stream) {
+    N2M_NOTNULL(poses); N2M_NOTNULL(uniforms); N2M_NOTNULL(images); N2M_NOTNULL(aabb); N2M_NOTNULL(rays_o); N2M_NOTNULL(rays_d);
+    N2M_NOTNULL(rgba); N2M_NOTNULL(nears); N2M_NOTNULL(fars); N2M_NOTNULL(noises);
+    N2M_REQUIRE(V >= 1 && (uint64_t)H * W < (1ull << 24), N2M_EINVAL, "batch_rays: need V >= 1 and H*W < 2^24 (pixel index from an fp32 uniform)");
+    if (N == 0) return 0;
+    batch_rays_kernel<<<n2m_ceil_div(N, 256), 256, 0, (hipStream_t)stream>>>(poses, uniforms, V, N, W, H * W, fx, fy, cx, cy, images, aabb, min_near,
+                                                                             rays_o, rays_d, rgba, nears, fars, noises, bg, counter);
     N2M_CHECK_LAUNCH();
     return 0;
 }

@@ -44,7 +44,8 @@ class _RayBufs:
         self.cap = cap
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         self.o, self.d, self.rgba = f(cap, 3), f(cap, 3), f(cap, 4)
-        self.nears, self.fars = f(cap), f(cap)
+        self.nears, self.fars, self.noises, self.bg_buf = f(cap), f(cap), f(cap), f(cap, 3)
+        self.u = self.bg = None
         self.rays = torch.empty(cap, 2, dtype=torch.int32, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.host_count = torch.empty(1, dtype=torch.int32, pin_memory=True)
@@ -57,8 +58,6 @@ class _RayBufs:
         self.samples = None          # [cap_m, 8] fp32: xyzs | dirs | ts (speculative write pass)
         self.cap_m = 0
         self.N = 0
-        self.noises = None
-        self.cam = self.pix = None
         self.args = None
         self.refreshed = False
 
@@ -76,12 +75,10 @@ class Stage0Engine:
         self.rank, self.world = rank, world_size
         self.global_step = 0
         self.num_rays = opt.num_rays
-        # three independent streams (pixel choice, background, march jitter): which batch a number goes to then does not depend on how
-        # far ahead batches are prepared, so this executor and Stage0Trainer consume identical draws (rank r: its own rays)
-        self.gen, self.gen_bg, self.gen_noise = (torch.Generator(device=dev) for _ in range(3))
+        # ONE draw per batch for everything random about it (synthetic.batch_from_uniforms): which batch a number goes to then does not
+        # depend on how far ahead batches are prepared, so this executor and Stage0Trainer consume identical draws (rank r: its own rays)
+        self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed + rank)
-        self.gen_bg.manual_seed(seed + rank + 7919)
-        self.gen_noise.manual_seed(seed + rank + 104729)
         self.optimizer = FusedAdamAMP(model.get_params(opt.lr), eps=1e-15, amp=True)
         self.images = None
         self.boxes = synthetic.boxes(dev)
@@ -197,23 +194,17 @@ class Stage0Engine:
             self.images = synthetic.preload_images(self.poses, self.boxes)
         b = self._ray_bufs(N)
         b.N, b.M = N, None
-        H = W = synthetic.LEGO_HW
-        f = float(synthetic.LEGO_FOCAL)
-        b.cam = torch.randint(0, self.poses.shape[0], (N,), device=dev, generator=self.gen)
-        b.pix = torch.randint(0, H * W, (N,), device=dev, generator=self.gen)
         s = L.stream()
-        L.call("n2m_get_rays", _p(self.poses), _p(b.cam), _p(b.pix), N, H, W, f, f, W / 2, H / 2, _p(self.images), _p(b.o), _p(b.d), _p(b.rgba), s)
+        # one draw for everything random about the batch + one kernel for pixels, rays, ground truth, near/far, jitter, background
+        b.u = torch.rand(N, 6, device=dev, generator=self.gen)
         self._aabb = model.aabb_train
-        L.call("n2m_near_far_from_aabb", _p(b.o), _p(b.d), _p(self._aabb), N, float(model.min_near), _p(b.nears), _p(b.fars), s)
-        b.noises = torch.rand(N, dtype=torch.float32, device=dev, generator=self.gen_noise)
-        # the random background of the batch (nerf/utils.py:649-652): drawn here, off the main stream; gen_bg is its own stream of
-        # numbers, so batch j gets the j-th draw exactly as in Stage0Trainer
-        b.bg = torch.rand(N, 3, device=dev, generator=self.gen_bg) if opt.background != "white" else None
+        b.bg = b.bg_buf if opt.background != "white" else None
+        synthetic.batch_from_uniforms(self.poses, self.images, b.u, self._aabb, model.min_near,
+                                      out=(b.o, b.d, b.rgba, b.nears, b.fars, b.noises, b.bg), counter=b.counter)
         bits = model.density_bitfield
         b.args = (_p(b.o), _p(b.d), _p(bits), float(model.real_bound), int(bool(opt.contract)), float(opt.dt_gamma), int(opt.max_steps), N,
                   int(model.cascade), int(model.grid_size), _p(b.nears), _p(b.fars))
         b.bits = bits
-        b.counter.zero_()
         L.call("n2m_march_rays_train", *b.args, None, None, None, _p(b.rays), _p(b.counter), _p(b.noises), s)
         b.host_count.copy_(b.counter, non_blocking=True)
         b.count_ready.record()
@@ -265,9 +256,7 @@ class Stage0Engine:
                 with torch.cuda.stream(self.side):
                     b = self._prepare(N)
                 main = torch.cuda.current_stream(self.device)
-                for t in (b.cam, b.pix, b.noises, b.bg):
-                    if t is not None:
-                        t.record_stream(main)
+                b.u.record_stream(main)
             b.index = j
             self._prepared = j
             self._last = b

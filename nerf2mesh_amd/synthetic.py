@@ -141,6 +141,37 @@ def random_batch(poses, images, N, generator=None, H=LEGO_HW, W=LEGO_HW, focal=L
     return o, d, images[cam, pix]
 
 
+def batch_from_uniforms(poses, images, u, aabb, min_near, H=LEGO_HW, W=LEGO_HW, focal=LEGO_FOCAL, out=None, counter=None):
+    """A training batch from ONE tensor of uniforms u [N,6] in [0,1): view = floor(u0 V), pixel = floor(u1 H W) (N random pixels over
+    random views: random_image_batch, nerf/provider.py:302-303 + nerf/utils.py:271), rays and ground truth like random_batch, near/far
+    of the aabb, march jitter = u2, random background = u3..u5 (nerf/utils.py:649-652).  Returns (rays_o, rays_d, rgba, nears, fars,
+    noises, bg).  On the GPU this is one kernel (n2m_batch_rays) writing into `out` (a tuple of preallocated tensors) when given; the
+    torch statement below is the same arithmetic.  Both training drivers draw their batches through this function, so they consume
+    identical numbers whatever their scheduling."""
+    dev = poses.device
+    N, V = u.shape[0], poses.shape[0]
+    if dev.type == "cuda":
+        from . import _lib as L
+        if out is None:
+            f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            out = (f(N, 3), f(N, 3), f(N, 4), f(N), f(N), f(N), f(N, 3))
+        o, d, rgba, nears, fars, noises, bg = out
+        L.call("n2m_batch_rays", L.ptr(poses), L.ptr(u), V, N, H, W, float(focal), float(focal), W / 2, H / 2, L.ptr(images), L.ptr(aabb),
+               float(min_near), L.ptr(o), L.ptr(d), L.ptr(rgba), L.ptr(nears), L.ptr(fars), L.ptr(noises), L.ptr(bg), L.ptr(counter), L.stream())
+        return o, d, rgba, nears, fars, noises, bg
+    cam = (u[:, 0] * V).long().clamp(max=V - 1)
+    pix = (u[:, 1] * (H * W)).long().clamp(max=H * W - 1)
+    o, d = rays_from_pixels(poses, cam, pix, H, W, focal)
+    inv = 1.0 / d
+    lo, hi = (aabb[:3] - o) * inv, (aabb[3:] - o) * inv
+    tn, tf = torch.minimum(lo, hi).amax(-1), torch.maximum(lo, hi).amin(-1)
+    miss = tn > tf
+    big = torch.finfo(torch.float32).max
+    nears = torch.where(miss, torch.full_like(tn, big), tn.clamp(min=min_near))
+    fars = torch.where(miss, torch.full_like(tf, big), tf)
+    return o, d, images[cam, pix], nears, fars, u[:, 2].contiguous(), u[:, 3:6].contiguous()
+
+
 def render_gt(rays_o, rays_d, bx=None):
     """First-hit shading of the box scene. Returns rgba [N,4] (alpha 0 = background)."""
     bx = boxes(rays_o.device) if bx is None else bx

@@ -23,13 +23,11 @@ class Stage0Trainer:
         self.rank, self.world = rank, world_size
         self.global_step = 0
         self.num_rays = opt.num_rays
-        # every rank draws its own rays.  Pixel choice, background and march jitter come from three independent
-        # streams, so a driver that prepares batches further ahead (engine.Stage0Engine) consumes identical numbers per batch
+        # every rank draws its own rays.  Everything random about a batch (pixels, march jitter, background) comes
+        # from ONE draw per batch of this generator, so a driver that prepares batches further ahead (engine.Stage0Engine) consumes
+        # identical numbers per batch
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(seed + rank)
-        self.gen_bg, self.gen_noise = torch.Generator(device=device), torch.Generator(device=device)
-        self.gen_bg.manual_seed(seed + rank + 7919)
-        self.gen_noise.manual_seed(seed + rank + 104729)
         # main.py:221 Adam(eps=1e-15) + nerf/utils.py:506 GradScaler.  Single GPU with the fused field: optim.FusedAdamAMP does both
         # in two launches and takes the inf/nan verdict from the kernels that produce the gradients.
         self.amp_adam = device.type == "cuda" and bool(getattr(opt, "fused_mlp", False)) and bool(opt.fp16) and getattr(opt, "ind_dim", 0) == 0
@@ -93,13 +91,13 @@ class Stage0Trainer:
             self.model.mark_untrained_grid(self.poses, (f, f, synthetic.LEGO_HW / 2, synthetic.LEGO_HW / 2))
 
     def batch(self):
-        if self.images is None and self.preload:
+        """(rays_o, rays_d, rgba, noises, bg) of the next batch: ONE draw of [num_rays, 6] uniforms from the ray generator, turned into
+        pixels, rays, ground truth, march jitter and random background by synthetic.batch_from_uniforms."""
+        if self.images is None:
             self.images = synthetic.preload_images(self.poses, self.boxes)     # nerf/provider.py:224-233 (`preload`)
-        if self.images is not None:
-            return synthetic.random_batch(self.poses, self.images, self.num_rays, self.gen)
-        rays_o, rays_d = synthetic.random_rays(self.poses, self.num_rays, self.gen)
-        rgba = synthetic.render_gt(rays_o, rays_d, self.boxes)
-        return rays_o, rays_d, rgba
+        u = torch.rand(self.num_rays, 6, device=self.device, generator=self.gen)
+        rays_o, rays_d, rgba, _, _, noises, bg = synthetic.batch_from_uniforms(self.poses, self.images, u, self.model.aabb_train, self.model.min_near)
+        return rays_o, rays_d, rgba, noises, bg
 
     def _prepare(self):
         """Occupancy refresh (every 16th step, nerf/utils.py:1155-1156) + next batch + march pass 1 for it."""
@@ -108,14 +106,13 @@ class Stage0Trainer:
             if self.sync is not None:
                 self.sync.sync_rng_for_grid_update(self.global_step)
             model.update_extra_state()
-        rays_o, rays_d, images = self.batch()
+        rays_o, rays_d, images, noises, bg = self.batch()
         # sample buffers for the speculative write pass: a quarter above the last batch (adaptive_num_rays steers M towards
         # opt.num_points, nerf/utils.py:796-797); a batch that still does not fit is re-marched exactly by finish()
         expect = 0 if self.last_num_points <= 0 else ((int(1.25 * max(self.last_num_points, 1024)) + 1023) // 1024) * 1024
-        noises = torch.rand(rays_o.shape[0], dtype=torch.float32, device=rays_o.device, generator=self.gen_noise) if self.pipeline else None
         ticket = model.march_ahead(rays_o, rays_d, dt_gamma=opt.dt_gamma, perturb=True, max_steps=opt.max_steps,
                                    expect_points=expect, noises=noises) if self.pipeline else None
-        return rays_o, rays_d, images, ticket
+        return rays_o, rays_d, images, ticket, (bg if opt.background != "white" else 1), noises
 
     def _prepare_overlapped(self):
         """_prepare() on the side stream.  The next batch's ray generation and march pass 1 read only the camera set and the occupancy
@@ -129,8 +126,8 @@ class Stage0Trainer:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             nxt = self._prepare()
-        rays_o, rays_d, images, ticket = nxt
-        for t in (rays_o, rays_d, images, ticket.rays, ticket.counter, ticket.noises) + tuple(ticket.keep) + tuple(ticket.spec or ()):
+        rays_o, rays_d, images, ticket, bg, noises = nxt
+        for t in (rays_o, rays_d, images, bg, noises, ticket.rays, ticket.counter, ticket.noises) + tuple(ticket.keep) + tuple(ticket.spec or ()):
             if torch.is_tensor(t):
                 t.record_stream(main)          # allocated on the side stream, consumed on the main one
         return nxt
@@ -141,12 +138,11 @@ class Stage0Trainer:
             model.train()
         if self._next is None:
             self._next = self._prepare()
-        rays_o, rays_d, images, ticket = self._next
+        rays_o, rays_d, images, ticket, bg_color, noises = self._next
         self._next = None
         self.global_step += 1
         self.optimizer.zero_grad(set_to_none=True)
         N = rays_o.shape[0]
-        bg_color = 1 if opt.background == "white" else torch.rand(N, 3, device=self.device, generator=self.gen_bg)
         if opt.sdf:
             opt.cos_anneal_ratio = min(1, self.global_step / (0.5 * opt.iters))
             opt.normal_anneal_epsilon = 1e-1 * (1 - min(0.999, self.global_step / (0.5 * opt.iters)))
