@@ -319,7 +319,8 @@ int n2m_photo_loss_backward(const float* image, const float* weights_sum, const 
  * A wave composites its ray, forms the ray's loss term and gradients and runs the backward scan right away (the seed gradient
  * *grad_loss / N does not depend on the loss value).  grad_sigmas [M] / grad_rgbs [M,3] are bit-identical to the four-call chain
  * (every sample of a ray's range is written); weights_sum [N] and image [N,3] (colour before the background blend) may be NULL;
- * partial: ceil(N/16) floats scratch; ticket: one zero uint32 (left zero); loss [1] = the mean over rays; loss_sum (may be NULL) += loss. */
+ * partial: ceil(N/16) floats scratch; ticket: one zero uint32 (left zero); loss [1] = the mean over rays; loss_sum (may be NULL) += loss.
+ * ticket == NULL: the kernel only leaves the per-workgroup partials (no fence, no arrival atomics); n2m_scaler_update_slots_loss sums them. */
 int n2m_composite_loss_train(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays, uint32_t M, uint32_t N,
                              float T_thresh, const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask,
                              const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas, float* grad_rgbs, float* partial,
@@ -356,6 +357,12 @@ int n2m_scaler_update(float* scale, float* growth_tracker, float* found_inf, flo
 int n2m_scaler_update_slots(float* scale, float* growth_tracker, float* found_inf, float* steps, float* bias,
                             uint32_t participants, double beta1, double beta2, float growth_factor, float backoff_factor,
                             float growth_interval, void* stream);
+
+/* n2m_scaler_update_slots + loss = sum(loss_partial[0 .. n_partial)) / n_rays, *loss_sum += loss (either may be NULL). */
+int n2m_scaler_update_slots_loss(float* scale, float* growth_tracker, float* found_inf, float* steps, float* bias,
+                                 uint32_t participants, double beta1, double beta2, float growth_factor, float backoff_factor,
+                                 float growth_interval, const float* loss_partial, uint32_t n_partial, uint32_t n_rays, float* loss,
+                                 float* loss_sum, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * shencoder   (reference: shencoder/src/shencoder.h:9-10, shencoder/src/bindings.cpp:5-8)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "n2m_adam_step": [_vp, ctypes.c_double, ctypes.c_double, _f32, _vp, _vp, _vp, _vp],
     "n2m_scaler_update": [_vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp],
     "n2m_scaler_update_slots": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp],
+    "n2m_scaler_update_slots_loss": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp, _u32, _u32, _vp, _vp, _vp],
     "n2m_photo_loss_forward": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _u32, _vp, _vp, _vp, _vp],
     "n2m_photo_loss_backward": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _u32, _vp, _vp, _vp, _vp],
     "n2m_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp],

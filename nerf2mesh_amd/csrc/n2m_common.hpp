@@ -78,40 +78,38 @@ __device__ __forceinline__ uint32_t n2m_gather3(uint32_t v) {
     return v;
 }
 
-// wave64 reductions / scans on shuffles (compiler lowers to DPP / ds_bpermute)
-__device__ __forceinline__ float n2m_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// wave64 scans and reductions on the DPP network (no LDS-pipe round trips: a ds_bpermute-based Hillis-Steele scan is six dependent
+// ~60-cycle trips, this is six VALU operations).  Inclusive scan: Hillis-Steele inside each row of 16 lanes (row_shr 1/2/4/8; lanes
+// without a source keep the identity), then lane 15 of rows 0/2 into rows 1/3 (row_bcast:15) and lane 31 into rows 2/3 (row_bcast:31).
+// Sums/products are associated in that order (fp results differ from a serial sum in the last bits, like any parallel reduction).
+#define N2M_DPP_STEP(OP, ident, ctrl, rows) v = OP(v, __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (T)(ident)), __builtin_bit_cast(int, v), (ctrl), (rows), 0xf, false)))
+template <typename T, class F>
+__device__ __forceinline__ T n2m_wave_scan_dpp(T v, T ident, F OP) {
+    N2M_DPP_STEP(OP, ident, 0x111, 0xf);   // row_shr:1
+    N2M_DPP_STEP(OP, ident, 0x112, 0xf);   // row_shr:2
+    N2M_DPP_STEP(OP, ident, 0x114, 0xf);   // row_shr:4
+    N2M_DPP_STEP(OP, ident, 0x118, 0xf);   // row_shr:8
+    N2M_DPP_STEP(OP, ident, 0x142, 0xa);   // row_bcast:15 -> rows 1, 3
+    N2M_DPP_STEP(OP, ident, 0x143, 0xc);   // row_bcast:31 -> rows 2, 3
     return v;
+}
+#undef N2M_DPP_STEP
+struct N2mAddF { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
+struct N2mMulF { __device__ __forceinline__ float operator()(float a, float b) const { return a * b; } };
+struct N2mAddU { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
+// inclusive prefix sum / product across the wave (`lane` kept in the signature for the callers; unused)
+__device__ __forceinline__ float n2m_wave_scan_add(float v, int) { return n2m_wave_scan_dpp<float>(v, 0.0f, N2mAddF()); }
+__device__ __forceinline__ uint32_t n2m_wave_scan_add_u32(uint32_t v, int) { return n2m_wave_scan_dpp<uint32_t>(v, 0u, N2mAddU()); }
+__device__ __forceinline__ float n2m_wave_scan_mul(float v, int) { return n2m_wave_scan_dpp<float>(v, 1.0f, N2mMulF()); }
+// wave totals: lane 63 of the inclusive scan, broadcast through an SGPR
+__device__ __forceinline__ float n2m_wave_sum(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n2m_wave_scan_add(v, 0)), 63));
 }
 __device__ __forceinline__ uint32_t n2m_wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)n2m_wave_scan_add_u32(v, 0), 63);
 }
-// inclusive prefix sum across the wave
-__device__ __forceinline__ float n2m_wave_scan_add(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float u = __shfl_up(v, o, 64);
-        if (lane >= o) v += u;
-    }
-    return v;
-}
-__device__ __forceinline__ uint32_t n2m_wave_scan_add_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = __shfl_up(v, o, 64);
-        if (lane >= o) v += u;
-    }
-    return v;
-}
-// inclusive prefix product across the wave
-__device__ __forceinline__ float n2m_wave_scan_mul(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float u = __shfl_up(v, o, 64);
-        if (lane >= o) v *= u;
-    }
-    return v;
+// value of lane 63 in every lane (through an SGPR) / value of the lane below, `first` in lane 0 (wave_shr:1)
+__device__ __forceinline__ float n2m_lane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+__device__ __forceinline__ float n2m_lane_below(float v, float first) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
 }

@@ -712,8 +712,7 @@ composite_train_fwd_kernel(const float* __restrict__ sigmas, const float* __rest
                 cr = rgbs[3 * i]; cg = rgbs[3 * i + 1]; cb = rgbs[3 * i + 2];
             }
             const float incl = n2m_wave_scan_mul(1.0f - alpha, lane);
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0f;
+            const float excl = n2m_lane_below(incl, 1.0f);
             const float T_before = carry_T * excl, T_after = carry_T * incl;
             // the sample that drives T below the threshold is still composited; everything after it is not
             const unsigned long long stop = __ballot(valid && T_after < T_thresh);
@@ -723,7 +722,7 @@ composite_train_fwd_kernel(const float* __restrict__ sigmas, const float* __rest
             if (valid) weights[i] = w;
             r += w * cr; g += w * cg; b += w * cb; ws += w; d += w * tmid;
             if (stop) stopped = true;
-            else carry_T = __shfl(T_after, 63, 64);
+            else carry_T = n2m_lane63(T_after);
         }
         r = n2m_wave_sum(r); g = n2m_wave_sum(g); b = n2m_wave_sum(b); ws = n2m_wave_sum(ws); d = n2m_wave_sum(d);
     } else if (cnt != 0 && off < M) {
@@ -778,8 +777,7 @@ composite_train_bwd_kernel(const float* __restrict__ grad_weights, const float* 
             gw = grad_weights[i];
         }
         const float incl = n2m_wave_scan_mul(1.0f - alpha, lane);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0f;
+        const float excl = n2m_lane_below(incl, 1.0f);
         const float T_before = carry_T * excl, T_after = carry_T * incl;
         const unsigned long long stop = __ballot(valid && T_after < T_thresh);
         const int last = stop ? (int)__ffsll((long long)stop) - 1 : 63;
@@ -801,9 +799,9 @@ composite_train_bwd_kernel(const float* __restrict__ grad_weights, const float* 
             grad_sigmas[i] = 0.f; grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f;
         }
         if (stop) { stopped = true; continue; }
-        carry_T = __shfl(T_after, 63, 64);
-        r0 = __shfl(r, 63, 64); g0 = __shfl(g, 63, 64); b0 = __shfl(b, 63, 64);
-        ws0 = __shfl(ws, 63, 64); d0 = __shfl(d, 63, 64);
+        carry_T = n2m_lane63(T_after);
+        r0 = n2m_lane63(r); g0 = n2m_lane63(g); b0 = n2m_lane63(b);
+        ws0 = n2m_lane63(ws); d0 = n2m_lane63(d);
     }
 }
 
@@ -846,15 +844,14 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
                     cr = rgbs[3 * i]; cg = rgbs[3 * i + 1]; cb = rgbs[3 * i + 2];
                 }
                 const float incl = n2m_wave_scan_mul(1.0f - alpha, lane);
-                float excl = __shfl_up(incl, 1, 64);
-                if (lane == 0) excl = 1.0f;
+                const float excl = n2m_lane_below(incl, 1.0f);
                 const float T_before = carry_T * excl, T_after = carry_T * incl;
                 const unsigned long long stop = __ballot(valid && T_after < T_thresh);
                 const int last = stop ? (int)__ffsll((long long)stop) - 1 : 63;
                 const float w = (valid && lane <= last) ? alpha * T_before : 0.f;
                 rF += w * cr; gF += w * cg; bF += w * cb; wsF += w;
                 if (stop) break;
-                carry_T = __shfl(T_after, 63, 64);
+                carry_T = n2m_lane63(T_after);
             }
             rF = n2m_wave_sum(rF); gF = n2m_wave_sum(gF); bF = n2m_wave_sum(bF); wsF = n2m_wave_sum(wsF);
         }
@@ -906,8 +903,7 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
                     cr = rgbs[3 * i]; cg = rgbs[3 * i + 1]; cb = rgbs[3 * i + 2];
                 }
                 const float incl = n2m_wave_scan_mul(1.0f - alpha, lane);
-                float excl = __shfl_up(incl, 1, 64);
-                if (lane == 0) excl = 1.0f;
+                const float excl = n2m_lane_below(incl, 1.0f);
                 const float T_before = carry_T * excl, T_after = carry_T * incl;
                 const unsigned long long stop = __ballot(valid && T_after < T_thresh);
                 const int last = stop ? (int)__ffsll((long long)stop) - 1 : 63;
@@ -926,8 +922,8 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
                     grad_sigmas[i] = 0.f; grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f;
                 }
                 if (stop) { stopped = true; continue; }
-                carry_T = __shfl(T_after, 63, 64);
-                r0 = __shfl(r, 63, 64); g0 = __shfl(g, 63, 64); b0 = __shfl(b, 63, 64); ws0 = __shfl(ws, 63, 64);
+                carry_T = n2m_lane63(T_after);
+                r0 = n2m_lane63(r); g0 = n2m_lane63(g); b0 = n2m_lane63(b); ws0 = n2m_lane63(ws);
             }
         }
     }
@@ -939,9 +935,13 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
 #pragma unroll
         for (int q = 0; q < 16; ++q) p += wave_loss[q];
         partial[blockIdx.x] = p;
-        __threadfence();
-        last_block = atomicAdd(ticket, 1u) == gridDim.x - 1;
+        last_block = false;
+        if (ticket) {           // ticket == NULL: the caller reduces the partials itself (n2m_scaler_update_slots_loss)
+            __threadfence();
+            last_block = atomicAdd(ticket, 1u) == gridDim.x - 1;
+        }
     }
+    if (ticket == nullptr) return;
     __syncthreads();
     if (last_block) {
         __threadfence();
@@ -1196,7 +1196,8 @@ extern "C" int n2m_composite_loss_train(const float* sigmas, const float* rgbs, 
                                         float T_thresh, const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb,
                                         float lambda_mask, const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas,
                                         float* grad_rgbs, float* partial, uint32_t* ticket, float* loss, float* loss_sum, void* stream) {
-    N2M_NOTNULL(rays); N2M_NOTNULL(gt_rgba); N2M_NOTNULL(grad_loss); N2M_NOTNULL(partial); N2M_NOTNULL(ticket); N2M_NOTNULL(loss);
+    N2M_NOTNULL(rays); N2M_NOTNULL(gt_rgba); N2M_NOTNULL(grad_loss); N2M_NOTNULL(partial);
+    N2M_REQUIRE(ticket == nullptr || loss != nullptr, N2M_ENULL, "composite_loss_train: a ticket needs the loss output");
     if (M > 0) { N2M_NOTNULL(sigmas); N2M_NOTNULL(rgbs); N2M_NOTNULL(ts); N2M_NOTNULL(grad_sigmas); N2M_NOTNULL(grad_rgbs); }
     if (N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;

@@ -390,8 +390,20 @@ extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, f
 // scaler bookkeeping and the global count (slot 0), thread s the count and the next-step corrections of slot s.
 __global__ void scaler_update_slots_kernel(float* scale, float* growth_tracker, float* found_inf, float* steps /*[1+MAX]*/,
                                            float* bias /*[1+MAX][2]*/, uint32_t participants, double beta1, double beta2,
-                                           float growth_factor, float backoff_factor, float growth_interval) {
+                                           float growth_factor, float backoff_factor, float growth_interval,
+                                           const float* __restrict__ loss_partial, uint32_t n_partial, float inv_rays,
+                                           float* __restrict__ loss, float* __restrict__ loss_sum) {
     const uint32_t s = threadIdx.x;
+    if (loss_partial) {       // the step's loss VALUE (nobody on the GPU waits for it): per-workgroup partials of n2m_composite_loss_train,
+        float acc = 0.0f;     // summed here in a fixed order (lane j takes partials j, j + 64, ...; then the lanes in scan order)
+        for (uint32_t i = s; i < n_partial; i += 64) acc += loss_partial[i];
+        acc = n2m_wave_sum(acc);
+        if (s == 0) {
+            const float v = acc * inv_rays;
+            if (loss) *loss = v;
+            if (loss_sum) *loss_sum += v;
+        }
+    }
     const bool ok = *found_inf == 0.0f;
     __syncthreads();                                  // everyone has read the verdict before thread 0 clears it
     if (s == 0) {
@@ -423,7 +435,23 @@ extern "C" int n2m_scaler_update_slots(float* scale, float* growth_tracker, floa
                                        float growth_interval, void* stream) {
     N2M_REQUIRE(found_inf != nullptr && steps != nullptr && bias != nullptr, N2M_ENULL, "scaler_update_slots: NULL found_inf / steps / bias");
     scaler_update_slots_kernel<<<1, 64, 0, (hipStream_t)stream>>>(scale, growth_tracker, found_inf, steps, bias, participants, beta1, beta2,
-                                                                  growth_factor, backoff_factor, growth_interval);
+                                                                  growth_factor, backoff_factor, growth_interval, nullptr, 0u, 0.0f, nullptr, nullptr);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+// The same + the final reduction of the loss value from the per-workgroup partials n2m_composite_loss_train leaves when it is given no
+// ticket (loss = sum(partial[0..n_partial)) / n_rays; *loss_sum += loss): keeps the arrival ticket -- one __threadfence + one same-address
+// atomic per workgroup -- out of the compositing kernel, whose loss VALUE nothing on the device waits for.
+extern "C" int n2m_scaler_update_slots_loss(float* scale, float* growth_tracker, float* found_inf, float* steps, float* bias,
+                                            uint32_t participants, double beta1, double beta2, float growth_factor, float backoff_factor,
+                                            float growth_interval, const float* loss_partial, uint32_t n_partial, uint32_t n_rays, float* loss,
+                                            float* loss_sum, void* stream) {
+    N2M_REQUIRE(found_inf != nullptr && steps != nullptr && bias != nullptr, N2M_ENULL, "scaler_update_slots: NULL found_inf / steps / bias");
+    N2M_REQUIRE(loss_partial != nullptr && n_rays > 0, N2M_EINVAL, "scaler_update_slots_loss: needs the loss partials and the ray count");
+    scaler_update_slots_kernel<<<1, 64, 0, (hipStream_t)stream>>>(scale, growth_tracker, found_inf, steps, bias, participants, beta1, beta2,
+                                                                  growth_factor, backoff_factor, growth_interval, loss_partial, n_partial,
+                                                                  1.0f / (float)n_rays, loss, loss_sum);
     N2M_CHECK_LAUNCH();
     return 0;
 }

@@ -311,7 +311,7 @@ class Stage0Engine:
         d = self._desc[key] = (desc, participants, groups)
         return d
 
-    def _optimizer_step(self, full, lr_factor):
+    def _optimizer_step(self, full, lr_factor, loss_out=None):
         o = self.optimizer
         desc, participants, groups = self._adam_desc(full)
         for k, gi in enumerate(groups):
@@ -321,8 +321,13 @@ class Stage0Engine:
         L.call("n2m_adam_step", ctypes.addressof(desc), float(b1), float(b2), float(o.param_groups[0]["eps"]), _p(o.scale), _p(o.found_inf),
                _p(o.bias), s)
         gf, bf, gi = o.growth
-        L.call("n2m_scaler_update_slots", _p(o.scale), _p(o.growth_tracker), _p(o.found_inf), _p(o.steps), _p(o.bias), participants,
-               float(b1), float(b2), gf, bf, gi, s)
+        if loss_out is None:
+            L.call("n2m_scaler_update_slots", _p(o.scale), _p(o.growth_tracker), _p(o.found_inf), _p(o.steps), _p(o.bias), participants,
+                   float(b1), float(b2), gf, bf, gi, s)
+        else:        # + the step's loss value from the compositing kernel's per-workgroup partials
+            n_rays, buf = loss_out
+            L.call("n2m_scaler_update_slots_loss", _p(o.scale), _p(o.growth_tracker), _p(o.found_inf), _p(o.steps), _p(o.bias), participants,
+                   float(b1), float(b2), gf, bf, gi, _p(self._w["partial"]), (n_rays + 15) // 16, n_rays, _p(buf), _p(self._loss_sum), s)
         nxt = lr_lambda(self.global_step, self.opt.iters)          # like LambdaLR.step(): param_groups carry the NEXT step's rate
         for group in o.param_groups:
             group["lr"] = float(group["initial_lr"]) * nxt
@@ -372,8 +377,7 @@ class Stage0Engine:
         early = None
         d_sigma, d_rgb = w["d_sr"][:max(M, 1)], w["d_sr"][max(M, 1):4 * max(M, 1)]
         L.call("n2m_composite_loss_train", _p(w["sigma"]), _p(w["rgb"]), _p(ts), _p(b.rays), M, N, 1e-4, _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask,
-               _p(seed), None, None, _p(d_sigma), _p(d_rgb), _p(w["partial"]), _p(self._ticket), _p(b.loss), _p(self._loss_sum), s)
-        loss = b.loss.view(())                 # lives in the batch's buffer set: valid until the set is reused three steps later
+               _p(seed), None, None, _p(d_sigma), _p(d_rgb), _p(w["partial"]), None, None, None, s)      # loss value: summed by the scaler kernel
         spec_loss = None
         if M > 0:
             d_spec = None
@@ -381,7 +385,6 @@ class Stage0Engine:
                 # + lambda_specular * mean_m sum_c spec^2 (nerf/utils.py:735-737): d/dspec = 2 lambda / M * spec, times the seed
                 spec_m = w["spec"][:3 * M]
                 spec_loss = opt.lambda_specular * (spec_m * spec_m).sum() / M
-                loss = loss + spec_loss
                 d_spec = w["d_spec"][:3 * M]
                 torch.mul(spec_m, seed * (2.0 * opt.lambda_specular / M), out=d_spec)
             L.call("n2m_field_backward", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 1,
@@ -423,15 +426,17 @@ class Stage0Engine:
         self._marker = torch.cuda.Event()
         self._marker.record()
         # ---- Adam + loss-scale bookkeeping, LR schedule (main.py:239)
-        self._lr_step(shading != 0)
+        self._lr_step(shading != 0, loss_out=(N, b.loss))
+        loss = b.loss.view(())                 # written by the scaler kernel; lives in the batch's buffer set (valid until the set comes round again)
         if spec_loss is not None:
-            self._loss_sum += spec_loss        # the photometric part was added by the loss kernel itself
+            loss = loss + spec_loss
+            self._loss_sum += spec_loss        # the photometric part was added by the scaler kernel itself
         self._fill_pipeline()
         return loss
 
-    def _lr_step(self, full):
+    def _lr_step(self, full, loss_out=None):
         if full is not None:
-            self._optimizer_step(full, lr_lambda(self.global_step - 1, self.opt.iters))
+            self._optimizer_step(full, lr_lambda(self.global_step - 1, self.opt.iters), loss_out)
 
     @torch.no_grad()
     def eval_psnr(self, cam=0, downscale=4):
