@@ -95,6 +95,19 @@ int n2m_march_rays_train_write(const float* rays_o, const float* rays_d, const u
                                const float* nears, const float* fars, float* xyzs, float* dirs, float* ts,
                                const int32_t* rays, const float* noises, uint32_t max_points, void* stream);
 
+/* The protocol of raymarching.py:229-241 with ONE march per ray: the count pass also records, per ray, the chunks of 64 candidates
+ * that kept samples (kept-lane mask + T of the first lane, 16 B each); a replay kernel derives every ray's offset -- the ray-order
+ * prefix sum of the counts, from 0 -- from per-group totals and recomputes only the kept candidates into the sample rows (no second
+ * walk of the occupancy grid, no scan kernel).  Outputs: rays [N,2] = (offset, count), counter[0] = sample count, xyzs/dirs/ts rows
+ * of every ray whose range fits max_points rows (raymarching.cu:417): bit-identical to n2m_march_rays_train (zeroed counter) +
+ * n2m_march_rays_train_write.  workspace: n2m_march_fused_workspace_bytes(N) bytes of device memory, contents irrelevant. */
+uint64_t n2m_march_fused_workspace_bytes(uint32_t N);
+int n2m_march_rays_train_fused(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, int contract,
+                               float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                               const float* nears, const float* fars, float* xyzs, float* dirs, float* ts,
+                               int32_t* rays, int32_t* counter, const float* noises, uint32_t max_points,
+                               void* workspace, uint64_t workspace_bytes, void* stream);
+
 /* Diagnostics.  march_rays_train resolves which candidates a ray visits with a wave-wide prefix maximum whose result is provably the
  * serial chain's whenever its check passes; a ray that fails the check is re-marched with the serial resolution.  Returns in *out
  * the number of such rays (count passes) since the previous call and resets it.  Synchronises the device. */

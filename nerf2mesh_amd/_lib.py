@@ -22,6 +22,8 @@ SIGNATURES = {
     "n2m_flatten_rays": [_vp, _u32, _u32, _vp, _vp],
     "n2m_march_rays_train": [_vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_march_rays_train_write": [_vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "n2m_march_rays_train_fused": [_vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _u64, _vp],
+    "n2m_march_fused_workspace_bytes": [_u32],
     "n2m_march_fallback_count": [_vp],
     "n2m_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _int, _vp, _vp, _vp, _vp, _vp],
     "n2m_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _int, _vp, _vp, _vp],
@@ -73,7 +75,7 @@ SIGNATURES = {
     "n2m_prof_read": [_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
 }
 
-RESTYPES = {"n2m_grid_binned_workspace_bytes": _u64, "n2m_grid_binned_pair_workspace_bytes": _u64}   # everything else returns an int status
+RESTYPES = {"n2m_grid_binned_workspace_bytes": _u64, "n2m_grid_binned_pair_workspace_bytes": _u64, "n2m_march_fused_workspace_bytes": _u64}   # everything else returns an int status
 
 F32, F16 = 0, 1
 ADAM_MAX = 16

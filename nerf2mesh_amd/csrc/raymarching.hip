@@ -264,6 +264,19 @@ __device__ __forceinline__ bool march_step(const MarchCtx& c, float& t, MarchSam
 // N waves (not N/64) to fill the machine.
 struct LaneEval { float cx, cy, cz, dt, tt; bool keep; };
 
+// Position (contracted when outside the unit box) and step of candidate t: the part of eval_candidate a kept sample's row is made of.
+__device__ __forceinline__ void candidate_point(const MarchCtx& c, float t, float& cx, float& cy, float& cz, float& dt) {
+    cx = n2m_clampf(c.ox + t * c.dx, -c.bound, c.bound);
+    cy = n2m_clampf(c.oy + t * c.dy, -c.bound, c.bound);
+    cz = n2m_clampf(c.oz + t * c.dz, -c.bound, c.bound);
+    dt = n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+    const float mag = fmaxf(fabsf(cx), fmaxf(fabsf(cy), fabsf(cz)));
+    if (c.contract && mag > 1.0f) {
+        const float k = (2.0f - 1.0f / mag) / mag;
+        cx *= k; cy *= k; cz *= k;
+    }
+}
+
 __device__ __forceinline__ LaneEval eval_candidate(const MarchCtx& c, float t) {
     LaneEval e;
     const float x = n2m_clampf(c.ox + t * c.dx, -c.bound, c.bound);
@@ -318,21 +331,30 @@ __device__ __forceinline__ float wave_scan_max_dpp(float v) {
     return v;
 }
 
-template <bool WRITE>
-__device__ __forceinline__ void march_train_one_ray(uint32_t n, int lane, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+// A chunk of 64 candidates that kept at least one sample, as the single-pass marcher remembers it between counting and writing:
+// which lanes were kept, T of lane 0 and (constant-step closed form) the per-candidate increment of T's bit pattern, 0 = recurrence.
+struct ChunkRec { unsigned long long mask; uint32_t tbits; uint32_t m; };
+constexpr uint32_t kChunkRecCap = 24;
+
+// WRITE: emit samples (offset / budget from `rays`, or given by the caller when RECORD is set too: the single-pass marcher's fallback).
+// !WRITE: count; with RECORD the non-empty chunks are logged into rec[0..kChunkRecCap) (wave-private LDS) and n_rec counts them all.
+template <bool WRITE, bool RECORD = false>
+__device__ __forceinline__ uint32_t march_train_one_ray(uint32_t n, int lane, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                         const uint8_t* __restrict__ grid,
                         float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                         const float* __restrict__ nears, const float* __restrict__ fars, float* __restrict__ xyzs,
                         float* __restrict__ dirs, float* __restrict__ ts, int32_t* __restrict__ rays,
-                        const float* __restrict__ noises, uint32_t max_points, bool force_serial) {
+                        const float* __restrict__ noises, uint32_t max_points, bool force_serial,
+                        ChunkRec* rec = nullptr, uint32_t* n_rec_out = nullptr, size_t out_given = 0, uint32_t budget_given = 0) {
     MarchCtx c;
     march_ctx_init(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, 0.0f, grid, bound, contract, dt_gamma, max_steps, C, H);
     uint32_t budget = max_steps;
     size_t out = 0;
+    uint32_t n_rec = 0;
     if (WRITE) {
-        out = (size_t)(uint32_t)rays[2 * n];
-        budget = (uint32_t)rays[2 * n + 1];
-        if (budget == 0 || out + budget > (size_t)max_points) return;     // does not fit the sample buffers (raymarching.cu:417)
+        out = RECORD ? out_given : (size_t)(uint32_t)rays[2 * n];
+        budget = RECORD ? budget_given : (uint32_t)rays[2 * n + 1];
+        if (budget == 0 || out + budget > (size_t)max_points) return 0;     // does not fit the sample buffers (raymarching.cu:417)
     }
     const float far = fars[n];
     const float t_start = nears[n] + n2m_clampf(nears[n] * dt_gamma, c.dt_min, c.dt_max) * noises[n];
@@ -348,6 +370,7 @@ __device__ __forceinline__ void march_train_one_ray(uint32_t n, int lane, const 
 restart_ray:
     float t_base = t_start;
     uint32_t kept = 0;
+    n_rec = 0;
     bool pending = false;      // an empty voxel's exit time lies beyond the previous chunk
     float pending_tt = 0.f;
     float carry_tt = -INFINITY; // parallel form: largest exit time of any empty candidate in earlier chunks
@@ -361,6 +384,7 @@ restart_ray:
         // integer m added to t's bit pattern -- so lane j reads T_{base+j} = bits(t_base) + j m in closed form.  Chunks
         // that leave the binade, and the tie |r| = 1/2 (round-to-even depends on t), take the serial loop below.
         bool closed_form = false;
+        uint32_t cf_m = 0;
         if (c.dt_gamma == 0.0f) {
             const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t_base));   // wave-uniform: scalar branch
             const uint32_t be = b >> 23;                                     // sign 0 and a normal exponent
@@ -374,6 +398,7 @@ restart_ray:
                         const uint32_t last = b + 64u * m;
                         if ((last >> 23) == be) {
                             closed_form = true;
+                            cf_m = m;
                             t = __uint_as_float(b + (uint32_t)lane * m);
                             t_next_base = __uint_as_float(last);
                         }
@@ -451,6 +476,10 @@ restart_ray:
         }
         }
         kept = kept_s;
+        if (!WRITE && RECORD && kept_mask) {
+            if (n_rec < kChunkRecCap && lane == 0) rec[n_rec] = ChunkRec{kept_mask, __float_as_uint(t_base), cf_m};
+            ++n_rec;
+        }
         // 4. emit
         if (WRITE && kept_mask) {
             if ((kept_mask >> lane) & 1ull) {
@@ -465,6 +494,8 @@ restart_ray:
         t_base = t_next_base;
     }
     if (!WRITE && lane == 0) rays[2 * n + 1] = (int32_t)kept;
+    if (!WRITE && RECORD) *n_rec_out = n_rec;
+    return kept;
 }
 
 // One wave per ray, four waves per workgroup; a workgroup walks rays blockIdx.x*4 + wave, += 4*gridDim.x.  With a grid that covers N
@@ -482,6 +513,97 @@ march_train_wave_kernel(const float* __restrict__ rays_o, const float* __restric
     for (uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6); n < N; n += gridDim.x * 4)
         march_train_one_ray<WRITE>(n, lane, rays_o, rays_d, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
                                    noises, max_points, force_serial);
+}
+
+// ---------------------------------------------------------------------------------- march once (count + record, then replay)
+// The two-pass protocol (count, offset scan, march AGAIN to write: raymarching.py:229-241) with ONE march per ray:
+//   march_train_record_kernel   the count pass; besides its count every ray leaves the chunks that kept samples (ChunkRec: kept-lane
+//                               mask + T of lane 0 + closed-form increment, 16 B each) and adds its count to the total of its group
+//                               of 256 rays (one no-return atomic per ray, 256 per address);
+//   march_train_replay_kernel   a ray's offset = totals of the groups before its own + counts of the <= 255 rays before it inside the
+//                               group (a handful of independent coalesced loads and one wave reduction: the deterministic ray-order
+//                               prefix sum of the two-pass form, bit for bit, without a scan kernel in between); then the kept lanes of
+//                               the recorded chunks are recomputed (T, position, step: no occupancy look-up, no resolution) and stored.
+// (A single kernel with a decoupled look-back between the two halves was measured first: 99 us against 50 + 6 + 24 for count, scan and
+// write -- the look-back chain over ~3 400 workgroups that all finish counting at about the same time costs more than it saves.)
+constexpr uint32_t kMarchGroupLog2 = 8;
+
+__global__ void __launch_bounds__(256)
+march_train_record_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
+                          float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                          const float* __restrict__ nears, const float* __restrict__ fars, int32_t* __restrict__ rays,
+                          const float* __restrict__ noises, bool force_serial, ChunkRec* __restrict__ recs, uint32_t* __restrict__ n_recs,
+                          uint32_t* __restrict__ group_total) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    uint32_t n_rec = 0;
+    const uint32_t kept = march_train_one_ray<false, true>(n, lane, rays_o, rays_d, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears, fars,
+                                                           nullptr, nullptr, nullptr, rays, noises, 0xFFFFFFFFu, force_serial,
+                                                           recs + (size_t)n * kChunkRecCap, &n_rec);
+    if (lane == 0) {
+        n_recs[n] = n_rec;
+        if (kept) __hip_atomic_fetch_add(group_total + (n >> kMarchGroupLog2), kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+march_train_replay_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
+                          float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                          const float* __restrict__ nears, const float* __restrict__ fars, float* __restrict__ xyzs,
+                          float* __restrict__ dirs, float* __restrict__ ts, int32_t* __restrict__ rays, int32_t* __restrict__ counter,
+                          const float* __restrict__ noises, uint32_t max_points, bool force_serial, const ChunkRec* __restrict__ recs,
+                          const uint32_t* __restrict__ n_recs, const uint32_t* __restrict__ group_total) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    // offset: whole groups before this ray's + the rays before it inside its group
+    const uint32_t g = n >> kMarchGroupLog2;
+    uint32_t acc = 0;
+    for (uint32_t i = (uint32_t)lane; i < g; i += 64u) acc += group_total[i];
+    for (uint32_t i = (g << kMarchGroupLog2) + (uint32_t)lane; i < n; i += 64u) acc += (uint32_t)rays[2 * i + 1];
+    const uint32_t kept = (uint32_t)rays[2 * n + 1], n_rec = n_recs[n];
+    ChunkRec mine = ChunkRec{0ull, 0u, 0u};
+    if ((uint32_t)lane < n_rec && n_rec <= kChunkRecCap) mine = recs[(size_t)n * kChunkRecCap + lane];      // lane r <- record r
+    const uint32_t off = n2m_wave_sum_u32(acc);
+    if (lane == 0) {
+        rays[2 * n] = (int32_t)off;
+        if (n == N - 1) counter[0] = (int32_t)(off + kept);                              // the batch's sample count
+    }
+    if (kept == 0 || (size_t)off + kept > (size_t)max_points) return;                   // does not fit the sample buffers (raymarching.cu:417)
+    if (n_rec > kChunkRecCap) {                                                          // more sample-bearing chunks than recorded: march again
+        march_train_one_ray<true, true>(n, lane, rays_o, rays_d, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears, fars, xyzs, dirs, ts,
+                                        rays, noises, max_points, force_serial, nullptr, nullptr, (size_t)off, kept);
+        return;
+    }
+    MarchCtx c;
+    march_ctx_init(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, 0.0f, grid, bound, contract, dt_gamma, max_steps, C, H);
+    size_t row0 = off;
+    for (uint32_t r = 0; r < n_rec; ++r) {
+        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine.mask, r);
+        const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine.mask >> 32), r);
+        const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+        const uint32_t tbits = (uint32_t)__builtin_amdgcn_readlane((int)mine.tbits, r), m = (uint32_t)__builtin_amdgcn_readlane((int)mine.m, r);
+        float t;
+        if (m) t = __uint_as_float(tbits + (uint32_t)lane * m);
+        else {
+            t = __uint_as_float(tbits);
+#pragma unroll 1
+            for (int i = 0; i < 63; ++i) {
+                const float nt = t + n2m_clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+                t = i < lane ? nt : t;
+            }
+        }
+        if ((mask >> lane) & 1ull) {
+            float cx, cy, cz, dt;
+            candidate_point(c, t, cx, cy, cz, dt);
+            const size_t row = row0 + (size_t)__popcll(mask & ((1ull << lane) - 1ull));
+            xyzs[3 * row] = cx; xyzs[3 * row + 1] = cy; xyzs[3 * row + 2] = cz;
+            dirs[3 * row] = c.dx; dirs[3 * row + 1] = c.dy; dirs[3 * row + 2] = c.dz;
+            *reinterpret_cast<float2*>(ts + 2 * row) = make_float2(t + dt, dt);
+        }
+        row0 += (size_t)__popcll(mask);
+    }
 }
 
 template <bool WRITE>
@@ -1140,6 +1262,49 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
             march_train_wave_kernel<true><<<march_grid(N), 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma,
                                                                              max_steps, N, C, H, nears, fars, xyzs, dirs, ts, rays,
                                                                              noises, max_points, serial_resolve());
+        N2M_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// n2m_march_rays_train (pass 1 + pass 2) with ONE march per ray (see march_train_record_kernel): rays[n] = (offset, count) with the
+// offsets in ray order from 0, counter[0] = the sample count, and the samples of every ray that fits max_points rows
+// (raymarching.cu:417) -- the same bits the two-pass call produces with a zeroed counter.  `workspace`:
+// n2m_march_fused_workspace_bytes(N) bytes, contents irrelevant.
+static inline uint32_t march_groups(uint32_t N) { return (N >> kMarchGroupLog2) + 1u; }
+extern "C" uint64_t n2m_march_fused_workspace_bytes(uint32_t N) {
+    return (uint64_t)N * kChunkRecCap * sizeof(ChunkRec) + (uint64_t)N * 4u + (uint64_t)march_groups(N) * 4u + 64u;
+}
+
+extern "C" int n2m_march_rays_train_fused(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, int contract,
+                                          float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float* nears,
+                                          const float* fars, float* xyzs, float* dirs, float* ts, int32_t* rays, int32_t* counter,
+                                          const float* noises, uint32_t max_points, void* workspace, uint64_t workspace_bytes, void* stream) {
+    N2M_NOTNULL(rays_o); N2M_NOTNULL(rays_d); N2M_NOTNULL(grid); N2M_NOTNULL(nears); N2M_NOTNULL(fars);
+    N2M_NOTNULL(rays); N2M_NOTNULL(noises); N2M_NOTNULL(counter); N2M_NOTNULL(workspace);
+    if (max_points > 0) { N2M_NOTNULL(xyzs); N2M_NOTNULL(dirs); N2M_NOTNULL(ts); }
+    N2M_REQUIRE(C >= 1 && H >= 1 && H <= 1024 && max_steps >= 1, N2M_EINVAL,
+                "march_rays_train_fused: need C>=1, 1<=H<=1024, max_steps>=1 (got C=%u H=%u max_steps=%u)", C, H, max_steps);
+    N2M_REQUIRE((double)C * H * H * H < 16777216.0 * 8, N2M_EINVAL, "march_rays_train_fused: C*H^3 too large (%u x %u^3)", C, H);
+    N2M_REQUIRE(workspace_bytes >= n2m_march_fused_workspace_bytes(N), N2M_EINVAL, "march_rays_train_fused: workspace of %llu bytes, need %llu",
+                (unsigned long long)workspace_bytes, (unsigned long long)n2m_march_fused_workspace_bytes(N));
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) { N2M_HIP(hipMemsetAsync(counter, 0, sizeof(int32_t), s)); return 0; }
+    ChunkRec* recs = (ChunkRec*)workspace;                                   // [N][kChunkRecCap]
+    uint32_t* n_recs = (uint32_t*)(recs + (size_t)N * kChunkRecCap);        // [N]
+    uint32_t* group_total = n_recs + N;                                      // [N / 256 + 1]
+    const uint32_t blocks = n2m_ceil_div(N, 4);
+    N2M_HIP(hipMemsetAsync(group_total, 0, (size_t)march_groups(N) * 4u, s));
+    {
+        N2M_PROF(N2M_K_MARCH_COUNT, s, 52.0 * N);
+        march_train_record_kernel<<<blocks, 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C, H, nears, fars, rays,
+                                                         noises, serial_resolve(), recs, n_recs, group_total);
+        N2M_CHECK_LAUNCH();
+    }
+    {
+        N2M_PROF(N2M_K_MARCH_WRITE, s, 44.0 * N);   // + 32 B per sample, added by the caller who knows M
+        march_train_replay_kernel<<<blocks, 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C, H, nears, fars, xyzs,
+                                                         dirs, ts, rays, counter, noises, max_points, serial_resolve(), recs, n_recs, group_total);
         N2M_CHECK_LAUNCH();
     }
     return 0;

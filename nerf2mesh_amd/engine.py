@@ -6,18 +6,18 @@ torch.autograd (custom Functions, ~50 tensor allocations, AccumulateGrad, Lambda
 step was HOST-bound (tools/cpu_bound.py).  The executor keeps PyTorch for what the task statement keeps it for -- device memory,
 streams, the random generators and torch.distributed -- and does the rest itself:
 
-  prepare (side stream, for batch i+1):  randint cam/pix -> n2m_get_rays -> n2m_near_far_from_aabb -> rand noises ->
-        n2m_march_rays_train pass 1 (count + offset scan) -> count to pinned memory + event -> n2m_march_rays_train_write (speculative)
-  step (main stream, batch i):  rand background -> [wait count] -> n2m_grid_encode_forward_packed -> n2m_field_forward ->
-        n2m_composite_rays_train_forward -> n2m_photo_loss_forward/backward -> n2m_composite_rays_train_backward -> n2m_field_backward ->
-        n2m_grid_encode_backward_binned_pair (+TV) -> [world > 1: SUM all-reduce of the fixed gradient buffers] -> n2m_adam_step ->
-        n2m_scaler_update_slots
+  prepare (side stream, for batch i+2):  torch.rand(N, 6) -> n2m_batch_rays (pixels, rays, ground truth, near/far, jitter, background)
+        -> n2m_march_rays_train_fused (one march: counts + recorded chunks, replay) -> count to pinned memory + event
+  step (main stream, batch i):  n2m_grid_encode_forward_packed -> n2m_field_forward -> n2m_composite_loss_train (compositing, loss head,
+        both backward passes) -> n2m_field_backward -> n2m_grid_encode_backward_binned_pair (+TV) -> [world > 1: SUM all-reduce of the
+        fixed gradient buffers, fine levels first] -> n2m_adam_step -> n2m_scaler_update_slots_loss
 
 Same kernels, same arguments, same random draws in the same order as Stage0Trainer: the two produce the same parameters
 (tests/test_engine.py).  What the reference does per iteration is cited there (nerf/utils.py:628-823,1152-1190, main.py:221-241).
 Configurations outside the fast path (SDF, individual codes, unfused MLPs, bound > 1 without the packed tables) stay on Stage0Trainer.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -48,6 +48,8 @@ class _RayBufs:
         self.u = self.bg = None
         self.rays = torch.empty(cap, 2, dtype=torch.int32, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ws = torch.empty(int(L.lib().n2m_march_fused_workspace_bytes(cap)), dtype=torch.uint8, device=dev)   # chunk records, group totals
+        self.one_pass = False        # samples written by the single-pass marcher (complete once the count is)
         self.host_count = torch.empty(1, dtype=torch.int32, pin_memory=True)
         self.count_ready = torch.cuda.Event()
         self.written = torch.cuda.Event()
@@ -92,6 +94,7 @@ class Stage0Engine:
         self.side = L.side_stream(dev, slot=2)
         self.split_backward = True            # multi-rank: table backward in two level halves, the first half's all-reduce under the second
         self.overlap = True                   # next batch on the side stream (False: everything on the main stream, same results)
+        self.single_pass = os.environ.get("N2M_MARCH_PASSES", "1") != "2"      # one-launch marcher (A/B: N2M_MARCH_PASSES=2)
 
         e1, e2 = model.encoder, model.encoder_color
         self.rows = e1.embeddings.shape[0]
@@ -205,6 +208,18 @@ class Stage0Engine:
         b.args = (_p(b.o), _p(b.d), _p(bits), float(model.real_bound), int(bool(opt.contract)), float(opt.dt_gamma), int(opt.max_steps), N,
                   int(model.cascade), int(model.grid_size), _p(b.nears), _p(b.fars))
         b.bits = bits
+        b.spec = b.one_pass = False
+        expect = 0 if self.last_num_points <= 0 else ((int(1.25 * max(self.last_num_points, 1024)) + 1023) // 1024) * 1024
+        if expect > 0 and self.single_pass:
+            # march ONCE: count + recorded chunks, then replayed into buffers a quarter above the last batch; a ray that does
+            # not fit is skipped like raymarching.cu:417 and _finish() then writes the batch exactly from the (offset, count) it left
+            x, d, t = self._sample_bufs(b, expect)
+            L.call("n2m_march_rays_train_fused", *b.args, _p(x), _p(d), _p(t), _p(b.rays), _p(b.counter), _p(b.noises), b.cap_m,
+                   _p(b.ws), b.ws.numel(), s)
+            b.host_count.copy_(b.counter, non_blocking=True)
+            b.count_ready.record()
+            b.spec = b.one_pass = True
+            return b
         L.call("n2m_march_rays_train", *b.args, None, None, None, _p(b.rays), _p(b.counter), _p(b.noises), s)
         b.host_count.copy_(b.counter, non_blocking=True)
         b.count_ready.record()
@@ -212,8 +227,6 @@ class Stage0Engine:
         # opt.num_points): a ray that does not fit is skipped like raymarching.cu:417 and _finish() re-marches the batch exactly.  With
         # batches prepared two ahead the pass has finished a whole step before its samples are read, so the consumer normally needs no
         # cross-stream wait at all (an event that has already fired is not waited for)
-        b.spec = False
-        expect = 0 if self.last_num_points <= 0 else ((int(1.25 * max(self.last_num_points, 1024)) + 1023) // 1024) * 1024
         if expect > 0:
             x, d, t = self._sample_bufs(b, expect)
             L.call("n2m_march_rays_train_write", *b.args, _p(x), _p(d), _p(t), _p(b.rays), _p(b.noises), b.cap_m, s)
@@ -267,7 +280,7 @@ class Stage0Engine:
         pass 2 on the main stream (the host has waited for the event behind the offset scan, so no cross-stream dependency is needed)."""
         M = self._count(b)
         if M > 0 and b.spec and M <= b.cap_m:
-            if not b.written.query():
+            if not b.one_pass and not b.written.query():      # (single pass: the host has seen the count, which the same kernel wrote last)
                 torch.cuda.current_stream(self.device).wait_event(b.written)
         elif M > 0:
             x, d, t = self._sample_bufs(b, ((int(1.25 * M) + 1023) // 1024) * 1024 if b.cap_m < M else b.cap_m)

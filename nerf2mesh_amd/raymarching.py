@@ -246,6 +246,36 @@ class MarchTicket:
 
 
 @torch.no_grad()
+def march_rays_train_fused(rays_o, rays_d, bound, contract, density_bitfield, C, H, nears, fars, noises, dt_gamma=0, max_steps=1024,
+                           max_points=0, out=None, rays=None, counter=None, workspace=None):
+    """march_rays_train with one march per ray (n2m_march_rays_train_fused: count + recorded chunks, then a replay kernel): offsets (ray
+    order, from 0), the sample count and the samples of every ray that fits `max_points` rows.  Returns (xyzs, dirs, ts, rays,
+    counter) with the sample arrays at capacity max_points: rows [0, counter) are defined when counter <= max_points (else the rays
+    that did not fit are missing, like raymarching.cu:417, and the caller re-marches with n2m_march_rays_train_write)."""
+    rays_o = _f32c(_dev(rays_o)).view(-1, 3)
+    rays_d = _f32c(_dev(rays_d)).view(-1, 3)
+    bits = _dev(density_bitfield).contiguous()
+    nears, fars, noises = _f32c(nears), _f32c(fars), _f32c(noises)
+    dev = rays_o.device
+    N = rays_o.shape[0]
+    cap = int(max_points)
+    if out is None:
+        buf = torch.empty(max(cap, 1) * 8, dtype=torch.float32, device=dev)
+        out = (buf[:3 * cap].view(-1, 3), buf[3 * cap:6 * cap].view(-1, 3), buf[6 * cap:8 * cap].view(-1, 2))
+    if rays is None:
+        rays = torch.empty(N, 2, dtype=torch.int32, device=dev)
+    if counter is None:
+        counter = torch.empty(1, dtype=torch.int32, device=dev)
+    need = int(L.lib().n2m_march_fused_workspace_bytes(N))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    L.call("n2m_march_rays_train_fused", _p(rays_o), _p(rays_d), _p(bits), float(bound), int(bool(contract)), float(dt_gamma), int(max_steps),
+           N, int(C), int(H), _p(nears), _p(fars), _p(out[0]), _p(out[1]), _p(out[2]), _p(rays), _p(counter), _p(noises), cap,
+           _p(workspace), need, L.stream())
+    return out[0], out[1], out[2], rays, counter
+
+
+@torch.no_grad()
 def march_rays_train_begin(rays_o, rays_d, bound, contract, density_bitfield, C, H, nears, fars, perturb=False, dt_gamma=0,
                            max_steps=1024, noises=None, expect_points=0):
     """Pass 1 (count + offset scan) of march_rays_train, with the sample count on its way to the host; march_rays_train_finish

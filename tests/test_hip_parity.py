@@ -145,6 +145,67 @@ def test_march_rays_train_bit_exact(be, oracle, scene, cfg):
     assert bits_equal(hx, ox) and bits_equal(hd, od) and bits_equal(ht, ot)
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(bound=1.0, contract=False, dt_gamma=0.0, C=1, N=4099),
+    dict(bound=1.0, contract=False, dt_gamma=1 / 256, C=1, N=4096),
+    dict(bound=4.0, contract=False, dt_gamma=1 / 256, C=3, N=3001),
+    dict(bound=4.0, contract=True, dt_gamma=0.0, C=2, N=3000),
+    dict(bound=1.0, contract=False, dt_gamma=0.0, C=1, N=2000, max_steps=64, dense=True),
+    dict(bound=1.0, contract=False, dt_gamma=0.0, C=1, N=70001),           # 274 groups of 256 rays
+    dict(bound=1.0, contract=False, dt_gamma=0.0, C=1, N=1000, empty=True),
+    dict(bound=4.0, contract=False, dt_gamma=0.0, C=3, N=3000, random=0.3),   # > 24 sample-bearing chunks per ray: re-march fallback
+    dict(bound=1.0, contract=False, dt_gamma=0.0, C=1, N=3, ),
+])
+def test_march_single_pass_equals_two_pass_protocol(be, oracle, scene, cfg):
+    """n2m_march_rays_train_fused (one march: count + recorded chunks, then replay) == the oracle's two-pass march: (offset, count) per
+    ray, the sample count and every sample bit for bit; with fewer rows than samples the rays that do not fit are left unwritten."""
+    torch, S = be["torch"], scene["S"]
+    from nerf2mesh_amd import raymarching as R
+    C, H = cfg["C"], 128 if cfg["C"] == 1 else 64
+    rng = np.random.default_rng(5)
+    if cfg.get("dense"):
+        bits = np.full(C * H ** 3 // 8, 255, np.uint8)
+    elif cfg.get("empty"):
+        bits = np.zeros(C * H ** 3 // 8, np.uint8)
+    elif cfg.get("random"):
+        bits = oracle.packbits((rng.random((C, H ** 3)) < cfg["random"]).astype(np.float32) * 50, 10.0)
+    elif C == 1:
+        bits = scene["bits"]
+    else:
+        grid = S.scene_density_grid(H=H, cascade=C, bound=cfg["bound"] if not cfg["contract"] else 2.0).numpy()
+        grid += (rng.random(grid.shape) < 0.02).astype(np.float32) * 50
+        bits = oracle.packbits(grid, 10.0)
+    N, b = cfg["N"], cfg["bound"]
+    o, d = make_rays(scene, N, seed=9)
+    if b > 1:
+        o = o * 1.1
+    nears, fars = oracle.near_far_from_aabb(o, d, np.array([-b, -b, -b, b, b, b], np.float32), 0.05)
+    noises = rng.random(N).astype(np.float32)
+    ms = cfg.get("max_steps", 1024)
+    ox, od, ot, orr = oracle.march_rays_train(o, d, b, cfg["contract"], bits, C, H, nears, fars, noises, cfg["dt_gamma"], ms)
+    M = int(orr[:, 1].sum())
+    a = (dev(be, o), dev(be, d), b, cfg["contract"], dev(be, bits), C, H, dev(be, nears), dev(be, fars), dev(be, noises), cfg["dt_gamma"], ms)
+    for cap in (M + 37, M, max(M // 2 + 5, 0)):
+        buf = torch.full((max(cap, 1) * 8,), -7.0, device="cuda")
+        out = (buf[:3 * cap].view(-1, 3), buf[3 * cap:6 * cap].view(-1, 3), buf[6 * cap:8 * cap].view(-1, 2))
+        x, dd, t, rays, counter = R.march_rays_train_fused(*a, max_points=cap, out=out)
+        assert int(counter.item()) == M
+        assert np.array_equal(rays.cpu().numpy(), orr), "per-ray (offset, count) must match the oracle exactly"
+        if M == 0:
+            continue
+        hx, ht, hd = x.cpu().numpy(), t.cpu().numpy(), dd.cpu().numpy()
+        fits = (orr[:, 0].astype(np.int64) + orr[:, 1]) <= cap
+        if cap >= M:
+            assert fits.all() and bits_equal(hx[:M], ox) and bits_equal(hd[:M], od) and bits_equal(ht[:M], ot)
+        else:
+            keep = np.zeros(cap, bool)
+            for off, cnt in orr[fits & (orr[:, 1] > 0)]:
+                keep[off:off + cnt] = True
+            assert keep.any()
+            assert bits_equal(hx[keep], ox[:cap][keep]) and bits_equal(ht[keep], ot[:cap][keep])
+            assert (hx[~keep] == -7.0).all() and (ht[~keep] == -7.0).all()       # rays that do not fit are not written
+
+
 def test_march_parallel_resolution_falls_back_exactly(be, oracle, scene):
     """Random 30 % occupancy = hundreds of empty->occupied crossings per ray: some exit times round past a candidate of the next,
     occupied voxel, the prefix-maximum check fails and the ray is re-marched serially.  Results stay bit-exact and the fallback is taken."""

@@ -1,5 +1,5 @@
 """Print the kernel timeline of one steady-state training step from a rocprofv3 --kernel-trace CSV (tail without header is fine):
-python tools/step_timeline.py <kernel_trace.csv> [step_index_from_middle]"""
+python tools/step_timeline.py <kernel_trace.csv> [offset from the step at 85 % of the run]"""
 import csv, re, sys
 HDR = ["Kind", "Agent_Id", "Queue_Id", "Stream_Id", "Thread_Id", "Dispatch_Id", "Kernel_Id", "Kernel_Name", "Correlation_Id", "Start_Timestamp",
        "End_Timestamp"]
@@ -12,7 +12,7 @@ for r in csv.reader(open(sys.argv[1])):
 rows.sort()
 short = lambda n: re.sub(r"_ZN12_GLOBAL__N_1\d+", "", re.sub(r"\(anonymous namespace\)::", "", n))[:52]
 adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[3]]
-k = len(adam) // 2 + (int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+k = int(len(adam) * 0.85) + (int(sys.argv[2]) if len(sys.argv) > 2 else 0)      # inside bench.py's timed region (after pre-training and warm-up)
 a, b = adam[k], adam[k + 1]
 t0 = rows[a][1]
 walls = [(rows[adam[i + 1]][1] - rows[adam[i]][1]) / 1e3 for i in range(len(adam) - 1)]
