@@ -200,6 +200,97 @@ __device__ __forceinline__ void load_color_inputs(const FieldArgs& a, uint32_t s
     }
 }
 
+// Software prefetch.  A wave works through its tiles one after the other with one or two waves per SIMD, so nothing hides a global load
+// issued at its point of use: the backward's producer wave had SIX exposed round trips per tile (h1, xyz, d_sigma, h2 + xyz, d_rgb +
+// d_specular, dirs: each its own branch with its own s_waitcnt) -- more than half of its time.  All per-sample inputs of the NEXT tile are
+// therefore requested, raw and unconverted, before the current tile's arithmetic starts, and turned into MFMA fragments one iteration
+// later.  Same loads, same conversions, same values.
+struct RawTile {
+    float h1v[8];        // density features 8kb + 4g + i   (kb = 0, 1)
+    uint32_t h2v[8];     // colour features: levels 4kb + 2g, 4kb + 2g + 1 as half2 bit patterns (kb = 0..3)
+    float xyz[3], dir[3], dsig, drgb[3], dspec[3];      // g = 0 lanes only
+};
+template <bool DO_DENSITY, bool DO_COLOR, bool BWD>
+__device__ __forceinline__ void fetch_tile(const FieldArgs& a, uint32_t tile, int n, int g, RawTile& r) {
+    const uint32_t s = tile * 32 + (uint32_t)n;
+    const size_t Mz = a.M;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { r.h1v[i] = 0.f; r.h2v[i] = 0u; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { r.xyz[i] = 0.f; r.dir[i] = 0.f; r.drgb[i] = 0.f; r.dspec[i] = 0.f; }
+    r.dsig = 0.f;
+    if (s >= a.M) return;
+    if (DO_DENSITY) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r.h1v[4 * kb + i] = a.h1[(size_t)(8 * kb + 4 * g + i) * Mz + s];
+    }
+    if (DO_COLOR) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            r.h2v[2 * kb] = *reinterpret_cast<const uint32_t*>(a.h2 + ((size_t)(4 * kb + 2 * g) * Mz + s) * 2);
+            r.h2v[2 * kb + 1] = *reinterpret_cast<const uint32_t*>(a.h2 + ((size_t)(4 * kb + 2 * g + 1) * Mz + s) * 2);
+        }
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r.xyz[i] = a.xyz[(size_t)s * 3 + i];
+        if (DO_COLOR && a.shading != 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) r.dir[i] = a.dirs[(size_t)s * 3 + i];
+        }
+        if (BWD) {
+            if (DO_DENSITY) r.dsig = a.d_sigma[s];
+            if (DO_COLOR) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) r.drgb[i] = a.d_rgb[(size_t)s * 3 + i];
+                if (a.d_specular && a.shading != 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) r.dspec[i] = a.d_specular[(size_t)s * 3 + i];
+                }
+            }
+        }
+    }
+}
+// "These registers are read here": makes the compiler finish the tile's loads at THIS point (the top of the iteration that consumes them,
+// a whole tile after they were issued) instead of carrying them as pending across the loop edge -- with the in-order vmcnt counter a
+// pending OLD load met in mid-iteration would also wait for the prefetch issued after it.
+__device__ __forceinline__ void settle_tile(RawTile& r) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { asm volatile("" : "+v"(r.h1v[i])); asm volatile("" : "+v"(r.h2v[i])); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { asm volatile("" : "+v"(r.xyz[i])); asm volatile("" : "+v"(r.dir[i])); asm volatile("" : "+v"(r.drgb[i])); asm volatile("" : "+v"(r.dspec[i])); }
+    asm volatile("" : "+v"(r.dsig));
+}
+// fragments from the raw tile: what load_density_inputs / load_color_inputs / load_dir build (lanes without a sample carry zeros)
+__device__ __forceinline__ void density_frags(const RawTile& r, h4 (&b)[3]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[kb][i] = (_Float16)r.h1v[4 * kb + i];
+    b[2] = zero4();
+    b[2][0] = (_Float16)r.xyz[0]; b[2][1] = (_Float16)r.xyz[1]; b[2][2] = (_Float16)r.xyz[2];
+}
+__device__ __forceinline__ void color_frags(const RawTile& r, h4 (&b)[5]) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const u2v_t v = {r.h2v[2 * kb], r.h2v[2 * kb + 1]};
+        b[kb] = __builtin_bit_cast(h4, v);
+    }
+    b[4] = zero4();
+    b[4][0] = (_Float16)r.xyz[0]; b[4][1] = (_Float16)r.xyz[1]; b[4][2] = (_Float16)r.xyz[2];
+}
+template <typename P>
+__device__ __forceinline__ void dir_frag(const FieldArgs& a, const RawTile& r, P& bp) {
+    float d0 = r.dir[0], d1 = r.dir[1], d2 = r.dir[2];
+    if (a.normalize_dirs) {
+        const float nn = sqrtf(fmaxf((d0 * d0 + d1 * d1) + d2 * d2, 1e-20f));
+        d0 /= nn; d1 /= nn; d2 /= nn;
+    }
+    bp[0] = (_Float16)d0; bp[1] = (_Float16)d1; bp[2] = (_Float16)d2;
+}
+
 // ================================================================================================== forward
 template <bool DO_DENSITY, bool DO_COLOR>
 __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
@@ -224,12 +315,17 @@ __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
     const int lane = threadIdx.x & 63, n = lane & 31, g = lane >> 5;
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     const uint32_t n_tiles = (a.M + 31) / 32;
+    RawTile nxt;
+    fetch_tile<DO_DENSITY, DO_COLOR, false>(a, wave, n, g, nxt);
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t s = tile * 32 + n;
         const bool valid = s < a.M;
+        settle_tile(nxt);
+        const RawTile cur = nxt;
+        fetch_tile<DO_DENSITY, DO_COLOR, false>(a, tile + n_waves, n, g, nxt);      // next tile's inputs in flight under this tile's MFMA chains
         if (DO_DENSITY) {   // ---- density: [h1 | xyz] -> 32 -> 1 -> exp
             h4 b0[3];
-            load_density_inputs(a, s, valid, g, b0);
+            density_frags(cur, b0);
             f16x d = zero16();
 #pragma unroll
             for (int kb = 0; kb < 3; ++kb) d = MFMA(ld_a(lds + O_S0, P_S0, 0, kb, lane), b0[kb], d);
@@ -241,7 +337,7 @@ __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
         }
         if (DO_COLOR) {   // ---- colour: [h2 | xyz] -> 64 -> 64 -> 6 -> sigmoid ; specular: [d | feat] -> 32 -> 3 -> sigmoid
             h4 b0[5];
-            load_color_inputs(a, s, valid, g, b0);
+            color_frags(cur, b0);
             f16x d1[2] = {zero16(), zero16()};
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -265,7 +361,7 @@ __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
             if (a.shading != 0) {
                 h4 bp = zero4();                      // K order of specular_net layer 0: d0 d1 d2 f0 | f1 f2 0 0
                 if (g == 0) {
-                    if (valid) load_dir(a, s, bp);
+                    if (valid) dir_frag(a, cur, bp);
                     bp[3] = (_Float16)q3;
                 } else { bp[0] = (_Float16)q0; bp[1] = (_Float16)q1; }   // g = 1: q0,q1 are rows 4,5 = feat1, feat2
                 f16x p1 = MFMA(ld_a(lds + O_P0, P_P0, 0, 0, lane), bp, zero16());
@@ -641,14 +737,19 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int j = 0; j < 2; ++j) { gC0[i][j] = zero16(); gC1[i][j] = zero16(); gC2[0][j] = zero16(); }
 
-    if (producer)
+    if (producer) {
+    RawTile nxt;
+    fetch_tile<DO_DENSITY, DO_COLOR, true>(a, blockIdx.x * 4 + pair, n, g, nxt);
     for (uint32_t base = blockIdx.x * 4; base < n_tiles; base += gridDim.x * 4) {
         const uint32_t tile = base + pair;      // may lie beyond the last tile: all lanes invalid, the stages still run (barriers)
         const uint32_t s = tile * 32 + n;
         const bool valid = s < a.M;
+        settle_tile(nxt);
+        const RawTile cur = nxt;
+        fetch_tile<DO_DENSITY, DO_COLOR, true>(a, tile + gridDim.x * 4, n, g, nxt);   // next tile's inputs: requested now, used one iteration later
         if (DO_DENSITY) {   // --------------------------------------------------------------------------- density net
             h4 b0[3];
-            load_density_inputs(a, s, valid, g, b0);
+            density_frags(cur, b0);
             f16x d = zero16();
 #pragma unroll
             for (int kb = 0; kb < 3; ++kb) d = MFMA(ld_a(lds + O_S0, P_S0, 0, kb, lane), b0[kb], d);
@@ -660,7 +761,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             h4 dy1 = zero4();
             if (valid && g == 0) {
                 const float pre = (float)(_Float16)o[0];
-                dy1[0] = a.raw_density ? (_Float16)a.d_sigma[s] : (_Float16)(a.d_sigma[s] * expf(fminf(fmaxf(pre, -15.f), 15.f)));
+                dy1[0] = a.raw_density ? (_Float16)cur.dsig : (_Float16)(cur.dsig * expf(fminf(fmaxf(pre, -15.f), 15.f)));
             }
             // stage S1: dW1 = dy1^T x H1
 #pragma unroll
@@ -687,7 +788,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
         if (DO_COLOR) {   // ---------------------------------------------------------------------------- colour + specular
             h4 b0[5];
-            load_color_inputs(a, s, valid, g, b0);
+            color_frags(cur, b0);
             f16x d1[2] = {zero16(), zero16()};
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -710,17 +811,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             // upstream gradients (g = 0 lanes own sample s)
             float gr = 0.f, gg = 0.f, gb = 0.f, es0 = 0.f, es1 = 0.f, es2 = 0.f;
             if (valid && g == 0) {
-                gr = a.d_rgb[(size_t)s * 3]; gg = a.d_rgb[(size_t)s * 3 + 1]; gb = a.d_rgb[(size_t)s * 3 + 2];
-                if (a.d_specular && a.shading != 0) {
-                    es0 = a.d_specular[(size_t)s * 3]; es1 = a.d_specular[(size_t)s * 3 + 1]; es2 = a.d_specular[(size_t)s * 3 + 2];
-                }
+                gr = cur.drgb[0]; gg = cur.drgb[1]; gb = cur.drgb[2];
+                es0 = cur.dspec[0]; es1 = cur.dspec[1]; es2 = cur.dspec[2];       // zeros without d_specular / with diffuse shading
             }
             float dq0 = 0.f, dq1 = 0.f, dq2 = 0.f, dq3 = 0.f;   // d geo rows 0..3 (g = 0) / rows 4,5 in dq0,dq1 (g = 1)
             if (a.shading == 0) { dq0 = gr; dq1 = gg; dq2 = gb; }
             else {
                 h4 bp = zero4();
                 if (g == 0) {
-                    if (valid) load_dir(a, s, bp);
+                    if (valid) dir_frag(a, cur, bp);
                     bp[3] = (_Float16)q3;
                 } else { bp[0] = (_Float16)q0; bp[1] = (_Float16)q1; }
                 const f16x p1 = MFMA(ld_a(lds + O_P0, P_P0, 0, 0, lane), bp, zero16());
@@ -810,7 +909,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
     }
-
+    }
     else
     for (uint32_t base = blockIdx.x * 4; base < n_tiles; base += gridDim.x * 4) {
         // consumer: one barrier per stage (the pair's producer has filled buffer st & 1 by then), then the sample contraction
