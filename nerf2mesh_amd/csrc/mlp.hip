@@ -19,6 +19,9 @@
 // Numerics = autocast: operands fp16, fp32 accumulate, layer outputs rounded to fp16; exp (trunc_exp) in fp32.
 // Input feature order inside the kernel is [encoder features | xyz | 0-pad] (the weight columns are permuted while
 // staging), so the encoder rows load as aligned 8-byte chunks.
+#include <map>
+#include <mutex>
+
 #include "n2m_common.hpp"
 #include "../../include/n2m_mlp.h"
 
@@ -52,7 +55,8 @@ constexpr int ALL_W_HALVES = O_P0T + 32 * P_P0T;
 constexpr int TILE_PITCH = 68;                                   // per-wave transpose tiles [32 samples][64 + 4]
 constexpr int TILE_HALVES = 32 * TILE_PITCH;
 constexpr int BWD_HALVES = ALL_W_HALVES + 4 * 2 * TILE_HALVES;   // 4 waves x (X tile + dY tile)
-constexpr int BWD_PC_HALVES = ALL_W_HALVES + 4 * 4 * TILE_HALVES; // producer/consumer form: 4 pairs x 2 buffers x (X tile + dY tile)
+constexpr int BWD_PC_TILES_HALVES = ALL_W_HALVES + 4 * 4 * TILE_HALVES; // producer/consumer form: 4 pairs x 2 buffers x (X tile + dY tile)
+constexpr int BWD_PC_HALVES = BWD_PC_TILES_HALVES > 65536 ? BWD_PC_TILES_HALVES : 65536;    // >= 128 KB: the epilogue's 4 x 2 x (64 x 64) fp32 copies
 
 // logical input feature k -> column of the nn.Linear weight (or -1 for padding)
 __device__ __forceinline__ int col_color0(int k) { return k < 32 ? 3 + k : (k < 35 ? k - 32 : -1); }
@@ -81,8 +85,98 @@ __device__ void stage_wt(_Float16* dst, int pitch, const float* __restrict__ W, 
     }
 }
 
+struct FieldArgs {
+    const float* xyz; const float* dirs; const float* h1; const _Float16* h2;
+    const float* w[7];       // sigma0, sigma1, color0, color1, color2, spec0, spec1
+    uint32_t M; int shading; int normalize_dirs;
+    int raw_density;         // SDF head: sigma = the fp16 Linear output as it is (nerf/network.py:100-101), no trunc_exp
+    float* sigma; float* rgb; float* specular;
+    // backward only
+    const float* d_sigma; const float* d_rgb; const float* d_specular;
+    float* d_h1; _Float16* d_h2; float* dw[7];
+    float* found_inf;        // set to 1 when a weight gradient is not finite (GradScaler's check), may be NULL
+    int dbg;                 // measurement switches (N2M_FIELD_DEBUG): 1 skip the tile loop, 2 skip the dW reduction
+    float* dw_partial;       // [gridDim.x][kDwTotal]: per-workgroup weight-gradient sums, reduced by dw_finalize_kernel
+};
+
+// Staging, fast form.  stage_w / stage_wt above walk the PADDED image and fetch one weight per iteration (integer division, a
+// dependent global load, a 2-byte LDS store: ~46 serial round trips per thread, 8-20 us of every launch).  Here every thread first
+// requests its share of the 7 648 real weights (coalesced, all loads in flight at once), the image area is cleared with 16-byte
+// stores, and each weight is then written to its place in the forward image and -- backward kernels -- the transposed image.
+template <int PERM>
+__device__ __forceinline__ int logical_k(int c) {      // inverse of col_of: weight column -> logical input feature
+    return PERM == PERM_COLOR0 ? (c < 3 ? 32 + c : c - 3) : PERM == PERM_SIGMA0 ? (c < 3 ? 16 + c : c - 3) : c;
+}
+template <int NT, int OUT, int IN>
+struct WRegs { float v[(OUT * IN + NT - 1) / NT]; };
+template <int NT, int OUT, int IN>
+__device__ __forceinline__ void w_fetch(WRegs<NT, OUT, IN>& r, const float* __restrict__ W) {
+#pragma unroll
+    for (int i = 0; i < (OUT * IN + NT - 1) / NT; ++i) {
+        const int e = (int)threadIdx.x + i * NT;
+        r.v[i] = e < OUT * IN ? W[e] : 0.f;
+    }
+}
+template <int NT, int OUT, int IN, int PERM, bool TR>
+__device__ __forceinline__ void w_place(const WRegs<NT, OUT, IN>& r, _Float16* fwd, int pitch, _Float16* tr, int pitch_t) {
+#pragma unroll
+    for (int i = 0; i < (OUT * IN + NT - 1) / NT; ++i) {
+        const int e = (int)threadIdx.x + i * NT;
+        if (e < OUT * IN) {
+            const int m = e / IN, k = logical_k<PERM>(e - m * IN);
+            const _Float16 h = (_Float16)r.v[i];
+            fwd[m * pitch + k] = h;
+            if (TR) tr[k * pitch_t + m] = h;
+        }
+    }
+}
+template <int NT, bool TR, bool DO_DENSITY, bool DO_COLOR>
+__device__ __forceinline__ void stage_images(_Float16* lds, const FieldArgs& a) {
+    WRegs<NT, 32, 19> s0; WRegs<NT, 1, 32> s1; WRegs<NT, 64, 35> c0; WRegs<NT, 64, 64> c1; WRegs<NT, 6, 64> c2; WRegs<NT, 32, 6> p0; WRegs<NT, 3, 32> p1;
+    const bool spec = DO_COLOR && a.shading != 0;
+    if (DO_DENSITY) { w_fetch(s0, a.w[0]); w_fetch(s1, a.w[1]); }
+    if (DO_COLOR) { w_fetch(c0, a.w[2]); w_fetch(c1, a.w[3]); w_fetch(c2, a.w[4]); }
+    if (spec) { w_fetch(p0, a.w[5]); w_fetch(p1, a.w[6]); }
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = threadIdx.x; i < (TR ? ALL_W_HALVES : FWD_HALVES) / 8; i += NT) reinterpret_cast<uint4*>(lds)[i] = z;
+    __syncthreads();
+    if (DO_DENSITY) {
+        w_place<NT, 32, 19, PERM_SIGMA0, TR>(s0, lds + O_S0, P_S0, lds + O_S0T, P_S0T);
+        w_place<NT, 1, 32, PERM_PLAIN, TR>(s1, lds + O_S1, P_S1, lds + O_S1T, P_S1T);
+    }
+    if (DO_COLOR) {
+        w_place<NT, 64, 35, PERM_COLOR0, TR>(c0, lds + O_C0, P_C0, lds + O_C0T, P_C0T);
+        w_place<NT, 64, 64, PERM_PLAIN, TR>(c1, lds + O_C1, P_C1, lds + O_C1T, P_C1T);
+        w_place<NT, 6, 64, PERM_PLAIN, TR>(c2, lds + O_C2, P_C2, lds + O_C2T, P_C2T);
+    }
+    if (spec) {
+        w_place<NT, 32, 6, PERM_PLAIN, TR>(p0, lds + O_P0, P_P0, lds + O_P0T, P_P0T);
+        w_place<NT, 3, 32, PERM_PLAIN, TR>(p1, lds + O_P1, P_P1, lds + O_P1T, P_P1T);
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ h4 ld_a(const _Float16* W, int pitch, int mb, int kb, int lane) {
     return *reinterpret_cast<const h4*>(W + (32 * mb + (lane & 31)) * pitch + 8 * kb + 4 * (lane >> 5));
+}
+
+// All A fragments (weights) of a layer into registers, and the layer's MFMAs with the M blocks interleaved.  Written apart because
+// the compiler otherwise re-reads ONE register pair per two MFMAs (ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs -> ds_read into the same
+// pair ...: the full LDS latency exposed forty times per tile) and runs each accumulator's K loop as one dependent chain (64-cycle
+// result latency against a 32-cycle issue).  The loads of layer L+1 are issued before the MFMAs of layer L.
+template <int MB, int KB>
+__device__ __forceinline__ void ld_layer(h4 (&w)[MB][KB], const _Float16* W, int pitch, int lane) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) w[mb][kb] = ld_a(W, pitch, mb, kb, lane);
+}
+template <int MB, int KB>
+__device__ __forceinline__ void mm_layer(f16x (&d)[MB], const h4 (&w)[MB][KB], const h4 (&b)[KB]) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) d[mb] = MFMA(w[mb][kb], b[kb], d[mb]);
 }
 
 __device__ __forceinline__ h4 zero4() { h4 z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0}; return z; }
@@ -139,17 +233,6 @@ __device__ __forceinline__ float sigmoid_h(float pre_acc) {
     return (float)(_Float16)(1.0f / (1.0f + expf(-x)));
 }
 
-struct FieldArgs {
-    const float* xyz; const float* dirs; const float* h1; const _Float16* h2;
-    const float* w[7];       // sigma0, sigma1, color0, color1, color2, spec0, spec1
-    uint32_t M; int shading; int normalize_dirs;
-    int raw_density;         // SDF head: sigma = the fp16 Linear output as it is (nerf/network.py:100-101), no trunc_exp
-    float* sigma; float* rgb; float* specular;
-    // backward only
-    const float* d_sigma; const float* d_rgb; const float* d_specular;
-    float* d_h1; _Float16* d_h2; float* dw[7];
-    float* found_inf;        // set to 1 when a weight gradient is not finite (GradScaler's check), may be NULL
-};
 
 // View direction of sample s as fp16 MLP operands.  normalize_dirs: the march kernel hands out the raw ray direction
 // (raymarching.cu:466-468) and the reference normalises it per sample in torch (safe_normalize, nerf/renderer.py:704,
@@ -297,20 +380,7 @@ __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
     // These kernels run beside the next batch's marcher (second stream): their waves win the SIMD's issue arbitration
     __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-    if (DO_DENSITY) {
-        stage_w(lds + O_S0, P_S0, a.w[0], 32, 19, 32, 24, PERM_SIGMA0);
-        stage_w(lds + O_S1, P_S1, a.w[1], 1, 32, 32, 32, PERM_PLAIN);
-    }
-    if (DO_COLOR) {
-        stage_w(lds + O_C0, P_C0, a.w[2], 64, 35, 64, 40, PERM_COLOR0);
-        stage_w(lds + O_C1, P_C1, a.w[3], 64, 64, 64, 64, PERM_PLAIN);
-        stage_w(lds + O_C2, P_C2, a.w[4], 6, 64, 32, 64, PERM_PLAIN);
-        if (a.shading != 0) {
-            stage_w(lds + O_P0, P_P0, a.w[5], 32, 6, 32, 8, PERM_PLAIN);
-            stage_w(lds + O_P1, P_P1, a.w[6], 3, 32, 32, 32, PERM_PLAIN);
-        }
-    }
-    __syncthreads();
+    stage_images<256, false, DO_DENSITY, DO_COLOR>(lds, a);
 
     const int lane = threadIdx.x & 63, n = lane & 31, g = lane >> 5;
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
@@ -399,9 +469,36 @@ __device__ __forceinline__ h4 tile_get(const _Float16* tile, int kq, int fb, int
     r[0] = p[0]; r[1] = p[TILE_PITCH]; r[2] = p[2 * TILE_PITCH]; r[3] = p[3 * TILE_PITCH];
     return r;
 }
+// The same operand with ONE gfx950 transpose read instead of four 2-byte reads: the 16 lanes of a group (fixed lane/32 and feature
+// half) hand ds_read_b64_tr_b16 the addresses of the 4-half pieces of a [4 samples][16 features] block (lane i: sample i/4, features
+// 4(i%4)..+3; the row stride is free) and get the block back column-major -- lane c holds feature c of the four samples (tools/tr_lab.hip
+// checks the mapping against tile_get element by element).
+typedef short s4v_t __attribute__((__vector_size__(8)));
+__device__ __forceinline__ h4 tile_get_tr(const _Float16* tile, int kq, int fb, int lane) {
+    const _Float16* p = tile + (8 * kq + 4 * (lane >> 5) + ((lane & 15) >> 2)) * TILE_PITCH + 32 * fb + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    return __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v_t*)p));
+}
 // acc[mb][nb] += dY^T (features 32mb..) x X (features 32nb..) over the 32 samples of the tile
-template <int MB, int NB>
+template <int MB, int NB, bool TR = false>
 __device__ __forceinline__ void dw_tile(f16x (&acc)[MB][NB], const _Float16* tY, const _Float16* tX, int lane) {
+    if constexpr (TR) {
+        // all operands of the stage first (4 x (MB + NB) transpose reads, issued back to back), then the MFMAs
+        h4 ay[4][MB], bx[4][NB];
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) ay[kq][mb] = tile_get_tr(tY, kq, mb, lane);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bx[kq][nb] = tile_get_tr(tX, kq, nb, lane);
+        }
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = MFMA(ay[kq][mb], bx[kq][nb], acc[mb][nb]);
+        return;
+    }
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {
         h4 ay[MB], bx[NB];
@@ -438,6 +535,70 @@ __device__ void dw_flush(float* __restrict__ dW, const float* stage, int in_pad,
         const float v = stage[m * in_pad + k];
         if (c >= 0 && v != 0.f) {
             unsafeAtomicAdd(dW + m * in + c, v);
+            if (!(fabsf(v) <= 3.0e38f) && found_inf) *found_inf = 1.0f;
+        }
+    }
+}
+
+// Second stage of the weight-gradient reduction.  Every workgroup used to add its 7 648 sums onto dW with global float atomics:
+// 256 workgroups x 7 648 = 2 M atomics onto the same 240 cache lines, 64 us -- HALF the backward kernel (N2M_FIELD_DEBUG ablation).
+// Now a workgroup stores its sums as one row of a [workgroups][7 648] scratch (plain coalesced stores) and this kernel adds the rows
+// up in a fixed order (sixteen interleaved slices per element, then slice 0..15): ~2 M L2-resident loads, no atomics, and the result no
+// longer depends on the order in which workgroups finish.
+constexpr int kDwOff[8] = {0, 608, 640, 2880, 6976, 7360, 7552, 7648};      // sigma0 sigma1 color0 color1 color2 spec0 spec1
+constexpr int kDwTotal = 7648;
+struct DwOut { float* dw[7]; };
+// accumulator tile of ONE consumer wave -> its own LDS copy (plain stores: four waves adding into one copy with ds_add_f32 measured
+// 62 us per launch for 224 instructions per lane -- the LDS float atomic is that slow), then the four copies are summed in wave order
+template <int MB, int NB>
+__device__ __forceinline__ void dw_to_copy(float* copy, int in_pad, const f16x (&acc)[MB][NB], int lane) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * mb + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), col = 32 * nb + (lane & 31);
+                copy[row * in_pad + col] = acc[mb][nb][r];
+            }
+}
+__device__ void dw_store_partial(float* __restrict__ part, const float* stage, int copy_stride, int in_pad, int out, int in, int k_real, int perm) {
+    for (int idx = threadIdx.x; idx < out * k_real; idx += blockDim.x) {
+        const int m = idx / k_real, k = idx - m * k_real;
+        const int c = col_of(perm, k, in);
+        const float* p = stage + m * in_pad + k;
+        if (c >= 0) part[m * in + c] = ((p[0] + p[copy_stride]) + p[2 * copy_stride]) + p[3 * copy_stride];
+    }
+}
+__global__ void __launch_bounds__(1024) dw_finalize_kernel(const float* __restrict__ part, uint32_t n_rows, DwOut o, uint32_t mask, float* found_inf) {
+    __shared__ float sm[16][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    int mat = 0;
+#pragma unroll
+    for (int i = 1; i < 7; ++i) mat += e >= kDwOff[i] ? 1 : 0;
+    const bool live = e < kDwTotal && ((mask >> mat) & 1u);
+    float acc = 0.f;
+    if (live) {
+        // rows slice, slice + 16, ...: <= 16 per thread for 256 workgroups, all loads of a thread in flight together
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t w = (uint32_t)slice + 16u * i;
+            v[i] = w < n_rows ? part[(size_t)w * kDwTotal + e] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += v[i];
+        for (uint32_t w = (uint32_t)slice + 256u; w < n_rows; w += 16u) acc += part[(size_t)w * kDwTotal + e];     // larger grids (not used today)
+    }
+    sm[slice][lane] = acc;
+    __syncthreads();
+    if (slice == 0 && live) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += sm[i][lane];
+        if (v != 0.f) {
+            o.dw[mat][e - kDwOff[mat]] += v;
             if (!(fabsf(v) <= 3.0e38f) && found_inf) *found_inf = 1.0f;
         }
     }
@@ -696,27 +857,7 @@ template <bool DO_DENSITY, bool DO_COLOR>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) field_backward_pc_kernel(FieldArgs a) {
     __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-    if (DO_DENSITY) {
-        stage_w(lds + O_S0, P_S0, a.w[0], 32, 19, 32, 24, PERM_SIGMA0);
-        stage_w(lds + O_S1, P_S1, a.w[1], 1, 32, 32, 32, PERM_PLAIN);
-        stage_wt(lds + O_S1T, P_S1T, a.w[1], 1, 32, 32, 8, PERM_PLAIN);
-        stage_wt(lds + O_S0T, P_S0T, a.w[0], 32, 19, 32, 32, PERM_SIGMA0);
-    }
-    if (DO_COLOR) {
-        stage_w(lds + O_C0, P_C0, a.w[2], 64, 35, 64, 40, PERM_COLOR0);
-        stage_w(lds + O_C1, P_C1, a.w[3], 64, 64, 64, 64, PERM_PLAIN);
-        stage_w(lds + O_C2, P_C2, a.w[4], 6, 64, 32, 64, PERM_PLAIN);
-        stage_wt(lds + O_C2T, P_C2T, a.w[4], 6, 64, 64, 8, PERM_PLAIN);
-        stage_wt(lds + O_C1T, P_C1T, a.w[3], 64, 64, 64, 64, PERM_PLAIN);
-        stage_wt(lds + O_C0T, P_C0T, a.w[2], 64, 35, 64, 64, PERM_COLOR0);
-        if (a.shading != 0) {
-            stage_w(lds + O_P0, P_P0, a.w[5], 32, 6, 32, 8, PERM_PLAIN);
-            stage_w(lds + O_P1, P_P1, a.w[6], 3, 32, 32, 32, PERM_PLAIN);
-            stage_wt(lds + O_P1T, P_P1T, a.w[6], 3, 32, 32, 8, PERM_PLAIN);
-            stage_wt(lds + O_P0T, P_P0T, a.w[5], 32, 6, 32, 32, PERM_PLAIN);
-        }
-    }
-    __syncthreads();
+    stage_images<512, true, DO_DENSITY, DO_COLOR>(lds, a);
 
     const int lane = threadIdx.x & 63, n = lane & 31, g = lane >> 5, wid = threadIdx.x >> 6;
     const int pair = wid & 3;
@@ -725,7 +866,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     _Float16* const tbase = lds + ALL_W_HALVES + pair * 4 * TILE_HALVES;
     auto TX = [&](uint32_t st) { return tbase + (st & 1u) * 2 * TILE_HALVES; };
     auto TY = [&](uint32_t st) { return tbase + (st & 1u) * 2 * TILE_HALVES + TILE_HALVES; };
-    const uint32_t n_tiles = (a.M + 31) / 32;
+    const uint32_t n_tiles = (a.dbg & 1) ? 0u : (a.M + 31) / 32;
     const size_t Mz = a.M;
     uint32_t st = 0;                 // running stage counter, identical in both waves of a pair
 
@@ -788,24 +929,24 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
         if (DO_COLOR) {   // ---------------------------------------------------------------------------- colour + specular
             h4 b0[5];
+            h4 wC0[2][5], wC1[2][8], wC2[1][8];
+            ld_layer(wC0, lds + O_C0, P_C0, lane);
             color_frags(cur, b0);
+            ld_layer(wC1, lds + O_C1, P_C1, lane);
+            __builtin_amdgcn_sched_barrier(0);                       // keep the reads above the MFMAs they are meant to hide behind
             f16x d1[2] = {zero16(), zero16()};
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int kb = 0; kb < 5; ++kb) d1[mb] = MFMA(ld_a(lds + O_C0, P_C0, mb, kb, lane), b0[kb], d1[mb]);
+            mm_layer(d1, wC0, b0);
+            ld_layer(wC2, lds + O_C2, P_C2, lane);
+            __builtin_amdgcn_sched_barrier(0);
             const h4 b1[8] = {relu_pack<0>(d1[0]), relu_pack<1>(d1[0]), relu_pack<2>(d1[0]), relu_pack<3>(d1[0]),
                               relu_pack<0>(d1[1]), relu_pack<1>(d1[1]), relu_pack<2>(d1[1]), relu_pack<3>(d1[1])};
             f16x d2[2] = {zero16(), zero16()};
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int kb = 0; kb < 8; ++kb) d2[mb] = MFMA(ld_a(lds + O_C1, P_C1, mb, kb, lane), b1[kb], d2[mb]);
+            mm_layer(d2, wC1, b1);
             const h4 b2[8] = {relu_pack<0>(d2[0]), relu_pack<1>(d2[0]), relu_pack<2>(d2[0]), relu_pack<3>(d2[0]),
                               relu_pack<0>(d2[1]), relu_pack<1>(d2[1]), relu_pack<2>(d2[1]), relu_pack<3>(d2[1])};
-            f16x d3 = zero16();
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) d3 = MFMA(ld_a(lds + O_C2, P_C2, 0, kb, lane), b2[kb], d3);
+            f16x d3v[1] = {zero16()};
+            mm_layer(d3v, wC2, b2);
+            const f16x d3 = d3v[0];
             const float q0 = sigmoid_h(d3[0]), q1 = sigmoid_h(d3[1]), q2 = sigmoid_h(d3[2]), q3 = sigmoid_h(d3[3]);
 
             // upstream gradients (g = 0 lanes own sample s)
@@ -872,6 +1013,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) tile_put(TY(st), kb, kb == 0 ? dc : zero4(), lane);
             __syncthreads(); ++st;
+            h4 wC1T[2][8];
+            ld_layer(wC1T, lds + O_C1T, P_C1T, lane);                 // next layer's operands: in flight under this one
+            __builtin_amdgcn_sched_barrier(0);
             f16x e2[2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) e2[mb] = MFMA(ld_a(lds + O_C2T, P_C2T, mb, 0, lane), dc, zero16());
@@ -882,11 +1026,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) { tile_put(TX(st), kb, b1[kb], lane); tile_put(TY(st), kb, dy2[kb], lane); }
             __syncthreads(); ++st;
+            h4 wC0T[1][8];
+            ld_layer(wC0T, lds + O_C0T, P_C0T, lane);
+            __builtin_amdgcn_sched_barrier(0);
             f16x e1[2] = {zero16(), zero16()};
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int kb = 0; kb < 8; ++kb) e1[mb] = MFMA(ld_a(lds + O_C1T, P_C1T, mb, kb, lane), dy2[kb], e1[mb]);
+            mm_layer(e1, wC1T, dy2);
             const h4 dy1[8] = {mask_pack<0>(e1[0], b1[0]), mask_pack<1>(e1[0], b1[1]), mask_pack<2>(e1[0], b1[2]), mask_pack<3>(e1[0], b1[3]),
                                mask_pack<0>(e1[1], b1[4]), mask_pack<1>(e1[1], b1[5]), mask_pack<2>(e1[1], b1[6]), mask_pack<3>(e1[1], b1[7])};
             // layer 1: dW = dy1^T x X0 ; d h2 = rows 0..31 of W1^T dy1
@@ -894,9 +1038,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) { tile_put(TY(st), kb, dy1[kb], lane); tile_put(TX(st), kb, kb < 5 ? b0[kb] : zero4(), lane); }
             __syncthreads(); ++st;
-            f16x e0 = zero16();
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) e0 = MFMA(ld_a(lds + O_C0T, P_C0T, 0, kb, lane), dy1[kb], e0);
+            f16x e0v[1] = {zero16()};
+            mm_layer(e0v, wC0T, dy1);
+            const f16x e0 = e0v[0];
             if (valid) {   // rows (2l, 2l+1) = level l of the C=2 encoder -> [16][M][2] fp16
                 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -914,44 +1058,51 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (uint32_t base = blockIdx.x * 4; base < n_tiles; base += gridDim.x * 4) {
         // consumer: one barrier per stage (the pair's producer has filled buffer st & 1 by then), then the sample contraction
         if (DO_DENSITY) {
-            __syncthreads(); dw_tile<1, 1>(gS1, TY(st), TX(st), lane); ++st;
-            __syncthreads(); dw_tile<1, 1>(gS0, TY(st), TX(st), lane); ++st;
+            __syncthreads(); dw_tile<1, 1, true>(gS1, TY(st), TX(st), lane); ++st;
+            __syncthreads(); dw_tile<1, 1, true>(gS0, TY(st), TX(st), lane); ++st;
         }
         if (DO_COLOR) {
             if (a.shading != 0) {
-                __syncthreads(); dw_tile<1, 1>(gP1, TY(st), TX(st), lane); ++st;
-                __syncthreads(); dw_tile<1, 1>(gP0, TY(st), TX(st), lane); ++st;
+                __syncthreads(); dw_tile<1, 1, true>(gP1, TY(st), TX(st), lane); ++st;
+                __syncthreads(); dw_tile<1, 1, true>(gP0, TY(st), TX(st), lane); ++st;
             }
-            __syncthreads(); dw_tile<1, 2>(gC2, TY(st), TX(st), lane); ++st;
-            __syncthreads(); dw_tile<2, 2>(gC1, TY(st), TX(st), lane); ++st;
-            __syncthreads(); dw_tile<2, 2>(gC0, TY(st), TX(st), lane); ++st;
+            __syncthreads(); dw_tile<1, 2, true>(gC2, TY(st), TX(st), lane); ++st;
+            __syncthreads(); dw_tile<2, 2, true>(gC1, TY(st), TX(st), lane); ++st;
+            __syncthreads(); dw_tile<2, 2, true>(gC0, TY(st), TX(st), lane); ++st;
         }
     }
 
     // ---------------------------------------------------------------------------- reduce dW: registers -> LDS -> HBM
     __syncthreads();
     float* stage = reinterpret_cast<float*>(lds);        // weights are dead now; 64 x 64 floats fit in the weight area
-    auto reduce = [&](auto& acc, int out_pad, int in_pad, float* dW, int out, int in, int k_real, int perm) {
-        for (int i = threadIdx.x; i < out_pad * in_pad; i += blockDim.x) stage[i] = 0.f;
-        __syncthreads();
-        if (!producer) dw_to_lds(stage, in_pad, acc, lane);
-        __syncthreads();
-        dw_flush(dW, stage, in_pad, out, in, k_real, perm, a.found_inf);
-        __syncthreads();
+    float* const part_row = a.dw_partial + (size_t)blockIdx.x * kDwTotal;
+    if (a.dbg & 2) return;
+    // every consumer wave leaves its tiles in its own LDS copy (plain stores), the workgroup sums the four copies in wave order and
+    // stores the row.  Two rounds: the two 64 x 64 layers (4 x 2 x 16 KB = 128 KB of the dead LDS), then the five small ones (96 KB).
+    auto put = [&](auto& acc, int base, int out_pad, int in_pad, int total) {           // total: floats of one wave's copy in this round
+        if (!producer) dw_to_copy(stage + pair * total + base, in_pad, acc, lane);
     };
-    if (DO_DENSITY) {
-        reduce(gS1, 32, 32, a.dw[1], 1, 32, 32, PERM_PLAIN);
-        reduce(gS0, 32, 32, a.dw[0], 32, 19, 19, PERM_SIGMA0);
-    }
+    auto sum = [&](int base, int total, int in_pad, int mat, int out, int in, int k_real, int perm) {
+        dw_store_partial(part_row + kDwOff[mat], stage + base, total, in_pad, out, in, k_real, perm);
+    };
     if (DO_COLOR) {
-        reduce(gC2, 32, 64, a.dw[4], 6, 64, 64, PERM_PLAIN);
-        reduce(gC1, 64, 64, a.dw[3], 64, 64, 64, PERM_PLAIN);
-        reduce(gC0, 64, 64, a.dw[2], 64, 35, 35, PERM_COLOR0);
-        if (a.shading != 0) {
-            reduce(gP1, 32, 32, a.dw[6], 3, 32, 32, PERM_PLAIN);
-            reduce(gP0, 32, 32, a.dw[5], 32, 6, 6, PERM_PLAIN);
-        }
+        put(gC1, 0, 64, 64, 8192); put(gC0, 4096, 64, 64, 8192);
+        __syncthreads();
+        sum(0, 8192, 64, 3, 64, 64, 64, PERM_PLAIN); sum(4096, 8192, 64, 2, 64, 35, 35, PERM_COLOR0);
+        __syncthreads();
     }
+    constexpr int kSmall = 6144;       // C2 32x64 | S1 | S0 | P1 | P0 (32x32 each)
+    if (DO_COLOR) {
+        put(gC2, 0, 32, 64, kSmall);
+        if (a.shading != 0) { put(gP1, 4096, 32, 32, kSmall); put(gP0, 5120, 32, 32, kSmall); }
+    }
+    if (DO_DENSITY) { put(gS1, 2048, 32, 32, kSmall); put(gS0, 3072, 32, 32, kSmall); }
+    __syncthreads();
+    if (DO_COLOR) {
+        sum(0, kSmall, 64, 4, 6, 64, 64, PERM_PLAIN);
+        if (a.shading != 0) { sum(4096, kSmall, 32, 6, 3, 32, 32, PERM_PLAIN); sum(5120, kSmall, 32, 5, 32, 6, 6, PERM_PLAIN); }
+    }
+    if (DO_DENSITY) { sum(2048, kSmall, 32, 1, 1, 32, 32, PERM_PLAIN); sum(3072, kSmall, 32, 0, 32, 19, 19, PERM_SIGMA0); }
 }
 
 int check_field(const char* fn, const float* xyz, const float* h1, const float* const* w, bool density, int shading) {
@@ -959,6 +1110,19 @@ int check_field(const char* fn, const float* xyz, const float* h1, const float* 
     N2M_REQUIRE(xyz, N2M_ENULL, "%s: xyz is NULL", fn);
     if (density) N2M_REQUIRE(h1 && w[0] && w[1], N2M_ENULL, "%s: density branch needs h1 and sigma_net weights", fn);
     return 0;
+}
+
+// [256][7 648] floats per stream that ever ran a backward (calls on one stream are ordered, so they can share it); never freed
+float* dw_scratch(hipStream_t s) {
+    static std::mutex mu;
+    static std::map<hipStream_t, float*> bufs;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = bufs.find(s);
+    if (it != bufs.end()) return it->second;
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, (size_t)256 * kDwTotal * sizeof(float)) != hipSuccess) return nullptr;
+    bufs[s] = p;
+    return p;
 }
 
 uint32_t persistent_grid(uint32_t M) {
@@ -1030,14 +1194,25 @@ extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const flo
     for (int i = 0; i < 7; ++i) { a.w[i] = w[i]; a.dw[i] = dw[i]; }
     a.M = M; a.shading = shading;
     a.d_sigma = d_sigma; a.d_rgb = d_rgb; a.d_specular = d_specular; a.d_h1 = d_h1; a.d_h2 = (_Float16*)d_h2; a.found_inf = found_inf;
+    static const int dbg = getenv("N2M_FIELD_DEBUG") ? atoi(getenv("N2M_FIELD_DEBUG")) : 0;
+    a.dbg = dbg;
     hipStream_t s = (hipStream_t)stream;
     N2M_PROF(N2M_K_MLP_BWD, s, (double)M * (12 + 64 + 4 + 64 + (color ? 64 + 12 + 24 + 64 : 0)));
     static const bool single_wave = getenv("N2M_FIELD_BWD_SINGLE") != nullptr;     // A/B switch: the one-wave-per-SIMD kernel
     if (!single_wave) {
         const size_t smem = (size_t)BWD_PC_HALVES * 2;
-        if (color && density) field_backward_pc_kernel<true, true><<<persistent_grid(M), 512, smem, s>>>(a);
-        else if (color) field_backward_pc_kernel<false, true><<<persistent_grid(M), 512, smem, s>>>(a);
-        else field_backward_pc_kernel<true, false><<<persistent_grid(M), 512, smem, s>>>(a);
+        const uint32_t grid = persistent_grid(M);
+        float* part = dw_scratch(s);
+        N2M_REQUIRE(part != nullptr, (int)hipErrorOutOfMemory, "field_backward: no memory for the weight-gradient scratch");
+        a.dw_partial = part;
+        if (color && density) field_backward_pc_kernel<true, true><<<grid, 512, smem, s>>>(a);
+        else if (color) field_backward_pc_kernel<false, true><<<grid, 512, smem, s>>>(a);
+        else field_backward_pc_kernel<true, false><<<grid, 512, smem, s>>>(a);
+        N2M_CHECK_LAUNCH();
+        DwOut o;
+        for (int i = 0; i < 7; ++i) o.dw[i] = dw[i];
+        const uint32_t mask = (density ? 0x03u : 0u) | (color ? 0x1Cu : 0u) | (color && shading != 0 ? 0x60u : 0u);
+        if (!(dbg & 2)) dw_finalize_kernel<<<(kDwTotal + 63) / 64, 1024, 0, s>>>(part, grid, o, mask, found_inf);
         N2M_CHECK_LAUNCH();
         return 0;
     }

@@ -7,7 +7,7 @@ from nerf2mesh_amd.network import NeRFNetwork
 from nerf2mesh_amd.options import make_options
 torch.manual_seed(0)
 net = NeRFNetwork(make_options(O=True, bound=1, dt_gamma=0, fused_mlp=True)).cuda()
-M = 2 ** 18
+M = int(os.environ.get('M', 2 ** 18))
 x = torch.rand(M, 3, device="cuda") * 1.9 - 0.95
 d = torch.randn(M, 3, device="cuda")
 for shading in ("diffuse", "full"):
@@ -23,4 +23,4 @@ for shading in ("diffuse", "full"):
         (s.sum() + c.sum()).backward()
     torch.cuda.synchronize(); L.prof_enable(0)
     nf, msf, _ = L.prof_read("mlp_forward"); nb, msb, _ = L.prof_read("mlp_backward")
-    print(f"{shading:8s} forward {1e3*msf/nf:7.1f} us  backward {1e3*msb/nb:7.1f} us   lib={os.environ.get('N2M_HIP_LIB','default')[-28:]}")
+    print(f"M={M} {shading:8s} forward {1e3*msf/nf:7.1f} us  backward {1e3*msb/nb:7.1f} us   lib={os.environ.get('N2M_HIP_LIB','default')[-28:]}")
