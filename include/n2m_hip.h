@@ -108,6 +108,10 @@ int n2m_march_rays_train_fused(const float* rays_o, const float* rays_d, const u
                                int32_t* rays, int32_t* counter, const float* noises, uint32_t max_points,
                                void* workspace, uint64_t workspace_bytes, void* stream);
 
+/* Measurement aid for the shared fill of n2m_grid_encode_backward_binned_pair: on != 0 arms shader-clock stamps in one of its workgroups
+ * (first 8 tile iterations x 6 phase boundaries); out (may be NULL) receives the stamps of the last armed launch.  Synchronises. */
+int n2m_debug_fill_times(int on, unsigned long long* out);
+
 /* Diagnostics.  march_rays_train resolves which candidates a ray visits with a wave-wide prefix maximum whose result is provably the
  * serial chain's whenever its check passes; a ray that fails the check is re-marched with the serial resolution.  Returns in *out
  * the number of such rays (count passes) since the previous call and resets it.  Synchronises the device. */

@@ -1427,6 +1427,12 @@ __device__ __forceinline__ bool merge_runs(bool inside, const uint32_t (&cell)[3
     return last;
 }
 
+// Measurement aid (n2m_debug_fill_times): shader-clock stamps of two workgroups' first 8 tile iterations, 6 per iteration --
+// loop top, entries ready, after barrier 1 (slots counted), after barrier 3 (run starts), after barrier 4 (tile staged), log stores issued.
+__device__ unsigned int g_fill_timing_on;
+__device__ unsigned long long g_fill_t[2][8][6];     // workgroup 3 (a fine, hashed level) and workgroup gridDim/2 + 3 (a coarse, dense one)
+#define N2M_FILL_STAMP(i) do { if (stamp && it < 8u) g_fill_t[stamp_w][it][(i)] = __builtin_readcyclecounter(); } while (0)
+
 template <bool TV>
 __global__ void __launch_bounds__(1024)
 bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Float16* __restrict__ grad2 /*[L,Bstride,2]*/,
@@ -1504,7 +1510,10 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
     request(tile);
     __syncthreads();
 
+    const bool stamp = g_fill_timing_on != 0u && tid == 0u && (blockIdx.x == 3u || blockIdx.x == gridDim.x / 2u + 3u);
+    const uint32_t stamp_w = blockIdx.x == 3u ? 0u : 1u;
     for (uint32_t it = 0; tile < plan.tiles; tile += n_groups, ++it) {
+        N2M_FILL_STAMP(0);
         uint32_t* cnt = cnt2[it & 1u];
         uint32_t* cnt_next = cnt2[(it & 1u) ^ 1u];
         float x[D] = {nx[0], nx[1], nx[2]};
@@ -1557,6 +1566,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
             if (keep && ((e_v1[c] << 1) | (e_v2[c] & 0x7FFF7FFFu)) != 0u) vmask |= 1u << c;
         }
 
+        N2M_FILL_STAMP(1);
         // slot of every entry inside its partition's run of this tile
         if (parts == 1u) {
             const unsigned long long below = (1ull << lane) - 1ull;
@@ -1575,6 +1585,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
                 if ((vmask >> c) & 1u) e_slot[c] = atomicAdd(&cnt[e_pr[c] >> 16], 1u);
         }
         __syncthreads();                                                     // (1) counters complete
+        N2M_FILL_STAMP(2);
 
         const uint32_t i0 = 2u * tid, i1 = i0 + 1u;
         const uint32_t a0 = i0 < parts ? cnt[i0] : 0u, a1c = i1 < parts ? cnt[i1] : 0u;
@@ -1594,6 +1605,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
         if (i1 < parts) { cnt[i1] = excl + a0; dir[i1] = excl + a0; }
         if (tid == 0) dir[parts] = total;
         __syncthreads();                                                     // (3) run starts in place
+        N2M_FILL_STAMP(3);
 
 #pragma unroll
         for (uint32_t c = 0; c < 8; ++c)
@@ -1605,6 +1617,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
             }
         for (uint32_t i = tid; i < parts; i += 1024) cnt_next[i] = 0;        // the other counter set, for the next tile
         __syncthreads();                                                     // (4) tile staged (and next counters clean)
+        N2M_FILL_STAMP(4);
 
         const size_t seg = ((size_t)level * plan.tiles + tile) * kTileEntries;
         // streaming stores: the log is read back by another kernel, it need not displace the level's table lines in L2
@@ -1618,6 +1631,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
             for (uint32_t i = tid; i < (total + 1u) / 2u; i += 1024) __builtin_nontemporal_store(src[i], &dst[i]);
         }
         // no barrier here: the next tile writes the stage only after its barrier (3), which every thread reaches after this copy
+        N2M_FILL_STAMP(5);
     }
 
     // level maxima of both tables: workgroup reduction, one conditional atomicMax each (see bin_fill_kernel)
@@ -2464,5 +2478,14 @@ extern "C" int n2m_grid_encode_forward_packed(const float* inputs, const void* p
                                                        max_level, lv, gridtype, align_corners != 0, interp, n_tiles, in_scale,
                                                        in_offset, xg);
     N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+// Measurement aid: on != 0 arms the stamps of bin_fill_pair_kernel (two workgroups, tid 0); out (may be NULL) receives the 2 x 8 x 6 stamps
+// of the last armed launch.  Synchronises the device.
+extern "C" int n2m_debug_fill_times(int on, unsigned long long* out) {
+    if (out) N2M_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fill_t), sizeof(unsigned long long) * 96));
+    const unsigned int v = on ? 1u : 0u;
+    N2M_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fill_timing_on), &v, sizeof(v)));
     return 0;
 }

@@ -12,6 +12,7 @@ from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward_pair
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--levels", action="store_true")
+ap.add_argument("--B", type=int, default=2 ** 18)
 ap.add_argument("--uniform", action="store_true", help="incoherent inputs U[0,1)^3 instead of ray samples")
 args = ap.parse_args()
 dev = torch.device("cuda")
@@ -30,7 +31,7 @@ def coherent_samples(B):
     return ((torch.cat(xs)[:B] + 1) / 2).contiguous()
 
 
-B = 2 ** 18
+B = args.B
 torch.manual_seed(0)
 e1 = GridEncoder(level_dim=1, desired_resolution=2048).to(dev)
 e2 = GridEncoder(level_dim=2, desired_resolution=2048).to(dev)
@@ -60,3 +61,21 @@ if args.levels:
     for ml in (1, 2, 4, 6, 8, 12, 16):
         print(f"   max_level={ml:2d} (no TV): {run(False, ml):8.1f} us")
 
+
+# phase stamps of one fill workgroup (shader clock): top -> entries -> barrier 1 -> barrier 3 -> barrier 4 -> stores issued
+import ctypes
+from nerf2mesh_amd import _lib as L
+L.call("n2m_debug_fill_times", 1, None)
+run(True)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 96)()
+L.call("n2m_debug_fill_times", 0, ctypes.addressof(buf))
+names = ["entries(+TV)", "slot atomics+bar1", "scan+bar2+bar3", "stage+bar4", "log stores"]
+for w, what in enumerate(("workgroup 3 (fine hashed level)", "workgroup grid/2+3 (coarse dense level)")):
+    t = [[buf[w * 48 + i * 6 + j] for j in range(6)] for i in range(8)]
+    print(what)
+    for i in range(8):
+        if t[i][0] == 0: continue
+        d = [t[i][j + 1] - t[i][j] for j in range(5)]
+        nxt = (t[i + 1][0] - t[i][5]) if i < 7 and t[i + 1][0] else 0
+        print(f"  iter {i}: " + "  ".join(f"{n} {v}" for n, v in zip(names, d)) + f"  | total {t[i][5]-t[i][0]} (+{nxt} to next top) cycles")
