@@ -1272,8 +1272,10 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
 // (raymarching.cu:417) -- the same bits the two-pass call produces with a zeroed counter.  `workspace`:
 // n2m_march_fused_workspace_bytes(N) bytes, contents irrelevant.
 static inline uint32_t march_groups(uint32_t N) { return (N >> kMarchGroupLog2) + 1u; }
+// the group totals lead the workspace, padded to 256 bytes: their clear is then ONE aligned fill (an unaligned hipMemsetAsync splits into three)
+static inline uint64_t march_group_bytes(uint32_t N) { return ((uint64_t)march_groups(N) * 4u + 255u) & ~(uint64_t)255u; }
 extern "C" uint64_t n2m_march_fused_workspace_bytes(uint32_t N) {
-    return (uint64_t)N * kChunkRecCap * sizeof(ChunkRec) + (uint64_t)N * 4u + (uint64_t)march_groups(N) * 4u + 64u;
+    return march_group_bytes(N) + (uint64_t)N * kChunkRecCap * sizeof(ChunkRec) + (uint64_t)N * 4u + 64u;
 }
 
 extern "C" int n2m_march_rays_train_fused(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, int contract,
@@ -1290,11 +1292,11 @@ extern "C" int n2m_march_rays_train_fused(const float* rays_o, const float* rays
                 (unsigned long long)workspace_bytes, (unsigned long long)n2m_march_fused_workspace_bytes(N));
     hipStream_t s = (hipStream_t)stream;
     if (N == 0) { N2M_HIP(hipMemsetAsync(counter, 0, sizeof(int32_t), s)); return 0; }
-    ChunkRec* recs = (ChunkRec*)workspace;                                   // [N][kChunkRecCap]
+    uint32_t* group_total = (uint32_t*)workspace;                            // [N / 256 + 1], padded
+    ChunkRec* recs = (ChunkRec*)((char*)workspace + march_group_bytes(N));  // [N][kChunkRecCap]
     uint32_t* n_recs = (uint32_t*)(recs + (size_t)N * kChunkRecCap);        // [N]
-    uint32_t* group_total = n_recs + N;                                      // [N / 256 + 1]
     const uint32_t blocks = n2m_ceil_div(N, 4);
-    N2M_HIP(hipMemsetAsync(group_total, 0, (size_t)march_groups(N) * 4u, s));
+    N2M_HIP(hipMemsetAsync(group_total, 0, march_group_bytes(N), s));
     {
         N2M_PROF(N2M_K_MARCH_COUNT, s, 52.0 * N);
         march_train_record_kernel<<<blocks, 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C, H, nears, fars, rays,

@@ -394,18 +394,22 @@ __global__ void scaler_update_slots_kernel(float* scale, float* growth_tracker, 
                                            const float* __restrict__ loss_partial, uint32_t n_partial, float inv_rays,
                                            float* __restrict__ loss, float* __restrict__ loss_sum) {
     const uint32_t s = threadIdx.x;
+    __shared__ float wave_part[16];
     if (loss_partial) {       // the step's loss VALUE (nobody on the GPU waits for it): per-workgroup partials of n2m_composite_loss_train,
-        float acc = 0.0f;     // summed here in a fixed order (lane j takes partials j, j + 64, ...; then the lanes in scan order)
-        for (uint32_t i = s; i < n_partial; i += 64) acc += loss_partial[i];
+        float acc = 0.0f;     // summed in a fixed order: thread j takes partials j, j + blockDim, ...; lanes in scan order; waves 0, 1, ...
+        for (uint32_t i = s; i < n_partial; i += blockDim.x) acc += loss_partial[i];      // (one wave did this alone: 17 serial round trips, 8 us)
         acc = n2m_wave_sum(acc);
-        if (s == 0) {
-            const float v = acc * inv_rays;
-            if (loss) *loss = v;
-            if (loss_sum) *loss_sum += v;
-        }
+        if ((s & 63u) == 0u) wave_part[s >> 6] = acc;
     }
     const bool ok = *found_inf == 0.0f;
     __syncthreads();                                  // everyone has read the verdict before thread 0 clears it
+    if (loss_partial && s == 0) {
+        float acc = 0.0f;
+        for (uint32_t w = 0; w < (blockDim.x + 63u) / 64u; ++w) acc += wave_part[w];
+        const float v = acc * inv_rays;
+        if (loss) *loss = v;
+        if (loss_sum) *loss_sum += v;
+    }
     if (s == 0) {
         if (!ok) {
             if (scale) *scale *= backoff_factor;
@@ -449,7 +453,7 @@ extern "C" int n2m_scaler_update_slots_loss(float* scale, float* growth_tracker,
                                             float* loss_sum, void* stream) {
     N2M_REQUIRE(found_inf != nullptr && steps != nullptr && bias != nullptr, N2M_ENULL, "scaler_update_slots: NULL found_inf / steps / bias");
     N2M_REQUIRE(loss_partial != nullptr && n_rays > 0, N2M_EINVAL, "scaler_update_slots_loss: needs the loss partials and the ray count");
-    scaler_update_slots_kernel<<<1, 64, 0, (hipStream_t)stream>>>(scale, growth_tracker, found_inf, steps, bias, participants, beta1, beta2,
+    scaler_update_slots_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(scale, growth_tracker, found_inf, steps, bias, participants, beta1, beta2,
                                                                   growth_factor, backoff_factor, growth_interval, loss_partial, n_partial,
                                                                   1.0f / (float)n_rays, loss, loss_sum);
     N2M_CHECK_LAUNCH();

@@ -95,6 +95,7 @@ class Stage0Engine:
         self.split_backward = True            # multi-rank: table backward in two level halves, the first half's all-reduce under the second
         self.overlap = True                   # next batch on the side stream (False: everything on the main stream, same results)
         self.single_pass = os.environ.get("N2M_MARCH_PASSES", "1") != "2"      # one-launch marcher (A/B: N2M_MARCH_PASSES=2)
+        self.marker_at = int(os.environ.get("N2M_MARKER_AT", "0"))             # side-stream go-ahead: 0 before Adam, 1 before the table backward, 2 before the field backward
 
         e1, e2 = model.encoder, model.encoder_color
         self.rows = e1.embeddings.shape[0]
@@ -400,6 +401,8 @@ class Stage0Engine:
                 spec_loss = opt.lambda_specular * (spec_m * spec_m).sum() / M
                 d_spec = w["d_spec"][:3 * M]
                 torch.mul(spec_m, seed * (2.0 * opt.lambda_specular / M), out=d_spec)
+            if self.marker_at == 2:
+                self._marker = torch.cuda.Event(); self._marker.record()
             L.call("n2m_field_backward", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 1,
                    _p(d_sigma), _p(d_rgb), _p(d_spec), _p(w["d_h1"]), _p(w["d_h2"]), *[_p(g) for g in self.dw_views], _p(o.found_inf), s)
             need = L.lib().n2m_grid_binned_pair_workspace_bytes(M, self.Lv, self.ho.ctypes.data)
@@ -410,6 +413,8 @@ class Stage0Engine:
                         _p(e1.embeddings) if tv else None, float(opt.lambda_tv), float(opt.lambda_tv * (10 if opt.bound > 1 else 1)),
                         float(0.5 / model.bound), _p(seed) if tv else None, _p(o.found_inf), float(self.aff[0]), float(self.aff[1]), 1, _p(ws),
                         ws.numel(), s)
+            if self.marker_at == 1:
+                self._marker = torch.cuda.Event(); self._marker.record()
             if self.sync is not None and self.split_backward and self.Lv == 16:
                 # multi-GPU: the table backward in two halves of the levels.  The rows of the fine half (levels 8..15: 68 % of the
                 # bytes) are final after the first call; their SUM all-reduce runs on the collective stream while the coarse half is
@@ -436,8 +441,9 @@ class Stage0Engine:
             self.sync.all_reduce_sum_end(token)
         # ONE event per step on the main stream (an event record is a marker packet the queue idles ~6 us behind, measured): behind the
         # last kernel that reads this batch's buffers and in front of the optimizer update -- the side stream's go-ahead
-        self._marker = torch.cuda.Event()
-        self._marker.record()
+        if self.marker_at == 0 or M == 0:
+            self._marker = torch.cuda.Event()
+            self._marker.record()
         # ---- Adam + loss-scale bookkeeping, LR schedule (main.py:239)
         self._lr_step(shading != 0, loss_out=(N, b.loss))
         loss = b.loss.view(())                 # written by the scaler kernel; lives in the batch's buffer set (valid until the set comes round again)
