@@ -109,7 +109,8 @@ int n2m_march_rays_train_fused(const float* rays_o, const float* rays_d, const u
                                void* workspace, uint64_t workspace_bytes, void* stream);
 
 /* Measurement aid for the shared fill of n2m_grid_encode_backward_binned_pair: on != 0 arms shader-clock stamps in one of its workgroups
- * (first 8 tile iterations x 6 phase boundaries); out (may be NULL) receives the stamps of the last armed launch.  Synchronises. */
+ * (first 8 tile iterations x 6 phase boundaries) and in two work items of each accumulate kernel (5 boundaries); out (may be NULL,
+ * else 116 words) receives the stamps of the last armed launch.  Synchronises. */
 int n2m_debug_fill_times(int on, unsigned long long* out);
 
 /* Diagnostics.  march_rays_train resolves which candidates a ray visits with a wave-wide prefix maximum whose result is provably the

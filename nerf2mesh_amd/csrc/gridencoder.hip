@@ -1510,7 +1510,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
     request(tile);
     __syncthreads();
 
-    const bool stamp = g_fill_timing_on != 0u && tid == 0u && (blockIdx.x == 3u || blockIdx.x == gridDim.x / 2u + 3u);
+    const bool stamp = (g_fill_timing_on & 1u) != 0u && tid == 0u && (blockIdx.x == 3u || blockIdx.x == gridDim.x / 2u + 3u);
     const uint32_t stamp_w = blockIdx.x == 3u ? 0u : 1u;
     for (uint32_t it = 0; tile < plan.tiles; tile += n_groups, ++it) {
         N2M_FILL_STAMP(0);
@@ -1621,6 +1621,12 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
 
         const size_t seg = ((size_t)level * plan.tiles + tile) * kTileEntries;
         // streaming stores: the log is read back by another kernel, it need not displace the level's table lines in L2
+        if (g_fill_timing_on & 2u) {                 // measurement switch: plain (cache-allocating) log stores
+            for (uint32_t i = tid; i < total; i += 1024) { log_v1[seg + i] = stage_v1[i]; log_v2[seg + i] = stage_v2[i]; }
+            const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(stage_rel);
+            uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(log_rel + seg);
+            for (uint32_t i = tid; i < (total + 1u) / 2u; i += 1024) dst[i] = src[i];
+        } else {
         for (uint32_t i = tid; i < total; i += 1024) {
             __builtin_nontemporal_store(stage_v1[i], &log_v1[seg + i]);
             __builtin_nontemporal_store(stage_v2[i], &log_v2[seg + i]);
@@ -1629,6 +1635,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
             const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(stage_rel);
             uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(log_rel + seg);
             for (uint32_t i = tid; i < (total + 1u) / 2u; i += 1024) __builtin_nontemporal_store(src[i], &dst[i]);
+        }
         }
         // no barrier here: the next tile writes the stage only after its barrier (3), which every thread reaches after this copy
         N2M_FILL_STAMP(5);
@@ -1655,6 +1662,11 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
 // partition-sorted tiles, so they stream as one run): LDS accumulator SUB * P * C * 8 bytes.  SUB = 2 lets the fp32 table, whose
 // rows are half as wide, keep 8192-row items on the 4096-row partition structure it shares with the fp16 table.
 // SOA: entries come as (u16 row-in-partition, u32 value) arrays (the shared-fill logs) instead of packed u64.
+// Measurement aid (n2m_debug_acc_times): shader-clock stamps of one work item per accumulate kernel (workgroup gridDim/2 + 1 and
+// workgroup 1): item start, accumulator cleared + directory in (barrier), runs walked, barrier, rows flushed.
+__device__ unsigned long long g_acc_t[2][2][5];
+#define N2M_ACC_STAMP(i) do { if (stamp) g_acc_t[sizeof(T) == 4 ? 0 : 1][stamp_w][(i)] = __builtin_readcyclecounter(); } while (0)
+
 template <typename T, uint32_t C, uint32_t P, uint32_t SUB, bool SOA = false>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners,
@@ -1671,7 +1683,10 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t total_items = plan.item_prefix[plan.levels];
 
+    const bool stamp = (g_fill_timing_on & 1u) != 0u && tid == 0u && (blockIdx.x == 1u || blockIdx.x == gridDim.x / 2u + 1u);
+    const uint32_t stamp_w = blockIdx.x == 1u ? 0u : 1u;
     for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x) {
+        N2M_ACC_STAMP(0);
         uint32_t level = 0;
         while (item >= plan.item_prefix[level + 1]) ++level;
         const uint32_t vm = level_max[level];
@@ -1720,9 +1735,49 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
         for (uint32_t i = tid; i < SUB * P * C; i += 1024) bin_acc[i] = 0ull;
         if (tid == 0) nonfinite_seen = 0u;
         __syncthreads();
+        N2M_ACC_STAMP(1);
         // walk(body): body(rel0, u, bits) for every entry of this item's runs
         auto walk = [&](auto&& body) {
-            for (uint32_t j = 0; j < (vm != 0u ? my_tiles : 0u); ++j) {
+            const uint32_t n_t = vm != 0u ? my_tiles : 0u;
+            if constexpr (SOA) {
+                // A wave's runs sit in different tiles: short pieces (64-128 entries) far apart in the log, each a DRAM round trip of
+                // ~1 us under load (shader-clock stamps: 16 serial trips = the whole walk).  The first 64 entries of kWalkAhead runs are
+                // therefore requested together before any of them is accumulated; what a long run has beyond that follows serially.
+                constexpr uint32_t kWalkAhead = 4;
+                for (uint32_t j0 = 0; j0 < n_t; j0 += kWalkAhead) {
+                    uint32_t r_rel[kWalkAhead], r_val[kWalkAhead], r_off[kWalkAhead], r_end[kWalkAhead], r_mid[kWalkAhead];
+                    size_t r_seg[kWalkAhead];
+#pragma unroll
+                    for (uint32_t u = 0; u < kWalkAhead; ++u) {
+                        const uint32_t j = j0 + u < n_t ? j0 + u : n_t - 1u;       // (clamped: the copy of the last run is not accumulated)
+                        r_off[u] = (uint32_t)__builtin_amdgcn_readlane((int)d_off, j);
+                        r_end[u] = j0 + u < n_t ? (uint32_t)__builtin_amdgcn_readlane((int)d_end, j) : 0u;
+                        r_mid[u] = (uint32_t)__builtin_amdgcn_readlane((int)d_mid, j);
+                        r_seg[u] = ((size_t)level * plan.tiles + (grp + wid * Gl + j * 16u * Gl)) * kTileEntries;
+                        const uint32_t i = r_off[u] + lane;
+                        r_rel[u] = 0u; r_val[u] = 0u;
+                        if (i < r_end[u]) {
+                            if (dbg & 4u) { r_rel[u] = i & (P - 1u); r_val[u] = 0x3f800000u; }
+                            else { r_rel[u] = log_rel[r_seg[u] + i]; r_val[u] = log_val[r_seg[u] + i]; }
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < kWalkAhead; ++u) {
+                        const uint32_t i = r_off[u] + lane;
+                        if (i < r_end[u]) body(r_rel[u], (SUB > 1u && i >= r_mid[u]) ? 1u : 0u, r_val[u]);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < kWalkAhead; ++u)
+                        for (uint32_t i = r_off[u] + lane + 64u; i < r_end[u]; i += 64u) {
+                            uint32_t rel0, bits;
+                            if (dbg & 4u) { rel0 = i & (P - 1u); bits = 0x3f800000u; }
+                            else { rel0 = log_rel[r_seg[u] + i]; bits = log_val[r_seg[u] + i]; }
+                            body(rel0, (SUB > 1u && i >= r_mid[u]) ? 1u : 0u, bits);
+                        }
+                }
+                return;
+            }
+            for (uint32_t j = 0; j < n_t; ++j) {
                 const uint32_t t = grp + wid * Gl + j * 16u * Gl;
                 const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)d_off, j), end = (uint32_t)__builtin_amdgcn_readlane((int)d_end, j);
                 const uint32_t mid = (uint32_t)__builtin_amdgcn_readlane((int)d_mid, j);      // first entry of the second partition
@@ -1781,7 +1836,9 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
                 if (v1 != 0.f) __hip_atomic_fetch_add(&bin_acc[rel * 2u + 1u], (unsigned long long)to_fixed(v1, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         });
+        N2M_ACC_STAMP(2);
         __syncthreads();
+        N2M_ACC_STAMP(3);
         const bool second_walk = store_all && nonfinite_seen != 0u;       // read here: the next item resets the flag before ITS first barrier
 
         for (uint32_t rel = tid; rel < ((dbg & 2u) ? 0u : SUB * P); rel += 1024) {
@@ -1825,6 +1882,7 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
             }
         }
         __syncthreads();
+        N2M_ACC_STAMP(4);
         if (second_walk) {
             __threadfence();                                               // the stores above before the atomics below
             walk([&](uint32_t rel0, uint32_t u, uint32_t bits) { if (!finite(bits)) bypass(rel0, u, bits); });
@@ -2165,11 +2223,24 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
                                                                              ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin);
         N2M_CHECK_LAUNCH();
         const uint32_t items = items2;
-        const uint32_t nb = items < 4096u ? items : 4096u;
+        static const uint32_t acc_cap2 = getenv("N2M_ACC_GRID") ? (uint32_t)atoi(getenv("N2M_ACC_GRID")) : 4096u;
+        const uint32_t nb = items < acc_cap2 ? items : acc_cap2;
         static const uint32_t acc_dbg = getenv("N2M_ACC_DEBUG") ? (uint32_t)atoi(getenv("N2M_ACC_DEBUG")) : 0u;   // measurement switches (wrong results)
-        bin_accumulate_kernel<float, 1, kPairP, 2, true><<<items1 < 4096u ? items1 : 4096u, 1024, kPairP * 16, s>>>(
+        static const uint32_t acc_cap = getenv("N2M_ACC_GRID") ? (uint32_t)atoi(getenv("N2M_ACC_GRID")) : 4096u;    // A/B: persistent workgroups
+        bin_accumulate_kernel<float, 1, kPairP, 2, true><<<items1 < acc_cap ? items1 : acc_cap, 1024, kPairP * 16, s>>>(
             table1, plan1, lv, gridtype, align, level_max, directory, nullptr, found_inf, log_rel, log_v1, ow, acc_dbg);
         N2M_CHECK_LAUNCH();
+        static const bool acc2_sub2 = getenv("N2M_ACC2_SUB") != nullptr && atoi(getenv("N2M_ACC2_SUB")) == 2;      // A/B: 8192-row items for the fp16 table too
+        if (acc2_sub2) {
+            static bool attr2 = false;
+            if (!attr2) {
+                (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<_Float16, 2, kPairP, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 32));
+                attr2 = true;
+            }
+            BinPlan plan2b = plan1;       // same item structure as the fp32 table: pairs of partitions; its split levels must be cleared for table 2 too
+            bin_accumulate_kernel<_Float16, 2, kPairP, 2, true><<<items1 < acc_cap ? items1 : acc_cap, 1024, kPairP * 32, s>>>(
+                table2, plan2b, lv, gridtype, align, level_max + kMaxLevels, directory, nullptr, found_inf, log_rel, log_v2, ow && cm1 == cm2, acc_dbg);
+        } else
         bin_accumulate_kernel<_Float16, 2, kPairP, 1, true><<<nb, 1024, kPairP * 16, s>>>(table2, plan2, lv, gridtype, align, level_max + kMaxLevels,
                                                                                         directory, nullptr, found_inf, log_rel, log_v2, ow, acc_dbg);
         N2M_CHECK_LAUNCH();
@@ -2481,11 +2552,12 @@ extern "C" int n2m_grid_encode_forward_packed(const float* inputs, const void* p
     return 0;
 }
 
-// Measurement aid: on != 0 arms the stamps of bin_fill_pair_kernel (two workgroups, tid 0); out (may be NULL) receives the 2 x 8 x 6 stamps
-// of the last armed launch.  Synchronises the device.
+// Measurement aid: on != 0 arms the stamps of bin_fill_pair_kernel (two workgroups, tid 0); out (may be NULL, else 116 words) receives the 2 x 8 x 6 fill stamps
+// and the 2 x 2 x 5 accumulate stamps (fp32 table kernel, fp16 table kernel; two work items each) of the last armed launch.  Synchronises the device.
 extern "C" int n2m_debug_fill_times(int on, unsigned long long* out) {
     if (out) N2M_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fill_t), sizeof(unsigned long long) * 96));
-    const unsigned int v = on ? 1u : 0u;
+    if (out) N2M_HIP(hipMemcpyFromSymbol(out + 96, HIP_SYMBOL(g_acc_t), sizeof(unsigned long long) * 20));
+    const unsigned int v = (unsigned int)on;        // bit 0: stamps, bit 1: plain log stores (measurement)
     N2M_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fill_timing_on), &v, sizeof(v)));
     return 0;
 }

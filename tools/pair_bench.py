@@ -55,6 +55,10 @@ def run(tv, ml=16):
     return 1e3 * a.elapsed_time(b) / args.reps
 
 
+if os.environ.get("FILL_MODE"):
+    import ctypes
+    from nerf2mesh_amd import _lib as L0
+    L0.call("n2m_debug_fill_times", int(os.environ["FILL_MODE"]), None)
 print(f"pair backward B=2^18 coherent, TV folded : {run(True):8.1f} us")
 print(f"pair backward B=2^18 coherent, no TV     : {run(False):8.1f} us")
 if args.levels:
@@ -65,10 +69,10 @@ if args.levels:
 # phase stamps of one fill workgroup (shader clock): top -> entries -> barrier 1 -> barrier 3 -> barrier 4 -> stores issued
 import ctypes
 from nerf2mesh_amd import _lib as L
-L.call("n2m_debug_fill_times", 1, None)
+L.call("n2m_debug_fill_times", 1 | int(os.environ.get("FILL_MODE", "0")), None)
 run(True)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 96)()
+buf = (ctypes.c_ulonglong * 116)()
 L.call("n2m_debug_fill_times", 0, ctypes.addressof(buf))
 names = ["entries(+TV)", "slot atomics+bar1", "scan+bar2+bar3", "stage+bar4", "log stores"]
 for w, what in enumerate(("workgroup 3 (fine hashed level)", "workgroup grid/2+3 (coarse dense level)")):
@@ -79,3 +83,8 @@ for w, what in enumerate(("workgroup 3 (fine hashed level)", "workgroup grid/2+3
         d = [t[i][j + 1] - t[i][j] for j in range(5)]
         nxt = (t[i + 1][0] - t[i][5]) if i < 7 and t[i + 1][0] else 0
         print(f"  iter {i}: " + "  ".join(f"{n} {v}" for n, v in zip(names, d)) + f"  | total {t[i][5]-t[i][0]} (+{nxt} to next top) cycles")
+for k, what in enumerate(("accumulate fp32 C=1", "accumulate fp16 C=2")):
+    for w in range(2):
+        t = [buf[96 + k * 10 + w * 5 + j] for j in range(5)]
+        if t[0]:
+            print(f"{what} item {w}: clear+directory {t[1]-t[0]}  walk {t[2]-t[1]}  barrier {t[3]-t[2]}  flush {t[4]-t[3]}  | total {t[4]-t[0]} cycles")
