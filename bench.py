@@ -202,6 +202,8 @@ def main():
     ap.add_argument("--recipe", default="lego", choices=["lego", "sdf", "garden"], help="lego: the headline config (BASELINE configs[1]); sdf: "
                     "`--sdf` stage 0 (config 5: NeuS alpha, 7 density evaluations per sample, eikonal loss); garden: `--bound 16 --dt_gamma 1/256`, "
                     "5 cascades, inner/outer TV split (config 4's recipe on the synthetic scene).  The last two run on trainer.Stage0Trainer")
+    ap.add_argument("--num-points", type=int, default=0, help="measurement aid: override the per-step sample target (2^18 in the recipe); "
+                                                               "a tiny value shows every kernel's fixed cost")
     ap.add_argument("--unfused", action="store_true", help="A/B: evaluate the MLPs with nn.Linear calls (the reference graph) instead of the fused MFMA kernels")
     args = ap.parse_args()
 
@@ -242,6 +244,9 @@ def main():
                "sdf": dict(bound=1, dt_gamma=0, sdf=True),                            # scripts/runall_syn_sdf.sh:1
                "garden": dict(bound=16, dt_gamma=1 / 256)}                            # scripts/runall_360.sh (bound 16, default dt_gamma)
     opt = make_options(O=True, iters=30000, fused_mlp=not args.unfused, **recipes[args.recipe])
+    if args.num_points > 0:
+        opt.num_points = args.num_points
+        opt.num_rays = max(64, args.num_points // 16)
     model = NeRFNetwork(opt)
     poses = synthetic.make_cameras(100, seed=0)
     from nerf2mesh_amd.engine import Stage0Engine

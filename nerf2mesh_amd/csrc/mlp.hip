@@ -1115,13 +1115,16 @@ int check_field(const char* fn, const float* xyz, const float* h1, const float* 
 // [256][7 648] floats per stream that ever ran a backward (calls on one stream are ordered, so they can share it); never freed
 float* dw_scratch(hipStream_t s) {
     static std::mutex mu;
-    static std::map<hipStream_t, float*> bufs;
+    static std::map<std::pair<int, hipStream_t>, float*> bufs;       // (device, stream): the null stream exists on every device
     std::lock_guard<std::mutex> lk(mu);
-    auto it = bufs.find(s);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const auto key = std::make_pair(dev, s);
+    auto it = bufs.find(key);
     if (it != bufs.end()) return it->second;
     float* p = nullptr;
     if (hipMalloc((void**)&p, (size_t)256 * kDwTotal * sizeof(float)) != hipSuccess) return nullptr;
-    bufs[s] = p;
+    bufs[key] = p;
     return p;
 }
 
