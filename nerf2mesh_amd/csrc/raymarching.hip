@@ -951,8 +951,16 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
     if (n < N) {
         const uint32_t off = (uint32_t)rays[2 * n], cnt = (uint32_t)rays[2 * n + 1];
         const bool whole = cnt != 0 && off + cnt <= M;
+        // everything per-ray the loss head needs is requested now, not after the forward loop (a wave owns its ray alone: every
+        // dependent global round trip is exposed -- the kernel cost 15 us for 110 rays and 18 us for 17 000)
+        const float4 gtv = *reinterpret_cast<const float4*>(gt + (size_t)n * 4);
+        const float gl = *grad_loss;
+        float bgv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bgv[c] = bg ? bg[(size_t)n * 3 + c] : bg_scalar;
         // ---- forward
         float rF = 0, gF = 0, bF = 0, wsF = 0;
+        float a0 = 0.f, dt0 = 0.f, cr0 = 0.f, cg0 = 0.f, cb0 = 0.f;     // the first 64 samples stay in registers for the backward pass
         if (whole) {
             float carry_T = 1.0f;
             for (uint32_t base = 0; base < cnt; base += 64) {
@@ -964,6 +972,7 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
                     const float2 tt = *reinterpret_cast<const float2*>(ts + 2 * i);
                     alpha = 1.0f - expf(-sigmas[i] * tt.y);
                     cr = rgbs[3 * i]; cg = rgbs[3 * i + 1]; cb = rgbs[3 * i + 2];
+                    if (base == 0) { a0 = alpha; dt0 = tt.y; cr0 = cr; cg0 = cg; cb0 = cb; }
                 }
                 const float incl = n2m_wave_scan_mul(1.0f - alpha, lane);
                 const float excl = n2m_lane_below(incl, 1.0f);
@@ -978,16 +987,15 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
             rF = n2m_wave_sum(rF); gF = n2m_wave_sum(gF); bF = n2m_wave_sum(bF); wsF = n2m_wave_sum(wsF);
         }
         // ---- loss term of the ray and its gradients (wave-uniform)
-        const float4 gtv = *reinterpret_cast<const float4*>(gt + (size_t)n * 4);
         const float a = gtv.w;
         const float gc[3] = {gtv.x, gtv.y, gtv.z}, pc[3] = {rF, gF, bF};
-        const float gscale = *grad_loss / (float)N;
+        const float gscale = gl / (float)N;
         float gi[3];
         const float m = wsF - a;
         float gws = gscale * lambda_mask * 2.0f * m;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float bgc = bg ? bg[(size_t)n * 3 + c] : bg_scalar;
+            const float bgc = bgv[c];
             const float target = gc[c] * a + bgc * (1.0f - a);
             const float pred = pc[c] + (1.0f - wsF) * bgc;
             const float e = pred - target;
@@ -1018,7 +1026,8 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
                     continue;
                 }
                 float alpha = 0.f, dt = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
-                if (valid) {
+                if (base == 0) { alpha = a0; dt = dt0; cr = cr0; cg = cg0; cb = cb0; }      // the forward pass's own values (zeros where !valid)
+                else if (valid) {
                     const float2 tt = *reinterpret_cast<const float2*>(ts + 2 * i);
                     alpha = 1.0f - expf(-sigmas[i] * tt.y);
                     dt = tt.y;
