@@ -359,6 +359,10 @@ extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, f
         if (t.shadow_mode[k] != 3) continue;
         for (uint32_t j = 0; j < d->count; ++j)
             if (t.shadow_mode[j] == 2 && d->half_shadow[j] == d->half_shadow[k] && d->numel[k] == 2 * d->numel[j] && ((uintptr_t)d->half_shadow[k] & 15u) == 0) {
+                // the paired update neither clears the partner's gradient nor zeroes it on a skipped step: a consume-and-clear gradient
+                // buffer for that tensor would silently keep its values
+                N2M_REQUIRE(!((t.clear_mask >> j) & 1u), N2M_EUNSUPPORTED,
+                            "adam_step: tensor %u shares a packed table with tensor %u and cannot use clear_grad", j, k);
                 t.partner[k] = (int8_t)j;
                 break;
             }
