@@ -31,6 +31,12 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16x __attribute__((ext_vector_type(16)));
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x8f16((a), (b), (c), 0, 0, 0)
+// gfx950's double-K form: one instruction for two K blocks at the issue cost of one (8 passes either way).  Lane (x, g) supplies
+// k = 8g + i, i = 0..7, to A and B alike; with i < 4 taken from K block 2j and i >= 4 from block 2j + 1 -- i.e. the two 32x32x8
+// fragments side by side -- every (g, i) names the same feature on both operands, so the sum runs over the same 16 features and no
+// image has to be re-staged.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 // ---------------------------------------------------------------------------------------------- LDS layout (halves)
 // forward operands W[out_pad][k_pad + 4]; backward operands W^T[in_pad][out_pad + 4]
@@ -171,12 +177,26 @@ __device__ __forceinline__ void ld_layer(h4 (&w)[MB][KB], const _Float16* W, int
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) w[mb][kb] = ld_a(W, pitch, mb, kb, lane);
 }
+__device__ __forceinline__ h8 cat8(const h4& lo, const h4& hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 template <int MB, int KB>
 __device__ __forceinline__ void mm_layer(f16x (&d)[MB], const h4 (&w)[MB][KB], const h4 (&b)[KB]) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+    for (int kb = 0; kb + 1 < KB; kb += 2)
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) d[mb] = MFMA(w[mb][kb], b[kb], d[mb]);
+        for (int mb = 0; mb < MB; ++mb) d[mb] = MFMA16(cat8(w[mb][kb], w[mb][kb + 1]), cat8(b[kb], b[kb + 1]), d[mb]);
+    if (KB & 1) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) d[mb] = MFMA(w[mb][KB - 1], b[KB - 1], d[mb]);
+    }
+}
+// the K loop of one M block straight from the LDS image (small layers)
+template <int KB>
+__device__ __forceinline__ f16x mm_k(const _Float16* W, int pitch, int mb, const h4 (&b)[KB], f16x acc, int lane) {
+#pragma unroll
+    for (int kb = 0; kb + 1 < KB; kb += 2)
+        acc = MFMA16(cat8(ld_a(W, pitch, mb, kb, lane), ld_a(W, pitch, mb, kb + 1, lane)), cat8(b[kb], b[kb + 1]), acc);
+    if (KB & 1) acc = MFMA(ld_a(W, pitch, mb, KB - 1, lane), b[KB - 1], acc);
+    return acc;
 }
 
 __device__ __forceinline__ h4 zero4() { h4 z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0}; return z; }
@@ -397,12 +417,10 @@ __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
             h4 b0[3];
             density_frags(cur, b0);
             f16x d = zero16();
-#pragma unroll
-            for (int kb = 0; kb < 3; ++kb) d = MFMA(ld_a(lds + O_S0, P_S0, 0, kb, lane), b0[kb], d);
+            d = mm_k<3>(lds + O_S0, P_S0, 0, b0, d, lane);
             const h4 b1[4] = {relu_pack<0>(d), relu_pack<1>(d), relu_pack<2>(d), relu_pack<3>(d)};
             f16x o = zero16();
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) o = MFMA(ld_a(lds + O_S1, P_S1, 0, kb, lane), b1[kb], o);
+            o = mm_k<4>(lds + O_S1, P_S1, 0, b1, o, lane);
             if (valid && g == 0) a.sigma[s] = a.raw_density ? (float)(_Float16)o[0] : expf((float)(_Float16)o[0]);
         }
         if (DO_COLOR) {   // ---- colour: [h2 | xyz] -> 64 -> 64 -> 6 -> sigmoid ; specular: [d | feat] -> 32 -> 3 -> sigmoid
@@ -411,20 +429,17 @@ __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
             f16x d1[2] = {zero16(), zero16()};
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int kb = 0; kb < 5; ++kb) d1[mb] = MFMA(ld_a(lds + O_C0, P_C0, mb, kb, lane), b0[kb], d1[mb]);
+                d1[mb] = mm_k<5>(lds + O_C0, P_C0, mb, b0, d1[mb], lane);
             const h4 b1[8] = {relu_pack<0>(d1[0]), relu_pack<1>(d1[0]), relu_pack<2>(d1[0]), relu_pack<3>(d1[0]),
                               relu_pack<0>(d1[1]), relu_pack<1>(d1[1]), relu_pack<2>(d1[1]), relu_pack<3>(d1[1])};
             f16x d2[2] = {zero16(), zero16()};
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int kb = 0; kb < 8; ++kb) d2[mb] = MFMA(ld_a(lds + O_C1, P_C1, mb, kb, lane), b1[kb], d2[mb]);
+                d2[mb] = mm_k<8>(lds + O_C1, P_C1, mb, b1, d2[mb], lane);
             const h4 b2[8] = {relu_pack<0>(d2[0]), relu_pack<1>(d2[0]), relu_pack<2>(d2[0]), relu_pack<3>(d2[0]),
                               relu_pack<0>(d2[1]), relu_pack<1>(d2[1]), relu_pack<2>(d2[1]), relu_pack<3>(d2[1])};
             f16x d3 = zero16();
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) d3 = MFMA(ld_a(lds + O_C2, P_C2, 0, kb, lane), b2[kb], d3);
+            d3 = mm_k<8>(lds + O_C2, P_C2, 0, b2, d3, lane);
             // rows 0..3 live in regs 0..3 of the g = 0 lanes, rows 4,5 in regs 0,1 of the g = 1 lanes
             const float q0 = sigmoid_h(d3[0]), q1 = sigmoid_h(d3[1]), q2 = sigmoid_h(d3[2]), q3 = sigmoid_h(d3[3]);
             float cr = q0, cg = q1, cb = q2;          // diffuse (g = 0 lanes)
@@ -437,8 +452,7 @@ __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
                 f16x p1 = MFMA(ld_a(lds + O_P0, P_P0, 0, 0, lane), bp, zero16());
                 const h4 bq[4] = {relu_pack<0>(p1), relu_pack<1>(p1), relu_pack<2>(p1), relu_pack<3>(p1)};
                 f16x p2 = zero16();
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) p2 = MFMA(ld_a(lds + O_P1, P_P1, 0, kb, lane), bq[kb], p2);
+                p2 = mm_k<4>(lds + O_P1, P_P1, 0, bq, p2, lane);
                 const float s0 = sigmoid_h(p2[0]), s1 = sigmoid_h(p2[1]), s2 = sigmoid_h(p2[2]);
                 if (valid && g == 0 && a.specular) {
                     a.specular[(size_t)s * 3] = s0; a.specular[(size_t)s * 3 + 1] = s1; a.specular[(size_t)s * 3 + 2] = s2;
@@ -492,11 +506,12 @@ __device__ __forceinline__ void dw_tile(f16x (&acc)[MB][NB], const _Float16* tY,
             for (int nb = 0; nb < NB; ++nb) bx[kq][nb] = tile_get_tr(tX, kq, nb, lane);
         }
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq)
+        for (int kq = 0; kq < 4; kq += 2)                 // 16 samples per instruction (32x32x16)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = MFMA(ay[kq][mb], bx[kq][nb], acc[mb][nb]);
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] = MFMA16(cat8(ay[kq][mb], ay[kq + 1][mb]), cat8(bx[kq][nb], bx[kq + 1][nb]), acc[mb][nb]);
         return;
     }
 #pragma unroll
@@ -892,12 +907,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             h4 b0[3];
             density_frags(cur, b0);
             f16x d = zero16();
-#pragma unroll
-            for (int kb = 0; kb < 3; ++kb) d = MFMA(ld_a(lds + O_S0, P_S0, 0, kb, lane), b0[kb], d);
+            d = mm_k<3>(lds + O_S0, P_S0, 0, b0, d, lane);
             const h4 b1[4] = {relu_pack<0>(d), relu_pack<1>(d), relu_pack<2>(d), relu_pack<3>(d)};
             f16x o = zero16();
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) o = MFMA(ld_a(lds + O_S1, P_S1, 0, kb, lane), b1[kb], o);
+            o = mm_k<4>(lds + O_S1, P_S1, 0, b1, o, lane);
             // trunc_exp backward: g * exp(clamp(x, -15, 15)) (activation.py:13-17), then into the fp16 Linear backward
             h4 dy1 = zero4();
             if (valid && g == 0) {
@@ -917,8 +930,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             __syncthreads(); ++st;
             // dX0 = W0^T dH1 : rows 0..15 are d h1 -> level-major [16][M] fp32 (values carry fp16 precision like autocast)
             f16x dx = zero16();
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) dx = MFMA(ld_a(lds + O_S0T, P_S0T, 0, kb, lane), dy0[kb], dx);
+            dx = mm_k<4>(lds + O_S0T, P_S0T, 0, dy0, dx, lane);
             if (valid) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -966,8 +978,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const f16x p1 = MFMA(ld_a(lds + O_P0, P_P0, 0, 0, lane), bp, zero16());
                 const h4 bq[4] = {relu_pack<0>(p1), relu_pack<1>(p1), relu_pack<2>(p1), relu_pack<3>(p1)};
                 f16x p2 = zero16();
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) p2 = MFMA(ld_a(lds + O_P1, P_P1, 0, kb, lane), bq[kb], p2);
+                p2 = mm_k<4>(lds + O_P1, P_P1, 0, bq, p2, lane);
                 const float s0 = sigmoid_h(p2[0]), s1 = sigmoid_h(p2[1]), s2 = sigmoid_h(p2[2]);
                 float ts0 = es0, ts1 = es1, ts2 = es2;          // d loss / d specular, total
                 if (a.shading == 2) { ts0 += gr; ts1 += gg; ts2 += gb; }
@@ -993,8 +1004,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int kb = 0; kb < 4; ++kb) { tile_put(TY(st), kb, dyp[kb], lane); tile_put(TX(st), kb, kb == 0 ? bp : zero4(), lane); }
                 __syncthreads(); ++st;
                 f16x dxp = zero16();
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) dxp = MFMA(ld_a(lds + O_P0T, P_P0T, 0, kb, lane), dyp[kb], dxp);
+                dxp = mm_k<4>(lds + O_P0T, P_P0T, 0, dyp, dxp, lane);
                 // rows 3 (g=0, reg 3), 4 and 5 (g=1, regs 0,1) are d feat
                 if (g == 0) dq3 = (float)(_Float16)dxp[3];
                 else { dq0 = (float)(_Float16)dxp[0]; dq1 = (float)(_Float16)dxp[1]; }
