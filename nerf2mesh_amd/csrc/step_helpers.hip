@@ -183,6 +183,22 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
     const bool g_half = (t.g_half_mask >> k) & 1u;
     float p[4], m[4], v[4], g[4];
     const bool full = i0 + 4u <= n;                                   // tensors are 16-byte aligned (torch allocations)
+    // the partner tensor's two rows (see below) are requested together with this tensor's values: one memory round trip per thread, not two
+    const int pk = t.partner[k];
+    const uint32_t r0 = i0 >> 1, n1 = pk >= 0 ? t.n[pk] : 0u;
+    float p1[2] = {0.f, 0.f}, m1v[2] = {0.f, 0.f}, v1v[2] = {0.f, 0.f}, g1v[2] = {0.f, 0.f};
+    if (pk >= 0) {
+        const float* __restrict__ P1 = reinterpret_cast<const float*>(t.p[pk]);
+        const float* __restrict__ M1 = reinterpret_cast<const float*>(t.m[pk]);
+        const float* __restrict__ V1 = reinterpret_cast<const float*>(t.v[pk]);
+        const bool g1_half = (t.g_half_mask >> pk) & 1u;
+#pragma unroll
+        for (uint32_t e = 0; e < 2; ++e) {
+            if (r0 + e >= n1) continue;
+            p1[e] = P1[r0 + e]; m1v[e] = M1[r0 + e]; v1v[e] = V1[r0 + e];
+            g1v[e] = g1_half ? (float)reinterpret_cast<const _Float16*>(t.g[pk])[r0 + e] : reinterpret_cast<const float*>(t.g[pk])[r0 + e];
+        }
+    }
     if (full) {
         const float4 pp = *reinterpret_cast<const float4*>(P + i0), mm = *reinterpret_cast<const float4*>(M + i0),
                      vv = *reinterpret_cast<const float4*>(V + i0);
@@ -213,7 +229,6 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
         const float denom = sqrtf(v[e]) / bc2_sqrt + eps;
         p[e] -= step_size * m[e] / denom;
     }
-    const int pk = t.partner[k];
     if (clear_g)
         for (uint32_t e = 0; e < 4u && i0 + e < n; ++e) reinterpret_cast<float*>(t.g[k])[i0 + e] = 0.0f;
     if (full) {
@@ -231,21 +246,19 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
         // this [rows,2] tensor shares a packed table with the [rows,1] tensor `pk`: the same thread updates rows r0, r0+1 of that
         // tensor too and writes the two complete 8-byte packed rows with one 16-byte store (separate column writes at an 8-byte
         // stride cost 22 us more, measured)
-        const uint32_t r0 = i0 >> 1, n1 = t.n[pk];
         float* __restrict__ P1 = reinterpret_cast<float*>(t.p[pk]);
         float* __restrict__ M1 = reinterpret_cast<float*>(t.m[pk]);
         float* __restrict__ V1 = reinterpret_cast<float*>(t.v[pk]);
-        const bool g1_half = (t.g_half_mask >> pk) & 1u;
         const float bc1p = bias[2u * t.slot[pk]], bc2p_sqrt = bias[2u * t.slot[pk] + 1u];      // the partner tensor's own step count
         const float step1 = t.lr[pk] / bc1p;
         float q[2] = {0.f, 0.f};
 #pragma unroll
         for (uint32_t e = 0; e < 2; ++e) {
             if (r0 + e >= n1) continue;
-            const float gr = (g1_half ? (float)reinterpret_cast<const _Float16*>(t.g[pk])[r0 + e] : reinterpret_cast<const float*>(t.g[pk])[r0 + e]) * inv_scale;
-            const float m1 = beta1 * M1[r0 + e] + omb1 * gr;
-            const float v1 = beta2 * V1[r0 + e] + omb2 * gr * gr;
-            q[e] = P1[r0 + e] - step1 * m1 / (sqrtf(v1) / bc2p_sqrt + eps);
+            const float gr = g1v[e] * inv_scale;
+            const float m1 = beta1 * m1v[e] + omb1 * gr;
+            const float v1 = beta2 * v1v[e] + omb2 * gr * gr;
+            q[e] = p1[e] - step1 * m1 / (sqrtf(v1) / bc2p_sqrt + eps);
             P1[r0 + e] = q[e]; M1[r0 + e] = m1; V1[r0 + e] = v1;
         }
         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
