@@ -332,7 +332,9 @@ def main():
                                 "sdf": "nerf_synthetic/lego --sdf stage-0 -O --bound 1 --dt_gamma 0 (NeuS alpha, finite-difference normals, eikonal loss)",
                                 "garden": "mip-360-style stage-0 -O --bound 16 --dt_gamma 1/256 (5 cascades, inner/outer TV) on the synthetic scene"}[args.recipe]
                                + ", 800x800 x 100 synthetic views, num_points target 2^18/GPU (adaptive num_rays), occupancy refresh every 16 steps",
-                   "parallelism": f"dp{world} (rays sharded, grad all-reduce over {dist.get_backend()})" if world > 1 else "single GPU",
+                   "parallelism": (f"dp{world} (rays sharded; table gradients reduce-scattered, Adam sharded over the ranks, packed rows all-gathered; "
+                                   f"{dist.get_backend()})" if getattr(tr, "shard", False) else
+                                   f"dp{world} (rays sharded, grad all-reduce over {dist.get_backend()})") if world > 1 else "single GPU",
                    "mlp": "nn.Linear (unfused)" if args.unfused else "fused MFMA field kernels",
                    "driver": "engine.Stage0Engine (fixed launch sequence)" if use_engine else "trainer.Stage0Trainer (torch.autograd)", "pretrain_steps": args.pretrain, "samples_per_step_per_gpu": samples / args.steps / world,
                    "rays_per_step_per_gpu": rays / args.steps / world, "params": 18367240},

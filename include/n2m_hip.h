@@ -108,6 +108,13 @@ int n2m_march_rays_train_fused(const float* rays_o, const float* rays_d, const u
                                int32_t* rays, int32_t* counter, const float* noises, uint32_t max_points,
                                void* workspace, uint64_t workspace_bytes, void* stream);
 
+/* Process-wide settings of the binned table backward (all n2m_grid_encode_backward_binned* / n2m_grad_total_variation_binned calls that
+ * follow).  tv_stride: floats between consecutive rows of the TV table (1 = an fp32 [rows,1] tensor as in gridencoder.h:15; 2 = the
+ * density column of the packed {fp32, half2} table n2m_grid_encode_forward_packed reads -- a caller that shards the optimizer over ranks
+ * keeps only that copy complete).  overflow_div: a gradient row whose magnitude exceeds max_of_type / overflow_div raises found_inf;
+ * a caller that sums the tables over W ranks passes W, so that an overflow only the cross-rank sum would produce is caught before it. */
+int n2m_grid_backward_config(int tv_stride, float overflow_div);
+
 /* Measurement aid for the shared fill of n2m_grid_encode_backward_binned_pair: on != 0 arms shader-clock stamps in one of its workgroups
  * (first 8 tile iterations x 6 phase boundaries) and in two work items of each accumulate kernel (5 boundaries); out (may be NULL,
  * else 116 words) receives the stamps of the last armed launch.  Synchronises. */

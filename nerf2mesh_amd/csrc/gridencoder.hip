@@ -13,6 +13,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "n2m_common.hpp"
 
 namespace {
@@ -1095,7 +1097,7 @@ __device__ __forceinline__ long long to_fixed(float v, float scale) {
 // Total-variation term of one cell (gridencoder.cu:505-609): w * sum_nb (g - g_nb) / sqrt(sum_nb (g - g_nb)^2 + 1e-9) over the
 // up-to-6 axis neighbours, in the reference's order (+1 then -1 neighbour, axis by axis).  C = 1 tables.
 __device__ __forceinline__ float tv_term(const float* __restrict__ tab, const Indexer<3>& ix, uint32_t (&cell)[3], uint32_t here,
-                                         uint32_t resolution, float w) {
+                                         uint32_t resolution, float w, uint32_t stride = 1) {
     constexpr uint32_t D = 3;
     uint32_t nb_row[2 * D];
     bool nb_ok[2 * D];
@@ -1110,10 +1112,10 @@ __device__ __forceinline__ float tv_term(const float* __restrict__ tab, const In
         nb_row[2 * d + 1] = nb_ok[2 * d + 1] ? ix.row(cell) : here;
         cell[d] = cur;
     }
-    const float centre = tab[here];
+    const float centre = tab[(size_t)here * stride];
     float nb[2 * D];
 #pragma unroll
-    for (uint32_t k = 0; k < 2 * D; ++k) nb[k] = tab[nb_row[k]];
+    for (uint32_t k = 0; k < 2 * D; ++k) nb[k] = tab[(size_t)nb_row[k] * stride];
     float sum = 0.f, sq = 0.f;
 #pragma unroll
     for (uint32_t k = 0; k < 2 * D; ++k)
@@ -1127,6 +1129,7 @@ struct TvParams {
     const float* table;       // fp32 [rows, 1]; NULL = no TV
     float weight, weight_outer, inner01;      // inner01: half extent of the inner region in [0,1] input space (>= 0.5: everything is inner)
     const float* scale_ptr;
+    uint32_t stride = 1;      // floats between consecutive rows of `table`: 2 reads the density column of a packed {fp32, half2} table
 };
 
 // MODE 0: backward entries; MODE 1: TV entries only (8 samples per thread); MODE 2: backward + TV folded into vertex 000's
@@ -1175,7 +1178,7 @@ bin_fill_kernel(const T* __restrict__ grad /*[L,Bstride,C], first sample of this
                 const bool inner = fmaxf(fmaxf(fabsf(x[0] - 0.5f), fabsf(x[1] - 0.5f)), fabsf(x[2] - 0.5f)) <= tv.inner01;
                 float w = (inner ? tv.weight : tv.weight_outer);
                 if (tv.scale_ptr) w *= *tv.scale_ptr;
-                tvv = tv_term(tv.table + (size_t)plan.row0[level], ix, cell, ix.row(cell), lv.resolution[level], w / (float)(2 * D));
+                tvv = tv_term(tv.table + (size_t)plan.row0[level] * tv.stride, ix, cell, ix.row(cell), lv.resolution[level], w / (float)(2 * D), tv.stride);
                 const float a = fabsf(tvv);
                 vmax += a <= 3.0e38f ? a : 1.0f;                         // |w*g + tv| <= |g| + |tv|
             }
@@ -1221,7 +1224,7 @@ bin_fill_kernel(const T* __restrict__ grad /*[L,Bstride,C], first sample of this
             const uint32_t here = ix.row(cell);
             const bool inner = fmaxf(fmaxf(fabsf(x[0] - 0.5f), fabsf(x[1] - 0.5f)), fabsf(x[2] - 0.5f)) <= tv.inner01;
             const float w = tv.scale_ptr ? (inner ? tv.weight : tv.weight_outer) * sc : (inner ? tv.weight : tv.weight_outer);
-            const float p = tv_term(tv.table + (size_t)plan.row0[level], ix, cell, here, resolution, w / (float)(2 * D));
+            const float p = tv_term(tv.table + (size_t)plan.row0[level] * tv.stride, ix, cell, here, resolution, w / (float)(2 * D), tv.stride);
             const uint32_t bits = __float_as_uint(p);
             pm.split(here, e_part[c8], e_rel[c8]);
             e_val[c8] = bits;
@@ -1340,7 +1343,7 @@ __device__ __forceinline__ void pair_entries(const PairCtx& cx, const Indexer<3>
         float w = (inner ? cx.tv.weight : cx.tv.weight_outer);
         if (cx.tv.scale_ptr) w *= *cx.tv.scale_ptr;
         w /= (float)(2 * D);
-        if constexpr (IMODE == 0) tvv = tv_term(cx.tv_tab, ix, cell, rows[0], cx.resolution, w);
+        if constexpr (IMODE == 0) tvv = tv_term(cx.tv_tab, ix, cell, rows[0], cx.resolution, w, cx.tv.stride);
         else {
             // gridencoder.cu:505-609, neighbours in the reference's order: +x -x +y -y +z -z; out-of-grid ones are skipped
             const float* __restrict__ tab = cx.tv_tab;
@@ -1348,10 +1351,11 @@ __device__ __forceinline__ void pair_entries(const PairCtx& cx, const Indexer<3>
                                         rows[4], comb(tx[0], ty[0], tz[0] - sz)};
             const bool nb_ok[6] = {cell[0] < cx.resolution, cell[0] > 0u, cell[1] < cx.resolution, cell[1] > 0u,
                                    cell[2] < cx.resolution, cell[2] > 0u};
-            const float centre = tab[rows[0]];
+            const uint32_t st = cx.tv.stride;
+            const float centre = tab[(size_t)rows[0] * st];
             float nb[6];
 #pragma unroll
-            for (uint32_t k = 0; k < 6; ++k) nb[k] = tab[nb_ok[k] ? nb_row[k] : rows[0]];
+            for (uint32_t k = 0; k < 6; ++k) nb[k] = tab[(size_t)(nb_ok[k] ? nb_row[k] : rows[0]) * st];
             float sum = 0.f, sq = 0.f;
 #pragma unroll
             for (uint32_t k = 0; k < 6; ++k)
@@ -1536,7 +1540,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
             const bool bad2 = !(fabsf(g2x) <= 3.0e38f) || !(fabsf(g2y) <= 3.0e38f);
             if ((!(a1 <= 3.0e38f) || bad2) && found_inf) *found_inf = 1.0f;
             if (bad2) vmax2 = fmaxf(vmax2, 1.0f);
-            const PairCtx cx{tv, tv.table ? tv.table + (size_t)plan.row0[level] : nullptr, scale, lv.resolution[level], align_corners, interp};
+            const PairCtx cx{tv, tv.table ? tv.table + (size_t)plan.row0[level] * tv.stride : nullptr, scale, lv.resolution[level], align_corners, interp};
             // one straight-line body per index mode (wave-uniform per level) instead of three-way branches around every row
             if (fast_hash) pair_entries<TV, 1, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell);
             else if (fast_dense && parts > 1u) pair_entries<TV, 2, true>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell);
@@ -1672,7 +1676,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)
 bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners,
                       const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ directory,
                       const uint64_t* __restrict__ log, float* __restrict__ found_inf, const uint16_t* __restrict__ log_rel = nullptr,
-                      const uint32_t* __restrict__ log_val = nullptr, bool overwrite = false, uint32_t dbg = 0) {
+                      const uint32_t* __restrict__ log_val = nullptr, bool overwrite = false, uint32_t dbg = 0, float inf_bound = 0.0f) {
     // overwrite: the gradient table holds no earlier sums.  Partitions owned by one workgroup (Gl == 1) are then STORED in full,
     // zeros included -- no read-modify-write round trips in the flush (measured: eight dependent load-add-store steps per item were
     // a third of this kernel) and no zero-fill of the table before the call; levels split over several groups still add
@@ -1689,10 +1693,12 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
         N2M_ACC_STAMP(0);
         uint32_t level = 0;
         while (item >= plan.item_prefix[level + 1]) ++level;
-        const uint32_t vm = level_max[level];
+        // the level's largest magnitude through the VECTOR memory path: as a scalar load its ~1 us would be waited for (in-order scalar
+        // counter) before the directory below could even be requested
+        const uint32_t vm_v = __hip_atomic_load(level_max + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t Gl = plan.groups[level];
         const bool store_all = overwrite && Gl == 1u;
-        if (vm == 0u && !store_all) continue;                               // no non-zero finite update in this level
+        if (!store_all && (uint32_t)__builtin_amdgcn_readfirstlane((int)vm_v) == 0u) continue;     // no non-zero finite update in this level
         const uint32_t local = item - plan.item_prefix[level];
         const uint32_t part0 = (local / Gl) * SUB, grp = local - (local / Gl) * Gl;
         const uint32_t parts = plan.parts[level], size = plan.size[level];
@@ -1710,12 +1716,6 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
         auto global_row = [&](uint32_t u, uint32_t rel) {                    // table row of entry `rel` of partition part0 + u
             return interleaved ? ((((rel >> 4) * parts + part0 + u) << 4) | (rel & 15u)) : (((part0 + u) << kLog2P) + rel);
         };
-
-        // unit = 2^-ex with |v| * 2^ex < 2^38 for every finite v of the level
-        int ex = 37 - ((int)((vm >> 23) & 255u) - 127);
-        ex = ex < -126 ? -126 : (ex > 126 ? 126 : ex);
-        const float scale = __uint_as_float((uint32_t)(ex + 127) << 23);
-        const float inv = __uint_as_float((uint32_t)(127 - ex) << 23);
 
         T* __restrict__ gtab = grad_table + (size_t)row0 * C;
         const uint32_t* __restrict__ dir_l = directory + plan.dir_base[level];
@@ -1736,6 +1736,12 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
         if (tid == 0) nonfinite_seen = 0u;
         __syncthreads();
         N2M_ACC_STAMP(1);
+        // unit = 2^-ex with |v| * 2^ex < 2^38 for every finite v of the level
+        const uint32_t vm = (uint32_t)__builtin_amdgcn_readfirstlane((int)vm_v);
+        int ex = 37 - ((int)((vm >> 23) & 255u) - 127);
+        ex = ex < -126 ? -126 : (ex > 126 ? 126 : ex);
+        const float scale = __uint_as_float((uint32_t)(ex + 127) << 23);
+        const float inv = __uint_as_float((uint32_t)(127 - ex) << 23);
         // walk(body): body(rel0, u, bits) for every entry of this item's runs
         auto walk = [&](auto&& body) {
             const uint32_t n_t = vm != 0u ? my_tiles : 0u;
@@ -1850,7 +1856,7 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
                 const long long a = (long long)bin_acc[rel];
                 if (a != 0 || store_all) {
                     const float f = (float)a * inv;
-                    if (!(fabsf(f) <= 3.0e38f) && found_inf) *found_inf = 1.0f;
+                    if (!(fabsf(f) <= (inf_bound > 0.0f ? inf_bound : 3.0e38f)) && found_inf) *found_inf = 1.0f;
                     if (store_all) gtab[row] = f;
                     else if (Gl == 1u) gtab[row] += f;
                     else unsafeAtomicAdd(gtab + row, f);
@@ -1860,7 +1866,8 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
                 const long long a0 = (long long)bin_acc[rel * 2u], a1 = (long long)bin_acc[rel * 2u + 1u];
                 if ((a0 | a1) != 0 || store_all) {
                     const float f0 = (float)a0 * inv, f1 = (float)a1 * inv;
-                    if (!(fabsf(f0) <= 65504.0f && fabsf(f1) <= 65504.0f) && found_inf) *found_inf = 1.0f;       // rounds to inf in fp16
+                    const float b16 = inf_bound > 0.0f ? inf_bound : 65504.0f;
+                    if (!(fabsf(f0) <= b16 && fabsf(f1) <= b16) && found_inf) *found_inf = 1.0f;       // rounds to inf in fp16 (or could, summed over ranks)
                     h2* dst = reinterpret_cast<h2*>(gtab + (size_t)row * 2u);
                     if (store_all) {
                         h2 o;
@@ -2067,6 +2074,13 @@ void launch_tv(const TvArgs& a) {
 
 
 // ---- binned path: host plan + launches
+// Process-wide settings of the binned backward (n2m_grid_backward_config): the row stride of the TV table and the margin of the
+// gradient overflow check.  A multi-GPU caller that SUMS gradient tables over W ranks sets the margin to W: a row whose local sum exceeds
+// max / W could overflow in the cross-rank sum, so it raises found_inf already (GradScaler then skips and backs off one notch early
+// instead of never seeing an overflow that only the reduction produces).
+static std::atomic<uint32_t> g_cfg_tv_stride{1};
+static std::atomic<float> g_cfg_overflow_div{1.0f};
+
 struct BinLayout {
     BinPlan plan;
     size_t dir_words, log_entries, bytes;
@@ -2137,8 +2151,9 @@ int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table
                                                                                                      level_max, directory, log, found_inf);
         N2M_CHECK_LAUNCH();
         const uint32_t items = lay.plan.item_prefix[max_level];
-        bin_accumulate_kernel<T, C, BinGeom<C>::P, 1><<<items < 2048u ? items : 2048u, 1024, kBinAccBytes, s>>>(grad_table, lay.plan, lv, gridtype, align, level_max,
-                                                                                                directory, log, found_inf);
+        bin_accumulate_kernel<T, C, BinGeom<C>::P, 1><<<items < 2048u ? items : 2048u, 1024, kBinAccBytes, s>>>(
+            grad_table, lay.plan, lv, gridtype, align, level_max, directory, log, found_inf, nullptr, nullptr, false, 0u,
+            (sizeof(T) == 2 ? 65504.0f : 3.0e38f) / g_cfg_overflow_div.load());
         N2M_CHECK_LAUNCH();
     }
     return 0;
@@ -2227,22 +2242,12 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         const uint32_t nb = items < acc_cap2 ? items : acc_cap2;
         static const uint32_t acc_dbg = getenv("N2M_ACC_DEBUG") ? (uint32_t)atoi(getenv("N2M_ACC_DEBUG")) : 0u;   // measurement switches (wrong results)
         static const uint32_t acc_cap = getenv("N2M_ACC_GRID") ? (uint32_t)atoi(getenv("N2M_ACC_GRID")) : 4096u;    // A/B: persistent workgroups
+        const float odiv = g_cfg_overflow_div.load();
         bin_accumulate_kernel<float, 1, kPairP, 2, true><<<items1 < acc_cap ? items1 : acc_cap, 1024, kPairP * 16, s>>>(
-            table1, plan1, lv, gridtype, align, level_max, directory, nullptr, found_inf, log_rel, log_v1, ow, acc_dbg);
+            table1, plan1, lv, gridtype, align, level_max, directory, nullptr, found_inf, log_rel, log_v1, ow, acc_dbg, 3.0e38f / odiv);
         N2M_CHECK_LAUNCH();
-        static const bool acc2_sub2 = getenv("N2M_ACC2_SUB") != nullptr && atoi(getenv("N2M_ACC2_SUB")) == 2;      // A/B: 8192-row items for the fp16 table too
-        if (acc2_sub2) {
-            static bool attr2 = false;
-            if (!attr2) {
-                (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<_Float16, 2, kPairP, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 32));
-                attr2 = true;
-            }
-            BinPlan plan2b = plan1;       // same item structure as the fp32 table: pairs of partitions; its split levels must be cleared for table 2 too
-            bin_accumulate_kernel<_Float16, 2, kPairP, 2, true><<<items1 < acc_cap ? items1 : acc_cap, 1024, kPairP * 32, s>>>(
-                table2, plan2b, lv, gridtype, align, level_max + kMaxLevels, directory, nullptr, found_inf, log_rel, log_v2, ow && cm1 == cm2, acc_dbg);
-        } else
         bin_accumulate_kernel<_Float16, 2, kPairP, 1, true><<<nb, 1024, kPairP * 16, s>>>(table2, plan2, lv, gridtype, align, level_max + kMaxLevels,
-                                                                                        directory, nullptr, found_inf, log_rel, log_v2, ow, acc_dbg);
+                                                                                        directory, nullptr, found_inf, log_rel, log_v2, ow, acc_dbg, 65504.0f / odiv);
         N2M_CHECK_LAUNCH();
     }
     return 0;
@@ -2414,7 +2419,7 @@ extern "C" int n2m_grid_encode_backward_binned(const void* grad, const float* in
     hipStream_t s = (hipStream_t)stream;
     const size_t esz = dtype == N2M_F16 ? 2 : 4;
     const LevelTable lv = make_levels(L, S, H);
-    const TvParams tv{tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale};
+    const TvParams tv{tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale, g_cfg_tv_stride.load()};
     N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (4.0 * D + (double)max_level * C * esz + 2.0 * max_level * (1u << D) * C * esz +
                                              (tv_embeddings ? (double)L * (1 + 2 * D) * 4.0 : 0.0)));
     if (dtype == N2M_F16)
@@ -2438,7 +2443,7 @@ extern "C" int n2m_grad_total_variation_binned(const float* inputs, const float*
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const LevelTable lv = make_levels(L, S, H);
-    const TvParams tv{embeddings, weight, weight_outer, inner01, weight_scale};
+    const TvParams tv{embeddings, weight, weight_outer, inner01, weight_scale, g_cfg_tv_stride.load()};
     N2M_PROF(N2M_K_GRID_TV, s, (double)B * (4.0 * D + (double)L * (1 + 2 * D) * C * 4.0 + (double)L * C * 8.0));
     return launch_binned<float, 1, 1>(nullptr, inputs, tv, grad, B, L, host_offsets, lv, gridtype, align_corners != 0, 0u, workspace,
                                       (size_t)workspace_bytes, s, fn);
@@ -2500,7 +2505,7 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
         return 0;
     }
     const LevelTable lv = make_levels(L, S, H);
-    const TvParams tv{tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale};
+    const TvParams tv{tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale, g_cfg_tv_stride.load()};
     // algorithmic bytes of BOTH encoders' backward + the TV stencil reads (a half call: its eight levels)
     const double lvls = half ? 8.0 : (double)max_level;
     N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (12.0 + lvls * (4 + 4) + 2.0 * lvls * 8 * (4 + 4) + (tv_embeddings ? lvls * 7 * 4.0 : 0.0)));
@@ -2561,3 +2566,11 @@ extern "C" int n2m_debug_fill_times(int on, unsigned long long* out) {
     N2M_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fill_timing_on), &v, sizeof(v)));
     return 0;
 }
+
+extern "C" int n2m_grid_backward_config(int tv_stride, float overflow_div) {
+    N2M_REQUIRE((tv_stride == 1 || tv_stride == 2) && overflow_div >= 1.0f, N2M_EINVAL, "grid_backward_config: tv_stride 1 or 2, overflow_div >= 1");
+    g_cfg_tv_stride = (uint32_t)tv_stride;
+    g_cfg_overflow_div = overflow_div;
+    return 0;
+}
+

@@ -128,6 +128,28 @@ class Stage0Engine:
         self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self._seed = None
         self._aabb = None
+        # ---- multi-GPU: optimizer sharded over the ranks (ZeRO-1 for the two tables).  Gradient rows are reduce-scattered (fine levels
+        # first, under the coarse half of the backward), each rank runs Adam on 1/W of the rows and the packed 8-byte rows the forward
+        # reads are all-gathered: fewer wire bytes than the all-reduce (73.5 + 49 MB against 2 x 73.5) and 1/W of the 540 MB Adam pass.
+        # Only the packed table stays complete on every rank: the TV stencil reads its density column (n2m_grid_backward_config);
+        # the fp32 parameter tensors are current inside the own shard only until sync_parameters() gathers them (checkpoint, export).
+        self.shard = False
+        if world_size > 1:
+            import torch.distributed as dist
+            W, split = world_size, int(self.ho[8]) if self.Lv == 16 else 0
+            fine = self.rows - split
+            ok = (self.Lv == 16 and split % W == 0 and fine % W == 0 and (split // W) % 2 == 0 and (fine // W) % 2 == 0
+                  and os.environ.get("N2M_SHARD_ADAM", "1") != "0")
+            if ok:
+                self.shard = True
+                self._split, self._Cs, self._Fs = split, split // W, fine // W
+                f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+                f16 = lambda *sh: torch.empty(*sh, dtype=torch.float16, device=dev)
+                self.g1s = {"c": f32(self._Cs, 1), "f": f32(self._Fs, 1)}
+                self.g2s = {"c": f16(self._Cs, 2), "f": f16(self._Fs, 2)}
+                self._inplace_gather = dist.get_backend() == "nccl"      # RCCL gathers in place; gloo (tests) gets a copy of the shard
+            # gradients are SUMMED over W ranks: a local row above max / W raises found_inf already (see n2m_grid_backward_config)
+            L.call("n2m_grid_backward_config", 2 if self.shard else 1, float(W))
 
     # ------------------------------------------------------------------------------------------------ configuration
     @staticmethod
@@ -188,6 +210,8 @@ class Stage0Engine:
         optimizer update of the step before."""
         if self.sync is not None:
             self.sync.sync_rng_for_grid_update(self.global_step)
+        if self.shard:
+            self.sync_parameters(density_only=True)      # the refresh evaluates the density from the fp32 table: gather the other ranks' rows
         self.model.update_extra_state()
 
     def _prepare(self, N):
@@ -301,6 +325,8 @@ class Stage0Engine:
         self._packed = pk
         desc = L.AdamDesc()
         params = [p for g in o.param_groups for p in g["params"]]
+        if self.shard:
+            return self._adam_desc_sharded(full, key, pk, params)
         grads = {model.encoder.embeddings: (self.g1, 0, 0, (pk, 2)), model.encoder_color.embeddings: (self.g2, 1, 0, (pk, 3))}
         for i, p in enumerate(self.mlp_params):
             grads[p] = (self.dw_views[i], 0, 1, None)
@@ -325,6 +351,78 @@ class Stage0Engine:
         d = self._desc[key] = (desc, participants, groups)
         return d
 
+    def _shard_ranges(self):
+        """(first row, rows) of this rank's slice of the coarse half (levels 0..7) and of the fine half (levels 8..15)."""
+        r = self.rank
+        return {"c": (r * self._Cs, self._Cs), "f": (self._split + r * self._Fs, self._Fs)}
+
+    def _adam_desc_sharded(self, full, key, pk, params):
+        """Descriptor of the rank's OWN rows: per level half one [rows,1] + one [rows,2] entry (pointers offset into the full state
+        tensors, gradients = the reduce-scattered slices, working copy = the same rows of the packed table), then the MLP weights."""
+        o, model = self.optimizer, self.model
+        desc = L.AdamDesc()
+        e1p, e2p = model.encoder.embeddings, model.encoder_color.embeddings
+        group_of = {p: gi for gi, g in enumerate(o.param_groups) for p in g["params"]}
+        k, participants, groups = 0, 0, []
+        for h, (row0, n) in self._shard_ranges().items():
+            for p, C, g, is_half, mode in ((e1p, 1, self.g1s[h], 0, 2), (e2p, 2, self.g2s[h], 1, 3)):
+                st = o.state[p]
+                off = row0 * C * 4
+                desc.param[k], desc.grad[k] = p.data_ptr() + off, g.data_ptr()
+                desc.exp_avg[k], desc.exp_avg_sq[k] = st["exp_avg"].data_ptr() + off, st["exp_avg_sq"].data_ptr() + off
+                desc.half_shadow[k], desc.shadow_mode[k] = pk.data_ptr() + row0 * 8, mode
+                desc.numel[k], desc.grad_is_half[k], desc.clear_grad[k] = n * C, is_half, 0
+                desc.slot[k] = o._slot[p]
+                participants |= 1 << (o._slot[p] - 1)
+                groups.append(group_of[p])
+                k += 1
+        live = set(self.mlp_params[:5]) | (set(self.mlp_params[5:]) if full else set())
+        views = dict(zip(self.mlp_params, self.dw_views))
+        for p in params:
+            if p not in live:
+                continue
+            st = o.state[p]
+            desc.param[k], desc.grad[k] = p.data_ptr(), views[p].data_ptr()
+            desc.exp_avg[k], desc.exp_avg_sq[k] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            desc.half_shadow[k], desc.shadow_mode[k] = None, 0
+            desc.numel[k], desc.grad_is_half[k], desc.clear_grad[k] = p.numel(), 0, 1
+            desc.slot[k] = o._slot[p]
+            participants |= 1 << (o._slot[p] - 1)
+            groups.append(group_of[p])
+            k += 1
+        desc.count = k
+        d = self._desc[key] = (desc, participants, groups)
+        return d
+
+    def _gather_packed(self):
+        """All-gather of the packed rows after the sharded Adam (each rank has refreshed its own rows); waited for at once: the next
+        kernel on the stream is the forward that reads them."""
+        import torch.distributed as dist
+        flat = self._packed.view(-1)                 # [rows * 2] fp32 words, 8 bytes per row
+        works = []
+        for h, (row0, n) in self._shard_ranges().items():
+            lo = 0 if h == "c" else self._split
+            out = flat[lo * 2:(lo + self.world * n) * 2]
+            mine = flat[row0 * 2:(row0 + n) * 2]
+            works.append(dist.all_gather_into_tensor(out, mine if self._inplace_gather else mine.clone(), async_op=True))
+        for w in works:
+            w.wait()
+
+    @torch.no_grad()
+    def sync_parameters(self, density_only=False):
+        """Sharded optimizer: bring the fp32 parameter tensors of both tables up to date on every rank (each rank owns 1/W of the
+        rows; the training step itself only needs the packed copy).  Called before the occupancy refresh (density table, every 16
+        steps: 24.5 MB) and to be called before a checkpoint, an export, an evaluation or a comparison."""
+        if not self.shard:
+            return
+        import torch.distributed as dist
+        tables = ((self.model.encoder.embeddings, 1),) if density_only else ((self.model.encoder.embeddings, 1), (self.model.encoder_color.embeddings, 2))
+        for p, C in tables:
+            flat = p.data.view(-1)
+            for h, (row0, n) in self._shard_ranges().items():
+                lo = 0 if h == "c" else self._split
+                dist.all_gather_into_tensor(flat[lo * C:(lo + self.world * n) * C], flat[row0 * C:(row0 + n) * C].clone())
+
     def _optimizer_step(self, full, lr_factor, loss_out=None):
         o = self.optimizer
         desc, participants, groups = self._adam_desc(full)
@@ -334,6 +432,8 @@ class Stage0Engine:
         s = L.stream()
         L.call("n2m_adam_step", ctypes.addressof(desc), float(b1), float(b2), float(o.param_groups[0]["eps"]), _p(o.scale), _p(o.found_inf),
                _p(o.bias), s)
+        if self.shard:
+            self._gather_packed()
         gf, bf, gi = o.growth
         if loss_out is None:
             L.call("n2m_scaler_update_slots", _p(o.scale), _p(o.growth_tracker), _p(o.found_inf), _p(o.steps), _p(o.bias), participants,
@@ -410,12 +510,20 @@ class Stage0Engine:
             tv = opt.lambda_tv > 0
             bwd_args = (_p(w["d_h1"]), _p(w["d_h2"]), _p(xyzs), self.ho.ctypes.data, _p(self.g1), _p(self.g2), M,
                         self.Lv, self.Lv, self.S, self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id,
-                        _p(e1.embeddings) if tv else None, float(opt.lambda_tv), float(opt.lambda_tv * (10 if opt.bound > 1 else 1)),
+                        (_p(pk) if self.shard else _p(e1.embeddings)) if tv else None, float(opt.lambda_tv), float(opt.lambda_tv * (10 if opt.bound > 1 else 1)),
                         float(0.5 / model.bound), _p(seed) if tv else None, _p(o.found_inf), float(self.aff[0]), float(self.aff[1]), 1, _p(ws),
                         ws.numel(), s)
             if self.marker_at == 1:
                 self._marker = torch.cuda.Event(); self._marker.record()
-            if self.sync is not None and self.split_backward and self.Lv == 16:
+            if self.shard:
+                import torch.distributed as dist
+                sp = self._split
+                rs = lambda out, src: dist.reduce_scatter_tensor(out.view(-1), src.view(-1), op=dist.ReduceOp.SUM, async_op=True)
+                L.call("n2m_grid_encode_backward_binned_pair_half", *bwd_args, 1)
+                early = [rs(self.g1s["f"], self.g1[sp:]), rs(self.g2s["f"], self.g2[sp:])]          # fine rows: exchanged under the coarse half
+                L.call("n2m_grid_encode_backward_binned_pair_half", *bwd_args, 2)
+                early += [rs(self.g1s["c"], self.g1[:sp]), rs(self.g2s["c"], self.g2[:sp])]
+            elif self.sync is not None and self.split_backward and self.Lv == 16:
                 # multi-GPU: the table backward in two halves of the levels.  The rows of the fine half (levels 8..15: 68 % of the
                 # bytes) are final after the first call; their SUM all-reduce runs on the collective stream while the coarse half is
                 # still being computed, so most of the exchange hides behind the backward's own tail (at 0.75 ms per step
@@ -431,7 +539,18 @@ class Stage0Engine:
             self.g1.zero_()
             self.g2.zero_()
         # ---- [multi-GPU] one SUM all-reduce per fixed gradient buffer (the colour table's stays fp16) + the small bucket
-        if self.sync is not None:
+        if self.shard:
+            token = self.sync.all_reduce_sum_begin([], [self.dw, o.found_inf])
+            if M > 0:
+                for w_ in early:
+                    w_.wait()
+            else:                                       # no samples on this rank: its (zero) rows still take part
+                import torch.distributed as dist
+                sp = self._split
+                for out, src in ((self.g1s["f"], self.g1[sp:]), (self.g2s["f"], self.g2[sp:]), (self.g1s["c"], self.g1[:sp]), (self.g2s["c"], self.g2[:sp])):
+                    dist.reduce_scatter_tensor(out.view(-1), src.view(-1), op=dist.ReduceOp.SUM)
+            self.sync.all_reduce_sum_end(token)
+        elif self.sync is not None:
             if early is not None:
                 split = int(self.ho[8])
                 token = self.sync.all_reduce_sum_begin([self.g1[:split], self.g2[:split]], [self.dw, o.found_inf])
@@ -460,4 +579,5 @@ class Stage0Engine:
     @torch.no_grad()
     def eval_psnr(self, cam=0, downscale=4):
         from .trainer import Stage0Trainer
+        self.sync_parameters()
         return Stage0Trainer.eval_psnr(self, cam, downscale)

@@ -27,10 +27,14 @@ else:
     tr = Stage0Trainer(NeRFNetwork(opt), opt, synthetic.make_cameras(100, seed=0), device, rank=rank, world_size=world, seed=0)
 tr.mark_untrained()
 losses = [float(tr.train_step()) for _ in range(steps)]
+if hasattr(tr, "sync_parameters"):
+    tr.sync_parameters()              # sharded optimizer: every rank owns 1/W of the table rows until the fp32 tensors are gathered
 torch.cuda.synchronize()
 flat = torch.cat([p.detach().float().reshape(-1) for p in tr.model.parameters()])
 digest = torch.stack([flat.double().sum(), flat.double().abs().sum(), tr.optimizer.scale.double() if hasattr(tr.optimizer, "scale") else torch.zeros((), device=device).double(),
                       tr.optimizer.step_count.double() if hasattr(tr.optimizer, "step_count") else torch.zeros((), device=device).double()]).cpu()
+if rank == 0 and os.environ.get("N2M_DIST_DUMP"):          # every 97th parameter, for run-to-run comparisons (tests/test_parallel_gpu.py)
+    torch.save(flat[::97].cpu(), os.environ["N2M_DIST_DUMP"])
 ok = torch.isfinite(flat).all().item() and all(l == l for l in losses)
 if world > 1:
     gathered = [torch.zeros_like(digest) for _ in range(world)]
@@ -40,7 +44,7 @@ if world > 1:
 first, last = sum(losses[:5]) / 5, sum(losses[-5:]) / 5
 ok = ok and last < first
 if rank == 0:
-    print(f"DIST_CHECK {'OK' if ok else 'FAILED'} driver={type(tr).__name__} world={world} steps={steps} loss {first:.5f} -> {last:.5f} digest={[float(x) for x in digest]}")
+    print(f"DIST_CHECK {'OK' if ok else 'FAILED'} driver={type(tr).__name__} shard={getattr(tr, 'shard', False)} world={world} steps={steps} loss {first:.5f} -> {last:.5f} digest={[float(x) for x in digest]}")
 if world > 1:
     dist.destroy_process_group()
 sys.exit(0 if ok else 1)
