@@ -75,6 +75,38 @@ def test_adam_refreshes_packed_table_columns():
     assert torch.equal(pk.view(torch.float16)[:, 2:], b.detach().half())
 
 
+def test_adam_refreshes_packed_rows_at_an_odd_row_offset():
+    """The same with every tensor starting at an ODD row of its buffer -- what a rank of the sharded optimizer gets at 8 GPUs (its slice
+    of the coarse levels starts at row r * 240 695): the packed rows are then 8- but not 16-byte aligned, the kernel falls back to separate
+    column stores, and parameters / moments sit at 4-byte-aligned addresses."""
+    import torch
+    from nerf2mesh_amd.optim import FusedAdamAMP
+    torch.manual_seed(2)
+    rows = 1027
+    A, B, PK = torch.randn(rows + 1, 1, device="cuda"), torch.randn(rows + 1, 2, device="cuda"), torch.zeros(rows + 1, 2, device="cuda")
+    a, b, pk = A[1:].requires_grad_(), B[1:].requires_grad_(), PK[1:]                 # views at row 1
+    assert pk.data_ptr() % 16 == 8 and a.data_ptr() % 16 == 4
+    ra, rb = a.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    ref = torch.optim.Adam([{"params": [ra], "lr": 1e-2}, {"params": [rb], "lr": 3e-3}], eps=1e-15)
+    opt = FusedAdamAMP([{"params": [a], "lr": 1e-2}, {"params": [b], "lr": 3e-3}], lr=1e-2, eps=1e-15, amp=False)
+    for p in (a, b):                                                                    # moments at odd offsets too
+        st = opt.state[p]
+        for k in ("exp_avg", "exp_avg_sq"):
+            buf = torch.zeros(p.numel() + p.shape[1], device="cuda")
+            st[k] = buf[p.shape[1]:].view_as(p)
+    opt.state_epoch = getattr(opt, "state_epoch", 0) + 1
+    opt.shadows[a] = lambda: (pk, 2)
+    opt.shadows[b] = lambda: (pk, 3)
+    for _ in range(3):
+        a.grad, b.grad = torch.randn_like(a), torch.randn_like(b)
+        ra.grad, rb.grad = a.grad.clone(), b.grad.clone()
+        opt.step(); ref.step()
+    assert torch.allclose(a, ra, rtol=1e-5, atol=1e-7) and torch.allclose(b, rb, rtol=1e-5, atol=1e-7)
+    assert torch.equal(pk[:, 0], a.detach()[:, 0])
+    assert torch.equal(pk.contiguous().view(torch.float16)[:, 2:], b.detach().half())
+    assert float(PK[0].abs().sum()) == 0.0 and torch.equal(A[0], A[0]) and float((B[0] - B[0]).abs().sum()) == 0.0      # row 0 untouched
+
+
 def test_backward_kernels_raise_found_inf():
     """The producing kernels flag non-finite gradients (binned table backward: value read / sum written; field backward: dW)."""
     import torch
