@@ -1445,10 +1445,19 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
                      uint32_t* __restrict__ directory, uint16_t* __restrict__ log_rel, uint32_t* __restrict__ log_v1,
                      uint32_t* __restrict__ log_v2, float* __restrict__ found_inf, float in_scale, float in_offset,
                      float* __restrict__ clear1, _Float16* __restrict__ clear2, uint32_t clear_mask1, uint32_t clear_mask2,
-                     uint32_t merge_levels, uint32_t groups_x, uint32_t slot_begin) {
+                     uint32_t merge_levels, uint32_t groups_x, uint32_t slot_begin, unsigned long long* __restrict__ lm_ready,
+                     unsigned long long lm_token) {
     __builtin_amdgcn_s_setprio(3);
     constexpr uint32_t D = 3;
     constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
+    // The level maxima start from zero.  Workgroup 0 clears them itself and then publishes this launch's token; every workgroup waits for
+    // the token before its ONE atomicMax at the very end (a whole tile walk later).  That removes a 256-byte memset launch from the
+    // stream -- a kernel boundary costs 6-7 us here whatever the kernel does (timeline).
+    if (blockIdx.x == 0u) {
+        if (threadIdx.x < 2u * kMaxLevels) level_max[threadIdx.x] = 0u;
+        __syncthreads();
+        if (threadIdx.x == 0u) __hip_atomic_store(lm_ready, lm_token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     // The logs are structure-of-arrays: row-in-partition as u16 (shared by both tables) + one 4-byte value array per table =
     // 10 bytes per update pair instead of 2 x 8; staged through LDS so that every array is written as one contiguous run.
@@ -1658,6 +1667,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
 #pragma unroll
         for (uint32_t w = 0; w < 16; ++w) m = max(m, wave_max[tid][w]);
         uint32_t* dst = level_max + tid * kMaxLevels + level;
+        while (__hip_atomic_load(lm_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != lm_token) __builtin_amdgcn_s_sleep(8);
         if (m > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, m);
     }
 }
@@ -2081,6 +2091,8 @@ void launch_tv(const TvArgs& a) {
 static std::atomic<uint32_t> g_cfg_tv_stride{1};
 static std::atomic<float> g_cfg_overflow_div{1.0f};
 
+constexpr size_t kBinHeaderBytes = 512;          // [level maxima 2 x 32 words][ready token 8 B][pad]
+
 struct BinLayout {
     BinPlan plan;
     size_t dir_words, log_entries, bytes;
@@ -2120,7 +2132,7 @@ BinLayout make_bin_plan(uint32_t Bc, uint32_t C, uint32_t max_level, const int32
     o.plan.item_prefix[max_level] = items;
     o.dir_words = dir;
     o.log_entries = (size_t)max_level * tiles * kTileEntries;
-    o.bytes = 256 + ((dir * 4 + 255) & ~(size_t)255) + (size_t)logs * o.log_entries * 8;
+    o.bytes = kBinHeaderBytes + ((dir * 4 + 255) & ~(size_t)255) + (size_t)logs * o.log_entries * 8;
     if (dir >= (1ull << 32)) o.ok = false;
     return o;
 }
@@ -2178,11 +2190,13 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         N2M_REQUIRE(lay.ok, N2M_EUNSUPPORTED, "%s: table layout not supported by the binned path", fn);
         N2M_REQUIRE(workspace_bytes >= lay.bytes, N2M_EINVAL, "%s: workspace too small (%zu < %zu bytes)", fn, workspace_bytes, lay.bytes);
         uint32_t* level_max = (uint32_t*)workspace;                                  // [2][32]
-        uint32_t* directory = (uint32_t*)((char*)workspace + 256);
-        uint32_t* log_v1 = (uint32_t*)((char*)workspace + 256 + ((lay.dir_words * 4 + 255) & ~(size_t)255));
+        unsigned long long* lm_ready = (unsigned long long*)((char*)workspace + 256);  // token of the launch that last cleared level_max
+        uint32_t* directory = (uint32_t*)((char*)workspace + kBinHeaderBytes);
+        uint32_t* log_v1 = (uint32_t*)((char*)workspace + kBinHeaderBytes + ((lay.dir_words * 4 + 255) & ~(size_t)255));
         uint32_t* log_v2 = log_v1 + lay.log_entries;
         uint16_t* log_rel = (uint16_t*)(log_v2 + lay.log_entries);
-        N2M_HIP(hipMemsetAsync(level_max, 0, 256, s));
+        static std::atomic<unsigned long long> launch_counter{1};
+        const unsigned long long lm_token = (0x6e326d4cull << 32) | (launch_counter.fetch_add(1) & 0xFFFFFFFFull);   // never what stale memory holds
         const bool ow = overwrite && b0 == 0;                 // later passes add onto the first one's sums
         const float* g1 = grad1 + (size_t)b0;
         const _Float16* g2 = grad2 + (size_t)b0 * 2;
@@ -2231,11 +2245,11 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         if (tv.table)
             bin_fill_pair_kernel<true><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
                                                                              directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset, ow ? table1 : nullptr,
-                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin);
+                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token);
         else
             bin_fill_pair_kernel<false><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
                                                                               directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset, ow ? table1 : nullptr,
-                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin);
+                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token);
         N2M_CHECK_LAUNCH();
         const uint32_t items = items2;
         static const uint32_t acc_cap2 = getenv("N2M_ACC_GRID") ? (uint32_t)atoi(getenv("N2M_ACC_GRID")) : 4096u;
