@@ -410,6 +410,7 @@ __global__ void scaler_update_slots_kernel(float* scale, float* growth_tracker, 
                                            float growth_factor, float backoff_factor, float growth_interval,
                                            const float* __restrict__ loss_partial, uint32_t n_partial, float inv_rays,
                                            float* __restrict__ loss, float* __restrict__ loss_sum) {
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t s = threadIdx.x;
     __shared__ float wave_part[16];
     if (loss_partial) {       // the step's loss VALUE (nobody on the GPU waits for it): per-workgroup partials of n2m_composite_loss_train,
@@ -470,7 +471,9 @@ extern "C" int n2m_scaler_update_slots_loss(float* scale, float* growth_tracker,
                                             float* loss_sum, void* stream) {
     N2M_REQUIRE(found_inf != nullptr && steps != nullptr && bias != nullptr, N2M_ENULL, "scaler_update_slots: NULL found_inf / steps / bias");
     N2M_REQUIRE(loss_partial != nullptr && n_rays > 0, N2M_EINVAL, "scaler_update_slots_loss: needs the loss partials and the ray count");
-    scaler_update_slots_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(scale, growth_tracker, found_inf, steps, bias, participants, beta1, beta2,
+    // 256 threads, not 1024: the launch sits on the main stream between Adam and the next forward while the side stream's marcher fills
+    // every CU, and a 16-wave workgroup then waits (measured: up to 27 us) for one CU to free 16 wave slots at once
+    scaler_update_slots_kernel<<<1, 256, 0, (hipStream_t)stream>>>(scale, growth_tracker, found_inf, steps, bias, participants, beta1, beta2,
                                                                   growth_factor, backoff_factor, growth_interval, loss_partial, n_partial,
                                                                   1.0f / (float)n_rays, loss, loss_sum);
     N2M_CHECK_LAUNCH();
