@@ -40,9 +40,10 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured floa
 _DEVICE_KERNELS = {"grid_encode_backward": (("bin_fill_pair_kernel", "bin_accumulate_kernel"), "sum"),     # one call = fill + both accumulates
                    "grid_encode_forward_packed": (("grid_forward3_packed_kernel",), "sum"),                  # one call = both tables (packed copy)
                    "adam_step": (("adam_kernel",), "sum"),
-                   "mlp_backward": (("field_backward_kernel",), "mean"), "mlp_forward": (("field_forward_kernel",), "mean"),
-                   "march_rays_train_count": (("march_train_wave_kernelILb0", "march_train_wave_kernel<false>"), "mean"),
-                   "march_rays_train_write": (("march_train_wave_kernelILb1", "march_train_wave_kernel<true>"), "mean")}
+                   "mlp_backward": (("field_backward_pc_kernel<true, true>", "field_backward_pc_kernelILb1ELb1", "dw_finalize_kernel"), "sum"),
+                   "mlp_forward": (("field_forward_kernel<true, true>", "field_forward_kernelILb1ELb1"), "mean"),
+                   "march_rays_train_count": (("march_train_record_kernel",), "mean"),                      # one march per ray: count + recorded chunks,
+                   "march_rays_train_write": (("march_train_replay_kernel",), "mean")}                      # then the replay that writes the samples
 
 
 def pmc_traffic(entry_point):
