@@ -103,6 +103,7 @@ def lib():
     """Load the library once. Raises if the HIP build is not present (no fallback by design)."""
     global _lib
     if _lib is None:
+        import torch  # noqa: F401  -- first: the library must bind to the HIP runtime torch ships, not load a second copy before torch does
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"nerf2mesh_amd: {LIB_PATH} is missing -- build it with `python -m nerf2mesh_amd.build` "
