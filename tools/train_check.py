@@ -13,10 +13,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=3000)
 ap.add_argument("--unfused", action="store_true")
 ap.add_argument("--every", type=int, default=500)
+ap.add_argument("--engine", action="store_true", help="the step executor (engine.Stage0Engine) instead of the autograd trainer")
 args = ap.parse_args()
 torch.manual_seed(0)
 opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=not args.unfused)
-tr = Stage0Trainer(NeRFNetwork(opt), opt, synthetic.make_cameras(100, seed=0), torch.device("cuda"), seed=0)
+if args.engine:
+    from nerf2mesh_amd.engine import Stage0Engine
+    tr = Stage0Engine(NeRFNetwork(opt), opt, synthetic.make_cameras(100, seed=0), torch.device("cuda", 0), seed=0)
+else:
+    tr = Stage0Trainer(NeRFNetwork(opt), opt, synthetic.make_cameras(100, seed=0), torch.device("cuda"), seed=0)
 tr.mark_untrained()
 t0 = time.time()
 for i in range(1, args.steps + 1):
