@@ -199,9 +199,12 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
             g1v[e] = g1_half ? (float)reinterpret_cast<const _Float16*>(t.g[pk])[r0 + e] : reinterpret_cast<const float*>(t.g[pk])[r0 + e];
         }
     }
+    typedef float f4v __attribute__((ext_vector_type(4)));
     if (full) {
-        const float4 pp = *reinterpret_cast<const float4*>(P + i0), mm = *reinterpret_cast<const float4*>(M + i0),
-                     vv = *reinterpret_cast<const float4*>(V + i0);
+        // streaming (non-temporal) accesses for the optimizer state: 540 MB pass through once per step, and the marcher that runs beside
+        // this kernel lives on a 256 KB bit field it wants to keep in L2
+        const f4v pp = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(P + i0)), mm = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(M + i0)),
+                  vv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(V + i0));
         p[0] = pp.x; p[1] = pp.y; p[2] = pp.z; p[3] = pp.w;
         m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
         v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; v[3] = vv.w;
@@ -232,9 +235,10 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
     if (clear_g)
         for (uint32_t e = 0; e < 4u && i0 + e < n; ++e) reinterpret_cast<float*>(t.g[k])[i0 + e] = 0.0f;
     if (full) {
-        *reinterpret_cast<float4*>(P + i0) = make_float4(p[0], p[1], p[2], p[3]);
-        *reinterpret_cast<float4*>(M + i0) = make_float4(m[0], m[1], m[2], m[3]);
-        *reinterpret_cast<float4*>(V + i0) = make_float4(v[0], v[1], v[2], v[3]);
+        const f4v po = {p[0], p[1], p[2], p[3]}, mo = {m[0], m[1], m[2], m[3]}, vo = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(po, reinterpret_cast<f4v*>(P + i0));
+        __builtin_nontemporal_store(mo, reinterpret_cast<f4v*>(M + i0));
+        __builtin_nontemporal_store(vo, reinterpret_cast<f4v*>(V + i0));
         if (S && pk < 0) shadow_store(S, smode, i0, p, 4u);
     } else {
 #pragma unroll
