@@ -1352,10 +1352,35 @@ __device__ __forceinline__ void pair_entries(const PairCtx& cx, const Indexer<3>
             const bool nb_ok[6] = {cell[0] < cx.resolution, cell[0] > 0u, cell[1] < cx.resolution, cell[1] > 0u,
                                    cell[2] < cx.resolution, cell[2] > 0u};
             const uint32_t st = cx.tv.stride;
-            const float centre = tab[(size_t)rows[0] * st];
-            float nb[6];
+            float centre, nb[6];
+            if (st == 1u) {
+                // Seven scattered 4-byte reads per (sample, level) pace the fine levels (a fully divergent wave load costs the CU 64 address
+                // cycles).  One of them is free: on a hashed level the x prime is 1, so the +x (cell even) or -x (cell odd) neighbour is row
+                // r ^ 1 -- the other half of the centre's aligned 8 bytes; on a dense level +x is row r + 1.  Six reads instead of seven.
+                typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+                if constexpr (IMODE == 1) {
+                    const float2 pr = *reinterpret_cast<const float2*>(tab + (rows[0] & ~1u));
+                    const bool odd_row = (rows[0] & 1u) != 0u, even_cell = (cell[0] & 1u) == 0u;
+                    centre = odd_row ? pr.y : pr.x;
+                    const float other = odd_row ? pr.x : pr.y;                       // +x neighbour of an even cell, -x of an odd one
+                    const uint32_t k_far = even_cell ? 1u : 0u;                      // the x neighbour the pair does not hold
+                    const float far = tab[(even_cell ? nb_ok[1] : nb_ok[0]) ? (even_cell ? nb_row[1] : nb_row[0]) : rows[0]];
+                    (void)k_far;
+                    nb[0] = even_cell ? other : far;
+                    nb[1] = even_cell ? far : other;
+                } else {
+                    const f2u pr = *reinterpret_cast<const f2u*>(tab + rows[0]);
+                    centre = pr.x;
+                    nb[0] = pr.y;
+                    nb[1] = tab[nb_ok[1] ? nb_row[1] : rows[0]];
+                }
 #pragma unroll
-            for (uint32_t k = 0; k < 6; ++k) nb[k] = tab[(size_t)(nb_ok[k] ? nb_row[k] : rows[0]) * st];
+                for (uint32_t k = 2; k < 6; ++k) nb[k] = tab[nb_ok[k] ? nb_row[k] : rows[0]];
+            } else {
+                centre = tab[(size_t)rows[0] * st];
+#pragma unroll
+                for (uint32_t k = 0; k < 6; ++k) nb[k] = tab[(size_t)(nb_ok[k] ? nb_row[k] : rows[0]) * st];
+            }
             float sum = 0.f, sq = 0.f;
 #pragma unroll
             for (uint32_t k = 0; k < 6; ++k)
