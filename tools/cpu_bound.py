@@ -33,9 +33,10 @@ else:
     R.march_rays_train_finish = timed
 for i in range(400): tr.train_step()
 torch.cuda.synchronize()
-wait[0] = 0; t0 = time.perf_counter()
+wait[0] = 0; t0 = time.perf_counter(); c0 = time.thread_time()
 for i in range(200): tr.train_step()
-t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+c1 = time.thread_time(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"host CPU time of the stepping thread (excludes blocking waits): {1e3*(c1-c0)/200:.3f} ms/step")
 print(f"driver={type(tr).__name__} pipeline={tr.pipeline} wall/step {1e3*(t2-t0)/200:.3f} ms  host loop/step {1e3*(t1-t0)/200:.3f}  blocked-on-count/step {1e3*wait[0]/200:.3f}  drain {1e3*(t2-t1):.2f} ms")
 if "--cprofile" in sys.argv:
     import cProfile, pstats
