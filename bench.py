@@ -284,6 +284,11 @@ def main():
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt, samples, rays = float(mx[0]), float(sm[1]), float(sm[2])
 
+    # sharded optimizer: every rank owns 1/W of the fp32 table rows -- gather them while all ranks are still here (collective), so that
+    # rank 0's PSNR evaluation below runs on complete tables without talking to anybody
+    if world > 1 and hasattr(tr, "sync_parameters"):
+        tr.sync_parameters()
+    barrier()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()

@@ -416,6 +416,12 @@ class Stage0Engine:
         steps: 24.5 MB) and to be called before a checkpoint, an export, an evaluation or a comparison."""
         if not self.shard:
             return
+        # COLLECTIVE: every rank must call it at the same step.  A repeat at the same step is a no-op (so a rank may evaluate or save on
+        # its own after all ranks have synchronised once -- bench.py's rank 0 does)
+        done = getattr(self, "_synced", (-1, False))
+        if done[0] == self.global_step and (done[1] or density_only):
+            return
+        self._synced = (self.global_step, not density_only)
         import torch.distributed as dist
         tables = ((self.model.encoder.embeddings, 1),) if density_only else ((self.model.encoder.embeddings, 1), (self.model.encoder_color.embeddings, 2))
         for p, C in tables:
@@ -539,17 +545,18 @@ class Stage0Engine:
             # no sample in the batch: every gradient is zero (the reduction below still takes part on every rank)
             self.g1.zero_()
             self.g2.zero_()
+            if self.shard:      # same collectives in the same ORDER as on the ranks that have samples (fine halves, coarse halves, then the bucket)
+                import torch.distributed as dist
+                sp = self._split
+                rs = lambda out, src: dist.reduce_scatter_tensor(out.view(-1), src.view(-1), op=dist.ReduceOp.SUM, async_op=True)
+                early = [rs(self.g1s["f"], self.g1[sp:]), rs(self.g2s["f"], self.g2[sp:]), rs(self.g1s["c"], self.g1[:sp]), rs(self.g2s["c"], self.g2[:sp])]
+            elif self.sync is not None and self.split_backward and self.Lv == 16:
+                early = self.sync.all_reduce_sum_begin([self.g1[int(self.ho[8]):], self.g2[int(self.ho[8]):]], [])
         # ---- [multi-GPU] one SUM all-reduce per fixed gradient buffer (the colour table's stays fp16) + the small bucket
         if self.shard:
             token = self.sync.all_reduce_sum_begin([], [self.dw, o.found_inf])
-            if M > 0:
-                for w_ in early:
-                    w_.wait()
-            else:                                       # no samples on this rank: its (zero) rows still take part
-                import torch.distributed as dist
-                sp = self._split
-                for out, src in ((self.g1s["f"], self.g1[sp:]), (self.g2s["f"], self.g2[sp:]), (self.g1s["c"], self.g1[:sp]), (self.g2s["c"], self.g2[:sp])):
-                    dist.reduce_scatter_tensor(out.view(-1), src.view(-1), op=dist.ReduceOp.SUM)
+            for w_ in early:
+                w_.wait()
             self.sync.all_reduce_sum_end(token)
         elif self.sync is not None:
             if early is not None:

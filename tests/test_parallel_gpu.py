@@ -61,6 +61,8 @@ def test_bench_spawns_the_ranks_it_is_asked_for():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "gloo" in d["config"]["parallelism"]
     assert d["config"]["samples_per_step_per_gpu"] > 1e5 and d["value"] > 0
+    # rank 0 evaluates a view after the other ranks have left: the sharded tables were gathered while everybody was still there
+    assert isinstance(d["psnr_view0_quarter_res"], float), d["psnr_view0_quarter_res"]
 
 
 @pytest.mark.gpu
