@@ -294,6 +294,34 @@ int n2m_grid_encode_backward_binned_pair_half(const float* grad1, const void* gr
                                          void* stream, int half);
 
 /* ------------------------------------------------------------------------------------------------------
+ * marching cubes   (reference: `mcubes.marching_cubes(volume, isovalue)` -- PyMCubes, an un-vendored dependency; call sites
+ * nerf/renderer.py:524-527 (stage-0 mesh), :563 and :616 (outer cascades).  SURVEY.md section 8f-4.)
+ * The reference copies the volume to the host (:518) and runs PyMCubes there; here the volume stays in HBM.
+ * volume [R0][R1][R2] f32 in C order; solid = !(value < iso) (PyMCubes marks value < iso: same surface); one vertex per crossed grid
+ * edge at PyMCubes' interpolation x1 + (iso - f1) / (f2 - f1), evaluated in double with the lower corner first; triangles from the
+ * 256-case table of nerf2mesh_amd/csrc/mc_table.inc (rule-generated, tools/gen_mc_table.py: PyMCubes' literal table is not available
+ * here; ambiguous faces never join their solid corners, which makes every extracted surface closed), normals pointing towards lower
+ * values.  Deterministic order: vertices by grid node (C order), then axis; triangles by cell (C order), then table order.
+ * Two calls with a host read in between, like march_rays_train: count -> totals -> allocate -> emit.
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* bytes of device scratch n2m_marching_cubes_count/_emit need for a volume (0: unsupported size, see _count) */
+uint64_t n2m_marching_cubes_workspace_bytes(uint32_t R0, uint32_t R1, uint32_t R2);
+
+/* Pass 1.  totals (device, 2 x u64) <- {number of vertices, number of triangles}.  Fills `workspace` for the emit pass.
+ * Each dimension <= 2048 and fewer than 2^31 nodes; an emit needs totals[0] < 2^29 and totals[1] < 2^32. */
+int n2m_marching_cubes_count(const float* volume, uint32_t R0, uint32_t R1, uint32_t R2, double iso, void* workspace,
+                             uint64_t workspace_bytes, uint64_t* totals, void* stream);
+
+/* Pass 2 (same volume, iso and workspace).  vertices [cap_v][3] (f32, or f64 when vertices_f64 != 0) <-
+ * ((index-space position / div) * mul) + add, evaluated in double (the reference: `vertices / (resolution - 1.0) * 2 - 1` on
+ * PyMCubes' doubles, then astype(float32), nerf/renderer.py:529-530); div = mul = 1, add = 0 gives PyMCubes' own coordinates.
+ * triangles [cap_t][3] i32.  Entries beyond a capacity are dropped (pass the totals of pass 1). */
+int n2m_marching_cubes_emit(const float* volume, uint32_t R0, uint32_t R1, uint32_t R2, double iso, const void* workspace,
+                            uint64_t workspace_bytes, double div, double mul, double add, void* vertices, int vertices_f64,
+                            uint32_t cap_v, int32_t* triangles, uint32_t cap_t, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * freqencoder   (reference: freqencoder/src/freqencoder.h:6-10, freqencoder/src/bindings.cpp:5-8)
  * ---------------------------------------------------------------------------------------------------- */
 

@@ -49,6 +49,10 @@ SIGNATURES = {
     "n2m_grid_encode_backward_binned_pair_half": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
                                                   _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _int, _vp, _u64, _vp, _int],
     "n2m_grad_total_variation_binned": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _vp, _u64, _vp],
+    "n2m_marching_cubes_workspace_bytes": [_u32, _u32, _u32],                                  # returns uint64 (RESTYPES)
+    "n2m_marching_cubes_count": [_vp, _u32, _u32, _u32, ctypes.c_double, _vp, _u64, _vp, _vp],
+    "n2m_marching_cubes_emit": [_vp, _u32, _u32, _u32, ctypes.c_double, _vp, _u64, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp, _int,
+                                _u32, _vp, _u32, _vp],
     "n2m_freq_encode_forward": [_vp, _u32, _u32, _u32, _u32, _vp, _vp],
     "n2m_freq_encode_backward": [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp],
     "n2m_get_rays": [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
@@ -77,7 +81,8 @@ SIGNATURES = {
     "n2m_prof_read": [_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
 }
 
-RESTYPES = {"n2m_grid_binned_workspace_bytes": _u64, "n2m_grid_binned_pair_workspace_bytes": _u64, "n2m_march_fused_workspace_bytes": _u64}   # everything else returns an int status
+RESTYPES = {"n2m_grid_binned_workspace_bytes": _u64, "n2m_grid_binned_pair_workspace_bytes": _u64, "n2m_march_fused_workspace_bytes": _u64,
+            "n2m_marching_cubes_workspace_bytes": _u64}   # everything else returns an int status
 
 F32, F16 = 0, 1
 ADAM_MAX = 16

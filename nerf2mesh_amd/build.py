@@ -39,7 +39,7 @@ def build(force=False, verbose=True, save_asm=False):
     os.makedirs(OBJDIR, exist_ok=True)
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) > _deps_mtime():
         return LIB
-    hdr_m = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".hpp"))
+    hdr_m = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc")))
     hdr_m = max(hdr_m, os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "n2m_hip.h")), os.path.getmtime(__file__))
 
     def compile_one(src):

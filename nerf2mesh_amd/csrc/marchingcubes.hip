@@ -1,0 +1,260 @@
+// Marching cubes on the device: the stage-0 mesh extraction the reference does on the host with PyMCubes
+// (`mcubes.marching_cubes(sigmas, density_thresh)`, nerf/renderer.py:524-527; outer cascades :563, :616) after copying the whole
+// density volume over PCIe (:518).  SURVEY.md 8f-4.
+//
+// The volume is HBM-resident fp32 [R0][R1][R2] (C order, like the torch tensor the reference builds).  One thread per grid NODE; a node
+// owns the three grid edges that leave it in +x, +y, +z (their vertices) and is the low corner of one cell (its triangles):
+//   count   classify, per-workgroup sums of owned vertices / triangles, per-node word (edge mask << 29 | vertex prefix inside the
+//           workgroup); one-workgroup scan of the workgroup sums -> exclusive offsets + totals (the host reads them, allocates, like the
+//           march_rays_train protocol);
+//   emit    vertices in node order (then axis), triangles in cell order (then table order): deterministic, no atomics.  A triangle's
+//           three vertex ids come from the owning nodes' words.
+// HBM-bound byte work: 4 B read + 4 B written per node in the count pass, 8 B read per node in the emit pass (neighbour values are
+// cache hits) + the mesh itself; workgroups without a crossing skip the emit pass after two loads.
+// Conventions (case table, solid = !(value < iso), interpolation in double with the lower corner first): tools/gen_mc_table.py.
+#include "n2m_common.hpp"
+#define N2M_MC_QUAL __device__
+#include "mc_table.inc"      // kMcNumTris[256], kMcTris[256][3 * N2M_MC_MAX_TRIS]: device-resident constants
+
+namespace {
+
+constexpr uint32_t kMcBlock = 256;
+constexpr uint32_t kPrefixMask = (1u << 29) - 1u;
+
+struct McNode {
+    float v[8];            // corner values, index x | y << 1 | z << 2 (x = dim 0); missing neighbours repeat the node's own value
+    uint32_t i, j, k;
+    uint32_t mask;         // owned crossed edges: bit a = the edge along dim a
+    uint32_t cas;          // cell case (0 when the node is not the low corner of a cell)
+};
+
+__device__ __forceinline__ McNode mc_load(const float* __restrict__ f, uint32_t n, uint32_t R0, uint32_t R1, uint32_t R2, double iso) {
+    McNode nd;
+    const uint32_t plane = R1 * R2;
+    nd.i = n / plane;
+    const uint32_t r = n - nd.i * plane;
+    nd.j = r / R2;
+    nd.k = r - nd.j * R2;
+    const bool hx = nd.i + 1u < R0, hy = nd.j + 1u < R1, hz = nd.k + 1u < R2;
+#pragma unroll
+    for (uint32_t c = 0; c < 8; ++c) {
+        const bool x = c & 1u, y = (c >> 1) & 1u, z = (c >> 2) & 1u;
+        const bool ok = (!x || hx) && (!y || hy) && (!z || hz);
+        nd.v[c] = f[ok ? (size_t)n + (x ? plane : 0u) + (y ? R2 : 0u) + (z ? 1u : 0u) : (size_t)n];
+    }
+    uint32_t bits = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 8; ++c) bits |= ((double)nd.v[c] < iso ? 0u : 1u) << c;
+    const uint32_t s0 = bits & 1u;
+    nd.mask = ((hx && ((bits >> 1) & 1u) != s0) ? 1u : 0u) | ((hy && ((bits >> 2) & 1u) != s0) ? 2u : 0u) | ((hz && ((bits >> 4) & 1u) != s0) ? 4u : 0u);
+    nd.cas = (hx && hy && hz) ? bits : 0u;
+    return nd;
+}
+
+// exclusive scan of (nt << 16 | nv) over the workgroup; returns the packed exclusive prefix, *total = packed workgroup sum
+__device__ __forceinline__ uint32_t mc_block_scan(uint32_t packed, uint32_t* wave_tot, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t incl = n2m_wave_scan_add_u32(packed, (int)lane);
+    if (lane == 63u) wave_tot[w] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kMcBlock / 64u; ++q) {
+        const uint32_t t = wave_tot[q];
+        if (q < w) off += t;
+        tot += t;
+    }
+    *total = tot;
+    return off + incl - packed;
+}
+
+__global__ void __launch_bounds__(kMcBlock)
+mc_count_kernel(const float* __restrict__ field, uint32_t R0, uint32_t R1, uint32_t R2, uint32_t N, double iso, uint32_t* __restrict__ info,
+                uint32_t* __restrict__ vsum, uint32_t* __restrict__ tsum) {
+    __shared__ uint32_t wave_tot[kMcBlock / 64u];
+    const uint32_t n = blockIdx.x * kMcBlock + threadIdx.x;
+    uint32_t mask = 0, nt = 0;
+    if (n < N) {
+        const McNode nd = mc_load(field, n, R0, R1, R2, iso);
+        mask = nd.mask;
+        nt = kMcNumTris[nd.cas];
+    }
+    uint32_t total;
+    const uint32_t excl = mc_block_scan((nt << 16) | (uint32_t)__popc(mask), wave_tot, &total);
+    if (n < N) info[n] = (mask << 29) | (excl & 0xFFFFu);
+    if (threadIdx.x == 0) {
+        vsum[blockIdx.x] = total & 0xFFFFu;
+        tsum[blockIdx.x] = total >> 16;
+    }
+}
+
+// One workgroup: exclusive scan of both workgroup-sum arrays in place (entry nb = total), 4096 entries per round with coalesced loads.
+// totals[0] = vertices, totals[1] = triangles (64-bit: the caller checks them against the 2^29 / 2^32 id ranges before emitting).
+__global__ void __launch_bounds__(1024)
+mc_scan_kernel(uint32_t* __restrict__ vsum, uint32_t* __restrict__ tsum, uint32_t nb, unsigned long long* __restrict__ totals) {
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    for (uint32_t which = 0; which < 2u; ++which) {
+        uint32_t* __restrict__ a = which ? tsum : vsum;
+        unsigned long long carry = 0;
+        for (uint32_t base = 0; base < nb; base += 4096u) {
+            uint32_t x[4];
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) x[e] = (base + tid * 4u + e) < nb ? a[base + tid * 4u + e] : 0u;
+            const uint32_t mine = x[0] + x[1] + x[2] + x[3];
+            const uint32_t incl = n2m_wave_scan_add_u32(mine, (int)lane);
+            __syncthreads();                             // wave_tot of the round before has been read
+            if (lane == 63u) wave_tot[w] = incl;
+            __syncthreads();
+            uint32_t off = 0, tot = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 16; ++q) {
+                const uint32_t t = wave_tot[q];
+                if (q < w) off += t;
+                tot += t;
+            }
+            unsigned long long run = carry + off + incl - mine;
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) {
+                if ((base + tid * 4u + e) < nb) a[base + tid * 4u + e] = (uint32_t)run;     // wraps past 2^32: the totals tell
+                run += x[e];
+            }
+            carry += tot;
+        }
+        if (tid == 0) {
+            a[nb] = (uint32_t)carry;
+            totals[which] = carry;
+        }
+        __syncthreads();
+    }
+}
+
+template <typename VT>
+__global__ void __launch_bounds__(kMcBlock)
+mc_emit_kernel(const float* __restrict__ field, uint32_t R0, uint32_t R1, uint32_t R2, uint32_t N, double iso,
+               const uint32_t* __restrict__ info, const uint32_t* __restrict__ voff, const uint32_t* __restrict__ toff, double div, double mul,
+               double add, VT* __restrict__ vertices, uint32_t cap_v, int32_t* __restrict__ triangles, uint32_t cap_t) {
+    __shared__ uint32_t wave_tot[kMcBlock / 64u];
+    const uint32_t b = blockIdx.x;
+    const uint32_t v0 = voff[b], t0 = toff[b];
+    if (voff[b + 1u] == v0 && toff[b + 1u] == t0) return;                 // nothing crosses this workgroup's nodes (block-uniform)
+    const uint32_t n = b * kMcBlock + threadIdx.x;
+    McNode nd;
+    nd.mask = 0; nd.cas = 0;
+    if (n < N) nd = mc_load(field, n, R0, R1, R2, iso);
+    const uint32_t nt = kMcNumTris[nd.cas];
+    uint32_t total;
+    const uint32_t excl = mc_block_scan((nt << 16) | (uint32_t)__popc(nd.mask), wave_tot, &total);
+    if (n >= N) return;
+    // ---- vertices of the owned edges: PyMCubes' interpolation, x1 + (iso - f1) / (f2 - f1) in double, lower corner first
+    uint32_t vid = v0 + (excl & 0xFFFFu);
+#pragma unroll
+    for (uint32_t a = 0; a < 3; ++a) {
+        if (!((nd.mask >> a) & 1u)) continue;
+        const double f1 = (double)nd.v[0], f2 = (double)nd.v[a == 0 ? 1 : (a == 1 ? 2 : 4)];
+        double p[3] = {(double)nd.i, (double)nd.j, (double)nd.k};
+        p[a] = p[a] + (iso - f1) / (f2 - f1);
+        if (vid < cap_v) {
+#pragma unroll
+            for (uint32_t d = 0; d < 3; ++d) vertices[(size_t)vid * 3u + d] = (VT)(((p[d] / div) * mul) + add);
+        }
+        ++vid;
+    }
+    // ---- triangles of the cell
+    if (nt == 0u) return;
+    const uint32_t plane = R1 * R2;
+    uint32_t tid_out = t0 + (excl >> 16);
+    const unsigned char* __restrict__ row = kMcTris[nd.cas];
+    for (uint32_t t = 0; t < nt; ++t, ++tid_out) {
+        int32_t ids[3];
+#pragma unroll
+        for (uint32_t m = 0; m < 3; ++m) {
+            const uint32_t e = row[3u * t + m];
+            const uint32_t a = e >> 2, u = e & 1u, v = (e >> 1) & 1u;
+            // the edge's lower corner: the other two coordinates in axis order (axis 0: (y, z), 1: (x, z), 2: (x, y))
+            const uint32_t dx = a == 0u ? 0u : u, dy = a == 0u ? u : (a == 1u ? 0u : v), dz = a == 2u ? 0u : v;
+            const uint32_t owner = n + dx * plane + dy * R2 + dz;
+            const uint32_t w = info[owner];
+            ids[m] = (int32_t)(voff[owner / kMcBlock] + (w & kPrefixMask) + (uint32_t)__popc((w >> 29) & ((1u << a) - 1u)));
+        }
+        if (tid_out < cap_t) {
+            triangles[(size_t)tid_out * 3u] = ids[0];
+            triangles[(size_t)tid_out * 3u + 1u] = ids[1];
+            triangles[(size_t)tid_out * 3u + 2u] = ids[2];
+        }
+    }
+}
+
+struct McLayout {
+    uint32_t N, nb;
+    size_t info, voff, toff, total;
+};
+McLayout mc_layout(uint32_t R0, uint32_t R1, uint32_t R2) {
+    McLayout l;
+    l.N = R0 * R1 * R2;
+    l.nb = n2m_ceil_div(l.N, kMcBlock);
+    auto up = [](size_t v) { return (v + 255u) & ~(size_t)255u; };
+    l.info = 0;
+    l.voff = up((size_t)l.N * 4u);
+    l.toff = l.voff + up(((size_t)l.nb + 1u) * 4u);
+    l.total = l.toff + up(((size_t)l.nb + 1u) * 4u);
+    return l;
+}
+
+int mc_check(const char* fn, const void* field, uint32_t R0, uint32_t R1, uint32_t R2, const void* ws, uint64_t ws_bytes) {
+    N2M_REQUIRE(field != nullptr && ws != nullptr, N2M_ENULL, "%s: NULL field / workspace", fn);
+    N2M_REQUIRE(R0 >= 1 && R1 >= 1 && R2 >= 1 && R0 <= 2048 && R1 <= 2048 && R2 <= 2048 && (uint64_t)R0 * R1 * R2 < (1ull << 31), N2M_EINVAL,
+                "%s: volume %u x %u x %u is outside the supported range (each <= 2048, fewer than 2^31 nodes)", fn, R0, R1, R2);
+    N2M_REQUIRE(ws_bytes >= mc_layout(R0, R1, R2).total, N2M_EINVAL, "%s: workspace of %llu bytes is too small (n2m_marching_cubes_workspace_bytes)", fn,
+                (unsigned long long)ws_bytes);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" uint64_t n2m_marching_cubes_workspace_bytes(uint32_t R0, uint32_t R1, uint32_t R2) {
+    if (R0 == 0 || R1 == 0 || R2 == 0 || (uint64_t)R0 * R1 * R2 >= (1ull << 31)) return 0;
+    return mc_layout(R0, R1, R2).total;
+}
+
+extern "C" int n2m_marching_cubes_count(const float* field, uint32_t R0, uint32_t R1, uint32_t R2, double iso, void* workspace,
+                                        uint64_t workspace_bytes, uint64_t* totals, void* stream) {
+    if (int rc = mc_check(__func__, field, R0, R1, R2, workspace, workspace_bytes)) return rc;
+    N2M_NOTNULL(totals);
+    N2M_REQUIRE(iso == iso, N2M_EINVAL, "marching_cubes_count: iso is NaN");
+    const McLayout l = mc_layout(R0, R1, R2);
+    char* ws = static_cast<char*>(workspace);
+    uint32_t* info = reinterpret_cast<uint32_t*>(ws + l.info);
+    uint32_t* voff = reinterpret_cast<uint32_t*>(ws + l.voff);
+    uint32_t* toff = reinterpret_cast<uint32_t*>(ws + l.toff);
+    hipStream_t s = (hipStream_t)stream;
+    mc_count_kernel<<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, iso, info, voff, toff);
+    N2M_CHECK_LAUNCH();
+    mc_scan_kernel<<<1, 1024, 0, s>>>(voff, toff, l.nb, reinterpret_cast<unsigned long long*>(totals));
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_marching_cubes_emit(const float* field, uint32_t R0, uint32_t R1, uint32_t R2, double iso, const void* workspace,
+                                       uint64_t workspace_bytes, double div, double mul, double add, void* vertices, int vertices_f64,
+                                       uint32_t cap_v, int32_t* triangles, uint32_t cap_t, void* stream) {
+    if (int rc = mc_check(__func__, field, R0, R1, R2, workspace, workspace_bytes)) return rc;
+    N2M_REQUIRE((vertices != nullptr || cap_v == 0) && (triangles != nullptr || cap_t == 0), N2M_ENULL, "marching_cubes_emit: NULL output with a non-zero capacity");
+    N2M_REQUIRE(cap_v < (1u << 29), N2M_EINVAL, "marching_cubes_emit: vertex ids are 29-bit (cap_v = %u)", cap_v);
+    N2M_REQUIRE(div != 0.0, N2M_EINVAL, "marching_cubes_emit: div = 0");
+    if (cap_v == 0 && cap_t == 0) return 0;
+    const McLayout l = mc_layout(R0, R1, R2);
+    const char* ws = static_cast<const char*>(workspace);
+    const uint32_t* info = reinterpret_cast<const uint32_t*>(ws + l.info);
+    const uint32_t* voff = reinterpret_cast<const uint32_t*>(ws + l.voff);
+    const uint32_t* toff = reinterpret_cast<const uint32_t*>(ws + l.toff);
+    hipStream_t s = (hipStream_t)stream;
+    if (vertices_f64)
+        mc_emit_kernel<double><<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, iso, info, voff, toff, div, mul, add, static_cast<double*>(vertices), cap_v,
+                                                        triangles, cap_t);
+    else
+        mc_emit_kernel<float><<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, iso, info, voff, toff, div, mul, add, static_cast<float*>(vertices), cap_v,
+                                                       triangles, cap_t);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}

@@ -122,3 +122,34 @@ def write_mlp_json(path, model):
     with open(path, "w") as fp:
         json.dump(mlp, fp, indent=2)
     return mlp
+
+
+# ------------------------------------------------------------------------------------------------ mesh filters
+# The two pymeshlab selections export_stage0 uses between marching cubes and the PLY (meshutils.py:63-143), on device tensors.
+# (clean_mesh / decimate_mesh, meshutils.py:27-60,146-190, are CPU mesh post-processing through pymeshlab: out of scope)
+
+def remove_vertices(vertices, triangles, selected):
+    """Deletes the selected vertices and every face that touches one (`meshing_remove_selected_vertices`, meshutils.py:122-143);
+    the remaining vertices keep their order.  vertices [V,3], triangles [F,3] int, selected [V] bool -> (vertices', triangles')."""
+    import torch
+    keep_v = ~selected
+    keep_f = keep_v[triangles.long()].all(dim=1)
+    remap = torch.cumsum(keep_v.to(torch.int64), 0) - 1
+    return vertices[keep_v], remap[triangles[keep_f].long()].to(triangles.dtype)
+
+
+def remove_faces(vertices, triangles, remove, dilation=5):
+    """meshutils.py:63-92: the KEPT faces (remove == 0) are grown `dilation` times over faces sharing a vertex with them
+    (`apply_selection_dilatation`), the rest is deleted, then unreferenced vertices are dropped."""
+    import torch
+    tri = triangles.long()
+    keep = ~remove.bool()
+    for _ in range(int(dilation)):
+        touched = torch.zeros(vertices.shape[0], dtype=torch.bool, device=vertices.device)
+        touched[tri[keep].reshape(-1)] = True
+        keep = touched[tri].any(dim=1)
+    tri = tri[keep]
+    used = torch.zeros(vertices.shape[0], dtype=torch.bool, device=vertices.device)
+    used[tri.reshape(-1)] = True
+    remap = torch.cumsum(used.to(torch.int64), 0) - 1
+    return vertices[used], remap[tri].to(triangles.dtype)

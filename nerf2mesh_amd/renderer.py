@@ -248,6 +248,90 @@ class NeRFRenderer(nn.Module):
         self.density_grid[(mask_cam == 0) | (mask_aabb == 0)] = -1
 
 
+    # ------------------------------------------------------------------------------------- stage-0 mesh export
+    @torch.no_grad()
+    def density_volume(self, resolution, S=128, scale=1.0):
+        """[R,R,R] fp32 density at linspace(-1, 1, R)^3 * scale, queried in S^3 blocks like nerf/renderer.py:493-506 (one block for R <= S)."""
+        dev = self.density_bitfield.device
+        sigmas = torch.zeros([resolution] * 3, dtype=torch.float32, device=dev)
+        axis = (torch.linspace(-1, 1, resolution, device=dev) * scale).split(S)
+        for xi, xs in enumerate(axis):
+            for yi, ys in enumerate(axis):
+                for zi, zs in enumerate(axis):
+                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                    pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1).contiguous()
+                    with torch.autocast(device_type="cuda", dtype=torch.float16, enabled=bool(self.opt.fp16)):
+                        val = self.density(pts)["sigma"]
+                    sigmas[xi * S:xi * S + len(xs), yi * S:yi * S + len(ys), zi * S:zi * S + len(zs)] = val.reshape(len(xs), len(ys), len(zs)).float()
+        return sigmas
+
+    def _grid_as_volume(self, cas):
+        """density_grid[cas] (Morton order) as a [H,H,H] volume indexed [x,y,z] (nerf/renderer.py:487-489)."""
+        H = self.grid_size
+        coords = raymarching.morton3D_invert(torch.arange(H ** 3, dtype=torch.int32, device=self.density_grid.device)).long()
+        vol = torch.zeros([H] * 3, dtype=torch.float32, device=self.density_grid.device)
+        vol[coords[:, 0], coords[:, 1], coords[:, 2]] = self.density_grid[cas]
+        return vol
+
+    @torch.no_grad()
+    def export_stage0(self, save_path, resolution=None, decimate_target=1e5, dataset=None, S=128):
+        """Stage-0 mesh extraction (nerf/renderer.py:472-672): density volume -> marching cubes -> mesh_{cas}.ply.  The volume never leaves
+        the device: the reference copies it to the host for PyMCubes (:518); here marching cubes is a HIP kernel (marching_cubes.py).
+        NOT done (pymeshlab, SURVEY section 2 OUT): clean_mesh and decimate_mesh (:535-539, :577-583, :639-646) -- the meshes written here
+        are the raw iso-surfaces (`decimate_target` is accepted for signature compatibility and ignored); the SDF recipe's contracted outer
+        shell (:548-601) is not built.  dataset: object with `.mvps [B,4,4]`, `.H`, `.W` for the visibility test, or None.
+        Returns {cascade: (vertices [V,3] f32, triangles [F,3] i32)} (device tensors)."""
+        import os
+        from . import export
+        from .marching_cubes import marching_cubes
+        os.makedirs(save_path, exist_ok=True)
+        dev = self.density_bitfield.device
+        if resolution is None:
+            resolution = self.grid_size
+        density_thresh = min(self.mean_density, self.density_thresh)
+        if resolution == self.grid_size:
+            sigmas = self._grid_as_volume(0)
+        else:
+            sigmas = self.density_volume(resolution, S)
+            if not self.opt.sdf:      # the occupancy grid as a baseline mask (also excludes untrained regions), :509-516
+                mask = F.interpolate(self._grid_as_volume(0)[None, None], size=[resolution] * 3, mode="nearest")[0, 0]
+                sigmas = sigmas * (mask > density_thresh)
+        sigmas = torch.nan_to_num(sigmas, 0)
+        if self.opt.sdf:
+            vertices, triangles = marching_cubes(-sigmas, 0.0, div=resolution - 1.0, mul=2.0, add=-1.0)
+        else:
+            vertices, triangles = marching_cubes(sigmas, density_thresh, div=resolution - 1.0, mul=2.0, add=-1.0)
+        if dataset is not None and triangles.shape[0] > 0:
+            unseen = self.mark_unseen_triangles(vertices, triangles, dataset.mvps, dataset.H, dataset.W)
+            vertices, triangles = export.remove_faces(vertices, triangles, unseen, dilation=getattr(self.opt, "visibility_mask_dilation", 5))
+        meshes = {0: (vertices, triangles)}
+        export.write_ply(os.path.join(save_path, "mesh_0.ply"), vertices.cpu().numpy(), triangles.cpu().numpy())
+        if self.bound > 1 and not self.opt.sdf:
+            # outer cascades from the occupancy grid itself (:603-672): trilinear resample to env_reso, binarise, iso 0.5, drop the centre
+            # that the inner cascades cover and everything outside aabb_train
+            target = int(getattr(self.opt, "env_reso", 256))
+            for cas in range(1, self.cascade):
+                bound = min(2 ** cas, self.bound)
+                hgs = bound / target
+                occ = F.interpolate(self._grid_as_volume(cas)[None, None], [target] * 3, mode="trilinear")[0, 0]
+                occ = (torch.nan_to_num(occ, 0) > density_thresh).float()
+                v, t = marching_cubes(occ, 0.5, div=target - 1.0, mul=2.0, add=-1.0)
+                r = 0.45
+                v, t = export.remove_vertices(v, t, (v.abs() <= r).all(dim=1))
+                if v.shape[0] == 0:
+                    continue
+                v = v * (bound - hgs)
+                lo, hi = self.aabb_train[:3] + hgs, self.aabb_train[3:] - hgs
+                v, t = export.remove_vertices(v, t, ((v <= lo) | (v >= hi)).any(dim=1))
+                if v.shape[0] == 0:
+                    continue
+                if dataset is not None and t.shape[0] > 0:
+                    unseen = self.mark_unseen_triangles(v, t, dataset.mvps, dataset.H, dataset.W)
+                    v, t = export.remove_faces(v, t, unseen, dilation=getattr(self.opt, "visibility_mask_dilation", 5))
+                meshes[cas] = (v, t)
+                export.write_ply(os.path.join(save_path, f"mesh_{cas}.ply"), v.cpu().numpy(), t.cpu().numpy())
+        return meshes
+
     # ------------------------------------------------------------------------------------------ stage 1
     def init_stage1(self, vertices, triangles, v_cumsum=None):
         """Attach the stage-0 mesh (what NeRFRenderer.__init__ loads from mesh_stage0/*.ply, nerf/renderer.py:123-165):
