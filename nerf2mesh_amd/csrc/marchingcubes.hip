@@ -5,7 +5,7 @@
 // The volume is HBM-resident fp32 [R0][R1][R2] (C order, like the torch tensor the reference builds).  One thread per grid NODE; a node
 // owns the three grid edges that leave it in +x, +y, +z (their vertices) and is the low corner of one cell (its triangles):
 //   count   classify, per-workgroup sums of owned vertices / triangles, per-node word (edge mask << 29 | vertex prefix inside the
-//           workgroup); one-workgroup scan of the workgroup sums -> exclusive offsets + totals (the host reads them, allocates, like the
+//           workgroup); two-level scan of the workgroup sums -> exclusive offsets + totals (the host reads them, allocates, like the
 //           march_rays_train protocol);
 //   emit    vertices in node order (then axis), triangles in cell order (then table order): deterministic, no atomics.  A triangle's
 //           three vertex ids come from the owning nodes' words.
@@ -70,7 +70,7 @@ __device__ __forceinline__ uint32_t mc_block_scan(uint32_t packed, uint32_t* wav
 
 __global__ void __launch_bounds__(kMcBlock)
 mc_count_kernel(const float* __restrict__ field, uint32_t R0, uint32_t R1, uint32_t R2, uint32_t N, double iso, uint32_t* __restrict__ info,
-                uint32_t* __restrict__ vsum, uint32_t* __restrict__ tsum) {
+                uint32_t* __restrict__ bsum) {
     __shared__ uint32_t wave_tot[kMcBlock / 64u];
     const uint32_t n = blockIdx.x * kMcBlock + threadIdx.x;
     uint32_t mask = 0, nt = 0;
@@ -82,62 +82,78 @@ mc_count_kernel(const float* __restrict__ field, uint32_t R0, uint32_t R1, uint3
     uint32_t total;
     const uint32_t excl = mc_block_scan((nt << 16) | (uint32_t)__popc(mask), wave_tot, &total);
     if (n < N) info[n] = (mask << 29) | (excl & 0xFFFFu);
-    if (threadIdx.x == 0) {
-        vsum[blockIdx.x] = total & 0xFFFFu;
-        tsum[blockIdx.x] = total >> 16;
-    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;                       // triangles << 16 | vertices of this workgroup's nodes
 }
 
-// One workgroup: exclusive scan of both workgroup-sum arrays in place (entry nb = total), 4096 entries per round with coalesced loads.
-// totals[0] = vertices, totals[1] = triangles (64-bit: the caller checks them against the 2^29 / 2^32 id ranges before emitting).
+// Offsets of the workgroups, two levels (a single workgroup walking all 524 288 sums of a 512^3 volume took 0.9 ms -- three times the
+// count pass itself): every scan workgroup takes a chunk of kMcChunk workgroup sums, writes their exclusive prefixes inside the chunk
+// (vertices and triangles) and the chunk's totals; one small workgroup then scans the chunk totals.  offset(b) = voff[b] + cv[b / chunk].
+constexpr uint32_t kMcChunk = 8192;              // 1024 threads x 8 sums
 __global__ void __launch_bounds__(1024)
-mc_scan_kernel(uint32_t* __restrict__ vsum, uint32_t* __restrict__ tsum, uint32_t nb, unsigned long long* __restrict__ totals) {
-    __shared__ uint32_t wave_tot[16];
+mc_scan_chunks_kernel(const uint32_t* __restrict__ bsum, uint32_t nb, uint32_t* __restrict__ voff, uint32_t* __restrict__ toff,
+                      unsigned long long* __restrict__ chunk_v, unsigned long long* __restrict__ chunk_t) {
+    __shared__ unsigned long long wave_tot[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    for (uint32_t which = 0; which < 2u; ++which) {
-        uint32_t* __restrict__ a = which ? tsum : vsum;
-        unsigned long long carry = 0;
-        for (uint32_t base = 0; base < nb; base += 4096u) {
-            uint32_t x[4];
+    const uint32_t b0 = blockIdx.x * kMcChunk + tid * 8u;
+    uint32_t x[8];
 #pragma unroll
-            for (uint32_t e = 0; e < 4; ++e) x[e] = (base + tid * 4u + e) < nb ? a[base + tid * 4u + e] : 0u;
-            const uint32_t mine = x[0] + x[1] + x[2] + x[3];
-            const uint32_t incl = n2m_wave_scan_add_u32(mine, (int)lane);
-            __syncthreads();                             // wave_tot of the round before has been read
-            if (lane == 63u) wave_tot[w] = incl;
-            __syncthreads();
-            uint32_t off = 0, tot = 0;
+    for (uint32_t e = 0; e < 8; ++e) x[e] = (b0 + e) < nb ? bsum[b0 + e] : 0u;
+    uint32_t mv = 0, mt = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < 16; ++q) {
-                const uint32_t t = wave_tot[q];
-                if (q < w) off += t;
-                tot += t;
-            }
-            unsigned long long run = carry + off + incl - mine;
+    for (uint32_t e = 0; e < 8; ++e) { mv += x[e] & 0xFFFFu; mt += x[e] >> 16; }
+    // per chunk: vertices <= 8192 * 768 < 2^23, triangles <= 8192 * 1280 < 2^24: both prefixes fit one 64-bit scan (32 bits each)
+    const uint32_t iv = n2m_wave_scan_add_u32(mv, (int)lane), it = n2m_wave_scan_add_u32(mt, (int)lane);
+    if (lane == 63u) wave_tot[w] = ((unsigned long long)it << 32) | iv;
+    __syncthreads();
+    uint32_t ov = 0, ot = 0, tv = 0, tt = 0;
 #pragma unroll
-            for (uint32_t e = 0; e < 4; ++e) {
-                if ((base + tid * 4u + e) < nb) a[base + tid * 4u + e] = (uint32_t)run;     // wraps past 2^32: the totals tell
-                run += x[e];
-            }
-            carry += tot;
-        }
-        if (tid == 0) {
-            a[nb] = (uint32_t)carry;
-            totals[which] = carry;
-        }
+    for (uint32_t q = 0; q < 16; ++q) {
+        const unsigned long long t = wave_tot[q];
+        if (q < w) { ov += (uint32_t)t; ot += (uint32_t)(t >> 32); }
+        tv += (uint32_t)t; tt += (uint32_t)(t >> 32);
+    }
+    uint32_t rv = ov + iv - mv, rt = ot + it - mt;
+#pragma unroll
+    for (uint32_t e = 0; e < 8; ++e) {
+        if ((b0 + e) < nb) { voff[b0 + e] = rv; toff[b0 + e] = rt; }
+        rv += x[e] & 0xFFFFu;
+        rt += x[e] >> 16;
+    }
+    if (tid == 0) { chunk_v[blockIdx.x] = tv; chunk_t[blockIdx.x] = tt; }
+}
+
+// chunk totals -> exclusive chunk offsets in place (<= 1024 chunks: one value per thread), totals[0] = vertices, totals[1] = triangles
+__global__ void __launch_bounds__(1024)
+mc_scan_top_kernel(unsigned long long* __restrict__ chunk_v, unsigned long long* __restrict__ chunk_t, uint32_t nc,
+                   unsigned long long* __restrict__ totals) {
+    __shared__ unsigned long long sv[1024], st[1024];
+    const uint32_t tid = threadIdx.x;
+    sv[tid] = tid < nc ? chunk_v[tid] : 0ull;
+    st[tid] = tid < nc ? chunk_t[tid] : 0ull;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {                            // Hillis-Steele over 1024 values: ten steps, launched once per mesh
+        const unsigned long long a = tid >= d ? sv[tid - d] : 0ull, b = tid >= d ? st[tid - d] : 0ull;
+        __syncthreads();
+        sv[tid] += a; st[tid] += b;
         __syncthreads();
     }
+    if (tid < nc) {
+        chunk_v[tid] = tid ? sv[tid - 1u] : 0ull;
+        chunk_t[tid] = tid ? st[tid - 1u] : 0ull;
+    }
+    if (tid == 0) { totals[0] = sv[1023]; totals[1] = st[1023]; }
 }
 
 template <typename VT>
 __global__ void __launch_bounds__(kMcBlock)
 mc_emit_kernel(const float* __restrict__ field, uint32_t R0, uint32_t R1, uint32_t R2, uint32_t N, double iso,
-               const uint32_t* __restrict__ info, const uint32_t* __restrict__ voff, const uint32_t* __restrict__ toff, double div, double mul,
-               double add, VT* __restrict__ vertices, uint32_t cap_v, int32_t* __restrict__ triangles, uint32_t cap_t) {
+               const uint32_t* __restrict__ info, const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ voff,
+               const uint32_t* __restrict__ toff, const unsigned long long* __restrict__ chunk_v, const unsigned long long* __restrict__ chunk_t,
+               double div, double mul, double add, VT* __restrict__ vertices, uint32_t cap_v, int32_t* __restrict__ triangles, uint32_t cap_t) {
     __shared__ uint32_t wave_tot[kMcBlock / 64u];
     const uint32_t b = blockIdx.x;
-    const uint32_t v0 = voff[b], t0 = toff[b];
-    if (voff[b + 1u] == v0 && toff[b + 1u] == t0) return;                 // nothing crosses this workgroup's nodes (block-uniform)
+    if (bsum[b] == 0u) return;                                            // nothing crosses this workgroup's nodes (block-uniform)
+    const uint32_t v0 = voff[b] + (uint32_t)chunk_v[b / kMcChunk], t0 = toff[b] + (uint32_t)chunk_t[b / kMcChunk];
     const uint32_t n = b * kMcBlock + threadIdx.x;
     McNode nd;
     nd.mask = 0; nd.cas = 0;
@@ -175,7 +191,8 @@ mc_emit_kernel(const float* __restrict__ field, uint32_t R0, uint32_t R1, uint32
             const uint32_t dx = a == 0u ? 0u : u, dy = a == 0u ? u : (a == 1u ? 0u : v), dz = a == 2u ? 0u : v;
             const uint32_t owner = n + dx * plane + dy * R2 + dz;
             const uint32_t w = info[owner];
-            ids[m] = (int32_t)(voff[owner / kMcBlock] + (w & kPrefixMask) + (uint32_t)__popc((w >> 29) & ((1u << a) - 1u)));
+            const uint32_t ob = owner / kMcBlock;
+            ids[m] = (int32_t)(voff[ob] + (uint32_t)chunk_v[ob / kMcChunk] + (w & kPrefixMask) + (uint32_t)__popc((w >> 29) & ((1u << a) - 1u)));
         }
         if (tid_out < cap_t) {
             triangles[(size_t)tid_out * 3u] = ids[0];
@@ -186,18 +203,22 @@ mc_emit_kernel(const float* __restrict__ field, uint32_t R0, uint32_t R1, uint32
 }
 
 struct McLayout {
-    uint32_t N, nb;
-    size_t info, voff, toff, total;
+    uint32_t N, nb, nc;
+    size_t info, bsum, voff, toff, chunk_v, chunk_t, total;
 };
 McLayout mc_layout(uint32_t R0, uint32_t R1, uint32_t R2) {
     McLayout l;
     l.N = R0 * R1 * R2;
     l.nb = n2m_ceil_div(l.N, kMcBlock);
+    l.nc = n2m_ceil_div(l.nb, kMcChunk);              // <= 1024 for fewer than 2^31 nodes
     auto up = [](size_t v) { return (v + 255u) & ~(size_t)255u; };
     l.info = 0;
-    l.voff = up((size_t)l.N * 4u);
-    l.toff = l.voff + up(((size_t)l.nb + 1u) * 4u);
-    l.total = l.toff + up(((size_t)l.nb + 1u) * 4u);
+    l.bsum = up((size_t)l.N * 4u);
+    l.voff = l.bsum + up((size_t)l.nb * 4u);
+    l.toff = l.voff + up((size_t)l.nb * 4u);
+    l.chunk_v = l.toff + up((size_t)l.nb * 4u);
+    l.chunk_t = l.chunk_v + up((size_t)l.nc * 8u);
+    l.total = l.chunk_t + up((size_t)l.nc * 8u);
     return l;
 }
 
@@ -225,12 +246,17 @@ extern "C" int n2m_marching_cubes_count(const float* field, uint32_t R0, uint32_
     const McLayout l = mc_layout(R0, R1, R2);
     char* ws = static_cast<char*>(workspace);
     uint32_t* info = reinterpret_cast<uint32_t*>(ws + l.info);
+    uint32_t* bsum = reinterpret_cast<uint32_t*>(ws + l.bsum);
     uint32_t* voff = reinterpret_cast<uint32_t*>(ws + l.voff);
     uint32_t* toff = reinterpret_cast<uint32_t*>(ws + l.toff);
+    unsigned long long* cv = reinterpret_cast<unsigned long long*>(ws + l.chunk_v);
+    unsigned long long* ct = reinterpret_cast<unsigned long long*>(ws + l.chunk_t);
     hipStream_t s = (hipStream_t)stream;
-    mc_count_kernel<<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, iso, info, voff, toff);
+    mc_count_kernel<<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, iso, info, bsum);
     N2M_CHECK_LAUNCH();
-    mc_scan_kernel<<<1, 1024, 0, s>>>(voff, toff, l.nb, reinterpret_cast<unsigned long long*>(totals));
+    mc_scan_chunks_kernel<<<l.nc, 1024, 0, s>>>(bsum, l.nb, voff, toff, cv, ct);
+    N2M_CHECK_LAUNCH();
+    mc_scan_top_kernel<<<1, 1024, 0, s>>>(cv, ct, l.nc, reinterpret_cast<unsigned long long*>(totals));
     N2M_CHECK_LAUNCH();
     return 0;
 }
@@ -246,15 +272,18 @@ extern "C" int n2m_marching_cubes_emit(const float* field, uint32_t R0, uint32_t
     const McLayout l = mc_layout(R0, R1, R2);
     const char* ws = static_cast<const char*>(workspace);
     const uint32_t* info = reinterpret_cast<const uint32_t*>(ws + l.info);
+    const uint32_t* bsum = reinterpret_cast<const uint32_t*>(ws + l.bsum);
     const uint32_t* voff = reinterpret_cast<const uint32_t*>(ws + l.voff);
     const uint32_t* toff = reinterpret_cast<const uint32_t*>(ws + l.toff);
+    const unsigned long long* cv = reinterpret_cast<const unsigned long long*>(ws + l.chunk_v);
+    const unsigned long long* ct = reinterpret_cast<const unsigned long long*>(ws + l.chunk_t);
     hipStream_t s = (hipStream_t)stream;
     if (vertices_f64)
-        mc_emit_kernel<double><<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, iso, info, voff, toff, div, mul, add, static_cast<double*>(vertices), cap_v,
-                                                        triangles, cap_t);
+        mc_emit_kernel<double><<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, iso, info, bsum, voff, toff, cv, ct, div, mul, add,
+                                                        static_cast<double*>(vertices), cap_v, triangles, cap_t);
     else
-        mc_emit_kernel<float><<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, iso, info, voff, toff, div, mul, add, static_cast<float*>(vertices), cap_v,
-                                                       triangles, cap_t);
+        mc_emit_kernel<float><<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, iso, info, bsum, voff, toff, cv, ct, div, mul, add,
+                                                       static_cast<float*>(vertices), cap_v, triangles, cap_t);
     N2M_CHECK_LAUNCH();
     return 0;
 }
