@@ -10,8 +10,10 @@
 //   emit    vertices in node order (then axis), triangles in cell order (then table order): deterministic, no atomics.  A triangle's
 //           three vertex ids come from the owning nodes' words.
 // HBM-bound byte work: 4 B read + 4 B written per node in the count pass, 8 B read per node in the emit pass (neighbour values are
-// cache hits) + the mesh itself; workgroups without a crossing skip the emit pass after two loads.
+// cache hits) + the mesh itself; workgroups without a crossing skip the emit pass after one load.
 // Conventions (case table, solid = !(value < iso), interpolation in double with the lower corner first): tools/gen_mc_table.py.
+#include <math.h>
+
 #include "n2m_common.hpp"
 #define N2M_MC_QUAL __device__
 #include "mc_table.inc"      // kMcNumTris[256], kMcTris[256][3 * N2M_MC_MAX_TRIS]: device-resident constants
@@ -21,34 +23,60 @@ namespace {
 constexpr uint32_t kMcBlock = 256;
 constexpr uint32_t kPrefixMask = (1u << 29) - 1u;
 
-struct McNode {
-    float v[8];            // corner values, index x | y << 1 | z << 2 (x = dim 0); missing neighbours repeat the node's own value
-    uint32_t i, j, k;
-    uint32_t mask;         // owned crossed edges: bit a = the edge along dim a
-    uint32_t cas;          // cell case (0 when the node is not the low corner of a cell)
+// A thread takes VEC consecutive nodes of one row (VEC = 4 when R2 % 4 == 0: the row loads are shared -- 4 x (dwordx4 + 1) loads and ONE
+// (i, j, k) computation per 4 nodes instead of 32 loads and 4 index computations, which is what bounded the first version: VALU work
+// per node, not bytes; VEC = 1 otherwise).  A workgroup covers kMcBlock * VEC consecutive nodes.
+template <uint32_t VEC>
+struct McThread {
+    float v[4][VEC + 1u];  // rows (y + 2 x) of the thread's nodes and the node after them (missing neighbours repeat the last value)
+    uint32_t solid[4];     // bit z of row r: !(v[r][z] < iso)
+    uint32_t i, j, k0;
+    bool hx, hy, hz_last;  // neighbours exist: plane i + 1, row j + 1, the node after the thread's last one
 };
 
-__device__ __forceinline__ McNode mc_load(const float* __restrict__ f, uint32_t n, uint32_t R0, uint32_t R1, uint32_t R2, double iso) {
-    McNode nd;
+// (double)v < iso for a float v  <=>  v < c with c = the smallest float >= iso (computed on the host): the classification compares floats
+template <uint32_t VEC>
+__device__ __forceinline__ void mc_load(const float* __restrict__ f, uint32_t n0, uint32_t R0, uint32_t R1, uint32_t R2, float iso_up, McThread<VEC>& t) {
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     const uint32_t plane = R1 * R2;
-    nd.i = n / plane;
-    const uint32_t r = n - nd.i * plane;
-    nd.j = r / R2;
-    nd.k = r - nd.j * R2;
-    const bool hx = nd.i + 1u < R0, hy = nd.j + 1u < R1, hz = nd.k + 1u < R2;
+    t.i = n0 / plane;
+    const uint32_t r = n0 - t.i * plane;
+    t.j = r / R2;
+    t.k0 = r - t.j * R2;
+    t.hx = t.i + 1u < R0;
+    t.hy = t.j + 1u < R1;
+    t.hz_last = t.k0 + VEC < R2;
+    const float* __restrict__ base = f + n0;
 #pragma unroll
-    for (uint32_t c = 0; c < 8; ++c) {
-        const bool x = c & 1u, y = (c >> 1) & 1u, z = (c >> 2) & 1u;
-        const bool ok = (!x || hx) && (!y || hy) && (!z || hz);
-        nd.v[c] = f[ok ? (size_t)n + (x ? plane : 0u) + (y ? R2 : 0u) + (z ? 1u : 0u) : (size_t)n];
+    for (uint32_t rr = 0; rr < 4; ++rr) {
+        const float* __restrict__ row = base + ((rr & 2u) && t.hx ? plane : 0u) + ((rr & 1u) && t.hy ? R2 : 0u);
+        if constexpr (VEC == 4u) {
+            const f4u q = *reinterpret_cast<const f4u*>(row);
+            t.v[rr][0] = q.x; t.v[rr][1] = q.y; t.v[rr][2] = q.z; t.v[rr][3] = q.w;
+        } else {
+            t.v[rr][0] = row[0];
+        }
+        t.v[rr][VEC] = t.hz_last ? row[VEC] : t.v[rr][VEC - 1u];
+        uint32_t sb = 0;
+#pragma unroll
+        for (uint32_t z = 0; z <= VEC; ++z) sb |= (t.v[rr][z] < iso_up ? 0u : 1u) << z;
+        t.solid[rr] = sb;
     }
+}
+
+// node q of the thread: owned crossed edges (bit a = the edge along dim a) and the cell case (0 when the node is no cell's low corner)
+template <uint32_t VEC>
+__device__ __forceinline__ void mc_node(const McThread<VEC>& t, uint32_t q, uint32_t& mask, uint32_t& cas) {
+    const bool hz = q + 1u < VEC || t.hz_last;
     uint32_t bits = 0;
 #pragma unroll
-    for (uint32_t c = 0; c < 8; ++c) bits |= ((double)nd.v[c] < iso ? 0u : 1u) << c;
+    for (uint32_t c = 0; c < 8; ++c) {
+        const uint32_t x = c & 1u, y = (c >> 1) & 1u, z = c >> 2;
+        bits |= ((t.solid[y + 2u * x] >> (q + z)) & 1u) << c;
+    }
     const uint32_t s0 = bits & 1u;
-    nd.mask = ((hx && ((bits >> 1) & 1u) != s0) ? 1u : 0u) | ((hy && ((bits >> 2) & 1u) != s0) ? 2u : 0u) | ((hz && ((bits >> 4) & 1u) != s0) ? 4u : 0u);
-    nd.cas = (hx && hy && hz) ? bits : 0u;
-    return nd;
+    mask = ((t.hx && ((bits >> 1) & 1u) != s0) ? 1u : 0u) | ((t.hy && ((bits >> 2) & 1u) != s0) ? 2u : 0u) | ((hz && ((bits >> 4) & 1u) != s0) ? 4u : 0u);
+    cas = (t.hx && t.hy && hz) ? bits : 0u;
 }
 
 // exclusive scan of (nt << 16 | nv) over the workgroup; returns the packed exclusive prefix, *total = packed workgroup sum
@@ -68,20 +96,35 @@ __device__ __forceinline__ uint32_t mc_block_scan(uint32_t packed, uint32_t* wav
     return off + incl - packed;
 }
 
+template <uint32_t VEC>
 __global__ void __launch_bounds__(kMcBlock)
-mc_count_kernel(const float* __restrict__ field, uint32_t R0, uint32_t R1, uint32_t R2, uint32_t N, double iso, uint32_t* __restrict__ info,
+mc_count_kernel(const float* __restrict__ field, uint32_t R0, uint32_t R1, uint32_t R2, uint32_t N, float iso_up, uint32_t* __restrict__ info,
                 uint32_t* __restrict__ bsum) {
     __shared__ uint32_t wave_tot[kMcBlock / 64u];
-    const uint32_t n = blockIdx.x * kMcBlock + threadIdx.x;
-    uint32_t mask = 0, nt = 0;
-    if (n < N) {
-        const McNode nd = mc_load(field, n, R0, R1, R2, iso);
-        mask = nd.mask;
-        nt = kMcNumTris[nd.cas];
+    const uint32_t n0 = (blockIdx.x * kMcBlock + threadIdx.x) * VEC;       // N % VEC == 0: a thread's nodes are all inside or all outside
+    uint32_t mask[VEC], packed = 0;
+    if (n0 < N) {
+        McThread<VEC> t;
+        mc_load<VEC>(field, n0, R0, R1, R2, iso_up, t);
+#pragma unroll
+        for (uint32_t q = 0; q < VEC; ++q) {
+            uint32_t cas;
+            mc_node<VEC>(t, q, mask[q], cas);
+            packed += ((uint32_t)kMcNumTris[cas] << 16) | (uint32_t)__popc(mask[q]);
+        }
     }
     uint32_t total;
-    const uint32_t excl = mc_block_scan((nt << 16) | (uint32_t)__popc(mask), wave_tot, &total);
-    if (n < N) info[n] = (mask << 29) | (excl & 0xFFFFu);
+    uint32_t excl = mc_block_scan(packed, wave_tot, &total) & 0xFFFFu;     // vertices in front of this thread's nodes inside the workgroup
+    if (n0 < N) {
+        uint32_t w[VEC];
+#pragma unroll
+        for (uint32_t q = 0; q < VEC; ++q) {
+            w[q] = (mask[q] << 29) | excl;
+            excl += (uint32_t)__popc(mask[q]);
+        }
+        if constexpr (VEC == 4u) *reinterpret_cast<uint4*>(info + n0) = make_uint4(w[0], w[1], w[2], w[3]);
+        else info[n0] = w[0];
+    }
     if (threadIdx.x == 0) bsum[blockIdx.x] = total;                       // triangles << 16 | vertices of this workgroup's nodes
 }
 
@@ -144,72 +187,85 @@ mc_scan_top_kernel(unsigned long long* __restrict__ chunk_v, unsigned long long*
     if (tid == 0) { totals[0] = sv[1023]; totals[1] = st[1023]; }
 }
 
-template <typename VT>
+template <typename VT, uint32_t VEC>
 __global__ void __launch_bounds__(kMcBlock)
-mc_emit_kernel(const float* __restrict__ field, uint32_t R0, uint32_t R1, uint32_t R2, uint32_t N, double iso,
+mc_emit_kernel(const float* __restrict__ field, uint32_t R0, uint32_t R1, uint32_t R2, uint32_t N, double iso, float iso_up,
                const uint32_t* __restrict__ info, const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ voff,
                const uint32_t* __restrict__ toff, const unsigned long long* __restrict__ chunk_v, const unsigned long long* __restrict__ chunk_t,
                double div, double mul, double add, VT* __restrict__ vertices, uint32_t cap_v, int32_t* __restrict__ triangles, uint32_t cap_t) {
     __shared__ uint32_t wave_tot[kMcBlock / 64u];
+    constexpr uint32_t kNodes = kMcBlock * VEC;                           // nodes per workgroup
     const uint32_t b = blockIdx.x;
     if (bsum[b] == 0u) return;                                            // nothing crosses this workgroup's nodes (block-uniform)
     const uint32_t v0 = voff[b] + (uint32_t)chunk_v[b / kMcChunk], t0 = toff[b] + (uint32_t)chunk_t[b / kMcChunk];
-    const uint32_t n = b * kMcBlock + threadIdx.x;
-    McNode nd;
-    nd.mask = 0; nd.cas = 0;
-    if (n < N) nd = mc_load(field, n, R0, R1, R2, iso);
-    const uint32_t nt = kMcNumTris[nd.cas];
-    uint32_t total;
-    const uint32_t excl = mc_block_scan((nt << 16) | (uint32_t)__popc(nd.mask), wave_tot, &total);
-    if (n >= N) return;
-    // ---- vertices of the owned edges: PyMCubes' interpolation, x1 + (iso - f1) / (f2 - f1) in double, lower corner first
-    uint32_t vid = v0 + (excl & 0xFFFFu);
+    const uint32_t n0 = (b * kMcBlock + threadIdx.x) * VEC;
+    McThread<VEC> th;
+    uint32_t mask[VEC], cas[VEC], packed = 0;
 #pragma unroll
-    for (uint32_t a = 0; a < 3; ++a) {
-        if (!((nd.mask >> a) & 1u)) continue;
-        const double f1 = (double)nd.v[0], f2 = (double)nd.v[a == 0 ? 1 : (a == 1 ? 2 : 4)];
-        double p[3] = {(double)nd.i, (double)nd.j, (double)nd.k};
-        p[a] = p[a] + (iso - f1) / (f2 - f1);
-        if (vid < cap_v) {
+    for (uint32_t q = 0; q < VEC; ++q) { mask[q] = 0; cas[q] = 0; }
+    if (n0 < N) {
+        mc_load<VEC>(field, n0, R0, R1, R2, iso_up, th);
 #pragma unroll
-            for (uint32_t d = 0; d < 3; ++d) vertices[(size_t)vid * 3u + d] = (VT)(((p[d] / div) * mul) + add);
+        for (uint32_t q = 0; q < VEC; ++q) {
+            mc_node<VEC>(th, q, mask[q], cas[q]);
+            packed += ((uint32_t)kMcNumTris[cas[q]] << 16) | (uint32_t)__popc(mask[q]);
         }
-        ++vid;
     }
-    // ---- triangles of the cell
-    if (nt == 0u) return;
+    uint32_t total;
+    const uint32_t excl = mc_block_scan(packed, wave_tot, &total);
+    if (n0 >= N || packed == 0u) return;
+    uint32_t vid = v0 + (excl & 0xFFFFu), tid_out = t0 + (excl >> 16);
     const uint32_t plane = R1 * R2;
-    uint32_t tid_out = t0 + (excl >> 16);
-    const unsigned char* __restrict__ row = kMcTris[nd.cas];
-    for (uint32_t t = 0; t < nt; ++t, ++tid_out) {
-        int32_t ids[3];
 #pragma unroll
-        for (uint32_t m = 0; m < 3; ++m) {
-            const uint32_t e = row[3u * t + m];
-            const uint32_t a = e >> 2, u = e & 1u, v = (e >> 1) & 1u;
-            // the edge's lower corner: the other two coordinates in axis order (axis 0: (y, z), 1: (x, z), 2: (x, y))
-            const uint32_t dx = a == 0u ? 0u : u, dy = a == 0u ? u : (a == 1u ? 0u : v), dz = a == 2u ? 0u : v;
-            const uint32_t owner = n + dx * plane + dy * R2 + dz;
-            const uint32_t w = info[owner];
-            const uint32_t ob = owner / kMcBlock;
-            ids[m] = (int32_t)(voff[ob] + (uint32_t)chunk_v[ob / kMcChunk] + (w & kPrefixMask) + (uint32_t)__popc((w >> 29) & ((1u << a) - 1u)));
+    for (uint32_t q = 0; q < VEC; ++q) {
+        // ---- vertices of the owned edges: PyMCubes' interpolation, x1 + (iso - f1) / (f2 - f1) in double, lower corner first
+#pragma unroll
+        for (uint32_t a = 0; a < 3; ++a) {
+            if (!((mask[q] >> a) & 1u)) continue;
+            const double f1 = (double)th.v[0][q], f2 = (double)(a == 0u ? th.v[2][q] : (a == 1u ? th.v[1][q] : th.v[0][q + 1u]));
+            double p[3] = {(double)th.i, (double)th.j, (double)(th.k0 + q)};
+            p[a] = p[a] + (iso - f1) / (f2 - f1);
+            if (vid < cap_v) {
+#pragma unroll
+                for (uint32_t d = 0; d < 3; ++d) vertices[(size_t)vid * 3u + d] = (VT)(((p[d] / div) * mul) + add);
+            }
+            ++vid;
         }
-        if (tid_out < cap_t) {
-            triangles[(size_t)tid_out * 3u] = ids[0];
-            triangles[(size_t)tid_out * 3u + 1u] = ids[1];
-            triangles[(size_t)tid_out * 3u + 2u] = ids[2];
+        // ---- triangles of the cell
+        const uint32_t nt = kMcNumTris[cas[q]];
+        const unsigned char* __restrict__ row = kMcTris[cas[q]];
+        const uint32_t n = n0 + q;
+        for (uint32_t t = 0; t < nt; ++t, ++tid_out) {
+            int32_t ids[3];
+#pragma unroll
+            for (uint32_t m = 0; m < 3; ++m) {
+                const uint32_t e = row[3u * t + m];
+                const uint32_t a = e >> 2, u = e & 1u, v = (e >> 1) & 1u;
+                // the edge's lower corner: the other two coordinates in axis order (axis 0: (y, z), 1: (x, z), 2: (x, y))
+                const uint32_t dx = a == 0u ? 0u : u, dy = a == 0u ? u : (a == 1u ? 0u : v), dz = a == 2u ? 0u : v;
+                const uint32_t owner = n + dx * plane + dy * R2 + dz;
+                const uint32_t w = info[owner];
+                const uint32_t ob = owner / kNodes;
+                ids[m] = (int32_t)(voff[ob] + (uint32_t)chunk_v[ob / kMcChunk] + (w & kPrefixMask) + (uint32_t)__popc((w >> 29) & ((1u << a) - 1u)));
+            }
+            if (tid_out < cap_t) {
+                triangles[(size_t)tid_out * 3u] = ids[0];
+                triangles[(size_t)tid_out * 3u + 1u] = ids[1];
+                triangles[(size_t)tid_out * 3u + 2u] = ids[2];
+            }
         }
     }
 }
 
 struct McLayout {
-    uint32_t N, nb, nc;
+    uint32_t N, nb, nc, vec;
     size_t info, bsum, voff, toff, chunk_v, chunk_t, total;
 };
 McLayout mc_layout(uint32_t R0, uint32_t R1, uint32_t R2) {
     McLayout l;
     l.N = R0 * R1 * R2;
-    l.nb = n2m_ceil_div(l.N, kMcBlock);
+    l.vec = (R2 % 4u == 0u) ? 4u : 1u;
+    l.nb = n2m_ceil_div(l.N, kMcBlock * l.vec);
     l.nc = n2m_ceil_div(l.nb, kMcChunk);              // <= 1024 for fewer than 2^31 nodes
     auto up = [](size_t v) { return (v + 255u) & ~(size_t)255u; };
     l.info = 0;
@@ -220,6 +276,13 @@ McLayout mc_layout(uint32_t R0, uint32_t R1, uint32_t R2) {
     l.chunk_t = l.chunk_v + up((size_t)l.nc * 8u);
     l.total = l.chunk_t + up((size_t)l.nc * 8u);
     return l;
+}
+
+// smallest float >= iso: (double)v < iso  <=>  v < mc_iso_up(iso) for every float v
+float mc_iso_up(double iso) {
+    float c = (float)iso;
+    if ((double)c < iso) c = nextafterf(c, INFINITY);
+    return c;
 }
 
 int mc_check(const char* fn, const void* field, uint32_t R0, uint32_t R1, uint32_t R2, const void* ws, uint64_t ws_bytes) {
@@ -252,7 +315,8 @@ extern "C" int n2m_marching_cubes_count(const float* field, uint32_t R0, uint32_
     unsigned long long* cv = reinterpret_cast<unsigned long long*>(ws + l.chunk_v);
     unsigned long long* ct = reinterpret_cast<unsigned long long*>(ws + l.chunk_t);
     hipStream_t s = (hipStream_t)stream;
-    mc_count_kernel<<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, iso, info, bsum);
+    if (l.vec == 4u) mc_count_kernel<4><<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, mc_iso_up(iso), info, bsum);
+    else mc_count_kernel<1><<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, mc_iso_up(iso), info, bsum);
     N2M_CHECK_LAUNCH();
     mc_scan_chunks_kernel<<<l.nc, 1024, 0, s>>>(bsum, l.nb, voff, toff, cv, ct);
     N2M_CHECK_LAUNCH();
@@ -278,12 +342,13 @@ extern "C" int n2m_marching_cubes_emit(const float* field, uint32_t R0, uint32_t
     const unsigned long long* cv = reinterpret_cast<const unsigned long long*>(ws + l.chunk_v);
     const unsigned long long* ct = reinterpret_cast<const unsigned long long*>(ws + l.chunk_t);
     hipStream_t s = (hipStream_t)stream;
-    if (vertices_f64)
-        mc_emit_kernel<double><<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, iso, info, bsum, voff, toff, cv, ct, div, mul, add,
-                                                        static_cast<double*>(vertices), cap_v, triangles, cap_t);
-    else
-        mc_emit_kernel<float><<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, iso, info, bsum, voff, toff, cv, ct, div, mul, add,
-                                                       static_cast<float*>(vertices), cap_v, triangles, cap_t);
+    const float up = mc_iso_up(iso);
+#define N2M_MC_EMIT(VT, VEC)                                                                                                              \
+    mc_emit_kernel<VT, VEC><<<l.nb, kMcBlock, 0, s>>>(field, R0, R1, R2, l.N, iso, up, info, bsum, voff, toff, cv, ct, div, mul, add,     \
+                                                     static_cast<VT*>(vertices), cap_v, triangles, cap_t)
+    if (vertices_f64) { if (l.vec == 4u) N2M_MC_EMIT(double, 4); else N2M_MC_EMIT(double, 1); }
+    else { if (l.vec == 4u) N2M_MC_EMIT(float, 4); else N2M_MC_EMIT(float, 1); }
+#undef N2M_MC_EMIT
     N2M_CHECK_LAUNCH();
     return 0;
 }

@@ -27,6 +27,8 @@ def _fields():
     out["ragged"] = (rng.normal(size=(5, 9, 33)).astype(np.float32), 0.25)      # open surface, three different extents
     ties = rng.integers(-1, 2, size=(9, 8, 7)).astype(np.float32)     # values exactly equal to iso count as solid
     out["ties"] = (ties, 0.0)
+    out["ragged4"] = (rng.normal(size=(5, 9, 32)).astype(np.float32), -0.3)     # last extent a multiple of 4: four nodes per thread
+    out["ties4"] = (rng.integers(-1, 2, size=(7, 9, 8)).astype(np.float32), 0.0)
     out["thin"] = (rng.normal(size=(1, 6, 6)).astype(np.float32), 0.0)          # a single layer of nodes: vertices, no cell
     out["point"] = (np.ones((1, 1, 1), np.float32), 0.0)
     out["empty"] = (np.full((6, 6, 6), -1.0, np.float32), 0.0)
@@ -105,7 +107,7 @@ def test_mesh_filters_restate_the_pymeshlab_selections():
 # ------------------------------------------------------------------------------------------------------------ GPU
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["sphere", "torus", "noise", "ragged", "ties", "thin", "point", "empty", "full"])
+@pytest.mark.parametrize("name", ["sphere", "torus", "noise", "ragged", "ties", "ragged4", "ties4", "thin", "point", "empty", "full"])
 def test_hip_marching_cubes_equals_the_oracle_bit_for_bit(name):
     import torch
     from nerf2mesh_amd.marching_cubes import marching_cubes
