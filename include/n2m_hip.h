@@ -321,6 +321,12 @@ int n2m_marching_cubes_emit(const float* volume, uint32_t R0, uint32_t R1, uint3
                             uint64_t workspace_bytes, double div, double mul, double add, void* vertices, int vertices_f64,
                             uint32_t cap_v, int32_t* triangles, uint32_t cap_t, void* stream);
 
+/* Texture-bake padding (reference: the host-side kd-tree fill of nerf/renderer.py:371-387, `NearestNeighbors(n_neighbors=1)` over texel
+ * coordinates).  feats [H][W][C] u8, in place; role [H][W] u8: bit 0 = source texel (chart boundary ring), bit 1 = destination texel
+ * (the band around the charts).  Every destination takes the features of the nearest source within `radius` texels (Euclidean on
+ * (row, column); ties: smallest row, then column); destinations with no source in range are left as they are. */
+int n2m_texture_pad_nearest(uint8_t* feats, const uint8_t* role, uint32_t H, uint32_t W, uint32_t C, uint32_t radius, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * freqencoder   (reference: freqencoder/src/freqencoder.h:6-10, freqencoder/src/bindings.cpp:5-8)
  * ---------------------------------------------------------------------------------------------------- */

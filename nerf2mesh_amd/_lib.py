@@ -53,6 +53,7 @@ SIGNATURES = {
     "n2m_marching_cubes_count": [_vp, _u32, _u32, _u32, ctypes.c_double, _vp, _u64, _vp, _vp],
     "n2m_marching_cubes_emit": [_vp, _u32, _u32, _u32, ctypes.c_double, _vp, _u64, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp, _int,
                                 _u32, _vp, _u32, _vp],
+    "n2m_texture_pad_nearest": [_vp, _vp, _u32, _u32, _u32, _u32, _vp],
     "n2m_freq_encode_forward": [_vp, _u32, _u32, _u32, _u32, _vp, _vp],
     "n2m_freq_encode_backward": [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp],
     "n2m_get_rays": [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],

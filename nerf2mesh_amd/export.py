@@ -153,3 +153,32 @@ def remove_faces(vertices, triangles, remove, dilation=5):
     used[tri.reshape(-1)] = True
     remap = torch.cumsum(used.to(torch.int64), 0) - 1
     return vertices[used], remap[tri].to(triangles.dtype)
+
+
+# ------------------------------------------------------------------------------------------------ texture atlas / images
+def grid_atlas(n_faces, margin=0.12, device="cpu"):
+    """A trivial UV atlas: face i gets its own right triangle in cell i // 2 of a G x G grid (two faces per cell, `margin` of the cell
+    kept free around each).  Returns (vt [3 F, 2] in [0, 1], ft [F, 3] int32).  Stand-in for the xatlas unwrap of nerf/renderer.py:312-322
+    (xatlas is an un-vendored dependency and UV unwrapping is outside the hot path): valid and seam-free per face,
+    but it spends the texture uniformly per face instead of per area."""
+    import math
+    import torch
+    F = int(n_faces)
+    G = max(1, math.ceil(math.sqrt((F + 1) // 2)))
+    s, m = 1.0 / G, margin / G
+    i = torch.arange(F, device=device)
+    cell = i // 2
+    ox, oy = (cell % G).float() * s, (cell // G).float() * s
+    lower = torch.tensor([[m, m], [s - 2 * m, m], [m, s - 2 * m]], device=device)
+    upper = torch.tensor([[s - m, s - m], [2 * m, s - m], [s - m, 2 * m]], device=device)
+    tri = torch.where((i % 2 == 0)[:, None, None], lower[None], upper[None])                       # [F, 3, 2]
+    vt = (tri + torch.stack([ox, oy], dim=-1)[:, None, :]).reshape(-1, 2).contiguous()
+    ft = torch.arange(3 * F, dtype=torch.int32, device=device).reshape(F, 3)
+    return vt, ft
+
+
+def write_jpg(path, rgb):
+    """[H, W, 3] uint8 RGB -> JPEG.  The reference writes through cv2.imwrite (default quality 95, nerf/renderer.py:399-400) after an
+    RGB -> BGR swap for cv2's channel order: the file holds the RGB image either way."""
+    from PIL import Image
+    Image.fromarray(np.ascontiguousarray(rgb, dtype=np.uint8), "RGB").save(path, quality=95)

@@ -34,6 +34,21 @@ def contract(xyzs):
     return torch.where(mag <= 1, xyzs, xyzs * (2 - 1 / mag) / mag)
 
 
+def dilate_cross(a):
+    """One step of scipy.ndimage.binary_dilation with its default (4-neighbour cross) structuring element, on a [H,W] bool tensor."""
+    b = a.clone()
+    b[1:] |= a[:-1]; b[:-1] |= a[1:]; b[:, 1:] |= a[:, :-1]; b[:, :-1] |= a[:, 1:]
+    return b
+
+
+def erode_cross(a):
+    """One step of scipy.ndimage.binary_erosion (cross element, border_value = 0: the outside of the image counts as empty)."""
+    b = a.clone()
+    b[1:] &= a[:-1]; b[:-1] &= a[1:]; b[:, 1:] &= a[:, :-1]; b[:, :-1] &= a[:, 1:]
+    b[0] = False; b[-1] = False; b[:, 0] = False; b[:, -1] = False
+    return b
+
+
 class NeRFRenderer(nn.Module):
     @property
     def mean_density(self):
@@ -341,10 +356,89 @@ class NeRFRenderer(nn.Module):
         self.vertices = vertices.float().to(dev).contiguous()
         self.triangles = triangles.int().to(dev).contiguous()
         self.v_cumsum = v_cumsum if v_cumsum is not None else [0, self.vertices.shape[0]]
+        self.f_cumsum = [0, self.triangles.shape[0]]        # one cascade unless the caller sets both (nerf/renderer.py:150-165)
         self.vertices_offsets = nn.Parameter(torch.zeros_like(self.vertices))
         self.triangles_errors = torch.zeros(self.triangles.shape[0], dtype=torch.float32, device=dev)
         self.triangles_errors_cnt = torch.zeros(self.triangles.shape[0], dtype=torch.float32, device=dev)
         self.triangles_errors_id = None
+
+    @torch.no_grad()
+    def bake_textures(self, v, f, vt, ft, h0, w0, ssaa=1, pad=32):
+        """The texture bake of nerf/renderer.py:324-397 for one mesh: rasterise the atlas (uv -> clip space), interpolate the surface
+        position of every covered texel, evaluate geo_feat there (6 channels: diffuse + specular features), quantise to uint8, fill the
+        band around the charts from the nearest chart-boundary texel, reduce by `ssaa`.  Everything up to the two uint8 images stays on
+        the device: the reference's host kd-tree search is a ring walk per band texel (csrc/texture.hip).
+        v [V,3], f [F,3] int32, vt [T,2] in [0,1], ft [F,3] int32 -> (feat0 [h0,w0,3] uint8, feat1 [h0,w0,3] uint8, mask [h,w] bool)."""
+        from . import _lib as L
+        dev = v.device
+        h, w = (int(h0 * ssaa), int(w0 * ssaa)) if ssaa > 1 else (h0, w0)
+        uv = vt.float() * 2.0 - 1.0
+        uv = torch.cat((uv, torch.zeros_like(uv[..., :1]), torch.ones_like(uv[..., :1])), dim=-1).contiguous()
+        ctx = self.glctx or dr.RasterizeGLContext(output_db=False)
+        rast, _ = dr.rasterize(ctx, uv.unsqueeze(0), ft.int().contiguous(), (h, w))
+        xyzs, _ = dr.interpolate(v.float().unsqueeze(0).contiguous(), rast, f.int().contiguous())
+        mask = (rast[..., 3] > 0).view(-1)        # == (interpolate(ones) > 0) of :333-338: a covered texel's barycentrics sum to one
+        xyzs = xyzs.view(-1, 3)
+        if self.opt.contract:
+            xyzs = contract(xyzs)
+        feats = torch.zeros(h * w, 6, device=dev, dtype=torch.float32)
+        idx = torch.nonzero(mask, as_tuple=False).squeeze(1)
+        ind_code = self.individual_codes[[0]] if self.individual_dim > 0 else None
+        for head in range(0, idx.numel(), 640000):
+            sel = idx[head:head + 640000]
+            with torch.autocast(device_type="cuda", dtype=torch.float16, enabled=bool(self.opt.fp16)):
+                feats[sel] = self.geo_feat(xyzs[sel].contiguous(), ind_code).float()
+        q = (feats * 255).to(torch.uint8).view(h, w, 6).contiguous()          # (feats * 255).astype(np.uint8): truncation (:366)
+        m = mask.view(h, w)
+        # band = 32 steps of 4-neighbour dilation minus the charts; sources = the charts minus their 3-step erosion (:371-377;
+        # scipy's default structuring element is the cross, the outside of the image counts as empty)
+        band = m
+        for _ in range(int(pad)):
+            band = dilate_cross(band)
+        band = band & ~m
+        core = m
+        for _ in range(3):
+            core = erode_cross(core)
+        ring = m & ~core
+        role = (ring.to(torch.uint8) | (band.to(torch.uint8) << 1)).contiguous()
+        if bool(ring.any()):
+            L.call("n2m_texture_pad_nearest", L.ptr(q), L.ptr(role), h, w, 6, int(pad), L.stream())
+        if ssaa > 1:      # cv2.resize(..., INTER_LINEAR) of :393-395; here bilinear on the device, rounded to nearest
+            x = q.permute(2, 0, 1).float().unsqueeze(0)
+            x = F.interpolate(x, size=(h0, w0), mode="bilinear", align_corners=False)
+            q = x[0].permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8)
+        return q[..., :3].contiguous(), q[..., 3:].contiguous(), m
+
+    @torch.no_grad()
+    def export_stage1(self, path, h0=2048, w0=2048, atlas=None):
+        """nerf/renderer.py:298-468: per cascade `mesh_{cas}.obj/.mtl`, `feat0_{cas}.jpg` (diffuse), `feat1_{cas}.jpg` (specular
+        features), and `mlp.json` -- the files renderer.html loads.  atlas: {cas: (vt [T,2] in [0,1], ft [F,3])}; the reference unwraps
+        with xatlas (:312-322, un-vendored, outside the hot path) -- without an atlas every face gets its own cell (export.grid_atlas)."""
+        import os
+        from . import export
+        assert self.opt.stage > 0, "export_stage1 needs the stage-1 mesh (init_stage1)"
+        os.makedirs(path, exist_ok=True)
+        v_all = (self.vertices + self.vertices_offsets).detach()
+        f_all = self.triangles.detach()
+        ssaa = int(getattr(self.opt, "ssaa", 1))
+        out = {}
+        for cas in range(len(self.v_cumsum) - 1):
+            v = v_all[self.v_cumsum[cas]:self.v_cumsum[cas + 1]].contiguous()
+            f = (f_all[self.f_cumsum[cas]:self.f_cumsum[cas + 1]] - self.v_cumsum[cas]).contiguous()
+            if f.shape[0] == 0:
+                continue
+            vt, ft = atlas[cas] if atlas is not None else export.grid_atlas(f.shape[0], device=v.device)
+            vt, ft = torch.as_tensor(vt).float().to(v.device), torch.as_tensor(ft).int().to(v.device)
+            feat0, feat1, mask = self.bake_textures(v, f, vt, ft, h0, w0, ssaa)
+            export.write_jpg(os.path.join(path, f"feat0_{cas}.jpg"), feat0.cpu().numpy())
+            export.write_jpg(os.path.join(path, f"feat1_{cas}.jpg"), feat1.cpu().numpy())
+            export.write_obj(path, cas, v.cpu().numpy(), f.cpu().numpy(), vt.cpu().numpy(), ft.cpu().numpy())
+            out[cas] = (feat0, feat1, mask)
+            if not self.opt.sdf and h0 > 2048 and w0 > 2048:      # half the texture resolution for the remote cascades (:446-448)
+                h0 //= 2
+                w0 //= 2
+        export.write_mlp_json(os.path.join(path, "mlp.json"), self)
+        return out
 
     def render_stage1(self, rays_o, rays_d, mvp, h0, w0, index=None, bg_color=None, shading="full", **kwargs):
         """Rasterise the mesh, shade covered pixels with the colour networks, antialias (nerf/renderer.py:816-921)."""
