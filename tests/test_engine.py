@@ -72,3 +72,28 @@ def test_engine_rejects_configurations_outside_the_fast_path():
     opt = make_options(O=True, bound=1, dt_gamma=0, sdf=True, fused_mlp=True)
     with pytest.raises(ValueError):
         Stage0Engine(NeRFNetwork(opt), opt, synthetic.make_cameras(4, seed=0), torch.device("cuda", 0))
+
+
+@pytest.mark.gpu
+def test_engine_steps_through_batches_without_a_single_sample():
+    """Cameras that look away from the scene: every ray misses the box, every batch has M = 0.  The step must still run its whole
+    sequence (a rank in that state still takes part in every collective of a multi-GPU step): loss finite, gradients zero, parameters
+    unchanged (Adam's update of a zero gradient with zero moments is zero), loss scale and step counts advancing like any other step."""
+    from nerf2mesh_amd import synthetic
+    from nerf2mesh_amd.engine import Stage0Engine
+    from nerf2mesh_amd.network import NeRFNetwork
+    from nerf2mesh_amd.options import make_options
+    torch.manual_seed(0)
+    opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=True)
+    poses = synthetic.make_cameras(6, seed=0).clone()
+    poses[:, :3, 3] = poses[:, :3, 3] * 1.0 + poses[:, :3, 2] * 50.0          # 50 units back along +z of the camera (it looks down -z) ...
+    poses[:, :3, :3] = poses[:, :3, :3] @ torch.diag(torch.tensor([1.0, -1.0, -1.0]))   # ... and turned around
+    eng = Stage0Engine(NeRFNetwork(opt), opt, poses, torch.device("cuda", 0), seed=0)
+    before = [p.detach().clone() for p in eng.model.parameters()]
+    losses = [float(eng.train_step()) for _ in range(20)]                       # crosses an occupancy refresh
+    torch.cuda.synchronize()
+    assert eng.samples_seen == 0 and eng.rays_seen > 0
+    assert all(np.isfinite(losses))
+    for p, q in zip(eng.model.parameters(), before):
+        assert torch.equal(p.detach(), q)
+    assert float(eng.optimizer.scale) > 0 and float(eng.optimizer.found_inf) == 0

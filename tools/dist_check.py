@@ -20,11 +20,18 @@ device = torch.device("cuda", local % torch.cuda.device_count())
 torch.cuda.set_device(device)
 torch.manual_seed(0)
 opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=True)
+poses = synthetic.make_cameras(100, seed=0)
+if os.environ.get("N2M_DIST_BLIND_RANK") == str(rank):
+    # this rank's cameras are moved 50 units back and turned around: every ray misses the scene, every batch of the rank has zero samples.
+    # It must still issue the same collectives in the same order as the ranks that have samples (and apply the summed gradients).
+    poses = poses.clone()
+    poses[:, :3, 3] = poses[:, :3, 3] + poses[:, :3, 2] * 50.0
+    poses[:, :3, :3] = poses[:, :3, :3] @ torch.diag(torch.tensor([1.0, -1.0, -1.0]))
 if ENGINE:
     from nerf2mesh_amd.engine import Stage0Engine
-    tr = Stage0Engine(NeRFNetwork(opt), opt, synthetic.make_cameras(100, seed=0), device, rank=rank, world_size=world, seed=0)
+    tr = Stage0Engine(NeRFNetwork(opt), opt, poses, device, rank=rank, world_size=world, seed=0)
 else:
-    tr = Stage0Trainer(NeRFNetwork(opt), opt, synthetic.make_cameras(100, seed=0), device, rank=rank, world_size=world, seed=0)
+    tr = Stage0Trainer(NeRFNetwork(opt), opt, poses, device, rank=rank, world_size=world, seed=0)
 tr.mark_untrained()
 losses = [float(tr.train_step()) for _ in range(steps)]
 if hasattr(tr, "sync_parameters"):
@@ -42,7 +49,14 @@ if world > 1:
     ok = ok and all(torch.equal(g, gathered[0]) for g in gathered)
     dist.barrier()
 first, last = sum(losses[:5]) / 5, sum(losses[-5:]) / 5
-ok = ok and last < first
+if os.environ.get("N2M_DIST_BLIND_RANK") is None:
+    ok = ok and last < first
+else:                                  # the blind rank's own loss is the constant background error
+    ok = ok and (last < first or os.environ.get("N2M_DIST_BLIND_RANK") == str(rank))
+    blind = torch.tensor([float(tr.samples_seen)], device=device)
+    allb = [torch.zeros_like(blind) for _ in range(world)]
+    dist.all_gather(allb, blind)
+    ok = ok and float(allb[int(os.environ["N2M_DIST_BLIND_RANK"])]) == 0 and sum(float(b) for b in allb) > 0
 if rank == 0:
     print(f"DIST_CHECK {'OK' if ok else 'FAILED'} driver={type(tr).__name__} shard={getattr(tr, 'shard', False)} world={world} steps={steps} loss {first:.5f} -> {last:.5f} digest={[float(x) for x in digest]}")
 if world > 1:
