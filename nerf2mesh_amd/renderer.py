@@ -143,6 +143,13 @@ class NeRFRenderer(nn.Module):
             else:
                 xyzs, dirs, ts, rays = raymarching.march_rays_train(rays_o, rays_d, self.real_bound, self.opt.contract, self.density_bitfield,
                                                                     self.cascade, self.grid_size, nears, fars, perturb, dt_gamma, max_steps)
+            if xyzs.shape[0] == 0:
+                # The reference launches zero-sized grids here and carries on with undefined outputs (no launch-error checks,
+                # raymarching.cu / gridencoder.cu); the C ABI of this package rejects empty tensors.  The step executor
+                # (engine.Stage0Engine) handles sample-free batches -- a rank in that state still takes part in every collective;
+                # this autograd path does not, and says so instead of hanging a multi-rank job half-way through its collectives.
+                raise RuntimeError("render: the batch marched no sample at all (cameras outside the scene / empty occupancy grid); "
+                                   "the autograd renderer needs at least one sample -- the step executor handles empty batches")
             if ind_code is not None and ind_code.shape[0] > 1:
                 ind_code = ind_code[raymarching.flatten_rays(rays, xyzs.shape[0]).long()]
             in_kernel = hasattr(self, "_can_fuse") and self._can_fuse(ind_code)      # fused field: safe_normalize happens on load

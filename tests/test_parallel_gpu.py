@@ -52,10 +52,11 @@ def test_sharded_optimizer_equals_the_all_reduce_path(tmp_path):
 def test_a_rank_without_samples_keeps_the_collectives_in_step(shard):
     """Rank 1 looks away from the scene: all of its batches are empty.  The step executor must neither hang nor let the replicas drift
     apart -- the empty rank issues the same reduce-scatters / all-reduces in the same order and applies the other rank's gradients
-    (both optimizer layouts: sharded and all-reduce)."""
+    (both optimizer layouts of the executor: sharded and all-reduce; the autograd trainer refuses such a batch loudly in render())."""
+    driver = "engine"
     env = dict(os.environ, N2M_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", N2M_SHARD_ADAM=shard, N2M_DIST_BLIND_RANK="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531" if shard == "1" else "29533", os.path.join(ROOT, "tools", "dist_check.py"), "24", "engine"]
+           "--master-port", {"1": "29531", "0": "29533"}[shard], os.path.join(ROOT, "tools", "dist_check.py"), "24", driver]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "DIST_CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
