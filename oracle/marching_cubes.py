@@ -157,6 +157,36 @@ def marching_cubes(field, iso, div=1.0, mul=1.0, add=0.0):
     return v, t
 
 
+def marching_cubes_c(field, iso, div=1.0, mul=1.0, add=0.0):
+    """The same extraction by the plain-C restatement (oracle/n2m_oracle.c: n2m_oracle_marching_cubes) -- for volumes the emission loop
+    above is too slow for.  The case table is this module's (passed to the C side, which holds none)."""
+    import ctypes
+    from . import oracle as o
+    global _TABLE
+    if _TABLE is None:
+        _TABLE = case_table()
+    stride = 15
+    num = np.array([len(c) for c in _TABLE], np.uint8)
+    tris = np.full((256, stride), 255, np.uint8)
+    for k, c in enumerate(_TABLE):
+        flat = [e for t in c for e in t]
+        tris[k, :len(flat)] = flat
+    f = np.ascontiguousarray(field, dtype=np.float32)
+    R0, R1, R2 = f.shape
+    fn = o.lib().n2m_oracle_marching_cubes
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                   ctypes.c_uint32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                   ctypes.c_uint64, ctypes.c_void_p]
+    counts = np.zeros(2, np.uint64)
+    args = (f.ctypes.data, R0, R1, R2, float(iso), num.ctypes.data, tris.ctypes.data, stride, float(div), float(mul), float(add))
+    fn(*args, None, 0, None, 0, counts.ctypes.data)
+    v = np.empty((int(counts[0]), 3), np.float32)
+    t = np.empty((int(counts[1]), 3), np.int32)
+    fn(*args, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], counts.ctypes.data)
+    return v, t
+
+
 def _active_nodes(solid):
     """Nodes that own at least one crossed edge, in C order."""
     R0, R1, R2 = solid.shape

@@ -838,3 +838,61 @@ void n2m_oracle_freq_encode_backward(const float* grad, const float* outputs, ui
         grad_inputs[t] = result;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------ marching cubes
+ * PARITY UNPINNED (PyMCubes, the reference's `mcubes.marching_cubes` of nerf/renderer.py:524-527, is an un-vendored dependency that is
+ * absent here): a plain-C restatement of the extraction documented in oracle/marching_cubes.py, for volumes too large for that file's
+ * pure-Python emission loop.  The 256-case table is NOT in this file: the caller passes the one oracle/marching_cubes.py derives
+ * (num_tris[256], tris[256][stride] edge ids; edge e = 4 * axis + (u | v << 1), owned by the node at its lower corner).
+ * solid = !(value < iso) compared in double; vertex = lower corner + (iso - f1) / (f2 - f1) in double, mapped ((p / div) * mul) + add,
+ * then cast to float; vertices by node (C order) then axis, triangles by cell (C order) then table order.
+ * counts[0] = vertices, counts[1] = triangles; entries beyond cap_v / cap_t are counted but not written. */
+void n2m_oracle_marching_cubes(const float* f, uint32_t R0, uint32_t R1, uint32_t R2, double iso, const uint8_t* num_tris,
+                               const uint8_t* tris, uint32_t stride, double div, double mul, double add, float* vertices, uint64_t cap_v,
+                               int32_t* triangles, uint64_t cap_t, uint64_t* counts) {
+    const size_t plane = (size_t)R1 * R2, N = (size_t)R0 * plane;
+    int64_t* vid = (int64_t*)malloc(N * 3 * sizeof(int64_t));     /* vertex id of the edge leaving node n along axis a, or -1 */
+    uint64_t nv = 0, nt = 0;
+    const size_t step[3] = {plane, R2, 1};
+    for (size_t n = 0; n < N; ++n) {
+        const uint32_t i = (uint32_t)(n / plane), j = (uint32_t)((n % plane) / R2), k = (uint32_t)(n % R2);
+        const uint32_t pos[3] = {i, j, k}, ext[3] = {R0, R1, R2};
+        const double f1 = (double)f[n];
+        const int s1 = !(f1 < iso);
+        for (int a = 0; a < 3; ++a) {
+            vid[n * 3 + a] = -1;
+            if (pos[a] + 1 >= ext[a]) continue;
+            const double f2 = (double)f[n + step[a]];
+            if ((!(f2 < iso)) == s1) continue;
+            double p[3] = {(double)i, (double)j, (double)k};
+            p[a] = p[a] + (iso - f1) / (f2 - f1);
+            if (nv < cap_v)
+                for (int d = 0; d < 3; ++d) vertices[nv * 3 + d] = (float)(((p[d] / div) * mul) + add);
+            vid[n * 3 + a] = (int64_t)nv++;
+        }
+    }
+    if (R0 >= 2 && R1 >= 2 && R2 >= 2) {
+        for (uint32_t i = 0; i + 1 < R0; ++i)
+            for (uint32_t j = 0; j + 1 < R1; ++j)
+                for (uint32_t k = 0; k + 1 < R2; ++k) {
+                    const size_t n = (size_t)i * plane + (size_t)j * R2 + k;
+                    uint32_t cas = 0;
+                    for (uint32_t c = 0; c < 8; ++c) {
+                        const size_t m = n + ((c & 1u) ? plane : 0) + ((c & 2u) ? R2 : 0) + ((c & 4u) ? 1 : 0);
+                        cas |= (uint32_t)(!((double)f[m] < iso)) << c;
+                    }
+                    for (uint32_t t = 0; t < num_tris[cas]; ++t, ++nt) {
+                        if (nt >= cap_t) continue;
+                        for (int m3 = 0; m3 < 3; ++m3) {
+                            const uint32_t e = tris[(size_t)cas * stride + 3u * t + m3];
+                            const uint32_t a = e >> 2, u = e & 1u, v = (e >> 1) & 1u;
+                            const uint32_t dx = a == 0 ? 0 : u, dy = a == 0 ? u : (a == 1 ? 0 : v), dz = a == 2 ? 0 : v;
+                            triangles[nt * 3 + m3] = (int32_t)vid[(n + dx * plane + (size_t)dy * R2 + dz) * 3 + a];
+                        }
+                    }
+                }
+    }
+    counts[0] = nv;
+    counts[1] = nt;
+    free(vid);
+}

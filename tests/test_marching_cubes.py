@@ -85,6 +85,16 @@ def test_oracle_surfaces_are_closed_oriented_and_where_they_should_be():
     assert len(v) > 0 and len(t) == 0
 
 
+def test_c_restatement_equals_the_python_restatement():
+    """oracle/n2m_oracle.c (n2m_oracle_marching_cubes, used for the full-size checks) against oracle/marching_cubes.py, bit for bit."""
+    from oracle import marching_cubes as omc
+    for name, (vol, iso) in _fields().items():
+        for kw in (dict(), dict(div=7.0, mul=2.0, add=-1.0)):
+            a, b = omc.marching_cubes(vol, iso, **kw), omc.marching_cubes_c(vol, iso, **kw)
+            assert a[0].shape == b[0].shape and a[1].shape == b[1].shape, name
+            assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1]), name
+
+
 def test_mesh_filters_restate_the_pymeshlab_selections():
     import torch
     from nerf2mesh_amd import export
@@ -125,6 +135,26 @@ def test_hip_marching_cubes_equals_the_oracle_bit_for_bit(name):
     v64, t64 = marching_cubes(torch.from_numpy(vol).cuda(), iso, dtype=torch.float64)
     ov, ot = omc.marching_cubes(vol, iso)
     assert np.array_equal(v64.cpu().numpy().astype(np.float32).view(np.uint32), ov.view(np.uint32)) and np.array_equal(t64.cpu().numpy(), ot)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(192, 192, 192), (200, 168, 132), (97, 101, 103)])
+def test_hip_marching_cubes_equals_the_c_oracle_at_size(shape):
+    """A wavy field with hundreds of components that run into the volume's faces (open surfaces), at export-like sizes: vertices (float
+    bits), triangles and their order equal the plain-C restatement.  (200, 168, 132): four nodes per thread; (97, 101, 103): one."""
+    import torch
+    from nerf2mesh_amd.marching_cubes import marching_cubes
+    from oracle import marching_cubes as omc
+    ax = [np.linspace(-1, 1, r, dtype=np.float32) for r in shape]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij")
+    vol = (np.sin(7 * X) * np.cos(5 * Y) + np.sin(6 * Z + 3 * X * Y)).astype(np.float32)
+    vol[::17, ::13, ::11] = 0.2                                          # exact ties with the iso value
+    kw = dict(div=shape[0] - 1.0, mul=2.0, add=-1.0)
+    ov, ot = omc.marching_cubes_c(vol, 0.2, **kw)
+    v, t = marching_cubes(torch.from_numpy(vol).cuda(), 0.2, **kw)
+    assert tuple(v.shape) == ov.shape and tuple(t.shape) == ot.shape and ov.shape[0] > 50000
+    assert np.array_equal(t.cpu().numpy(), ot)
+    assert np.array_equal(v.cpu().numpy().view(np.uint32), ov.view(np.uint32))
 
 
 @pytest.mark.gpu
