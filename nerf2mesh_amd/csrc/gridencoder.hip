@@ -1784,7 +1784,10 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
                 // A wave's runs sit in different tiles: short pieces (64-128 entries) far apart in the log, each a DRAM round trip of
                 // ~1 us under load (shader-clock stamps: 16 serial trips = the whole walk).  The first 64 entries of kWalkAhead runs are
                 // therefore requested together before any of them is accumulated; what a long run has beyond that follows serially.
-                constexpr uint32_t kWalkAhead = 4;
+#ifndef N2M_WALK_AHEAD
+#define N2M_WALK_AHEAD 4
+#endif
+                constexpr uint32_t kWalkAhead = N2M_WALK_AHEAD;
                 for (uint32_t j0 = 0; j0 < n_t; j0 += kWalkAhead) {
                     uint32_t r_rel[kWalkAhead], r_val[kWalkAhead], r_off[kWalkAhead], r_end[kWalkAhead], r_mid[kWalkAhead];
                     size_t r_seg[kWalkAhead];
