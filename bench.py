@@ -12,6 +12,12 @@ rays over 100 synthetic 800x800 views -> near/far -> occupancy march -> 2 hash-g
 inside the timed region.  Data: synthetic lego-like scene (nerf2mesh_amd/synthetic.py), random-init network that is
 first trained for `--pretrain` untimed iterations so that the occupancy grid is in its pruned, steady state.
 
+WHICH step: the reference trains its first `diffuse_step` = 1000 iterations with diffuse-only shading (main.py:59,
+nerf/utils.py:669-672: no specular branch, no specular loss) and the other 29 000 of 30 000 with shading = 'full' (specular MLP +
+lambda_specular * mean(sum(specular^2)), nerf/utils.py:733-737).  The default `--pretrain 1000` puts warm-up and timed region BEHIND that
+switch: the line reports the steady-state step (`config.shading` = "full").  `--diffuse` times the warm-up phase instead (pretrain 300,
+steps 306.. as rounds 1-2 reported) and says so in `config.shading`.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant HIP kernel of the step: algorithmic bytes per launch / mean launch duration, measured with
                   hipEvents recorded on the launch stream inside the timed region (n2m_prof_*), against the 8 TB/s HBM peak
@@ -192,7 +198,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--pretrain", type=int, default=300, help="untimed iterations before warmup so the occupancy grid is pruned")
+    ap.add_argument("--pretrain", type=int, default=None, help="untimed iterations before warmup (default 1000 = the reference's diffuse_step: the "
+                    "occupancy grid is pruned and the timed steps run with shading='full' like 29 000 of the reference's 30 000 iterations; 300 with --diffuse)")
+    ap.add_argument("--diffuse", action="store_true", help="time the reference's first-1000-iterations phase (diffuse shading: no specular branch / loss) "
+                    "instead of the steady-state step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel hipEvents in the timed region")
     ap.add_argument("--prof-every", type=int, default=4, help="time every n-th launch of each kernel with hipEvents (1 = all)")
@@ -215,6 +224,8 @@ def main():
     from nerf2mesh_amd.trainer import Stage0Trainer
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    if args.pretrain is None:
+        args.pretrain = 300 if args.diffuse else 1000
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become the launcher -- one rank per GPU under torch.distributed.run, exactly
         # the command the driver uses (the JSON line then reports n_gpus = the rank count that actually ran)
@@ -264,6 +275,12 @@ def main():
     for _ in range(args.pretrain + args.warmup):
         tr.train_step()
     barrier()
+    first_timed = tr.global_step + 1
+    shading_of = lambda it: "diffuse" if (it < opt.diffuse_step or opt.diffuse_only) else "full"       # nerf/utils.py:669-672
+    shading = shading_of(first_timed) if shading_of(first_timed) == shading_of(first_timed + args.steps - 1) else "mixed"
+    if args.stage == 0 and not args.diffuse and shading != "full":
+        print(f"[bench] WARNING: timed steps {first_timed}..{first_timed + args.steps - 1} run with shading={shading} "
+              f"(diffuse_step={opt.diffuse_step}); raise --pretrain", file=sys.stderr)
     if not args.no_prof:
         _lib.prof_reset()
         _lib.prof_enable(args.prof_every)       # hipEvent pairs on every n-th launch of each kernel inside the timed region
@@ -295,15 +312,18 @@ def main():
         return
 
     kernels = {}
+    side_stream = ("march_rays_train_count", "march_rays_train_write", "near_far_from_aabb") if use_engine else ()
     if not args.no_prof:
         for name in ("grid_encode_forward_packed", "grid_encode_forward", "grid_encode_backward", "grad_total_variation", "march_rays_train_count",
                      "march_rays_train_write", "composite_rays_train_forward", "composite_rays_train_backward",
                      "near_far_from_aabb", "packbits", "mlp_forward", "mlp_backward", "adam_step"):
             n, ms, by = _lib.prof_read(name)
             if n:
-                kernels[name] = {"launches": n, "avg_us": 1e3 * ms / n, "algo_bytes_per_launch": by / n,
+                seen = _lib.prof_seen(name)              # ALL launches in the timed region (every prof_every-th of them carries events)
+                kernels[name] = {"launches": n, "launches_seen": seen, "avg_us": 1e3 * ms / n, "algo_bytes_per_launch": by / n,
                                  "GBps": (by / n) / (ms / n * 1e-3) / 1e9 if ms > 0 else None,
-                                 "ms_per_step": ms * max(args.prof_every, 1) / args.steps}       # every prof_every-th launch is timed
+                                 "ms_per_step": (ms / n) * seen / args.steps,                    # mean timed duration x launches per step
+                                 "stream": "side (overlaps the main stream: not part of the step's critical path)" if name in side_stream else "main"}
     def roofline_of(name):
         k = kernels[name]
         traffic, source = pmc_traffic(name)
@@ -312,8 +332,10 @@ def main():
                 "avg_us": k["avg_us"], "algo_bytes_per_launch": k["algo_bytes_per_launch"],
                 "note": "achieved = algorithmic bytes per launch (SURVEY.md 8d; cache hits count) / mean hipEvent duration over the timed region"}
     roof = roof_lookup = None
+    main_ms = sum(k["ms_per_step"] for k in kernels.values() if k["stream"] == "main")
+    side_ms = sum(k["ms_per_step"] for k in kernels.values() if k["stream"] != "main")
     if kernels:
-        roof = roofline_of(max(kernels, key=lambda k: kernels[k]["ms_per_step"]))          # the dominant entry point of the step
+        roof = roofline_of(max((k for k in kernels if kernels[k]["stream"] == "main"), key=lambda k: kernels[k]["ms_per_step"]))   # the dominant entry point of the step
         if "grid_encode_forward_packed" in kernels:
             roof_lookup = roofline_of("grid_encode_forward_packed")                          # north_star's hash-grid lookup (training launches only)
 
@@ -338,13 +360,21 @@ def main():
                                 "sdf": "nerf_synthetic/lego --sdf stage-0 -O --bound 1 --dt_gamma 0 (NeuS alpha, finite-difference normals, eikonal loss)",
                                 "garden": "mip-360-style stage-0 -O --bound 16 --dt_gamma 1/256 (5 cascades, inner/outer TV) on the synthetic scene"}[args.recipe]
                                + ", 800x800 x 100 synthetic views, num_points target 2^18/GPU (adaptive num_rays), occupancy refresh every 16 steps",
+                   "shading": shading, "timed_steps": [first_timed, first_timed + args.steps - 1], "diffuse_step": int(opt.diffuse_step),
                    "parallelism": (f"dp{world} (rays sharded; table gradients reduce-scattered, Adam sharded over the ranks, packed rows all-gathered; "
                                    f"{dist.get_backend()})" if getattr(tr, "shard", False) else
                                    f"dp{world} (rays sharded, grad all-reduce over {dist.get_backend()})") if world > 1 else "single GPU",
                    "mlp": "nn.Linear (unfused)" if args.unfused else "fused MFMA field kernels",
                    "driver": "engine.Stage0Engine (fixed launch sequence)" if use_engine else "trainer.Stage0Trainer (torch.autograd)", "pretrain_steps": args.pretrain, "samples_per_step_per_gpu": samples / args.steps / world,
                    "rays_per_step_per_gpu": rays / args.steps / world, "params": 18367240},
-        "roofline": roof, "roofline_lookup": roof_lookup, "kernels": kernels, "cpu_baseline": cpu, "psnr_view0_quarter_res": psnr,
+        "roofline": roof, "roofline_lookup": roof_lookup, "kernels": kernels,
+        "kernels_note": (f"per-kernel hipEvent pairs on every {args.prof_every}-th launch; ms_per_step = mean timed duration x launches seen / steps. "
+                         f"Main-stream entries sum to {main_ms:.3f} ms/step (an event pair adds 3-7 us of queue latency around what it encloses, "
+                         f"profiles/r02_trace_vs_events.txt; small launches without events -- composite+loss, bookkeeping -- are not listed); "
+                         f"side-stream entries ({side_ms:.3f} ms/step: next-but-one batch's ray generation and march) run beside the main stream's "
+                         "Adam / forward and are NOT part of the step time; grid_encode_forward (unpacked) = the occupancy refresh's density query, "
+                         "once per 16 steps") if kernels else None,
+        "cpu_baseline": cpu, "psnr_view0_quarter_res": psnr,
         "loss_mean": float(tr.loss_acc / max(tr.global_step, 1)),
     }
     print(json.dumps(line))

@@ -422,6 +422,13 @@ int n2m_scaler_update_slots_loss(float* scale, float* growth_tracker, float* fou
                                  uint32_t participants, double beta1, double beta2, float growth_factor, float backoff_factor,
                                  float growth_interval, const float* loss_partial, uint32_t n_partial, uint32_t n_rays, float* loss,
                                  float* loss_sum, void* stream);
+/* The same + a second term with its own normalisation: loss += extra_scale * sum(extra_partial[0 .. n_extra)).  The training step's
+ * specular regulariser lambda_specular * mean_m sum_c specular^2 (nerf/utils.py:733-737) arrives this way: extra_partial = the
+ * per-workgroup sums n2m_field_forward_train leaves, extra_scale = lambda_specular / M.  extra_partial == NULL: no second term. */
+int n2m_scaler_update_slots_loss2(float* scale, float* growth_tracker, float* found_inf, float* steps, float* bias,
+                                  uint32_t participants, double beta1, double beta2, float growth_factor, float backoff_factor,
+                                  float growth_interval, const float* loss_partial, uint32_t n_partial, uint32_t n_rays, float* loss,
+                                  float* loss_sum, const float* extra_partial, uint32_t n_extra, float extra_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * shencoder   (reference: shencoder/src/shencoder.h:9-10, shencoder/src/bindings.cpp:5-8)
@@ -456,6 +463,8 @@ int n2m_prof_reset(void);
 /* Synchronises the recorded events, then returns the number of timed launches of `kernel_id`, their summed
  * duration in milliseconds and the algorithmic bytes the library attributed to them. */
 int n2m_prof_read(int kernel_id, uint64_t* launches, double* total_ms, double* algo_bytes);
+/* Launches of `kernel_id` SEEN since n2m_prof_reset (timed or not): with sampled timing, per-step cost = mean timed duration x seen / steps. */
+int n2m_prof_seen(int kernel_id, uint64_t* launches_seen);
 const char* n2m_prof_name(int kernel_id);
 
 #ifdef __cplusplus

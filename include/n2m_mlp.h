@@ -60,6 +60,27 @@ int n2m_field_backward(const float* xyz, const float* dirs, const float* h1, con
                        float* d_w_sigma1, float* d_w_color0, float* d_w_color1, float* d_w_color2, float* d_w_spec0,
                        float* d_w_spec1, float* found_inf, void* stream);
 
+/* Training forms with the specular regulariser of the reference's train_step folded in (nerf/utils.py:733-737:
+ * loss += lambda_specular * (specular ** 2).sum(-1).mean(), present whenever shading != diffuse, i.e. for 29 000 of the 30 000 iterations
+ * of main.py:59).  The reference forms the term with four elementwise/reduction launches over the [M,3] specular tensor and autograd sends
+ * 2 lambda / M * specular back; here the forward leaves per-workgroup sums of specular^2 (fp32 squares of the fp16 sigmoid outputs, summed
+ * in a fixed order) in spec_sq_partial[0 .. n2m_field_spec_partials()) -- unused slots are written as zeros -- and the backward adds
+ * specular * (*seed * spec_reg) to d loss / d specular of the recomputed activations (seed: device scalar, the seed gradient of the step =
+ * loss scale [/ world]; spec_reg = 2 lambda_specular / M on the host).  `specular` may then be NULL in the forward and `d_specular` NULL in
+ * the backward: the [M,3] tensor is neither written nor read.  spec_sq_partial == NULL / seed == NULL or spec_reg == 0: identical to the
+ * plain entry points.  Ignored with shading == 0. */
+int n2m_field_forward_train(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
+                            const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
+                            const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs, float* sigma, float* rgb,
+                            float* specular, float* spec_sq_partial, void* stream);
+int n2m_field_backward_train(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
+                             const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
+                             const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs, const float* d_sigma,
+                             const float* d_rgb, const float* d_specular, float* d_h1, void* d_h2, float* d_w_sigma0,
+                             float* d_w_sigma1, float* d_w_color0, float* d_w_color1, float* d_w_color2, float* d_w_spec0,
+                             float* d_w_spec1, float* found_inf, float spec_reg, const float* seed, void* stream);
+uint32_t n2m_field_spec_partials(void);      /* slots the forward writes into spec_sq_partial (512) */
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,8 @@ SIGNATURES = {
     "n2m_scaler_update": [_vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp],
     "n2m_scaler_update_slots": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp],
     "n2m_scaler_update_slots_loss": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp, _u32, _u32, _vp, _vp, _vp],
+    "n2m_scaler_update_slots_loss2": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp, _u32, _u32, _vp, _vp,
+                                      _vp, _u32, _f32, _vp],
     "n2m_photo_loss_forward": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _u32, _vp, _vp, _vp, _vp],
     "n2m_photo_loss_backward": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _u32, _vp, _vp, _vp, _vp],
     "n2m_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp],
@@ -69,6 +71,9 @@ SIGNATURES = {
     # include/n2m_mlp.h
     "n2m_field_forward": [_vp] * 11 + [_u32, _int, _int] + [_vp] * 4,
     "n2m_field_backward": [_vp] * 11 + [_u32, _int, _int] + [_vp] * 14,
+    "n2m_field_forward_train": [_vp] * 11 + [_u32, _int, _int] + [_vp] * 5,
+    "n2m_field_backward_train": [_vp] * 11 + [_u32, _int, _int] + [_vp] * 13 + [_f32, _vp, _vp],
+    "n2m_field_spec_partials": [],
     # include/n2m_raster.h
     "n2m_rasterize_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "n2m_rasterize_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp],
@@ -80,10 +85,11 @@ SIGNATURES = {
     "n2m_prof_enable": [_int],
     "n2m_prof_reset": [],
     "n2m_prof_read": [_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
+    "n2m_prof_seen": [_int, ctypes.POINTER(ctypes.c_uint64)],
 }
 
 RESTYPES = {"n2m_grid_binned_workspace_bytes": _u64, "n2m_grid_binned_pair_workspace_bytes": _u64, "n2m_march_fused_workspace_bytes": _u64,
-            "n2m_marching_cubes_workspace_bytes": _u64}   # everything else returns an int status
+            "n2m_marching_cubes_workspace_bytes": _u64, "n2m_field_spec_partials": _u32}   # everything else returns an int status
 
 F32, F16 = 0, 1
 ADAM_MAX = 16
@@ -134,6 +140,20 @@ def call(name, *args):
     rc = getattr(L, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {L.n2m_last_error().decode()}")
+
+
+_BWD_CFG = [None]
+
+
+def grid_backward_config(tv_stride=1, overflow_div=1.0):
+    """n2m_grid_backward_config is PROCESS-wide state of the binned backward (row stride of the TV table, fp16 overflow margin).  Every
+    Python caller of a binned backward / binned TV entry point states what it needs right before its call -- a sharded engine (stride 2,
+    margin W) and a plain trainer or single-GPU engine (1, 1) can then live in one process without inheriting each other's setting.  The
+    last value is cached: the common case costs one tuple compare."""
+    want = (int(tv_stride), float(overflow_div))
+    if _BWD_CFG[0] != want:
+        call("n2m_grid_backward_config", want[0], want[1])
+        _BWD_CFG[0] = want
 
 
 _WORKSPACE = {}
@@ -197,6 +217,14 @@ def prof_enable(on=True):
 
 def prof_reset():
     call("n2m_prof_reset")
+
+
+def prof_seen(kernel):
+    """Launches of `kernel` seen since the last reset, timed or not (sampled timing: per-step cost = mean timed duration x seen / steps)."""
+    kid = KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+    n = ctypes.c_uint64(0)
+    call("n2m_prof_seen", kid, ctypes.byref(n))
+    return int(n.value)
 
 
 def prof_read(kernel):

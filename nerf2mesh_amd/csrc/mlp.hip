@@ -103,7 +103,12 @@ struct FieldArgs {
     float* found_inf;        // set to 1 when a weight gradient is not finite (GradScaler's check), may be NULL
     int dbg;                 // measurement switches (N2M_FIELD_DEBUG): 1 skip the tile loop, 2 skip the dW reduction
     float* dw_partial;       // [gridDim.x][kDwTotal]: per-workgroup weight-gradient sums, reduced by dw_finalize_kernel
+    // specular regulariser lambda * mean_m sum_c specular^2 (nerf/utils.py:733-737), folded into the field kernels (*_train entry points):
+    float* spec_sq_partial;  // forward: [kSpecPartials] per-workgroup sums of specular^2 (unused slots zeroed), NULL = off
+    float spec_reg;          // backward: d loss / d specular += specular * (*seed * spec_reg), spec_reg = 2 lambda / M; 0 = off
+    const float* seed;       // device scalar: the seed gradient (loss scale [/ world]); read only when spec_reg != 0
 };
+constexpr int kSpecPartials = 512;      // >= the largest forward grid (2 x 256 workgroups)
 
 // Staging, fast form.  stage_w / stage_wt above walk the PADDED image and fetch one weight per iteration (integer division, a
 // dependent global load, a 2-byte LDS store: ~46 serial round trips per thread, 8-20 us of every launch).  Here every thread first
@@ -406,6 +411,7 @@ __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     const uint32_t n_tiles = (a.M + 31) / 32;
     RawTile nxt;
+    float spec_sq = 0.f;             // this lane's sum of specular^2 over its samples (g = 0 lanes; a.spec_sq_partial)
     fetch_tile<DO_DENSITY, DO_COLOR, false>(a, wave, n, g, nxt);
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t s = tile * 32 + n;
@@ -457,6 +463,7 @@ __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
                 if (valid && g == 0 && a.specular) {
                     a.specular[(size_t)s * 3] = s0; a.specular[(size_t)s * 3 + 1] = s1; a.specular[(size_t)s * 3 + 2] = s2;
                 }
+                if (valid && g == 0) spec_sq += (s0 * s0 + s1 * s1) + s2 * s2;      // fp32 squares of the fp16 outputs, like autocast's pow
                 if (a.shading == 2) { cr = s0; cg = s1; cb = s2; }
                 else {   // (specular + diffuse).clamp(0, 1) evaluated in fp16 like the autocast graph
                     cr = fminf(fmaxf((float)(_Float16)(s0 + q0), 0.f), 1.f);
@@ -468,6 +475,16 @@ __global__ void __launch_bounds__(256) field_forward_kernel(FieldArgs a) {
                 a.rgb[(size_t)s * 3] = cr; a.rgb[(size_t)s * 3 + 1] = cg; a.rgb[(size_t)s * 3 + 2] = cb;
             }
         }
+    }
+    if (DO_COLOR && a.spec_sq_partial) {
+        // fixed order: lanes by the wave scan, waves 0..3, one slot per workgroup; workgroup 0 clears the slots no workgroup owns
+        __shared__ float spec_wave[4];
+        const float w = n2m_wave_sum(spec_sq);             // (all 64 lanes are active here: the tile loop is wave-uniform)
+        if (lane == 0) spec_wave[threadIdx.x >> 6] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) a.spec_sq_partial[blockIdx.x] = ((spec_wave[0] + spec_wave[1]) + spec_wave[2]) + spec_wave[3];
+        if (blockIdx.x == 0)
+            for (int i = (int)gridDim.x + (int)threadIdx.x; i < kSpecPartials; i += 256) a.spec_sq_partial[i] = 0.f;
     }
 }
 
@@ -650,6 +667,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const uint32_t wave = blockIdx.x * 4 + wid, n_waves = gridDim.x * 4;
     const uint32_t n_tiles = (a.M + 31) / 32;
     const size_t Mz = a.M;
+    const float spec_k = a.spec_reg != 0.f ? *a.seed * a.spec_reg : 0.f;     // seed gradient x 2 lambda / M
 
     // weight-gradient accumulators, fp32, live for the whole launch
     f16x gS0[1][1] = {{zero16()}}, gS1[1][1] = {{zero16()}};
@@ -749,6 +767,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 for (int kb = 0; kb < 4; ++kb) p2 = MFMA(ld_a(lds + O_P1, P_P1, 0, kb, lane), bq[kb], p2);
                 const float s0 = sigmoid_h(p2[0]), s1 = sigmoid_h(p2[1]), s2 = sigmoid_h(p2[2]);
                 float ts0 = es0, ts1 = es1, ts2 = es2;          // d loss / d specular, total
+                if (valid && g == 0) { ts0 += s0 * spec_k; ts1 += s1 * spec_k; ts2 += s2 * spec_k; }     // + d (lambda mean sum specular^2); lanes without a sample contribute nothing
                 if (a.shading == 2) { ts0 += gr; ts1 += gg; ts2 += gb; }
                 else {   // clamp backward passes the gradient where 0 <= x <= 1
                     const float t0 = (float)(_Float16)(s0 + q0), t1 = (float)(_Float16)(s1 + q1), t2 = (float)(_Float16)(s2 + q2);
@@ -884,6 +903,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const uint32_t n_tiles = (a.dbg & 1) ? 0u : (a.M + 31) / 32;
     const size_t Mz = a.M;
     uint32_t st = 0;                 // running stage counter, identical in both waves of a pair
+    const float spec_k = a.spec_reg != 0.f ? *a.seed * a.spec_reg : 0.f;     // seed gradient x 2 lambda / M
 
     // weight-gradient accumulators, fp32, live for the whole launch
     f16x gS0[1][1] = {{zero16()}}, gS1[1][1] = {{zero16()}};
@@ -981,6 +1001,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 p2 = mm_k<4>(lds + O_P1, P_P1, 0, bq, p2, lane);
                 const float s0 = sigmoid_h(p2[0]), s1 = sigmoid_h(p2[1]), s2 = sigmoid_h(p2[2]);
                 float ts0 = es0, ts1 = es1, ts2 = es2;          // d loss / d specular, total
+                if (valid && g == 0) { ts0 += s0 * spec_k; ts1 += s1 * spec_k; ts2 += s2 * spec_k; }     // + d (lambda mean sum specular^2); lanes without a sample contribute nothing
                 if (a.shading == 2) { ts0 += gr; ts1 += gg; ts2 += gb; }
                 else {   // clamp backward passes the gradient where 0 <= x <= 1
                     const float t0 = (float)(_Float16)(s0 + q0), t1 = (float)(_Float16)(s1 + q1), t2 = (float)(_Float16)(s2 + q2);
@@ -1146,10 +1167,10 @@ uint32_t persistent_grid(uint32_t M) {
 
 }  // namespace
 
-extern "C" int n2m_field_forward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
+static int field_forward_impl(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
                                  const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
                                  const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs, float* sigma, float* rgb,
-                                 float* specular, void* stream) {
+                                 float* specular, float* spec_sq_partial, void* stream) {
     const float* w[7] = {w_sigma0, w_sigma1, w_color0, w_color1, w_color2, w_spec0, w_spec1};
     const bool density = sigma != nullptr;
     if (int rc = check_field("field_forward", xyz, h1, w, density, shading)) return rc;
@@ -1164,6 +1185,7 @@ extern "C" int n2m_field_forward(const float* xyz, const float* dirs, const floa
     a.xyz = xyz; a.dirs = dirs; a.h1 = h1; a.h2 = (const _Float16*)h2; a.normalize_dirs = normalize_dirs & 1; a.raw_density = (normalize_dirs >> 1) & 1;
     for (int i = 0; i < 7; ++i) a.w[i] = w[i];
     a.M = M; a.shading = shading; a.sigma = sigma; a.rgb = rgb; a.specular = specular;
+    a.spec_sq_partial = (color && shading != 0) ? spec_sq_partial : nullptr;
     hipStream_t s = (hipStream_t)stream;
     N2M_PROF(N2M_K_MLP_FWD, s, (double)M * (12 + 64 + 4 + (color ? 64 + 12 + 12 + 12 : 0)));
     const size_t smem = (size_t)FWD_HALVES * 2;
@@ -1174,12 +1196,28 @@ extern "C" int n2m_field_forward(const float* xyz, const float* dirs, const floa
     return 0;
 }
 
-extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
+extern "C" int n2m_field_forward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
+                                 const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
+                                 const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs, float* sigma, float* rgb,
+                                 float* specular, void* stream) {
+    return field_forward_impl(xyz, dirs, h1, h2, w_sigma0, w_sigma1, w_color0, w_color1, w_color2, w_spec0, w_spec1, M, shading, normalize_dirs,
+                              sigma, rgb, specular, nullptr, stream);
+}
+extern "C" int n2m_field_forward_train(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
+                                       const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
+                                       const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs, float* sigma,
+                                       float* rgb, float* specular, float* spec_sq_partial, void* stream) {
+    return field_forward_impl(xyz, dirs, h1, h2, w_sigma0, w_sigma1, w_color0, w_color1, w_color2, w_spec0, w_spec1, M, shading, normalize_dirs,
+                              sigma, rgb, specular, spec_sq_partial, stream);
+}
+extern "C" uint32_t n2m_field_spec_partials(void) { return (uint32_t)kSpecPartials; }
+
+static int field_backward_impl(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
                                   const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
                                   const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs, const float* d_sigma,
                                   const float* d_rgb, const float* d_specular, float* d_h1, void* d_h2, float* d_w_sigma0,
                                   float* d_w_sigma1, float* d_w_color0, float* d_w_color1, float* d_w_color2, float* d_w_spec0,
-                                  float* d_w_spec1, float* found_inf, void* stream) {
+                                  float* d_w_spec1, float* found_inf, float spec_reg, const float* seed, void* stream) {
     const float* w[7] = {w_sigma0, w_sigma1, w_color0, w_color1, w_color2, w_spec0, w_spec1};
     float* dw[7] = {d_w_sigma0, d_w_sigma1, d_w_color0, d_w_color1, d_w_color2, d_w_spec0, d_w_spec1};
     const bool density = d_sigma != nullptr;
@@ -1206,6 +1244,7 @@ extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const flo
     a.xyz = xyz; a.dirs = dirs; a.h1 = h1; a.h2 = (const _Float16*)h2; a.normalize_dirs = normalize_dirs & 1; a.raw_density = (normalize_dirs >> 1) & 1;
     for (int i = 0; i < 7; ++i) { a.w[i] = w[i]; a.dw[i] = dw[i]; }
     a.M = M; a.shading = shading;
+    a.spec_reg = (color && shading != 0 && seed) ? spec_reg : 0.f; a.seed = seed;
     a.d_sigma = d_sigma; a.d_rgb = d_rgb; a.d_specular = d_specular; a.d_h1 = d_h1; a.d_h2 = (_Float16*)d_h2; a.found_inf = found_inf;
     static const int dbg = getenv("N2M_FIELD_DEBUG") ? atoi(getenv("N2M_FIELD_DEBUG")) : 0;
     a.dbg = dbg;
@@ -1235,4 +1274,25 @@ extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const flo
     else field_backward_kernel<true, false><<<persistent_grid(M), 256, smem, s>>>(a);
     N2M_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int n2m_field_backward(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
+                                  const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
+                                  const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs, const float* d_sigma,
+                                  const float* d_rgb, const float* d_specular, float* d_h1, void* d_h2, float* d_w_sigma0,
+                                  float* d_w_sigma1, float* d_w_color0, float* d_w_color1, float* d_w_color2, float* d_w_spec0,
+                                  float* d_w_spec1, float* found_inf, void* stream) {
+    return field_backward_impl(xyz, dirs, h1, h2, w_sigma0, w_sigma1, w_color0, w_color1, w_color2, w_spec0, w_spec1, M, shading, normalize_dirs,
+                               d_sigma, d_rgb, d_specular, d_h1, d_h2, d_w_sigma0, d_w_sigma1, d_w_color0, d_w_color1, d_w_color2, d_w_spec0,
+                               d_w_spec1, found_inf, 0.f, nullptr, stream);
+}
+extern "C" int n2m_field_backward_train(const float* xyz, const float* dirs, const float* h1, const void* h2, const float* w_sigma0,
+                                        const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
+                                        const float* w_spec0, const float* w_spec1, uint32_t M, int shading, int normalize_dirs,
+                                        const float* d_sigma, const float* d_rgb, const float* d_specular, float* d_h1, void* d_h2,
+                                        float* d_w_sigma0, float* d_w_sigma1, float* d_w_color0, float* d_w_color1, float* d_w_color2,
+                                        float* d_w_spec0, float* d_w_spec1, float* found_inf, float spec_reg, const float* seed, void* stream) {
+    return field_backward_impl(xyz, dirs, h1, h2, w_sigma0, w_sigma1, w_color0, w_color1, w_color2, w_spec0, w_spec1, M, shading, normalize_dirs,
+                               d_sigma, d_rgb, d_specular, d_h1, d_h2, d_w_sigma0, d_w_sigma1, d_w_color0, d_w_color1, d_w_color2, d_w_spec0,
+                               d_w_spec1, found_inf, spec_reg, seed, stream);
 }

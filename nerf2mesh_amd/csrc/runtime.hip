@@ -97,6 +97,13 @@ extern "C" int n2m_prof_read(int kernel_id, uint64_t* launches, double* total_ms
     return 0;
 }
 
+extern "C" int n2m_prof_seen(int kernel_id, uint64_t* launches_seen) {
+    N2M_REQUIRE(kernel_id >= 0 && kernel_id < N2M_K_COUNT, N2M_EINVAL, "n2m_prof_seen: bad kernel id %d", kernel_id);
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (launches_seen) *launches_seen = g_seen[kernel_id];
+    return 0;
+}
+
 extern "C" const char* n2m_prof_name(int kernel_id) {
     return (kernel_id >= 0 && kernel_id < N2M_K_COUNT) ? kNames[kernel_id] : "?";
 }

@@ -125,6 +125,7 @@ class Stage0Engine:
         self._cur = 0
 
         self._work_cap = (0, 0)
+        self._n_spec = int(L.lib().n2m_field_spec_partials())
         self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self._seed = None
         self._aabb = None
@@ -149,8 +150,12 @@ class Stage0Engine:
                 self.g1s = {"c": f32(self._Cs, 1), "f": f32(self._Fs, 1)}
                 self.g2s = {"c": f16(self._Cs, 2), "f": f16(self._Fs, 2)}
                 self._inplace_gather = dist.get_backend() == "nccl"      # RCCL gathers in place; gloo (tests) gets a copy of the shard
-            # gradients are SUMMED over W ranks: a local row above max / W raises found_inf already (see n2m_grid_backward_config)
-            L.call("n2m_grid_backward_config", 2 if self.shard else 1, float(W))
+        # process-wide settings of the binned backward, stated before every backward of this engine (train_step): sharded -> the TV stencil
+        # reads the density column of the packed table (row stride 2); W ranks -> gradients are SUMMED, so a local fp16 row above max / W
+        # raises found_inf already
+        self._bwd_cfg = (2 if self.shard else 1, float(world_size))
+        if self.shard:
+            self.optimizer.shard_sync = lambda: self.sync_parameters(moments=True)      # state_dict() of a sharded run: gather first
 
     # ------------------------------------------------------------------------------------------------ configuration
     @staticmethod
@@ -197,8 +202,8 @@ class Stage0Engine:
             w["h1"], w["d_h1"] = f(16 * cm), f(16 * cm)
             w["h2"] = torch.empty(32 * cm, dtype=torch.float16, device=dev)
             w["d_h2"] = torch.empty(32 * cm, dtype=torch.float16, device=dev)
-            w["sigma"], w["rgb"], w["spec"], w["weights"], w["d_sr"] = f(cm), f(3 * cm), f(3 * cm), f(cm), f(4 * cm)
-            w["d_spec"] = f(3 * cm)
+            w["sigma"], w["rgb"], w["weights"], w["d_sr"] = f(cm), f(3 * cm), f(cm), f(4 * cm)
+            w["spec_partial"] = torch.zeros(self._n_spec, dtype=torch.float32, device=dev)
             w["ws"], w["depth"], w["image"], w["d_image"], w["d_ws"], w["bg"] = f(cn), f(cn), f(3 * cn), f(3 * cn), f(cn), f(3 * cn)
             w["partial"] = f((cn + 3) // 4 + 1)
             w["zeros"] = torch.zeros(max(cm, 3 * cn), dtype=torch.float32, device=dev)
@@ -317,12 +322,15 @@ class Stage0Engine:
     def _adam_desc(self, full):
         """The N2mAdamDesc of this model (pointers are fixed for the life of the engine); `full`: the specular head takes part."""
         o, model = self.optimizer, self.model
-        key = (full, getattr(o, "state_epoch", 0))
+        # packed_tables() hands out a NEW tensor whenever a table was changed through torch (load_state_dict, an in-place edit): the
+        # descriptor carries its address (Adam refreshes the copy the forward gathers from), so the address is part of the key
+        pk = model.packed_tables()
+        assert pk is not None
+        key = (full, getattr(o, "state_epoch", 0), pk.data_ptr(), model.encoder.embeddings.data_ptr(), model.encoder_color.embeddings.data_ptr())
         d = self._desc.get(key)
         if d is not None:
             return d
-        pk = model.packed_tables()
-        assert pk is not None
+        self._desc = {k: v for k, v in self._desc.items() if k[1:] == key[1:]}      # descriptors of an older table / state generation
         self._packed = pk
         desc = L.AdamDesc()
         params = [p for g in o.param_groups for p in g["params"]]
@@ -410,22 +418,30 @@ class Stage0Engine:
             w.wait()
 
     @torch.no_grad()
-    def sync_parameters(self, density_only=False):
+    def sync_parameters(self, density_only=False, moments=False):
         """Sharded optimizer: bring the fp32 parameter tensors of both tables up to date on every rank (each rank owns 1/W of the
         rows; the training step itself only needs the packed copy).  Called before the occupancy refresh (density table, every 16
         steps: 24.5 MB) and to be called before a checkpoint, an export, an evaluation or a comparison."""
         if not self.shard:
             return
         # COLLECTIVE: every rank must call it at the same step.  A repeat at the same step is a no-op (so a rank may evaluate or save on
-        # its own after all ranks have synchronised once -- bench.py's rank 0 does)
-        done = getattr(self, "_synced", (-1, False))
-        if done[0] == self.global_step and (done[1] or density_only):
+        # its own after all ranks have synchronised once -- bench.py's rank 0 does).  moments=True also gathers Adam's exp_avg / exp_avg_sq
+        # of both tables (each rank has only advanced its own rows): what a checkpoint needs -- FusedAdamAMP.state_dict() of a sharded
+        # run calls it, so optimizer.state_dict() is a collective too (the reference saves complete optimizer state, nerf/utils.py:1336-1350)
+        done = getattr(self, "_synced", (-1, False, False))
+        level = (not density_only, moments)
+        if done[0] == self.global_step and (done[1] or density_only) and (done[2] or not moments):
             return
-        self._synced = (self.global_step, not density_only)
+        self._synced = (self.global_step, level[0] or (done[0] == self.global_step and done[1]), level[1] or (done[0] == self.global_step and done[2]))
         import torch.distributed as dist
-        tables = ((self.model.encoder.embeddings, 1),) if density_only else ((self.model.encoder.embeddings, 1), (self.model.encoder_color.embeddings, 2))
-        for p, C in tables:
-            flat = p.data.view(-1)
+        e1p, e2p = self.model.encoder.embeddings, self.model.encoder_color.embeddings
+        tables = [(e1p.data, 1)] if density_only else [(e1p.data, 1), (e2p.data, 2)]
+        if moments:
+            for p, C in ((e1p, 1), (e2p, 2)):
+                st = self.optimizer.state[p]
+                tables += [(st["exp_avg"], C), (st["exp_avg_sq"], C)]
+        for t, C in tables:
+            flat = t.view(-1)
             for h, (row0, n) in self._shard_ranges().items():
                 lo = 0 if h == "c" else self._split
                 dist.all_gather_into_tensor(flat[lo * C:(lo + self.world * n) * C], flat[row0 * C:(row0 + n) * C].clone())
@@ -446,9 +462,11 @@ class Stage0Engine:
             L.call("n2m_scaler_update_slots", _p(o.scale), _p(o.growth_tracker), _p(o.found_inf), _p(o.steps), _p(o.bias), participants,
                    float(b1), float(b2), gf, bf, gi, s)
         else:        # + the step's loss value from the compositing kernel's per-workgroup partials
-            n_rays, buf = loss_out
-            L.call("n2m_scaler_update_slots_loss", _p(o.scale), _p(o.growth_tracker), _p(o.found_inf), _p(o.steps), _p(o.bias), participants,
-                   float(b1), float(b2), gf, bf, gi, _p(self._w["partial"]), (n_rays + 15) // 16, n_rays, _p(buf), _p(self._loss_sum), s)
+            n_rays, buf, extra = loss_out
+            ex_buf, ex_scale = extra if extra is not None else (None, 0.0)
+            L.call("n2m_scaler_update_slots_loss2", _p(o.scale), _p(o.growth_tracker), _p(o.found_inf), _p(o.steps), _p(o.bias), participants,
+                   float(b1), float(b2), gf, bf, gi, _p(self._w["partial"]), (n_rays + 15) // 16, n_rays, _p(buf), _p(self._loss_sum),
+                   _p(ex_buf), self._n_spec, float(ex_scale), s)
         nxt = lr_lambda(self.global_step, self.opt.iters)          # like LambdaLR.step(): param_groups carry the NEXT step's rate
         for group in o.param_groups:
             group["lr"] = float(group["initial_lr"]) * nxt
@@ -489,8 +507,12 @@ class Stage0Engine:
         if M > 0:
             L.call("n2m_grid_encode_forward_packed", _p(xyzs), _p(pk), _p(e1.offsets), _p(w["h1"]), _p(w["h2"]), M, self.Lv, self.Lv, self.S,
                    self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, float(self.aff[0]), float(self.aff[1]), s)
-            L.call("n2m_field_forward", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 1,
-                   _p(w["sigma"]), _p(w["rgb"]), _p(w["spec"]) if shading != 0 else None, s)
+            # full shading: the specular regulariser (nerf/utils.py:733-737) rides in the field kernels -- the forward leaves per-workgroup
+            # sums of specular^2, the backward adds 2 lambda / M * specular * seed to the recomputed activation's gradient; the [M,3]
+            # specular tensor is neither written nor read
+            spec_reg = shading != 0 and opt.lambda_specular > 0
+            L.call("n2m_field_forward_train", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 1,
+                   _p(w["sigma"]), _p(w["rgb"]), None, _p(w["spec_partial"]) if spec_reg else None, s)
         bg_t, bg_s = (bg, 0.0) if random_bg else (None, 1.0)
         lam_rgb, lam_mask = float(opt.lambda_rgb), float(max(opt.lambda_mask, 0.0))
         # ---- compositing + loss head + both backward passes: one launch (seed gradient = loss scale [/ world]: gradients are SUMMED over ranks)
@@ -499,19 +521,13 @@ class Stage0Engine:
         d_sigma, d_rgb = w["d_sr"][:max(M, 1)], w["d_sr"][max(M, 1):4 * max(M, 1)]
         L.call("n2m_composite_loss_train", _p(w["sigma"]), _p(w["rgb"]), _p(ts), _p(b.rays), M, N, 1e-4, _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask,
                _p(seed), None, None, _p(d_sigma), _p(d_rgb), _p(w["partial"]), None, None, None, s)      # loss value: summed by the scaler kernel
-        spec_loss = None
         if M > 0:
-            d_spec = None
-            if shading != 0 and opt.lambda_specular > 0:
-                # + lambda_specular * mean_m sum_c spec^2 (nerf/utils.py:735-737): d/dspec = 2 lambda / M * spec, times the seed
-                spec_m = w["spec"][:3 * M]
-                spec_loss = opt.lambda_specular * (spec_m * spec_m).sum() / M
-                d_spec = w["d_spec"][:3 * M]
-                torch.mul(spec_m, seed * (2.0 * opt.lambda_specular / M), out=d_spec)
             if self.marker_at == 2:
                 self._marker = torch.cuda.Event(); self._marker.record()
-            L.call("n2m_field_backward", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 1,
-                   _p(d_sigma), _p(d_rgb), _p(d_spec), _p(w["d_h1"]), _p(w["d_h2"]), *[_p(g) for g in self.dw_views], _p(o.found_inf), s)
+            L.call("n2m_field_backward_train", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 1,
+                   _p(d_sigma), _p(d_rgb), None, _p(w["d_h1"]), _p(w["d_h2"]), *[_p(g) for g in self.dw_views], _p(o.found_inf),
+                   float(2.0 * opt.lambda_specular / M) if spec_reg else 0.0, _p(seed) if spec_reg else None, s)
+            L.grid_backward_config(*self._bwd_cfg)
             need = L.lib().n2m_grid_binned_pair_workspace_bytes(M, self.Lv, self.ho.ctypes.data)
             ws = L.workspace(dev, need)
             tv = opt.lambda_tv > 0
@@ -572,11 +588,9 @@ class Stage0Engine:
             self._marker = torch.cuda.Event()
             self._marker.record()
         # ---- Adam + loss-scale bookkeeping, LR schedule (main.py:239)
-        self._lr_step(shading != 0, loss_out=(N, b.loss))
-        loss = b.loss.view(())                 # written by the scaler kernel; lives in the batch's buffer set (valid until the set comes round again)
-        if spec_loss is not None:
-            loss = loss + spec_loss
-            self._loss_sum += spec_loss        # the photometric part was added by the scaler kernel itself
+        extra = (w["spec_partial"], float(opt.lambda_specular / M)) if (M > 0 and shading != 0 and opt.lambda_specular > 0) else None
+        self._lr_step(shading != 0, loss_out=(N, b.loss, extra))
+        loss = b.loss.view(())                 # written by the scaler kernel (photometric + specular terms); lives in the batch's buffer set (valid until the set comes round again)
         self._fill_pipeline()
         return loss
 

@@ -50,6 +50,10 @@ class FusedAdamAMP(torch.optim.Optimizer):
         """torch's optimizer state (exp_avg / exp_avg_sq per parameter, param_groups) + what torch keeps in state[p]["step"] and in a
         separate GradScaler: per-slot step counts, loss scale, growth tracker.  A resumed run continues its bias corrections and its
         loss scale where the saved one stopped (the reference saves optimizer and scaler state side by side, nerf/utils.py:1336-1350)."""
+        if getattr(self, "shard_sync", None) is not None:
+            # engine.Stage0Engine with the optimizer sharded over the ranks: each rank has advanced the moments of its own 1/W of the table
+            # rows only.  Gather them (COLLECTIVE: every rank calls state_dict() at the same step) so that the saved state is complete
+            self.shard_sync()
         sd = super().state_dict()
         sd["n2m_amp"] = {"steps": self.steps.detach().cpu().clone(), "scale": float(self.scale), "growth_tracker": float(self.growth_tracker),
                          "amp": self.amp, "growth": self.growth}

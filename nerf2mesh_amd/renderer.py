@@ -355,15 +355,21 @@ class NeRFRenderer(nn.Module):
         return meshes
 
     # ------------------------------------------------------------------------------------------ stage 1
-    def init_stage1(self, vertices, triangles, v_cumsum=None):
+    def init_stage1(self, vertices, triangles, v_cumsum=None, f_cumsum=None):
         """Attach the stage-0 mesh (what NeRFRenderer.__init__ loads from mesh_stage0/*.ply, nerf/renderer.py:123-165):
         vertices [V,3] f32, triangles [F,3] int32, learnable per-vertex offsets, per-face error accumulators."""
         dev = self.density_bitfield.device
         self.glctx = dr.RasterizeGLContext(output_db=False)
         self.vertices = vertices.float().to(dev).contiguous()
         self.triangles = triangles.int().to(dev).contiguous()
-        self.v_cumsum = v_cumsum if v_cumsum is not None else [0, self.vertices.shape[0]]
-        self.f_cumsum = [0, self.triangles.shape[0]]        # one cascade unless the caller sets both (nerf/renderer.py:150-165)
+        self.v_cumsum = [int(x) for x in v_cumsum] if v_cumsum is not None else [0, self.vertices.shape[0]]
+        if f_cumsum is None:
+            # cascades are concatenated in order and a cascade's faces only name its own vertices (nerf/renderer.py:143-150): the face
+            # ranges follow from the vertex ranges (number of faces whose first vertex lies below each vertex bound)
+            first = self.triangles[:, 0].long()
+            f_cumsum = [0] + [int((first < b).sum()) for b in self.v_cumsum[1:]]
+        self.f_cumsum = [int(x) for x in f_cumsum]
+        assert len(self.f_cumsum) == len(self.v_cumsum) and self.f_cumsum[-1] == self.triangles.shape[0]
         self.vertices_offsets = nn.Parameter(torch.zeros_like(self.vertices))
         self.triangles_errors = torch.zeros(self.triangles.shape[0], dtype=torch.float32, device=dev)
         self.triangles_errors_cnt = torch.zeros(self.triangles.shape[0], dtype=torch.float32, device=dev)
@@ -432,15 +438,14 @@ class NeRFRenderer(nn.Module):
         for cas in range(len(self.v_cumsum) - 1):
             v = v_all[self.v_cumsum[cas]:self.v_cumsum[cas + 1]].contiguous()
             f = (f_all[self.f_cumsum[cas]:self.f_cumsum[cas + 1]] - self.v_cumsum[cas]).contiguous()
-            if f.shape[0] == 0:
-                continue
-            vt, ft = atlas[cas] if atlas is not None else export.grid_atlas(f.shape[0], device=v.device)
-            vt, ft = torch.as_tensor(vt).float().to(v.device), torch.as_tensor(ft).int().to(v.device)
-            feat0, feat1, mask = self.bake_textures(v, f, vt, ft, h0, w0, ssaa)
-            export.write_jpg(os.path.join(path, f"feat0_{cas}.jpg"), feat0.cpu().numpy())
-            export.write_jpg(os.path.join(path, f"feat1_{cas}.jpg"), feat1.cpu().numpy())
-            export.write_obj(path, cas, v.cpu().numpy(), f.cpu().numpy(), vt.cpu().numpy(), ft.cpu().numpy())
-            out[cas] = (feat0, feat1, mask)
+            if f.shape[0] > 0:       # (an empty cascade writes nothing but still takes part in the halving below, nerf/renderer.py:440-448)
+                vt, ft = atlas[cas] if atlas is not None else export.grid_atlas(f.shape[0], device=v.device)
+                vt, ft = torch.as_tensor(vt).float().to(v.device), torch.as_tensor(ft).int().to(v.device)
+                feat0, feat1, mask = self.bake_textures(v, f, vt, ft, h0, w0, ssaa)
+                export.write_jpg(os.path.join(path, f"feat0_{cas}.jpg"), feat0.cpu().numpy())
+                export.write_jpg(os.path.join(path, f"feat1_{cas}.jpg"), feat1.cpu().numpy())
+                export.write_obj(path, cas, v.cpu().numpy(), f.cpu().numpy(), vt.cpu().numpy(), ft.cpu().numpy())
+                out[cas] = (feat0, feat1, mask)
             if not self.opt.sdf and h0 > 2048 and w0 > 2048:      # half the texture resolution for the remote cascades (:446-448)
                 h0 //= 2
                 w0 //= 2
@@ -522,5 +527,7 @@ class NeRFRenderer(nn.Module):
             clip = to_clip(vertices, mvp.to(dev)).unsqueeze(0)
             rast, _ = dr.rasterize(ctx, clip, triangles, (H, W))
             ids = rast[..., -1].long().view(-1) - 1
-            seen[ids[ids >= 0]] = True
+            # reference quirk, kept: `mask[trig_id] += 1` (:973) indexes with -1 for every empty pixel, which names the LAST face --
+            # so the last face counts as seen by any view that has background in it
+            seen[ids] = True
         return ~seen

@@ -15,8 +15,10 @@ Which kernels sit under the wrappers (`backend=`):
     boundary; device tensors.
 Both function tables can live in one process: `use_backend()` swaps the `_backend` global of the three wrapper modules.
 
-Modules the reference imports at module scope but that this path never calls (cv2, trimesh, nvdiffrast, ... SURVEY 8b) are
-registered as empty stubs; `nvdiffrast.torch` resolves to the HIP facade when backend == "hip".
+Modules the reference imports at module scope but that this path never calls (cv2, xatlas, pymeshlab, ... SURVEY 8b) are
+registered as empty stubs.  Stage 1 (nerf/renderer.py:123-165,816-981): `nvdiffrast.torch` resolves to the HIP facade
+(nerf2mesh_amd/backends/nvdiffrast/torch.py) when backend == "hip" and to the scalar C rasteriser (oracle/nvdiffrast_oracle.py, forward
+only) when backend == "ref"; `torch_scatter.scatter_add` to backends/torch_scatter.py / `index_add_`; `trimesh.load` to a PLY reader.
 """
 import contextlib
 import importlib
@@ -186,7 +188,40 @@ def use_backend(kind):
     sys.modules["shencoder.sphere_harmonics"]._backend = sh
     sys.modules["freqencoder.freq"]._backend = fq
     if kind == "hip":
-        sys.modules["nerf.renderer"].dr = importlib.import_module("nerf2mesh_amd.raster")
+        # the facade FILES a maintainer puts on sys.path (nerf2mesh_amd/backends/nvdiffrast/torch.py, backends/torch_scatter.py), loaded by path
+        from nerf2mesh_amd import backends
+        bdir = backends.path()
+
+        def imp(name, rel):
+            spec = importlib.util.spec_from_file_location(name, os.path.join(bdir, rel))
+            m = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(m)
+            return m
+        sys.modules["nerf.renderer"].dr = imp("n2m_hip_nvdiffrast_torch", os.path.join("nvdiffrast", "torch.py"))
+        sys.modules["torch_scatter"].scatter_add = imp("n2m_hip_torch_scatter", "torch_scatter.py").scatter_add
+    else:
+        # stage 1 on the CPU: nvdiffrast.torch = the scalar C rasteriser (forward only, parity unpinned -- oracle/nvdiffrast_oracle.py);
+        # torch_scatter.scatter_add(src, index, out=out) = out.index_add_ (its documented semantics for a 1-D index)
+        sys.modules["nerf.renderer"].dr = importlib.import_module("oracle.nvdiffrast_oracle")
+        sys.modules["torch_scatter"].scatter_add = lambda src, index, dim=-1, out=None, dim_size=None: out.index_add_(0, index, src)
+    sys.modules["nerf.renderer"].TORCH_SCATTER = None      # nerf/renderer.py:43,934-938 caches the module on first use
+    sys.modules["trimesh"].load = _trimesh_load
+
+
+def _trimesh_load(path, **kwargs):
+    """Stand-in for trimesh.load(path, force='mesh', skip_material=True, process=False) (nerf/renderer.py:137-141): the reference reads
+    `.vertices` [V,3] and `.faces` [F,3] of a binary little-endian PLY (what trimesh, and nerf2mesh_amd.export.write_ply, write)."""
+    import numpy as np
+    with open(path, "rb") as fp:
+        data = fp.read()
+    end = data.index(b"end_header\n") + len(b"end_header\n")
+    head = data[:end].decode("ascii").split()
+    assert "binary_little_endian" in head, "the stand-in reads binary little-endian PLY only"
+    nv, nf = int(head[head.index("vertex") + 1]), int(head[head.index("face") + 1])
+    v = np.frombuffer(data, dtype="<f4", count=nv * 3, offset=end).reshape(nv, 3)
+    rec = np.frombuffer(data, dtype=np.dtype([("n", "u1"), ("idx", "<i4", (3,))]), count=nf, offset=end + nv * 12)
+    assert (rec["n"] == 3).all()
+    return types.SimpleNamespace(vertices=v.astype(np.float64), faces=rec["idx"].astype(np.int64))
 
 
 @contextlib.contextmanager
@@ -207,6 +242,7 @@ def reference_opt(**kw):
     """The `opt` fields NeRFNetwork / NeRFRenderer read (nerf/renderer.py:68-168, nerf/network.py:57-79), main.py defaults."""
     d = dict(bound=1.0, contract=False, grid_size=128, min_near=0.05, density_thresh=10, ind_num=500, ind_dim=0, cuda_ray=True,
              trainable_density_grid=False, stage=0, gui=False, tcnn=False, sdf=False, fp16=False, lr=1e-2,
-             normal_anneal_epsilon=1e-4, cos_anneal_ratio=1.0, lambda_density=0, workspace="", mesh="", ckpt="scratch")
+             normal_anneal_epsilon=1e-4, cos_anneal_ratio=1.0, lambda_density=0, workspace="", mesh="", ckpt="scratch",
+             ssaa=2, pos_gradient_boost=1, enable_offset_nerf_grad=False, lr_vert=1e-4)              # stage 1: main.py:49-50,108
     d.update(kw)
     return types.SimpleNamespace(**d)

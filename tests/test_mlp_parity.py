@@ -218,3 +218,62 @@ def test_fused_field_is_no_farther_from_fp32_truth_than_the_reference_fp16_graph
         if not ef <= 1.5 * ea + floor:
             bad.append(name)
     assert not bad, f"fused field farther from the fp32 truth than 1.5 x the reference's fp16 graph: {bad}"
+
+
+@pytest.mark.parametrize("M", [77, 262144 + 13])
+def test_train_entry_points_fold_the_specular_regulariser(M):
+    """n2m_field_forward_train / n2m_field_backward_train (include/n2m_mlp.h) against the plain entry points + the torch statement of
+    nerf/utils.py:733-737: loss += lambda * (specular ** 2).sum(-1).mean(), whose gradient 2 lambda / M * specular (times the seed
+    gradient) autograd hands to the specular output.  Forward: sigma / rgb bit-identical, sum of the partials == the torch sum within
+    fp32 summation order, unused slots zero.  Backward: d_h1 / d_h2 and the seven dW BIT-identical to the plain backward that is given
+    the materialised d_specular = specular * (seed * 2 lambda / M) -- the kernel forms the same product from its recomputed activation."""
+    import torch
+    from nerf2mesh_amd import _lib as L
+    _, net = make_nets()
+    p = L.ptr
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x, d = samples(M, seed=9)
+    h1 = (torch.rand(16, M, device=dev, generator=g) - 0.5).contiguous()
+    h2 = (torch.rand(16, M, 2, device=dev, generator=g) - 0.5).half().contiguous()
+    w = [q.detach().contiguous() for m in (net.sigma_net, net.color_net, net.specular_net) for q in m.parameters()]
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    n_slots = int(L.lib().n2m_field_spec_partials())
+    s = L.stream()
+    sig0, rgb0, spec0 = f(M), f(M, 3), f(M, 3)
+    L.call("n2m_field_forward", p(x), p(d), p(h1), p(h2), *[p(t) for t in w], M, 1, 1, p(sig0), p(rgb0), p(spec0), s)
+    sig1, rgb1 = f(M), f(M, 3)
+    part = torch.full((n_slots,), 7.0, device=dev)
+    L.call("n2m_field_forward_train", p(x), p(d), p(h1), p(h2), *[p(t) for t in w], M, 1, 1, p(sig1), p(rgb1), None, p(part), s)
+    assert torch.equal(sig0, sig1) and torch.equal(rgb0, rgb1)
+    want = (spec0.double() ** 2).sum().item()
+    assert abs(part.double().sum().item() - want) <= 2e-6 * want
+    grid = min(256, max(1, ((M + 31) // 32 + 3) // 4)) * 2
+    assert float(part[grid:].abs().max()) == 0.0 if grid < n_slots else True
+    # backward
+    lam, seed = 1e-5, torch.tensor(4096.0, device=dev)
+    d_sigma, d_rgb = torch.randn(M, device=dev, generator=g), torch.randn(M, 3, device=dev, generator=g)
+    d_spec = spec0 * (seed * (2.0 * lam / M))
+    outs = []
+    for fused in (False, True):
+        dh1, dh2 = f(16, M), torch.empty(16, M, 2, dtype=torch.float16, device=dev)
+        dws = [torch.zeros_like(t) for t in w]
+        finf = torch.zeros((), device=dev)
+        if fused:
+            L.call("n2m_field_backward_train", p(x), p(d), p(h1), p(h2), *[p(t) for t in w], M, 1, 1, p(d_sigma), p(d_rgb), None, p(dh1), p(dh2),
+                   *[p(t) for t in dws], p(finf), float(2.0 * lam / M), p(seed), s)
+        else:
+            L.call("n2m_field_backward", p(x), p(d), p(h1), p(h2), *[p(t) for t in w], M, 1, 1, p(d_sigma), p(d_rgb), p(d_spec), p(dh1), p(dh2),
+                   *[p(t) for t in dws], p(finf), s)
+        outs.append((dh1, dh2, dws))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
+    assert outs[1][2][5].abs().sum() > 0
+    # and the regulariser does reach the gradients: without it the specular head's dW differs
+    dws = [torch.zeros_like(t) for t in w]
+    L.call("n2m_field_backward", p(x), p(d), p(h1), p(h2), *[p(t) for t in w], M, 1, 1, p(d_sigma), p(d_rgb), None, f(16, M).data_ptr(),
+           torch.empty(16, M, 2, dtype=torch.float16, device=dev).data_ptr(), *[p(t) for t in dws], None, s)
+    torch.cuda.synchronize()
+    assert not torch.equal(dws[6], outs[1][2][6])

@@ -57,8 +57,19 @@ else:                                  # the blind rank's own loss is the consta
     allb = [torch.zeros_like(blind) for _ in range(world)]
     dist.all_gather(allb, blind)
     ok = ok and float(allb[int(os.environ["N2M_DIST_BLIND_RANK"])]) == 0 and sum(float(b) for b in allb) > 0
+if os.environ.get("N2M_DIST_CKPT"):
+    # every rank writes what a checkpoint would hold (optimizer.state_dict() is a collective for a sharded run: it gathers the moments)
+    sd = tr.optimizer.state_dict()
+    keep = {}
+    for i in (0, 1):                                   # the two tables are the first two parameters (get_params order)
+        st = sd["state"][i]
+        keep[f"exp_avg.{i}"], keep[f"exp_avg_sq.{i}"] = st["exp_avg"].detach().cpu(), st["exp_avg_sq"].detach().cpu()
+    keep["steps"] = sd["n2m_amp"]["steps"]
+    torch.save(keep, f"{os.environ['N2M_DIST_CKPT']}.rank{rank}.pt")
+    if world > 1:
+        dist.barrier()
 if rank == 0:
-    print(f"DIST_CHECK {'OK' if ok else 'FAILED'} driver={type(tr).__name__} shard={getattr(tr, 'shard', False)} world={world} steps={steps} loss {first:.5f} -> {last:.5f} digest={[float(x) for x in digest]}")
+    print(f"DIST_CHECK {'OK' if ok else 'FAILED'} driver={type(tr).__name__} shard={getattr(tr, 'shard', False)} backend={dist.get_backend() if world > 1 else 'none'} world={world} steps={steps} loss {first:.5f} -> {last:.5f} digest={[float(x) for x in digest]}")
 if world > 1:
     dist.destroy_process_group()
 sys.exit(0 if ok else 1)
