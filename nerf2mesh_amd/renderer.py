@@ -502,7 +502,8 @@ class NeRFRenderer(nn.Module):
             trig_id = F.interpolate(trig_id.view(1, 1, h, w), (h0, w0), mode="nearest").view(h0, w0)
         self.triangles_errors_id = trig_id
         image = image + T * bg_color
-        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": (1 - T).view(*prefix)}
+        # (weights_sum keeps the image shape [h0, w0, 1] like the reference's `1 - T`, nerf/renderer.py:911; its train_step flattens it)
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": 1 - T}
 
     @torch.no_grad()
     def update_triangles_errors(self, loss):
