@@ -305,9 +305,12 @@ class Stage0Trainer:
 
 
 class UniformLaplacian:
-    """Uniform-Laplacian smoothness of the mesh (nerf/utils.py:176-221): mean || mean_nb(v) - v ||^2.  The unique
-    directed edge list depends on the topology only, so it is built once per mesh (the reference rebuilds its sparse
-    matrix every step) and the loss is two index_add passes."""
+    """Uniform-Laplacian smoothness of the mesh, `laplacian_smooth_loss(verts, faces)` of nerf/utils.py:176-221: with L = D - A over the
+    UNIQUE directed edges (diagonal = number of distinct neighbours, -1 per neighbour), loss = mean_i || (L v)_i ||_2 =
+    mean_i || deg_i v_i - sum_{j in N(i)} v_j || -- a norm, not a squared norm, and not divided by the degree (checked against the unchanged
+    reference function in tests/test_stage1_reference.py; rounds 1-2 had the squared, degree-normalised form here).  The edge list
+    depends on the topology only, so it is built once per mesh (the reference rebuilds its sparse matrix every step) and the loss is
+    two index_add passes."""
 
     def __init__(self, faces, n_verts):
         f = faces.long()
@@ -315,12 +318,11 @@ class UniformLaplacian:
         jj = torch.cat([f[:, 1], f[:, 0], f[:, 2], f[:, 1], f[:, 0], f[:, 2]])
         key = torch.unique(ii * n_verts + jj)
         self.ii, self.jj = key // n_verts, key % n_verts
-        deg = torch.zeros(n_verts, device=faces.device).index_add_(0, self.ii, torch.ones_like(self.ii, dtype=torch.float32))
-        self.inv_deg = (1.0 / deg.clamp(min=1)).unsqueeze(1)
+        self.deg = torch.zeros(n_verts, device=faces.device).index_add_(0, self.ii, torch.ones_like(self.ii, dtype=torch.float32)).unsqueeze(1)
 
     def __call__(self, verts):
         nb = _NeighbourSum.apply(verts, self.ii, self.jj)
-        return ((nb * self.inv_deg - verts) ** 2).sum(-1).mean()
+        return (verts * self.deg - nb).norm(dim=1).mean()
 
 
 class _NeighbourSum(torch.autograd.Function):
