@@ -210,8 +210,8 @@ def main():
     ap.add_argument("--autograd", action="store_true", help="A/B: drive the step through torch.autograd (trainer.Stage0Trainer) instead of the step "
                     "executor (engine.Stage0Engine): same kernels, same arguments, more host time")
     ap.add_argument("--recipe", default="lego", choices=["lego", "sdf", "garden"], help="lego: the headline config (BASELINE configs[1]); sdf: "
-                    "`--sdf` stage 0 (config 5: NeuS alpha, 7 density evaluations per sample, eikonal loss); garden: `--bound 16 --dt_gamma 1/256`, "
-                    "5 cascades, inner/outer TV split (config 4's recipe on the synthetic scene).  The last two run on trainer.Stage0Trainer")
+                    "`--sdf` stage 0 (config 5: NeuS alpha, 7 density evaluations per sample, eikonal loss); garden: config 4's recipe "
+                    "(`--bound 16 --enable_cam_near_far --lambda_entropy 1e-3`, 5 cascades, colmap-style AABB, inner/outer TV) on the synthetic yard scene")
     ap.add_argument("--num-points", type=int, default=0, help="measurement aid: override the per-step sample target (2^18 in the recipe); "
                                                                "a tiny value shows every kernel's fixed cost")
     ap.add_argument("--unfused", action="store_true", help="A/B: evaluate the MLPs with nn.Linear calls (the reference graph) instead of the fused MFMA kernels")
@@ -254,12 +254,15 @@ def main():
     torch.manual_seed(0)                                           # seed_everything(0), identical init on every rank
     recipes = {"lego": dict(bound=1, dt_gamma=0),                                    # scripts/runall_syn.sh:1
                "sdf": dict(bound=1, dt_gamma=0, sdf=True),                            # scripts/runall_syn_sdf.sh:1
-               "garden": dict(bound=16, dt_gamma=1 / 256)}                            # scripts/runall_360.sh (bound 16, default dt_gamma)
+               # scripts/runall_360_outdoor.sh:2: -O --bound 16 --enable_cam_near_far --lambda_entropy 1e-3 (default dt_gamma 1/256), colmap AABB
+               "garden": dict(bound=16, dt_gamma=1 / 256, lambda_entropy=1e-3, enable_cam_near_far=True, scene="garden")}
     opt = make_options(O=True, iters=30000, fused_mlp=not args.unfused, **recipes[args.recipe])
     if args.num_points > 0:
         opt.num_points = args.num_points
         opt.num_rays = max(64, args.num_points // 16)
     model = NeRFNetwork(opt)
+    if args.recipe == "garden":
+        model.update_aabb(synthetic.pts_aabb("garden"))       # main.py:234-235: the sparse points give a tighter AABB than the bound
     poses = synthetic.make_cameras(100, seed=0)
     from nerf2mesh_amd.engine import Stage0Engine
     use_engine = not args.autograd and not args.unfused and Stage0Engine.supported(model, opt)
@@ -358,7 +361,8 @@ def main():
         "rays_per_sec": rays / dt,
         "config": {"workload": {"lego": "nerf_synthetic/lego stage-0 -O --bound 1 --dt_gamma 0",
                                 "sdf": "nerf_synthetic/lego --sdf stage-0 -O --bound 1 --dt_gamma 0 (NeuS alpha, finite-difference normals, eikonal loss)",
-                                "garden": "mip-360-style stage-0 -O --bound 16 --dt_gamma 1/256 (5 cascades, inner/outer TV) on the synthetic scene"}[args.recipe]
+                                "garden": "mip-360 outdoor recipe (scripts/runall_360_outdoor.sh:2) stage-0 -O --bound 16 --enable_cam_near_far "
+                                          "--lambda_entropy 1e-3, dt_gamma 1/256 (5 cascades, colmap-style AABB, inner/outer TV) on the synthetic yard scene"}[args.recipe]
                                + ", 800x800 x 100 synthetic views, num_points target 2^18/GPU (adaptive num_rays), occupancy refresh every 16 steps",
                    "shading": shading, "timed_steps": [first_timed, first_timed + args.steps - 1], "diffuse_step": int(opt.diffuse_step),
                    "parallelism": (f"dp{world} (rays sharded; table gradients reduce-scattered, Adam sharded over the ranks, packed rows all-gathered; "

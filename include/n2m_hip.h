@@ -166,6 +166,24 @@ int n2m_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int al
 int n2m_compact_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out, int32_t* n_out_dev,
                       void* stream);
 
+/* The inference loop of nerf/renderer.py:764-802 with the ray count kept ON THE DEVICE.  The reference reads n_alive back every round
+ * (`rays_alive = rays_alive[rays_alive >= 0]`, :799) to size the next round's launches and to derive n_step = max(min(N // n_alive, 8), 1)
+ * (:775).  Here `state` = {n_alive, step} (int32 x 2, device) carries both; the three kernels of a round read it, derive n_step the same way
+ * and skip the round when n_alive == 0 or step >= max_steps; n2m_compact_alive_dev writes the next round's state {survivors, step + n_step}
+ * into state_out (state and the ray lists ping-pong between two buffers).  The host passes n_alive_ub >= n_alive (the count never grows, so
+ * any earlier value is a bound) for the grid sizes and may learn the true count as late as it likes.  Buffers xyzs / dirs / ts / sigmas /
+ * rgbs need N rows (n_alive * n_step <= N for every round); N = the ray count of the image.  Per-ray arithmetic is that of n2m_march_rays /
+ * n2m_composite_rays: same image, bit for bit. */
+int n2m_march_rays_dev(const int32_t* state, uint32_t n_alive_ub, uint32_t N, const int32_t* rays_alive, const float* rays_t,
+                       const float* rays_o, const float* rays_d, float bound, int contract, float dt_gamma, uint32_t max_steps, uint32_t C,
+                       uint32_t H, const uint8_t* grid, const float* fars, float* xyzs, float* dirs, float* ts, const float* noises,
+                       void* stream);
+int n2m_composite_rays_dev(const int32_t* state, uint32_t n_alive_ub, uint32_t N, uint32_t max_steps, float T_thresh, int alpha_mode,
+                           int32_t* rays_alive, float* rays_t, const float* sigmas, const float* rgbs, const float* ts, float* weights_sum,
+                           float* depth, float* image, void* stream);
+int n2m_compact_alive_dev(const int32_t* rays_alive, const int32_t* state, uint32_t n_alive_ub, uint32_t N, uint32_t max_steps, int32_t* out,
+                          int32_t* state_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * gridencoder   (reference: gridencoder/src/gridencoder.h:12-15, gridencoder/src/bindings.cpp:5-9)
  * ---------------------------------------------------------------------------------------------------- */
@@ -357,6 +375,12 @@ int n2m_get_rays(const float* poses, const int64_t* cam, const int64_t* pix, uin
 int n2m_batch_rays(const float* poses, const float* uniforms, uint32_t V, uint32_t N, uint32_t H, uint32_t W, float fx, float fy, float cx,
                    float cy, const float* images, const float* aabb, float min_near, float* rays_o, float* rays_d, float* rgba,
                    float* nears, float* fars, float* noises, float* bg, int32_t* counter, void* stream);
+/* The same with the per-view near / far clamp of `--enable_cam_near_far` (nerf/renderer.py:689-691; colmap_provider.py:270,563-565 hands
+ * every ray the (near, far) of its camera): cam_near_far [V,2] f32, nears = max(nears, cnf[view,0]), fars = min(fars, cnf[view,1]); NULL =
+ * n2m_batch_rays. */
+int n2m_batch_rays_cnf(const float* poses, const float* uniforms, uint32_t V, uint32_t N, uint32_t H, uint32_t W, float fx, float fy, float cx,
+                       float cy, const float* images, const float* aabb, float min_near, float* rays_o, float* rays_d, float* rgba,
+                       float* nears, float* fars, float* noises, float* bg, int32_t* counter, const float* cam_near_far, void* stream);
 
 /* Photometric loss head of the stage-0 step in one launch per direction:
  *   pred   = image + (1 - weights_sum) * bg                      nerf/renderer.py:747
@@ -384,6 +408,15 @@ int n2m_composite_loss_train(const float* sigmas, const float* rgbs, const float
                              float T_thresh, const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask,
                              const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas, float* grad_rgbs, float* partial,
                              uint32_t* ticket, float* loss, float* loss_sum, void* stream);
+/* The same + the entropy regulariser of nerf/utils.py:728-733 (config 4: `--lambda_entropy 1e-3`, scripts/runall_360_outdoor.sh:2):
+ * loss += lambda_entropy * (mean over the M samples of H(clamp(w)) + mean over the N rays of H(clamp(weights_sum))),
+ * H(p) = -p log2 p - (1 - p) log2 (1 - p), clamp to [1e-5, 1 - 1e-5].  Its gradient w.r.t. a sample's weight is the `grad_weights` input of
+ * composite_rays_train's backward and enters grad_sigmas exactly where the reference kernel reads grad_weights[i] (raymarching.cu:676).
+ * lambda_entropy == 0: identical to n2m_composite_loss_train. */
+int n2m_composite_loss_train_ent(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays, uint32_t M, uint32_t N,
+                                 float T_thresh, const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask,
+                                 const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas, float* grad_rgbs, float* partial,
+                                 uint32_t* ticket, float* loss, float* loss_sum, float lambda_entropy, void* stream);
 
 /* Adam + GradScaler for the whole parameter set in two launches (torch.optim.Adam(fused=True) + torch.amp.GradScaler of
  * main.py:221 / nerf/utils.py:506,1187-1190).  All tensors fp32 and 16-byte aligned, except grad which may be fp16

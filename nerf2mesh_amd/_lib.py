@@ -30,9 +30,13 @@ SIGNATURES = {
     "n2m_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _int, _vp, _vp, _vp, _vp, _vp],
     "n2m_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _int, _vp, _vp, _vp],
     "n2m_composite_loss_train": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "n2m_composite_loss_train_ent": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp],
     "n2m_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_composite_rays": [_u32, _u32, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_compact_alive": [_vp, _u32, _vp, _vp, _vp],
+    "n2m_march_rays_dev": [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "n2m_composite_rays_dev": [_vp, _u32, _u32, _u32, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "n2m_compact_alive_dev": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
     "n2m_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _int, _u32, _int, _vp],
     "n2m_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _int, _u32, _int, _vp],
     "n2m_grad_total_variation": [_vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _int, _vp],
@@ -58,6 +62,7 @@ SIGNATURES = {
     "n2m_freq_encode_backward": [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp],
     "n2m_get_rays": [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "n2m_batch_rays": [_vp, _vp, _u32, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "n2m_batch_rays_cnf": [_vp, _vp, _u32, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_adam_step": [_vp, ctypes.c_double, ctypes.c_double, _f32, _vp, _vp, _vp, _vp],
     "n2m_scaler_update": [_vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp],
     "n2m_scaler_update_slots": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp],

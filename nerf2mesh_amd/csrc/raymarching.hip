@@ -67,7 +67,7 @@ batch_rays_kernel(const float* __restrict__ poses /*[V,4,4]*/, const float* __re
                   uint32_t HW, float fx, float fy, float cx, float cy, const float* __restrict__ images /*[V,HW,4]*/,
                   const float* __restrict__ aabb, float min_near, float* __restrict__ rays_o, float* __restrict__ rays_d,
                   float* __restrict__ rgba, float* __restrict__ nears, float* __restrict__ fars, float* __restrict__ noises,
-                  float* __restrict__ bg, int32_t* __restrict__ counter) {
+                  float* __restrict__ bg, int32_t* __restrict__ counter, const float* __restrict__ cam_near_far /*[V,2] or NULL*/) {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
     if (n == 0 && counter) counter[0] = 0;
     if (n >= N) return;
@@ -85,7 +85,13 @@ batch_rays_kernel(const float* __restrict__ poses /*[V,4,4]*/, const float* __re
         rays_o[(size_t)n * 3 + k] = o[k];
     }
     *reinterpret_cast<float4*>(rgba + (size_t)n * 4) = *reinterpret_cast<const float4*>(images + ((size_t)v * HW + (size_t)p) * 4);
-    near_far_of(o, d, aabb, min_near, nears[n], fars[n]);
+    float tn, tf;
+    near_far_of(o, d, aabb, min_near, tn, tf);
+    if (cam_near_far) {       // per-view clamp from the sparse points (nerf/renderer.py:689-691, colmap_provider.py:563-565): maximum / minimum
+        tn = fmaxf(tn, cam_near_far[2 * v]);
+        tf = fminf(tf, cam_near_far[2 * v + 1]);
+    }
+    nears[n] = tn; fars[n] = tf;
     noises[n] = un[2];
     if (bg) { bg[(size_t)n * 3] = un[3]; bg[(size_t)n * 3 + 1] = un[4]; bg[(size_t)n * 3 + 2] = un[5]; }
 }
@@ -672,6 +678,57 @@ march_infer_kernel(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict_
     }
 }
 
+// ---- inference loop with the ray count ON THE DEVICE (nerf/renderer.py:764-802 without its per-round host read of n_alive) ----
+// state = {n_alive, step} (int32 x 2).  A round's kernels read the count from device memory and derive n_step exactly as the reference's
+// host code does, n_step = max(min(N / n_alive, 8), 1) (:775); the host sizes its launches from an UPPER bound (n_alive never grows) that
+// it learns a few rounds late through asynchronous copies, so nothing waits for a read-back.  A round whose state says "done"
+// (n_alive == 0 or step >= max_steps) does nothing.
+struct InferRound { uint32_t n_alive, n_step; bool active; };
+__device__ __forceinline__ InferRound infer_round(const int32_t* __restrict__ state, uint32_t N, uint32_t max_steps) {
+    InferRound r;
+    r.n_alive = (uint32_t)state[0];
+    const uint32_t step = (uint32_t)state[1];
+    r.active = r.n_alive != 0u && step < max_steps;
+    const uint32_t q = r.n_alive ? N / r.n_alive : 0u;
+    r.n_step = max(min(q, 8u), 1u);
+    return r;
+}
+
+__global__ void __launch_bounds__(64)
+march_infer_dev_kernel(const int32_t* __restrict__ state, uint32_t N, const int32_t* __restrict__ rays_alive, const float* __restrict__ rays_t,
+                       const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound, bool contract,
+                       float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                       const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs,
+                       float* __restrict__ ts, const float* __restrict__ noises) {
+    const InferRound rd = infer_round(state, N, max_steps);
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!rd.active || n >= rd.n_alive) return;
+    const uint32_t n_step = rd.n_step;
+    const int32_t ray = rays_alive[n];
+    MarchCtx c;
+    march_ctx_init(c, rays_o + 3 * (size_t)ray, rays_d + 3 * (size_t)ray, 1e-10f, grid, bound, contract, dt_gamma, max_steps, C, H);
+    float* px = xyzs + 3 * (size_t)n * n_step;
+    float* pd = dirs + 3 * (size_t)n * n_step;
+    float* pt = ts + 2 * (size_t)n * n_step;
+    const float far = fars[ray];
+    float t = rays_t[ray];
+    t += n2m_clampf(t * dt_gamma, c.dt_min, c.dt_max) * (noises ? noises[n] : 0.0f);
+    uint32_t kept = 0;
+    MarchSample s;
+    while (t < far && kept < n_step) {
+        if (!march_step(c, t, s)) continue;
+        px[0] = s.cx; px[1] = s.cy; px[2] = s.cz;
+        pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+        *reinterpret_cast<float2*>(pt) = make_float2(s.t_after, s.dt);
+        px += 3; pd += 3; pt += 2;
+        ++kept;
+    }
+    // the reference's wrapper hands the kernel freshly zeroed buffers every round (raymarching.py:343-345): an unused slot has ts == 0,
+    // which ends the ray in composite_rays (:877).  The buffers persist here, so the unused slots are cleared by their owner; positions and
+    // directions of unused slots keep older (finite, in-range) values -- the field evaluates them, nobody reads the result.
+    for (; kept < n_step; ++kept) { *reinterpret_cast<float2*>(pt) = make_float2(0.0f, 0.0f); pt += 2; }
+}
+
 // -------------------------------------------------------------------------------------- exclusive scans
 // Generic exclusive scan over n items; Op supplies load(i), store(i, value, exclusive_prefix), base(), finish(total).
 
@@ -796,6 +853,25 @@ struct CompactOp {
     __device__ uint32_t load(uint32_t i) const { return in[i] >= 0 ? 1u : 0u; }
     __device__ void store(uint32_t i, uint32_t v, uint32_t excl) const { if (v) out[excl] = in[i]; }
     __device__ void finish(uint32_t total) const { n_out[0] = (int32_t)total; }
+};
+
+struct CompactDevOp {      // the same with the item count in device memory; writes the NEXT round's state {n_alive, step + n_step}
+    const int32_t* in;
+    int32_t* out;
+    const int32_t* state;
+    int32_t* state_out;
+    uint32_t N, max_steps;
+    __device__ uint32_t base() const { return 0u; }
+    __device__ uint32_t load(uint32_t i) const {
+        const InferRound rd = infer_round(state, N, max_steps);
+        return (rd.active && i < rd.n_alive && in[i] >= 0) ? 1u : 0u;
+    }
+    __device__ void store(uint32_t i, uint32_t v, uint32_t excl) const { if (v) out[excl] = in[i]; }
+    __device__ void finish(uint32_t total) const {
+        const InferRound rd = infer_round(state, N, max_steps);
+        state_out[0] = rd.active ? (int32_t)total : 0;
+        state_out[1] = state[1] + (rd.active ? (int32_t)rd.n_step : 0);
+    }
 };
 
 // ------------------------------------------------------------------------------------ compositing (train)
@@ -936,13 +1012,23 @@ composite_train_bwd_kernel(const float* __restrict__ grad_weights, const float* 
 // chain, the loss value differs by its summation order only (per-workgroup partials, summed in index order by the last workgroup).
 // 16 waves per workgroup, one ray per wave: same-address atomics retire one per ~11 ns (tools/atomic_bench.hip), so the arrival ticket
 // must be taken by ~N/16 workgroups, not N/4 (measured: 80 us with 4-ray workgroups at N = 15 k, the ticket chain alone)
+// ENT: + the entropy regulariser of nerf/utils.py:728-733, lambda_entropy * (mean_m H(clamp(w_m)) + mean_n H(clamp(ws_n))) with
+// H(p) = -p log2 p - (1-p) log2(1-p) and clamp to [1e-5, 1 - 1e-5] -- the one loss term that hands composite_rays_train's backward a
+// non-zero grad_weights (config 4, scripts/runall_360_outdoor.sh:2).  A sample's H'(w) enters the backward exactly where the reference
+// kernel reads grad_weights[i] (raymarching.cu:676, its per-sample factor on the ray-suffix term, kept as it is).
+__device__ __forceinline__ float n2m_entropy(float p) { return -p * log2f(p) - (1.0f - p) * log2f(1.0f - p); }
+__device__ __forceinline__ float n2m_entropy_grad(float x) {       // d H(clamp(x)) / dx: clamp passes the gradient on [1e-5, 1 - 1e-5] inclusive
+    const float lo = 1e-5f, hi = 1.0f - 1e-5f;
+    return (x >= lo && x <= hi) ? (-log2f(x) - 1.4426950408889634f) + (log2f(1.0f - x) + 1.4426950408889634f) : 0.0f;
+}
+template <bool ENT>
 __global__ void __launch_bounds__(1024)
 composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ ts,
                             const int32_t* __restrict__ rays, uint32_t M, uint32_t N, float T_thresh, const float* __restrict__ gt,
                             const float* __restrict__ bg, float bg_scalar, float lambda_rgb, float lambda_mask,
                             const float* __restrict__ grad_loss, float* __restrict__ weights_sum, float* __restrict__ image,
                             float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs, float* __restrict__ partial,
-                            uint32_t* __restrict__ ticket, float* __restrict__ loss, float* __restrict__ loss_sum) {
+                            uint32_t* __restrict__ ticket, float* __restrict__ loss, float* __restrict__ loss_sum, float lambda_entropy) {
     __shared__ float wave_loss[16];
     __shared__ bool last_block;
     const uint32_t wid = threadIdx.x >> 6, n = blockIdx.x * 16 + wid;
@@ -961,6 +1047,8 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
         // ---- forward
         float rF = 0, gF = 0, bF = 0, wsF = 0;
         float a0 = 0.f, dt0 = 0.f, cr0 = 0.f, cg0 = 0.f, cb0 = 0.f;     // the first 64 samples stay in registers for the backward pass
+        float entF = 0.f;                  // ENT: sum of H(clamp(w)) over this ray's samples (weights after the early stop are zeros)
+        uint32_t visited = 0;
         if (whole) {
             float carry_T = 1.0f;
             for (uint32_t base = 0; base < cnt; base += 64) {
@@ -981,11 +1069,16 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
                 const int last = stop ? (int)__ffsll((long long)stop) - 1 : 63;
                 const float w = (valid && lane <= last) ? alpha * T_before : 0.f;
                 rF += w * cr; gF += w * cg; bF += w * cb; wsF += w;
+                if (ENT) {
+                    if (valid) entF += n2m_entropy(fminf(fmaxf(w, 1e-5f), 1.0f - 1e-5f));
+                    visited = min(cnt, base + 64u);
+                }
                 if (stop) break;
                 carry_T = n2m_lane63(T_after);
             }
             rF = n2m_wave_sum(rF); gF = n2m_wave_sum(gF); bF = n2m_wave_sum(bF); wsF = n2m_wave_sum(wsF);
-        }
+            if (ENT) entF = n2m_wave_sum(entF) + (float)(cnt - visited) * n2m_entropy(1e-5f);
+        } else if (ENT && cnt != 0 && off < M) entF = (float)(M - off) * n2m_entropy(1e-5f);      // cut off by M: its weights stay zero
         // ---- loss term of the ray and its gradients (wave-uniform)
         const float a = gtv.w;
         const float gc[3] = {gtv.x, gtv.y, gtv.z}, pc[3] = {rF, gF, bF};
@@ -1004,6 +1097,13 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
             if (c == 0) l_ray = e * e; else l_ray += e * e;
         }
         l_ray = lambda_rgb * (l_ray / 3.0f) + lambda_mask * (m * m);
+        float gE = 0.f;                     // ENT: seed gradient of one sample's entropy term, lambda / M
+        if (ENT) {
+            const float inv_m = M ? 1.0f / (float)M : 0.0f;
+            l_ray += lambda_entropy * (n2m_entropy(fminf(fmaxf(wsF, 1e-5f), 1.0f - 1e-5f)) + entF * ((float)N * inv_m));
+            gws += gscale * lambda_entropy * n2m_entropy_grad(wsF);
+            gE = gl * lambda_entropy * inv_m;
+        }
         if (lane == 0) {
             if (weights_sum) weights_sum[n] = wsF;
             if (image) { image[3 * n] = rF; image[3 * n + 1] = gF; image[3 * n + 2] = bF; }
@@ -1047,8 +1147,9 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
                 if (live) {
                     grad_rgbs[3 * i] = gi[0] * w; grad_rgbs[3 * i + 1] = gi[1] * w; grad_rgbs[3 * i + 2] = gi[2] * w;
                     // composite_train_bwd_kernel's expression with grad_weights = grad_depth = 0 (their terms are exact zeros there)
+                    const float gw = ENT ? gE * n2m_entropy_grad(w) : 0.f;      // grad_weights[i]
                     grad_sigmas[i] = dt * (gi[0] * (T_after * cr - (rF - r)) + gi[1] * (T_after * cg - (gF - g)) +
-                                           gi[2] * (T_after * cb - (bF - b)) + (gws + 0.f) * (T_after - (wsF - ws)) + 0.f * 0.f);
+                                           gi[2] * (T_after * cb - (bF - b)) + (gws + gw) * (T_after - (wsF - ws)) + 0.f * 0.f);
                 } else if (valid) {
                     grad_sigmas[i] = 0.f; grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f;
                 }
@@ -1128,6 +1229,40 @@ __global__ void composite_infer_kernel(uint32_t n_alive, uint32_t n_step, float 
     image[3 * ray] = r; image[3 * ray + 1] = g; image[3 * ray + 2] = b;
 }
 
+__global__ void composite_infer_dev_kernel(const int32_t* __restrict__ state, uint32_t N, uint32_t max_steps, float T_thresh, bool alpha_mode,
+                                           int32_t* __restrict__ rays_alive, float* __restrict__ rays_t,
+                                           const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                           const float* __restrict__ ts, float* __restrict__ weights_sum,
+                                           float* __restrict__ depth, float* __restrict__ image) {
+    const InferRound rd = infer_round(state, N, max_steps);
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!rd.active || n >= rd.n_alive) return;
+    const uint32_t n_step = rd.n_step;
+    const int32_t ray = rays_alive[n];
+    const size_t base = (size_t)n * n_step;
+    float t = 0.0f;
+    float d = depth[ray], r = image[3 * ray], g = image[3 * ray + 1], b = image[3 * ray + 2], ws = weights_sum[ray];
+    uint32_t step = 0;
+    while (step < n_step) {
+        const size_t i = base + step;
+        const float2 tt = *reinterpret_cast<const float2*>(ts + 2 * i);
+        if (tt.x == 0) break;
+        const float alpha = alpha_mode ? sigmas[i] : (1.0f - expf(-sigmas[i] * tt.y));
+        const float T = 1 - ws;
+        const float w = alpha * T;
+        ws += w;
+        t = tt.x;
+        d += w * t;
+        r += w * rgbs[3 * i]; g += w * rgbs[3 * i + 1]; b += w * rgbs[3 * i + 2];
+        if (T < T_thresh) break;
+        ++step;
+    }
+    if (step < n_step) rays_alive[n] = -1; else rays_t[ray] = t;
+    weights_sum[ray] = ws;
+    depth[ray] = d;
+    image[3 * ray] = r; image[3 * ray + 1] = g; image[3 * ray + 2] = b;
+}
+
 bool serial_march() {   // A/B switch: N2M_MARCH_SERIAL=1 selects the one-ray-per-lane kernels
     static const bool v = getenv("N2M_MARCH_SERIAL") != nullptr;
     return v;
@@ -1148,17 +1283,25 @@ extern "C" int n2m_near_far_from_aabb(const float* rays_o, const float* rays_d, 
     return 0;
 }
 
-extern "C" int n2m_batch_rays(const float* poses, const float* uniforms, uint32_t V, uint32_t N, uint32_t H, uint32_t W, float fx, float fy,
+extern "C" int n2m_batch_rays_cnf(const float* poses, const float* uniforms, uint32_t V, uint32_t N, uint32_t H, uint32_t W, float fx, float fy,
                               float cx, float cy, const float* images, const float* aabb, float min_near, float* rays_o, float* rays_d,
-                              float* rgba, float* nears, float* fars, float* noises, float* bg, int32_t* counter, void* stream) {
+                              float* rgba, float* nears, float* fars, float* noises, float* bg, int32_t* counter, const float* cam_near_far,
+                                  void* stream) {
     N2M_NOTNULL(poses); N2M_NOTNULL(uniforms); N2M_NOTNULL(images); N2M_NOTNULL(aabb); N2M_NOTNULL(rays_o); N2M_NOTNULL(rays_d);
     N2M_NOTNULL(rgba); N2M_NOTNULL(nears); N2M_NOTNULL(fars); N2M_NOTNULL(noises);
     N2M_REQUIRE(V >= 1 && (uint64_t)H * W < (1ull << 24), N2M_EINVAL, "batch_rays: need V >= 1 and H*W < 2^24 (pixel index from an fp32 uniform)");
     if (N == 0) return 0;
     batch_rays_kernel<<<n2m_ceil_div(N, 256), 256, 0, (hipStream_t)stream>>>(poses, uniforms, V, N, W, H * W, fx, fy, cx, cy, images, aabb, min_near,
-                                                                             rays_o, rays_d, rgba, nears, fars, noises, bg, counter);
+                                                                             rays_o, rays_d, rgba, nears, fars, noises, bg, counter, cam_near_far);
     N2M_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int n2m_batch_rays(const float* poses, const float* uniforms, uint32_t V, uint32_t N, uint32_t H, uint32_t W, float fx, float fy,
+                              float cx, float cy, const float* images, const float* aabb, float min_near, float* rays_o, float* rays_d,
+                              float* rgba, float* nears, float* fars, float* noises, float* bg, int32_t* counter, void* stream) {
+    return n2m_batch_rays_cnf(poses, uniforms, V, N, H, W, fx, fy, cx, cy, images, aabb, min_near, rays_o, rays_d, rgba, nears, fars, noises, bg,
+                              counter, nullptr, stream);
 }
 
 extern "C" int n2m_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
@@ -1368,21 +1511,35 @@ extern "C" int n2m_composite_rays_train_forward(const float* sigmas, const float
 
 // Training fast path: compositing, loss head and both backward passes of n2m_composite_rays_train_forward/backward +
 // n2m_photo_loss_forward/backward in one launch (density mode; no grad_weights / grad_depth: the plain rgb + mask loss).
-extern "C" int n2m_composite_loss_train(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays, uint32_t M, uint32_t N,
+extern "C" int n2m_composite_loss_train_ent(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays, uint32_t M, uint32_t N,
                                         float T_thresh, const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb,
                                         float lambda_mask, const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas,
-                                        float* grad_rgbs, float* partial, uint32_t* ticket, float* loss, float* loss_sum, void* stream) {
+                                        float* grad_rgbs, float* partial, uint32_t* ticket, float* loss, float* loss_sum, float lambda_entropy,
+                                            void* stream) {
     N2M_NOTNULL(rays); N2M_NOTNULL(gt_rgba); N2M_NOTNULL(grad_loss); N2M_NOTNULL(partial);
     N2M_REQUIRE(ticket == nullptr || loss != nullptr, N2M_ENULL, "composite_loss_train: a ticket needs the loss output");
     if (M > 0) { N2M_NOTNULL(sigmas); N2M_NOTNULL(rgbs); N2M_NOTNULL(ts); N2M_NOTNULL(grad_sigmas); N2M_NOTNULL(grad_rgbs); }
     if (N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     N2M_PROF(N2M_K_COMPOSITE_FWD, s, 28.0 * M + 28.0 * N + 44.0 * M + 48.0 * N);     // forward + backward of SURVEY 8d, one launch
-    composite_loss_train_kernel<<<n2m_ceil_div(N, 16), 1024, 0, s>>>(sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar, lambda_rgb,
-                                                                    lambda_mask, grad_loss, weights_sum, image, grad_sigmas, grad_rgbs, partial,
-                                                                    ticket, loss, loss_sum);
+    if (lambda_entropy > 0.0f)
+        composite_loss_train_kernel<true><<<n2m_ceil_div(N, 16), 1024, 0, s>>>(sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar,
+                                                                              lambda_rgb, lambda_mask, grad_loss, weights_sum, image, grad_sigmas,
+                                                                              grad_rgbs, partial, ticket, loss, loss_sum, lambda_entropy);
+    else
+        composite_loss_train_kernel<false><<<n2m_ceil_div(N, 16), 1024, 0, s>>>(sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar,
+                                                                               lambda_rgb, lambda_mask, grad_loss, weights_sum, image, grad_sigmas,
+                                                                               grad_rgbs, partial, ticket, loss, loss_sum, 0.0f);
     N2M_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int n2m_composite_loss_train(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays, uint32_t M, uint32_t N,
+                                        float T_thresh, const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb,
+                                        float lambda_mask, const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas,
+                                        float* grad_rgbs, float* partial, uint32_t* ticket, float* loss, float* loss_sum, void* stream) {
+    return n2m_composite_loss_train_ent(sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask, grad_loss,
+                                        weights_sum, image, grad_sigmas, grad_rgbs, partial, ticket, loss, loss_sum, 0.0f, stream);
 }
 
 extern "C" int n2m_composite_rays_train_backward(const float* grad_weights, const float* grad_weights_sum,
@@ -1442,6 +1599,46 @@ extern "C" int n2m_compact_alive(const int32_t* rays_alive, uint32_t n_alive, in
     if (n_alive > 0) { N2M_NOTNULL(rays_alive); N2M_NOTNULL(out); }
     const int rc = run_exclusive_scan(CompactOp{rays_alive, out, n_out_dev}, n_alive, (hipStream_t)stream);
     if (rc) { n2m_set_error("compact_alive: scan failed (%d)", rc); return rc; }
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- the device-count forms (include/n2m_hip.h): `state` = {n_alive, step} in device memory, n_alive_ub = the host's upper bound of n_alive
+extern "C" int n2m_march_rays_dev(const int32_t* state, uint32_t n_alive_ub, uint32_t N, const int32_t* rays_alive, const float* rays_t,
+                                  const float* rays_o, const float* rays_d, float bound, int contract, float dt_gamma, uint32_t max_steps,
+                                  uint32_t C, uint32_t H, const uint8_t* grid, const float* fars, float* xyzs, float* dirs, float* ts,
+                                  const float* noises, void* stream) {
+    if (n_alive_ub == 0) return 0;
+    N2M_NOTNULL(state); N2M_NOTNULL(rays_alive); N2M_NOTNULL(rays_t); N2M_NOTNULL(rays_o); N2M_NOTNULL(rays_d); N2M_NOTNULL(grid);
+    N2M_NOTNULL(fars); N2M_NOTNULL(xyzs); N2M_NOTNULL(dirs); N2M_NOTNULL(ts);
+    N2M_REQUIRE(C >= 1 && H >= 1 && H <= 1024 && max_steps >= 1 && N >= n_alive_ub, N2M_EINVAL, "march_rays_dev: bad C/H/max_steps/N");
+    march_infer_dev_kernel<<<n2m_ceil_div(n_alive_ub, 64), 64, 0, (hipStream_t)stream>>>(state, N, rays_alive, rays_t, rays_o, rays_d, bound,
+                                                                                        contract != 0, dt_gamma, max_steps, C, H, grid, fars,
+                                                                                        xyzs, dirs, ts, noises);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_composite_rays_dev(const int32_t* state, uint32_t n_alive_ub, uint32_t N, uint32_t max_steps, float T_thresh, int alpha_mode,
+                                      int32_t* rays_alive, float* rays_t, const float* sigmas, const float* rgbs, const float* ts,
+                                      float* weights_sum, float* depth, float* image, void* stream) {
+    if (n_alive_ub == 0) return 0;
+    N2M_NOTNULL(state); N2M_NOTNULL(rays_alive); N2M_NOTNULL(rays_t); N2M_NOTNULL(weights_sum); N2M_NOTNULL(depth); N2M_NOTNULL(image);
+    N2M_NOTNULL(sigmas); N2M_NOTNULL(rgbs); N2M_NOTNULL(ts);
+    composite_infer_dev_kernel<<<n2m_ceil_div(n_alive_ub, 128), 128, 0, (hipStream_t)stream>>>(state, N, max_steps, T_thresh, alpha_mode != 0,
+                                                                                              rays_alive, rays_t, sigmas, rgbs, ts, weights_sum,
+                                                                                              depth, image);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_compact_alive_dev(const int32_t* rays_alive, const int32_t* state, uint32_t n_alive_ub, uint32_t N, uint32_t max_steps,
+                                     int32_t* out, int32_t* state_out, void* stream) {
+    N2M_NOTNULL(state); N2M_NOTNULL(state_out); N2M_NOTNULL(rays_alive); N2M_NOTNULL(out);
+    N2M_REQUIRE(state != state_out && rays_alive != out, N2M_EINVAL, "compact_alive_dev: state / ray lists must ping-pong (in != out)");
+    // n_alive_ub == 0 still runs the one-block scan: its finish() writes the next state
+    const int rc = run_exclusive_scan(CompactDevOp{rays_alive, out, state, state_out, N, max_steps}, n_alive_ub, (hipStream_t)stream);
+    if (rc) { n2m_set_error("compact_alive_dev: scan failed (%d)", rc); return rc; }
     N2M_CHECK_LAUNCH();
     return 0;
 }

@@ -83,7 +83,10 @@ class Stage0Engine:
         self.gen.manual_seed(seed + rank)
         self.optimizer = FusedAdamAMP(model.get_params(opt.lr), eps=1e-15, amp=True)
         self.images = None
-        self.boxes = synthetic.boxes(dev)
+        self.scene = getattr(opt, "scene", "lego")
+        self.boxes = synthetic.boxes(dev, self.scene)
+        # --enable_cam_near_far (main.py:40, config 4): per-view (near, far) from the sparse points, applied by the batch kernel
+        self.cam_near_far = synthetic.cam_near_far(self.poses, self.scene) if getattr(opt, "enable_cam_near_far", False) else None
         self.samples_seen = self.rays_seen = 0
         self.last_num_points = 0
         self._loss_pending, self._loss_sum = [], torch.zeros(1, device=dev)
@@ -163,7 +166,7 @@ class Stage0Engine:
         e1, e2 = model.encoder, model.encoder_color
         return (bool(getattr(opt, "fused_mlp", False)) and bool(opt.fp16) and not opt.sdf and getattr(opt, "ind_dim", 0) == 0
                 and _affine(float(model.bound)) is not None and same_geometry(e1, e2) and e1.embeddings.shape[1] == 1
-                and e2.embeddings.shape[1] == 2 and not getattr(opt, "progressive_level", False) and opt.lambda_entropy <= 0
+                and e2.embeddings.shape[1] == 2 and not getattr(opt, "progressive_level", False)
                 and opt.patch_size == 1 and model.max_level >= e1.num_levels)
 
     @property
@@ -173,7 +176,7 @@ class Stage0Engine:
     def mark_untrained(self):
         if self.opt.mark_untrained:
             f = synthetic.LEGO_FOCAL
-            self.model.mark_untrained_grid(self.poses, (f, f, synthetic.LEGO_HW / 2, synthetic.LEGO_HW / 2))
+            self.model.mark_untrained_grid(self.poses, (f, f, synthetic.LEGO_HW / 2, synthetic.LEGO_HW / 2), cam_near_far=self.cam_near_far)
 
     # ------------------------------------------------------------------------------------------------------ buffers
     def _ray_bufs(self, N):
@@ -234,7 +237,7 @@ class Stage0Engine:
         self._aabb = model.aabb_train
         b.bg = b.bg_buf if opt.background != "white" else None
         synthetic.batch_from_uniforms(self.poses, self.images, b.u, self._aabb, model.min_near,
-                                      out=(b.o, b.d, b.rgba, b.nears, b.fars, b.noises, b.bg), counter=b.counter)
+                                      out=(b.o, b.d, b.rgba, b.nears, b.fars, b.noises, b.bg), counter=b.counter, cam_near_far=self.cam_near_far)
         bits = model.density_bitfield
         b.args = (_p(b.o), _p(b.d), _p(bits), float(model.real_bound), int(bool(opt.contract)), float(opt.dt_gamma), int(opt.max_steps), N,
                   int(model.cascade), int(model.grid_size), _p(b.nears), _p(b.fars))
@@ -519,8 +522,9 @@ class Stage0Engine:
         seed = o.scale if self.world == 1 else o.scale / self.world
         early = None
         d_sigma, d_rgb = w["d_sr"][:max(M, 1)], w["d_sr"][max(M, 1):4 * max(M, 1)]
-        L.call("n2m_composite_loss_train", _p(w["sigma"]), _p(w["rgb"]), _p(ts), _p(b.rays), M, N, 1e-4, _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask,
-               _p(seed), None, None, _p(d_sigma), _p(d_rgb), _p(w["partial"]), None, None, None, s)      # loss value: summed by the scaler kernel
+        # (+ the entropy regulariser of config 4, nerf/utils.py:728-733: its per-sample gradient is the backward's grad_weights)
+        L.call("n2m_composite_loss_train_ent", _p(w["sigma"]), _p(w["rgb"]), _p(ts), _p(b.rays), M, N, 1e-4, _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask,
+               _p(seed), None, None, _p(d_sigma), _p(d_rgb), _p(w["partial"]), None, None, None, float(max(opt.lambda_entropy, 0.0)), s)      # loss value: summed by the scaler kernel
         if M > 0:
             if self.marker_at == 2:
                 self._marker = torch.cuda.Event(); self._marker.record()

@@ -15,6 +15,8 @@ _DEFAULTS = dict(
     ssaa=2, texture_size=4096, refine=False, gui=False,
     cos_anneal_ratio=1.0, normal_anneal_epsilon=1e-4,
     fused_mlp=False,     # opt-in: fused MFMA field kernels (nerf2mesh_amd/fused.py) instead of nn.Linear calls
+    enable_cam_near_far=False,     # main.py:40 (colmap mode): clamp every ray to its camera's sparse-point depth range
+    scene="lego",        # not a reference option: which synthetic stand-in the drivers render (nerf2mesh_amd/synthetic.py: "lego" | "garden")
 )
 
 

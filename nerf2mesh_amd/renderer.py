@@ -10,6 +10,8 @@ Buffer names/shapes follow the reference (`density_grid [cascade, H^3]`, `densit
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -47,6 +49,10 @@ def erode_cross(a):
     b[1:] &= a[:-1]; b[:-1] &= a[1:]; b[:, 1:] &= a[:, :-1]; b[:, :-1] &= a[:, 1:]
     b[0] = False; b[-1] = False; b[:, 0] = False; b[:, -1] = False
     return b
+
+
+# A/B switch: the reference's host-paced inference loop (one read of n_alive per round) instead of the device-count loop
+_HOST_INFER_LOOP = os.environ.get("N2M_INFER_HOST_LOOP", "0") == "1"
 
 
 class NeRFRenderer(nn.Module):
@@ -104,12 +110,17 @@ class NeRFRenderer(nn.Module):
 
     # ------------------------------------------------------------------------------------------ stage 0
     @torch.no_grad()
-    def march_ahead(self, rays_o, rays_d, dt_gamma=0, perturb=True, max_steps=1024, cam_near_far=None, expect_points=0, noises=None):
+    def march_ahead(self, rays_o, rays_d, dt_gamma=0, perturb=True, max_steps=1024, cam_near_far=None, expect_points=0, noises=None,
+                    nears_fars=None):
         """Enqueue near/far + march pass 1 for a FUTURE training batch (they read only the occupancy bit field) and return a
-        ticket for render(..., ticket=...).  Lets the training loop keep the GPU queue full across the sample-count read-back."""
+        ticket for render(..., ticket=...).  Lets the training loop keep the GPU queue full across the sample-count read-back.
+        nears_fars: (nears, fars) the batch kernel already derived (aabb slab test + the per-view cam_near_far clamp)."""
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
+        if nears_fars is not None:
+            nears, fars = nears_fars
+        else:
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
         if cam_near_far is not None:
             nears = torch.maximum(nears, cam_near_far[:, 0])
             fars = torch.minimum(fars, cam_near_far[:, 1])
@@ -171,33 +182,99 @@ class NeRFRenderer(nn.Module):
             weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
             depth = torch.zeros(N, dtype=torch.float32, device=device)
             image = torch.zeros(N, 3, dtype=torch.float32, device=device)
-            rays_alive = torch.arange(N, dtype=torch.int32, device=device)
-            rays_t = nears.clone()
-            step = 0
-            while step < max_steps:
-                n_alive = rays_alive.shape[0]
-                if n_alive <= 0:
-                    break
-                n_step = max(min(N // n_alive, 8), 1)
-                xyzs, dirs, ts = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.real_bound,
-                                                        self.opt.contract, self.density_bitfield, self.cascade, self.grid_size, nears,
-                                                        fars, perturb if step == 0 else False, dt_gamma, max_steps)
-                dirs = safe_normalize(dirs)
-                with amp:
-                    sigmas, rgbs, speculars = self(xyzs, dirs, ind_code, shading)
-                if self.opt.sdf:
-                    true_cos = -F.relu(-(dirs * safe_normalize(self.normal(xyzs))).sum(-1))
-                    sigmas = self._sdf_to_alpha(sigmas, true_cos, ts[:, 1])
-                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, ts, weights_sum, depth, image, T_thresh,
-                                           self.opt.sdf)
-                rays_alive = raymarching.compact_alive(rays_alive)
-                step += n_step
+            if device.type == "cuda" and not _HOST_INFER_LOOP and N > 0:
+                self._infer_loop_device(rays_o, rays_d, nears, fars, ind_code, shading, dt_gamma, max_steps, T_thresh, perturb, amp,
+                                        weights_sum, depth, image)
+            else:
+                self._infer_loop_host(rays_o, rays_d, nears, fars, ind_code, shading, dt_gamma, max_steps, T_thresh, perturb, amp,
+                                      weights_sum, depth, image)
 
         if blend_bg:       # blend_bg=False: the caller folds the blend into its loss kernel (losses.photo_loss)
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         results["depth"] = depth.view(*prefix)
         results["image"] = image.view(*prefix, 3)
         return results
+
+    def _infer_shade(self, xyzs, dirs, ts, ind_code, shading, amp):
+        """Field evaluation of one inference round (nerf/renderer.py:779-794): (sigmas | alphas, rgbs)."""
+        dirs = safe_normalize(dirs)
+        with amp:
+            sigmas, rgbs, _ = self(xyzs, dirs, ind_code, shading)
+        if self.opt.sdf:
+            true_cos = -F.relu(-(dirs * safe_normalize(self.normal(xyzs))).sum(-1))
+            sigmas = self._sdf_to_alpha(sigmas, true_cos, ts[:, 1])
+        return sigmas, rgbs
+
+    def _infer_loop_host(self, rays_o, rays_d, nears, fars, ind_code, shading, dt_gamma, max_steps, T_thresh, perturb, amp,
+                         weights_sum, depth, image):
+        """The reference's loop as it is written (nerf/renderer.py:764-802): one host read of n_alive per round."""
+        N, device = rays_o.shape[0], rays_o.device
+        rays_alive = torch.arange(N, dtype=torch.int32, device=device)
+        rays_t = nears.clone()
+        step = 0
+        while step < max_steps:
+            n_alive = rays_alive.shape[0]
+            if n_alive <= 0:
+                break
+            n_step = max(min(N // n_alive, 8), 1)
+            xyzs, dirs, ts = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.real_bound,
+                                                    self.opt.contract, self.density_bitfield, self.cascade, self.grid_size, nears,
+                                                    fars, perturb if step == 0 else False, dt_gamma, max_steps)
+            sigmas, rgbs = self._infer_shade(xyzs, dirs, ts, ind_code, shading, amp)
+            raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, ts, weights_sum, depth, image, T_thresh,
+                                       self.opt.sdf)
+            rays_alive = raymarching.compact_alive(rays_alive)
+            step += n_step
+
+    def _infer_loop_device(self, rays_o, rays_d, nears, fars, ind_code, shading, dt_gamma, max_steps, T_thresh, perturb, amp,
+                           weights_sum, depth, image, run_ahead=3):
+        """The same loop with the ray count on the device (n2m_*_dev, include/n2m_hip.h): the kernels of a round read {n_alive, step} from
+        device memory and derive n_step like the host code above; the host sizes launches from an upper bound of n_alive that reaches it
+        through asynchronous copies `run_ahead` rounds late, so no round waits for a read-back (the reference -- and _infer_loop_host --
+        drain the queue up to 1024 times per image).  Same per-ray arithmetic: the image is bit-identical as long as the field's per-sample
+        results do not depend on the batch size (true of the fused field kernels; BLAS GEMMs may pick another kernel for another M)."""
+        from . import _lib as L
+        p = L.ptr
+        N, device = rays_o.shape[0], rays_o.device
+        i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=device)
+        alive = [torch.arange(N, dtype=torch.int32, device=device), i32(N)]
+        state = [torch.tensor([N, 0], dtype=torch.int32, device=device), i32(2)]
+        rays_t = nears.clone()
+        xyzs, dirs = torch.zeros(N, 3, device=device), torch.zeros(N, 3, device=device)
+        ts = torch.zeros(N, 2, device=device)
+        bits = self.density_bitfield.contiguous()
+        noises = torch.rand(N, dtype=torch.float32, device=device) if perturb else None      # first round only (:777)
+        host = [torch.empty(2, dtype=torch.int32, pin_memory=True) for _ in range(run_ahead + 1)]
+        events = [torch.cuda.Event() for _ in range(run_ahead + 1)]
+        pending = []                      # rounds whose next-state copy is in flight: (slot, round index)
+        ub, done, rnd = N, False, 0
+        while not done:
+            # every count that has arrived tightens the bound (and tells when the loop is over); at most run_ahead rounds in flight
+            while pending and (len(pending) > run_ahead or events[pending[0]].query()):
+                slot = pending.pop(0)
+                events[slot].synchronize()
+                ub = min(ub, int(host[slot][0]))
+                if ub <= 0 or int(host[slot][1]) >= max_steps:
+                    done = True
+            if done:
+                break
+            cur, nxt = rnd & 1, (rnd & 1) ^ 1
+            s = L.stream()
+            m = max(1, min(N, ub * 8))                    # rows any round of <= ub rays can fill: n_alive * n_step <= min(N, 8 n_alive)
+            L.call("n2m_march_rays_dev", p(state[cur]), ub, N, p(alive[cur]), p(rays_t), p(rays_o), p(rays_d), float(self.real_bound),
+                   int(bool(self.opt.contract)), float(dt_gamma), int(max_steps), int(self.cascade), int(self.grid_size), p(bits), p(fars),
+                   p(xyzs), p(dirs), p(ts), p(noises) if rnd == 0 else None, s)
+            sigmas, rgbs = self._infer_shade(xyzs[:m], dirs[:m], ts[:m], ind_code, shading, amp)
+            sigmas, rgbs = sigmas.float().contiguous(), rgbs.float().contiguous()
+            L.call("n2m_composite_rays_dev", p(state[cur]), ub, N, int(max_steps), float(T_thresh), int(bool(self.opt.sdf)), p(alive[cur]),
+                   p(rays_t), p(sigmas), p(rgbs), p(ts), p(weights_sum), p(depth), p(image), s)
+            L.call("n2m_compact_alive_dev", p(alive[cur]), p(state[cur]), ub, N, int(max_steps), p(alive[nxt]), p(state[nxt]), s)
+            slot = rnd % (run_ahead + 1)
+            host[slot].copy_(state[nxt], non_blocking=True)
+            events[slot].record()
+            pending.append(slot)
+            rnd += 1
+        self.last_infer_rounds = rnd
 
     def _sdf_to_alpha(self, sdf, cos, dt):
         """NeuS-style alpha from sdf samples (nerf/renderer.py:724-739)."""

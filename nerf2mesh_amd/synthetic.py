@@ -35,8 +35,57 @@ _BOXES = [
 ]
 
 
-def boxes(device="cpu"):
-    return torch.tensor(_BOXES, dtype=torch.float32, device=device)
+# "garden": the same object on a lawn inside a hedged yard that reaches |x| = 8 -- a stand-in for an unbounded mip-NeRF-360 capture
+# (BASELINE config 4: --bound 16, 5 cascades): content in cascades 0..3, a sparse-point AABB much tighter than the bound, per-camera depth
+# ranges (colmap_provider.py:223,270).  Same cameras as the lego stand-in (they circle the centre piece like the garden's table).
+_GARDEN_EXTRA = [
+    (-8.00, -8.00, -0.62, 8.00, 8.00, -0.45, 0.30, 0.46, 0.20),   # lawn (its top carries the base plate)
+    (-7.60, -7.60, -0.45, -6.80, 7.60, 1.20, 0.16, 0.36, 0.14),   # hedge west
+    (6.80, -7.60, -0.45, 7.60, 7.60, 1.00, 0.18, 0.38, 0.15),     # hedge east
+    (-6.80, 6.80, -0.45, 6.80, 7.60, 1.40, 0.15, 0.34, 0.13),     # hedge north
+    (-6.80, -7.60, -0.45, 6.80, -6.80, 0.90, 0.17, 0.37, 0.16),   # hedge south
+    (-1.30, -1.10, -0.45, 1.30, 1.10, -0.42, 0.62, 0.48, 0.32),   # table top under the object
+    (2.60, 1.70, -0.45, 3.10, 2.20, 1.80, 0.36, 0.25, 0.15),      # tree trunk
+    (1.90, 1.00, 1.80, 3.80, 2.90, 3.20, 0.20, 0.42, 0.18),       # crown
+    (-3.90, -2.40, -0.45, -3.10, -1.60, 0.35, 0.55, 0.52, 0.50),  # planter
+    (-2.20, 3.40, -0.45, -0.60, 4.10, 0.05, 0.45, 0.30, 0.20),    # bench
+    (4.40, -3.60, -0.45, 5.20, -2.80, 0.60, 0.58, 0.56, 0.52),    # stone
+]
+SCENES = {"lego": _BOXES, "garden": _BOXES + _GARDEN_EXTRA}
+
+
+def boxes(device="cpu", scene="lego"):
+    return torch.tensor(SCENES[scene], dtype=torch.float32, device=device)
+
+
+def scene_points(scene="lego", per_edge=5):
+    """A sparse point cloud of the scene (box surface lattice points) -- the stand-in for colmap's points3D."""
+    bx = boxes("cpu", scene)
+    lin = torch.linspace(0, 1, per_edge)
+    a, b, c = torch.meshgrid(lin, lin, lin, indexing="ij")
+    t = torch.stack([a.reshape(-1), b.reshape(-1), c.reshape(-1)], -1)
+    t = t[((t == 0) | (t == 1)).any(-1)]                                           # surface lattice only
+    return (bx[:, None, 0:3] + t[None] * (bx[:, None, 3:6] - bx[:, None, 0:3])).reshape(-1, 3)
+
+
+def pts_aabb(scene="lego"):
+    """[6] min / max of the sparse points (colmap_provider.py:223), what main.py:234-235 hands to update_aabb."""
+    p = scene_points(scene)
+    return torch.cat([p.min(0).values, p.max(0).values])
+
+
+def cam_near_far(poses, scene="lego", H=LEGO_HW, W=LEGO_HW, focal=LEGO_FOCAL):
+    """[V,2] per-camera (min, max) depth of the sparse points the camera observes, depth = (P[:3,3] - pts) @ P[:3,2]
+    (colmap_provider.py:243-270: the points with a key point inside the image; here: the lattice points that project into the frame)."""
+    p = scene_points(scene, per_edge=9).to(poses.device)
+    rel = p[None] - poses[:, None, :3, 3]                                          # [V, P, 3]
+    xc, yc = (rel * poses[:, None, :3, 0]).sum(-1), (rel * poses[:, None, :3, 1]).sum(-1)
+    depth = -(rel * poses[:, None, :3, 2]).sum(-1)
+    front = (depth > 0) & (xc.abs() <= 0.5 * W / focal * depth) & (yc.abs() <= 0.5 * H / focal * depth)
+    big = torch.finfo(torch.float32).max
+    near = torch.where(front, depth, torch.full_like(depth, big)).min(1).values
+    far = torch.where(front, depth, torch.zeros_like(depth)).max(1).values
+    return torch.stack([near, far], 1).float().contiguous()
 
 
 def make_cameras(n=100, radius=LEGO_RADIUS, seed=0, device="cpu"):
@@ -141,7 +190,7 @@ def random_batch(poses, images, N, generator=None, H=LEGO_HW, W=LEGO_HW, focal=L
     return o, d, images[cam, pix]
 
 
-def batch_from_uniforms(poses, images, u, aabb, min_near, H=LEGO_HW, W=LEGO_HW, focal=LEGO_FOCAL, out=None, counter=None):
+def batch_from_uniforms(poses, images, u, aabb, min_near, H=LEGO_HW, W=LEGO_HW, focal=LEGO_FOCAL, out=None, counter=None, cam_near_far=None):
     """A training batch from ONE tensor of uniforms u [N,6] in [0,1): view = floor(u0 V), pixel = floor(u1 H W) (N random pixels over
     random views: random_image_batch, nerf/provider.py:302-303 + nerf/utils.py:271), rays and ground truth like random_batch, near/far
     of the aabb, march jitter = u2, random background = u3..u5 (nerf/utils.py:649-652).  Returns (rays_o, rays_d, rgba, nears, fars,
@@ -156,8 +205,9 @@ def batch_from_uniforms(poses, images, u, aabb, min_near, H=LEGO_HW, W=LEGO_HW, 
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
             out = (f(N, 3), f(N, 3), f(N, 4), f(N), f(N), f(N), f(N, 3))
         o, d, rgba, nears, fars, noises, bg = out
-        L.call("n2m_batch_rays", L.ptr(poses), L.ptr(u), V, N, H, W, float(focal), float(focal), W / 2, H / 2, L.ptr(images), L.ptr(aabb),
-               float(min_near), L.ptr(o), L.ptr(d), L.ptr(rgba), L.ptr(nears), L.ptr(fars), L.ptr(noises), L.ptr(bg), L.ptr(counter), L.stream())
+        L.call("n2m_batch_rays_cnf", L.ptr(poses), L.ptr(u), V, N, H, W, float(focal), float(focal), W / 2, H / 2, L.ptr(images), L.ptr(aabb),
+               float(min_near), L.ptr(o), L.ptr(d), L.ptr(rgba), L.ptr(nears), L.ptr(fars), L.ptr(noises), L.ptr(bg), L.ptr(counter),
+               L.ptr(cam_near_far), L.stream())
         return o, d, rgba, nears, fars, noises, bg
     cam = (u[:, 0] * V).long().clamp(max=V - 1)
     pix = (u[:, 1] * (H * W)).long().clamp(max=H * W - 1)
@@ -169,6 +219,9 @@ def batch_from_uniforms(poses, images, u, aabb, min_near, H=LEGO_HW, W=LEGO_HW, 
     big = torch.finfo(torch.float32).max
     nears = torch.where(miss, torch.full_like(tn, big), tn.clamp(min=min_near))
     fars = torch.where(miss, torch.full_like(tf, big), tf)
+    if cam_near_far is not None:                       # nerf/renderer.py:689-691 with the per-ray pairs of colmap_provider.py:563-565
+        nears = torch.maximum(nears, cam_near_far[cam, 0])
+        fars = torch.minimum(fars, cam_near_far[cam, 1])
     return o, d, images[cam, pix], nears, fars, u[:, 2].contiguous(), u[:, 3:6].contiguous()
 
 

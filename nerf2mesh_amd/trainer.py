@@ -61,7 +61,10 @@ class Stage0Trainer:
             self.optimizer, lambda it: 0.01 + 0.99 * (it / 500) if it <= 500 else 0.1 ** ((it - 500) / (iters - 500)))   # main.py:239
         self.scaler = torch.amp.GradScaler("cuda", enabled=bool(opt.fp16) and device.type == "cuda")
         self.sync = GradSync(model, world_size) if world_size > 1 else None
-        self.boxes = synthetic.boxes(device)
+        self.scene = getattr(opt, "scene", "lego")
+        self.boxes = synthetic.boxes(device, self.scene)
+        # --enable_cam_near_far (main.py:40): every ray is clamped to its camera's sparse-point depth range (nerf/renderer.py:689-691)
+        self.cam_near_far = synthetic.cam_near_far(self.poses, self.scene) if getattr(opt, "enable_cam_near_far", False) else None
         self._loss_sum = torch.zeros((), device=device)
         self._loss_pending = []
         self.samples_seen = 0
@@ -88,7 +91,7 @@ class Stage0Trainer:
     def mark_untrained(self):
         if self.opt.mark_untrained:
             f = synthetic.LEGO_FOCAL
-            self.model.mark_untrained_grid(self.poses, (f, f, synthetic.LEGO_HW / 2, synthetic.LEGO_HW / 2))
+            self.model.mark_untrained_grid(self.poses, (f, f, synthetic.LEGO_HW / 2, synthetic.LEGO_HW / 2), cam_near_far=self.cam_near_far)
 
     def batch(self):
         """(rays_o, rays_d, rgba, noises, bg) of the next batch: ONE draw of [num_rays, 6] uniforms from the ray generator, turned into
@@ -96,7 +99,9 @@ class Stage0Trainer:
         if self.images is None:
             self.images = synthetic.preload_images(self.poses, self.boxes)     # nerf/provider.py:224-233 (`preload`)
         u = torch.rand(self.num_rays, 6, device=self.device, generator=self.gen)
-        rays_o, rays_d, rgba, _, _, noises, bg = synthetic.batch_from_uniforms(self.poses, self.images, u, self.model.aabb_train, self.model.min_near)
+        rays_o, rays_d, rgba, nears, fars, noises, bg = synthetic.batch_from_uniforms(self.poses, self.images, u, self.model.aabb_train,
+                                                                                      self.model.min_near, cam_near_far=self.cam_near_far)
+        self._nears_fars = (nears, fars) if self.cam_near_far is not None else None
         return rays_o, rays_d, rgba, noises, bg
 
     def _prepare(self):
@@ -111,7 +116,7 @@ class Stage0Trainer:
         # opt.num_points, nerf/utils.py:796-797); a batch that still does not fit is re-marched exactly by finish()
         expect = 0 if self.last_num_points <= 0 else ((int(1.25 * max(self.last_num_points, 1024)) + 1023) // 1024) * 1024
         ticket = model.march_ahead(rays_o, rays_d, dt_gamma=opt.dt_gamma, perturb=True, max_steps=opt.max_steps,
-                                   expect_points=expect, noises=noises) if self.pipeline else None
+                                   expect_points=expect, noises=noises, nears_fars=self._nears_fars) if self.pipeline else None
         return rays_o, rays_d, images, ticket, (bg if opt.background != "white" else 1), noises
 
     def _prepare_overlapped(self):
@@ -298,8 +303,9 @@ class Stage0Trainer:
         rays_o, rays_d = synthetic.rays_from_pixels(self.poses, torch.full_like(pix, cam), pix)
         rgba = synthetic.render_gt(rays_o, rays_d, self.boxes)
         gt = rgba[:, :3] * rgba[:, 3:] + (1 - rgba[:, 3:])
+        cnf = getattr(self, "cam_near_far", None)
         out = self.model.render(rays_o, rays_d, bg_color=1, perturb=False, shading="full", dt_gamma=self.opt.dt_gamma,
-                                max_steps=self.opt.max_steps, T_thresh=1e-4)
+                                max_steps=self.opt.max_steps, T_thresh=1e-4, cam_near_far=None if cnf is None else cnf[cam:cam + 1])
         mse = F.mse_loss(out["image"], gt)
         return float(-10 * torch.log10(mse))
 

@@ -26,7 +26,12 @@ CROP = 64
 LEVEL0_ROWS = 4920          # (16+1)^3 = 4913 rounded up to a multiple of 8 (gridencoder/grid.py:127-133)
 
 
-def make_state(sdf, rows=6119864, seed=1234):
+# BASELINE config 4's shape (scripts/runall_360_outdoor.sh:2: --bound 16 --enable_cam_near_far --lambda_entropy 1e-3, dt_gamma 1/256 default):
+# 5 cascades, 6 837 544 table rows, a colmap-style AABB tighter than the bound, per-camera near/far, entropy loss, inner/outer TV
+GARDEN = dict(bound=16.0, rows=6837544, aabb=[-6.0, -5.0, -4.0, 7.0, 6.0, 5.0], dt_gamma=1.0 / 256, lambda_entropy=1e-3, lambda_tv=1e-3)
+
+
+def make_state(sdf, rows=6119864, seed=1234, garden=False):
     """Deterministic parameters (reference key names).  The density head is shaped by hand so that the occupancy grid is
     sparse like a trained scene: level 0 of the density table is the constant 1 (a bias the bias-free MLP lacks), six hidden units
     carry relu(+-x_i), so the head sees |x|+|y|+|z|; all remaining weights and table rows are random."""
@@ -50,6 +55,9 @@ def make_state(sdf, rows=6119864, seed=1234):
     if sdf:
         w1[0, :6] = 1.0
         w1[0, 6] = -0.4                              # sdf ~ |x|_1 - 0.4 + noise
+    elif garden:
+        w1[0, :6] = -1.2
+        w1[0, 6] = 4.0                               # log sigma ~ 4 - 1.2 |x|_1 + noise: occupied out to |x|_1 ~ 4, i.e. cascades 0..2
     else:
         w1[0, :6] = -12.0
         w1[0, 6] = 6.0                               # log sigma ~ 6 - 12 |x|_1 + noise
@@ -68,6 +76,12 @@ def cameras():
     poses = S.make_cameras(N_CAMS, seed=0)
     intr = np.array([S.LEGO_FOCAL, S.LEGO_FOCAL, S.LEGO_HW / 2, S.LEGO_HW / 2], dtype=np.float32)
     return poses, intr
+
+
+def cam_near_far():
+    """[N_CAMS, 2] per-camera (near, far) as colmap_provider.py:270 derives them from the sparse points (seeded stand-in)."""
+    g = torch.Generator().manual_seed(31)
+    return torch.stack([1.2 + 0.6 * torch.rand(N_CAMS, generator=g), 4.5 + 1.5 * torch.rand(N_CAMS, generator=g)], dim=1)
 
 
 def _morton_of_meshgrid(H):
@@ -107,14 +121,23 @@ def loss_weights(n):
     return torch.rand(n, 3, generator=g), torch.rand(n, generator=g), torch.rand(n, generator=g)
 
 
-def run_case(model, mark_untrained, jitter_order, device, sdf=False, bitfield_override=None, ctx=contextlib.nullcontext):
-    """The scripted iteration.  `mark_untrained(model, poses, intrinsics)` adapts the two signatures of mark_untrained_grid.
-    Returns a dict of numpy arrays (what the fixtures hold)."""
+def run_case(model, mark_untrained, jitter_order, device, sdf=False, bitfield_override=None, ctx=contextlib.nullcontext, garden=False):
+    """The scripted iteration.  `mark_untrained(model, poses, intrinsics[, cam_near_far])` adapts the two signatures of
+    mark_untrained_grid.  garden=True adds what BASELINE config 4 adds to the iteration: update_aabb (main.py:234-235), the per-ray
+    cam_near_far clamp (nerf/renderer.py:689-691), dt_gamma 1/256, the entropy loss on weights / weights_sum (nerf/utils.py:728-733: the
+    only source of `grad_weights` in composite_rays_train's backward) and the inner / outer TV split of post_train_step
+    (nerf/utils.py:812-821).  Returns a dict of numpy arrays (what the fixtures hold)."""
     out = {}
     poses, intr = cameras()
     model.train()
+    dt_gamma = GARDEN["dt_gamma"] if garden else 0
     with ctx():
-        mark_untrained(model, poses, intr)
+        if garden:
+            model.update_aabb(np.asarray(GARDEN["aabb"], dtype=np.float32))
+            out["aabb_train"] = model.aabb_train.detach().cpu().numpy().copy()
+            mark_untrained(model, poses, intr, cam_near_far().to(device))
+        else:
+            mark_untrained(model, poses, intr)
         out["untrained"] = np.packbits((model.density_grid.detach() < 0).cpu().numpy().reshape(-1))
         for k, seed in enumerate((100, 101)):
             with seeded_jitter(seed, jitter_order):
@@ -127,7 +150,12 @@ def run_case(model, mark_untrained, jitter_order, device, sdf=False, bitfield_ov
 
         o, d = S.crop_rays(poses, cam=0, size=CROP)
         o, d = o.to(device), d.to(device)
-        res = model.render(o, d, dt_gamma=0, bg_color=1, perturb=False, max_steps=1024, shading="full")
+        extra = {}
+        if garden:      # per-ray [N, 2] as random_image_batch hands them out (colmap_provider.py:563-565); a seeded spread around camera 0's pair
+            g = torch.Generator().manual_seed(32)
+            cnf = cam_near_far()[0].unsqueeze(0) + (torch.rand(o.shape[0], 2, generator=g) - 0.5) * torch.tensor([0.4, 1.0])
+            extra["cam_near_far"] = cnf.to(device).contiguous()
+        res = model.render(o, d, dt_gamma=dt_gamma, bg_color=1, perturb=False, max_steps=1024, shading="full", **extra)
         out["num_points"] = np.int64(res["num_points"])
         out["image"] = res["image"].detach().cpu().numpy()
         out["depth"] = res["depth"].detach().cpu().numpy()
@@ -135,6 +163,13 @@ def run_case(model, mark_untrained, jitter_order, device, sdf=False, bitfield_ov
         out["xyzs_head"] = res["xyzs"][:4096].detach().cpu().numpy()
         wi, ww, wd = (t.to(device) for t in loss_weights(o.shape[0]))
         loss = (res["image"] * wi).sum() + (res["weights_sum"] * ww).sum() + (res["depth"] * wd).sum()
+        if garden:      # nerf/utils.py:728-733, weighted up so that grad_weights is a visible share of the sample gradients
+            w = res["weights"].clamp(1e-5, 1 - 1e-5)
+            w2 = res["weights_sum"].clamp(1e-5, 1 - 1e-5)
+            ent = lambda p: (-p * torch.log2(p) - (1 - p) * torch.log2(1 - p)).mean()
+            out["entropy"] = np.float32((ent(w) + ent(w2)).item())
+            out["weights_head"] = res["weights"][:4096].detach().cpu().numpy()
+            loss = loss + (GARDEN["lambda_entropy"] * 1e3 * o.shape[0]) * (ent(w) + ent(w2))
         if sdf:
             out["normal_head"] = res["normal"][:4096].detach().cpu().numpy()
             loss = loss + 0.1 * ((res["normal"].norm(dim=-1) - 1) ** 2).mean() * o.shape[0]     # eikonal term, nerf/utils.py:740-743
@@ -142,6 +177,12 @@ def run_case(model, mark_untrained, jitter_order, device, sdf=False, bitfield_ov
             p.grad = None
         loss.backward()
         out["loss"] = np.float32(loss.item())
+        if garden:      # post_train_step, nerf/utils.py:812-821: in-place TV on the density table's gradient, outer samples ten-fold
+            xyzs = res["xyzs"].detach()
+            inner = xyzs.abs().amax(dim=-1) <= 1
+            out["tv_inner"] = np.int64(int(inner.sum()))
+            model.encoder.grad_total_variation(GARDEN["lambda_tv"], xyzs[inner].contiguous(), model.bound)
+            model.encoder.grad_total_variation(GARDEN["lambda_tv"] * 10, xyzs[~inner].contiguous(), model.bound)
         for name, p in model.named_parameters():
             if p.grad is None:
                 continue
@@ -156,24 +197,27 @@ def run_case(model, mark_untrained, jitter_order, device, sdf=False, bitfield_ov
 
         model.eval()
         with torch.no_grad():
-            res = model.render(o, d, dt_gamma=0, bg_color=1, perturb=False, max_steps=1024, shading="full")
+            res = model.render(o, d, dt_gamma=dt_gamma, bg_color=1, perturb=False, max_steps=1024, shading="full", **extra)
         out["eval_image"] = res["image"].detach().cpu().numpy()
         out["eval_depth"] = res["depth"].detach().cpu().numpy()
         model.train()
     return out
 
 
-def compress_for_fixture(out):
-    """What is committed: everything except the full density grid (8 MB) -- a strided subsample of it instead."""
+def compress_for_fixture(out, stride=32):
+    """What is committed: everything except the full density grid (8 MB; 40 MB with 5 cascades) -- a strided subsample of it instead."""
     fx = dict(out)
     grid = fx.pop("density_grid")
-    fx["density_grid_stride"] = np.int64(32)
-    fx["density_grid_sub"] = grid.reshape(-1)[::32].copy()
+    fx["density_grid_stride"] = np.int64(stride)
+    fx["density_grid_sub"] = grid.reshape(-1)[::stride].copy()
     fx["density_grid_sum"] = np.float64(np.clip(grid, 0, None).astype(np.float64).sum())
     fx["density_grid_neg"] = np.int64((grid < 0).sum())
     return fx
 
 
-def dataset_stub(poses, intr):
-    """The two attributes mark_untrained_grid reads from the reference's dataset object (nerf/renderer.py:989-990)."""
-    return types.SimpleNamespace(poses=poses, intrinsics=intr)
+def dataset_stub(poses, intr, cam_near_far=None):
+    """The attributes mark_untrained_grid reads from the reference's dataset object (nerf/renderer.py:989-991)."""
+    ns = types.SimpleNamespace(poses=poses, intrinsics=intr)
+    if cam_near_far is not None:
+        ns.cam_near_far = cam_near_far
+    return ns

@@ -11,9 +11,14 @@ def _run(cls, steps, **over):
     from nerf2mesh_amd.network import NeRFNetwork
     from nerf2mesh_amd.options import make_options
     torch.manual_seed(0)
-    opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=True, **over)
+    kw = dict(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=True)
+    kw.update(over)
+    opt = make_options(**kw)
     dev = torch.device("cuda", 0)
-    tr = cls(NeRFNetwork(opt), opt, synthetic.make_cameras(6, seed=0), dev, seed=0)
+    model = NeRFNetwork(opt)
+    if opt.scene == "garden":
+        model.update_aabb(synthetic.pts_aabb("garden"))          # main.py:234-235
+    tr = cls(model, opt, synthetic.make_cameras(6, seed=0), dev, seed=0)
     tr.mark_untrained()
     losses = [float(tr.train_step()) for _ in range(steps)]
     torch.cuda.synchronize()
@@ -46,6 +51,34 @@ def test_engine_reproduces_the_autograd_trainer():
     assert torch.equal(sa.scale, sb.scale) and torch.equal(sa.steps, sb.steps)
     for g, h in zip(sa.param_groups, sb.param_groups):
         assert abs(g["lr"] - h["lr"]) <= 1e-12 * max(g["lr"], 1e-30)
+
+
+@pytest.mark.gpu
+def test_engine_runs_the_outdoor_recipe_like_the_trainer():
+    """BASELINE config 4 as the reference runs it (scripts/runall_360_outdoor.sh:2): --bound 16 (5 cascades, dt_gamma 1/256, inner/outer TV)
+    --enable_cam_near_far --lambda_entropy 1e-3, update_aabb from the sparse points.  The executor (entropy term and its grad_weights inside
+    the fused compositing kernel, per-view near/far clamp inside the batch kernel) against the autograd trainer (torch statement of the
+    entropy loss through composite_rays_train's backward, clamp from the same batch function)."""
+    from nerf2mesh_amd.engine import Stage0Engine
+    from nerf2mesh_amd.trainer import Stage0Trainer
+    cfg = dict(bound=16, dt_gamma=1 / 256, lambda_entropy=1e-3, enable_cam_near_far=True, scene="garden", diffuse_step=12)
+    steps = 24
+    a, la = _run(Stage0Trainer, steps, **cfg)
+    b, lb = _run(Stage0Engine, steps, **cfg)
+    assert a.model.cascade == 5 and a.cam_near_far is not None
+    assert a.samples_seen == b.samples_seen and a.rays_seen == b.rays_seen, "same batches, same sample counts"
+    np.testing.assert_allclose(la, lb, rtol=3e-4, atol=1e-7)
+    a2, _ = _run(Stage0Trainer, steps, **cfg)
+
+    def rel(p, q):
+        return ((p - q).norm() / p.norm().clamp_min(1e-30)).item()
+    for (n, p), (_, q), (_, r) in zip(a.model.named_parameters(), b.model.named_parameters(), a2.model.named_parameters()):
+        d_te, d_tt = rel(p, q), rel(p, r)
+        print(f"{n:36s} trainer-vs-engine {d_te:.3g}   trainer-vs-trainer {d_tt:.3g}")
+        assert d_te <= 10 * d_tt + 2e-4, f"{n}: executor differs from the trainer by {d_te:.3g}, two trainer runs differ by {d_tt:.3g}"
+    # the entropy term is really there: with lambda_entropy = 0 the same batches give a different loss
+    c, lc = _run(Stage0Engine, 4, **dict(cfg, lambda_entropy=0))
+    assert abs(lc[0] - lb[0]) > 1e-5 * abs(lb[0])
 
 
 @pytest.mark.gpu

@@ -37,6 +37,8 @@ TOL = {
     # SDF: normals are central differences with eps = 1e-4 (nerf/network.py:143-154): a 1e-7 difference of two densities is
     # amplified 5000x, and the alpha derived from them feeds every output; grid density = sigmoid(-sdf * s) * s with s = e^5 = 148
     "sdf": dict(grid=2e-3, image=5e-5, depth=1e-4, grad=2e-2, normal=1e-3, flips=4),      # measured: 3.6e-4, 2.4e-6, 3.8e-6, 3.4e-3, 3.5e-5, 0
+    # config 4's shape: 5 cascades (5 x the cells), ~290 samples per ray (composite sums four times as long), dt grows with t
+    "garden": dict(grid=2e-4, image=3e-5, depth=2e-4, grad=5e-4, normal=None, flips=10),
 }
 
 
@@ -72,6 +74,11 @@ def compare(out, fx, tol, what):
     mine, ref = np.unpackbits(out["density_bitfield"], bitorder="little"), np.unpackbits(fx["density_bitfield"], bitorder="little")
     flips = np.flatnonzero(mine != ref)
     thr = min(float(fx["mean_density"]), 0.001 if "sdf" in what else 10.0)
+    if "aabb_train" in fx:       # config 4 extras: update_aabb, entropy loss (the grad_weights path), inner / outer TV split
+        check("aabb_train: differing values", float((out["aabb_train"] != fx["aabb_train"]).sum()), 0, True)
+        check("tv inner-sample count", abs(int(out["tv_inner"]) - int(fx["tv_inner"])), 0, True)
+        check("entropy rel err", abs(float(out["entropy"]) - float(fx["entropy"])) / abs(float(fx["entropy"])), 10 * tol["image"])
+        check("weights abs err", float(np.abs(out["weights_head"] - fx["weights_head"]).max()), tol["image"])
     check("density_bitfield: differing bits", float(flips.size), tol["flips"], True)
     if flips.size:
         check("  their |density - threshold| / threshold", float((np.abs(grid[flips] - thr) / thr).max()), 2 * tol["grid"])
@@ -104,10 +111,16 @@ def compare(out, fx, tol, what):
 # ------------------------------------------------------------------------------------------------------------------ CPU
 
 def test_fixture_has_content():
-    for name in ("nerf", "sdf"):
+    for name in ("nerf", "sdf", "garden"):
         fx = fixture(name)
         occ = np.unpackbits(fx["density_bitfield"]).mean()
-        assert 0.005 < occ < 0.2 and int(fx["num_points"]) > 100000 and 0 < int(fx["density_grid_neg"]) < 128 ** 3
+        cells = 128 ** 3 * (5 if name == "garden" else 1)
+        assert 0.005 < occ < 0.3 and int(fx["num_points"]) > 100000 and 0 < int(fx["density_grid_neg"]) < cells
+        if name == "garden":      # cascades 1 and 2 carry occupied cells, the clamp to the colmap AABB took place, both TV groups are populated
+            bits = np.unpackbits(fx["density_bitfield"], bitorder="little").reshape(5, -1)
+            assert bits[1].mean() > 0.01 and bits[2].mean() > 0.001
+            assert fx["aabb_train"].tolist() == RC.GARDEN["aabb"]
+            assert 0 < int(fx["tv_inner"]) < int(fx["num_points"]) and float(fx["entropy"]) > 0
         assert fx["image"].std() > 0.02 and np.abs(fx["grad.sigma_net.net.0.weight"]).max() > 0
 
 
@@ -139,8 +152,7 @@ def test_fixture_is_what_the_reference_python_produces_today():
     import make_golden_render as MG
     ns = RP.load("ref")
     model = MG.reference_model(ns, sdf=False)
-    out = RC.run_case(model, lambda m, poses, intr: m.mark_untrained_grid(RC.dataset_stub(poses, intr)), "meshgrid", "cpu",
-                      ctx=RP.cpu_mode)
+    out = RC.run_case(model, _ref_mark, "meshgrid", "cpu", ctx=RP.cpu_mode)
     live, fx = RC.compress_for_fixture(out), fixture("nerf")
     assert set(live) == set(fx)
     for k in fx:
@@ -149,50 +161,60 @@ def test_fixture_is_what_the_reference_python_produces_today():
 
 # ------------------------------------------------------------------------------------------------------------------ GPU
 
-def _ours(sdf, fp16=False, fused=False):
+def _state(sdf, garden):
+    return RC.make_state(sdf, rows=RC.GARDEN["rows"] if garden else 6119864, garden=garden)
+
+
+def _ours(sdf, fp16=False, fused=False, garden=False):
     from nerf2mesh_amd.network import NeRFNetwork
     from nerf2mesh_amd.options import make_options
-    opt = make_options(bound=1.0, fp16=fp16, sdf=sdf, fused_mlp=fused, dt_gamma=0)
+    opt = make_options(bound=RC.GARDEN["bound"] if garden else 1.0, fp16=fp16, sdf=sdf, fused_mlp=fused, dt_gamma=RC.GARDEN["dt_gamma"] if garden else 0)
     model = NeRFNetwork(opt).cuda()
-    model.load_state_dict(RC.make_state(sdf), strict=False)
+    model.load_state_dict(_state(sdf, garden), strict=False)
     return model
 
 
-def _ours_mark(m, poses, intr):
-    m.mark_untrained_grid(poses, tuple(float(v) for v in intr))
+def _ours_mark(m, poses, intr, cam_near_far=None):
+    m.mark_untrained_grid(poses, tuple(float(v) for v in intr), cam_near_far=cam_near_far)
 
 
-def _reference_on_hip(sdf, fp16=False):
+def _ref_mark(m, poses, intr, cam_near_far=None):
+    m.mark_untrained_grid(RC.dataset_stub(poses, intr, cam_near_far))
+
+
+def _reference_on_hip(sdf, fp16=False, garden=False):
     from oracle import ref_python as RP
     if not RP.available():
         pytest.skip("reference Python not available (oracle/_ref/pyref not built)")
     ns = RP.load("hip")
     RP.use_backend("hip")
-    model = ns.network.NeRFNetwork(RP.reference_opt(sdf=sdf, fp16=fp16, density_thresh=0.001 if sdf else 10))
-    model.load_state_dict(RC.make_state(sdf), strict=False)
+    opt = RP.reference_opt(sdf=sdf, fp16=fp16, density_thresh=0.001 if sdf else 10)
+    if garden:
+        opt.bound = RC.GARDEN["bound"]
+    model = ns.network.NeRFNetwork(opt)
+    model.load_state_dict(_state(sdf, garden), strict=False)
     return model.cuda()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["nerf", "sdf"])
+@pytest.mark.parametrize("name", ["nerf", "sdf", "garden"])
 def test_restated_renderer_reproduces_the_reference_python(name):
     fx = fixture(name)
-    model = _ours(name == "sdf")
-    out = RC.run_case(model, _ours_mark, "morton", "cuda", sdf=name == "sdf", bitfield_override=fx["density_bitfield"])
+    model = _ours(name == "sdf", garden=name == "garden")
+    out = RC.run_case(model, _ours_mark, "morton", "cuda", sdf=name == "sdf", bitfield_override=fx["density_bitfield"], garden=name == "garden")
     flips = compare(out, fx, TOL[name], f"nerf2mesh_amd[{name}]")
     print(f"{name}: {flips} borderline occupancy bits")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["nerf", "sdf"])
+@pytest.mark.parametrize("name", ["nerf", "sdf", "garden"])
 def test_unchanged_reference_python_over_the_hip_backend(name):
     """Row b: nerf/renderer.py + nerf/network.py + the autograd wrappers, unchanged, on libn2m_hip.so through backends/_*.py."""
     fx = fixture(name)
-    model = _reference_on_hip(name == "sdf")
+    model = _reference_on_hip(name == "sdf", garden=name == "garden")
     import raymarching.raymarching as rrm
     assert rrm._backend.__file__.endswith(os.path.join("backends", "_raymarching_mob.py"))
-    out = RC.run_case(model, lambda m, poses, intr: m.mark_untrained_grid(RC.dataset_stub(poses, intr)), "meshgrid", "cuda",
-                      sdf=name == "sdf", bitfield_override=fx["density_bitfield"])
+    out = RC.run_case(model, _ref_mark, "meshgrid", "cuda", sdf=name == "sdf", bitfield_override=fx["density_bitfield"], garden=name == "garden")
     compare(out, fx, TOL[name], f"reference-python-on-hip[{name}]")
 
 

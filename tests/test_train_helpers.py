@@ -97,3 +97,52 @@ def test_fused_composite_loss_equals_the_four_kernel_chain(bg_kind):
     assert torch.equal(d_sr[:M], sig.grad) and torch.equal(d_sr[M:].view(M, 3), rgb.grad)
     np.testing.assert_allclose(lv.item(), loss.item(), rtol=5e-6)
     assert abs(lsum.item() - (2.0 + lv.item())) < 1e-6 and int(ticket) == 0
+
+
+def test_fused_composite_loss_with_the_entropy_regulariser():
+    """n2m_composite_loss_train_ent == the autograd statement of config 4's loss (nerf/utils.py:728-733 on top of the rgb + mask loss):
+    the entropy of the sample weights reaches composite_rays_train's backward as grad_weights (the per-sample factor the reference kernel
+    applies at raymarching.cu:676), the entropy of weights_sum as an extra grad_weights_sum.  Gradients to 2e-5 of their maximum (log2
+    spelled once instead of twice, fp32), loss value to 1e-5; lambda = 0 reproduces the plain kernel bit for bit."""
+    import torch
+    from nerf2mesh_amd import _lib as L, raymarching, synthetic as S
+    from nerf2mesh_amd.losses import photo_loss
+    dev = torch.device("cuda")
+    poses = S.make_cameras(16, seed=2).to(dev)
+    bits = raymarching.packbits(S.scene_density_grid(H=128, device=dev), 10.0)
+    g = torch.Generator(device=dev).manual_seed(19)
+    o, d = S.random_rays(poses, 6000, g)
+    nears, fars = raymarching.near_far_from_aabb(o, d, torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev), 0.05)
+    xyzs, dirs, ts, rays = raymarching.march_rays_train(o, d, 1.0, False, bits, 1, 128, nears, fars, True, 0.0, 1024)
+    M, N = xyzs.shape[0], o.shape[0]
+    sig = (torch.rand(M, device=dev, generator=g) * 40).requires_grad_()          # early stops on most rays that hit
+    rgb = torch.rand(M, 3, device=dev, generator=g).requires_grad_()
+    gt = torch.rand(N, 4, device=dev, generator=g)
+    bg = torch.rand(N, 3, device=dev, generator=g)
+    scale = torch.tensor(256.0, device=dev)
+    lam = 0.05                                                                    # (the recipe's 1e-3 would hide in the fp32 noise of the rgb term)
+    w, ws, dp, im = raymarching.composite_rays_train(sig, rgb, ts, rays, 1e-4, False, rays_tile_samples=True)
+    loss = photo_loss(im, ws, gt, bg, 1.0, 0.1)
+    ent = lambda p: (-p * torch.log2(p) - (1 - p) * torch.log2(1 - p)).mean()
+    loss = loss + lam * (ent(w.clamp(1e-5, 1 - 1e-5)) + ent(ws.clamp(1e-5, 1 - 1e-5)))
+    loss.backward(gradient=scale)
+
+    def fused(lam_):
+        d_sr = torch.empty(4 * M, device=dev)
+        partial = torch.empty((N + 15) // 16, device=dev)
+        L.call("n2m_composite_loss_train_ent", L.ptr(sig.detach()), L.ptr(rgb.detach()), L.ptr(ts), L.ptr(rays), M, N, 1e-4, L.ptr(gt), L.ptr(bg),
+               0.0, 1.0, 0.1, L.ptr(scale), None, None, L.ptr(d_sr[:M]), L.ptr(d_sr[M:]), L.ptr(partial), None, None, None, float(lam_), L.stream())
+        return d_sr[:M].clone(), d_sr[M:].view(M, 3).clone(), float(partial.double().sum() / N)
+    gs, gr, lv = fused(lam)
+    assert torch.equal(gr, rgb.grad)                                               # the colour gradient does not see the term
+    err = (gs - sig.grad).abs().max().item() / sig.grad.abs().max().item()
+    assert err <= 2e-5, err
+    assert abs(lv - loss.item()) <= 1e-5 * abs(loss.item())
+    # the term matters at this weight, and vanishes exactly at lambda = 0
+    gs0, gr0, lv0 = fused(0.0)
+    assert (gs0 - gs).abs().max().item() > 1e-3 * gs.abs().max().item()
+    d_sr = torch.empty(4 * M, device=dev)
+    partial = torch.empty((N + 15) // 16, device=dev)
+    L.call("n2m_composite_loss_train", L.ptr(sig.detach()), L.ptr(rgb.detach()), L.ptr(ts), L.ptr(rays), M, N, 1e-4, L.ptr(gt), L.ptr(bg),
+           0.0, 1.0, 0.1, L.ptr(scale), None, None, L.ptr(d_sr[:M]), L.ptr(d_sr[M:]), L.ptr(partial), None, None, None, L.stream())
+    assert torch.equal(d_sr[:M], gs0) and torch.equal(d_sr[M:].view(M, 3), gr0)
