@@ -132,6 +132,31 @@ def cpu_baseline(n_rays=32768, reps=4, threads=None):
                       f"{M} samples, best of {reps}; oracle C/OpenMP + torch-CPU MLPs"}
 
 
+def cpu_baseline_stage1(v, f, reps=2):
+    """The scalar C rasteriser / interpolator / antialiaser of oracle/n2m_raster_oracle.c (SURVEY 8d's stage-1 CPU baseline) on ONE view
+    of the same mesh at the same resolution: rasterize (bbox form, bit-identical to the brute-force oracle) + interpolate(xyz) +
+    interpolate(ones) + antialias(alpha) + antialias(rgb), forward only, one core."""
+    from oracle import oracle as orc
+    from nerf2mesh_amd import synthetic as S
+    poses = S.make_cameras(100, seed=0)
+    mvp = S.mvp_matrix(poses[0], 800, 800)
+    vc = (torch.cat([v.cpu(), torch.ones(v.shape[0], 1)], 1) @ mvp.T).numpy()
+    vn, fn = v.cpu().numpy(), f.cpu().numpy()
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        rast = orc.rasterize(vc, fn, 1600, 1600, bbox=True)
+        xyz = orc.interpolate(vn, rast, fn)
+        mask = orc.interpolate(np.ones((vn.shape[0], 1), np.float32), rast, fn)
+        orc.antialias(mask, rast, vc, fn)
+        orc.antialias(xyz, rast, vc, fn)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": 800 * 800 / best, "unit": "output pixels/s", "cores": 1, "kind": "port",
+            "sample": f"raster operators of ONE 800x800 view at 1600x1600 (rasterize + 2 interpolate + 2 antialias, forward only, no shading / "
+                      f"backward / optimizer), {fn.shape[0]} faces, best of {reps}: {best:.2f} s; scalar C (oracle/n2m_raster_oracle.c)"}
+
+
 def bench_stage1(args, rank, world, device):
     """One step = render_stage1 of one 800x800 view at 1600x1600 (ssaa 2) on a ~300k-face mesh + loss + backward + Adam
     (nerf/utils.py:708-721, nerf/renderer.py:816-921); views shard across ranks."""
@@ -151,6 +176,7 @@ def bench_stage1(args, rank, world, device):
         dist.barrier()
     if not args.no_prof:
         _lib.prof_reset(); _lib.prof_enable(args.prof_every)
+    c0 = tr.covered_seen
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.train_step()
@@ -165,30 +191,52 @@ def bench_stage1(args, rank, world, device):
         dt = float(stats[0])
     if rank == 0:
         px = 800 * 800 * args.steps * world
+        HW = 1600.0 * 1600.0
+        cov = (tr.covered_seen - c0) / args.steps            # covered (shaded) full-resolution pixels per view, measured
+        V, F = float(v.shape[0]), float(f.shape[0])
+        # ALGORITHMIC bytes per launch with the MEASURED coverage (SURVEY 8d's formulas; rounds 1-2 counted every pixel as covered, which
+        # put interpolate above the HBM peak): per pixel what every pixel costs (the rast read, the output write), per COVERED pixel the
+        # triangle's indices and vertex attributes.  interpolate runs twice per step (A = 3 positions, A = 1 mask): mean of the two.
+        interp_f = lambda A: HW * (16 + 4 * A) + cov * (12 + 12 * A)
+        interp_b = lambda A, rast_grad: HW * (16 + 4 * A) + cov * (12 + 12 * A + 24 * A) + (16 * HW if rast_grad else 0)
+        model = {"rasterize": 16 * V + 12 * F + 16 * HW, "rasterize_backward": 16 * HW + cov * 16 + 16 * V,
+                 "interpolate_forward": 0.5 * (interp_f(3) + interp_f(1)), "interpolate_backward": interp_b(3, True),
+                 "antialias_forward": 0.5 * ((8 * 1 + 16) + (8 * 3 + 16)) * HW, "antialias_backward": 0.5 * ((12 * 1 + 16) + (12 * 3 + 16)) * HW}
         kernels = {}
         for name in ("rasterize", "rasterize_backward", "interpolate_forward", "interpolate_backward", "antialias_forward", "antialias_backward",
                      "mlp_forward", "mlp_backward", "grid_encode_forward", "grid_encode_backward"):
             n, ms, by = _lib.prof_read(name)
             if n:
-                gbps = (by / n) / (ms / n * 1e-3) / 1e9 if ms > 0 else None
-                kernels[name] = {"launches": n, "avg_us": 1e3 * ms / n, "ms_per_step": ms * max(args.prof_every, 1) / args.steps,
-                                 "algo_bytes_per_launch": by / n, "GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS if gbps else None}
+                seen = _lib.prof_seen(name)
+                by_launch = model.get(name, by / n)
+                gbps = by_launch / (ms / n * 1e-3) / 1e9 if ms > 0 else None
+                kernels[name] = {"launches": n, "launches_seen": seen, "avg_us": 1e3 * ms / n, "ms_per_step": (ms / n) * seen / args.steps,
+                                 "algo_bytes_per_launch": by_launch, "GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS if gbps else None}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         roof = None
         if dom:
             k = kernels[dom]
             roof = {"kernel": dom, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["frac_of_hbm_peak"],
                     "traffic": None, "avg_us": k["avg_us"], "algo_bytes_per_launch": k["algo_bytes_per_launch"],
-                    "note": "algorithmic bytes per SURVEY.md 8d (raster ops: every pixel counted as covered = upper bound)"}
+                    "note": "algorithmic bytes per SURVEY.md 8d; raster operators with the measured covered-pixel count of the timed views"}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline_stage1(v, f)
+            except Exception as e:
+                cpu = {"value": None, "unit": "output pixels/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps({"metric": "stage1_train_pixels_per_sec", "value": px / dt, "unit": "output pixels/s (800x800 views, rendered at 1600x1600)",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 raster, f16 autocast shading",
                           "data": "synthetic", "config": {"workload": f"nerf_synthetic/lego stage-1 -O --bound 1: {f.shape[0]} faces, "
                                                                        f"{v.shape[0]} vertices, ssaa 2, refine error tracking on",
+                                                          "covered_pixels_per_view": cov, "coverage": cov / HW,
+                                                          "image_head": "fused (n2m_stage1_head)" if tr.fused_head else "torch graph",
                                                           "parallelism": f"views sharded over {world} GPU(s)",
-                                                          "parity": "UNPINNED: nvdiffrast is not under /root/reference; the HIP rasterize/interpolate/antialias "
-                                                                    "are validated against closed forms and the scalar oracle (tests/test_raster_*.py)"},
-                          "roofline": roof, "kernels": kernels}))
+                                                          "parity": "caller pinned to the unchanged reference Python (tests/test_stage1_reference.py); the "
+                                                                    "rasterize / interpolate / antialias operators themselves UNPINNED: nvdiffrast is not "
+                                                                    "under /root/reference (tests/test_raster_*.py check them against the scalar oracle)"},
+                          "roofline": roof, "kernels": kernels, "cpu_baseline": cpu}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -63,6 +63,20 @@ int n2m_antialias_backward(const float* color, const float* rast, const float* p
                            uint32_t H, uint32_t W, float pos_gradient_boost, float* grad_color, float* grad_pos,
                            void* stream);
 
+/* Stage-1 image head, forward AND backward in one launch: what nerf/renderer.py:886-913 does with the two antialias outputs (clamp,
+ * image = alpha * rgb, depth = alpha * z/w, T = 1 - alpha, ssaa reduction by `scale_img_hwc` = bilinear minification (exactly the 2 x 2
+ * mean for ssaa 2) and nearest for the triangle id, image + T * bg, weights_sum = 1 - T) plus the per-pixel loss of nerf/utils.py:708-721
+ * (lambda_rgb * mean_c (image - gt_rgb)^2 + lambda_mask * (weights_sum - gt_a)^2, gt_rgb = gt * gt_a + bg * (1 - gt_a)).
+ *   aa_alpha [h0 s, w0 s] f32, aa_rgb [h0 s, w0 s, 3] f32: the antialias outputs BEFORE the clamp; rast [h0 s, w0 s, 4]; s = ssaa (1 | 2)
+ *   gt_rgba [h0 w0, 4]; bg [h0 w0, 3] or NULL (then bg_scalar)
+ *   out: image [h0 w0, 3], depth / weights_sum / trig_id (id - 1 as float, -1 = empty) / loss_px [h0 w0]; partial [ceil(h0 w0 / 256)] =
+ *        per-workgroup sums of loss_px (mean = sum(partial) / (h0 w0), summed by the caller in index order)
+ *   d_alpha [h0 s, w0 s], d_rgb [h0 s, w0 s, 3] (both or neither): gradient of mean(loss_px) w.r.t. aa_alpha / aa_rgb; the caller scales
+ *        them by its incoming gradient (the loss scale). */
+int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const float* rast, uint32_t h0, uint32_t w0, uint32_t ssaa,
+                    const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask, float* image, float* depth,
+                    float* weights_sum, float* trig_id, float* loss_px, float* d_alpha, float* d_rgb, float* partial, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,101 @@ photo_loss_backward_kernel(const float* __restrict__ image, const float* __restr
     d_wsum[r] = dw;
 }
 
+// Stage-1 image head in ONE launch, forward and backward (nerf/renderer.py:886-913 after the two antialias calls + the loss of
+// nerf/utils.py:708-721): clamp(alpha), clamp(rgb) -> image = alpha * rgb, depth = alpha * z/w, T = 1 - alpha -> ssaa reduction (bilinear
+// minification by an integer factor 2 = the mean of the 2 x 2 block in the association torch's kernel uses; nearest for the triangle id) ->
+// image + T * bg, weights_sum = 1 - T -> per-pixel loss lambda_rgb * mean_c (image - gt_rgb)^2 + lambda_mask * (weights_sum - gt_a)^2 with
+// gt_rgb = gt * gt_a + bg * (1 - gt_a) -> its mean (per-workgroup partials).  The gradient of that mean w.r.t. the two antialias OUTPUTS
+// (through the clamps: passed on [0, 1] inclusive like torch.clamp) is written in the same pass -- like the stage-0 head it does not
+// depend on the loss value.  The reference spends ~40 full-image elementwise / resize launches (and their autograd nodes) on this.
+template <int S>
+__global__ void __launch_bounds__(256)
+stage1_head_kernel(const float* __restrict__ aa_alpha /*[h0 S, w0 S]*/, const float* __restrict__ aa_rgb /*[h0 S, w0 S, 3]*/,
+                   const float* __restrict__ rast /*[h0 S, w0 S, 4]*/, uint32_t h0, uint32_t w0, const float* __restrict__ gt /*[h0 w0, 4]*/,
+                   const float* __restrict__ bg /*[h0 w0, 3] or NULL*/, float bg_scalar, float lambda_rgb, float lambda_mask,
+                   float* __restrict__ image, float* __restrict__ depth, float* __restrict__ wsum, float* __restrict__ trig_id,
+                   float* __restrict__ loss_px, float* __restrict__ d_alpha, float* __restrict__ d_rgb, float* __restrict__ partial) {
+    __shared__ float wave_sum[4];
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint32_t N = h0 * w0, w = w0 * S;
+    float l = 0.0f;
+    if (n < N) {
+        const uint32_t y = n / w0, x = n - y * w0;
+        float a[S * S], c[S * S][3], z[S * S];
+        bool pass_a[S * S], pass_c[S * S][3];
+#pragma unroll
+        for (int j = 0; j < S; ++j)
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const size_t p = (size_t)(y * S + j) * w + (x * S + i);
+                const int k = j * S + i;
+                const float ra = aa_alpha[p];
+                pass_a[k] = ra >= 0.0f && ra <= 1.0f;
+                a[k] = fminf(fmaxf(ra, 0.0f), 1.0f);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float rc = aa_rgb[p * 3 + ch];
+                    pass_c[k][ch] = rc >= 0.0f && rc <= 1.0f;
+                    c[k][ch] = fminf(fmaxf(rc, 0.0f), 1.0f);
+                }
+                z[k] = rast[p * 4 + 2];
+            }
+        // reduction of a quantity q over the block: S = 1 identity; S = 2: 0.5 (0.5 q00 + 0.5 q01) + 0.5 (0.5 q10 + 0.5 q11)
+        auto down = [&](auto q) -> float {
+            if (S == 1) return q(0);
+            return 0.5f * (0.5f * q(0) + 0.5f * q(1)) + 0.5f * (0.5f * q(2) + 0.5f * q(3));
+        };
+        float im[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) im[ch] = down([&](int k) { return a[k] * c[k][ch]; });
+        const float dp = down([&](int k) { return a[k] * z[k]; });
+        const float T = down([&](int k) { return 1.0f - a[k]; });
+        const float ws = 1.0f - T;
+        const float4 g = *reinterpret_cast<const float4*>(gt + (size_t)n * 4);
+        const float gc[3] = {g.x, g.y, g.z}, ga = g.w;
+        float e[3], bgc[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            bgc[ch] = bg ? bg[(size_t)n * 3 + ch] : bg_scalar;
+            im[ch] = im[ch] + T * bgc[ch];
+            const float target = gc[ch] * ga + bgc[ch] * (1.0f - ga);
+            e[ch] = im[ch] - target;
+            image[(size_t)n * 3 + ch] = im[ch];
+        }
+        const float m = ws - ga;
+        l = lambda_rgb * ((e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) / 3.0f) + lambda_mask * (m * m);
+        depth[n] = dp; wsum[n] = ws; loss_px[n] = l;
+        trig_id[n] = rast[((size_t)(y * S) * w + (size_t)(x * S)) * 4 + 3] - 1.0f;      // nearest: the block's first sub-pixel
+        if (d_alpha) {
+            // d mean / d image_c, d mean / d weights_sum (seed 1 / N; the caller scales by the incoming gradient)
+            const float inv = 1.0f / (float)N;
+            float gi[3], gT = -(inv * lambda_mask * 2.0f * m);                         // weights_sum = 1 - T
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { gi[ch] = inv * lambda_rgb * (2.0f * e[ch] / 3.0f); gT += gi[ch] * bgc[ch]; }
+            const float share = S == 1 ? 1.0f : 0.25f;
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    const size_t p = (size_t)(y * S + j) * w + (x * S + i);
+                    const int k = j * S + i;
+                    float da = -(share * gT);                                           // T_sub = 1 - alpha
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float dis = share * gi[ch];                               // d image_sub
+                        da += dis * c[k][ch];
+                        d_rgb[p * 3 + ch] = pass_c[k][ch] ? dis * a[k] : 0.0f;
+                    }
+                    d_alpha[p] = pass_a[k] ? da : 0.0f;
+                }
+        }
+    }
+    l = n2m_wave_sum(l);
+    if (lane == 0) wave_sum[wid] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+}
+
 // rays of pixels pix[n] (flat index j*W + i) of views cam[n]: directions ((i+0.5-cx)/fx, -(j+0.5-cy)/fy, -1) rotated by
 // the pose (NOT normalised: t is then z-depth, nerf/utils.py:285), origin = pose translation; rgba = images[cam, pix]
 __global__ void __launch_bounds__(256)
@@ -339,6 +434,27 @@ extern "C" int n2m_photo_loss_backward(const float* image, const float* weights_
     hipStream_t s = (hipStream_t)stream;
     photo_loss_backward_kernel<<<n2m_ceil_div(N, 256), 256, 0, s>>>(image, weights_sum, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask, N, grad_loss,
                                                                      d_image, d_weights_sum);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const float* rast, uint32_t h0, uint32_t w0, uint32_t ssaa,
+                               const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask, float* image,
+                               float* depth, float* weights_sum, float* trig_id, float* loss_px, float* d_alpha, float* d_rgb, float* partial,
+                               void* stream) {
+    N2M_REQUIRE(aa_alpha && aa_rgb && rast && gt_rgba && image && depth && weights_sum && trig_id && loss_px && partial, N2M_ENULL,
+                "stage1_head: NULL tensor");
+    N2M_REQUIRE((d_alpha == nullptr) == (d_rgb == nullptr), N2M_ENULL, "stage1_head: d_alpha and d_rgb come together");
+    N2M_REQUIRE(ssaa == 1 || ssaa == 2, N2M_EUNSUPPORTED, "stage1_head: ssaa 1 or 2 (the reduction is the exact 2 x 2 mean of torch's bilinear minification)");
+    N2M_REQUIRE(h0 > 0 && w0 > 0 && (uint64_t)h0 * w0 < (1ull << 31), N2M_EINVAL, "stage1_head: bad image size");
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t N = h0 * w0;
+    if (ssaa == 1)
+        stage1_head_kernel<1><<<n2m_ceil_div(N, 256), 256, 0, s>>>(aa_alpha, aa_rgb, rast, h0, w0, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask,
+                                                                  image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial);
+    else
+        stage1_head_kernel<2><<<n2m_ceil_div(N, 256), 256, 0, s>>>(aa_alpha, aa_rgb, rast, h0, w0, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask,
+                                                                  image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial);
     N2M_CHECK_LAUNCH();
     return 0;
 }

@@ -49,3 +49,40 @@ def photo_loss(image, weights_sum, gt_rgba, bg, lambda_rgb=1.0, lambda_mask=0.0)
     -- the stage-0 loss of nerf/utils.py:658-683 with the background blend of nerf/renderer.py:747 folded in.
     `image` is the composited colour BEFORE that blend; bg is a float (uniform) or an [N,3] tensor."""
     return _photo_loss.apply(image, weights_sum, gt_rgba, bg, lambda_rgb, lambda_mask)
+
+
+class _stage1_head(Function):
+    """n2m_stage1_head: clamp / alpha * rgb / depth / T / ssaa reduction / background blend / per-pixel loss and its mean in one launch;
+    the gradient of the mean w.r.t. the two antialias outputs is formed in the same pass (it does not depend on the loss value) and
+    scaled by the incoming gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb, lambda_mask):
+        dev = aa_alpha.device
+        aa_alpha, aa_rgb, rast = aa_alpha.float().contiguous(), aa_rgb.float().contiguous(), rast.float().contiguous()
+        gt_rgba = gt_rgba.float().contiguous()
+        N = h0 * w0
+        bg_t, bg_s = (bg.float().reshape(N, 3).contiguous(), 0.0) if torch.is_tensor(bg) else (None, float(bg))
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        image, depth, ws, trig, loss_px = f(N, 3), f(N), f(N), f(N), f(N)
+        partial = f((N + 255) // 256)
+        need = any(ctx.needs_input_grad[:2])
+        d_alpha, d_rgb = (torch.empty_like(aa_alpha), torch.empty_like(aa_rgb)) if need else (None, None)
+        L.call("n2m_stage1_head", _p(aa_alpha), _p(aa_rgb), _p(rast), int(h0), int(w0), int(ssaa), _p(gt_rgba), _p(bg_t), bg_s, float(lambda_rgb),
+               float(lambda_mask), _p(image), _p(depth), _p(ws), _p(trig), _p(loss_px), _p(d_alpha), _p(d_rgb), _p(partial), L.stream())
+        ctx.grads = (d_alpha, d_rgb)
+        loss = partial.sum() / N
+        ctx.mark_non_differentiable(image, depth, ws, trig, loss_px)
+        return loss, image, depth, ws, trig, loss_px
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        d_alpha, d_rgb = ctx.grads
+        ctx.grads = None
+        return d_alpha * g, d_rgb * g, None, None, None, None, None, None, None, None
+
+
+def stage1_head(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb=1.0, lambda_mask=0.0):
+    """(loss, image [N,3], depth [N], weights_sum [N], trig_id [N] float, loss_px [N]) of one stage-1 view from the two antialias outputs
+    (before their clamp) and the rasteriser's image: nerf/renderer.py:886-913 + the loss of nerf/utils.py:708-721, N = h0 * w0."""
+    return _stage1_head.apply(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb, lambda_mask)

@@ -529,9 +529,9 @@ class NeRFRenderer(nn.Module):
         export.write_mlp_json(os.path.join(path, "mlp.json"), self)
         return out
 
-    def render_stage1(self, rays_o, rays_d, mvp, h0, w0, index=None, bg_color=None, shading="full", **kwargs):
-        """Rasterise the mesh, shade covered pixels with the colour networks, antialias (nerf/renderer.py:816-921)."""
-        prefix = rays_d.shape[:-1]
+    def _stage1_front(self, rays_d, mvp, h0, w0, shading="full"):
+        """Everything of render_stage1 up to and including the two antialias calls (nerf/renderer.py:816-887): returns
+        (rast [1,h,w,4], alpha [1,h,w,1] and rgb [1,h,w,3] as antialias hands them out, BEFORE the clamp)."""
         rays_d = rays_d.contiguous().view(-1, 3)
         device = rays_d.device
         ssaa = int(self.opt.ssaa)
@@ -542,11 +542,6 @@ class NeRFRenderer(nn.Module):
             h, w = h0, w0
             dirs = rays_d
         dirs = safe_normalize(dirs)
-        if bg_color is None:
-            bg_color = 1
-        if torch.is_tensor(bg_color) and bg_color.dim() == 2:
-            bg_color = bg_color.view(h0, w0, 3)
-
         vertices = self.vertices + self.vertices_offsets
         vertices_clip = to_clip(vertices, mvp).unsqueeze(0)
         rast, _ = dr.rasterize(self.glctx, vertices_clip, self.triangles, (h, w))
@@ -558,6 +553,7 @@ class NeRFRenderer(nn.Module):
             xyzs = contract(xyzs)
         rgbs = torch.zeros(h * w, 3, device=device, dtype=torch.float32)
         idx = torch.nonzero(mask_flatten, as_tuple=False).squeeze(1)
+        self.last_covered = int(idx.numel())
         if idx.numel() > 0:
             pts = xyzs[idx] if self.opt.enable_offset_nerf_grad else xyzs[idx].detach()
             with torch.autocast(device_type="cuda", dtype=torch.float16, enabled=bool(self.opt.fp16)):
@@ -566,8 +562,22 @@ class NeRFRenderer(nn.Module):
         rgbs = rgbs.view(1, h, w, 3)
         alphas = mask.float()
         boost = self.opt.pos_gradient_boost
-        alphas = dr.antialias(alphas, rast, vertices_clip, self.triangles, pos_gradient_boost=boost).squeeze(0).clamp(0, 1)
-        rgbs = dr.antialias(rgbs, rast, vertices_clip, self.triangles, pos_gradient_boost=boost).squeeze(0).clamp(0, 1)
+        alphas = dr.antialias(alphas, rast, vertices_clip, self.triangles, pos_gradient_boost=boost)
+        rgbs = dr.antialias(rgbs, rast, vertices_clip, self.triangles, pos_gradient_boost=boost)
+        return rast, alphas, rgbs
+
+    def render_stage1(self, rays_o, rays_d, mvp, h0, w0, index=None, bg_color=None, shading="full", **kwargs):
+        """Rasterise the mesh, shade covered pixels with the colour networks, antialias (nerf/renderer.py:816-921)."""
+        prefix = rays_d.shape[:-1]
+        ssaa = int(self.opt.ssaa)
+        h, w = (int(h0 * ssaa), int(w0 * ssaa)) if ssaa > 1 else (h0, w0)
+        if bg_color is None:
+            bg_color = 1
+        if torch.is_tensor(bg_color) and bg_color.dim() == 2:
+            bg_color = bg_color.view(h0, w0, 3)
+        rast, alphas, rgbs = self._stage1_front(rays_d, mvp, h0, w0, shading)
+        alphas = alphas.squeeze(0).clamp(0, 1)
+        rgbs = rgbs.squeeze(0).clamp(0, 1)
         image = alphas * rgbs
         depth = alphas * rast[0, :, :, [2]]
         T = 1 - alphas

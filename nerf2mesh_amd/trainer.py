@@ -380,7 +380,8 @@ class Stage1Trainer:
         self.pix = (jj * W + ii).reshape(-1)
         self.laplacian = UniformLaplacian(model.triangles, model.vertices.shape[0])
         self.view_cache = {}          # per view: rays + ground-truth RGBA, resident in HBM like the reference's --preload
-        self.covered_seen = 0
+        self.covered_seen = 0         # shaded (covered) full-resolution pixels so far: the unit of the stage-1 byte model
+        self.fused_head = torch.device(device).type == "cuda" and int(opt.ssaa) in (1, 2)      # losses.stage1_head (False: the torch graph)
 
     def _view(self, v):
         if v not in self.view_cache:
@@ -400,17 +401,29 @@ class Stage1Trainer:
         self.global_step += 1
         rays_o, rays_d, rgba = self._view(v)
         bg = torch.rand(self.H * self.W, 3, device=self.device, generator=self.gen)
-        gt_mask = rgba[:, 3:]
-        gt_rgb = rgba[:, :3] * gt_mask + bg * (1 - gt_mask)
         self.optimizer.zero_grad(set_to_none=True)
         shading = "diffuse" if opt.diffuse_only else "full"                  # nerf/utils.py:669-672 (diffuse_step only gates stage 0)
-        out = model.render_stage1(rays_o, rays_d, self.mvps[v], self.H, self.W, bg_color=bg, shading=shading)
-        loss = opt.lambda_rgb * F.mse_loss(out["image"], gt_rgb, reduction="none").mean(-1)
-        if opt.lambda_mask > 0:
-            loss = loss + opt.lambda_mask * F.mse_loss(out["weights_sum"].view(-1), gt_mask.view(-1), reduction="none")
-        if opt.refine:
-            model.update_triangles_errors(loss.detach())
-        loss = loss.mean()
+        if self.fused_head:
+            # everything behind the two antialias calls (clamp, alpha * rgb, depth, T, ssaa reduction, background blend, per-pixel loss,
+            # mean) and its backward in ONE launch (losses.stage1_head) instead of ~40 full-image elementwise / resize launches
+            from .losses import stage1_head
+            rast, aa_alpha, aa_rgb = model._stage1_front(rays_d, self.mvps[v], self.H, self.W, shading)
+            loss, _, _, _, trig, loss_px = stage1_head(aa_alpha, aa_rgb, rast, rgba, bg, self.H, self.W, int(opt.ssaa), opt.lambda_rgb,
+                                                       max(opt.lambda_mask, 0.0))
+            if opt.refine:
+                model.triangles_errors_id = trig.view(self.H, self.W)
+                model.update_triangles_errors(loss_px)
+        else:
+            gt_mask = rgba[:, 3:]
+            gt_rgb = rgba[:, :3] * gt_mask + bg * (1 - gt_mask)
+            out = model.render_stage1(rays_o, rays_d, self.mvps[v], self.H, self.W, bg_color=bg, shading=shading)
+            loss = opt.lambda_rgb * F.mse_loss(out["image"], gt_rgb, reduction="none").mean(-1)
+            if opt.lambda_mask > 0:
+                loss = loss + opt.lambda_mask * F.mse_loss(out["weights_sum"].view(-1), gt_mask.view(-1), reduction="none")
+            if opt.refine:
+                model.update_triangles_errors(loss.detach())
+            loss = loss.mean()
+        self.covered_seen += getattr(model, "last_covered", 0)
         if opt.lambda_lap > 0:
             loss = loss + opt.lambda_lap * self.laplacian(model.vertices + model.vertices_offsets)
         if opt.lambda_offsets > 0:                                           # nerf/utils.py:772-789

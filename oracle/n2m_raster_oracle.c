@@ -100,6 +100,45 @@ void n2m_oracle_rasterize(const float* pos, const int32_t* tri, uint32_t V, uint
     free(best);
 }
 
+/* The same image with each triangle confined to the pixel box of its vertices (+1 px: the 1/256-pixel snap of `covers`): a pixel outside
+ * that box cannot pass the edge tests, so the result equals n2m_oracle_rasterize bit for bit (tests/test_raster_oracle.py) at a cost of
+ * O(covered pixels) instead of O(F H W).  Triangles with a vertex at w <= 0 (float homogeneous path) keep the full image.  This is the
+ * form bench.py times as the stage-1 CPU baseline (a scalar software rasteriser on the same inputs). */
+void n2m_oracle_rasterize_bbox(const float* pos, const int32_t* tri, uint32_t V, uint32_t F, uint32_t H, uint32_t W, float* rast) {
+    memset(rast, 0, sizeof(float) * 4 * (size_t)H * W);
+    float* best = (float*)malloc(sizeof(float) * (size_t)H * W);
+    for (size_t i = 0; i < (size_t)H * W; ++i) best[i] = INFINITY;
+    for (uint32_t f = 0; f < F; ++f) {
+        const tri_t t = fetch(pos, tri, f, V);
+        if (!t.ok) continue;
+        int x0 = 0, x1 = (int)W - 1, y0 = 0, y1 = (int)H - 1;
+        if (t.w[0] > 1e-12f && t.w[1] > 1e-12f && t.w[2] > 1e-12f) {
+            float lox = INFINITY, hix = -INFINITY, loy = INFINITY, hiy = -INFINITY;
+            int finite = 1;
+            for (int k = 0; k < 3; ++k) {
+                const float px = (t.x[k] / t.w[k] * 0.5f + 0.5f) * (float)W, py = (t.y[k] / t.w[k] * 0.5f + 0.5f) * (float)H;
+                if (!(fabsf(px) < 1048576.f && fabsf(py) < 1048576.f)) finite = 0;
+                lox = fminf(lox, px); hix = fmaxf(hix, px); loy = fminf(loy, py); hiy = fmaxf(hiy, py);
+            }
+            if (finite) {
+                x0 = (int)fmaxf(0.f, floorf(lox) - 1.f); x1 = (int)fminf((float)W - 1.f, ceilf(hix) + 1.f);
+                y0 = (int)fmaxf(0.f, floorf(loy) - 1.f); y1 = (int)fminf((float)H - 1.f, ceilf(hiy) + 1.f);
+            }
+        }
+        for (int iy = y0; iy <= y1; ++iy)
+            for (int ix = x0; ix <= x1; ++ix) {
+                float zw, b0, b1;
+                if (!covers(&t, ix, iy, H, W, &zw, &b0, &b1)) continue;
+                const size_t i = (size_t)iy * W + ix;
+                if (zw < best[i]) {
+                    best[i] = zw;
+                    rast[4 * i] = b0; rast[4 * i + 1] = b1; rast[4 * i + 2] = fminf(fmaxf(zw, -1.f), 1.f); rast[4 * i + 3] = (float)(f + 1);
+                }
+            }
+    }
+    free(best);
+}
+
 void n2m_oracle_interpolate(const float* attr, const float* rast, const int32_t* tri, uint32_t V, uint32_t F, uint32_t A,
                             uint32_t H, uint32_t W, float* out) {
     (void)V;

@@ -313,10 +313,11 @@ def freq_encode_backward(grad, outputs, D, degree):
 
 # ------------------------------------------------------------------------------------------- stage-1 raster
 
-def rasterize(pos, tri, H, W):
+def rasterize(pos, tri, H, W, bbox=False):
+    """bbox=True: every triangle confined to its pixel box -- the same image bit for bit at O(covered pixels) (the CPU-baseline form)."""
     pos, tri = _c(pos, np.float32).reshape(-1, 4), _c(tri, np.int32).reshape(-1, 3)
     rast = np.zeros((H, W, 4), np.float32)
-    _call("rasterize", _p(pos), _p(tri), _u32(pos.shape[0]), _u32(tri.shape[0]), _u32(H), _u32(W), _p(rast))
+    _call("rasterize_bbox" if bbox else "rasterize", _p(pos), _p(tri), _u32(pos.shape[0]), _u32(tri.shape[0]), _u32(H), _u32(W), _p(rast))
     return rast
 
 

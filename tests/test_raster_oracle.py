@@ -143,3 +143,23 @@ def test_antialias_ignores_non_silhouette_edges(impl):
     color = rng.random((16, 16, 3)).astype(np.float32)
     out = impl.antialias(color, rast, pos, tri)
     np.testing.assert_array_equal(out, color)
+
+
+def test_bbox_form_of_the_oracle_rasteriser_is_the_same_image():
+    """oracle.rasterize(bbox=True) -- each triangle confined to its pixel box, the form bench.py times as the stage-1 CPU baseline --
+    against the brute-force per-pixel loop over all triangles: bit-identical, including triangles behind the camera (w <= 0: full image)
+    and triangles that leave the frame."""
+    import torch
+    from nerf2mesh_amd import synthetic as S
+    from oracle import oracle as orc
+    v, f = S.scene_mesh(1500)
+    poses = S.make_cameras(4, seed=0)
+    for cam, res, zoom in ((1, 96, 1.0), (2, 64, 6.0)):                 # zoom 6: most of the mesh outside the frame, some vertices behind it
+        mvp = S.mvp_matrix(poses[cam], res, res, S.LEGO_FOCAL * res / S.LEGO_HW * zoom)
+        pos = (torch.cat([v, torch.ones_like(v[:, :1])], 1) @ mvp.T).numpy()
+        if zoom > 1:
+            pos[::7, 3] *= -1.0                                           # a few vertices at w < 0
+        a = orc.rasterize(pos, f.numpy(), res, res)
+        b = orc.rasterize(pos, f.numpy(), res, res, bbox=True)
+        assert np.array_equal(a, b)
+        assert (a[..., 3] > 0).mean() > 0.02

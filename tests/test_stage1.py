@@ -43,3 +43,77 @@ def test_fused_color_matches_unfused():
             c0, p0 = ref.rgb(x, d, None, "full")
         c1, p1 = fused.rgb(x, d, None, "full")
     assert (c0.float() - c1).abs().max().item() < 6e-3 and (p0.float() - p1).abs().max().item() < 6e-3
+
+
+@pytest.mark.parametrize("ssaa", [2, 1])
+def test_fused_image_head_equals_the_torch_graph(ssaa):
+    """losses.stage1_head (n2m_stage1_head: clamp, alpha * rgb, depth, T, ssaa reduction, background blend, per-pixel loss, mean and the
+    gradient of that mean, one launch) against the torch statement of nerf/renderer.py:886-913 + nerf/utils.py:708-721 that
+    renderer.render_stage1 / Stage1Trainer spell out (and that tests/test_stage1_reference.py pins to the unchanged reference): outputs to
+    fp32 rounding, gradients w.r.t. both antialias outputs to 1e-6 of their maximum, triangle ids exactly."""
+    import torch
+    import torch.nn.functional as F
+    from nerf2mesh_amd.losses import stage1_head
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(3)
+    h0, w0 = 37, 53
+    h, w = h0 * ssaa, w0 * ssaa
+    aa_alpha = (torch.rand(1, h, w, 1, device=dev, generator=g) * 1.4 - 0.2).requires_grad_()      # some values outside [0, 1]: the clamp bites
+    aa_rgb = (torch.rand(1, h, w, 3, device=dev, generator=g) * 1.4 - 0.2).requires_grad_()
+    rast = torch.rand(1, h, w, 4, device=dev, generator=g)
+    rast[..., 3] = torch.randint(0, 50, (1, h, w), device=dev, generator=g).float()
+    gt = torch.rand(h0 * w0, 4, device=dev, generator=g)
+    bg = torch.rand(h0 * w0, 3, device=dev, generator=g)
+    lam_rgb, lam_mask = 1.0, 0.1
+    # torch graph
+    alphas, rgbs = aa_alpha.squeeze(0).clamp(0, 1), aa_rgb.squeeze(0).clamp(0, 1)
+    image, depth, T = alphas * rgbs, alphas * rast[0, :, :, [2]], 1 - alphas
+    trig = rast[0, :, :, -1] - 1
+    if ssaa > 1:
+        down = lambda x: F.interpolate(x.permute(2, 0, 1).unsqueeze(0), (h0, w0), mode="bilinear").squeeze(0).permute(1, 2, 0).contiguous()
+        image, depth, T = down(image), down(depth), down(T)
+        trig = F.interpolate(trig.view(1, 1, h, w), (h0, w0), mode="nearest").view(h0, w0)
+    image = (image + T * bg.view(h0, w0, 3)).view(-1, 3)
+    ws = (1 - T).view(-1)
+    gt_mask = gt[:, 3:]
+    gt_rgb = gt[:, :3] * gt_mask + bg * (1 - gt_mask)
+    loss_px = lam_rgb * F.mse_loss(image, gt_rgb, reduction="none").mean(-1) + lam_mask * F.mse_loss(ws, gt_mask.view(-1), reduction="none")
+    loss = loss_px.mean()
+    seed = torch.tensor(1024.0, device=dev)
+    (loss * seed).backward()
+    ga, gr = aa_alpha.grad.clone(), aa_rgb.grad.clone()
+    aa_alpha.grad = aa_rgb.grad = None
+    # fused head
+    l2, im2, dp2, ws2, tr2, lp2 = stage1_head(aa_alpha, aa_rgb, rast, gt, bg, h0, w0, ssaa, lam_rgb, lam_mask)
+    (l2 * seed).backward()
+    close = lambda a, b, tol: float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-30)
+    assert close(im2, image.detach(), 1e-6) and close(ws2, ws.detach(), 1e-6) and close(dp2, depth.detach().view(-1), 1e-6)
+    assert torch.equal(tr2.view(h0, w0), trig)
+    assert close(lp2, loss_px.detach(), 2e-6) and abs(float(l2) - float(loss)) <= 2e-6 * float(loss)
+    assert close(aa_alpha.grad, ga, 2e-6) and close(aa_rgb.grad, gr, 2e-6)
+    assert float((aa_alpha.grad == 0).float().mean()) > 0.1, "the clamp masks were not exercised"
+
+
+def test_stage1_step_with_and_without_the_fused_head():
+    """Stage1Trainer.train_step with fused_head on / off: same loss and the same gradients on the first step (same view, same background)."""
+    import torch
+    from nerf2mesh_amd import synthetic as S
+    from nerf2mesh_amd.network import NeRFNetwork
+    from nerf2mesh_amd.options import make_options
+    from nerf2mesh_amd.trainer import Stage1Trainer
+    outs = []
+    for fused in (False, True):
+        torch.manual_seed(0)
+        opt = make_options(O=True, bound=1, dt_gamma=0, stage=1, fused_mlp=True)
+        v, f = S.scene_mesh(20000)
+        tr = Stage1Trainer(NeRFNetwork(opt), opt, S.make_cameras(6, seed=0), v, f, torch.device("cuda"), H=160, W=160)
+        tr.fused_head = fused
+        loss = float(tr.train_step().detach())
+        m = tr.model
+        outs.append((loss, m.vertices_offsets.grad.clone(), m.encoder_color.embeddings.grad.clone().float(), m.triangles_errors.clone(),
+                     m.triangles_errors_cnt.clone()))
+    (la, va, ea, ta, ca), (lb, vb, eb, tb, cb) = outs
+    assert abs(la - lb) <= 1e-5 * abs(la)
+    assert torch.equal(ca, cb) and float((ta - tb).abs().max()) <= 1e-5 * float(ta.abs().max())
+    rel = lambda a, b: float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+    assert rel(va, vb) <= 1e-3 and rel(ea, eb) <= 1e-2          # (scaled fp16 path of the colour field: atomics order noise on top)
