@@ -198,9 +198,11 @@ def bench_stage1(args, rank, world, device):
         # put interpolate above the HBM peak): per pixel what every pixel costs (the rast read, the output write), per COVERED pixel the
         # triangle's indices and vertex attributes.  interpolate runs twice per step (A = 3 positions, A = 1 mask): mean of the two.
         interp_f = lambda A: HW * (16 + 4 * A) + cov * (12 + 12 * A)
-        interp_b = lambda A, rast_grad: HW * (16 + 4 * A) + cov * (12 + 12 * A + 24 * A) + (16 * HW if rast_grad else 0)
+        # backward: the one launch per step is the mask's (A = 1; the positions are detached, nerf/renderer.py:878): rast read + grad_rast
+        # written for every pixel, d_out / indices / attributes for covered pixels only
+        interp_b = lambda A, rast_grad: HW * 16 + (16 * HW if rast_grad else 0) + cov * (4 * A + 12 + 12 * A)
         model = {"rasterize": 16 * V + 12 * F + 16 * HW, "rasterize_backward": 16 * HW + cov * 16 + 16 * V,
-                 "interpolate_forward": 0.5 * (interp_f(3) + interp_f(1)), "interpolate_backward": interp_b(3, True),
+                 "interpolate_forward": 0.5 * (interp_f(3) + interp_f(1)), "interpolate_backward": interp_b(1, True),
                  "antialias_forward": 0.5 * ((8 * 1 + 16) + (8 * 3 + 16)) * HW, "antialias_backward": 0.5 * ((12 * 1 + 16) + (12 * 3 + 16)) * HW}
         kernels = {}
         for name in ("rasterize", "rasterize_backward", "interpolate_forward", "interpolate_backward", "antialias_forward", "antialias_backward",
