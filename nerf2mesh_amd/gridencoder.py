@@ -12,6 +12,8 @@
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -99,6 +101,9 @@ def _host_offsets(enc):
     return arr
 
 
+_PAIR_FOR_COLOR = os.environ.get("N2M_COLOR_BWD_SINGLE", "0") != "1"      # A/B switch: the round-1 single-table kernels for a lone C=2 fp16 table
+
+
 def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level, tv=None, found_inf=None, ws_slot=0):
     """grad_embeddings += scatter of grad_lm [L,B,C] through the binned fixed-point kernels (include/n2m_hip.h);
     returns False when the configuration is not covered (caller uses n2m_grid_encode_backward).
@@ -108,6 +113,17 @@ def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level, tv=None, foun
         return False
     dt = _dtype_id(grad_embeddings)
     ho = _host_offsets(enc)
+    if C == 2 and dt == L.F16 and tv is None and max_level > 0 and B > 0 and _PAIR_FOR_COLOR:
+        # the colour table alone through the shared-fill kernels (grad1 = NULL): same-cell runs of consecutive samples merged, SoA logs,
+        # XCD-aware level order, walk-ahead accumulate -- measured 435 -> ~170 us on a stage-1 frame against the round-1 single-table kernels
+        need = L.lib().n2m_grid_binned_pair_workspace_bytes(B, max_level, ho.ctypes.data)
+        if need != 0:
+            ws = L.workspace(x01.device, need, ws_slot)
+            L.grid_backward_config(1, 1.0)
+            L.call("n2m_grid_encode_backward_binned_pair", None, _p(grad_lm), _p(x01), ho.ctypes.data, None, _p(grad_embeddings), B, enc.num_levels,
+                   max_level, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)),
+                   enc.interp_id, None, 0.0, 0.0, 1.0, None, _p(found_inf), 1.0, 0.0, 0, _p(ws), ws.numel(), L.stream())
+            return True
     need = L.lib().n2m_grid_binned_workspace_bytes(B, 3, C, max_level, ho.ctypes.data, dt, 0)
     if need == 0:
         return False

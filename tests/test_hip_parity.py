@@ -1134,3 +1134,33 @@ def test_binned_pair_backward_in_two_level_halves_equals_the_full_call(be):
             np.testing.assert_allclose(b2[sl].float().cpu().numpy(), a2[sl].float().cpu().numpy(), rtol=2e-3, atol=1e-2 * float(a2[sl].float().abs().max()))
     with pytest.raises(RuntimeError):
         L.call("n2m_grid_encode_backward_binned_pair_half", *args, 3)
+
+
+def test_colour_only_pair_backward_equals_the_pair_call(be):
+    """n2m_grid_encode_backward_binned_pair with grad1 = NULL (stage 1: the colour table alone through the shared-fill kernels) writes the
+    SAME colour-table gradient, bit for bit, as the full pair call on the same inputs -- the fp32 table's entries never enter the fp16
+    sums -- and leaves no trace elsewhere; gridencoder.binned_backward routes a lone C = 2 fp16 table there."""
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L
+    from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward, binned_backward_pair
+    B = 150001
+    g = torch.Generator(device="cuda").manual_seed(21)
+    # image-order-like coherent samples: a slow walk through the cube, so that consecutive lanes share cells on the coarse levels
+    t = torch.linspace(0, 1, B, device="cuda")
+    x = torch.stack([0.5 + 0.45 * torch.sin(37 * t), 0.5 + 0.45 * torch.cos(23 * t), 0.05 + 0.9 * t], -1).contiguous()
+    x = (x + 1e-3 * torch.rand(B, 3, device="cuda", generator=g)).clamp(0, 1).contiguous()
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    e2 = GridEncoder(level_dim=2, desired_resolution=2048).cuda()
+    rows = e1.embeddings.shape[0]
+    d1 = torch.randn(16, B, 1, device="cuda", generator=g) * 1e-3
+    d2 = (torch.randn(16, B, 2, device="cuda", generator=g) * 0.05).half()
+    a1 = torch.zeros(rows, 1, device="cuda"); a2 = torch.zeros(rows, 2, device="cuda", dtype=torch.float16)
+    assert binned_backward_pair(e1, e2, d1, d2, x, a1, a2, 16)
+    b2 = torch.zeros(rows, 2, device="cuda", dtype=torch.float16)
+    assert binned_backward(e2, d2, x, b2, 16)                      # -> the pair entry with grad1 = NULL
+    assert torch.equal(a2, b2)
+    assert float(b2.float().abs().sum()) > 0
+    # added onto what is there (not overwritten), like the single-table path
+    assert binned_backward(e2, d2, x, b2, 16)
+    ref = (a2.float() * 2)
+    assert float((b2.float() - ref).abs().max()) <= 2.0 ** -10 * float(ref.abs().max())
