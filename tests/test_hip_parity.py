@@ -1138,7 +1138,7 @@ def test_binned_pair_backward_in_two_level_halves_equals_the_full_call(be):
 
 def test_colour_only_pair_backward_equals_the_pair_call(be):
     """n2m_grid_encode_backward_binned_pair with grad1 = NULL (stage 1: the colour table alone through the shared-fill kernels) writes the
-    SAME colour-table gradient, bit for bit, as the full pair call on the same inputs -- the fp32 table's entries never enter the fp16
+    SAME colour-table gradient as the full pair call on the same inputs (bit for bit wherever the pair call itself is reproducible) -- the fp32 table's entries never enter the fp16
     sums -- and leaves no trace elsewhere; gridencoder.binned_backward routes a lone C = 2 fp16 table there."""
     torch = be["torch"]
     from nerf2mesh_amd import _lib as L
@@ -1158,7 +1158,12 @@ def test_colour_only_pair_backward_equals_the_pair_call(be):
     assert binned_backward_pair(e1, e2, d1, d2, x, a1, a2, 16)
     b2 = torch.zeros(rows, 2, device="cuda", dtype=torch.float16)
     assert binned_backward(e2, d2, x, b2, 16)                      # -> the pair entry with grad1 = NULL
-    assert torch.equal(a2, b2)
+    # levels whose partitions one work item owns (all hashed levels) are bit-reproducible; the small dense levels that are split over tile
+    # groups end in fp16 float atomics whose order differs from launch to launch (two identical calls differ there as well)
+    first_hashed = int(np.asarray(e1.host_offsets)[8])
+    assert torch.equal(a2[first_hashed:], b2[first_hashed:])
+    d = (a2[:first_hashed].float() - b2[:first_hashed].float()).abs()
+    assert float(d.max()) <= 2.0 ** -9 * float(a2[:first_hashed].float().abs().max())
     assert float(b2.float().abs().sum()) > 0
     # added onto what is there (not overwritten), like the single-table path
     assert binned_backward(e2, d2, x, b2, 16)
