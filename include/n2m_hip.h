@@ -290,7 +290,9 @@ int n2m_grid_encode_forward_packed(const float* inputs, const void* packed, cons
  * overwrite = 0: the sums are added onto grad_embeddings1/2 (zero-filled by the caller, or running sums) like the reference's
  * atomicAdd (gridencoder.cu:324-334); overwrite = 1: the call DEFINES both tables completely (all host_offsets[L] rows, zeros
  * included) -- no zero-fill beforehand and no read-modify-write in the flush.  * grad1 == NULL together with grad_embeddings1 == NULL: the COLOUR table alone through the same kernels (stage 1 shades with the colour
- * networks only, nerf/renderer.py:875-881): no density gradient is read, no fp32 log written, the fp32 accumulate not launched; no TV. */
+ * networks only, nerf/renderer.py:875-881): no density gradient is read, no fp32 log written, the fp32 accumulate not launched; no TV.
+ * grad2 == NULL together with grad_embeddings2 == NULL: the DENSITY table alone (the stacked finite-difference evaluations of the SDF head,
+ * nerf/network.py:143-154), TV allowed. */
 uint64_t n2m_grid_binned_pair_workspace_bytes(uint32_t B, uint32_t max_level, const int32_t* host_offsets);
 int n2m_grid_encode_backward_binned_pair(const float* grad1, const void* grad2, const float* inputs,
                                          const int32_t* host_offsets, float* grad_embeddings1,

@@ -1542,7 +1542,8 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
 #pragma unroll
             for (uint32_t d = 0; d < D; ++d) nx[d] = nx[d] * in_scale + in_offset;
             ng1 = grad1 ? grad1[(size_t)level * Bstride + s] : 0.0f;        // grad1 == NULL: colour table only (stage 1: the density branch is idle)
-            ng2 = *reinterpret_cast<const h2*>(grad2 + ((size_t)level * Bstride + s) * 2);
+            if (grad2) ng2 = *reinterpret_cast<const h2*>(grad2 + ((size_t)level * Bstride + s) * 2);      // grad2 == NULL: density table only
+            else ng2 = h2{(_Float16)0, (_Float16)0};
         }
     };
     request(tile);
@@ -1650,7 +1651,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
             if ((vmask >> c) & 1u) {
                 const uint32_t pos = cnt[e_pr[c] >> 16] + e_slot[c];         // position in the sorted tile
                 if (log_v1) stage_v1[pos] = e_v1[c];
-                stage_v2[pos] = e_v2[c];
+                if (log_v2) stage_v2[pos] = e_v2[c];
                 stage_rel[pos] = (uint16_t)(e_pr[c] & 0xFFFFu);
             }
         for (uint32_t i = tid; i < parts; i += 1024) cnt_next[i] = 0;        // the other counter set, for the next tile
@@ -1660,14 +1661,14 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
         const size_t seg = ((size_t)level * plan.tiles + tile) * kTileEntries;
         // streaming stores: the log is read back by another kernel, it need not displace the level's table lines in L2
         if (g_fill_timing_on & 2u) {                 // measurement switch: plain (cache-allocating) log stores
-            for (uint32_t i = tid; i < total; i += 1024) { if (log_v1) log_v1[seg + i] = stage_v1[i]; log_v2[seg + i] = stage_v2[i]; }
+            for (uint32_t i = tid; i < total; i += 1024) { if (log_v1) log_v1[seg + i] = stage_v1[i]; if (log_v2) log_v2[seg + i] = stage_v2[i]; }
             const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(stage_rel);
             uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(log_rel + seg);
             for (uint32_t i = tid; i < (total + 1u) / 2u; i += 1024) dst[i] = src[i];
         } else {
         for (uint32_t i = tid; i < total; i += 1024) {
             if (log_v1) __builtin_nontemporal_store(stage_v1[i], &log_v1[seg + i]);
-            __builtin_nontemporal_store(stage_v2[i], &log_v2[seg + i]);
+            if (log_v2) __builtin_nontemporal_store(stage_v2[i], &log_v2[seg + i]);
         }
         {   // rows as u32 pairs (seg is even; a trailing odd entry drags one stale u16 along: never read back)
             const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(stage_rel);
@@ -2228,10 +2229,12 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         const bool ow = overwrite && b0 == 0;                 // later passes add onto the first one's sums
         // grad1 == NULL: the colour table alone (stage 1 shades with the colour networks only, nerf/renderer.py:875-881): the fill neither
         // reads a density gradient nor writes its log, the fp32 accumulate is not launched, table1 is not touched
-        const bool both = grad1 != nullptr;
+        // grad2 == NULL: the density table alone (the stacked finite-difference evaluations of the SDF head, nerf/network.py:143-154)
+        const bool both = grad1 != nullptr, has2 = grad2 != nullptr;
         const float* g1 = both ? grad1 + (size_t)b0 : nullptr;
         if (!both) log_v1 = nullptr;
-        const _Float16* g2 = grad2 + (size_t)b0 * 2;
+        const _Float16* g2 = has2 ? grad2 + (size_t)b0 * 2 : nullptr;
+        if (!has2) log_v2 = nullptr;
         const float* x = inputs + (size_t)b0 * 3;
         // the fp32 table accumulates two partitions per work item: same item count and LDS bytes as on its own 8192-row structure
         // half != 0 (max_level == 16, XCD-aware fill): this call covers the levels of ONE fill slot only -- 1: levels 8..15 (slot 0),
@@ -2253,14 +2256,14 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
             items1 += pairs * g;
             items2 += lay.plan.parts[l] * lay.plan.groups[l];
             if (ow && g > 1u && both) cm1 |= 1u << l;              // levels that add atomically: cleared by the fill kernel
-            if (ow && lay.plan.groups[l] > 1u) cm2 |= 1u << l;
+            if (ow && lay.plan.groups[l] > 1u && has2) cm2 |= 1u << l;
         }
         plan1.item_prefix[max_level] = items1;
         plan2.item_prefix[max_level] = items2;
         if (ow && max_level < L) {                                  // levels the call does not touch
             const size_t t0 = (size_t)host_offsets[max_level], t1 = (size_t)host_offsets[L];
             if (both) N2M_HIP(hipMemsetAsync(table1 + t0, 0, (t1 - t0) * sizeof(float), s));
-            N2M_HIP(hipMemsetAsync(table2 + t0 * 2u, 0, (t1 - t0) * 2u * sizeof(_Float16), s));
+            if (has2) N2M_HIP(hipMemsetAsync(table2 + t0 * 2u, 0, (t1 - t0) * 2u * sizeof(_Float16), s));
         }
         static const uint32_t merge_levels = getenv("N2M_BIN_MERGE_LEVELS") ? (uint32_t)atoi(getenv("N2M_BIN_MERGE_LEVELS")) : kPairMergeLevels;
         static const bool xcd_map = getenv("N2M_FILL_NO_XCD") == nullptr;       // A/B switch; measured 332 -> 311 us for fill + accumulates
@@ -2294,9 +2297,11 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
                 table1, plan1, lv, gridtype, align, level_max, directory, nullptr, found_inf, log_rel, log_v1, ow, acc_dbg, 3.0e38f / odiv);
             N2M_CHECK_LAUNCH();
         }
-        bin_accumulate_kernel<_Float16, 2, kPairP, 1, true><<<nb, 1024, kPairP * 16, s>>>(table2, plan2, lv, gridtype, align, level_max + kMaxLevels,
-                                                                                        directory, nullptr, found_inf, log_rel, log_v2, ow, acc_dbg, 65504.0f / odiv);
-        N2M_CHECK_LAUNCH();
+        if (has2) {
+            bin_accumulate_kernel<_Float16, 2, kPairP, 1, true><<<nb, 1024, kPairP * 16, s>>>(table2, plan2, lv, gridtype, align, level_max + kMaxLevels,
+                                                                                            directory, nullptr, found_inf, log_rel, log_v2, ow, acc_dbg, 65504.0f / odiv);
+            N2M_CHECK_LAUNCH();
+        }
     }
     return 0;
 }
@@ -2542,15 +2547,16 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
                              void* workspace, uint64_t workspace_bytes, void* stream, int half) {
     const char* fn = "grid_encode_backward_binned_pair";
     if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
-    N2M_REQUIRE(grad2 && inputs && host_offsets && grad_embeddings2 && workspace, N2M_ENULL, "%s: NULL tensor", fn);
+    N2M_REQUIRE(inputs && host_offsets && workspace && (grad1 || grad2), N2M_ENULL, "%s: NULL tensor", fn);
     N2M_REQUIRE((grad1 == nullptr) == (grad_embeddings1 == nullptr), N2M_ENULL, "%s: grad1 and grad_embeddings1 come together (both NULL: colour table only)", fn);
+    N2M_REQUIRE((grad2 == nullptr) == (grad_embeddings2 == nullptr), N2M_ENULL, "%s: grad2 and grad_embeddings2 come together (both NULL: density table only)", fn);
     N2M_REQUIRE(grad1 != nullptr || tv_embeddings == nullptr, N2M_EINVAL, "%s: the TV term rides on the density table's entries", fn);
     N2M_REQUIRE(!tv_embeddings || max_level == L, N2M_EUNSUPPORTED, "%s: the fused TV term needs max_level == L", fn);
     hipStream_t s = (hipStream_t)stream;
     if (B == 0 || max_level == 0) {
         if (overwrite && host_offsets[L] > 0 && half != 2) {
             if (grad_embeddings1) N2M_HIP(hipMemsetAsync(grad_embeddings1, 0, (size_t)host_offsets[L] * sizeof(float), s));
-            N2M_HIP(hipMemsetAsync(grad_embeddings2, 0, (size_t)host_offsets[L] * 2u * sizeof(_Float16), s));
+            if (grad_embeddings2) N2M_HIP(hipMemsetAsync(grad_embeddings2, 0, (size_t)host_offsets[L] * 2u * sizeof(_Float16), s));
         }
         return 0;
     }
@@ -2558,7 +2564,7 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
     const TvParams tv{tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale, g_cfg_tv_stride.load()};
     // algorithmic bytes of BOTH encoders' backward + the TV stencil reads (a half call: its eight levels)
     const double lvls = half ? 8.0 : (double)max_level;
-    const double esz = grad1 ? 8.0 : 4.0;       // bytes per (vertex, table set): fp32 C=1 + fp16 C=2, or the colour table alone
+    const double esz = (grad1 && grad2) ? 8.0 : 4.0;       // bytes per (vertex, table set): fp32 C=1 + fp16 C=2, or one of them alone
     N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (12.0 + lvls * esz + 2.0 * lvls * 8 * esz + (tv_embeddings ? lvls * 7 * 4.0 : 0.0)));
     return launch_binned_pair(grad1, (const _Float16*)grad2, inputs, tv, grad_embeddings1, (_Float16*)grad_embeddings2, B, max_level, host_offsets, lv,
                               gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf, in_scale, in_offset, overwrite != 0, L,

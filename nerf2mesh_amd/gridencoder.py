@@ -124,6 +124,18 @@ def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level, tv=None, foun
                    max_level, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)),
                    enc.interp_id, None, 0.0, 0.0, 1.0, None, _p(found_inf), 1.0, 0.0, 0, _p(ws), ws.numel(), L.stream())
             return True
+    if C == 1 and dt == L.F32 and max_level > 0 and B > 0 and _PAIR_FOR_COLOR and (tv is None or max_level == enc.num_levels):
+        # the density table alone through the same kernels (grad2 = NULL): the 6 M stacked finite-difference samples of the SDF head
+        need = L.lib().n2m_grid_binned_pair_workspace_bytes(B, max_level, ho.ctypes.data)
+        if need != 0:
+            ws = L.workspace(x01.device, need, ws_slot)
+            tv_emb, tv_w, tv_wo, tv_in, tv_scale = tv if tv is not None else (None, 0.0, 0.0, 1.0, None)
+            L.grid_backward_config(1, 1.0)
+            L.call("n2m_grid_encode_backward_binned_pair", _p(grad_lm), None, _p(x01), ho.ctypes.data, _p(grad_embeddings), None, B, enc.num_levels,
+                   max_level, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)),
+                   enc.interp_id, _p(tv_emb), float(tv_w), float(tv_wo), float(tv_in), _p(tv_scale), _p(found_inf), 1.0, 0.0, 0, _p(ws),
+                   ws.numel(), L.stream())
+            return True
     need = L.lib().n2m_grid_binned_workspace_bytes(B, 3, C, max_level, ho.ctypes.data, dt, 0)
     if need == 0:
         return False

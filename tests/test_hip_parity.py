@@ -1169,3 +1169,33 @@ def test_colour_only_pair_backward_equals_the_pair_call(be):
     assert binned_backward(e2, d2, x, b2, 16)
     ref = (a2.float() * 2)
     assert float((b2.float() - ref).abs().max()) <= 2.0 ** -10 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("max_level", [16, 5])
+def test_density_only_pair_backward_equals_the_pair_call(be, max_level):
+    """grad2 = NULL: the density table alone through the shared-fill kernels (the SDF head's stacked finite-difference samples; progressive
+    max_level < 16 included), against the full pair call: bitwise on the levels a single work item owns, fp32 atomic-order noise on the
+    small dense levels that are split over tile groups."""
+    torch = be["torch"]
+    from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward, binned_backward_pair
+    B = 120007
+    g = torch.Generator(device="cuda").manual_seed(22)
+    t = torch.linspace(0, 1, B, device="cuda")
+    x = torch.stack([0.5 + 0.45 * torch.sin(31 * t), 0.5 + 0.45 * torch.cos(19 * t), 0.05 + 0.9 * t], -1)
+    x = (x + 1e-3 * torch.rand(B, 3, device="cuda", generator=g)).clamp(0, 1).contiguous()
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    e2 = GridEncoder(level_dim=2, desired_resolution=2048).cuda()
+    rows = e1.embeddings.shape[0]
+    d1 = torch.randn(16, B, 1, device="cuda", generator=g) * 1e-3
+    d2 = (torch.randn(16, B, 2, device="cuda", generator=g) * 0.05).half()
+    a1 = torch.zeros(rows, 1, device="cuda"); a2 = torch.zeros(rows, 2, device="cuda", dtype=torch.float16)
+    assert binned_backward_pair(e1, e2, d1, d2, x, a1, a2, max_level)
+    b1 = torch.zeros(rows, 1, device="cuda")
+    assert binned_backward(e1, d1, x, b1, max_level)               # -> the pair entry with grad2 = NULL
+    offs = np.asarray(e1.host_offsets)
+    lo, hi = int(offs[min(8, max_level)]), int(offs[max_level])
+    assert torch.equal(a1[lo:hi], b1[lo:hi])
+    assert float(b1[hi:].abs().max() if hi < rows else 0.0) == 0.0          # levels beyond max_level are not touched
+    d = (a1[:lo] - b1[:lo]).abs()
+    assert float(d.max()) <= 2e-6 * float(a1[:lo].abs().max())
+    assert float(b1.abs().sum()) > 0
