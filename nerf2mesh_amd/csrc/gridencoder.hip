@@ -2271,7 +2271,9 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         uint32_t groups_x = 0, slot_begin = 0;
         N2M_REQUIRE(half == 0 || (xcd_map && max_level == 16u && (half == 1 || half == 2)), N2M_EUNSUPPORTED,
                     "%s: level halves need max_level == 16 and the XCD-aware fill", fn);
-        if (xcd_map) {           // 1-D grid: 8 XCDs x ceil(levels / 8) level slots (rounded to pairs) x groups
+        // (the XCD-aware order deals level PAIRS (p, L-1-p) to the 8 XCDs: with fewer than 16 levels -- progressive training of the SDF recipe,
+        // max_level 4..15 -- it would leave most XCDs without work, so those calls keep the plain (group, level) grid)
+        if (xcd_map && (max_level == 16u || half != 0)) {           // 1-D grid: 8 XCDs x ceil(levels / 8) level slots (rounded to pairs) x groups
             groups_x = grid.x;
             uint32_t slots = 2u * ((max_level + 15u) / 16u);
             if (half != 0) { slot_begin = (uint32_t)half - 1u; slots = 1u; }
