@@ -314,6 +314,21 @@ int n2m_grid_encode_backward_binned_pair_half(const float* grad1, const void* gr
                                          float in_offset, int overwrite, void* workspace, uint64_t workspace_bytes,
                                          void* stream, int half);
 
+/* The TV terms of a batch on their own: tv_out[level, s] (f32 [L, B]) = the total-variation term of (sample s, level) exactly as the shared
+ * fill evaluates it in place when it is handed tv_embeddings (gridencoder.cu:505-609 on the cell floor(x * scale + 0.5); weight / weight_outer /
+ * inner01 / scale as in n2m_grid_encode_backward_binned_pair) -- and n2m_grid_encode_backward_binned_pair_tvt, the same backward consuming
+ * those terms instead of gathering the 7-point stencil itself (tv_terms [L, B]; half: 0 all levels, 1 levels 8..15, 2 levels 0..7).  The
+ * terms depend on the samples and the density table only, so a training step can evaluate them on a second stream beside its field kernels:
+ * the stencil's scattered gathers (45 us of the fill) leave the backward's critical path.  Results are bit-identical to the in-place form. */
+int n2m_grid_tv_terms(const float* inputs, const float* tv_embeddings, const int32_t* host_offsets, uint32_t B, uint32_t L, float S, uint32_t H,
+                      uint32_t gridtype, int align_corners, uint32_t interp, float tv_weight, float tv_weight_outer, float tv_inner01,
+                      const float* tv_scale, float in_scale, float in_offset, float* tv_out, void* stream);
+int n2m_grid_encode_backward_binned_pair_tvt(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
+                                             float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level, float S,
+                                             uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, const float* tv_terms,
+                                             float* found_inf, float in_scale, float in_offset, int overwrite, void* workspace,
+                                             uint64_t workspace_bytes, void* stream, int half);
+
 /* ------------------------------------------------------------------------------------------------------
  * marching cubes   (reference: `mcubes.marching_cubes(volume, isovalue)` -- PyMCubes, an un-vendored dependency; call sites
  * nerf/renderer.py:524-527 (stage-0 mesh), :563 and :616 (outer cascades).  SURVEY.md section 8f-4.)

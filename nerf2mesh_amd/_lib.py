@@ -52,6 +52,9 @@ SIGNATURES = {
                                              _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _int, _vp, _u64, _vp],
     "n2m_grid_encode_backward_binned_pair_half": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
                                                   _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _int, _vp, _u64, _vp, _int],
+    "n2m_grid_tv_terms": [_vp, _vp, _vp, _u32, _u32, _f32, _u32, _u32, _int, _u32, _f32, _f32, _f32, _vp, _f32, _f32, _vp, _vp],
+    "n2m_grid_encode_backward_binned_pair_tvt": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
+                                                 _vp, _vp, _f32, _f32, _int, _vp, _u64, _vp, _int],
     "n2m_grad_total_variation_binned": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _vp, _u64, _vp],
     "n2m_marching_cubes_workspace_bytes": [_u32, _u32, _u32],                                  # returns uint64 (RESTYPES)
     "n2m_marching_cubes_count": [_vp, _u32, _u32, _u32, ctypes.c_double, _vp, _u64, _vp, _vp],

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "n2m_common.hpp"
 
@@ -1315,30 +1316,16 @@ struct PairCtx {
     TvParams tv; const float* tv_tab; float scale; uint32_t resolution; bool align_corners; uint32_t interp;
 };
 
-template <bool TV, int IMODE, bool ILV>
-__device__ __forceinline__ void pair_entries(const PairCtx& cx, const Indexer<3>& ix, const PartMap& pm, const float (&x)[3], float g1,
-                                             float g2x, float g2y, float a1, float& vmax1, uint32_t (&e_pr)[8], float (&f1)[8],
-                                             float (&f2x)[8], float (&f2y)[8], uint32_t (&cell)[3]) {
+// TV term of one (sample, level): gridencoder.cu:505-609 on the cell floor(x * scale + 0.5) -- vertex 000 of the interpolation cell.  One
+// function for the fill that computes it in place (TV mode 1) and for the stand-alone pre-pass n2m_grid_tv_terms (whose result the fill
+// of TV mode 2 reads back): identical bits either way.
+template <int IMODE>
+__device__ __forceinline__ float pair_tv_value(const PairCtx& cx, const Indexer<3>& ix, const float (&x)[3], uint32_t (&cell)[3],
+                                               const uint32_t (&rows)[8], const uint32_t (&tx)[2], const uint32_t (&ty)[2],
+                                               const uint32_t (&tz)[2], uint32_t sy, uint32_t sz) {
     constexpr uint32_t D = 3;
-    float frac[D], dfrac[D];
-    locate<D>(x, cx.scale, cx.align_corners, cx.interp, cell, frac, dfrac);
-    const uint32_t sy = IMODE == 1 ? kPrimes[1] : ix.stride[1], sz = IMODE == 1 ? kPrimes[2] : ix.stride[2];
-    const uint32_t tx[2] = {cell[0], cell[0] + 1u};
-    const uint32_t ty0 = cell[1] * sy, tz0 = cell[2] * sz;
-    const uint32_t ty[2] = {ty0, ty0 + sy}, tz[2] = {tz0, tz0 + sz};
     auto comb = [&](uint32_t a, uint32_t b, uint32_t c) { return IMODE == 1 ? ((a ^ b ^ c) & ix.mask) : (a + b + c); };
-    uint32_t rows[8];
-#pragma unroll
-    for (uint32_t corner = 0; corner < 8; ++corner) {
-        const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
-        if constexpr (IMODE != 0) rows[corner] = comb(tx[i], ty[j], tz[k]);
-        else {
-            const uint32_t v[D] = {cell[0] + i, cell[1] + j, cell[2] + k};
-            rows[corner] = ix.row(v);
-        }
-    }
     float tvv = 0.0f;
-    if constexpr (TV) {
         const bool inner = fmaxf(fmaxf(fabsf(x[0] - 0.5f), fabsf(x[1] - 0.5f)), fabsf(x[2] - 0.5f)) <= cx.tv.inner01;
         float w = (inner ? cx.tv.weight : cx.tv.weight_outer);
         if (cx.tv.scale_ptr) w *= *cx.tv.scale_ptr;
@@ -1387,6 +1374,35 @@ __device__ __forceinline__ void pair_entries(const PairCtx& cx, const Indexer<3>
                 if (nb_ok[k]) { const float dv = centre - nb[k]; sum += dv; sq += dv * dv; }
             tvv = w * sum * (1.0f / sqrtf(sq + 1e-9f));
         }
+    return tvv;
+}
+
+template <int TV, int IMODE, bool ILV>
+__device__ __forceinline__ void pair_entries(const PairCtx& cx, const Indexer<3>& ix, const PartMap& pm, const float (&x)[3], float g1,
+                                             float g2x, float g2y, float a1, float& vmax1, uint32_t (&e_pr)[8], float (&f1)[8],
+                                             float (&f2x)[8], float (&f2y)[8], uint32_t (&cell)[3], float tv_given = 0.0f) {
+    constexpr uint32_t D = 3;
+    float frac[D], dfrac[D];
+    locate<D>(x, cx.scale, cx.align_corners, cx.interp, cell, frac, dfrac);
+    const uint32_t sy = IMODE == 1 ? kPrimes[1] : ix.stride[1], sz = IMODE == 1 ? kPrimes[2] : ix.stride[2];
+    const uint32_t tx[2] = {cell[0], cell[0] + 1u};
+    const uint32_t ty0 = cell[1] * sy, tz0 = cell[2] * sz;
+    const uint32_t ty[2] = {ty0, ty0 + sy}, tz[2] = {tz0, tz0 + sz};
+    auto comb = [&](uint32_t a, uint32_t b, uint32_t c) { return IMODE == 1 ? ((a ^ b ^ c) & ix.mask) : (a + b + c); };
+    uint32_t rows[8];
+#pragma unroll
+    for (uint32_t corner = 0; corner < 8; ++corner) {
+        const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
+        if constexpr (IMODE != 0) rows[corner] = comb(tx[i], ty[j], tz[k]);
+        else {
+            const uint32_t v[D] = {cell[0] + i, cell[1] + j, cell[2] + k};
+            rows[corner] = ix.row(v);
+        }
+    }
+    float tvv = 0.0f;
+    if constexpr (TV != 0) {
+        if constexpr (TV == 1) tvv = pair_tv_value<IMODE>(cx, ix, x, cell, rows, tx, ty, tz, sy, sz);
+        else tvv = tv_given;                       // precomputed by n2m_grid_tv_terms (same function, same bits)
         const float a = fabsf(tvv);
         vmax1 = fmaxf(vmax1, (a1 <= 3.0e38f ? a1 : 1.0f) + (a <= 3.0e38f ? a : 1.0f));       // |w*g + tv| <= |g| + |tv|
     }
@@ -1396,7 +1412,7 @@ __device__ __forceinline__ void pair_entries(const PairCtx& cx, const Indexer<3>
         const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
         const float w = (wx[i] * wy[j]) * wz[k];                     // forward's association
         float p1 = w * g1;
-        if (TV && corner == 0) p1 += tvv;
+        if (TV != 0 && corner == 0) p1 += tvv;
         f1[corner] = p1;
         f2x[corner] = (float)half_product(w, g2x);                   // each product rounded to half like the reference (:326)
         f2y[corner] = (float)half_product(w, g2y);
@@ -1456,16 +1472,60 @@ __device__ __forceinline__ bool merge_runs(bool inside, const uint32_t (&cell)[3
     return last;
 }
 
+// The TV terms of a batch on their own (n2m_grid_tv_terms): tv_out[level, s] = pair_tv_value of (sample s, level) -- what the shared fill adds
+// to vertex 000's entry.  Reads the samples and the density table only, i.e. nothing the step produces after its forward lookup: the step
+// executor runs it on a side stream beside the field kernels (MFMA / latency bound, they leave the L2 request path idle) and hands the fill
+// the finished terms.  Grid (tiles of 256 samples, level).
+__global__ void __launch_bounds__(256)
+tv_terms_kernel(const float* __restrict__ inputs, TvParams tv, uint32_t B, uint32_t Bstride, BinPlan plan, LevelTable lv, uint32_t gridtype,
+                bool align_corners, uint32_t interp, float in_scale, float in_offset, float* __restrict__ tv_out) {
+    constexpr uint32_t D = 3;
+    const uint32_t level = blockIdx.y, s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= B) return;
+    float x[D];
+    load_point<D>(inputs, s, x);
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) x[d] = x[d] * in_scale + in_offset;
+    float tvv = 0.0f;
+    if (!outside_unit_cube<D>(x)) {
+        const uint32_t size = plan.size[level];
+        const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
+        const PairCtx cx{tv, tv.table + (size_t)plan.row0[level] * tv.stride, lv.scale[level], lv.resolution[level], align_corners, interp};
+        const bool fast_hash = ix.hashed && ix.pow2, fast_dense = !ix.hashed && !ix.wrap;
+        uint32_t cell[D];
+        float frac[D], dfrac[D];
+        locate<D>(x, cx.scale, align_corners, interp, cell, frac, dfrac);
+        auto run = [&](auto mode) {
+            constexpr int IMODE = decltype(mode)::value;
+            const uint32_t sy = IMODE == 1 ? kPrimes[1] : ix.stride[1], sz = IMODE == 1 ? kPrimes[2] : ix.stride[2];
+            const uint32_t tx[2] = {cell[0], cell[0] + 1u};
+            const uint32_t ty0 = cell[1] * sy, tz0 = cell[2] * sz;
+            const uint32_t ty[2] = {ty0, ty0 + sy}, tz[2] = {tz0, tz0 + sz};
+            auto comb = [&](uint32_t a, uint32_t b, uint32_t c) { return IMODE == 1 ? ((a ^ b ^ c) & ix.mask) : (a + b + c); };
+            uint32_t rows[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            if constexpr (IMODE != 0) { rows[0] = comb(tx[0], ty[0], tz[0]); rows[1] = comb(tx[1], ty[0], tz[0]); rows[2] = comb(tx[0], ty[1], tz[0]); rows[4] = comb(tx[0], ty[0], tz[1]); }
+            else { const uint32_t v[D] = {cell[0], cell[1], cell[2]}; rows[0] = ix.row(v); }
+            return pair_tv_value<IMODE>(cx, ix, x, cell, rows, tx, ty, tz, sy, sz);
+        };
+        if (fast_hash) tvv = run(std::integral_constant<int, 1>{});
+        else if (fast_dense) tvv = run(std::integral_constant<int, 2>{});
+        else tvv = run(std::integral_constant<int, 0>{});
+    }
+    tv_out[(size_t)level * Bstride + s] = tvv;
+}
+
 // Measurement aid (n2m_debug_fill_times): shader-clock stamps of two workgroups' first 8 tile iterations, 6 per iteration --
 // loop top, entries ready, after barrier 1 (slots counted), after barrier 3 (run starts), after barrier 4 (tile staged), log stores issued.
 __device__ unsigned int g_fill_timing_on;
 __device__ unsigned long long g_fill_t[2][8][6];     // workgroup 3 (a fine, hashed level) and workgroup gridDim/2 + 3 (a coarse, dense one)
 #define N2M_FILL_STAMP(i) do { if (stamp && it < 8u) g_fill_t[stamp_w][it][(i)] = __builtin_readcyclecounter(); } while (0)
 
-template <bool TV>
+// TV: 0 none, 1 computed in place (pair_tv_value), 2 read from `tv_terms` [L, Bstride] (n2m_grid_tv_terms wrote it earlier, beside the
+// field kernels: the stencil's scattered gathers -- 45 us of this kernel -- then run where nobody waits for the L2 request path)
+template <int TV>
 __global__ void __launch_bounds__(1024)
 bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Float16* __restrict__ grad2 /*[L,Bstride,2]*/,
-                     const float* __restrict__ inputs, TvParams tv, uint32_t B, uint32_t Bstride, BinPlan plan, LevelTable lv,
+                     const float* __restrict__ inputs, TvParams tv, const float* __restrict__ tv_terms, uint32_t B, uint32_t Bstride, BinPlan plan, LevelTable lv,
                      uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max /*[2][32]*/,
                      uint32_t* __restrict__ directory, uint16_t* __restrict__ log_rel, uint32_t* __restrict__ log_v1,
                      uint32_t* __restrict__ log_v2, float* __restrict__ found_inf, float in_scale, float in_offset,
@@ -1532,7 +1592,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
 
     // inputs of the first tile
     uint32_t tile = group;
-    float nx[D] = {2.f, 2.f, 2.f}, ng1 = 0.0f;
+    float nx[D] = {2.f, 2.f, 2.f}, ng1 = 0.0f, ntv = 0.0f;
     h2 ng2 = {(_Float16)0, (_Float16)0};
     auto request = [&](uint32_t t) {
         const uint32_t s = t * 1024u + tid;
@@ -1544,6 +1604,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
             ng1 = grad1 ? grad1[(size_t)level * Bstride + s] : 0.0f;        // grad1 == NULL: colour table only (stage 1: the density branch is idle)
             if (grad2) ng2 = *reinterpret_cast<const h2*>(grad2 + ((size_t)level * Bstride + s) * 2);      // grad2 == NULL: density table only
             else ng2 = h2{(_Float16)0, (_Float16)0};
+            if (TV == 2) ntv = tv_terms[(size_t)level * Bstride + s];
         }
     };
     request(tile);
@@ -1556,7 +1617,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
         uint32_t* cnt = cnt2[it & 1u];
         uint32_t* cnt_next = cnt2[(it & 1u) ^ 1u];
         float x[D] = {nx[0], nx[1], nx[2]};
-        const float g1 = ng1;
+        const float g1 = ng1, tvg = ntv;
         const h2 g2 = ng2;
         request(tile + n_groups);                        // next tile's inputs are in flight while this one is processed
 
@@ -1577,10 +1638,10 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
             if (bad2) vmax2 = fmaxf(vmax2, 1.0f);
             const PairCtx cx{tv, tv.table ? tv.table + (size_t)plan.row0[level] * tv.stride : nullptr, scale, lv.resolution[level], align_corners, interp};
             // one straight-line body per index mode (wave-uniform per level) instead of three-way branches around every row
-            if (fast_hash) pair_entries<TV, 1, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell);
-            else if (fast_dense && parts > 1u) pair_entries<TV, 2, true>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell);
-            else if (fast_dense) pair_entries<TV, 2, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell);
-            else pair_entries<TV, 0, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell);
+            if (fast_hash) pair_entries<TV, 1, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
+            else if (fast_dense && parts > 1u) pair_entries<TV, 2, true>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
+            else if (fast_dense) pair_entries<TV, 2, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
+            else pair_entries<TV, 0, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
         }
         bool keep = inside;
         if (level < merge_levels) {                                    // block-uniform
@@ -2204,11 +2265,12 @@ int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table
 int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* inputs, TvParams tv, float* table1, _Float16* table2, uint32_t B,
                        uint32_t max_level, const int32_t* host_offsets, const LevelTable& lv, uint32_t gridtype, bool align, uint32_t interp,
                        void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn, float* found_inf, float in_scale,
-                       float in_offset, bool overwrite, uint32_t L, int half = 0) {
+                       float in_offset, bool overwrite, uint32_t L, int half = 0, const float* tv_terms = nullptr) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
-        (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
+        (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
+        (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
+        (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
         (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<float, 1, kPairP, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
         (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<_Float16, 2, kPairP, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
         attr_set = true;
@@ -2279,14 +2341,13 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
             if (half != 0) { slot_begin = (uint32_t)half - 1u; slots = 1u; }
             grid = dim3(8u * slots * groups_x, 1);
         }
-        if (tv.table)
-            bin_fill_pair_kernel<true><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
-                                                                             directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset, ow ? table1 : nullptr,
-                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token);
-        else
-            bin_fill_pair_kernel<false><<<grid, 1024, kTileEntries * 10, s>>>(g1, g2, x, tv, Bc, B, lay.plan, lv, gridtype, align, interp, level_max,
-                                                                              directory, log_rel, log_v1, log_v2, found_inf, in_scale, in_offset, ow ? table1 : nullptr,
-                                                                             ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token);
+        const float* tvt = tv_terms ? tv_terms + (size_t)b0 : nullptr;          // [L, B]: this pass's column block
+#define N2M_FILL_ARGS g1, g2, x, tv, tvt, Bc, B, lay.plan, lv, gridtype, align, interp, level_max, directory, log_rel, log_v1, log_v2, found_inf, in_scale, \
+                      in_offset, ow ? table1 : nullptr, ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token
+        if (tv.table) bin_fill_pair_kernel<1><<<grid, 1024, kTileEntries * 10, s>>>(N2M_FILL_ARGS);
+        else if (tvt) bin_fill_pair_kernel<2><<<grid, 1024, kTileEntries * 10, s>>>(N2M_FILL_ARGS);
+        else bin_fill_pair_kernel<0><<<grid, 1024, kTileEntries * 10, s>>>(N2M_FILL_ARGS);
+#undef N2M_FILL_ARGS
         N2M_CHECK_LAUNCH();
         const uint32_t items = items2;
         static const uint32_t acc_cap2 = getenv("N2M_ACC_GRID") ? (uint32_t)atoi(getenv("N2M_ACC_GRID")) : 4096u;
@@ -2516,7 +2577,7 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
                              float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                              const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
                              const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
-                             void* workspace, uint64_t workspace_bytes, void* stream, int half);
+                             void* workspace, uint64_t workspace_bytes, void* stream, int half, const float* tv_terms = nullptr);
 
 extern "C" int n2m_grid_encode_backward_binned_pair(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
                                                     float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
@@ -2546,7 +2607,7 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
                              float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                              const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
                              const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
-                             void* workspace, uint64_t workspace_bytes, void* stream, int half) {
+                             void* workspace, uint64_t workspace_bytes, void* stream, int half, const float* tv_terms) {
     const char* fn = "grid_encode_backward_binned_pair";
     if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
     N2M_REQUIRE(inputs && host_offsets && workspace && (grad1 || grad2), N2M_ENULL, "%s: NULL tensor", fn);
@@ -2567,10 +2628,46 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
     // algorithmic bytes of BOTH encoders' backward + the TV stencil reads (a half call: its eight levels)
     const double lvls = half ? 8.0 : (double)max_level;
     const double esz = (grad1 && grad2) ? 8.0 : 4.0;       // bytes per (vertex, table set): fp32 C=1 + fp16 C=2, or one of them alone
-    N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (12.0 + lvls * esz + 2.0 * lvls * 8 * esz + (tv_embeddings ? lvls * 7 * 4.0 : 0.0)));
+    N2M_REQUIRE(!(tv_terms && tv_embeddings), N2M_EINVAL, "%s: either the TV table (computed in place) or precomputed TV terms", fn);
+    N2M_REQUIRE(!tv_terms || (grad1 && max_level == L), N2M_EINVAL, "%s: TV terms ride on the density table's entries and need max_level == L", fn);
+    // (+ the TV stencil's reads when it is evaluated in place; precomputed terms: 4 B per (sample, level), the stencil is n2m_grid_tv_terms')
+    N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (12.0 + lvls * esz + 2.0 * lvls * 8 * esz + (tv_embeddings ? lvls * 7 * 4.0 : 0.0) + (tv_terms ? lvls * 4.0 : 0.0)));
     return launch_binned_pair(grad1, (const _Float16*)grad2, inputs, tv, grad_embeddings1, (_Float16*)grad_embeddings2, B, max_level, host_offsets, lv,
                               gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf, in_scale, in_offset, overwrite != 0, L,
-                              half);
+                              half, tv_terms);
+}
+
+// The same call with the TV terms of the batch precomputed by n2m_grid_tv_terms (tv_terms [L, B] f32): the fill adds tv_terms[level, s] to
+// vertex 000's entry instead of gathering the stencil itself.  Same bits as the tv_embeddings form (one device function computes the term).
+extern "C" int n2m_grid_encode_backward_binned_pair_tvt(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
+                                                        float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
+                                                        float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                                        const float* tv_terms, float* found_inf, float in_scale, float in_offset, int overwrite,
+                                                        void* workspace, uint64_t workspace_bytes, void* stream, int half) {
+    N2M_REQUIRE(half >= 0 && half <= 2, N2M_EINVAL, "grid_encode_backward_binned_pair_tvt: half must be 0 (all levels), 1 (8..15) or 2 (0..7)");
+    return binned_pair_entry(grad1, grad2, inputs, host_offsets, grad_embeddings1, grad_embeddings2, B, L, max_level, S, H, gridtype, align_corners,
+                             interp, nullptr, 0.0f, 0.0f, 1.0f, nullptr, found_inf, in_scale, in_offset, overwrite, workspace, workspace_bytes, stream,
+                             half, tv_terms);
+}
+
+// TV terms of a batch: tv_out[level, s] for B samples, all L levels (what the shared fill would add to vertex 000's entry of the density table).
+extern "C" int n2m_grid_tv_terms(const float* inputs, const float* tv_embeddings, const int32_t* host_offsets, uint32_t B, uint32_t L, float S,
+                                 uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, float tv_weight, float tv_weight_outer,
+                                 float tv_inner01, const float* tv_scale, float in_scale, float in_offset, float* tv_out, void* stream) {
+    const char* fn = "grid_tv_terms";
+    if (int rc = check_dims(fn, 3, 1, L, L, N2M_F32)) return rc;
+    N2M_REQUIRE(inputs && tv_embeddings && host_offsets && tv_out, N2M_ENULL, "%s: NULL tensor", fn);
+    N2M_REQUIRE(B <= kBinChunk, N2M_EUNSUPPORTED, "%s: at most %u samples per call", fn, kBinChunk);
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const BinLayout lay = make_bin_plan(B, 2, L, host_offsets, false, kPairP, 2);
+    N2M_REQUIRE(lay.ok, N2M_EUNSUPPORTED, "%s: table layout not supported", fn);
+    const LevelTable lv = make_levels(L, S, H);
+    const TvParams tv{tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale, g_cfg_tv_stride.load()};
+    N2M_PROF(N2M_K_GRID_TV, s, (double)B * (12.0 + (double)L * 7 * 4.0 + (double)L * 4.0));
+    tv_terms_kernel<<<dim3(n2m_ceil_div(B, 256), L), 256, 0, s>>>(inputs, tv, B, B, lay.plan, lv, gridtype, align_corners != 0, interp, in_scale, in_offset, tv_out);
+    N2M_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int n2m_grid_encode_forward_pair(const float* inputs, const float* embeddings1, const void* embeddings2, const int32_t* offsets,

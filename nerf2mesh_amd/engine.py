@@ -95,6 +95,10 @@ class Stage0Engine:
             from .parallel import GradSync
             self.sync = GradSync(model, world_size)
         self.side = L.side_stream(dev, slot=2)
+        # TV terms of the batch on a third stream beside the field kernels (n2m_grid_tv_terms): the stencil's gathers leave the backward's
+        # critical path (A/B: N2M_TV_SPLIT=0 evaluates them inside the fill as before; same bits)
+        self.tv_stream = L.side_stream(dev, slot=3)
+        self.tv_split = os.environ.get("N2M_TV_SPLIT", "1") != "0"
         self.split_backward = True            # multi-rank: table backward in two level halves, the first half's all-reduce under the second
         self.overlap = True                   # next batch on the side stream (False: everything on the main stream, same results)
         self.single_pass = os.environ.get("N2M_MARCH_PASSES", "1") != "2"      # one-launch marcher (A/B: N2M_MARCH_PASSES=2)
@@ -206,6 +210,7 @@ class Stage0Engine:
             w["h2"] = torch.empty(32 * cm, dtype=torch.float16, device=dev)
             w["d_h2"] = torch.empty(32 * cm, dtype=torch.float16, device=dev)
             w["sigma"], w["rgb"], w["weights"], w["d_sr"] = f(cm), f(3 * cm), f(cm), f(4 * cm)
+            w["tv"] = f(16 * cm)
             w["spec_partial"] = torch.zeros(self._n_spec, dtype=torch.float32, device=dev)
             w["ws"], w["depth"], w["image"], w["d_image"], w["d_ws"], w["bg"] = f(cn), f(cn), f(3 * cn), f(3 * cn), f(cn), f(3 * cn)
             w["partial"] = f((cn + 3) // 4 + 1)
@@ -506,10 +511,27 @@ class Stage0Engine:
         pk = model.packed_tables()
         sw = self.mlp_params
         e1 = model.encoder
+        # seed gradient = loss scale [/ world]: gradients are SUMMED over ranks
+        seed = o.scale if self.world == 1 else o.scale / self.world
         # ---- forward
         if M > 0:
             L.call("n2m_grid_encode_forward_packed", _p(xyzs), _p(pk), _p(e1.offsets), _p(w["h1"]), _p(w["h2"]), M, self.Lv, self.Lv, self.S,
                    self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, float(self.aff[0]), float(self.aff[1]), s)
+            tv_terms = None
+            if opt.lambda_tv > 0 and self.tv_split and self.Lv == 16:
+                # the TV terms need the samples and the density table only: evaluated on their own stream while the field kernels run
+                fwd_done = torch.cuda.Event()
+                fwd_done.record()
+                self.tv_stream.wait_event(fwd_done)
+                L.grid_backward_config(*self._bwd_cfg)
+                with torch.cuda.stream(self.tv_stream):
+                    L.call("n2m_grid_tv_terms", _p(xyzs), _p(pk) if self.shard else _p(e1.embeddings), self.ho.ctypes.data, M, self.Lv, self.S, self.H0,
+                           e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, float(opt.lambda_tv),
+                           float(opt.lambda_tv * (10 if opt.bound > 1 else 1)), float(0.5 / model.bound),
+                           _p(seed), float(self.aff[0]), float(self.aff[1]), _p(w["tv"]), L.stream())
+                    self._tv_done = torch.cuda.Event()
+                    self._tv_done.record()
+                tv_terms = w["tv"]
             # full shading: the specular regulariser (nerf/utils.py:733-737) rides in the field kernels -- the forward leaves per-workgroup
             # sums of specular^2, the backward adds 2 lambda / M * specular * seed to the recomputed activation's gradient; the [M,3]
             # specular tensor is neither written nor read
@@ -519,7 +541,6 @@ class Stage0Engine:
         bg_t, bg_s = (bg, 0.0) if random_bg else (None, 1.0)
         lam_rgb, lam_mask = float(opt.lambda_rgb), float(max(opt.lambda_mask, 0.0))
         # ---- compositing + loss head + both backward passes: one launch (seed gradient = loss scale [/ world]: gradients are SUMMED over ranks)
-        seed = o.scale if self.world == 1 else o.scale / self.world
         early = None
         d_sigma, d_rgb = w["d_sr"][:max(M, 1)], w["d_sr"][max(M, 1):4 * max(M, 1)]
         # (+ the entropy regulariser of config 4, nerf/utils.py:728-733: its per-sample gradient is the backward's grad_weights)
@@ -535,20 +556,26 @@ class Stage0Engine:
             need = L.lib().n2m_grid_binned_pair_workspace_bytes(M, self.Lv, self.ho.ctypes.data)
             ws = L.workspace(dev, need)
             tv = opt.lambda_tv > 0
-            bwd_args = (_p(w["d_h1"]), _p(w["d_h2"]), _p(xyzs), self.ho.ctypes.data, _p(self.g1), _p(self.g2), M,
-                        self.Lv, self.Lv, self.S, self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id,
-                        (_p(pk) if self.shard else _p(e1.embeddings)) if tv else None, float(opt.lambda_tv), float(opt.lambda_tv * (10 if opt.bound > 1 else 1)),
-                        float(0.5 / model.bound), _p(seed) if tv else None, _p(o.found_inf), float(self.aff[0]), float(self.aff[1]), 1, _p(ws),
-                        ws.numel(), s)
+            common = (_p(w["d_h1"]), _p(w["d_h2"]), _p(xyzs), self.ho.ctypes.data, _p(self.g1), _p(self.g2), M,
+                      self.Lv, self.Lv, self.S, self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id)
+            tail = (_p(o.found_inf), float(self.aff[0]), float(self.aff[1]), 1, _p(ws), ws.numel(), s)
+            if tv_terms is not None:
+                torch.cuda.current_stream(dev).wait_event(self._tv_done)
+                backward = lambda half: L.call("n2m_grid_encode_backward_binned_pair_tvt", *common, _p(tv_terms), *tail, half)
+            else:
+                tv_args = ((_p(pk) if self.shard else _p(e1.embeddings)) if tv else None, float(opt.lambda_tv),
+                           float(opt.lambda_tv * (10 if opt.bound > 1 else 1)), float(0.5 / model.bound), _p(seed) if tv else None)
+                backward = lambda half: (L.call("n2m_grid_encode_backward_binned_pair", *common, *tv_args, *tail) if half == 0 else
+                                         L.call("n2m_grid_encode_backward_binned_pair_half", *common, *tv_args, *tail, half))
             if self.marker_at == 1:
                 self._marker = torch.cuda.Event(); self._marker.record()
             if self.shard:
                 import torch.distributed as dist
                 sp = self._split
                 rs = lambda out, src: dist.reduce_scatter_tensor(out.view(-1), src.view(-1), op=dist.ReduceOp.SUM, async_op=True)
-                L.call("n2m_grid_encode_backward_binned_pair_half", *bwd_args, 1)
+                backward(1)
                 early = [rs(self.g1s["f"], self.g1[sp:]), rs(self.g2s["f"], self.g2[sp:])]          # fine rows: exchanged under the coarse half
-                L.call("n2m_grid_encode_backward_binned_pair_half", *bwd_args, 2)
+                backward(2)
                 early += [rs(self.g1s["c"], self.g1[:sp]), rs(self.g2s["c"], self.g2[:sp])]
             elif self.sync is not None and self.split_backward and self.Lv == 16:
                 # multi-GPU: the table backward in two halves of the levels.  The rows of the fine half (levels 8..15: 68 % of the
@@ -556,11 +583,11 @@ class Stage0Engine:
                 # still being computed, so most of the exchange hides behind the backward's own tail (at 0.75 ms per step
                 # a 49 MB all-reduce no longer is the "< 4 %" the survey estimated at 26 ms per step)
                 split = int(self.ho[8])
-                L.call("n2m_grid_encode_backward_binned_pair_half", *bwd_args, 1)
+                backward(1)
                 early = self.sync.all_reduce_sum_begin([self.g1[split:], self.g2[split:]], [])
-                L.call("n2m_grid_encode_backward_binned_pair_half", *bwd_args, 2)
+                backward(2)
             else:
-                L.call("n2m_grid_encode_backward_binned_pair", *bwd_args)
+                backward(0)
         else:
             # no sample in the batch: every gradient is zero (the reduction below still takes part on every rank)
             self.g1.zero_()

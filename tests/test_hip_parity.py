@@ -1199,3 +1199,60 @@ def test_density_only_pair_backward_equals_the_pair_call(be, max_level):
     d = (a1[:lo] - b1[:lo]).abs()
     assert float(d.max()) <= 2e-6 * float(a1[:lo].abs().max())
     assert float(b1.abs().sum()) > 0
+
+
+def test_precomputed_tv_terms_equal_the_in_place_stencil(be):
+    """n2m_grid_tv_terms + n2m_grid_encode_backward_binned_pair_tvt (the TV terms of the batch evaluated ahead of the backward, on another
+    stream in the step executor) against the pair call that gathers the stencil inside its fill: one device function computes the term,
+    so the density-table gradient is the same bit for bit on every level a single work item owns (fp32 atomic-order noise on the small split
+    dense levels, as between two identical calls); with the inner / outer weighting of bound > 1 and a loss scale on the device."""
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L
+    from nerf2mesh_amd.gridencoder import GridEncoder, _host_offsets
+    p = L.ptr
+    B = 100003
+    g = torch.Generator(device="cuda").manual_seed(23)
+    t = torch.linspace(0, 1, B, device="cuda")
+    x = torch.stack([0.5 + 0.49 * torch.sin(29 * t), 0.5 + 0.49 * torch.cos(17 * t), 0.01 + 0.98 * t], -1)
+    x = (x + 1e-3 * torch.rand(B, 3, device="cuda", generator=g)).clamp(0, 1).contiguous()
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    with torch.no_grad():
+        e1.embeddings.uniform_(-1e-2, 1e-2)
+    rows = e1.embeddings.shape[0]
+    ho = _host_offsets(e1)
+    S, H0 = float(np.log2(e1.per_level_scale)), int(e1.base_resolution)
+    d1 = torch.randn(16, B, device="cuda", generator=g) * 1e-3
+    d2 = (torch.randn(16, B, 2, device="cuda", generator=g) * 0.05).half()
+    scale = torch.tensor(512.0, device="cuda")
+    lam, lam_out, inner = 1e-4, 1e-3, 0.25
+    emb = e1.embeddings.detach().contiguous()
+    need = L.lib().n2m_grid_binned_pair_workspace_bytes(B, 16, ho.ctypes.data)
+    ws = L.workspace(x.device, need)
+    L.grid_backward_config(1, 1.0)
+    outs = []
+    for split in (False, True):
+        g1 = torch.empty(rows, 1, device="cuda"); g2 = torch.empty(rows, 2, device="cuda", dtype=torch.float16)
+        finf = torch.zeros((), device="cuda")
+        common = (p(d1), p(d2), p(x), ho.ctypes.data, p(g1), p(g2), B, 16, 16, S, H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id)
+        tail = (p(finf), 1.0, 0.0, 1, p(ws), ws.numel(), L.stream())
+        if split:
+            terms = torch.empty(16, B, device="cuda")
+            L.call("n2m_grid_tv_terms", p(x), p(emb), ho.ctypes.data, B, 16, S, H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, lam,
+                   lam_out, inner, p(scale), 1.0, 0.0, p(terms), L.stream())
+            assert float(terms.abs().max()) > 0
+            L.call("n2m_grid_encode_backward_binned_pair_tvt", *common, p(terms), *tail, 0)
+        else:
+            L.call("n2m_grid_encode_backward_binned_pair", *common, p(emb), lam, lam_out, inner, p(scale), *tail)
+        torch.cuda.synchronize()
+        outs.append((g1, g2))
+    (a1, a2), (b1, b2) = outs
+    lo = int(np.asarray(e1.host_offsets)[8])
+    assert torch.equal(a1[lo:], b1[lo:]) and torch.equal(a2[lo:], b2[lo:])
+    assert float((a1[:lo] - b1[:lo]).abs().max()) <= 2e-6 * float(a1[:lo].abs().max())
+    # and the halves of the multi-rank step equal the full call
+    g1 = torch.empty(rows, 1, device="cuda"); g2 = torch.empty(rows, 2, device="cuda", dtype=torch.float16)
+    common = (p(d1), p(d2), p(x), ho.ctypes.data, p(g1), p(g2), B, 16, 16, S, H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id)
+    for half in (1, 2):
+        L.call("n2m_grid_encode_backward_binned_pair_tvt", *common, p(terms), p(finf), 1.0, 0.0, 1, p(ws), ws.numel(), L.stream(), half)
+    torch.cuda.synchronize()
+    assert torch.equal(g1[lo:], b1[lo:]) and torch.equal(g2[lo:], b2[lo:])
