@@ -97,8 +97,9 @@ class Stage0Engine:
         self.side = L.side_stream(dev, slot=2)
         # TV terms of the batch on a third stream beside the field kernels (n2m_grid_tv_terms): the stencil's gathers leave the backward's
         # critical path (A/B: N2M_TV_SPLIT=0 evaluates them inside the fill as before; same bits)
-        self.tv_stream = L.side_stream(dev, slot=3)
+        self.tv_stream = L.side_stream(dev, slot=3, priority=int(os.environ.get("N2M_TV_PRIO", "0")))
         self.tv_split = os.environ.get("N2M_TV_SPLIT", "1") != "0"
+        self.tv_at = int(os.environ.get("N2M_TV_AT", "0"))      # where the terms' kernel may start: 0 behind the lookup, 1 behind the field forward, 2 behind compositing
         self.split_backward = True            # multi-rank: table backward in two level halves, the first half's all-reduce under the second
         self.overlap = True                   # next batch on the side stream (False: everything on the main stream, same results)
         self.single_pass = os.environ.get("N2M_MARCH_PASSES", "1") != "2"      # one-launch marcher (A/B: N2M_MARCH_PASSES=2)
@@ -518,11 +519,12 @@ class Stage0Engine:
             L.call("n2m_grid_encode_forward_packed", _p(xyzs), _p(pk), _p(e1.offsets), _p(w["h1"]), _p(w["h2"]), M, self.Lv, self.Lv, self.S,
                    self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, float(self.aff[0]), float(self.aff[1]), s)
             tv_terms = None
-            if opt.lambda_tv > 0 and self.tv_split and self.Lv == 16:
+
+            def start_tv():
                 # the TV terms need the samples and the density table only: evaluated on their own stream while the field kernels run
-                fwd_done = torch.cuda.Event()
-                fwd_done.record()
-                self.tv_stream.wait_event(fwd_done)
+                go = torch.cuda.Event()
+                go.record()
+                self.tv_stream.wait_event(go)
                 L.grid_backward_config(*self._bwd_cfg)
                 with torch.cuda.stream(self.tv_stream):
                     L.call("n2m_grid_tv_terms", _p(xyzs), _p(pk) if self.shard else _p(e1.embeddings), self.ho.ctypes.data, M, self.Lv, self.S, self.H0,
@@ -531,13 +533,19 @@ class Stage0Engine:
                            _p(seed), float(self.aff[0]), float(self.aff[1]), _p(w["tv"]), L.stream())
                     self._tv_done = torch.cuda.Event()
                     self._tv_done.record()
+            want_tv = opt.lambda_tv > 0 and self.tv_split and self.Lv == 16
+            if want_tv:
                 tv_terms = w["tv"]
+                if self.tv_at == 0:
+                    start_tv()
             # full shading: the specular regulariser (nerf/utils.py:733-737) rides in the field kernels -- the forward leaves per-workgroup
             # sums of specular^2, the backward adds 2 lambda / M * specular * seed to the recomputed activation's gradient; the [M,3]
             # specular tensor is neither written nor read
             spec_reg = shading != 0 and opt.lambda_specular > 0
             L.call("n2m_field_forward_train", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 1,
                    _p(w["sigma"]), _p(w["rgb"]), None, _p(w["spec_partial"]) if spec_reg else None, s)
+            if want_tv and self.tv_at == 1:
+                start_tv()
         bg_t, bg_s = (bg, 0.0) if random_bg else (None, 1.0)
         lam_rgb, lam_mask = float(opt.lambda_rgb), float(max(opt.lambda_mask, 0.0))
         # ---- compositing + loss head + both backward passes: one launch (seed gradient = loss scale [/ world]: gradients are SUMMED over ranks)
@@ -547,6 +555,8 @@ class Stage0Engine:
         L.call("n2m_composite_loss_train_ent", _p(w["sigma"]), _p(w["rgb"]), _p(ts), _p(b.rays), M, N, 1e-4, _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask,
                _p(seed), None, None, _p(d_sigma), _p(d_rgb), _p(w["partial"]), None, None, None, float(max(opt.lambda_entropy, 0.0)), s)      # loss value: summed by the scaler kernel
         if M > 0:
+            if want_tv and self.tv_at == 2:
+                start_tv()
             if self.marker_at == 2:
                 self._marker = torch.cuda.Event(); self._marker.record()
             L.call("n2m_field_backward_train", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 1,
