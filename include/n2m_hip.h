@@ -435,6 +435,12 @@ int n2m_composite_loss_train_ent(const float* sigmas, const float* rgbs, const f
                                  float T_thresh, const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask,
                                  const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas, float* grad_rgbs, float* partial,
                                  uint32_t* ticket, float* loss, float* loss_sum, float lambda_entropy, void* stream);
+/* ... and with alpha_mode != 0 the SDF recipe's compositing (raymarching.cu:534,671: `sigmas` ARE the alphas, backward scale 1 / (1 - alpha);
+ * nerf/renderer.py:739-741).  The entropy term is not available in alpha mode. */
+int n2m_composite_loss_train_ex(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays, uint32_t M, uint32_t N,
+                                float T_thresh, const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask,
+                                const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas, float* grad_rgbs, float* partial,
+                                uint32_t* ticket, float* loss, float* loss_sum, float lambda_entropy, int alpha_mode, void* stream);
 
 /* Adam + GradScaler for the whole parameter set in two launches (torch.optim.Adam(fused=True) + torch.amp.GradScaler of
  * main.py:221 / nerf/utils.py:506,1187-1190).  All tensors fp32 and 16-byte aligned, except grad which may be fp16
@@ -480,6 +486,22 @@ int n2m_scaler_update_slots_loss2(float* scale, float* growth_tracker, float* fo
                                   uint32_t participants, double beta1, double beta2, float growth_factor, float backoff_factor,
                                   float growth_interval, const float* loss_partial, uint32_t n_partial, uint32_t n_rays, float* loss,
                                   float* loss_sum, const float* extra_partial, uint32_t n_extra, float extra_scale, void* stream);
+
+/* SDF head of the step executor (config 5; the caller-side arithmetic of nerf/renderer.py:724-739, nerf/network.py:143-154 and the eikonal
+ * loss of nerf/utils.py:740-743 -- the torch statement in nerf2mesh_amd/{renderer,network}.py is the parity baseline):
+ *  n2m_sdf_offsets        pts [6, M, 3] = clamp(xyz +- eps e_axis, -bound, bound) (k = 2 axis + (minus ? 1 : 0)), pts01 = (pts + bound) / (2 bound)
+ *  n2m_sdf_alpha_forward  sdf [M], sdf6 [6, M] (the field at pts), dirs [M,3] (raw ray directions), ts [M,2], variance (device scalar)
+ *                         -> alpha [M] (NeuS-style, clipped to [0,1]), normal [M,3] (raw finite-difference normal, may be NULL), eik_partial
+ *                            [ceil(M/256)] = per-workgroup sums of (|normal| - 1)^2 (may be NULL)
+ *  n2m_sdf_alpha_backward d_alpha [M] -> d_sdf [M], d_sdf6 [6, M], d_variance [1] (= sum of var_partial [ceil(M/256)], fixed order; found_inf is
+ *                         raised when it is not finite); adds the eikonal term's gradient *seed * eik_coef * (|n| - 1) n / |n| with
+ *                         eik_coef = lambda_eikonal * 2 / M on the host. */
+int n2m_sdf_offsets(const float* xyz, uint32_t M, float eps, float bound, float* pts, float* pts01, void* stream);
+int n2m_sdf_alpha_forward(const float* sdf, const float* sdf6, const float* dirs, const float* ts, uint32_t M, const float* variance, float eps,
+                          float cos_anneal_ratio, float* alpha, float* normal, float* eik_partial, void* stream);
+int n2m_sdf_alpha_backward(const float* d_alpha, const float* sdf, const float* sdf6, const float* dirs, const float* ts, uint32_t M,
+                           const float* variance, float eps, float cos_anneal_ratio, const float* seed, float eik_coef, float* d_sdf,
+                           float* d_sdf6, float* var_partial, float* d_variance, float* found_inf, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * shencoder   (reference: shencoder/src/shencoder.h:9-10, shencoder/src/bindings.cpp:5-8)

@@ -31,6 +31,7 @@ SIGNATURES = {
     "n2m_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _int, _vp, _vp, _vp],
     "n2m_composite_loss_train": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_composite_loss_train_ent": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp],
+    "n2m_composite_loss_train_ex": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _int, _vp],
     "n2m_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_composite_rays": [_u32, _u32, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_compact_alive": [_vp, _u32, _vp, _vp, _vp],
@@ -72,6 +73,9 @@ SIGNATURES = {
     "n2m_scaler_update_slots_loss": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp, _u32, _u32, _vp, _vp, _vp],
     "n2m_scaler_update_slots_loss2": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp, _u32, _u32, _vp, _vp,
                                       _vp, _u32, _f32, _vp],
+    "n2m_sdf_offsets": [_vp, _u32, _f32, _f32, _vp, _vp, _vp],
+    "n2m_sdf_alpha_forward": [_vp, _vp, _vp, _vp, _u32, _vp, _f32, _f32, _vp, _vp, _vp, _vp],
+    "n2m_sdf_alpha_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _f32, _f32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_photo_loss_forward": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _u32, _vp, _vp, _vp, _vp],
     "n2m_photo_loss_backward": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _u32, _vp, _vp, _vp, _vp],
     "n2m_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp],

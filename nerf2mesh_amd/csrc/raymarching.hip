@@ -1021,7 +1021,8 @@ __device__ __forceinline__ float n2m_entropy_grad(float x) {       // d H(clamp(
     const float lo = 1e-5f, hi = 1.0f - 1e-5f;
     return (x >= lo && x <= hi) ? (-log2f(x) - 1.4426950408889634f) + (log2f(1.0f - x) + 1.4426950408889634f) : 0.0f;
 }
-template <bool ENT>
+// ALPHA: the SDF recipe's alpha mode (raymarching.cu:534,671: alpha = the `sigmas` input itself, backward scale 1 / (1 - alpha))
+template <bool ENT, bool ALPHA = false>
 __global__ void __launch_bounds__(1024)
 composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ ts,
                             const int32_t* __restrict__ rays, uint32_t M, uint32_t N, float T_thresh, const float* __restrict__ gt,
@@ -1058,7 +1059,7 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
                 float alpha = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
                 if (valid) {
                     const float2 tt = *reinterpret_cast<const float2*>(ts + 2 * i);
-                    alpha = 1.0f - expf(-sigmas[i] * tt.y);
+                    alpha = ALPHA ? sigmas[i] : 1.0f - expf(-sigmas[i] * tt.y);
                     cr = rgbs[3 * i]; cg = rgbs[3 * i + 1]; cb = rgbs[3 * i + 2];
                     if (base == 0) { a0 = alpha; dt0 = tt.y; cr0 = cr; cg0 = cg; cb0 = cb; }
                 }
@@ -1129,7 +1130,7 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
                 if (base == 0) { alpha = a0; dt = dt0; cr = cr0; cg = cg0; cb = cb0; }      // the forward pass's own values (zeros where !valid)
                 else if (valid) {
                     const float2 tt = *reinterpret_cast<const float2*>(ts + 2 * i);
-                    alpha = 1.0f - expf(-sigmas[i] * tt.y);
+                    alpha = ALPHA ? sigmas[i] : 1.0f - expf(-sigmas[i] * tt.y);
                     dt = tt.y;
                     cr = rgbs[3 * i]; cg = rgbs[3 * i + 1]; cb = rgbs[3 * i + 2];
                 }
@@ -1148,7 +1149,8 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
                     grad_rgbs[3 * i] = gi[0] * w; grad_rgbs[3 * i + 1] = gi[1] * w; grad_rgbs[3 * i + 2] = gi[2] * w;
                     // composite_train_bwd_kernel's expression with grad_weights = grad_depth = 0 (their terms are exact zeros there)
                     const float gw = ENT ? gE * n2m_entropy_grad(w) : 0.f;      // grad_weights[i]
-                    grad_sigmas[i] = dt * (gi[0] * (T_after * cr - (rF - r)) + gi[1] * (T_after * cg - (gF - g)) +
+                    const float gscl = ALPHA ? 1.0f / (1.0f - alpha) : dt;      // (alpha = 1: inf, un-guarded like the reference; the caller clips alpha)
+                    grad_sigmas[i] = gscl * (gi[0] * (T_after * cr - (rF - r)) + gi[1] * (T_after * cg - (gF - g)) +
                                            gi[2] * (T_after * cb - (bF - b)) + (gws + gw) * (T_after - (wsF - ws)) + 0.f * 0.f);
                 } else if (valid) {
                     grad_sigmas[i] = 0.f; grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f;
@@ -1511,18 +1513,23 @@ extern "C" int n2m_composite_rays_train_forward(const float* sigmas, const float
 
 // Training fast path: compositing, loss head and both backward passes of n2m_composite_rays_train_forward/backward +
 // n2m_photo_loss_forward/backward in one launch (density mode; no grad_weights / grad_depth: the plain rgb + mask loss).
-extern "C" int n2m_composite_loss_train_ent(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays, uint32_t M, uint32_t N,
+extern "C" int n2m_composite_loss_train_ex(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays, uint32_t M, uint32_t N,
                                         float T_thresh, const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb,
                                         float lambda_mask, const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas,
                                         float* grad_rgbs, float* partial, uint32_t* ticket, float* loss, float* loss_sum, float lambda_entropy,
-                                            void* stream) {
+                                            int alpha_mode, void* stream) {
     N2M_NOTNULL(rays); N2M_NOTNULL(gt_rgba); N2M_NOTNULL(grad_loss); N2M_NOTNULL(partial);
     N2M_REQUIRE(ticket == nullptr || loss != nullptr, N2M_ENULL, "composite_loss_train: a ticket needs the loss output");
     if (M > 0) { N2M_NOTNULL(sigmas); N2M_NOTNULL(rgbs); N2M_NOTNULL(ts); N2M_NOTNULL(grad_sigmas); N2M_NOTNULL(grad_rgbs); }
     if (N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     N2M_PROF(N2M_K_COMPOSITE_FWD, s, 28.0 * M + 28.0 * N + 44.0 * M + 48.0 * N);     // forward + backward of SURVEY 8d, one launch
-    if (lambda_entropy > 0.0f)
+    if (alpha_mode) {
+        N2M_REQUIRE(lambda_entropy <= 0.0f, N2M_EUNSUPPORTED, "composite_loss_train: alpha mode with the entropy term is not built");
+        composite_loss_train_kernel<false, true><<<n2m_ceil_div(N, 16), 1024, 0, s>>>(sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar,
+                                                                                     lambda_rgb, lambda_mask, grad_loss, weights_sum, image, grad_sigmas,
+                                                                                     grad_rgbs, partial, ticket, loss, loss_sum, 0.0f);
+    } else if (lambda_entropy > 0.0f)
         composite_loss_train_kernel<true><<<n2m_ceil_div(N, 16), 1024, 0, s>>>(sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar,
                                                                               lambda_rgb, lambda_mask, grad_loss, weights_sum, image, grad_sigmas,
                                                                               grad_rgbs, partial, ticket, loss, loss_sum, lambda_entropy);
@@ -1532,6 +1539,15 @@ extern "C" int n2m_composite_loss_train_ent(const float* sigmas, const float* rg
                                                                                grad_rgbs, partial, ticket, loss, loss_sum, 0.0f);
     N2M_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int n2m_composite_loss_train_ent(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays, uint32_t M, uint32_t N,
+                                            float T_thresh, const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb,
+                                            float lambda_mask, const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas,
+                                            float* grad_rgbs, float* partial, uint32_t* ticket, float* loss, float* loss_sum, float lambda_entropy,
+                                            void* stream) {
+    return n2m_composite_loss_train_ex(sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask, grad_loss, weights_sum,
+                                       image, grad_sigmas, grad_rgbs, partial, ticket, loss, loss_sum, lambda_entropy, 0, stream);
 }
 
 extern "C" int n2m_composite_loss_train(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays, uint32_t M, uint32_t N,

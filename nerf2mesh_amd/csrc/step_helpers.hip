@@ -185,6 +185,146 @@ stage1_head_kernel(const float* __restrict__ aa_alpha /*[h0 S, w0 S]*/, const fl
     if (threadIdx.x == 0) partial[blockIdx.x] = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
 }
 
+// ------------------------------------------------------------------------------------------------ SDF head (config 5)
+// The caller-side arithmetic of the reference's SDF branch (nerf/renderer.py:724-739, nerf/network.py:143-154, nerf/utils.py:740-743) as
+// three kernels for the step executor; the torch statement in nerf2mesh_amd/{renderer,network}.py stays the parity baseline.
+//   offsets : pts[k, m] = clamp(x[m] +- eps e_axis, -bound, bound) for the six finite-difference copies (k = 2 axis + (minus ? 1 : 0)),
+//             and the same points normalised to [0,1] as grid.py:156 does ((p + bound) / (2 bound))
+//   forward : normal = 0.5 (s+ - s-) / eps; cos = dir^ . normal^ (safe_normalize both); iter_cos = -(relu(0.5 - 0.5 cos)(1 - car) +
+//             relu(-cos) car); inv_s = clip(exp(10 variance), 1e-6, 1e6); p = sigmoid((sdf - iter_cos dt / 2) inv_s), q = sigmoid((sdf +
+//             iter_cos dt / 2) inv_s); alpha = clip((p - q + 1e-5) / (p + 1e-5), 0, 1); eikonal partial sums of (|normal| - 1)^2
+//   backward: d alpha -> d sdf, d s+-, d variance (per-workgroup partials) + the eikonal term's gradient lambda * 2 (|n| - 1) n / |n| / M
+__global__ void __launch_bounds__(256)
+sdf_offsets_kernel(const float* __restrict__ xyz, uint32_t M, float eps, float bound, float* __restrict__ pts, float* __restrict__ pts01) {
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float x[3] = {xyz[3 * (size_t)m], xyz[3 * (size_t)m + 1], xyz[3 * (size_t)m + 2]};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const size_t o = ((size_t)k * M + m) * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float off = (a == (k >> 1)) ? ((k & 1) ? -eps : eps) : 0.0f;
+            const float p = fminf(fmaxf(x[a] + off, -bound), bound);
+            pts[o + a] = p;
+            pts01[o + a] = (p + bound) / (2.0f * bound);
+        }
+    }
+}
+
+struct SdfSample { float n[3], nn, dh[3], nh[3], tc, a, b, ic, s, p, q, raw, sdf, dt; bool s_free; };
+__device__ __forceinline__ SdfSample sdf_sample(const float* __restrict__ sdf, const float* __restrict__ s6, const float* __restrict__ dirs,
+                                                const float* __restrict__ ts, uint32_t M, uint32_t m, float var, float eps, float car) {
+    SdfSample r;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) r.n[a] = 0.5f * (s6[(size_t)(2 * a) * M + m] - s6[(size_t)(2 * a + 1) * M + m]) / eps;
+    const float d[3] = {dirs[3 * (size_t)m], dirs[3 * (size_t)m + 1], dirs[3 * (size_t)m + 2]};
+    const float dd = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
+    r.nn = (r.n[0] * r.n[0] + r.n[1] * r.n[1]) + r.n[2] * r.n[2];
+    const float dl = sqrtf(fmaxf(dd, 1e-20f)), nl = sqrtf(fmaxf(r.nn, 1e-20f));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { r.dh[a] = d[a] / dl; r.nh[a] = r.n[a] / nl; }
+    r.tc = (r.dh[0] * r.nh[0] + r.dh[1] * r.nh[1]) + r.dh[2] * r.nh[2];
+    r.a = fmaxf(-r.tc * 0.5f + 0.5f, 0.0f);
+    r.b = fmaxf(-r.tc, 0.0f);
+    r.ic = -(r.a * (1.0f - car) + r.b * car);
+    const float e = expf(var * 10.0f);
+    r.s = fminf(fmaxf(e, 1e-6f), 1e6f);
+    r.s_free = e >= 1e-6f && e <= 1e6f;
+    r.sdf = sdf[m];
+    r.dt = ts[2 * (size_t)m + 1];
+    const float h = r.ic * r.dt * 0.5f;
+    r.p = 1.0f / (1.0f + expf(-((r.sdf - h) * r.s)));
+    r.q = 1.0f / (1.0f + expf(-((r.sdf + h) * r.s)));
+    r.raw = (r.p - r.q + 1e-5f) / (r.p + 1e-5f);
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+sdf_alpha_forward_kernel(const float* __restrict__ sdf, const float* __restrict__ s6, const float* __restrict__ dirs, const float* __restrict__ ts,
+                         uint32_t M, const float* __restrict__ variance, float eps, float car, float* __restrict__ alpha,
+                         float* __restrict__ normal, float* __restrict__ eik_partial) {
+    __shared__ float wave_sum[4];
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    float e = 0.0f;
+    if (m < M) {
+        const SdfSample r = sdf_sample(sdf, s6, dirs, ts, M, m, *variance, eps, car);
+        alpha[m] = fminf(fmaxf(r.raw, 0.0f), 1.0f);
+        if (normal) { normal[3 * (size_t)m] = r.n[0]; normal[3 * (size_t)m + 1] = r.n[1]; normal[3 * (size_t)m + 2] = r.n[2]; }
+        const float t = sqrtf(r.nn) - 1.0f;
+        e = t * t;
+    }
+    e = n2m_wave_sum(e);
+    if (lane == 0) wave_sum[wid] = e;
+    __syncthreads();
+    if (threadIdx.x == 0 && eik_partial) eik_partial[blockIdx.x] = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+}
+
+__global__ void __launch_bounds__(256)
+sdf_alpha_backward_kernel(const float* __restrict__ d_alpha, const float* __restrict__ sdf, const float* __restrict__ s6,
+                          const float* __restrict__ dirs, const float* __restrict__ ts, uint32_t M, const float* __restrict__ variance, float eps,
+                          float car, const float* __restrict__ seed, float eik_coef /* lambda_eikonal * 2 / M */, float* __restrict__ d_sdf,
+                          float* __restrict__ d_s6, float* __restrict__ var_partial) {
+    __shared__ float wave_sum[4];
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    float dvar = 0.0f;
+    if (m < M) {
+        const SdfSample r = sdf_sample(sdf, s6, dirs, ts, M, m, *variance, eps, car);
+        const float g = d_alpha[m];
+        const float draw = (r.raw >= 0.0f && r.raw <= 1.0f) ? g : 0.0f;             // clip passes the gradient on [0, 1] inclusive
+        const float pe = r.p + 1e-5f;
+        const float dp = draw * (r.q / (pe * pe)), dq = -draw / pe;
+        const float du = dp * r.p * (1.0f - r.p), dv = dq * r.q * (1.0f - r.q);     // through the two sigmoids
+        const float h = r.ic * r.dt * 0.5f;
+        d_sdf[m] = r.s * (du + dv);
+        const float dh = r.s * (dv - du);
+        const float ds = du * (r.sdf - h) + dv * (r.sdf + h);
+        dvar = r.s_free ? ds * 10.0f * r.s : 0.0f;
+        const float dic = dh * r.dt * 0.5f;
+        const float da = -(1.0f - car) * dic, db = -car * dic;
+        const float dtc = (r.a > 0.0f ? -0.5f * da : 0.0f) + (r.b > 0.0f ? -db : 0.0f);
+        // cos = dir^ . normal^ : d normal^ = dtc dir^ ; through safe_normalize (x / sqrt(max(x.x, 1e-20)))
+        float dn[3];
+        const float nl = sqrtf(fmaxf(r.nn, 1e-20f));
+        const float proj = dtc * r.tc;                                             // normal^ . d normal^
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dn[a] = (r.nn > 1e-20f) ? (dtc * r.dh[a] - r.nh[a] * proj) / nl : dtc * r.dh[a] / nl;
+        // eikonal: lambda mean (|n| - 1)^2, torch.linalg.norm (no clamp; zero vector: zero gradient)
+        const float nrm = sqrtf(r.nn);
+        if (eik_coef != 0.0f && nrm > 0.0f) {
+            const float k = *seed * eik_coef * (nrm - 1.0f) / nrm;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) dn[a] += k * r.n[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float t = 0.5f * dn[a] / eps;
+            d_s6[(size_t)(2 * a) * M + m] = t;
+            d_s6[(size_t)(2 * a + 1) * M + m] = -t;
+        }
+    }
+    dvar = n2m_wave_sum(dvar);
+    if (lane == 0) wave_sum[wid] = dvar;
+    __syncthreads();
+    if (threadIdx.x == 0) var_partial[blockIdx.x] = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+}
+
+// out[0] (+)= sum(partial[0 .. n)) in a fixed order; raises found_inf when the sum is not finite
+__global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restrict__ partial, uint32_t n, float* __restrict__ out, int add,
+                                                           float* __restrict__ found_inf) {
+    __shared__ float wave_sum[4];
+    float acc = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    acc = n2m_wave_sum(acc);
+    if ((threadIdx.x & 63u) == 0) wave_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+        out[0] = add ? out[0] + t : t;
+        if (found_inf && !(fabsf(t) <= 3.0e38f)) *found_inf = 1.0f;
+    }
+}
+
 // rays of pixels pix[n] (flat index j*W + i) of views cam[n]: directions ((i+0.5-cx)/fx, -(j+0.5-cy)/fy, -1) rotated by
 // the pose (NOT normalised: t is then z-depth, nerf/utils.py:285), origin = pose translation; rgba = images[cam, pix]
 __global__ void __launch_bounds__(256)
@@ -434,6 +574,40 @@ extern "C" int n2m_photo_loss_backward(const float* image, const float* weights_
     hipStream_t s = (hipStream_t)stream;
     photo_loss_backward_kernel<<<n2m_ceil_div(N, 256), 256, 0, s>>>(image, weights_sum, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask, N, grad_loss,
                                                                      d_image, d_weights_sum);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_sdf_offsets(const float* xyz, uint32_t M, float eps, float bound, float* pts, float* pts01, void* stream) {
+    N2M_REQUIRE(xyz && pts && pts01, N2M_ENULL, "sdf_offsets: NULL tensor");
+    N2M_REQUIRE(eps > 0.0f && bound > 0.0f, N2M_EINVAL, "sdf_offsets: eps and bound must be positive");
+    if (M == 0) return 0;
+    sdf_offsets_kernel<<<n2m_ceil_div(M, 256), 256, 0, (hipStream_t)stream>>>(xyz, M, eps, bound, pts, pts01);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_sdf_alpha_forward(const float* sdf, const float* sdf6, const float* dirs, const float* ts, uint32_t M, const float* variance,
+                                     float eps, float cos_anneal_ratio, float* alpha, float* normal, float* eik_partial, void* stream) {
+    N2M_REQUIRE(sdf && sdf6 && dirs && ts && variance && alpha, N2M_ENULL, "sdf_alpha_forward: NULL tensor");
+    if (M == 0) return 0;
+    sdf_alpha_forward_kernel<<<n2m_ceil_div(M, 256), 256, 0, (hipStream_t)stream>>>(sdf, sdf6, dirs, ts, M, variance, eps, cos_anneal_ratio, alpha,
+                                                                                  normal, eik_partial);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_sdf_alpha_backward(const float* d_alpha, const float* sdf, const float* sdf6, const float* dirs, const float* ts, uint32_t M,
+                                      const float* variance, float eps, float cos_anneal_ratio, const float* seed, float eik_coef, float* d_sdf,
+                                      float* d_sdf6, float* var_partial, float* d_variance, float* found_inf, void* stream) {
+    N2M_REQUIRE(d_alpha && sdf && sdf6 && dirs && ts && variance && d_sdf && d_sdf6 && var_partial && d_variance, N2M_ENULL,
+                "sdf_alpha_backward: NULL tensor");
+    N2M_REQUIRE(eik_coef == 0.0f || seed, N2M_ENULL, "sdf_alpha_backward: the eikonal term needs the seed gradient");
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nb = n2m_ceil_div(M, 256);
+    if (M > 0) sdf_alpha_backward_kernel<<<nb, 256, 0, s>>>(d_alpha, sdf, sdf6, dirs, ts, M, variance, eps, cos_anneal_ratio, seed, eik_coef, d_sdf,
+                                                           d_sdf6, var_partial);
+    sum_partials_kernel<<<1, 256, 0, s>>>(var_partial, M > 0 ? nb : 0u, d_variance, 0, found_inf);
     N2M_CHECK_LAUNCH();
     return 0;
 }

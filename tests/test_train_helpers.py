@@ -146,3 +146,64 @@ def test_fused_composite_loss_with_the_entropy_regulariser():
     L.call("n2m_composite_loss_train", L.ptr(sig.detach()), L.ptr(rgb.detach()), L.ptr(ts), L.ptr(rays), M, N, 1e-4, L.ptr(gt), L.ptr(bg),
            0.0, 1.0, 0.1, L.ptr(scale), None, None, L.ptr(d_sr[:M]), L.ptr(d_sr[M:]), L.ptr(partial), None, None, None, L.stream())
     assert torch.equal(d_sr[:M], gs0) and torch.equal(d_sr[M:].view(M, 3), gr0)
+
+
+def test_sdf_head_kernels_against_the_torch_statement():
+    """n2m_sdf_offsets / n2m_sdf_alpha_forward / n2m_sdf_alpha_backward against the torch statement of the reference's SDF branch that
+    renderer.render / network.normal spell out (nerf/renderer.py:724-739, nerf/network.py:143-154, eikonal term nerf/utils.py:740-743,
+    pinned to the unchanged reference Python by tests/test_reference_render.py[sdf]): offsets bit for bit, alpha / normal to fp32 rounding,
+    gradients w.r.t. the sdf, the six finite-difference values and the variance to 2e-5 of their maximum."""
+    import torch
+    import torch.nn.functional as F
+    from nerf2mesh_amd import _lib as L
+    from nerf2mesh_amd.renderer import safe_normalize
+    p = L.ptr
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(5)
+    M, eps, car, bound = 70001, 3e-2, 0.3, 1.0
+    xyz = (torch.rand(M, 3, device=dev, generator=g) * 2 - 1) * 1.01
+    xyz.clamp_(-1, 1)
+    pts = torch.empty(6, M, 3, device=dev); pts01 = torch.empty(6, M, 3, device=dev)
+    L.call("n2m_sdf_offsets", p(xyz), M, eps, bound, p(pts), p(pts01), L.stream())
+    off = torch.zeros(6, 1, 3, device=dev)
+    for axis in range(3):
+        off[2 * axis, 0, axis] = eps
+        off[2 * axis + 1, 0, axis] = -eps
+    want = (xyz.unsqueeze(0) + off).clamp(-bound, bound)
+    assert torch.equal(pts, want) and torch.equal(pts01, (want + bound) / (2 * bound))
+
+    sdf = (torch.randn(M, device=dev, generator=g) * 0.05).requires_grad_()
+    s6 = (sdf.detach().unsqueeze(0) + torch.randn(6, M, device=dev, generator=g) * eps * 1.2).requires_grad_()
+    s6.data[:, :7] = sdf.detach()[:7]                                  # a few exactly flat samples: zero normal (the clamps of safe_normalize / norm)
+    dirs = torch.randn(M, 3, device=dev, generator=g) * 2.0
+    ts = torch.rand(M, 2, device=dev, generator=g) * 0.01 + 0.002
+    var = torch.tensor(0.35, device=dev, requires_grad=True)
+    lam_eik, seed = 0.1, torch.tensor(64.0, device=dev)
+    # torch statement
+    normal = torch.stack([0.5 * (s6[0] - s6[1]) / eps, 0.5 * (s6[2] - s6[3]) / eps, 0.5 * (s6[4] - s6[5]) / eps], dim=-1)
+    true_cos = (safe_normalize(dirs) * safe_normalize(normal)).sum(-1)
+    iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - car) + F.relu(-true_cos) * car)
+    inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
+    prev, nxt = torch.sigmoid((sdf - iter_cos * ts[:, 1] * 0.5) * inv_s), torch.sigmoid((sdf + iter_cos * ts[:, 1] * 0.5) * inv_s)
+    alpha = ((prev - nxt + 1e-5) / (prev + 1e-5)).view(-1).clip(0, 1)
+    eik = ((torch.linalg.norm(normal, ord=2, dim=-1) - 1) ** 2).mean()
+    w = torch.randn(M, device=dev, generator=g)
+    loss = (alpha * w).sum() + lam_eik * eik * seed          # the executor's d_alpha already carries the seed; the eikonal term takes it from `seed`
+    loss.backward()
+    # kernels
+    a2, n2 = torch.empty(M, device=dev), torch.empty(M, 3, device=dev)
+    nb = (M + 255) // 256
+    eik_part = torch.empty(nb, device=dev)
+    L.call("n2m_sdf_alpha_forward", p(sdf.detach()), p(s6.detach()), p(dirs), p(ts), M, p(var.detach()), eps, car, p(a2), p(n2), p(eik_part), L.stream())
+    assert float((a2 - alpha.detach()).abs().max()) <= 2e-6
+    assert float((n2 - normal.detach()).abs().max()) <= 1e-6 * float(normal.detach().abs().max())
+    assert abs(float(eik_part.double().sum() / M) - float(eik)) <= 1e-5 * float(eik)
+    d_sdf, d_s6 = torch.empty(M, device=dev), torch.empty(6, M, device=dev)
+    var_part, d_var, finf = torch.empty(nb, device=dev), torch.empty(1, device=dev), torch.zeros((), device=dev)
+    L.call("n2m_sdf_alpha_backward", p(w), p(sdf.detach()), p(s6.detach()), p(dirs), p(ts), M, p(var.detach()), eps, car, p(seed),
+           float(lam_eik * 2.0 / M), p(d_sdf), p(d_s6), p(var_part), p(d_var), p(finf), L.stream())
+    rel = lambda a, b: float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+    assert rel(d_sdf, sdf.grad) <= 2e-5, rel(d_sdf, sdf.grad)
+    assert rel(d_s6, s6.grad) <= 2e-5, rel(d_s6, s6.grad)
+    assert abs(float(d_var) - float(var.grad)) <= 2e-4 * abs(float(var.grad)), (float(d_var), float(var.grad))
+    assert float(finf) == 0.0
