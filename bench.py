@@ -306,7 +306,11 @@ def main():
                "sdf": dict(bound=1, dt_gamma=0, sdf=True),                            # scripts/runall_syn_sdf.sh:1
                # scripts/runall_360_outdoor.sh:2: -O --bound 16 --enable_cam_near_far --lambda_entropy 1e-3 (default dt_gamma 1/256), colmap AABB
                "garden": dict(bound=16, dt_gamma=1 / 256, lambda_entropy=1e-3, enable_cam_near_far=True, scene="garden")}
-    opt = make_options(O=True, iters=30000, fused_mlp=not args.unfused, **recipes[args.recipe])
+    # --sdf: the schedules of the recipe (progressive levels 4 -> 16, normal epsilon 1e-1 -> 1e-4, cos anneal 0 -> 1: nerf/utils.py:651-655) run
+    # over the first HALF of the iterations; the other half trains in the end state.  iters = 2000 puts the timed steps (1000+) into that
+    # end state -- 16 levels, epsilon 1e-4 -- instead of the 4-level start the default 30 000 would show at step 1000
+    iters = 2000 if (args.recipe == "sdf" and not args.diffuse) else 30000
+    opt = make_options(O=True, iters=iters, fused_mlp=not args.unfused, **recipes[args.recipe])
     if args.num_points > 0:
         opt.num_points = args.num_points
         opt.num_rays = max(64, args.num_points // 16)
@@ -414,6 +418,8 @@ def main():
                                 "garden": "mip-360 outdoor recipe (scripts/runall_360_outdoor.sh:2) stage-0 -O --bound 16 --enable_cam_near_far "
                                           "--lambda_entropy 1e-3, dt_gamma 1/256 (5 cascades, colmap-style AABB, inner/outer TV) on the synthetic yard scene"}[args.recipe]
                                + ", 800x800 x 100 synthetic views, num_points target 2^18/GPU (adaptive num_rays), occupancy refresh every 16 steps",
+                   "sdf_schedule": (f"max_level {model.max_level}, normal epsilon {opt.normal_anneal_epsilon:.2g}, cos_anneal_ratio {opt.cos_anneal_ratio:.2g}"
+                                    if args.recipe == "sdf" else None),
                    "shading": shading, "timed_steps": [first_timed, first_timed + args.steps - 1], "diffuse_step": int(opt.diffuse_step),
                    "parallelism": (f"dp{world} (rays sharded; table gradients reduce-scattered, Adam sharded over the ranks, packed rows all-gathered; "
                                    f"{dist.get_backend()})" if getattr(tr, "shard", False) else

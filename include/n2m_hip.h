@@ -486,6 +486,12 @@ int n2m_scaler_update_slots_loss2(float* scale, float* growth_tracker, float* fo
                                   uint32_t participants, double beta1, double beta2, float growth_factor, float backoff_factor,
                                   float growth_interval, const float* loss_partial, uint32_t n_partial, uint32_t n_rays, float* loss,
                                   float* loss_sum, const float* extra_partial, uint32_t n_extra, float extra_scale, void* stream);
+/* ... and a third term, loss += extra2_scale * sum(extra2_partial[0 .. n_extra2)) (SDF recipe: the eikonal loss from n2m_sdf_alpha_forward's partials). */
+int n2m_scaler_update_slots_loss3(float* scale, float* growth_tracker, float* found_inf, float* steps, float* bias,
+                                  uint32_t participants, double beta1, double beta2, float growth_factor, float backoff_factor,
+                                  float growth_interval, const float* loss_partial, uint32_t n_partial, uint32_t n_rays, float* loss,
+                                  float* loss_sum, const float* extra_partial, uint32_t n_extra, float extra_scale,
+                                  const float* extra2_partial, uint32_t n_extra2, float extra2_scale, void* stream);
 
 /* SDF head of the step executor (config 5; the caller-side arithmetic of nerf/renderer.py:724-739, nerf/network.py:143-154 and the eikonal
  * loss of nerf/utils.py:740-743 -- the torch statement in nerf2mesh_amd/{renderer,network}.py is the parity baseline):

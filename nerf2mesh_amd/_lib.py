@@ -73,6 +73,8 @@ SIGNATURES = {
     "n2m_scaler_update_slots_loss": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp, _u32, _u32, _vp, _vp, _vp],
     "n2m_scaler_update_slots_loss2": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp, _u32, _u32, _vp, _vp,
                                       _vp, _u32, _f32, _vp],
+    "n2m_scaler_update_slots_loss3": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp, _u32, _u32, _vp, _vp,
+                                      _vp, _u32, _f32, _vp, _u32, _f32, _vp],
     "n2m_sdf_offsets": [_vp, _u32, _f32, _f32, _vp, _vp, _vp],
     "n2m_sdf_alpha_forward": [_vp, _vp, _vp, _vp, _u32, _vp, _f32, _f32, _vp, _vp, _vp, _vp],
     "n2m_sdf_alpha_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _f32, _f32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp],

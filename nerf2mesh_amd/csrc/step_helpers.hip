@@ -704,10 +704,17 @@ __global__ void scaler_update_slots_kernel(float* scale, float* growth_tracker, 
                                            float growth_factor, float backoff_factor, float growth_interval,
                                            const float* __restrict__ loss_partial, uint32_t n_partial, float inv_rays,
                                            float* __restrict__ loss, float* __restrict__ loss_sum,
-                                           const float* __restrict__ extra_partial, uint32_t n_extra, float extra_scale) {
+                                           const float* __restrict__ extra_partial, uint32_t n_extra, float extra_scale,
+                                           const float* __restrict__ extra2_partial = nullptr, uint32_t n_extra2 = 0, float extra2_scale = 0.0f) {
     __builtin_amdgcn_s_setprio(3);
     const uint32_t s = threadIdx.x;
-    __shared__ float wave_part[16], wave_extra[16];
+    __shared__ float wave_part[16], wave_extra[16], wave_extra2[16];
+    if (extra2_partial) {     // a third term (SDF recipe: the eikonal loss, lambda / M x sum of (|normal| - 1)^2)
+        float acc = 0.0f;
+        for (uint32_t i = s; i < n_extra2; i += blockDim.x) acc += extra2_partial[i];
+        acc = n2m_wave_sum(acc);
+        if ((s & 63u) == 0u) wave_extra2[s >> 6] = acc;
+    }
     if (extra_partial) {      // a second term of the loss value with its own normalisation (specular regulariser: lambda / M x sum of squares)
         float acc = 0.0f;
         for (uint32_t i = s; i < n_extra; i += blockDim.x) acc += extra_partial[i];
@@ -730,6 +737,11 @@ __global__ void scaler_update_slots_kernel(float* scale, float* growth_tracker, 
             float e = 0.0f;
             for (uint32_t w = 0; w < (blockDim.x + 63u) / 64u; ++w) e += wave_extra[w];
             v += e * extra_scale;
+        }
+        if (extra2_partial) {
+            float e = 0.0f;
+            for (uint32_t w = 0; w < (blockDim.x + 63u) / 64u; ++w) e += wave_extra2[w];
+            v += e * extra2_scale;
         }
         if (loss) *loss = v;
         if (loss_sum) *loss_sum += v;
@@ -771,19 +783,30 @@ extern "C" int n2m_scaler_update_slots(float* scale, float* growth_tracker, floa
 // The same + the final reduction of the loss value from the per-workgroup partials n2m_composite_loss_train leaves when it is given no
 // ticket (loss = sum(partial[0..n_partial)) / n_rays; *loss_sum += loss): keeps the arrival ticket -- one __threadfence + one same-address
 // atomic per workgroup -- out of the compositing kernel, whose loss VALUE nothing on the device waits for.
-extern "C" int n2m_scaler_update_slots_loss2(float* scale, float* growth_tracker, float* found_inf, float* steps, float* bias,
+extern "C" int n2m_scaler_update_slots_loss3(float* scale, float* growth_tracker, float* found_inf, float* steps, float* bias,
                                             uint32_t participants, double beta1, double beta2, float growth_factor, float backoff_factor,
                                             float growth_interval, const float* loss_partial, uint32_t n_partial, uint32_t n_rays, float* loss,
-                                            float* loss_sum, const float* extra_partial, uint32_t n_extra, float extra_scale, void* stream) {
+                                            float* loss_sum, const float* extra_partial, uint32_t n_extra, float extra_scale, const float* extra2_partial,
+                                             uint32_t n_extra2, float extra2_scale, void* stream) {
     N2M_REQUIRE(found_inf != nullptr && steps != nullptr && bias != nullptr, N2M_ENULL, "scaler_update_slots: NULL found_inf / steps / bias");
     N2M_REQUIRE(loss_partial != nullptr && n_rays > 0, N2M_EINVAL, "scaler_update_slots_loss: needs the loss partials and the ray count");
     // 256 threads, not 1024: the launch sits on the main stream between Adam and the next forward while the side stream's marcher fills
     // every CU, and a 16-wave workgroup then waits (measured: up to 27 us) for one CU to free 16 wave slots at once
     scaler_update_slots_kernel<<<1, 256, 0, (hipStream_t)stream>>>(scale, growth_tracker, found_inf, steps, bias, participants, beta1, beta2,
                                                                   growth_factor, backoff_factor, growth_interval, loss_partial, n_partial,
-                                                                  1.0f / (float)n_rays, loss, loss_sum, extra_partial, extra_partial ? n_extra : 0u, extra_scale);
+                                                                  1.0f / (float)n_rays, loss, loss_sum, extra_partial, extra_partial ? n_extra : 0u, extra_scale,
+                                                                  extra2_partial, extra2_partial ? n_extra2 : 0u, extra2_scale);
     N2M_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int n2m_scaler_update_slots_loss2(float* scale, float* growth_tracker, float* found_inf, float* steps, float* bias,
+                                             uint32_t participants, double beta1, double beta2, float growth_factor, float backoff_factor,
+                                             float growth_interval, const float* loss_partial, uint32_t n_partial, uint32_t n_rays, float* loss,
+                                             float* loss_sum, const float* extra_partial, uint32_t n_extra, float extra_scale, void* stream) {
+    return n2m_scaler_update_slots_loss3(scale, growth_tracker, found_inf, steps, bias, participants, beta1, beta2, growth_factor, backoff_factor,
+                                         growth_interval, loss_partial, n_partial, n_rays, loss, loss_sum, extra_partial, n_extra, extra_scale,
+                                         nullptr, 0u, 0.0f, stream);
 }
 
 extern "C" int n2m_scaler_update_slots_loss(float* scale, float* growth_tracker, float* found_inf, float* steps, float* bias,

@@ -69,8 +69,10 @@ class Stage0Engine:
         self.model, self.opt, self.device = model.to(device), opt, torch.device(device)
         dev = self.device
         assert dev.type == "cuda", "the step executor drives HIP kernels: no CPU path"
+        if bool(opt.sdf) and world_size > 1:
+            raise ValueError("Stage0Engine runs the SDF recipe on one rank; use trainer.Stage0Trainer for multi-rank SDF training")
         if not self.supported(model, opt):
-            raise ValueError("Stage0Engine covers the fused lego-style recipe (fused_mlp, fp16, no SDF / individual codes, power-of-two "
+            raise ValueError("Stage0Engine covers the fused recipes (fused_mlp, fp16, no individual codes, power-of-two "
                              "bound, shared encoder geometry); use trainer.Stage0Trainer for other configurations")
         L.lib()
         self.poses = poses.to(dev).float().contiguous()
@@ -169,10 +171,11 @@ class Stage0Engine:
     @staticmethod
     def supported(model, opt):
         e1, e2 = model.encoder, model.encoder_color
-        return (bool(getattr(opt, "fused_mlp", False)) and bool(opt.fp16) and not opt.sdf and getattr(opt, "ind_dim", 0) == 0
+        sdf = bool(opt.sdf)      # SDF recipe (config 5): NeuS alpha, finite-difference normals, eikonal loss, progressive levels -- _step_sdf
+        return (bool(getattr(opt, "fused_mlp", False)) and bool(opt.fp16) and getattr(opt, "ind_dim", 0) == 0
                 and _affine(float(model.bound)) is not None and same_geometry(e1, e2) and e1.embeddings.shape[1] == 1
-                and e2.embeddings.shape[1] == 2 and not getattr(opt, "progressive_level", False)
-                and opt.patch_size == 1 and model.max_level >= e1.num_levels)
+                and e2.embeddings.shape[1] == 2 and (sdf or not getattr(opt, "progressive_level", False))
+                and opt.patch_size == 1 and (sdf or model.max_level >= e1.num_levels) and not (sdf and opt.lambda_entropy > 0))
 
     @property
     def loss_acc(self):
@@ -349,6 +352,9 @@ class Stage0Engine:
         for i, p in enumerate(self.mlp_params):
             grads[p] = (self.dw_views[i], 0, 1, None)
         live = set(params[:2]) | set(self.mlp_params[:5]) | (set(self.mlp_params[5:]) if full else set())
+        if self.opt.sdf:          # the NeuS variance (lr x 0.1, nerf/network.py:186): its gradient is a scalar the SDF head's backward leaves in d_var
+            grads[model.variance] = (self._sdf_buf()["d_var"], 0, 0, None)
+            live.add(model.variance)
         k, participants, groups = 0, 0, []
         group_of = {p: gi for gi, g in enumerate(o.param_groups) for p in g["params"]}
         for p in params:
@@ -471,11 +477,13 @@ class Stage0Engine:
             L.call("n2m_scaler_update_slots", _p(o.scale), _p(o.growth_tracker), _p(o.found_inf), _p(o.steps), _p(o.bias), participants,
                    float(b1), float(b2), gf, bf, gi, s)
         else:        # + the step's loss value from the compositing kernel's per-workgroup partials
-            n_rays, buf, extra = loss_out
+            n_rays, buf, extra = loss_out[:3]
+            extra2 = loss_out[3] if len(loss_out) > 3 else None
             ex_buf, ex_scale = extra if extra is not None else (None, 0.0)
-            L.call("n2m_scaler_update_slots_loss2", _p(o.scale), _p(o.growth_tracker), _p(o.found_inf), _p(o.steps), _p(o.bias), participants,
+            e2_buf, e2_n, e2_scale = extra2 if extra2 is not None else (None, 0, 0.0)
+            L.call("n2m_scaler_update_slots_loss3", _p(o.scale), _p(o.growth_tracker), _p(o.found_inf), _p(o.steps), _p(o.bias), participants,
                    float(b1), float(b2), gf, bf, gi, _p(self._w["partial"]), (n_rays + 15) // 16, n_rays, _p(buf), _p(self._loss_sum),
-                   _p(ex_buf), self._n_spec, float(ex_scale), s)
+                   _p(ex_buf), self._n_spec, float(ex_scale), _p(e2_buf), int(e2_n), float(e2_scale), s)
         nxt = lr_lambda(self.global_step, self.opt.iters)          # like LambdaLR.step(): param_groups carry the NEXT step's rate
         for group in o.param_groups:
             group["lr"] = float(group["initial_lr"]) * nxt
@@ -502,6 +510,11 @@ class Stage0Engine:
         self.samples_seen += M
         self.rays_seen += N
 
+        if opt.sdf:               # schedules of the SDF recipe (nerf/utils.py:651-655), exactly as trainer.Stage0Trainer sets them
+            opt.cos_anneal_ratio = min(1, self.global_step / (0.5 * opt.iters))
+            opt.normal_anneal_epsilon = 1e-1 * (1 - min(0.999, self.global_step / (0.5 * opt.iters)))
+            if opt.progressive_level:
+                model.max_level = 4 + int(12 * min(1, self.global_step / (0.5 * opt.iters)))
         w = self._work(max(M, 1), N)
         s = L.stream()
         c = b.cap_m
@@ -514,6 +527,8 @@ class Stage0Engine:
         e1 = model.encoder
         # seed gradient = loss scale [/ world]: gradients are SUMMED over ranks
         seed = o.scale if self.world == 1 else o.scale / self.world
+        if opt.sdf:
+            return self._step_sdf(b, M, N, w, xyzs, dirs, ts, shading, seed, pk)
         # ---- forward
         if M > 0:
             L.call("n2m_grid_encode_forward_packed", _p(xyzs), _p(pk), _p(e1.offsets), _p(w["h1"]), _p(w["h2"]), M, self.Lv, self.Lv, self.S,
@@ -632,6 +647,109 @@ class Stage0Engine:
         extra = (w["spec_partial"], float(opt.lambda_specular / M)) if (M > 0 and shading != 0 and opt.lambda_specular > 0) else None
         self._lr_step(shading != 0, loss_out=(N, b.loss, extra))
         loss = b.loss.view(())                 # written by the scaler kernel (photometric + specular terms); lives in the batch's buffer set (valid until the set comes round again)
+        self._fill_pipeline()
+        return loss
+
+    # ------------------------------------------------------------------------------------------------ SDF recipe (config 5)
+    def _sdf_buf(self, M=0):
+        """Buffers of the SDF head, grow-only: the six finite-difference copies of the batch (points, [0,1] points, density features, sdf
+        values and their gradients), alpha, per-workgroup partials, the variance gradient."""
+        cap = getattr(self, "_sdf_cap", 0)
+        if not hasattr(self, "_sdf") or M > cap:
+            cap = max(cap, int(M * 1.25) + 1024)
+            dev = self.device
+            f = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+            old = getattr(self, "_sdf", None)
+            self._sdf = {"pts": f(18 * cap), "pts01": f(18 * cap), "h6": f(16 * 6 * cap), "d_h6": f(16 * 6 * cap), "s6": f(6 * cap), "d_s6": f(6 * cap),
+                         "alpha": f(cap), "d_sdf": f(cap), "x01": f(3 * cap), "eik": f((cap + 255) // 256 + 1), "varp": f((cap + 255) // 256 + 1),
+                         "d_var": old["d_var"] if old is not None else torch.zeros(1, dtype=torch.float32, device=dev)}      # (the Adam descriptor holds its address)
+            self._sdf_cap = cap
+        return self._sdf
+
+    def _step_sdf(self, b, M, N, w, xyzs, dirs, ts, shading, seed, pk):
+        """The iteration of the SDF recipe (nerf/renderer.py:724-741, nerf/network.py:143-154, nerf/utils.py:651-655,740-743) as a fixed launch
+        sequence: lookup -> field (raw sdf) -> six finite-difference copies through the density encoder + sigma_net (ONE stacked call each
+        way) -> NeuS alpha (n2m_sdf_alpha_forward) -> compositing + loss in alpha mode -> n2m_sdf_alpha_backward (+ eikonal) -> field
+        backward (batch and stacked copies) -> table backward (shared fill for the batch, the density table alone for the copies, TV) ->
+        Adam (+ the variance) -> bookkeeping (loss = photometric + specular + eikonal terms).  trainer.Stage0Trainer is the parity baseline."""
+        opt, model, dev, o = self.opt, self.model, self.device, self.optimizer
+        s = L.stream()
+        e1 = model.encoder
+        sw = self.mlp_params
+        ml = int(min(model.max_level, self.Lv))
+        eps, car = float(opt.normal_anneal_epsilon), float(opt.cos_anneal_ratio)
+        random_bg = b.bg is not None
+        bg_t, bg_s = (b.bg, 0.0) if random_bg else (None, 1.0)
+        lam_rgb, lam_mask = float(opt.lambda_rgb), float(max(opt.lambda_mask, 0.0))
+        sb = self._sdf_buf(M)
+        d_sigma, d_rgb = w["d_sr"][:max(M, 1)], w["d_sr"][max(M, 1):4 * max(M, 1)]
+        extra = extra2 = None
+        if M > 0:
+            M6 = 6 * M
+            if ml < self.Lv:          # progressive levels: the kernels leave the inactive levels alone, the field reads all sixteen
+                w["h1"][ml * M:16 * M].zero_()
+                w["h2"][2 * ml * M:32 * M].zero_()
+                sb["h6"][ml * M6:16 * M6].zero_()
+            L.call("n2m_grid_encode_forward_packed", _p(xyzs), _p(pk), _p(e1.offsets), _p(w["h1"]), _p(w["h2"]), M, self.Lv, ml, self.S,
+                   self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, float(self.aff[0]), float(self.aff[1]), s)
+            spec_reg = shading != 0 and opt.lambda_specular > 0
+            L.call("n2m_field_forward_train", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 3,
+                   _p(w["sigma"]), _p(w["rgb"]), None, _p(w["spec_partial"]) if spec_reg else None, s)
+            # finite-difference normals: six offset copies, one encode + one sigma_net evaluation for all of them
+            L.call("n2m_sdf_offsets", _p(xyzs), M, eps, float(model.bound), _p(sb["pts"]), _p(sb["pts01"]), s)
+            L.call("n2m_grid_encode_forward", _p(sb["pts01"]), _p(e1.embeddings), _p(e1.offsets), _p(sb["h6"]), M6, 3, 1, self.Lv, ml, self.S, self.H0,
+                   None, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, L.F32, s)
+            L.call("n2m_field_forward", _p(sb["pts"]), None, _p(sb["h6"]), None, *[_p(p) for p in sw], M6, 0, 2, _p(sb["s6"]), None, None, s)
+            L.call("n2m_sdf_alpha_forward", _p(w["sigma"]), _p(sb["s6"]), _p(dirs), _p(ts), M, _p(model.variance), eps, car, _p(sb["alpha"]), None,
+                   _p(sb["eik"]) if opt.lambda_eikonal > 0 else None, s)
+        # compositing in alpha mode + loss head + their backward
+        L.call("n2m_composite_loss_train_ex", _p(sb["alpha"]), _p(w["rgb"]), _p(ts), _p(b.rays), M, N, 1e-4, _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask,
+               _p(seed), None, None, _p(d_sigma), _p(d_rgb), _p(w["partial"]), None, None, None, 0.0, 1, s)
+        if M > 0:
+            M6 = 6 * M
+            lam_eik = float(opt.lambda_eikonal) if opt.lambda_eikonal > 0 else 0.0
+            L.call("n2m_sdf_alpha_backward", _p(d_sigma), _p(w["sigma"]), _p(sb["s6"]), _p(dirs), _p(ts), M, _p(model.variance), eps, car, _p(seed),
+                   float(lam_eik * 2.0 / M), _p(sb["d_sdf"]), _p(sb["d_s6"]), _p(sb["varp"]), _p(sb["d_var"]), _p(o.found_inf), s)
+            L.call("n2m_field_backward_train", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 3,
+                   _p(sb["d_sdf"]), _p(d_rgb), None, _p(w["d_h1"]), _p(w["d_h2"]), *[_p(g) for g in self.dw_views], _p(o.found_inf),
+                   float(2.0 * opt.lambda_specular / M) if spec_reg else 0.0, _p(seed) if spec_reg else None, s)
+            L.call("n2m_field_backward", _p(sb["pts"]), None, _p(sb["h6"]), None, *[_p(p) for p in sw], M6, 0, 2, _p(sb["d_s6"]), None, None,
+                   _p(sb["d_h6"]), None, *[_p(g) for g in self.dw_views], _p(o.found_inf), s)
+            # table gradients: the batch through the shared fill (both tables, overwrite), the stacked copies onto the density table alone
+            L.grid_backward_config(*self._bwd_cfg)
+            need = max(L.lib().n2m_grid_binned_pair_workspace_bytes(M, ml, self.ho.ctypes.data),
+                       L.lib().n2m_grid_binned_pair_workspace_bytes(M6, ml, self.ho.ctypes.data))
+            ws = L.workspace(dev, need)
+            tv_fold = opt.lambda_tv > 0 and ml == self.Lv
+            tv_w, tv_wo = float(opt.lambda_tv), float(opt.lambda_tv * (10 if opt.bound > 1 else 1))
+            geo = (self.Lv, ml, self.S, self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id)
+            L.call("n2m_grid_encode_backward_binned_pair", _p(w["d_h1"]), _p(w["d_h2"]), _p(xyzs), self.ho.ctypes.data, _p(self.g1), _p(self.g2), M, *geo,
+                   _p(e1.embeddings) if tv_fold else None, tv_w, tv_wo, float(0.5 / model.bound), _p(seed) if tv_fold else None, _p(o.found_inf),
+                   float(self.aff[0]), float(self.aff[1]), 1, _p(ws), ws.numel(), s)
+            L.call("n2m_grid_encode_backward_binned_pair", _p(sb["d_h6"]), None, _p(sb["pts01"]), self.ho.ctypes.data, _p(self.g1), None, M6, *geo,
+                   None, 0.0, 0.0, 1.0, None, _p(o.found_inf), 1.0, 0.0, 0, _p(ws), ws.numel(), s)
+            if opt.lambda_tv > 0 and not tv_fold:
+                # progressive levels: the TV term covers ALL levels of the table (grid.py:170-192 has no max_level), as its own pass
+                x01 = sb["x01"][:3 * M]
+                torch.add(xyzs[:3 * M], float(model.bound), out=x01)
+                x01.div_(2.0 * float(model.bound))
+                need_tv = L.lib().n2m_grid_binned_workspace_bytes(M, 3, 1, self.Lv, self.ho.ctypes.data, L.F32, 1)
+                ws_tv = L.workspace(dev, need_tv, 1)
+                L.call("n2m_grad_total_variation_binned", _p(x01), _p(e1.embeddings), _p(self.g1), self.ho.ctypes.data, tv_w, tv_wo,
+                       float(0.5 / model.bound), _p(seed), M, 3, 1, self.Lv, self.S, self.H0, e1.gridtype_id, int(bool(e1.align_corners)),
+                       _p(ws_tv), ws_tv.numel(), s)
+            if spec_reg:
+                extra = (w["spec_partial"], float(opt.lambda_specular / M))
+            if lam_eik > 0:
+                extra2 = (sb["eik"], (M + 255) // 256, float(lam_eik / M))
+        else:
+            self.g1.zero_()
+            self.g2.zero_()
+            sb["d_var"].zero_()
+        self._marker = torch.cuda.Event()
+        self._marker.record()
+        self._lr_step(True if shading != 0 else False, loss_out=(N, b.loss, extra, extra2))
+        loss = b.loss.view(())
         self._fill_pipeline()
         return loss
 

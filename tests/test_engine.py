@@ -82,6 +82,34 @@ def test_engine_runs_the_outdoor_recipe_like_the_trainer():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("iters", [30000, 40])
+def test_engine_runs_the_sdf_recipe_like_the_trainer(iters):
+    """BASELINE config 5 (`--sdf`, scripts/runall_syn_sdf.sh:1): NeuS alpha from the raw sdf, finite-difference normals (six stacked density
+    evaluations), eikonal loss, alpha-mode compositing, the variance parameter, progressive levels.  The executor's fixed launch sequence
+    (engine._step_sdf over n2m_sdf_* and the alpha mode of the fused compositing kernel) against the autograd trainer.  iters = 30000: the
+    early schedule (4 active levels, large epsilon); iters = 40: the schedule runs to its end inside the test (16 levels, TV folded in,
+    epsilon 1e-4, cos_anneal_ratio 1)."""
+    from nerf2mesh_amd.engine import Stage0Engine
+    from nerf2mesh_amd.trainer import Stage0Trainer
+    cfg = dict(sdf=True, iters=iters, diffuse_step=10)
+    steps = 30
+    a, la = _run(Stage0Trainer, steps, **cfg)
+    b, lb = _run(Stage0Engine, steps, **cfg)
+    assert a.model.max_level == b.model.max_level == (16 if iters == 40 else 4)
+    assert a.samples_seen == b.samples_seen and a.rays_seen == b.rays_seen, "same batches, same sample counts"
+    np.testing.assert_allclose(la, lb, rtol=2e-3, atol=1e-6)
+    a2, _ = _run(Stage0Trainer, steps, **cfg)
+
+    def rel(p, q):
+        return ((p - q).norm() / p.norm().clamp_min(1e-30)).item()
+    for (n, p), (_, q), (_, r) in zip(a.model.named_parameters(), b.model.named_parameters(), a2.model.named_parameters()):
+        d_te, d_tt = rel(p, q), rel(p, r)
+        print(f"{n:36s} trainer-vs-engine {d_te:.3g}   trainer-vs-trainer {d_tt:.3g}")
+        assert d_te <= 10 * d_tt + 5e-4, f"{n}: executor differs from the trainer by {d_te:.3g}, two trainer runs differ by {d_tt:.3g}"
+    assert torch.equal(a.optimizer.scale, b.optimizer.scale) and torch.equal(a.optimizer.steps, b.optimizer.steps)
+
+
+@pytest.mark.gpu
 def test_engine_serial_schedule_equals_overlapped():
     """overlap=False (next batch on the main stream) is the same computation in a different order of issue."""
     from nerf2mesh_amd.engine import Stage0Engine
@@ -102,7 +130,7 @@ def test_engine_rejects_configurations_outside_the_fast_path():
     from nerf2mesh_amd.engine import Stage0Engine
     from nerf2mesh_amd.network import NeRFNetwork
     from nerf2mesh_amd.options import make_options
-    opt = make_options(O=True, bound=1, dt_gamma=0, sdf=True, fused_mlp=True)
+    opt = make_options(O=True, bound=1, dt_gamma=0, fused_mlp=False)            # unfused MLPs: the autograd trainer's territory
     with pytest.raises(ValueError):
         Stage0Engine(NeRFNetwork(opt), opt, synthetic.make_cameras(4, seed=0), torch.device("cuda", 0))
 
