@@ -171,7 +171,11 @@ class NeRFRenderer(nn.Module):
             if self.opt.sdf:
                 raw_normal = self.normal(xyzs, self.opt.normal_anneal_epsilon)
                 results["normal"] = raw_normal
-                true_cos = (dirs * safe_normalize(raw_normal)).sum(-1)
+                # (the fused field normalises the ray directions on load and leaves `dirs` raw: the cosine needs the unit vectors of
+                # nerf/renderer.py:720 -- rounds 1-2 used the raw ones here, |d| up to 1.1, found when the step executor's SDF head, written
+                # from the reference text, disagreed with this path)
+                unit_dirs = safe_normalize(dirs) if in_kernel else dirs
+                true_cos = (unit_dirs * safe_normalize(raw_normal)).sum(-1)
                 car = self.opt.cos_anneal_ratio
                 iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - car) + F.relu(-true_cos) * car)
                 sigmas = self._sdf_to_alpha(sigmas, iter_cos, ts[:, 1])
