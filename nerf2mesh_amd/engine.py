@@ -97,10 +97,12 @@ class Stage0Engine:
             from .parallel import GradSync
             self.sync = GradSync(model, world_size)
         self.side = L.side_stream(dev, slot=2)
-        # TV terms of the batch on a third stream beside the field kernels (n2m_grid_tv_terms): the stencil's gathers leave the backward's
-        # critical path (A/B: N2M_TV_SPLIT=0 evaluates them inside the fill as before; same bits)
+        # TV terms of the batch as their own kernel on a third stream beside the field kernels (n2m_grid_tv_terms + ..._pair_tvt): takes the
+        # stencil's gathers out of the fill (backward 286 -> 250 us) -- but whatever kernel the terms' launch overlaps slows down by about its
+        # own 55-95 us (field forward 31 -> 52, compositing 18 -> 50, field backward 59 -> 102: tools/sweep_tv.sh, profiles/r03_tv_split_sweep.txt),
+        # so the step LOSES 14-27 us.  Kept as a measured alternative (N2M_TV_SPLIT=1, N2M_TV_AT, N2M_TV_PRIO); off by default.  Same bits.
         self.tv_stream = L.side_stream(dev, slot=3, priority=int(os.environ.get("N2M_TV_PRIO", "0")))
-        self.tv_split = os.environ.get("N2M_TV_SPLIT", "1") != "0"
+        self.tv_split = os.environ.get("N2M_TV_SPLIT", "0") == "1"
         self.tv_at = int(os.environ.get("N2M_TV_AT", "0"))      # where the terms' kernel may start: 0 behind the lookup, 1 behind the field forward, 2 behind compositing
         self.split_backward = True            # multi-rank: table backward in two level halves, the first half's all-reduce under the second
         self.overlap = True                   # next batch on the side stream (False: everything on the main stream, same results)
