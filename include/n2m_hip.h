@@ -495,11 +495,12 @@ int n2m_scaler_update_slots_loss3(float* scale, float* growth_tracker, float* fo
 
 /* SDF head of the step executor (config 5; the caller-side arithmetic of nerf/renderer.py:724-739, nerf/network.py:143-154 and the eikonal
  * loss of nerf/utils.py:740-743 -- the torch statement in nerf2mesh_amd/{renderer,network}.py is the parity baseline):
- *  n2m_sdf_offsets        pts [6, M, 3] = clamp(xyz +- eps e_axis, -bound, bound) (k = 2 axis + (minus ? 1 : 0)), pts01 = (pts + bound) / (2 bound)
- *  n2m_sdf_alpha_forward  sdf [M], sdf6 [6, M] (the field at pts), dirs [M,3] (raw ray directions), ts [M,2], variance (device scalar)
+ *  n2m_sdf_offsets        pts [M, 6, 3] = clamp(xyz +- eps e_axis, -bound, bound) (k = 2 axis + (minus ? 1 : 0)), pts01 = (pts + bound) / (2 bound);
+ *                         SAMPLE-major: the six copies of a sample are adjacent (they share their cell on almost every level)
+ *  n2m_sdf_alpha_forward  sdf [M], sdf6 [M, 6] (the field at pts), dirs [M,3] (raw ray directions), ts [M,2], variance (device scalar)
  *                         -> alpha [M] (NeuS-style, clipped to [0,1]), normal [M,3] (raw finite-difference normal, may be NULL), eik_partial
  *                            [ceil(M/256)] = per-workgroup sums of (|normal| - 1)^2 (may be NULL)
- *  n2m_sdf_alpha_backward d_alpha [M] -> d_sdf [M], d_sdf6 [6, M], d_variance [1] (= sum of var_partial [ceil(M/256)], fixed order; found_inf is
+ *  n2m_sdf_alpha_backward d_alpha [M] -> d_sdf [M], d_sdf6 [M, 6], d_variance [1] (= sum of var_partial [ceil(M/256)], fixed order; found_inf is
  *                         raised when it is not finite); adds the eikonal term's gradient *seed * eik_coef * (|n| - 1) n / |n| with
  *                         eik_coef = lambda_eikonal * 2 / M on the host. */
 int n2m_sdf_offsets(const float* xyz, uint32_t M, float eps, float bound, float* pts, float* pts01, void* stream);

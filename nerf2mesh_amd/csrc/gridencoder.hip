@@ -2327,7 +2327,9 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
             if (both) N2M_HIP(hipMemsetAsync(table1 + t0, 0, (t1 - t0) * sizeof(float), s));
             if (has2) N2M_HIP(hipMemsetAsync(table2 + t0 * 2u, 0, (t1 - t0) * 2u * sizeof(_Float16), s));
         }
-        static const uint32_t merge_levels = getenv("N2M_BIN_MERGE_LEVELS") ? (uint32_t)atoi(getenv("N2M_BIN_MERGE_LEVELS")) : kPairMergeLevels;
+        static const uint32_t merge_env = getenv("N2M_BIN_MERGE_LEVELS") ? (uint32_t)atoi(getenv("N2M_BIN_MERGE_LEVELS")) : kPairMergeLevels;
+        // the density table alone = the SDF head's finite-difference copies, six adjacent samples a few 1e-4 apart: same cell on ALL levels
+        const uint32_t merge_levels = has2 ? merge_env : kMaxLevels;
         static const bool xcd_map = getenv("N2M_FILL_NO_XCD") == nullptr;       // A/B switch; measured 332 -> 311 us for fill + accumulates
         dim3 grid((lay.plan.tiles + kPairTilesPerWg - 1) / kPairTilesPerWg, max_level);           // each workgroup walks ~kPairTilesPerWg tiles
         uint32_t groups_x = 0, slot_begin = 0;

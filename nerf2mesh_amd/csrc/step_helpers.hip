@@ -188,8 +188,10 @@ stage1_head_kernel(const float* __restrict__ aa_alpha /*[h0 S, w0 S]*/, const fl
 // ------------------------------------------------------------------------------------------------ SDF head (config 5)
 // The caller-side arithmetic of the reference's SDF branch (nerf/renderer.py:724-739, nerf/network.py:143-154, nerf/utils.py:740-743) as
 // three kernels for the step executor; the torch statement in nerf2mesh_amd/{renderer,network}.py stays the parity baseline.
-//   offsets : pts[k, m] = clamp(x[m] +- eps e_axis, -bound, bound) for the six finite-difference copies (k = 2 axis + (minus ? 1 : 0)),
-//             and the same points normalised to [0,1] as grid.py:156 does ((p + bound) / (2 bound))
+//   offsets : pts[m, k] = clamp(x[m] +- eps e_axis, -bound, bound) for the six finite-difference copies (k = 2 axis + (minus ? 1 : 0)),
+//             and the same points normalised to [0,1] as grid.py:156 does ((p + bound) / (2 bound)).  The copies of a sample are ADJACENT
+//             (sample-major [M, 6]; the torch statement stacks them [6, M]): they fall into the same cell on almost every level, so the
+//             density encoder's gathers coalesce and its backward merges the six updates of a vertex into one entry
 //   forward : normal = 0.5 (s+ - s-) / eps; cos = dir^ . normal^ (safe_normalize both); iter_cos = -(relu(0.5 - 0.5 cos)(1 - car) +
 //             relu(-cos) car); inv_s = clip(exp(10 variance), 1e-6, 1e6); p = sigmoid((sdf - iter_cos dt / 2) inv_s), q = sigmoid((sdf +
 //             iter_cos dt / 2) inv_s); alpha = clip((p - q + 1e-5) / (p + 1e-5), 0, 1); eikonal partial sums of (|normal| - 1)^2
@@ -201,7 +203,7 @@ sdf_offsets_kernel(const float* __restrict__ xyz, uint32_t M, float eps, float b
     const float x[3] = {xyz[3 * (size_t)m], xyz[3 * (size_t)m + 1], xyz[3 * (size_t)m + 2]};
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        const size_t o = ((size_t)k * M + m) * 3;
+        const size_t o = ((size_t)m * 6 + k) * 3;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float off = (a == (k >> 1)) ? ((k & 1) ? -eps : eps) : 0.0f;
@@ -217,7 +219,7 @@ __device__ __forceinline__ SdfSample sdf_sample(const float* __restrict__ sdf, c
                                                 const float* __restrict__ ts, uint32_t M, uint32_t m, float var, float eps, float car) {
     SdfSample r;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) r.n[a] = 0.5f * (s6[(size_t)(2 * a) * M + m] - s6[(size_t)(2 * a + 1) * M + m]) / eps;
+    for (int a = 0; a < 3; ++a) r.n[a] = 0.5f * (s6[(size_t)m * 6 + 2 * a] - s6[(size_t)m * 6 + 2 * a + 1]) / eps;
     const float d[3] = {dirs[3 * (size_t)m], dirs[3 * (size_t)m + 1], dirs[3 * (size_t)m + 2]};
     const float dd = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
     r.nn = (r.n[0] * r.n[0] + r.n[1] * r.n[1]) + r.n[2] * r.n[2];
@@ -299,8 +301,8 @@ sdf_alpha_backward_kernel(const float* __restrict__ d_alpha, const float* __rest
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float t = 0.5f * dn[a] / eps;
-            d_s6[(size_t)(2 * a) * M + m] = t;
-            d_s6[(size_t)(2 * a + 1) * M + m] = -t;
+            d_s6[(size_t)m * 6 + 2 * a] = t;
+            d_s6[(size_t)m * 6 + 2 * a + 1] = -t;
         }
     }
     dvar = n2m_wave_sum(dvar);

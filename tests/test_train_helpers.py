@@ -163,8 +163,9 @@ def test_sdf_head_kernels_against_the_torch_statement():
     M, eps, car, bound = 70001, 3e-2, 0.3, 1.0
     xyz = (torch.rand(M, 3, device=dev, generator=g) * 2 - 1) * 1.01
     xyz.clamp_(-1, 1)
-    pts = torch.empty(6, M, 3, device=dev); pts01 = torch.empty(6, M, 3, device=dev)
+    pts = torch.empty(M, 6, 3, device=dev); pts01 = torch.empty(M, 6, 3, device=dev)         # sample-major: the six copies adjacent
     L.call("n2m_sdf_offsets", p(xyz), M, eps, bound, p(pts), p(pts01), L.stream())
+    pts, pts01 = pts.permute(1, 0, 2), pts01.permute(1, 0, 2)                                  # -> the torch statement's [6, M, 3]
     off = torch.zeros(6, 1, 3, device=dev)
     for axis in range(3):
         off[2 * axis, 0, axis] = eps
@@ -194,16 +195,17 @@ def test_sdf_head_kernels_against_the_torch_statement():
     a2, n2 = torch.empty(M, device=dev), torch.empty(M, 3, device=dev)
     nb = (M + 255) // 256
     eik_part = torch.empty(nb, device=dev)
-    L.call("n2m_sdf_alpha_forward", p(sdf.detach()), p(s6.detach()), p(dirs), p(ts), M, p(var.detach()), eps, car, p(a2), p(n2), p(eik_part), L.stream())
+    s6k = s6.detach().t().contiguous()                                                       # [M, 6] as the kernels take it
+    L.call("n2m_sdf_alpha_forward", p(sdf.detach()), p(s6k), p(dirs), p(ts), M, p(var.detach()), eps, car, p(a2), p(n2), p(eik_part), L.stream())
     assert float((a2 - alpha.detach()).abs().max()) <= 2e-6
     assert float((n2 - normal.detach()).abs().max()) <= 1e-6 * float(normal.detach().abs().max())
     assert abs(float(eik_part.double().sum() / M) - float(eik)) <= 1e-5 * float(eik)
-    d_sdf, d_s6 = torch.empty(M, device=dev), torch.empty(6, M, device=dev)
+    d_sdf, d_s6 = torch.empty(M, device=dev), torch.empty(M, 6, device=dev)
     var_part, d_var, finf = torch.empty(nb, device=dev), torch.empty(1, device=dev), torch.zeros((), device=dev)
-    L.call("n2m_sdf_alpha_backward", p(w), p(sdf.detach()), p(s6.detach()), p(dirs), p(ts), M, p(var.detach()), eps, car, p(seed),
+    L.call("n2m_sdf_alpha_backward", p(w), p(sdf.detach()), p(s6k), p(dirs), p(ts), M, p(var.detach()), eps, car, p(seed),
            float(lam_eik * 2.0 / M), p(d_sdf), p(d_s6), p(var_part), p(d_var), p(finf), L.stream())
     rel = lambda a, b: float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
     assert rel(d_sdf, sdf.grad) <= 2e-5, rel(d_sdf, sdf.grad)
-    assert rel(d_s6, s6.grad) <= 2e-5, rel(d_s6, s6.grad)
+    assert rel(d_s6.t(), s6.grad) <= 2e-5, rel(d_s6.t(), s6.grad)
     assert abs(float(d_var) - float(var.grad)) <= 2e-4 * abs(float(var.grad)), (float(d_var), float(var.grad))
     assert float(finf) == 0.0
