@@ -1174,8 +1174,7 @@ def test_colour_only_pair_backward_equals_the_pair_call(be):
 @pytest.mark.parametrize("max_level", [16, 5])
 def test_density_only_pair_backward_equals_the_pair_call(be, max_level):
     """grad2 = NULL: the density table alone through the shared-fill kernels (the SDF head's stacked finite-difference samples; progressive
-    max_level < 16 included), against the full pair call: bitwise on the levels a single work item owns, fp32 atomic-order noise on the
-    small dense levels that are split over tile groups."""
+    max_level < 16 included), against the full pair call: equal up to fp32 rounding of merged runs / atomic order."""
     torch = be["torch"]
     from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward, binned_backward_pair
     B = 120007
@@ -1193,11 +1192,12 @@ def test_density_only_pair_backward_equals_the_pair_call(be, max_level):
     b1 = torch.zeros(rows, 1, device="cuda")
     assert binned_backward(e1, d1, x, b1, max_level)               # -> the pair entry with grad2 = NULL
     offs = np.asarray(e1.host_offsets)
-    lo, hi = int(offs[min(8, max_level)]), int(offs[max_level])
-    assert torch.equal(a1[lo:hi], b1[lo:hi])
+    hi = int(offs[max_level])
     assert float(b1[hi:].abs().max() if hi < rows else 0.0) == 0.0          # levels beyond max_level are not touched
-    d = (a1[:lo] - b1[:lo]).abs()
-    assert float(d.max()) <= 2e-6 * float(a1[:lo].abs().max())
+    # the lone density table merges same-cell runs on ALL levels (its callers are the SDF head's adjacent finite-difference copies), the pair
+    # call on levels 0..8: one more fp32 rounding per merged run on the fine levels, atomic-order noise on the small split dense levels
+    d = (a1[:hi] - b1[:hi]).abs()
+    assert float(d.max()) <= 4e-6 * float(a1[:hi].abs().max())
     assert float(b1.abs().sum()) > 0
 
 
