@@ -25,4 +25,8 @@ python bench.py > $O/${TAG}_bench.json 2>$O/bench.err; python tools/show_bench.p
 python bench.py --diffuse --no-cpu-baseline > $O/${TAG}_bench_diffuse.json 2>/dev/null; python tools/show_bench.py $O/${TAG}_bench_diffuse.json | head -1
 python bench.py --stage 1 > $O/${TAG}_bench_stage1.json 2>/dev/null; python tools/show_bench.py $O/${TAG}_bench_stage1.json | head -1
 python bench.py --recipe sdf --no-cpu-baseline > $O/${TAG}_bench_sdf.json 2>/dev/null; python tools/show_bench.py $O/${TAG}_bench_sdf.json | head -1
+python bench.py --recipe sdf --diffuse --no-cpu-baseline > $O/${TAG}_bench_sdf_early.json 2>/dev/null; python tools/show_bench.py $O/${TAG}_bench_sdf_early.json | head -1
+python bench.py --recipe sdf --no-cpu-baseline --autograd > $O/${TAG}_bench_sdf_autograd.json 2>/dev/null; python tools/show_bench.py $O/${TAG}_bench_sdf_autograd.json | head -1
+bash tools/sweep_tv.sh > $O/${TAG}_tv_split_sweep.txt 2>&1; cat $O/${TAG}_tv_split_sweep.txt
+bash tools/sweep_marker.sh > $O/${TAG}_marker_sweep.txt 2>&1; cat $O/${TAG}_marker_sweep.txt
 python bench.py --recipe garden --no-cpu-baseline > $O/${TAG}_bench_garden.json 2>/dev/null; python tools/show_bench.py $O/${TAG}_bench_garden.json | head -1
