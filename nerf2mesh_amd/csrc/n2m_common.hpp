@@ -82,6 +82,10 @@ __device__ __forceinline__ uint32_t n2m_gather3(uint32_t v) {
 // ~60-cycle trips, this is six VALU operations).  Inclusive scan: Hillis-Steele inside each row of 16 lanes (row_shr 1/2/4/8; lanes
 // without a source keep the identity), then lane 15 of rows 0/2 into rows 1/3 (row_bcast:15) and lane 31 into rows 2/3 (row_bcast:31).
 // Sums/products are associated in that order (fp results differ from a serial sum in the last bits, like any parallel reduction).
+// PRECONDITION of every helper below (scans, n2m_wave_sum*, n2m_lane63, n2m_lane_below): ALL 64 LANES ACTIVE at the call -- wave-uniform
+// control flow only.  A DPP source lane that is masked off leaves the identity in place (silently dropping its value from the scan) and
+// v_readlane of lane 63 returns a stale register when that lane is inactive; the ds_bpermute helpers these replaced tolerated divergence.
+// Callers mask with a select (`valid ? x : identity`), never with a branch around the call.
 #define N2M_DPP_STEP(OP, ident, ctrl, rows) v = OP(v, __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (T)(ident)), __builtin_bit_cast(int, v), (ctrl), (rows), 0xf, false)))
 template <typename T, class F>
 __device__ __forceinline__ T n2m_wave_scan_dpp(T v, T ident, F OP) {
