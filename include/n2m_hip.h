@@ -314,6 +314,37 @@ int n2m_grid_encode_backward_binned_pair_half(const float* grad1, const void* gr
                                          float in_offset, int overwrite, void* workspace, uint64_t workspace_bytes,
                                          void* stream, int half);
 
+/* The table backward with the OPTIMIZER PASS of the hashed levels inside it.  On every level whose partitions one accumulate work item owns
+ * (n2m_grid_pair_fuse_plan: all levels from first_level on, for batches up to max_samples) the flush holds the final gradient row in registers;
+ * n2m_grid_encode_backward_binned_pair_adam lets it do what n2m_adam_step would do for that row -- same arithmetic, element for element --
+ * instead of storing the gradient for a later pass: the 98 MB gradient round trip disappears.  MEASURED SLOWER than the separate pass on
+ * MI355X (the accumulates move the optimizer state at a third of n2m_adam_step's rate: step 0.632 -> 0.682 ms); the
+ * engine uses it only with N2M_FUSE_ADAM=1.  GradScaler's skip is all-or-nothing and the verdict is known only when the last item has flushed, so
+ * the update is written BESIDE the old state: parameter and both moments of the two tables exist twice, the flush reads the *_in buffers and
+ * writes the *_out buffers (and its column of the packed table).  Rows below first_row (small dense levels, split over tile groups) and all
+ * other tensors keep n2m_adam_step, in place on the *_in buffers.  n2m_adam_fuse_restore, launched behind BOTH (and in front of the scaler
+ * update that clears found_inf), then copies rows [0, first_row) from *_in to *_out and, when found_inf is set, the remaining rows too
+ * (re-packing the old parameters): after it the *_out buffers hold the complete state of the step -- taken or skipped -- and the caller
+ * swaps the roles of the two buffer sets without reading the verdict.
+ * [0] = density table (C = 1, fp32 gradient), [1] = colour table (C = 2, gradient rounded to fp16 like the unfused path's). */
+typedef struct {
+    const float* p_in[2]; const float* m_in[2]; const float* v_in[2];      /* live buffers, whole tables: element row * C + c */
+    float* p_out[2]; float* m_out[2]; float* v_out[2];                    /* the other set */
+    void* packed;                                                         /* the packed table the lookup reads (all rows) */
+    uint32_t first_level;
+    float lr[2]; int32_t slot[2];                                          /* learning rate / step-count slot (bias[2 slot], bias[2 slot + 1]) per table */
+    double beta1, beta2; float eps;
+    const float* scale; const float* bias;                                /* device: loss scale (may be NULL), bias corrections as n2m_adam_step */
+} N2mAdamFuse;
+int n2m_grid_pair_fuse_plan(uint32_t max_samples, uint32_t L, const int32_t* host_offsets, uint32_t* first_level, uint32_t* first_row);
+int n2m_grid_encode_backward_binned_pair_adam(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
+                                              float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level, float S,
+                                              uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, const float* tv_embeddings,
+                                              float tv_weight, float tv_weight_outer, float tv_inner01, const float* tv_scale, float* found_inf,
+                                              float in_scale, float in_offset, void* workspace, uint64_t workspace_bytes, const N2mAdamFuse* fuse,
+                                              void* stream);
+int n2m_adam_fuse_restore(const N2mAdamFuse* fuse, const int32_t* host_offsets, uint32_t L, const float* found_inf, void* stream);
+
 /* The TV terms of a batch on their own: tv_out[level, s] (f32 [L, B]) = the total-variation term of (sample s, level) exactly as the shared
  * fill evaluates it in place when it is handed tv_embeddings (gridencoder.cu:505-609 on the cell floor(x * scale + 0.5); weight / weight_outer /
  * inner01 / scale as in n2m_grid_encode_backward_binned_pair) -- and n2m_grid_encode_backward_binned_pair_tvt, the same backward consuming

@@ -53,6 +53,10 @@ SIGNATURES = {
                                              _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _int, _vp, _u64, _vp],
     "n2m_grid_encode_backward_binned_pair_half": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
                                                   _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _int, _vp, _u64, _vp, _int],
+    "n2m_grid_pair_fuse_plan": [_u32, _u32, _vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)],
+    "n2m_grid_encode_backward_binned_pair_adam": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
+                                                  _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _vp, _u64, _vp, _vp],
+    "n2m_adam_fuse_restore": [_vp, _vp, _u32, _vp, _vp],
     "n2m_grid_tv_terms": [_vp, _vp, _vp, _u32, _u32, _f32, _u32, _u32, _int, _u32, _f32, _f32, _f32, _vp, _f32, _f32, _vp, _vp],
     "n2m_grid_encode_backward_binned_pair_tvt": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
                                                  _vp, _vp, _f32, _f32, _int, _vp, _u64, _vp, _int],
@@ -115,6 +119,13 @@ class AdamDesc(ctypes.Structure):
     _fields_ = [("param", _vp * ADAM_MAX), ("grad", _vp * ADAM_MAX), ("exp_avg", _vp * ADAM_MAX), ("exp_avg_sq", _vp * ADAM_MAX),
                 ("half_shadow", _vp * ADAM_MAX), ("numel", _u32 * ADAM_MAX), ("lr", _f32 * ADAM_MAX), ("grad_is_half", _i32 * ADAM_MAX),
                 ("shadow_mode", _i32 * ADAM_MAX), ("clear_grad", _i32 * ADAM_MAX), ("slot", _i32 * ADAM_MAX), ("count", _u32)]
+
+
+class AdamFuse(ctypes.Structure):
+    """N2mAdamFuse of include/n2m_hip.h."""
+    _fields_ = [("p_in", _vp * 2), ("m_in", _vp * 2), ("v_in", _vp * 2), ("p_out", _vp * 2), ("m_out", _vp * 2), ("v_out", _vp * 2),
+                ("packed", _vp), ("first_level", _u32), ("lr", _f32 * 2), ("slot", _i32 * 2), ("beta1", ctypes.c_double),
+                ("beta2", ctypes.c_double), ("eps", _f32), ("scale", _vp), ("bias", _vp)]
 
 
 KERNEL_IDS = {"grid_encode_forward": 0, "grid_encode_backward": 1, "grad_total_variation": 2, "march_rays_train_count": 3,

@@ -1759,6 +1759,24 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
     }
 }
 
+// Adam inside the accumulate's flush (n2m_grid_encode_backward_binned_pair_adam): on the levels whose partitions ONE work item owns (every
+// hashed level of a 2^18-sample batch) the flush has the final gradient row in registers -- instead of storing it for an optimizer pass that
+// reads it back together with parameter and moments, the item performs that pass for its rows: reads p / m / v from the LIVE buffers, writes
+// the updated ones to the OTHER buffers (double-buffered: GradScaler's skip is all-or-nothing and the verdict is only known when the last
+// item has flushed, so the update is made beside the old state and a restore pass copies the old state over it on a skipped step) and
+// refreshes its column of the packed table the lookup reads.  Arithmetic = adam_kernel's (step_helpers.hip), element for element.
+#ifndef N2M_FUSE_BATCH
+#define N2M_FUSE_BATCH 2      // (measured: 2 -> backward 401 us, 4 -> 433 us, 8 -> 472 us: more loads in flight only add spills)
+#endif
+struct AdamFuse {
+    const float* p_in; const float* m_in; const float* v_in;      // live buffers (whole tables: element row * C + c)
+    float* p_out; float* m_out; float* v_out;                    // the other buffers
+    uint32_t* packed;                                            // packed table, 8-byte rows {fp32 density, half2 colour}
+    uint32_t first_level;                                        // first fused level
+    float lr, beta1, beta2, omb1, omb2, eps;
+    const float* scale; const float* bias; uint32_t slot;
+};
+
 // P = table rows per partition; SUB = consecutive partitions one work item accumulates (their runs are adjacent in the
 // partition-sorted tiles, so they stream as one run): LDS accumulator SUB * P * C * 8 bytes.  SUB = 2 lets the fp32 table, whose
 // rows are half as wide, keep 8192-row items on the 4096-row partition structure it shares with the fp16 table.
@@ -1768,12 +1786,13 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
 __device__ unsigned long long g_acc_t[2][2][5];
 #define N2M_ACC_STAMP(i) do { if (stamp) g_acc_t[sizeof(T) == 4 ? 0 : 1][stamp_w][(i)] = __builtin_readcyclecounter(); } while (0)
 
-template <typename T, uint32_t C, uint32_t P, uint32_t SUB, bool SOA = false>
+template <typename T, uint32_t C, uint32_t P, uint32_t SUB, bool SOA = false, bool FUSE = false>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, uint32_t gridtype, bool align_corners,
                       const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ directory,
                       const uint64_t* __restrict__ log, float* __restrict__ found_inf, const uint16_t* __restrict__ log_rel = nullptr,
-                      const uint32_t* __restrict__ log_val = nullptr, bool overwrite = false, uint32_t dbg = 0, float inf_bound = 0.0f) {
+                      const uint32_t* __restrict__ log_val = nullptr, bool overwrite = false, uint32_t dbg = 0, float inf_bound = 0.0f,
+                      AdamFuse af = AdamFuse{}) {
     // overwrite: the gradient table holds no earlier sums.  Partitions owned by one workgroup (Gl == 1) are then STORED in full,
     // zeros included -- no read-modify-write round trips in the flush (measured: eight dependent load-add-store steps per item were
     // a third of this kernel) and no zero-fill of the table before the call; levels split over several groups still add
@@ -1947,7 +1966,62 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
         N2M_ACC_STAMP(3);
         const bool second_walk = store_all && nonfinite_seen != 0u;       // read here: the next item resets the flag before ITS first barrier
 
-        for (uint32_t rel = tid; rel < ((dbg & 2u) ? 0u : SUB * P); rel += 1024) {
+        const bool fused_level = FUSE && level >= af.first_level;         // (store_all holds: these levels are owned by one work item)
+        if (fused_level && !(dbg & 2u)) {
+            // the optimizer pass for this item's rows: parameter and moments in (streaming, like adam_kernel's), the sums from LDS, the
+            // update, the stores -- N2M_FUSE_BATCH values per thread requested together
+            constexpr uint32_t IT = SUB * P / 1024u, IB = N2M_FUSE_BATCH / C;      // rows per thread, rows per batch of loads (registers: 64 per lane)
+            typedef float vC __attribute__((ext_vector_type(C == 1 ? 1 : 2)));
+            const float bc1 = af.bias[2u * af.slot], bc2_sqrt = af.bias[2u * af.slot + 1u];
+            const float step_size = af.lr / bc1, inv_scale = af.scale ? 1.0f / *af.scale : 1.0f;
+            const float bound = inf_bound > 0.0f ? inf_bound : (sizeof(T) == 4 ? 3.0e38f : 65504.0f);
+            for (uint32_t ib = 0; ib < IT; ib += IB) {
+                vC pi[IB], mi[IB], vi[IB];
+                uint32_t grow[IB];
+#pragma unroll
+                for (uint32_t it = 0; it < IB; ++it) {
+                    const uint32_t rel = tid + (ib + it) * 1024u, u = rel >> kLog2P, rel0 = rel & (P - 1u);
+                    grow[it] = 0xffffffffu;
+                    if (part0 + u >= part_end || rel0 >= rows_of(part0 + u)) continue;
+                    const uint32_t row = global_row(u, rel0);
+                    if (row >= size) continue;
+                    grow[it] = row0 + row;
+                    const size_t e = (size_t)grow[it] * C;
+                    pi[it] = __builtin_nontemporal_load(reinterpret_cast<const vC*>(af.p_in + e));
+                    mi[it] = __builtin_nontemporal_load(reinterpret_cast<const vC*>(af.m_in + e));
+                    vi[it] = __builtin_nontemporal_load(reinterpret_cast<const vC*>(af.v_in + e));
+                }
+#pragma unroll
+                for (uint32_t it = 0; it < IB; ++it) {
+                    if (grow[it] == 0xffffffffu) continue;
+                    const uint32_t rel = tid + (ib + it) * 1024u;
+                    vC po, mo, vo;
+#pragma unroll
+                    for (uint32_t c = 0; c < C; ++c) {
+                        const float f = (float)(long long)bin_acc[rel * C + c] * inv;
+                        if (!(fabsf(f) <= bound) && found_inf) *found_inf = 1.0f;
+                        // the gradient as the separate pass would read it back from the table: fp32, or the sum rounded to fp16 and widened again
+                        const float gr = (sizeof(T) == 4 ? f : (float)(_Float16)f) * inv_scale;
+                        const float m = af.beta1 * mi[it][c] + af.omb1 * gr;
+                        const float v = af.beta2 * vi[it][c] + af.omb2 * gr * gr;
+                        const float denom = sqrtf(v) / bc2_sqrt + af.eps;
+                        po[c] = pi[it][c] - step_size * m / denom;
+                        mo[c] = m; vo[c] = v;
+                    }
+                    const size_t e = (size_t)grow[it] * C;
+                    __builtin_nontemporal_store(po, reinterpret_cast<vC*>(af.p_out + e));
+                    __builtin_nontemporal_store(mo, reinterpret_cast<vC*>(af.m_out + e));
+                    __builtin_nontemporal_store(vo, reinterpret_cast<vC*>(af.v_out + e));
+                    if constexpr (C == 1) af.packed[(size_t)grow[it] * 2u] = __float_as_uint(po[0]);
+                    else {
+                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                        h2 c16; c16.x = (_Float16)po[0]; c16.y = (_Float16)po[1];
+                        af.packed[(size_t)grow[it] * 2u + 1u] = __builtin_bit_cast(uint32_t, c16);
+                    }
+                }
+            }
+        }
+        for (uint32_t rel = tid; rel < ((dbg & 2u) || fused_level ? 0u : SUB * P); rel += 1024) {
             const uint32_t u = rel >> kLog2P, rel0 = rel & (P - 1u);
             if (part0 + u >= part_end || rel0 >= rows_of(part0 + u)) continue;
             const uint32_t row = global_row(u, rel0);
@@ -2265,7 +2339,8 @@ int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table
 int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* inputs, TvParams tv, float* table1, _Float16* table2, uint32_t B,
                        uint32_t max_level, const int32_t* host_offsets, const LevelTable& lv, uint32_t gridtype, bool align, uint32_t interp,
                        void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn, float* found_inf, float in_scale,
-                       float in_offset, bool overwrite, uint32_t L, int half = 0, const float* tv_terms = nullptr) {
+                       float in_offset, bool overwrite, uint32_t L, int half = 0, const float* tv_terms = nullptr,
+                       const AdamFuse* fuse1 = nullptr, const AdamFuse* fuse2 = nullptr) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
@@ -2273,6 +2348,8 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
         (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<float, 1, kPairP, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
         (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<_Float16, 2, kPairP, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
+        (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<float, 1, kPairP, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
+        (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<_Float16, 2, kPairP, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
         attr_set = true;
     }
     for (uint32_t b0 = 0; b0 < B; b0 += kBinChunk) {
@@ -2357,6 +2434,21 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         static const uint32_t acc_dbg = getenv("N2M_ACC_DEBUG") ? (uint32_t)atoi(getenv("N2M_ACC_DEBUG")) : 0u;   // measurement switches (wrong results)
         static const uint32_t acc_cap = getenv("N2M_ACC_GRID") ? (uint32_t)atoi(getenv("N2M_ACC_GRID")) : 4096u;    // A/B: persistent workgroups
         const float odiv = g_cfg_overflow_div.load();
+        if (fuse1 || fuse2) {
+            // Adam in the flush: every fused level must be owned by one work item per partition (its flush holds the FINAL sums), in one pass
+            N2M_REQUIRE(both && has2 && fuse1 && fuse2 && ow && half == 0 && B <= kBinChunk, N2M_EINVAL,
+                        "%s: the fused optimizer pass needs both tables, overwrite mode, all levels and one pass (B <= %u)", fn, kBinChunk);
+            for (uint32_t l = fuse1->first_level; l < max_level; ++l)
+                N2M_REQUIRE(plan1.groups[l] == 1u && lay.plan.groups[l] == 1u, N2M_EINVAL,
+                            "%s: level %u is split over tile groups at B = %u: it cannot take the fused optimizer pass (n2m_grid_pair_fuse_plan)", fn, l, B);
+            bin_accumulate_kernel<float, 1, kPairP, 2, true, true><<<items1 < acc_cap ? items1 : acc_cap, 1024, kPairP * 16, s>>>(
+                table1, plan1, lv, gridtype, align, level_max, directory, nullptr, found_inf, log_rel, log_v1, ow, acc_dbg, 3.0e38f / odiv, *fuse1);
+            N2M_CHECK_LAUNCH();
+            bin_accumulate_kernel<_Float16, 2, kPairP, 1, true, true><<<nb, 1024, kPairP * 16, s>>>(
+                table2, plan2, lv, gridtype, align, level_max + kMaxLevels, directory, nullptr, found_inf, log_rel, log_v2, ow, acc_dbg, 65504.0f / odiv, *fuse2);
+            N2M_CHECK_LAUNCH();
+            continue;
+        }
         if (both) {
             bin_accumulate_kernel<float, 1, kPairP, 2, true><<<items1 < acc_cap ? items1 : acc_cap, 1024, kPairP * 16, s>>>(
                 table1, plan1, lv, gridtype, align, level_max, directory, nullptr, found_inf, log_rel, log_v1, ow, acc_dbg, 3.0e38f / odiv);
@@ -2579,7 +2671,8 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
                              float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                              const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
                              const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
-                             void* workspace, uint64_t workspace_bytes, void* stream, int half, const float* tv_terms = nullptr);
+                             void* workspace, uint64_t workspace_bytes, void* stream, int half, const float* tv_terms = nullptr,
+                             const AdamFuse* fuse1 = nullptr, const AdamFuse* fuse2 = nullptr);
 
 extern "C" int n2m_grid_encode_backward_binned_pair(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
                                                     float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
@@ -2609,7 +2702,8 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
                              float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                              const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
                              const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
-                             void* workspace, uint64_t workspace_bytes, void* stream, int half, const float* tv_terms) {
+                             void* workspace, uint64_t workspace_bytes, void* stream, int half, const float* tv_terms, const AdamFuse* fuse1,
+                             const AdamFuse* fuse2) {
     const char* fn = "grid_encode_backward_binned_pair";
     if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
     N2M_REQUIRE(inputs && host_offsets && workspace && (grad1 || grad2), N2M_ENULL, "%s: NULL tensor", fn);
@@ -2636,7 +2730,93 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
     N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (12.0 + lvls * esz + 2.0 * lvls * 8 * esz + (tv_embeddings ? lvls * 7 * 4.0 : 0.0) + (tv_terms ? lvls * 4.0 : 0.0)));
     return launch_binned_pair(grad1, (const _Float16*)grad2, inputs, tv, grad_embeddings1, (_Float16*)grad_embeddings2, B, max_level, host_offsets, lv,
                               gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf, in_scale, in_offset, overwrite != 0, L,
-                              half, tv_terms);
+                              half, tv_terms, fuse1, fuse2);
+}
+
+// ---- the table backward with the optimizer pass of the hashed levels inside the accumulates' flush (see AdamFuse)
+extern "C" int n2m_grid_pair_fuse_plan(uint32_t max_samples, uint32_t L, const int32_t* host_offsets, uint32_t* first_level, uint32_t* first_row) {
+    N2M_REQUIRE(host_offsets && first_level && first_row && max_samples > 0 && max_samples <= kBinChunk, N2M_EINVAL, "grid_pair_fuse_plan: bad arguments");
+    const BinLayout lay = make_bin_plan(max_samples, 2, L, host_offsets, false, kPairP, 2);
+    N2M_REQUIRE(lay.ok, N2M_EUNSUPPORTED, "grid_pair_fuse_plan: table layout not supported by the binned path");
+    uint32_t fl = L;
+    for (uint32_t l = L; l-- > 0;) {
+        const uint32_t pairs = (lay.plan.parts[l] + 1u) / 2u;
+        const uint64_t per_item = (uint64_t)8 * max_samples / pairs;
+        const uint32_t g1 = (uint32_t)((per_item + 65535u) / 65536u);
+        if (g1 > 1u || lay.plan.groups[l] > 1u) break;        // same rule as launch_binned_pair
+        fl = l;
+    }
+    *first_level = fl;
+    *first_row = fl < L ? (uint32_t)host_offsets[fl] : (uint32_t)host_offsets[L];
+    return 0;
+}
+
+namespace {
+__global__ void __launch_bounds__(256)
+adam_fuse_restore_kernel(const float* __restrict__ found_inf, AdamFuse f1, AdamFuse f2, uint32_t first_row, uint32_t n_rows) {
+    // rows below first_row: n2m_adam_step has updated them IN PLACE in the live buffers (or left them alone on a skipped step) -- the other
+    // buffers, live from the next step on, get a copy either way (6 % of the rows).  Rows from first_row on: the flush has written the other
+    // buffers; on a skipped step (GradScaler) they must hold the OLD state again, and the packed rows the lookup reads the old parameters.
+    const uint32_t end = *found_inf != 0.0f ? n_rows : first_row;
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < end; r += gridDim.x * 256u) {
+        const float p1 = f1.p_in[r];
+        f1.p_out[r] = p1; f1.m_out[r] = f1.m_in[r]; f1.v_out[r] = f1.v_in[r];
+        const float2 p2 = *reinterpret_cast<const float2*>(f2.p_in + 2u * (size_t)r);
+        *reinterpret_cast<float2*>(f2.p_out + 2u * (size_t)r) = p2;
+        *reinterpret_cast<float2*>(f2.m_out + 2u * (size_t)r) = *reinterpret_cast<const float2*>(f2.m_in + 2u * (size_t)r);
+        *reinterpret_cast<float2*>(f2.v_out + 2u * (size_t)r) = *reinterpret_cast<const float2*>(f2.v_in + 2u * (size_t)r);
+        if (r >= first_row) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 c; c.x = (_Float16)p2.x; c.y = (_Float16)p2.y;
+            *reinterpret_cast<uint2*>(f1.packed + (size_t)r * 2u) = make_uint2(__float_as_uint(p1), __builtin_bit_cast(uint32_t, c));
+        }
+    }
+}
+
+int make_fuse(const N2mAdamFuse* d, AdamFuse& f1, AdamFuse& f2, const char* fn) {
+    N2M_REQUIRE(d && d->packed && d->bias, N2M_ENULL, "%s: NULL fuse descriptor / packed table / bias", fn);
+    for (int t = 0; t < 2; ++t)
+        N2M_REQUIRE(d->p_in[t] && d->m_in[t] && d->v_in[t] && d->p_out[t] && d->m_out[t] && d->v_out[t] && d->p_in[t] != d->p_out[t], N2M_ENULL,
+                    "%s: the fused optimizer pass needs live and shadow buffers of parameter and moments (distinct)", fn);
+    AdamFuse* f[2] = {&f1, &f2};
+    for (int t = 0; t < 2; ++t) {
+        f[t]->p_in = d->p_in[t]; f[t]->m_in = d->m_in[t]; f[t]->v_in = d->v_in[t];
+        f[t]->p_out = d->p_out[t]; f[t]->m_out = d->m_out[t]; f[t]->v_out = d->v_out[t];
+        f[t]->packed = (uint32_t*)d->packed; f[t]->first_level = d->first_level;
+        f[t]->lr = d->lr[t]; f[t]->beta1 = (float)d->beta1; f[t]->beta2 = (float)d->beta2;
+        f[t]->omb1 = (float)(1.0 - d->beta1); f[t]->omb2 = (float)(1.0 - d->beta2); f[t]->eps = d->eps;
+        f[t]->scale = d->scale; f[t]->bias = d->bias; f[t]->slot = (uint32_t)d->slot[t];
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int n2m_grid_encode_backward_binned_pair_adam(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
+                                                         float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
+                                                         float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                                         const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
+                                                         const float* tv_scale, float* found_inf, float in_scale, float in_offset,
+                                                         void* workspace, uint64_t workspace_bytes, const N2mAdamFuse* fuse, void* stream) {
+    const char* fn = "grid_encode_backward_binned_pair_adam";
+    N2M_REQUIRE(host_offsets && fuse && max_level == L && B > 0 && found_inf, N2M_EINVAL, "%s: needs all levels, a non-empty batch and found_inf", fn);
+    N2M_REQUIRE(fuse->first_level < L, N2M_EINVAL, "%s: no level takes the fused pass (first_level %u)", fn, fuse->first_level);
+    AdamFuse f1{}, f2{};
+    if (int rc = make_fuse(fuse, f1, f2, fn)) return rc;
+    return binned_pair_entry(grad1, grad2, inputs, host_offsets, grad_embeddings1, grad_embeddings2, B, L, max_level, S, H, gridtype, align_corners,
+                             interp, tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale, found_inf, in_scale, in_offset, 1, workspace,
+                             workspace_bytes, stream, 0, nullptr, &f1, &f2);
+}
+
+extern "C" int n2m_adam_fuse_restore(const N2mAdamFuse* fuse, const int32_t* host_offsets, uint32_t L, const float* found_inf, void* stream) {
+    const char* fn = "adam_fuse_restore";
+    N2M_REQUIRE(host_offsets && fuse && found_inf && fuse->first_level < L, N2M_EINVAL, "%s: bad arguments", fn);
+    AdamFuse f1{}, f2{};
+    const uint32_t first_row = (uint32_t)host_offsets[fuse->first_level];
+    if (int rc = make_fuse(fuse, f1, f2, fn)) return rc;
+    adam_fuse_restore_kernel<<<n2m_ceil_div(first_row > 0 ? first_row : 1u, 256u), 256, 0, (hipStream_t)stream>>>(found_inf, f1, f2, first_row,
+                                                                                                              (uint32_t)host_offsets[L]);
+    N2M_CHECK_LAUNCH();
+    return 0;
 }
 
 // The same call with the TV terms of the batch precomputed by n2m_grid_tv_terms (tv_terms [L, B] f32): the fill adds tv_terms[level, s] to

@@ -168,6 +168,21 @@ class Stage0Engine:
         self._bwd_cfg = (2 if self.shard else 1, float(world_size))
         if self.shard:
             self.optimizer.shard_sync = lambda: self.sync_parameters(moments=True)      # state_dict() of a sharded run: gather first
+        # ---- single GPU, measured alternative (N2M_FUSE_ADAM=1, off by default): the optimizer pass of the hashed levels (94 % of the rows)
+        # inside the table backward's accumulate kernels (n2m_grid_encode_backward_binned_pair_adam): parameter and moments of both tables
+        # exist twice, the flush reads one set and writes the other, and the two sets swap roles after every step -- model.encoder.embeddings
+        # .data / optimizer.state always name the current one, so nothing outside the step sees the double buffering.  The TV stencil reads
+        # the density column of the packed table.  Same bits as the separate pass (tests/test_engine.py), but the step LOSES 50-85 us: the
+        # accumulates are latency-bound work items (2 per CU, barriers between their phases) and move the optimizer's 0.3 GB at a third of the
+        # rate the streaming n2m_adam_step reaches (backward 287 -> 399-434 us against Adam 93 -> 15 us; lookup 74 -> 88 us), DESIGN 4.11h.
+        self.fuse_adam = None
+        if world_size == 1 and not opt.sdf and self.Lv == 16 and os.environ.get("N2M_FUSE_ADAM", "0") == "1":
+            fl, fr = ctypes.c_uint32(0), ctypes.c_uint32(0)
+            self._fuse_cap = 1 << 19               # samples per batch the plan below holds for (larger batches take the unfused pass)
+            L.call("n2m_grid_pair_fuse_plan", self._fuse_cap, self.Lv, self.ho.ctypes.data, ctypes.byref(fl), ctypes.byref(fr))
+            if fl.value < self.Lv:
+                self.fuse_adam = {"first_level": int(fl.value), "first_row": int(fr.value), "alt": None, "desc": {}}
+                self._bwd_cfg = (2, 1.0)
 
     # ------------------------------------------------------------------------------------------------ configuration
     @staticmethod
@@ -333,18 +348,22 @@ class Stage0Engine:
         return M
 
     # ------------------------------------------------------------------------------------------------------- Adam
-    def _adam_desc(self, full):
-        """The N2mAdamDesc of this model (pointers are fixed for the life of the engine); `full`: the specular head takes part."""
+    def _adam_desc(self, full, dense_only=False):
+        """The N2mAdamDesc of this model (pointers are fixed for the life of the engine); `full`: the specular head takes part;
+        `dense_only`: the two tables take part with their rows below fuse_adam['first_row'] only (the others got their update inside the
+        table backward)."""
         o, model = self.optimizer, self.model
         # packed_tables() hands out a NEW tensor whenever a table was changed through torch (load_state_dict, an in-place edit): the
         # descriptor carries its address (Adam refreshes the copy the forward gathers from), so the address is part of the key
         pk = model.packed_tables()
         assert pk is not None
-        key = (full, getattr(o, "state_epoch", 0), pk.data_ptr(), model.encoder.embeddings.data_ptr(), model.encoder_color.embeddings.data_ptr())
+        key = (full, getattr(o, "state_epoch", 0), pk.data_ptr(), model.encoder.embeddings.data_ptr(), model.encoder_color.embeddings.data_ptr(),
+               dense_only)
         d = self._desc.get(key)
         if d is not None:
             return d
-        self._desc = {k: v for k, v in self._desc.items() if k[1:] == key[1:]}      # descriptors of an older table / state generation
+        live = lambda k: k[1:3] == key[1:3] and (k[3:5] == key[3:5] or (self.fuse_adam is not None and self._is_alt(k[3], k[4])))
+        self._desc = {k: v for k, v in self._desc.items() if live(k)}      # drop descriptors of an older table / state generation
         self._packed = pk
         desc = L.AdamDesc()
         params = [p for g in o.param_groups for p in g["params"]]
@@ -370,12 +389,59 @@ class Stage0Engine:
             desc.half_shadow[k] = sh[0].data_ptr() if sh is not None else None
             desc.shadow_mode[k] = sh[1] if sh is not None else 0
             desc.numel[k], desc.grad_is_half[k], desc.clear_grad[k] = p.numel(), is_half, clear
+            if dense_only and sh is not None:
+                desc.numel[k] = self.fuse_adam["first_row"] * p.shape[1]
             desc.slot[k] = o._slot[p]
             participants |= 1 << (o._slot[p] - 1)
             k += 1
         desc.count = k
         d = self._desc[key] = (desc, participants, groups)
         return d
+
+    # ---- double-buffered table state of the fused optimizer pass
+    def _is_alt(self, p1_ptr, p2_ptr):
+        alt = self.fuse_adam["alt"]
+        return alt is not None and alt["p"][0].data_ptr() == p1_ptr and alt["p"][1].data_ptr() == p2_ptr
+
+    def _fuse_desc(self, lr_factor):
+        """N2mAdamFuse for this step: live set = what the model / optimizer name now, other set = fuse_adam['alt']."""
+        f, o, model = self.fuse_adam, self.optimizer, self.model
+        ps = (model.encoder.embeddings, model.encoder_color.embeddings)
+        if f["alt"] is None or getattr(o, "state_epoch", 0) != f.get("epoch"):
+            f["alt"] = {"p": [torch.empty_like(p.data) for p in ps], "m": [torch.empty_like(p.data) for p in ps],
+                        "v": [torch.empty_like(p.data) for p in ps]}
+            f["epoch"], f["desc"] = getattr(o, "state_epoch", 0), {}
+        alt = f["alt"]
+        key = (ps[0].data_ptr(), ps[1].data_ptr(), self._packed.data_ptr())
+        d = f["desc"].get(key)
+        if d is None:
+            d = L.AdamFuse()
+            for t, p in enumerate(ps):
+                st = o.state[p]
+                d.p_in[t], d.m_in[t], d.v_in[t] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                d.p_out[t], d.m_out[t], d.v_out[t] = alt["p"][t].data_ptr(), alt["m"][t].data_ptr(), alt["v"][t].data_ptr()
+                d.slot[t] = o._slot[p]
+            d.packed, d.first_level = self._packed.data_ptr(), f["first_level"]
+            d.beta1, d.beta2 = (float(x) for x in o.param_groups[0]["betas"])
+            d.eps, d.scale, d.bias = float(o.param_groups[0]["eps"]), o.scale.data_ptr(), o.bias.data_ptr()
+            f["desc"] = {k: v for k, v in f["desc"].items() if k[2] == key[2]}
+            f["desc"][key] = d
+        group_of = {p: g for g in o.param_groups for p in g["params"]}
+        for t, p in enumerate(ps):
+            d.lr[t] = float(group_of[p]["initial_lr"]) * lr_factor
+        return d
+
+    def _fuse_swap(self):
+        """The other buffer set holds the state of the finished step (n2m_adam_fuse_restore has completed it): make it the one the model
+        and the optimizer name."""
+        alt, o, model = self.fuse_adam["alt"], self.optimizer, self.model
+        for t, p in enumerate((model.encoder.embeddings, model.encoder_color.embeddings)):
+            st = o.state[p]
+            p.data, alt["p"][t] = alt["p"][t], p.data
+            st["exp_avg"], alt["m"][t] = alt["m"][t], st["exp_avg"]
+            st["exp_avg_sq"], alt["v"][t] = alt["v"][t], st["exp_avg_sq"]
+        a, b = model.encoder.embeddings, model.encoder_color.embeddings
+        model._packed_key = (a._version, b._version, a.data_ptr(), b.data_ptr())       # same values, new address: the packed copy stays valid
 
     def _shard_ranges(self):
         """(first row, rows) of this rank's slice of the coarse half (levels 0..7) and of the fine half (levels 8..15)."""
@@ -463,15 +529,18 @@ class Stage0Engine:
                 lo = 0 if h == "c" else self._split
                 dist.all_gather_into_tensor(flat[lo * C:(lo + self.world * n) * C], flat[row0 * C:(row0 + n) * C].clone())
 
-    def _optimizer_step(self, full, lr_factor, loss_out=None):
+    def _optimizer_step(self, full, lr_factor, loss_out=None, fused=None):
         o = self.optimizer
-        desc, participants, groups = self._adam_desc(full)
+        desc, participants, groups = self._adam_desc(full, dense_only=fused is not None)
         for k, gi in enumerate(groups):
             desc.lr[k] = float(o.param_groups[gi]["initial_lr"]) * lr_factor
         b1, b2 = o.param_groups[0]["betas"]
         s = L.stream()
         L.call("n2m_adam_step", ctypes.addressof(desc), float(b1), float(b2), float(o.param_groups[0]["eps"]), _p(o.scale), _p(o.found_inf),
                _p(o.bias), s)
+        if fused is not None:      # behind both optimizer passes, in front of the scaler update that clears found_inf
+            L.call("n2m_adam_fuse_restore", ctypes.addressof(fused), self.ho.ctypes.data, self.Lv, _p(o.found_inf), s)
+            self._fuse_swap()
         if self.shard:
             self._gather_packed()
         gf, bf, gi = o.growth
@@ -544,7 +613,7 @@ class Stage0Engine:
                 self.tv_stream.wait_event(go)
                 L.grid_backward_config(*self._bwd_cfg)
                 with torch.cuda.stream(self.tv_stream):
-                    L.call("n2m_grid_tv_terms", _p(xyzs), _p(pk) if self.shard else _p(e1.embeddings), self.ho.ctypes.data, M, self.Lv, self.S, self.H0,
+                    L.call("n2m_grid_tv_terms", _p(xyzs), _p(pk) if self._bwd_cfg[0] == 2 else _p(e1.embeddings), self.ho.ctypes.data, M, self.Lv, self.S, self.H0,
                            e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, float(opt.lambda_tv),
                            float(opt.lambda_tv * (10 if opt.bound > 1 else 1)), float(0.5 / model.bound),
                            _p(seed), float(self.aff[0]), float(self.aff[1]), _p(w["tv"]), L.stream())
@@ -586,11 +655,20 @@ class Stage0Engine:
             common = (_p(w["d_h1"]), _p(w["d_h2"]), _p(xyzs), self.ho.ctypes.data, _p(self.g1), _p(self.g2), M,
                       self.Lv, self.Lv, self.S, self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id)
             tail = (_p(o.found_inf), float(self.aff[0]), float(self.aff[1]), 1, _p(ws), ws.numel(), s)
-            if tv_terms is not None:
+            fused = None
+            if self.fuse_adam is not None and M <= self._fuse_cap and tv_terms is None:
+                self._adam_desc(shading != 0, dense_only=True)             # (names self._packed)
+                fused = self._fuse_desc(lr_lambda(self.global_step - 1, opt.iters))
+            if fused is not None:
+                tv_args = (_p(pk) if tv else None, float(opt.lambda_tv), float(opt.lambda_tv * (10 if opt.bound > 1 else 1)),
+                           float(0.5 / model.bound), _p(seed) if tv else None)
+                backward = lambda half: L.call("n2m_grid_encode_backward_binned_pair_adam", *common, *tv_args, *tail[:3], _p(ws), ws.numel(),
+                                               ctypes.addressof(fused), s)
+            elif tv_terms is not None:
                 torch.cuda.current_stream(dev).wait_event(self._tv_done)
                 backward = lambda half: L.call("n2m_grid_encode_backward_binned_pair_tvt", *common, _p(tv_terms), *tail, half)
             else:
-                tv_args = ((_p(pk) if self.shard else _p(e1.embeddings)) if tv else None, float(opt.lambda_tv),
+                tv_args = ((_p(pk) if self._bwd_cfg[0] == 2 else _p(e1.embeddings)) if tv else None, float(opt.lambda_tv),
                            float(opt.lambda_tv * (10 if opt.bound > 1 else 1)), float(0.5 / model.bound), _p(seed) if tv else None)
                 backward = lambda half: (L.call("n2m_grid_encode_backward_binned_pair", *common, *tv_args, *tail) if half == 0 else
                                          L.call("n2m_grid_encode_backward_binned_pair_half", *common, *tv_args, *tail, half))
@@ -647,7 +725,7 @@ class Stage0Engine:
             self._marker.record()
         # ---- Adam + loss-scale bookkeeping, LR schedule (main.py:239)
         extra = (w["spec_partial"], float(opt.lambda_specular / M)) if (M > 0 and shading != 0 and opt.lambda_specular > 0) else None
-        self._lr_step(shading != 0, loss_out=(N, b.loss, extra))
+        self._lr_step(shading != 0, loss_out=(N, b.loss, extra), fused=fused if M > 0 else None)
         loss = b.loss.view(())                 # written by the scaler kernel (photometric + specular terms); lives in the batch's buffer set (valid until the set comes round again)
         self._fill_pipeline()
         return loss
@@ -755,9 +833,9 @@ class Stage0Engine:
         self._fill_pipeline()
         return loss
 
-    def _lr_step(self, full, loss_out=None):
+    def _lr_step(self, full, loss_out=None, fused=None):
         if full is not None:
-            self._optimizer_step(full, lr_lambda(self.global_step - 1, self.opt.iters), loss_out)
+            self._optimizer_step(full, lr_lambda(self.global_step - 1, self.opt.iters), loss_out, fused)
 
     @torch.no_grad()
     def eval_psnr(self, cam=0, downscale=4):

@@ -168,3 +168,74 @@ def test_engine_steps_through_batches_without_a_single_sample():
     for p, q in zip(eng.model.parameters(), before):
         assert torch.equal(p.detach(), q)
     assert float(eng.optimizer.scale) > 0 and float(eng.optimizer.found_inf) == 0
+
+
+def _table_state(tr):
+    o = tr.optimizer
+    out = {}
+    for name, p in (("density", tr.model.encoder.embeddings), ("colour", tr.model.encoder_color.embeddings)):
+        st = o.state[p]
+        out[name] = (p.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone())
+    out["packed"] = tr.model.packed_tables().clone()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("steps", [1, 2, 7])
+def test_optimizer_pass_inside_the_table_backward_is_the_separate_pass(monkeypatch, steps):
+    """n2m_grid_encode_backward_binned_pair_adam (N2M_FUSE_ADAM=1; a measured alternative, off by default) against n2m_grid_encode_backward_binned_pair + n2m_adam_step
+    (N2M_FUSE_ADAM=0): same arithmetic element for element.  One step from the same state: parameter, both moments and the packed rows of
+    every level that takes the fused pass are BIT-equal (their gradient sums are fixed-point, order-free); the small dense levels differ
+    by their float atomics as two runs of the unfused path do.  Odd / even step counts end in either buffer set: the model and the
+    optimizer must name the current one."""
+    from nerf2mesh_amd.engine import Stage0Engine
+    monkeypatch.setenv("N2M_FUSE_ADAM", "0")
+    a, la = _run(Stage0Engine, steps, diffuse_step=4)
+    a2, _ = _run(Stage0Engine, steps, diffuse_step=4)
+    monkeypatch.setenv("N2M_FUSE_ADAM", "1")
+    b, lb = _run(Stage0Engine, steps, diffuse_step=4)
+    assert a.fuse_adam is None and b.fuse_adam is not None
+    r0 = b.fuse_adam["first_row"]
+    assert 0 < r0 < 0.1 * b.rows, "the hashed levels (94 % of the rows) take the fused pass"
+    sa, sa2, sb = _table_state(a), _table_state(a2), _table_state(b)
+    np.testing.assert_allclose(la, lb, rtol=2e-4, atol=1e-7)
+    for name in ("density", "colour"):
+        for which, x, x2, y in zip(("param", "exp_avg", "exp_avg_sq"), sa[name], sa2[name], sb[name]):
+            if steps == 1:
+                assert torch.equal(x[r0:], y[r0:]), f"{name} {which}: fused rows differ after one step"
+            rel = lambda p, q: ((p - q).norm() / p.norm().clamp_min(1e-30)).item()
+            d_ab, d_aa = rel(x, y), rel(x, x2)
+            print(f"{name:8s} {which:10s} fused-vs-unfused {d_ab:.3g}   unfused-vs-unfused {d_aa:.3g}")
+            assert d_ab <= 10 * d_aa + 1e-6
+    if steps == 1:
+        assert torch.equal(sa["packed"][r0:], sb["packed"][r0:])
+    # the packed copy the lookup reads IS the parameters (fp32 density, colour rounded to fp16), whichever buffer set is current
+    pk = sb["packed"]
+    assert torch.equal(pk[:, 0], sb["density"][0][:, 0])
+    assert torch.equal(pk.view(torch.float16)[:, 2:], sb["colour"][0].half())
+    assert torch.equal(b.optimizer.steps, a.optimizer.steps)
+
+
+@pytest.mark.gpu
+def test_skipped_step_takes_the_fused_update_back(monkeypatch):
+    """GradScaler skips a step whose gradients overflow: the fused pass has written its update by then -- n2m_adam_fuse_restore must leave
+    parameter, moments and packed rows exactly as they were, the scale must back off and the step counts must not advance."""
+    from nerf2mesh_amd.engine import Stage0Engine
+    monkeypatch.setenv("N2M_FUSE_ADAM", "1")
+    tr, _ = _run(Stage0Engine, 3)
+    assert tr.fuse_adam is not None
+    before = _table_state(tr)
+    steps0, scale0 = tr.optimizer.steps.clone(), float(tr.optimizer.scale)
+    tr.optimizer.scale.fill_(3.0e38)                       # every gradient overflows
+    tr.train_step()
+    torch.cuda.synchronize()
+    after = _table_state(tr)
+    for name in ("density", "colour"):
+        for which, x, y in zip(("param", "exp_avg", "exp_avg_sq"), before[name], after[name]):
+            assert torch.equal(x, y), f"{name} {which} changed on a skipped step"
+    assert torch.equal(before["packed"], after["packed"])
+    assert torch.equal(tr.optimizer.steps, steps0) and float(tr.optimizer.scale) < 3.0e38
+    # and training goes on from there
+    tr.optimizer.scale.fill_(scale0)
+    l = [float(tr.train_step()) for _ in range(4)]
+    assert np.isfinite(l).all() and not torch.equal(_table_state(tr)["density"][0], before["density"][0])
