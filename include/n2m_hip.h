@@ -68,6 +68,17 @@ int n2m_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* b
  * density_thresh), nerf/renderer.py:1142-1145) needs no host read-back of the mean. */
 int n2m_packbits_dev(const float* grid, uint32_t N, const float* density_thresh, uint8_t* bitfield, void* stream);
 
+/* Occupancy refresh (nerf/renderer.py:1074-1149), the elementwise work around the density query.
+ * n2m_occupancy_points: xyz[i] = cells[i] * inner + (u[i] * 2 - 1) * half_grid_size over n floats -- the reference's expression (:1096-1100:
+ * cells = 2 c / (H - 1) - 1 in Morton order, inner = bound - half_grid_size, u = torch.rand_like draws) with its rounding points.
+ * n2m_occupancy_update: grid = max(grid * decay, tmp) where both are >= 0 (:1133-1134), mean of max(grid, 0) (:1136) and the threshold
+ * min(mean, density_thresh) (:1140) left on the device for n2m_packbits_dev -- no host read-back (the reference reads the mean with .item()).
+ * partials: n2m_occupancy_update_partials(n) floats of scratch; ticket: one zero-initialised u32 the kernel resets; n floats, 16-byte aligned. */
+int n2m_occupancy_points(const float* cells, const float* u, float inner, float half_grid_size, float* xyz, uint32_t n, void* stream);
+uint32_t n2m_occupancy_update_partials(uint32_t n);
+int n2m_occupancy_update(float* grid, const float* tmp, float decay, uint32_t n, float density_thresh, float* partials, uint32_t* ticket,
+                         float* mean, float* thresh, void* stream);
+
 /* raymarching.h:12  flatten_rays   kernel raymarching.cu:303-319.
  * rays [N,2] = (offset,count); res [M] int32: res[offset .. offset+count) = n.  Other entries untouched. */
 int n2m_flatten_rays(const int32_t* rays, uint32_t N, uint32_t M, int32_t* res, void* stream);

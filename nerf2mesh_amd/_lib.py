@@ -53,6 +53,9 @@ SIGNATURES = {
                                              _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _int, _vp, _u64, _vp],
     "n2m_grid_encode_backward_binned_pair_half": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
                                                   _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _int, _vp, _u64, _vp, _int],
+    "n2m_occupancy_update_partials": [_u32],                                                     # returns uint32 (RESTYPES)
+    "n2m_occupancy_points": [_vp, _vp, _f32, _f32, _vp, _u32, _vp],
+    "n2m_occupancy_update": [_vp, _vp, _f32, _u32, _f32, _vp, _vp, _vp, _vp, _vp],
     "n2m_grid_pair_fuse_plan": [_u32, _u32, _vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)],
     "n2m_grid_encode_backward_binned_pair_adam": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
                                                   _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _vp, _u64, _vp, _vp],
@@ -107,7 +110,7 @@ SIGNATURES = {
     "n2m_prof_seen": [_int, ctypes.POINTER(ctypes.c_uint64)],
 }
 
-RESTYPES = {"n2m_grid_binned_workspace_bytes": _u64, "n2m_grid_binned_pair_workspace_bytes": _u64, "n2m_march_fused_workspace_bytes": _u64,
+RESTYPES = {"n2m_occupancy_update_partials": _u32, "n2m_grid_binned_workspace_bytes": _u64, "n2m_grid_binned_pair_workspace_bytes": _u64, "n2m_march_fused_workspace_bytes": _u64,
             "n2m_marching_cubes_workspace_bytes": _u64, "n2m_field_spec_partials": _u32}   # everything else returns an int status
 
 F32, F16 = 0, 1

@@ -469,7 +469,7 @@ grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __res
     const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
     const uint2* __restrict__ tab = packed + (size_t)row0;
     float* o1 = out1 + (size_t)level * B + b;
-    _Float16* o2 = out2 + ((size_t)level * B + b) * 2;
+    _Float16* o2 = out2 ? out2 + ((size_t)level * B + b) * 2 : nullptr;      // NULL: the density column alone (occupancy refresh)
 
     float x[D];
     load_point<D>(inputs, b, x);
@@ -479,7 +479,7 @@ grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __res
         *o1 = 0.0f;
         Row<_Float16, 2> z;
         z.v[0] = z.v[1] = (_Float16)0;
-        z.store(o2);
+        if (o2) z.store(o2);
         return;
     }
     uint32_t cell[D];
@@ -542,6 +542,7 @@ grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __res
         accum(a2[1], w, c2.y);
     }
     *o1 = a1;
+    if (!o2) return;
     Row<_Float16, 2> r2;
     r2.v[0] = a2[0]; r2.v[1] = a2[1];
     r2.store(o2);
@@ -2877,13 +2878,17 @@ extern "C" int n2m_grid_encode_forward_packed(const float* inputs, const void* p
                                               int align_corners, uint32_t interp, float in_scale, float in_offset, void* stream) {
     const char* fn = "grid_encode_forward_packed";
     if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
-    N2M_REQUIRE(inputs && packed && offsets && outputs1 && outputs2, N2M_ENULL, "%s: NULL tensor", fn);
+    // outputs2 == NULL: the density encoder alone from the packed rows.  (Built for the occupancy refresh's 2 M-point query and measured
+    // slower there than n2m_grid_encode_forward on the plain table, 488 against 382 us: those points are Morton-ordered cell centres whose
+    // 4-byte gathers coalesce in the L1; the refresh stays on the plain table.)
+    N2M_REQUIRE(inputs && packed && offsets && outputs1, N2M_ENULL, "%s: NULL tensor", fn);
     N2M_REQUIRE(((uintptr_t)packed & 15u) == 0, N2M_EINVAL, "%s: the packed table must be 16-byte aligned", fn);
     if (B == 0 || max_level == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const LevelTable lv = make_levels(L, S, H);
     // algorithmic bytes of both encoders' forward (588 B/sample each at L = 16, one 12-byte input read shared)
-    N2M_PROF(N2M_K_GRID_FWD_PACKED, s, (double)B * (12.0 + (double)max_level * 8 * (4 + 4) + (double)max_level * (4 + 4)));
+    if (outputs2) N2M_PROF(N2M_K_GRID_FWD_PACKED, s, (double)B * (12.0 + (double)max_level * 8 * (4 + 4) + (double)max_level * (4 + 4)));
+    else N2M_PROF(N2M_K_GRID_FWD, s, (double)B * (12.0 + (double)max_level * 8 * 4 + (double)max_level * 4));
     const uint32_t n_tiles = n2m_ceil_div(B, 256);
     static const uint32_t xg_env = getenv("N2M_FWD_XCD_GROUP") ? (uint32_t)atoi(getenv("N2M_FWD_XCD_GROUP")) : 4u;     // A/B switch: 0 = level-major grid
     const uint32_t xg = (max_level == 16u && (xg_env == 1u || xg_env == 2u || xg_env == 4u)) ? xg_env : 0u;

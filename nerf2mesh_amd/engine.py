@@ -18,6 +18,7 @@ Configurations outside the fast path (SDF, individual codes, unfused MLPs, bound
 """
 import ctypes
 import os
+import time
 
 import numpy as np
 import torch
@@ -297,19 +298,27 @@ class Stage0Engine:
     def _count(self, b):
         """Sample count of batch b on the host (waits for the event behind its offset scan; normally long complete)."""
         if b.M is None:
-            b.count_ready.synchronize()
+            # poll before blocking: hipEventSynchronize parks the thread, and waking it costs tens of microseconds the GPU then idles
+            # (after an occupancy refresh the step cannot be enqueued before this count is known)
+            t0 = time.perf_counter()
+            while not b.count_ready.query():
+                if time.perf_counter() - t0 > 5e-3:
+                    b.count_ready.synchronize()
+                    break
             b.M = int(b.host_count[0])
         return b.M
 
-    def _fill_pipeline(self):
-        """Prepare batches until `depth` of them wait in the queue.  Batch j takes its ray count from batch j-1's sample count
+    def _fill_pipeline(self, max_new=None):
+        """Prepare batches until `depth` of them wait in the queue (at most max_new of them in this call).  Batch j takes its ray count from batch j-1's sample count
         (adaptive num_rays, nerf/utils.py:796-797) and, when (j-1) % 16 == 0, follows an occupancy refresh that needs step j-1's
         parameter update: such a batch cannot be prepared early -- it is issued on the main stream behind that step.  Every other batch
         is issued on the side stream behind the marker in front of the running step's Adam kernel: its count pass then runs beside
         the optimizer update (a streaming kernel that leaves the ALUs idle) instead of beside the forward lookup, and its count is on
         the host a whole step before it is needed."""
         opt = self.opt
-        while len(self._queue) < self.depth:
+        new = 0
+        while len(self._queue) < self.depth and (max_new is None or new < max_new):
+            new += 1
             j = self._prepared + 1
             need_refresh = (j - 1) % opt.update_extra_interval == 0
             if need_refresh and j - 1 > self.global_step:
@@ -320,12 +329,23 @@ class Stage0Engine:
                 if opt.adaptive_num_rays and M > 0:
                     self.num_rays = max(1, int(round((opt.num_points / M) * prev.N)))
             N = int(self.num_rays)
+            defer = False
             if need_refresh or not self.overlap or self._marker is None:
                 if need_refresh:
                     self._refresh()
                 b = self._prepare(N)
+                if need_refresh and self.overlap and self._marker is not None:
+                    # the batch behind this one needs THIS batch's count, which the host can only wait for -- and the running step cannot be
+                    # enqueued before it has that count either.  So the next batch is prepared right behind the step's first launch (the
+                    # lookup: _mid_step_fill), on the side stream behind this event instead of the step's marker: it marches beside the
+                    # lookup and the field kernels as before, but the GPU no longer idles ~100 us while the host prepares it
+                    self._post_refresh = torch.cuda.Event()
+                    self._post_refresh.record()
+                    self._mid_fill = True
+                    defer = True
             else:
-                self.side.wait_event(self._marker)
+                after_refresh = (j - 2) % opt.update_extra_interval == 0 and getattr(self, "_post_refresh", None) is not None
+                self.side.wait_event(self._post_refresh if after_refresh else self._marker)
                 with torch.cuda.stream(self.side):
                     b = self._prepare(N)
                 main = torch.cuda.current_stream(self.device)
@@ -334,6 +354,14 @@ class Stage0Engine:
             self._prepared = j
             self._last = b
             self._queue.append(b)
+            if defer:
+                break
+
+    def _mid_step_fill(self):
+        """Behind the step's first launch: the one batch whose preparation the refresh in front of this step had to put off."""
+        if getattr(self, "_mid_fill", False):
+            self._mid_fill = False
+            self._fill_pipeline(max_new=1)
 
     def _finish(self, b):
         """Samples of batch b: the speculative pass 2 of _prepare() when the count fits its buffers (the normal case), else an exact
@@ -604,6 +632,7 @@ class Stage0Engine:
         if M > 0:
             L.call("n2m_grid_encode_forward_packed", _p(xyzs), _p(pk), _p(e1.offsets), _p(w["h1"]), _p(w["h2"]), M, self.Lv, self.Lv, self.S,
                    self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, float(self.aff[0]), float(self.aff[1]), s)
+            self._mid_step_fill()
             tv_terms = None
 
             def start_tv():
@@ -772,6 +801,7 @@ class Stage0Engine:
                 sb["h6"][ml * M6:16 * M6].zero_()
             L.call("n2m_grid_encode_forward_packed", _p(xyzs), _p(pk), _p(e1.offsets), _p(w["h1"]), _p(w["h2"]), M, self.Lv, ml, self.S,
                    self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, float(self.aff[0]), float(self.aff[1]), s)
+            self._mid_step_fill()
             spec_reg = shading != 0 and opt.lambda_specular > 0
             L.call("n2m_field_forward_train", _p(xyzs), _p(dirs) if shading != 0 else None, _p(w["h1"]), _p(w["h2"]), *[_p(p) for p in sw], M, shading, 3,
                    _p(w["sigma"]), _p(w["rgb"]), None, _p(w["spec_partial"]) if spec_reg else None, s)

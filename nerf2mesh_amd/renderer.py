@@ -303,25 +303,37 @@ class NeRFRenderer(nn.Module):
         grid = max(grid*decay, sample) where both are valid, threshold = min(mean, density_thresh), packbits."""
         if self.opt.stage > 0:
             return
+        from . import _lib as L
+        _p = L.ptr
         cells = self._cells()
-        tmp_grid = torch.empty_like(self.density_grid)
+        grid = self.density_grid
+        dev = grid.device
+        st = getattr(self, "_refresh_bufs", None)
+        if st is None or st["tmp"].shape != grid.shape or st["tmp"].device != dev:
+            n_part = int(L.lib().n2m_occupancy_update_partials(grid.numel()))
+            st = self._refresh_bufs = {"tmp": torch.empty_like(grid), "xyz": torch.empty_like(cells),
+                                       "partials": torch.empty(n_part, dtype=torch.float32, device=dev),
+                                       "ticket": torch.zeros(1, dtype=torch.int32, device=dev),
+                                       "mean": torch.zeros(1, dtype=torch.float32, device=dev), "thresh": torch.zeros(1, dtype=torch.float32, device=dev)}
+        tmp_grid, xyzs = st["tmp"], st["xyz"]
         for cas in range(self.cascade):
             bound = min(2 ** cas, self.bound)
             hgs = bound / self.grid_size
-            xyzs = cells * (bound - hgs) + (torch.rand_like(cells) * 2 - 1) * hgs
+            # xyzs = cells * (bound - hgs) + (torch.rand_like(cells) * 2 - 1) * hgs: the draws stay torch's, the arithmetic is one launch
+            L.call("n2m_occupancy_points", _p(cells), _p(torch.rand_like(cells)), float(bound - hgs), float(hgs), _p(xyzs), cells.numel(), L.stream())
             with torch.autocast(device_type="cuda", dtype=torch.float16, enabled=bool(self.opt.fp16)):
                 sigmas = self.density(xyzs)["sigma"].reshape(-1).detach()
                 if self.opt.sdf:
                     inv_s = torch.exp(self.variance * 10.0).clip(1e-6, 1e6)
                     sigmas = torch.sigmoid(-sigmas * inv_s) * inv_s
             tmp_grid[cas] = sigmas.float()
-        valid = (self.density_grid >= 0) & (tmp_grid >= 0)
-        self.density_grid.copy_(torch.where(valid, torch.maximum(self.density_grid * decay, tmp_grid), self.density_grid))
-        # mean and threshold stay on the device (the reference reads the mean back every refresh, :1142): no queue drain
-        self._mean_density_t = torch.mean(self.density_grid.clamp(min=0))
+        # grid = max(grid * decay, sample) where both are valid; mean of max(grid, 0); threshold = min(mean, density_thresh): one launch, and
+        # both scalars stay on the device (the reference reads the mean back every refresh, :1142): no queue drain
+        L.call("n2m_occupancy_update", _p(grid), _p(tmp_grid), float(decay), grid.numel(), float(self.density_thresh), _p(st["partials"]),
+               _p(st["ticket"]), _p(st["mean"]), _p(st["thresh"]), L.stream())
+        self._mean_density_t = st["mean"]
         self.iter_density += 1
-        density_thresh = self._mean_density_t.clamp(max=self.density_thresh)
-        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
+        self.density_bitfield = raymarching.packbits(grid, st["thresh"], self.density_bitfield)
 
     @torch.no_grad()
     def mark_untrained_grid(self, poses, intrinsics, cam_near_far=None, S=64):

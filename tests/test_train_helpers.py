@@ -209,3 +209,78 @@ def test_sdf_head_kernels_against_the_torch_statement():
     assert rel(d_s6.t(), s6.grad) <= 2e-5, rel(d_s6.t(), s6.grad)
     assert abs(float(d_var) - float(var.grad)) <= 2e-4 * abs(float(var.grad)), (float(d_var), float(var.grad))
     assert float(finf) == 0.0
+
+
+@pytest.mark.parametrize("cascade,bound", [(1, 1.0), (3, 4.0)])
+def test_occupancy_refresh_kernels_against_the_torch_statement(cascade, bound):
+    """n2m_occupancy_points / n2m_occupancy_update against the reference's expressions (nerf/renderer.py:1096-1100, 1133-1140) written in
+    torch: points and the updated grid bit for bit (same operations, same rounding points), mean to fp32 accuracy (the kernel sums
+    per-workgroup partials in double, torch.mean in fp32), threshold = min(mean, density_thresh), packbits from the device threshold."""
+    import torch
+    from nerf2mesh_amd import _lib as L
+    from nerf2mesh_amd import raymarching
+    p = L.ptr
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(cascade)
+    H = 128
+    n_cells = H ** 3
+    coords = raymarching.morton3D_invert(torch.arange(n_cells, dtype=torch.int32, device=dev))
+    cells = 2 * coords.float() / (H - 1) - 1
+    grid = torch.rand(cascade, n_cells, device=dev, generator=g) * 20 - 2        # some cells < 0: -1 marks untrained cells
+    grid[:, ::7] = -1.0
+    tmp_all = torch.rand(cascade, n_cells, device=dev, generator=g) * 30
+    tmp_all[:, ::11] = -0.5                                                      # a negative sample leaves its cell alone
+    tmp_all[0, 5] = float("nan")
+    for cas in range(cascade):
+        b = min(2 ** cas, bound)
+        hgs = b / H
+        u = torch.rand(n_cells, 3, device=dev, generator=g)
+        want = cells * (b - hgs) + (u * 2 - 1) * hgs
+        got = torch.empty_like(cells)
+        L.call("n2m_occupancy_points", p(cells), p(u), float(b - hgs), float(hgs), p(got), cells.numel(), L.stream())
+        assert torch.equal(got, want), f"cascade {cas}"
+    decay, thresh0 = 0.95, 10.0
+    valid = (grid >= 0) & (tmp_all >= 0)
+    want_grid = torch.where(valid, torch.maximum(grid * decay, tmp_all), grid)
+    want_mean = torch.mean(want_grid.clamp(min=0).double()).item()
+    n_part = int(L.lib().n2m_occupancy_update_partials(grid.numel()))
+    partials = torch.empty(n_part, device=dev)
+    ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+    mean, thresh = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    for rep in range(2):                                                          # the ticket resets itself
+        got_grid = grid.clone()
+        L.call("n2m_occupancy_update", p(got_grid), p(tmp_all), decay, grid.numel(), thresh0, p(partials), p(ticket), p(mean), p(thresh), L.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(got_grid, want_grid)
+        assert abs(mean.item() - want_mean) <= 2e-7 * want_mean
+        assert thresh.item() == min(mean.item(), thresh0) and int(ticket.item()) == 0
+    L.call("n2m_occupancy_update", p(got_grid), p(tmp_all), decay, grid.numel(), 1e9, p(partials), p(ticket), p(mean), p(thresh), L.stream())
+    assert thresh.item() == mean.item()
+    bits_dev = raymarching.packbits(got_grid, thresh)
+    bits_host = raymarching.packbits(got_grid, thresh.item())
+    assert torch.equal(bits_dev, bits_host)
+
+
+def test_density_query_from_the_packed_rows_equals_the_plain_table():
+    """The occupancy refresh's density query reads the density column of the packed rows (n2m_grid_encode_forward_packed with outputs2 = NULL):
+    same features, bit for bit, as n2m_grid_encode_forward on the fp32 table -- all 16 levels and with a level cap."""
+    import torch
+    from nerf2mesh_amd.network import NeRFNetwork
+    from nerf2mesh_amd.options import make_options
+    from nerf2mesh_amd import fused
+    torch.manual_seed(3)
+    dev = torch.device("cuda", 0)
+    net = NeRFNetwork(make_options(O=True, bound=1, fused_mlp=True)).to(dev)
+    with torch.no_grad():
+        net.encoder.embeddings.uniform_(-1, 1)
+        net.encoder_color.embeddings.uniform_(-1, 1)
+    x = torch.rand(100_003, 3, device=dev) * 2.2 - 1.1                           # some points outside the cube
+    pk = net.packed_tables()
+    aff = fused._affine(1.0)
+    for ml in (16, 5):
+        h_packed = fused._encode_lm_packed(x, pk, net, ml, aff, density_only=True)[0]
+        h_plain = fused._encode_lm((x + 1) / 2, net.encoder.embeddings.detach(), net.encoder, ml)
+        assert torch.equal(h_packed.view(-1), h_plain.view(-1)), f"max_level {ml}"
+    with torch.no_grad():
+        s1 = net.density(x)["sigma"]
+    assert torch.isfinite(s1).all()
