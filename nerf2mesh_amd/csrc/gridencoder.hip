@@ -1521,9 +1521,60 @@ __device__ unsigned int g_fill_timing_on;
 __device__ unsigned long long g_fill_t[2][8][6];     // workgroup 3 (a fine, hashed level) and workgroup gridDim/2 + 3 (a coarse, dense one)
 #define N2M_FILL_STAMP(i) do { if (stamp && it < 8u) g_fill_t[stamp_w][it][(i)] = __builtin_readcyclecounter(); } while (0)
 
+// ---- SDF recipe: the six finite-difference copies of a sample (x +- eps e_a, nerf/network.py:143-154) folded into the sample's own entries.
+// At the end of the schedule eps = 1e-4 is a tenth of the finest cell: a copy nearly always lies in the cell of its centre sample on every
+// level, i.e. it updates the SAME eight rows with slightly different weights.  Instead of going through the fill as six more samples (the
+// stacked pass: 480 us per step), such a copy adds w_copy(corner) * g_copy to the centre's eight values here; the copies that leave the cell
+// on some level (n2m_sdf_fold_plan marks them, ~30 %) take the stacked pass, compacted.  Positions are recomputed exactly as
+// n2m_sdf_offsets writes them (clamp(x + off, -bound, bound), then (p + bound) / (2 bound)), so a folded copy's weights are the ones the
+// stacked pass would have used, bit for bit; what changes is the association of the fp32 sum (centre + copies here, a lane scan there).
+struct FoldArgs {
+    const uint8_t* flags;       // [B] bit c: copy c (= 2 axis + (0: +eps, 1: -eps)) shares the centre's cell on every active level
+    const float* grad6;         // [L, 6 B] gradient of the stacked copies' features, sample-major inside a level
+    const float* raw;           // [B, 3] the samples as the caller has them (before the in_scale / in_offset map)
+    uint32_t stride6;           // 6 B
+    float eps, bound;
+};
+
+__device__ __forceinline__ void fold_copies(const FoldArgs& fo, uint32_t s, uint32_t level, const float (&x01)[3], float scale, bool align_corners,
+                                            uint32_t interp, uint32_t fl, float (&f1)[8], float& vmax1, float* found_inf) {
+    uint32_t cell[3];
+    float frac[3], dfrac[3];
+    locate<3>(x01, scale, align_corners, interp, cell, frac, dfrac);
+    const float2* gp = reinterpret_cast<const float2*>(fo.grad6 + (size_t)level * fo.stride6 + (size_t)s * 6u);
+    const float2 g01 = gp[0], g23 = gp[1], g45 = gp[2];
+    const float g6[6] = {g01.x, g01.y, g23.x, g23.y, g45.x, g45.y};
+    const float xw[3] = {fo.raw[(size_t)s * 3u], fo.raw[(size_t)s * 3u + 1u], fo.raw[(size_t)s * 3u + 2u]};
+#pragma unroll
+    for (uint32_t c = 0; c < 6; ++c) {
+        if (!((fl >> c) & 1u)) continue;
+        const uint32_t a = c >> 1;
+        const float g = g6[c];
+        if (!(fabsf(g) <= 3.0e38f)) { if (found_inf) *found_inf = 1.0f; continue; }
+        const float pw = fminf(fmaxf(xw[a] + ((c & 1u) ? -fo.eps : fo.eps), -fo.bound), fo.bound);
+        const float p01 = (pw + fo.bound) / (2.0f * fo.bound);
+        float fr = p01 * scale + (align_corners ? 0.0f : 0.5f);
+        fr -= (float)cell[a];                                           // (same cell: the plan has checked floor() of this very value)
+        if (interp == 1) fr = fr * fr * (3.0f - 2.0f * fr);
+        float w2[3][2];
+#pragma unroll
+        for (uint32_t d = 0; d < 3; ++d) { const float f = d == a ? fr : frac[d]; w2[d][0] = 1 - f; w2[d][1] = f; }
+#pragma unroll
+        for (uint32_t corner = 0; corner < 8; ++corner) {
+            const float w = (w2[0][corner & 1u] * w2[1][(corner >> 1) & 1u]) * w2[2][corner >> 2];
+            f1[corner] += w * g;
+        }
+    }
+    float m = 0.0f;
+#pragma unroll
+    for (uint32_t corner = 0; corner < 8; ++corner) m = fmaxf(m, fabsf(f1[corner]));
+    vmax1 = fmaxf(vmax1, m <= 3.0e38f ? m : 1.0f);
+    if (!(m <= 3.0e38f) && found_inf) *found_inf = 1.0f;
+}
+
 // TV: 0 none, 1 computed in place (pair_tv_value), 2 read from `tv_terms` [L, Bstride] (n2m_grid_tv_terms wrote it earlier, beside the
 // field kernels: the stencil's scattered gathers -- 45 us of this kernel -- then run where nobody waits for the L2 request path)
-template <int TV>
+template <int TV, bool FOLD = false>
 __global__ void __launch_bounds__(1024)
 bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Float16* __restrict__ grad2 /*[L,Bstride,2]*/,
                      const float* __restrict__ inputs, TvParams tv, const float* __restrict__ tv_terms, uint32_t B, uint32_t Bstride, BinPlan plan, LevelTable lv,
@@ -1532,14 +1583,18 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
                      uint32_t* __restrict__ log_v2, float* __restrict__ found_inf, float in_scale, float in_offset,
                      float* __restrict__ clear1, _Float16* __restrict__ clear2, uint32_t clear_mask1, uint32_t clear_mask2,
                      uint32_t merge_levels, uint32_t groups_x, uint32_t slot_begin, unsigned long long* __restrict__ lm_ready,
-                     unsigned long long lm_token) {
+                     unsigned long long lm_token, FoldArgs fold = FoldArgs{}) {
     __builtin_amdgcn_s_setprio(3);
     constexpr uint32_t D = 3;
     constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
     // The level maxima start from zero.  Workgroup 0 clears them itself and then publishes this launch's token; every workgroup waits for
     // the token before its ONE atomicMax at the very end (a whole tile walk later).  That removes a 256-byte memset launch from the
     // stream -- a kernel boundary costs 6-7 us here whatever the kernel does (timeline).
-    if (blockIdx.x == 0u) {
+    // (ONE workgroup: on the plain 2-D grid of a call with fewer than 16 levels blockIdx.x == 0 names one workgroup PER LEVEL -- each of them
+    // used to clear the maxima again, whenever it happened to start, wiping out what faster workgroups had already published: levels then
+    // reached the accumulate kernels with a maximum of zero (skipped) or too small a unit.  Found by the folded-copies test against the
+    // scatter backward; max_level == 16 runs the 1-D XCD grid and was never affected.)
+    if (blockIdx.x == 0u && blockIdx.y == 0u) {
         if (threadIdx.x < 2u * kMaxLevels) level_max[threadIdx.x] = 0u;
         __syncthreads();
         if (threadIdx.x == 0u) __hip_atomic_store(lm_ready, lm_token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1643,6 +1698,11 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
             else if (fast_dense && parts > 1u) pair_entries<TV, 2, true>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
             else if (fast_dense) pair_entries<TV, 2, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
             else pair_entries<TV, 0, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
+            if constexpr (FOLD) {
+                const uint32_t sidx = tile * 1024u + tid;
+                const uint32_t fl = fold.flags[sidx];
+                if (fl != 0u) fold_copies(fold, sidx, level, x, scale, align_corners, interp, fl, f1, vmax1, found_inf);
+            }
         }
         bool keep = inside;
         if (level < merge_levels) {                                    // block-uniform
@@ -2341,9 +2401,11 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
                        uint32_t max_level, const int32_t* host_offsets, const LevelTable& lv, uint32_t gridtype, bool align, uint32_t interp,
                        void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn, float* found_inf, float in_scale,
                        float in_offset, bool overwrite, uint32_t L, int half = 0, const float* tv_terms = nullptr,
-                       const AdamFuse* fuse1 = nullptr, const AdamFuse* fuse2 = nullptr) {
+                       const AdamFuse* fuse1 = nullptr, const AdamFuse* fuse2 = nullptr, const FoldArgs* fold = nullptr) {
     static bool attr_set = false;
     if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
+        (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
         (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
         (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
         (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
@@ -2424,6 +2486,13 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         const float* tvt = tv_terms ? tv_terms + (size_t)b0 : nullptr;          // [L, B]: this pass's column block
 #define N2M_FILL_ARGS g1, g2, x, tv, tvt, Bc, B, lay.plan, lv, gridtype, align, interp, level_max, directory, log_rel, log_v1, log_v2, found_inf, in_scale, \
                       in_offset, ow ? table1 : nullptr, ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token
+        if (fold) {
+            N2M_REQUIRE(both && !tvt && B <= kBinChunk && half == 0, N2M_EINVAL, "%s: folded copies need the density gradient, one pass (B <= %u) and all levels", fn, kBinChunk);
+            FoldArgs fo = *fold;
+            fo.stride6 = 6u * B;
+            if (tv.table) bin_fill_pair_kernel<1, true><<<grid, 1024, kTileEntries * 10, s>>>(N2M_FILL_ARGS, fo);
+            else bin_fill_pair_kernel<0, true><<<grid, 1024, kTileEntries * 10, s>>>(N2M_FILL_ARGS, fo);
+        } else
         if (tv.table) bin_fill_pair_kernel<1><<<grid, 1024, kTileEntries * 10, s>>>(N2M_FILL_ARGS);
         else if (tvt) bin_fill_pair_kernel<2><<<grid, 1024, kTileEntries * 10, s>>>(N2M_FILL_ARGS);
         else bin_fill_pair_kernel<0><<<grid, 1024, kTileEntries * 10, s>>>(N2M_FILL_ARGS);
@@ -2673,7 +2742,7 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
                              const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
                              const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
                              void* workspace, uint64_t workspace_bytes, void* stream, int half, const float* tv_terms = nullptr,
-                             const AdamFuse* fuse1 = nullptr, const AdamFuse* fuse2 = nullptr);
+                             const AdamFuse* fuse1 = nullptr, const AdamFuse* fuse2 = nullptr, const FoldArgs* fold = nullptr);
 
 extern "C" int n2m_grid_encode_backward_binned_pair(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
                                                     float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
@@ -2704,7 +2773,7 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
                              const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
                              const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
                              void* workspace, uint64_t workspace_bytes, void* stream, int half, const float* tv_terms, const AdamFuse* fuse1,
-                             const AdamFuse* fuse2) {
+                             const AdamFuse* fuse2, const FoldArgs* fold) {
     const char* fn = "grid_encode_backward_binned_pair";
     if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
     N2M_REQUIRE(inputs && host_offsets && workspace && (grad1 || grad2), N2M_ENULL, "%s: NULL tensor", fn);
@@ -2731,7 +2800,109 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
     N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (12.0 + lvls * esz + 2.0 * lvls * 8 * esz + (tv_embeddings ? lvls * 7 * 4.0 : 0.0) + (tv_terms ? lvls * 4.0 : 0.0)));
     return launch_binned_pair(grad1, (const _Float16*)grad2, inputs, tv, grad_embeddings1, (_Float16*)grad_embeddings2, B, max_level, host_offsets, lv,
                               gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf, in_scale, in_offset, overwrite != 0, L,
-                              half, tv_terms, fuse1, fuse2);
+                              half, tv_terms, fuse1, fuse2, fold);
+}
+
+// ---- SDF recipe: which finite-difference copies fold into their centre sample (FoldArgs), and the others as a compact list
+namespace {
+__global__ void __launch_bounds__(256)
+sdf_fold_plan_kernel(const float* __restrict__ xyz, uint32_t M, float eps, float bound, uint32_t max_level, LevelTable lv, bool align_corners,
+                     uint8_t* __restrict__ flags, float* __restrict__ left_pts01, uint32_t* __restrict__ left_src,
+                     uint32_t* __restrict__ counters, uint32_t parity) {
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) counters[parity ^ 1u] = 0u;        // the other step's counter: nobody reads it any more
+    uint32_t fl = 0u, n_left = 0u;
+    float p01[6];
+    float c01[3] = {2.f, 2.f, 2.f};
+    if (m < M) {
+        const float x[3] = {xyz[3 * (size_t)m], xyz[3 * (size_t)m + 1], xyz[3 * (size_t)m + 2]};
+        // the centre as the table backward maps it (x * in_scale + in_offset == (x + bound) / (2 bound) for the power-of-two bounds it accepts)
+#pragma unroll
+        for (uint32_t a = 0; a < 3; ++a) c01[a] = (x[a] + bound) / (2.0f * bound);
+#pragma unroll
+        for (uint32_t c = 0; c < 6; ++c) {
+            const float pw = fminf(fmaxf(x[c >> 1] + ((c & 1u) ? -eps : eps), -bound), bound);      // n2m_sdf_offsets' own expression
+            p01[c] = (pw + bound) / (2.0f * bound);
+        }
+        const bool centre_in = !outside_unit_cube<3>(c01) && fabsf(x[0]) <= bound && fabsf(x[1]) <= bound && fabsf(x[2]) <= bound;
+        fl = centre_in ? 63u : 0u;
+        const float half = align_corners ? 0.0f : 0.5f;
+        for (uint32_t l = 0; l < max_level && fl != 0u; ++l) {
+            const float scale = lv.scale[l];
+#pragma unroll
+            for (uint32_t c = 0; c < 6; ++c)
+                if (floorf(p01[c] * scale + half) != floorf(c01[c >> 1] * scale + half)) fl &= ~(1u << c);
+        }
+        flags[m] = (uint8_t)fl;
+        n_left = 6u - (uint32_t)__builtin_popcount(fl);
+    }
+    // compact list of the other copies (order: by wave arrival -- the sums they feed are order-free fixed point or float atomics anyway)
+    const uint32_t incl = n2m_wave_scan_add_u32(n_left, 0);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t base = 0u;
+    if (lane == 63u && total != 0u) base = atomicAdd(counters + parity, total);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+    if (m >= M) return;
+    uint32_t j = base + incl - n_left;
+    const float x[3] = {xyz[3 * (size_t)m], xyz[3 * (size_t)m + 1], xyz[3 * (size_t)m + 2]};
+#pragma unroll
+    for (uint32_t c = 0; c < 6; ++c) {
+        if ((fl >> c) & 1u) continue;
+#pragma unroll
+        for (uint32_t a = 0; a < 3; ++a)      // the other axes: n2m_sdf_offsets clamps them too
+            left_pts01[(size_t)j * 3u + a] = a == (c >> 1) ? p01[c] : (fminf(fmaxf(x[a] + 0.0f, -bound), bound) + bound) / (2.0f * bound);
+        left_src[j] = m * 6u + c;
+        ++j;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sdf_fold_gather_kernel(const float* __restrict__ grad6, uint32_t stride6, const uint32_t* __restrict__ left_src, const uint32_t* __restrict__ counter,
+                       float* __restrict__ out) {
+    const uint32_t K = *counter, j = blockIdx.x * 256u + threadIdx.x, l = blockIdx.y;
+    if (j >= K) return;
+    out[(size_t)l * K + j] = grad6[(size_t)l * stride6 + left_src[j]];
+}
+}  // namespace
+
+extern "C" int n2m_sdf_fold_plan(const float* xyz, uint32_t M, float eps, float bound, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                 int align_corners, uint8_t* flags, float* left_pts01, uint32_t* left_src, uint32_t* counters, uint32_t parity,
+                                 void* stream) {
+    const char* fn = "sdf_fold_plan";
+    N2M_REQUIRE(xyz && flags && left_pts01 && left_src && counters, N2M_ENULL, "%s: NULL tensor", fn);
+    N2M_REQUIRE(L >= 1 && L <= kMaxLevels && max_level <= L && parity <= 1u && eps > 0.0f && bound > 0.0f, N2M_EINVAL, "%s: bad arguments", fn);
+    if (M == 0) return 0;
+    sdf_fold_plan_kernel<<<n2m_ceil_div(M, 256), 256, 0, (hipStream_t)stream>>>(xyz, M, eps, bound, max_level, make_levels(L, S, H), align_corners != 0,
+                                                                               flags, left_pts01, left_src, counters, parity);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_sdf_fold_gather(const float* grad6, uint32_t M, uint32_t levels, const uint32_t* left_src, const uint32_t* counter, float* out,
+                                   void* stream) {
+    N2M_REQUIRE(grad6 && left_src && counter && out, N2M_ENULL, "sdf_fold_gather: NULL tensor");
+    if (M == 0 || levels == 0) return 0;
+    sdf_fold_gather_kernel<<<dim3(n2m_ceil_div(6u * M, 256), levels), 256, 0, (hipStream_t)stream>>>(grad6, 6u * M, left_src, counter, out);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_grid_encode_backward_binned_pair_fold(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
+                                                         float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
+                                                         float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                                         const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
+                                                         const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
+                                                         void* workspace, uint64_t workspace_bytes, const uint8_t* fold_flags, const float* fold_grad6,
+                                                         float fold_eps, float fold_bound, void* stream) {
+    const char* fn = "grid_encode_backward_binned_pair_fold";
+    N2M_REQUIRE(fold_flags && fold_grad6 && grad1 && fold_eps > 0.0f && fold_bound > 0.0f, N2M_EINVAL, "%s: needs flags, the copies' gradient and the density gradient", fn);
+    // the plan compares cells of (x + bound) / (2 bound): the fill must map its samples the same way
+    N2M_REQUIRE(in_scale == 1.0f / (2.0f * fold_bound) && in_offset == 0.5f, N2M_EINVAL, "%s: in_scale / in_offset must be the map of bound %g", fn, (double)fold_bound);
+    FoldArgs fo{};
+    fo.flags = fold_flags; fo.grad6 = fold_grad6; fo.raw = inputs; fo.eps = fold_eps; fo.bound = fold_bound;
+    return binned_pair_entry(grad1, grad2, inputs, host_offsets, grad_embeddings1, grad_embeddings2, B, L, max_level, S, H, gridtype, align_corners,
+                             interp, tv_embeddings, tv_weight, tv_weight_outer, tv_inner01, tv_scale, found_inf, in_scale, in_offset, overwrite, workspace,
+                             workspace_bytes, stream, 0, nullptr, nullptr, nullptr, &fo);
 }
 
 // ---- the table backward with the optimizer pass of the hashed levels inside the accumulates' flush (see AdamFuse)

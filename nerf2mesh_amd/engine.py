@@ -176,6 +176,7 @@ class Stage0Engine:
         # the density column of the packed table.  Same bits as the separate pass (tests/test_engine.py), but the step LOSES 50-85 us: the
         # accumulates are latency-bound work items (2 per CU, barriers between their phases) and move the optimizer's 0.3 GB at a third of the
         # rate the streaming n2m_adam_step reaches (backward 287 -> 399-434 us against Adam 93 -> 15 us; lookup 74 -> 88 us), DESIGN 4.11h.
+        self.sdf_fold = os.environ.get("N2M_SDF_FOLD", "1") != "0"      # SDF recipe: finite-difference copies folded into the batch's table backward
         self.fuse_adam = None
         if world_size == 1 and not opt.sdf and self.Lv == 16 and os.environ.get("N2M_FUSE_ADAM", "0") == "1":
             fl, fr = ctypes.c_uint32(0), ctypes.c_uint32(0)
@@ -771,7 +772,12 @@ class Stage0Engine:
             old = getattr(self, "_sdf", None)
             self._sdf = {"pts": f(18 * cap), "pts01": f(18 * cap), "h6": f(16 * 6 * cap), "d_h6": f(16 * 6 * cap), "s6": f(6 * cap), "d_s6": f(6 * cap),
                          "alpha": f(cap), "d_sdf": f(cap), "x01": f(3 * cap), "eik": f((cap + 255) // 256 + 1), "varp": f((cap + 255) // 256 + 1),
-                         "d_var": old["d_var"] if old is not None else torch.zeros(1, dtype=torch.float32, device=dev)}      # (the Adam descriptor holds its address)
+                         "d_var": old["d_var"] if old is not None else torch.zeros(1, dtype=torch.float32, device=dev),      # (the Adam descriptor holds its address)
+                         # folded copies (n2m_sdf_fold_*): per-sample flags, the compact list of the copies that keep the stacked pass
+                         "flags": torch.empty(cap, dtype=torch.uint8, device=dev), "left_pts": f(18 * cap),
+                         "left_src": torch.empty(6 * cap, dtype=torch.int32, device=dev), "left_g": f(16 * 6 * cap),
+                         "fold_cnt": old["fold_cnt"] if old is not None else torch.zeros(2, dtype=torch.int32, device=dev),
+                         "fold_host": old["fold_host"] if old is not None else torch.zeros(1, dtype=torch.int32).pin_memory()}
             self._sdf_cap = cap
         return self._sdf
 
@@ -807,6 +813,19 @@ class Stage0Engine:
                    _p(w["sigma"]), _p(w["rgb"]), None, _p(w["spec_partial"]) if spec_reg else None, s)
             # finite-difference normals: six offset copies, one encode + one sigma_net evaluation for all of them
             L.call("n2m_sdf_offsets", _p(xyzs), M, eps, float(model.bound), _p(sb["pts"]), _p(sb["pts01"]), s)
+            # Table backward of the copies: once epsilon is a fraction of the finest active cell, a copy nearly always lies in its centre
+            # sample's cell on every level -- those fold into the batch's own backward (n2m_grid_encode_backward_binned_pair_fold), the others
+            # (~30 % at the end of the schedule) take the stacked pass as a compact list whose length the host reads back (it is known long
+            # before the backward is enqueued: the plan only needs the samples)
+            finest = self.H0 * 2.0 ** (self.S * (ml - 1))
+            fold = self.sdf_fold and eps / (2.0 * float(model.bound)) * finest < 0.25
+            if fold:
+                par = self.global_step & 1
+                L.call("n2m_sdf_fold_plan", _p(xyzs), M, eps, float(model.bound), self.Lv, ml, self.S, self.H0, int(bool(e1.align_corners)),
+                       _p(sb["flags"]), _p(sb["left_pts"]), _p(sb["left_src"]), _p(sb["fold_cnt"]), par, s)
+                sb["fold_host"].copy_(sb["fold_cnt"][par:par + 1], non_blocking=True)
+                fold_ready = torch.cuda.Event()
+                fold_ready.record()
             L.call("n2m_grid_encode_forward", _p(sb["pts01"]), _p(e1.embeddings), _p(e1.offsets), _p(sb["h6"]), M6, 3, 1, self.Lv, ml, self.S, self.H0,
                    None, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, L.F32, s)
             L.call("n2m_field_forward", _p(sb["pts"]), None, _p(sb["h6"]), None, *[_p(p) for p in sw], M6, 0, 2, _p(sb["s6"]), None, None, s)
@@ -833,11 +852,26 @@ class Stage0Engine:
             tv_fold = opt.lambda_tv > 0 and ml == self.Lv
             tv_w, tv_wo = float(opt.lambda_tv), float(opt.lambda_tv * (10 if opt.bound > 1 else 1))
             geo = (self.Lv, ml, self.S, self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id)
-            L.call("n2m_grid_encode_backward_binned_pair", _p(w["d_h1"]), _p(w["d_h2"]), _p(xyzs), self.ho.ctypes.data, _p(self.g1), _p(self.g2), M, *geo,
-                   _p(e1.embeddings) if tv_fold else None, tv_w, tv_wo, float(0.5 / model.bound), _p(seed) if tv_fold else None, _p(o.found_inf),
-                   float(self.aff[0]), float(self.aff[1]), 1, _p(ws), ws.numel(), s)
-            L.call("n2m_grid_encode_backward_binned_pair", _p(sb["d_h6"]), None, _p(sb["pts01"]), self.ho.ctypes.data, _p(self.g1), None, M6, *geo,
-                   None, 0.0, 0.0, 1.0, None, _p(o.found_inf), 1.0, 0.0, 0, _p(ws), ws.numel(), s)
+            batch_args = (_p(w["d_h1"]), _p(w["d_h2"]), _p(xyzs), self.ho.ctypes.data, _p(self.g1), _p(self.g2), M, *geo,
+                          _p(e1.embeddings) if tv_fold else None, tv_w, tv_wo, float(0.5 / model.bound), _p(seed) if tv_fold else None, _p(o.found_inf),
+                          float(self.aff[0]), float(self.aff[1]), 1, _p(ws), ws.numel())
+            if fold:
+                L.call("n2m_sdf_fold_gather", _p(sb["d_h6"]), M, ml, _p(sb["left_src"]), sb["fold_cnt"].data_ptr() + 4 * par, _p(sb["left_g"]), s)
+                L.call("n2m_grid_encode_backward_binned_pair_fold", *batch_args, _p(sb["flags"]), _p(sb["d_h6"]), eps, float(model.bound), s)
+                t0 = time.perf_counter()
+                while not fold_ready.query():
+                    if time.perf_counter() - t0 > 5e-3:
+                        fold_ready.synchronize()
+                        break
+                K = int(sb["fold_host"][0])
+                self.last_fold_left = K
+                if K > 0:
+                    L.call("n2m_grid_encode_backward_binned_pair", _p(sb["left_g"]), None, _p(sb["left_pts"]), self.ho.ctypes.data, _p(self.g1), None, K,
+                           *geo, None, 0.0, 0.0, 1.0, None, _p(o.found_inf), 1.0, 0.0, 0, _p(ws), ws.numel(), s)
+            else:
+                L.call("n2m_grid_encode_backward_binned_pair", *batch_args, s)
+                L.call("n2m_grid_encode_backward_binned_pair", _p(sb["d_h6"]), None, _p(sb["pts01"]), self.ho.ctypes.data, _p(self.g1), None, M6, *geo,
+                       None, 0.0, 0.0, 1.0, None, _p(o.found_inf), 1.0, 0.0, 0, _p(ws), ws.numel(), s)
             if opt.lambda_tv > 0 and not tv_fold:
                 # progressive levels: the TV term covers ALL levels of the table (grid.py:170-192 has no max_level), as its own pass
                 x01 = sb["x01"][:3 * M]

@@ -97,6 +97,10 @@ def test_engine_runs_the_sdf_recipe_like_the_trainer(iters, steps):
     a, la = _run(Stage0Trainer, steps, **cfg)
     b, lb = _run(Stage0Engine, steps, **cfg)
     assert a.model.max_level == b.model.max_level == {30000: 4, 120: 10, 40: 16}[iters]
+    if iters == 40:     # the end of the schedule runs with the finite-difference copies folded into the batch's table backward
+        assert 0 < b.last_fold_left < 0.6 * 6 * b.last_num_points
+    elif iters == 30000:
+        assert not hasattr(b, "last_fold_left"), "epsilon 0.1 spans many cells: the stacked pass stays"
     assert a.samples_seen == b.samples_seen and a.rays_seen == b.rays_seen, "same batches, same sample counts"
     a2, la2 = _run(Stage0Trainer, steps, **cfg)
     # yardstick for the loss curve as for the parameters: two runs of the trainer (late in the schedule the normals are finite differences of

@@ -1256,3 +1256,143 @@ def test_precomputed_tv_terms_equal_the_in_place_stencil(be):
         L.call("n2m_grid_encode_backward_binned_pair_tvt", *common, p(terms), p(finf), 1.0, 0.0, 1, p(ws), ws.numel(), L.stream(), half)
     torch.cuda.synchronize()
     assert torch.equal(g1[lo:], b1[lo:]) and torch.equal(g2[lo:], b2[lo:])
+
+
+@pytest.mark.parametrize("eps,max_level,with_tv", [(1e-4, 16, True), (1e-4, 16, False), (2e-3, 16, True), (1e-4, 9, False)])
+def test_sdf_copies_folded_into_the_batch_backward_equal_the_stacked_pass(be, eps, max_level, with_tv):
+    """SDF recipe: the table backward of the six finite-difference copies (nerf/network.py:143-154).  Stacked form: the batch through the
+    pair call, then the 6 M copies (n2m_sdf_offsets' points) through the density-only call.  Folded form: n2m_sdf_fold_plan marks the
+    copies that share their centre's cell on every level, n2m_grid_encode_backward_binned_pair_fold adds those to the centre's entries,
+    the others go through the density-only call as the compact list n2m_sdf_fold_gather fills.  Same sums up to fp32 association;
+    the colour table does not see the copies at all.  Flags and list are checked against a torch statement of the cell test."""
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L
+    from nerf2mesh_amd.gridencoder import GridEncoder, _host_offsets
+    p = L.ptr
+    M = 60011
+    g = torch.Generator(device="cuda").manual_seed(31)
+    t = torch.linspace(0, 1, M, device="cuda")
+    xyz = torch.stack([0.9 * torch.sin(23 * t), 0.9 * torch.cos(13 * t), -0.95 + 1.9 * t], -1)
+    xyz = (xyz + 1e-3 * torch.rand(M, 3, device="cuda", generator=g)).clamp(-1, 1).contiguous()
+    xyz[:7] = torch.tensor([1.0, -1.0, 0.3], device="cuda")                     # on the faces of the cube: copies are clamped
+    bound = 1.0
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    with torch.no_grad():
+        e1.embeddings.uniform_(-1e-2, 1e-2)
+    rows = e1.embeddings.shape[0]
+    ho = _host_offsets(e1)
+    S, H0 = float(np.log2(e1.per_level_scale)), int(e1.base_resolution)
+    geo = (16, max_level, S, H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id)
+    d1 = torch.randn(16, M, device="cuda", generator=g) * 1e-3
+    d2 = (torch.randn(16, M, 2, device="cuda", generator=g) * 0.05).half()
+    d6 = torch.randn(16, 6 * M, device="cuda", generator=g) * 1e-3
+    pts = torch.empty(M, 6, 3, device="cuda"); pts01 = torch.empty(M, 6, 3, device="cuda")
+    L.call("n2m_sdf_offsets", p(xyz), M, eps, bound, p(pts), p(pts01), L.stream())
+    scale_t = torch.tensor(128.0, device="cuda")
+    emb = e1.embeddings.detach().contiguous()
+    tv = (p(emb), 1e-4, 1e-4, 0.5, p(scale_t)) if with_tv else (None, 0.0, 0.0, 1.0, None)
+    need = L.lib().n2m_grid_binned_pair_workspace_bytes(6 * M, 16, ho.ctypes.data)
+    ws = L.workspace(xyz.device, need)
+    L.grid_backward_config(1, 1.0)
+    finf = torch.zeros((), device="cuda")
+
+    def batch_args(g1, g2):
+        return (p(d1), p(d2), p(xyz), ho.ctypes.data, p(g1), p(g2), M, *geo, *tv, p(finf), 0.5, 0.5, 1, p(ws), ws.numel())
+
+    def copies(grad, points, n, g1):
+        L.call("n2m_grid_encode_backward_binned_pair", p(grad), None, p(points), ho.ctypes.data, p(g1), None, n, *geo, None, 0.0, 0.0, 1.0, None,
+               p(finf), 1.0, 0.0, 0, p(ws), ws.numel(), L.stream())
+
+    a1 = torch.empty(rows, 1, device="cuda"); a2 = torch.empty(rows, 2, device="cuda", dtype=torch.float16)
+    L.call("n2m_grid_encode_backward_binned_pair", *batch_args(a1, a2), L.stream())
+    only_batch = a1.clone()
+    copies(d6, pts01, 6 * M, a1)
+    # ---- folded
+    flags = torch.empty(M, dtype=torch.uint8, device="cuda")
+    left_pts = torch.empty(6 * M, 3, device="cuda"); left_src = torch.empty(6 * M, dtype=torch.int32, device="cuda")
+    left_g = torch.empty(16 * 6 * M, device="cuda")
+    cnt = torch.tensor([0, 12345], dtype=torch.int32, device="cuda")
+    L.call("n2m_sdf_fold_plan", p(xyz), M, eps, bound, 16, max_level, S, H0, int(bool(e1.align_corners)), p(flags), p(left_pts), p(left_src), p(cnt), 0,
+           L.stream())
+    K = int(cnt[0])
+    assert int(cnt[1]) == 0, "the other parity's counter is cleared"
+    # (the level scales come from the library's own table through the plan; here the folded RESULT is what pins them -- a wrong flag puts a
+    # copy's weight on the wrong rows and the comparison with the stacked pass below fails)
+    fl = flags.int()
+    n_left = 6 * M - int(sum(((fl >> c) & 1).sum() for c in range(6)))
+    assert K == n_left
+    src = left_src[:K].long()
+    assert torch.equal(torch.sort(src)[0], torch.sort(torch.nonzero(((fl.unsqueeze(1) >> torch.arange(6, device="cuda")) & 1).reshape(-1) == 0).reshape(-1))[0])
+    assert torch.equal(left_pts[:K], pts01.view(-1, 3)[src]), "the listed copies carry n2m_sdf_offsets' own coordinates"
+    if eps == 1e-4 and max_level == 16:
+        assert 0.5 < (6 * M - K) / (6 * M) < 0.85, "most copies of a 1e-4 offset share their centre's cell on all 16 levels"
+    L.call("n2m_sdf_fold_gather", p(d6), M, max_level, p(left_src), p(cnt), p(left_g), L.stream())
+    assert torch.equal(left_g[:max_level * K].view(max_level, K), d6[:max_level, src])
+    b1 = torch.empty(rows, 1, device="cuda"); b2 = torch.empty(rows, 2, device="cuda", dtype=torch.float16)
+    L.call("n2m_grid_encode_backward_binned_pair_fold", *batch_args(b1, b2), p(flags), p(d6), eps, bound, L.stream())
+    if K > 0:
+        copies(left_g, left_pts, K, b1)
+    torch.cuda.synchronize()
+    hi = int(np.asarray(e1.host_offsets)[max_level])
+    lo = int(np.asarray(e1.host_offsets)[min(8, max_level)])
+    assert torch.equal(a2[lo:hi], b2[lo:hi]), "colour table: untouched by the copies (levels one work item owns: bit-equal)"
+    d = (a1[:hi] - b1[:hi]).abs()
+    ref = float(a1[:hi].abs().max())
+    print(f"eps {eps} max_level {max_level}: folded {6 * M - K} of {6 * M} copies; max |diff| {float(d.max()):.3g} of {ref:.3g}")
+    offs_ = np.asarray(e1.host_offsets)
+    for l in range(max_level):
+        dl = d[int(offs_[l]):int(offs_[l + 1])]
+        print(f"   level {l}: max |diff| {float(dl.max()):.3g}  (max |a| {float(a1[int(offs_[l]):int(offs_[l + 1])].abs().max()):.3g})")
+    assert float(d.max()) <= 4e-6 * ref
+    assert float((a1[:hi] - only_batch[:hi]).abs().max()) > 100 * float(d.max()), "the copies' contribution is far above the tolerance"
+    assert float(finf) == 0.0
+
+
+@pytest.mark.parametrize("B", [262144, 600000])
+@pytest.mark.parametrize("max_level", [5, 9, 12])
+def test_binned_pair_backward_with_a_level_cap_equals_the_scatter_backward(be, B, max_level):
+    """Fewer than 16 active levels (the SDF recipe's progressive schedule, nerf/utils.py:651-655) run the shared fill on its plain
+    (tile group, level) grid.  On that grid every level's first workgroup used to clear the level maxima again -- levels then reached the
+    accumulate kernels with a maximum of zero (skipped) or too small a fixed-point unit: wrong sums on the coarse levels at training batch
+    sizes, found in round 3.  Both forms of the call (density table alone, adding; both tables, overwriting) against the scatter backward
+    n2m_grid_encode_backward, which shares no code with the binned path."""
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L
+    from nerf2mesh_amd.gridencoder import GridEncoder, _host_offsets
+    p = L.ptr
+    g = torch.Generator(device="cuda").manual_seed(B + max_level)
+    t = torch.linspace(0, 1, B, device="cuda")
+    x = torch.stack([0.5 + 0.45 * torch.sin(31 * t), 0.5 + 0.45 * torch.cos(19 * t), 0.05 + 0.9 * t], -1)
+    x = (x + 1e-3 * torch.rand(B, 3, device="cuda", generator=g)).clamp(0, 1).contiguous()
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    rows = e1.embeddings.shape[0]
+    ho = _host_offsets(e1)
+    offs = np.asarray(e1.host_offsets)
+    S, H0 = float(np.log2(e1.per_level_scale)), int(e1.base_resolution)
+    emb = e1.embeddings.detach().contiguous()
+    d1 = torch.randn(16, B, device="cuda", generator=g) * 1e-3
+    d2 = (torch.randn(16, B, 2, device="cuda", generator=g) * 0.05).half()
+    need = L.lib().n2m_grid_binned_pair_workspace_bytes(B, 16, ho.ctypes.data)
+    ws = L.workspace(x.device, need)
+    L.grid_backward_config(1, 1.0)
+    finf = torch.zeros((), device="cuda")
+    geo = (16, max_level, S, H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id)
+    ref = torch.zeros(rows, 1, device="cuda")
+    L.call("n2m_grid_encode_backward", p(d1), p(x), p(emb), p(e1.offsets), p(ref), B, 3, 1, 16, max_level, S, H0, None, None, e1.gridtype_id,
+           int(bool(e1.align_corners)), e1.interp_id, L.F32, L.stream())
+    hi = int(offs[max_level])
+    tol = 1e-5 * float(ref.abs().max())
+    for rep in range(3):                                                # the failure depended on which workgroup started when
+        lone = torch.zeros(rows, 1, device="cuda")
+        L.call("n2m_grid_encode_backward_binned_pair", p(d1), None, p(x), ho.ctypes.data, p(lone), None, B, *geo, None, 0.0, 0.0, 1.0, None, p(finf),
+               1.0, 0.0, 0, p(ws), ws.numel(), L.stream())
+        g1 = torch.full((rows, 1), 7.0, device="cuda"); g2 = torch.full((rows, 2), 7.0, device="cuda", dtype=torch.float16)
+        L.call("n2m_grid_encode_backward_binned_pair", p(d1), p(d2), p(x), ho.ctypes.data, p(g1), p(g2), B, *geo, None, 0.0, 0.0, 1.0, None, p(finf),
+               1.0, 0.0, 1, p(ws), ws.numel(), L.stream())
+        torch.cuda.synchronize()
+        for name, got in (("density table alone", lone), ("both tables", g1)):
+            for l in range(max_level):
+                d = float((got[int(offs[l]):int(offs[l + 1])] - ref[int(offs[l]):int(offs[l + 1])]).abs().max())
+                assert d <= tol, f"{name}, level {l}: max |diff| {d:.3g} against the scatter backward (values up to {float(ref.abs().max()):.3g})"
+        assert float(g1[hi:].abs().max()) == 0.0 and float(g2[hi:].float().abs().max()) == 0.0, "overwrite mode defines the untouched levels as zero"
+        assert float(g2[:hi].float().abs().max()) > 0
