@@ -69,12 +69,15 @@ int n2m_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* b
 int n2m_packbits_dev(const float* grid, uint32_t N, const float* density_thresh, uint8_t* bitfield, void* stream);
 
 /* Occupancy refresh (nerf/renderer.py:1074-1149), the elementwise work around the density query.
- * n2m_occupancy_points: xyz[i] = cells[i] * inner + (u[i] * 2 - 1) * half_grid_size over n floats -- the reference's expression (:1096-1100:
- * cells = 2 c / (H - 1) - 1 in Morton order, inner = bound - half_grid_size, u = torch.rand_like draws) with its rounding points.
+ * n2m_occupancy_points: xyz[j] = cells[c] * inner + (u[c] * 2 - 1) * half_grid_size per component, c = idx ? idx[j] : j, for n_points points --
+ * the reference's expression (:1096-1100: cells [H^3, 3] = 2 c / (H - 1) - 1 in Morton order, inner = bound - half_grid_size, u = torch.rand_like
+ * draws for ALL cells) with its rounding points.  idx lists the cells whose grid value is >= 0: the others are never updated (:1131-1134), so
+ * their density need not be queried (outdoor recipe, 5 cascades: 37 % of the cells are valid).
  * n2m_occupancy_update: grid = max(grid * decay, tmp) where both are >= 0 (:1133-1134), mean of max(grid, 0) (:1136) and the threshold
  * min(mean, density_thresh) (:1140) left on the device for n2m_packbits_dev -- no host read-back (the reference reads the mean with .item()).
  * partials: n2m_occupancy_update_partials(n) floats of scratch; ticket: one zero-initialised u32 the kernel resets; n floats, 16-byte aligned. */
-int n2m_occupancy_points(const float* cells, const float* u, float inner, float half_grid_size, float* xyz, uint32_t n, void* stream);
+int n2m_occupancy_points(const float* cells, const float* u, const int32_t* idx, float inner, float half_grid_size, float* xyz, uint32_t n_points,
+                         void* stream);
 uint32_t n2m_occupancy_update_partials(uint32_t n);
 int n2m_occupancy_update(float* grid, const float* tmp, float decay, uint32_t n, float density_thresh, float* partials, uint32_t* ticket,
                          float* mean, float* thresh, void* stream);

@@ -58,7 +58,7 @@ SIGNATURES = {
     "n2m_grid_encode_backward_binned_pair_fold": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
                                                   _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _int, _vp, _u64, _vp, _vp, _f32, _f32, _vp],
     "n2m_occupancy_update_partials": [_u32],                                                     # returns uint32 (RESTYPES)
-    "n2m_occupancy_points": [_vp, _vp, _f32, _f32, _vp, _u32, _vp],
+    "n2m_occupancy_points": [_vp, _vp, _vp, _f32, _f32, _vp, _u32, _vp],
     "n2m_occupancy_update": [_vp, _vp, _f32, _u32, _f32, _vp, _vp, _vp, _vp, _vp],
     "n2m_grid_pair_fuse_plan": [_u32, _u32, _vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)],
     "n2m_grid_encode_backward_binned_pair_adam": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,

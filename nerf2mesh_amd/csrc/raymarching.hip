@@ -1356,13 +1356,19 @@ extern "C" int n2m_packbits_dev(const float* grid, uint32_t N, const float* dens
 }
 
 // ---- occupancy refresh (nerf/renderer.py:1074-1149), the elementwise work around the density query as two launches
-// points: xyz = cell * (bound - hgs) + (u * 2 - 1) * hgs, the reference's expression (:1096-1100) with its rounding points (no contraction)
+// points: xyz = cell * (bound - hgs) + (u * 2 - 1) * hgs, the reference's expression (:1096-1100) with its rounding points (no contraction);
+// idx != NULL: only the listed cells (point j <- cell idx[j]: the cells whose grid value is >= 0 -- the others are never updated, :1131-1134)
 __global__ void __launch_bounds__(256)
-occupancy_points_kernel(const float* __restrict__ cells, const float* __restrict__ u, float inner, float hgs, float* __restrict__ xyz, uint32_t n) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const float jitter = (u[i] * 2.0f - 1.0f) * hgs;
-    xyz[i] = cells[i] * inner + jitter;
+occupancy_points_kernel(const float* __restrict__ cells, const float* __restrict__ u, const int32_t* __restrict__ idx, float inner, float hgs,
+                        float* __restrict__ xyz, uint32_t n) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n) return;
+    const size_t c = idx ? (size_t)idx[j] : (size_t)j;
+#pragma unroll
+    for (uint32_t a = 0; a < 3; ++a) {
+        const float jitter = (u[c * 3u + a] * 2.0f - 1.0f) * hgs;
+        xyz[(size_t)j * 3u + a] = cells[c * 3u + a] * inner + jitter;
+    }
 }
 
 // update: grid = max(grid * decay, tmp) where both are >= 0 (:1133-1134); sum of max(grid, 0) -> mean (:1136) -> threshold
@@ -1424,10 +1430,11 @@ occupancy_update_kernel(float* __restrict__ grid, const float* __restrict__ tmp,
     }
 }
 
-extern "C" int n2m_occupancy_points(const float* cells, const float* u, float inner, float half_grid_size, float* xyz, uint32_t n, void* stream) {
+extern "C" int n2m_occupancy_points(const float* cells, const float* u, const int32_t* idx, float inner, float half_grid_size, float* xyz,
+                                    uint32_t n_points, void* stream) {
     N2M_NOTNULL(cells); N2M_NOTNULL(u); N2M_NOTNULL(xyz);
-    if (n == 0) return 0;
-    occupancy_points_kernel<<<n2m_ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(cells, u, inner, half_grid_size, xyz, n);
+    if (n_points == 0) return 0;
+    occupancy_points_kernel<<<n2m_ceil_div(n_points, 256), 256, 0, (hipStream_t)stream>>>(cells, u, idx, inner, half_grid_size, xyz, n_points);
     N2M_CHECK_LAUNCH();
     return 0;
 }

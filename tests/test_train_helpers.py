@@ -237,8 +237,13 @@ def test_occupancy_refresh_kernels_against_the_torch_statement(cascade, bound):
         u = torch.rand(n_cells, 3, device=dev, generator=g)
         want = cells * (b - hgs) + (u * 2 - 1) * hgs
         got = torch.empty_like(cells)
-        L.call("n2m_occupancy_points", p(cells), p(u), float(b - hgs), float(hgs), p(got), cells.numel(), L.stream())
+        L.call("n2m_occupancy_points", p(cells), p(u), None, float(b - hgs), float(hgs), p(got), n_cells, L.stream())
         assert torch.equal(got, want), f"cascade {cas}"
+        # only the cells whose grid value is >= 0: the listed cells get the points they would have got
+        idx = torch.nonzero(grid[cas] >= 0).reshape(-1)
+        sub = torch.full_like(cells, 123.0)
+        L.call("n2m_occupancy_points", p(cells), p(u), p(idx.to(torch.int32)), float(b - hgs), float(hgs), p(sub), idx.numel(), L.stream())
+        assert torch.equal(sub[:idx.numel()], want[idx]) and bool((sub[idx.numel():] == 123.0).all())
     decay, thresh0 = 0.95, 10.0
     valid = (grid >= 0) & (tmp_all >= 0)
     want_grid = torch.where(valid, torch.maximum(grid * decay, tmp_all), grid)
@@ -284,3 +289,52 @@ def test_density_query_from_the_packed_rows_equals_the_plain_table():
     with torch.no_grad():
         s1 = net.density(x)["sigma"]
     assert torch.isfinite(s1).all()
+
+
+def test_occupancy_refresh_skips_untrained_cells_without_changing_the_result():
+    """Cells marked -1 are never updated (nerf/renderer.py:1131-1134); update_extra_state therefore queries the density of the OTHER cells
+    only.  Against a torch statement of the reference's full update fed with the same random draws: same grid, same bit field."""
+    import torch
+    from nerf2mesh_amd import raymarching
+    from nerf2mesh_amd.network import NeRFNetwork
+    from nerf2mesh_amd.options import make_options
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(5)
+    net = NeRFNetwork(make_options(O=True, bound=4, fused_mlp=True)).to(dev)
+    assert net.cascade == 3
+    with torch.no_grad():
+        net.encoder.embeddings.uniform_(-1, 1)
+    g = torch.Generator(device=dev).manual_seed(1)
+    net.density_grid.copy_(torch.rand(net.density_grid.shape, device=dev, generator=g) * 5)
+    net.density_grid[0, ::3] = -1
+    net.density_grid[1, 100_000:] = -1
+    net.density_grid[2] = -1                                    # a cascade without a single valid cell
+    before = net.density_grid.clone()
+    state = torch.cuda.get_rng_state(dev)
+    net.update_extra_state()
+    got_grid, got_bits, got_mean = net.density_grid.clone(), net.density_bitfield.clone(), net.mean_density
+    # the reference's full update with the same draws
+    torch.cuda.set_rng_state(state, dev)
+    cells = net._cells()
+    tmp = torch.empty_like(before)
+    with torch.no_grad():
+        for cas in range(net.cascade):
+            bound = min(2 ** cas, net.bound)
+            hgs = bound / net.grid_size
+            xyzs = cells * (bound - hgs) + (torch.rand_like(cells) * 2 - 1) * hgs
+            with torch.autocast(device_type="cuda", dtype=torch.float16):
+                tmp[cas] = net.density(xyzs)["sigma"].reshape(-1).float()
+    valid = (before >= 0) & (tmp >= 0)
+    want = torch.where(valid, torch.maximum(before * 0.95, tmp), before)
+    assert torch.equal(got_grid, want)
+    assert bool((got_grid[2] == -1).all()) and bool((got_grid[0, ::3] == -1).all())
+    want_mean = float(want.clamp(min=0).double().mean())
+    assert abs(got_mean - want_mean) <= 2e-7 * want_mean
+    assert torch.equal(got_bits, raymarching.packbits(want, min(got_mean, net.density_thresh)))
+    # a second refresh reuses the cached lists (the grid was only touched through the kernels) and still agrees
+    net.update_extra_state()
+    assert bool((net.density_grid[2] == -1).all())
+    # marking through torch invalidates them
+    net.density_grid[0, 1::3] = -1
+    net.update_extra_state()
+    assert bool((net.density_grid[0, 1::3] == -1).all())
