@@ -19,6 +19,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s 
 cp $(find /tmp/prof_s -name "*kernel_stats.csv" | head -1) $O/${TAG}_step_kernel_stats.csv
 TR=$(find /tmp/prof_s -name "*kernel_trace.csv" | head -1)
 python $R/tools/step_timeline.py $TR > $O/${TAG}_step_timeline.txt
+python $R/tools/refresh_timeline.py $TR > $O/${TAG}_refresh_timeline.txt
 python $R/tools/trace_vs_events.py $TR $O/${TAG}_bench_traced.json > $O/${TAG}_trace_vs_events.txt 2>&1; cat $O/${TAG}_trace_vs_events.txt
 cd $R
 python bench.py > $O/${TAG}_bench.json 2>$O/bench.err; python tools/show_bench.py $O/${TAG}_bench.json
@@ -27,6 +28,5 @@ python bench.py --stage 1 > $O/${TAG}_bench_stage1.json 2>/dev/null; python tool
 python bench.py --recipe sdf --no-cpu-baseline > $O/${TAG}_bench_sdf.json 2>/dev/null; python tools/show_bench.py $O/${TAG}_bench_sdf.json | head -1
 python bench.py --recipe sdf --diffuse --no-cpu-baseline > $O/${TAG}_bench_sdf_early.json 2>/dev/null; python tools/show_bench.py $O/${TAG}_bench_sdf_early.json | head -1
 python bench.py --recipe sdf --no-cpu-baseline --autograd > $O/${TAG}_bench_sdf_autograd.json 2>/dev/null; python tools/show_bench.py $O/${TAG}_bench_sdf_autograd.json | head -1
-bash tools/sweep_tv.sh > $O/${TAG}_tv_split_sweep.txt 2>&1; cat $O/${TAG}_tv_split_sweep.txt
-bash tools/sweep_marker.sh > $O/${TAG}_marker_sweep.txt 2>&1; cat $O/${TAG}_marker_sweep.txt
+# (the TV-split and marker sweeps of this round: tools/sweep_tv.sh, tools/sweep_marker.sh -> profiles/r03_tv_split_sweep.txt, r03_marker_sweep.txt)
 python bench.py --recipe garden --no-cpu-baseline > $O/${TAG}_bench_garden.json 2>/dev/null; python tools/show_bench.py $O/${TAG}_bench_garden.json | head -1
