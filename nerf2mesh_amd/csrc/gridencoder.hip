@@ -3058,8 +3058,10 @@ extern "C" int n2m_grid_encode_forward_packed(const float* inputs, const void* p
     hipStream_t s = (hipStream_t)stream;
     const LevelTable lv = make_levels(L, S, H);
     // algorithmic bytes of both encoders' forward (588 B/sample each at L = 16, one 12-byte input read shared)
-    if (outputs2) N2M_PROF(N2M_K_GRID_FWD_PACKED, s, (double)B * (12.0 + (double)max_level * 8 * (4 + 4) + (double)max_level * (4 + 4)));
-    else N2M_PROF(N2M_K_GRID_FWD, s, (double)B * (12.0 + (double)max_level * 8 * 4 + (double)max_level * 4));
+    // (one scope object for the whole launch: its destructor records the closing event)
+    N2M_PROF(outputs2 ? N2M_K_GRID_FWD_PACKED : N2M_K_GRID_FWD, s,
+             outputs2 ? (double)B * (12.0 + (double)max_level * 8 * (4 + 4) + (double)max_level * (4 + 4))
+                      : (double)B * (12.0 + (double)max_level * 8 * 4 + (double)max_level * 4));
     const uint32_t n_tiles = n2m_ceil_div(B, 256);
     static const uint32_t xg_env = getenv("N2M_FWD_XCD_GROUP") ? (uint32_t)atoi(getenv("N2M_FWD_XCD_GROUP")) : 4u;     // A/B switch: 0 = level-major grid
     const uint32_t xg = (max_level == 16u && (xg_env == 1u || xg_env == 2u || xg_env == 4u)) ? xg_env : 0u;
