@@ -397,6 +397,10 @@ def main():
         roof = roofline_of(max((k for k in kernels if kernels[k]["stream"] == "main"), key=lambda k: kernels[k]["ms_per_step"]))   # the dominant entry point of the step
         if "grid_encode_forward_packed" in kernels:
             roof_lookup = roofline_of("grid_encode_forward_packed")                          # north_star's hash-grid lookup (training launches only)
+        for r in (roof, roof_lookup):       # a broken measurement must not pass as a number (an event pair that closed before its launch once did)
+            if r is not None and r["frac"] is not None and not (0.0 < r["frac"] <= 1.0):
+                raise SystemExit(f"bench: implausible roofline entry {r['kernel']}: {r['achieved']:.0f} GB/s of {HBM_PEAK_GBS:.0f} -- "
+                                 "the per-kernel events do not bracket the launch")
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
