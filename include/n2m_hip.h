@@ -360,28 +360,38 @@ int n2m_grid_encode_backward_binned_pair_adam(const float* grad1, const void* gr
 int n2m_adam_fuse_restore(const N2mAdamFuse* fuse, const int32_t* host_offsets, uint32_t L, const float* found_inf, void* stream);
 
 /* SDF recipe (nerf/network.py:143-154: normals by finite differences, six copies x +- eps e_a of every sample through the density encoder):
- * the copies' TABLE BACKWARD folded into the batch's own.  At the end of the schedule eps = 1e-4 is a tenth of the finest cell, so a copy
- * nearly always shares its centre sample's cell on every level -- it updates the same eight rows with slightly different weights.
- *   n2m_sdf_fold_plan    flags[m] bit c (c = 2 axis + (minus ? 1 : 0), n2m_sdf_offsets' order): copy c of sample m lies in the centre's cell
- *                        on every level < max_level (0 for a centre outside the unit cube); the OTHER copies as a compact list --
- *                        left_pts01 [K, 3] ([0,1] coordinates as n2m_sdf_offsets writes them), left_src [K] (= 6 m + c), K added to
- *                        counters[parity] (the kernel clears counters[parity ^ 1]: alternate parity from step to step; buffers for 6 M entries).
- *   n2m_sdf_fold_gather  out [levels, K] = grad6[level, left_src[j]] (grad6 = the stacked copies' feature gradient [levels, 6 M], K read from
- *                        the device counter): the gradient columns of the listed copies, ready for n2m_grid_encode_backward_binned_pair.
- *   n2m_grid_encode_backward_binned_pair_fold   n2m_grid_encode_backward_binned_pair (one pass, B <= 2^20) that adds, for every copy with
- *                        its flag set, w_copy(corner) * grad6[level, 6 s + c] to the centre sample's eight density entries (weights from
+ * the copies' TABLE BACKWARD folded into the batch's own.  At the end of the schedule eps = 1e-4 is a tenth of the finest cell, so on a given
+ * level a copy nearly always shares its centre sample's cell (99.9 % on level 0 ... 90 % on level 15) -- it updates the same eight rows with
+ * slightly different weights.
+ *   n2m_sdf_fold_plan    flags[l, m] bit c (c = 2 axis + (minus ? 1 : 0), n2m_sdf_offsets' order): copy c of sample m lies in the centre's cell
+ *                        on level l (0 for a centre outside the unit cube); per level the OTHER copies as a compact list -- left_pts01
+ *                        [L, cap, 3] ([0,1] coordinates as n2m_sdf_offsets writes them), left_src [L, cap] (= 6 m + c), their number added to
+ *                        counters[parity][l] (counters [2][32]; the kernel clears counters[parity ^ 1]: alternate parity from step to step;
+ *                        cap >= 6 M).
+ *   n2m_sdf_fold_gather  out [levels, B] = grad6[level, left_src[level, j]] for the listed copies (grad6 = the stacked copies' feature gradient
+ *                        [levels, 6 M]; counters = this step's row), zero beyond a level's list, whose points are set outside the unit
+ *                        cube up to B (the caller's common list length, >= every counter): ready for n2m_grid_encode_backward_binned_lists.
+ *   n2m_grid_encode_backward_binned_pair_fold   n2m_grid_encode_backward_binned_pair (one pass, B <= 2^20) that adds, for every (copy, level)
+ *                        with its flag set, w_copy(corner) * grad6[level, 6 s + c] to the centre sample's eight density entries (weights from
  *                        the copy's own position, recomputed as n2m_sdf_offsets does: the values the stacked pass would have used).
- * The caller then runs the plain pair backward on the K listed copies (K from the counter, read back on the host).  Sums equal the
- * stacked pass's up to fp32 association (centre + copies in one thread instead of a lane scan). */
+ *   n2m_grid_encode_backward_binned_lists       the density-only backward with one point list PER LEVEL (inputs [L, level_stride, 3], grad1
+ *                        [L, B]); points outside the unit cube are skipped.
+ * The caller reads the row of counters back (they are final long before the backward is enqueued: the plan only needs the samples) and runs the
+ * lists call with B = their maximum.  Sums equal the stacked pass's up to fp32 association (centre + copies in one thread instead of a lane scan). */
 int n2m_sdf_fold_plan(const float* xyz, uint32_t M, float eps, float bound, uint32_t L, uint32_t max_level, float S, uint32_t H, int align_corners,
-                      uint8_t* flags, float* left_pts01, uint32_t* left_src, uint32_t* counters, uint32_t parity, void* stream);
-int n2m_sdf_fold_gather(const float* grad6, uint32_t M, uint32_t levels, const uint32_t* left_src, const uint32_t* counter, float* out, void* stream);
+                      uint8_t* flags, float* left_pts01, uint32_t* left_src, uint32_t cap, uint32_t* counters, uint32_t parity, void* stream);
+int n2m_sdf_fold_gather(const float* grad6, uint32_t M, uint32_t levels, const uint32_t* left_src, float* left_pts01, uint32_t cap,
+                        const uint32_t* counters, uint32_t B, float* out, void* stream);
 int n2m_grid_encode_backward_binned_pair_fold(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
                                               float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level, float S,
                                               uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, const float* tv_embeddings,
                                               float tv_weight, float tv_weight_outer, float tv_inner01, const float* tv_scale, float* found_inf,
                                               float in_scale, float in_offset, int overwrite, void* workspace, uint64_t workspace_bytes,
                                               const uint8_t* fold_flags, const float* fold_grad6, float fold_eps, float fold_bound, void* stream);
+int n2m_grid_encode_backward_binned_lists(const float* grad1, const float* inputs, uint32_t level_stride, const int32_t* host_offsets,
+                                          float* grad_embeddings1, uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
+                                          int align_corners, uint32_t interp, float* found_inf, int overwrite, void* workspace,
+                                          uint64_t workspace_bytes, void* stream);
 
 /* The TV terms of a batch on their own: tv_out[level, s] (f32 [L, B]) = the total-variation term of (sample s, level) exactly as the shared
  * fill evaluates it in place when it is handed tv_embeddings (gridencoder.cu:505-609 on the cell floor(x * scale + 0.5); weight / weight_outer /

@@ -53,8 +53,9 @@ SIGNATURES = {
                                              _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _int, _vp, _u64, _vp],
     "n2m_grid_encode_backward_binned_pair_half": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
                                                   _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _int, _vp, _u64, _vp, _int],
-    "n2m_sdf_fold_plan": [_vp, _u32, _f32, _f32, _u32, _u32, _f32, _u32, _int, _vp, _vp, _vp, _vp, _u32, _vp],
-    "n2m_sdf_fold_gather": [_vp, _u32, _u32, _vp, _vp, _vp, _vp],
+    "n2m_sdf_fold_plan": [_vp, _u32, _f32, _f32, _u32, _u32, _f32, _u32, _int, _vp, _vp, _vp, _u32, _vp, _u32, _vp],
+    "n2m_sdf_fold_gather": [_vp, _u32, _u32, _vp, _vp, _u32, _vp, _u32, _vp, _vp],
+    "n2m_grid_encode_backward_binned_lists": [_vp, _vp, _u32, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _vp, _int, _vp, _u64, _vp],
     "n2m_grid_encode_backward_binned_pair_fold": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
                                                   _vp, _f32, _f32, _f32, _vp, _vp, _f32, _f32, _int, _vp, _u64, _vp, _vp, _f32, _f32, _vp],
     "n2m_occupancy_update_partials": [_u32],                                                     # returns uint32 (RESTYPES)

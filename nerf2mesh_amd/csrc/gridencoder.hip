@@ -1522,14 +1522,15 @@ __device__ unsigned long long g_fill_t[2][8][6];     // workgroup 3 (a fine, has
 #define N2M_FILL_STAMP(i) do { if (stamp && it < 8u) g_fill_t[stamp_w][it][(i)] = __builtin_readcyclecounter(); } while (0)
 
 // ---- SDF recipe: the six finite-difference copies of a sample (x +- eps e_a, nerf/network.py:143-154) folded into the sample's own entries.
-// At the end of the schedule eps = 1e-4 is a tenth of the finest cell: a copy nearly always lies in the cell of its centre sample on every
-// level, i.e. it updates the SAME eight rows with slightly different weights.  Instead of going through the fill as six more samples (the
-// stacked pass: 480 us per step), such a copy adds w_copy(corner) * g_copy to the centre's eight values here; the copies that leave the cell
-// on some level (n2m_sdf_fold_plan marks them, ~30 %) take the stacked pass, compacted.  Positions are recomputed exactly as
-// n2m_sdf_offsets writes them (clamp(x + off, -bound, bound), then (p + bound) / (2 bound)), so a folded copy's weights are the ones the
-// stacked pass would have used, bit for bit; what changes is the association of the fp32 sum (centre + copies here, a lane scan there).
+// At the end of the schedule eps = 1e-4 is a tenth of the finest cell: on a given level a copy nearly always lies in the cell of its centre
+// sample (99.9 % on level 0 ... 90 % on level 15), i.e. it updates the SAME eight rows with slightly different weights.  Instead of going
+// through the fill as six more samples (the stacked pass: ~800 us per step), such a (copy, level) pair adds w_copy(corner) * g_copy to the
+// centre's eight values here; the pairs that leave the cell (n2m_sdf_fold_plan lists them per level, 2.4 % of all) take a density-only call
+// over those lists.  Positions are recomputed exactly as n2m_sdf_offsets writes them (clamp(x + off, -bound, bound), then
+// (p + bound) / (2 bound)), so a folded copy's weights are the ones the stacked pass would have used, bit for bit; what changes is the
+// association of the fp32 sum (centre + copies here, a lane scan there).
 struct FoldArgs {
-    const uint8_t* flags;       // [B] bit c: copy c (= 2 axis + (0: +eps, 1: -eps)) shares the centre's cell on every active level
+    const uint8_t* flags;       // [L, B] bit c: copy c (= 2 axis + (0: +eps, 1: -eps)) shares the centre's cell on this level
     const float* grad6;         // [L, 6 B] gradient of the stacked copies' features, sample-major inside a level
     const float* raw;           // [B, 3] the samples as the caller has them (before the in_scale / in_offset map)
     uint32_t stride6;           // 6 B
@@ -1583,7 +1584,8 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
                      uint32_t* __restrict__ log_v2, float* __restrict__ found_inf, float in_scale, float in_offset,
                      float* __restrict__ clear1, _Float16* __restrict__ clear2, uint32_t clear_mask1, uint32_t clear_mask2,
                      uint32_t merge_levels, uint32_t groups_x, uint32_t slot_begin, unsigned long long* __restrict__ lm_ready,
-                     unsigned long long lm_token, FoldArgs fold = FoldArgs{}) {
+                     unsigned long long lm_token, uint32_t in_level_stride = 0u /* floats between the levels' own point lists; 0: one list */,
+                     FoldArgs fold = FoldArgs{}) {
     __builtin_amdgcn_s_setprio(3);
     constexpr uint32_t D = 3;
     constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
@@ -1654,7 +1656,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
         const uint32_t s = t * 1024u + tid;
         nx[0] = nx[1] = nx[2] = 2.f;
         if (t < plan.tiles && s < B) {
-            load_point<D>(inputs, s, nx);
+            load_point<D>(inputs + (size_t)level * in_level_stride, s, nx);
 #pragma unroll
             for (uint32_t d = 0; d < D; ++d) nx[d] = nx[d] * in_scale + in_offset;
             ng1 = grad1 ? grad1[(size_t)level * Bstride + s] : 0.0f;        // grad1 == NULL: colour table only (stage 1: the density branch is idle)
@@ -1700,7 +1702,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
             else pair_entries<TV, 0, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
             if constexpr (FOLD) {
                 const uint32_t sidx = tile * 1024u + tid;
-                const uint32_t fl = fold.flags[sidx];
+                const uint32_t fl = fold.flags[(size_t)level * B + sidx];
                 if (fl != 0u) fold_copies(fold, sidx, level, x, scale, align_corners, interp, fl, f1, vmax1, found_inf);
             }
         }
@@ -2401,7 +2403,8 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
                        uint32_t max_level, const int32_t* host_offsets, const LevelTable& lv, uint32_t gridtype, bool align, uint32_t interp,
                        void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn, float* found_inf, float in_scale,
                        float in_offset, bool overwrite, uint32_t L, int half = 0, const float* tv_terms = nullptr,
-                       const AdamFuse* fuse1 = nullptr, const AdamFuse* fuse2 = nullptr, const FoldArgs* fold = nullptr) {
+                       const AdamFuse* fuse1 = nullptr, const AdamFuse* fuse2 = nullptr, const FoldArgs* fold = nullptr,
+                       uint32_t in_level_stride = 0) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bin_fill_pair_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileEntries * 10));
@@ -2415,6 +2418,7 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<_Float16, 2, kPairP, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
         attr_set = true;
     }
+    N2M_REQUIRE(in_level_stride == 0 || B <= kBinChunk, N2M_EINVAL, "%s: per-level point lists need one pass (B <= %u)", fn, kBinChunk);
     for (uint32_t b0 = 0; b0 < B; b0 += kBinChunk) {
         const uint32_t Bc = B - b0 < kBinChunk ? B - b0 : kBinChunk;
         const BinLayout lay = make_bin_plan(Bc, 2, max_level, host_offsets, false, kPairP, 2);     // 2 x 8 B per entry >= the 10 B used
@@ -2485,9 +2489,10 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         }
         const float* tvt = tv_terms ? tv_terms + (size_t)b0 : nullptr;          // [L, B]: this pass's column block
 #define N2M_FILL_ARGS g1, g2, x, tv, tvt, Bc, B, lay.plan, lv, gridtype, align, interp, level_max, directory, log_rel, log_v1, log_v2, found_inf, in_scale, \
-                      in_offset, ow ? table1 : nullptr, ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token
+                      in_offset, ow ? table1 : nullptr, ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token, in_level_stride
         if (fold) {
-            N2M_REQUIRE(both && !tvt && B <= kBinChunk && half == 0, N2M_EINVAL, "%s: folded copies need the density gradient, one pass (B <= %u) and all levels", fn, kBinChunk);
+            N2M_REQUIRE(both && !tvt && B <= kBinChunk && half == 0 && in_level_stride == 0, N2M_EINVAL,
+                        "%s: folded copies need the density gradient, one pass (B <= %u), all levels and one point list", fn, kBinChunk);
             FoldArgs fo = *fold;
             fo.stride6 = 6u * B;
             if (tv.table) bin_fill_pair_kernel<1, true><<<grid, 1024, kTileEntries * 10, s>>>(N2M_FILL_ARGS, fo);
@@ -2742,7 +2747,8 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
                              const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
                              const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
                              void* workspace, uint64_t workspace_bytes, void* stream, int half, const float* tv_terms = nullptr,
-                             const AdamFuse* fuse1 = nullptr, const AdamFuse* fuse2 = nullptr, const FoldArgs* fold = nullptr);
+                             const AdamFuse* fuse1 = nullptr, const AdamFuse* fuse2 = nullptr, const FoldArgs* fold = nullptr,
+                             uint32_t in_level_stride = 0);
 
 extern "C" int n2m_grid_encode_backward_binned_pair(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,
                                                     float* grad_embeddings1, void* grad_embeddings2, uint32_t B, uint32_t L, uint32_t max_level,
@@ -2773,7 +2779,7 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
                              const float* tv_embeddings, float tv_weight, float tv_weight_outer, float tv_inner01,
                              const float* tv_scale, float* found_inf, float in_scale, float in_offset, int overwrite,
                              void* workspace, uint64_t workspace_bytes, void* stream, int half, const float* tv_terms, const AdamFuse* fuse1,
-                             const AdamFuse* fuse2, const FoldArgs* fold) {
+                             const AdamFuse* fuse2, const FoldArgs* fold, uint32_t in_level_stride) {
     const char* fn = "grid_encode_backward_binned_pair";
     if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
     N2M_REQUIRE(inputs && host_offsets && workspace && (grad1 || grad2), N2M_ENULL, "%s: NULL tensor", fn);
@@ -2800,91 +2806,122 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
     N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (12.0 + lvls * esz + 2.0 * lvls * 8 * esz + (tv_embeddings ? lvls * 7 * 4.0 : 0.0) + (tv_terms ? lvls * 4.0 : 0.0)));
     return launch_binned_pair(grad1, (const _Float16*)grad2, inputs, tv, grad_embeddings1, (_Float16*)grad_embeddings2, B, max_level, host_offsets, lv,
                               gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf, in_scale, in_offset, overwrite != 0, L,
-                              half, tv_terms, fuse1, fuse2, fold);
+                              half, tv_terms, fuse1, fuse2, fold, in_level_stride);
 }
 
-// ---- SDF recipe: which finite-difference copies fold into their centre sample (FoldArgs), and the others as a compact list
+// ---- SDF recipe: which (copy, level) pairs fold into their centre sample (FoldArgs), and the others as one compact list per level
 namespace {
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 sdf_fold_plan_kernel(const float* __restrict__ xyz, uint32_t M, float eps, float bound, uint32_t max_level, LevelTable lv, bool align_corners,
-                     uint8_t* __restrict__ flags, float* __restrict__ left_pts01, uint32_t* __restrict__ left_src,
-                     uint32_t* __restrict__ counters, uint32_t parity) {
-    const uint32_t m = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
-    if (blockIdx.x == 0u && threadIdx.x == 0u) counters[parity ^ 1u] = 0u;        // the other step's counter: nobody reads it any more
-    uint32_t fl = 0u, n_left = 0u;
-    float p01[6];
-    float c01[3] = {2.f, 2.f, 2.f};
+                     uint8_t* __restrict__ flags /*[L, M]*/, float* __restrict__ left_pts01 /*[L, cap, 3]*/, uint32_t* __restrict__ left_src /*[L, cap]*/,
+                     uint32_t cap, uint32_t* __restrict__ counters /*[2][kMaxLevels]*/, uint32_t parity) {
+    __shared__ uint32_t wave_tot[16], wave_base[16];
+    const uint32_t tid = threadIdx.x, m = blockIdx.x * 1024u + tid, lane = tid & 63u, wid = tid >> 6;
+    if (blockIdx.x == 0u && tid < kMaxLevels) counters[(parity ^ 1u) * kMaxLevels + tid] = 0u;      // the other step's counters: nobody reads them any more
+    float x[3] = {0.f, 0.f, 0.f}, p01[6], c01[3] = {2.f, 2.f, 2.f};
+    bool centre_in = false;
     if (m < M) {
-        const float x[3] = {xyz[3 * (size_t)m], xyz[3 * (size_t)m + 1], xyz[3 * (size_t)m + 2]};
-        // the centre as the table backward maps it (x * in_scale + in_offset == (x + bound) / (2 bound) for the power-of-two bounds it accepts)
 #pragma unroll
-        for (uint32_t a = 0; a < 3; ++a) c01[a] = (x[a] + bound) / (2.0f * bound);
-#pragma unroll
-        for (uint32_t c = 0; c < 6; ++c) {
-            const float pw = fminf(fmaxf(x[c >> 1] + ((c & 1u) ? -eps : eps), -bound), bound);      // n2m_sdf_offsets' own expression
-            p01[c] = (pw + bound) / (2.0f * bound);
+        for (uint32_t a = 0; a < 3; ++a) {
+            x[a] = xyz[3 * (size_t)m + a];
+            // the centre as the table backward maps it (x * in_scale + in_offset == (x + bound) / (2 bound) for the power-of-two bounds it accepts)
+            c01[a] = (x[a] + bound) / (2.0f * bound);
         }
-        const bool centre_in = !outside_unit_cube<3>(c01) && fabsf(x[0]) <= bound && fabsf(x[1]) <= bound && fabsf(x[2]) <= bound;
-        fl = centre_in ? 63u : 0u;
-        const float half = align_corners ? 0.0f : 0.5f;
-        for (uint32_t l = 0; l < max_level && fl != 0u; ++l) {
-            const float scale = lv.scale[l];
-#pragma unroll
-            for (uint32_t c = 0; c < 6; ++c)
-                if (floorf(p01[c] * scale + half) != floorf(c01[c >> 1] * scale + half)) fl &= ~(1u << c);
-        }
-        flags[m] = (uint8_t)fl;
-        n_left = 6u - (uint32_t)__builtin_popcount(fl);
+        centre_in = !outside_unit_cube<3>(c01) && fabsf(x[0]) <= bound && fabsf(x[1]) <= bound && fabsf(x[2]) <= bound;
     }
-    // compact list of the other copies (order: by wave arrival -- the sums they feed are order-free fixed point or float atomics anyway)
-    const uint32_t incl = n2m_wave_scan_add_u32(n_left, 0);
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    uint32_t base = 0u;
-    if (lane == 63u && total != 0u) base = atomicAdd(counters + parity, total);
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
-    if (m >= M) return;
-    uint32_t j = base + incl - n_left;
-    const float x[3] = {xyz[3 * (size_t)m], xyz[3 * (size_t)m + 1], xyz[3 * (size_t)m + 2]};
 #pragma unroll
     for (uint32_t c = 0; c < 6; ++c) {
-        if ((fl >> c) & 1u) continue;
+        const float pw = fminf(fmaxf(x[c >> 1] + ((c & 1u) ? -eps : eps), -bound), bound);      // n2m_sdf_offsets' own expression
+        p01[c] = (pw + bound) / (2.0f * bound);
+    }
+    const float half = align_corners ? 0.0f : 0.5f;
+    for (uint32_t l = 0; l < max_level; ++l) {
+        const float scale = lv.scale[l];
+        uint32_t fl = 0u;
+        if (centre_in) {
 #pragma unroll
-        for (uint32_t a = 0; a < 3; ++a)      // the other axes: n2m_sdf_offsets clamps them too
-            left_pts01[(size_t)j * 3u + a] = a == (c >> 1) ? p01[c] : (fminf(fmaxf(x[a] + 0.0f, -bound), bound) + bound) / (2.0f * bound);
-        left_src[j] = m * 6u + c;
-        ++j;
+            for (uint32_t c = 0; c < 6; ++c)
+                if (floorf(p01[c] * scale + half) == floorf(c01[c >> 1] * scale + half)) fl |= 1u << c;
+        }
+        const uint32_t n_left = m < M ? 6u - (uint32_t)__builtin_popcount(fl) : 0u;
+        if (m < M) flags[(size_t)l * M + m] = (uint8_t)fl;
+        // this level's list of the other copies (order: by workgroup arrival -- the sums they feed are order-free fixed point or float atomics)
+        const uint32_t incl = n2m_wave_scan_add_u32(n_left, 0);
+        if (lane == 63u) wave_tot[wid] = incl;
+        __syncthreads();
+        if (tid == 0u) {
+            uint32_t run = 0u;
+            for (uint32_t w = 0; w < 16u; ++w) { wave_base[w] = run; run += wave_tot[w]; }
+            const uint32_t base = run != 0u ? atomicAdd(counters + parity * kMaxLevels + l, run) : 0u;
+            for (uint32_t w = 0; w < 16u; ++w) wave_base[w] += base;
+        }
+        __syncthreads();
+        uint32_t j = wave_base[wid] + incl - n_left;
+        if (m < M) {
+#pragma unroll
+            for (uint32_t c = 0; c < 6; ++c) {
+                if ((fl >> c) & 1u) continue;
+                float* dst = left_pts01 + ((size_t)l * cap + j) * 3u;
+#pragma unroll
+                for (uint32_t a = 0; a < 3; ++a)      // the other axes: n2m_sdf_offsets clamps them too
+                    dst[a] = a == (c >> 1) ? p01[c] : (fminf(fmaxf(x[a] + 0.0f, -bound), bound) + bound) / (2.0f * bound);
+                left_src[(size_t)l * cap + j] = m * 6u + c;
+                ++j;
+            }
+        }
+        __syncthreads();
     }
 }
 
+// columns of the listed copies, and the lists padded to a common length B with points outside the unit cube (the fill drops those)
 __global__ void __launch_bounds__(256)
-sdf_fold_gather_kernel(const float* __restrict__ grad6, uint32_t stride6, const uint32_t* __restrict__ left_src, const uint32_t* __restrict__ counter,
-                       float* __restrict__ out) {
-    const uint32_t K = *counter, j = blockIdx.x * 256u + threadIdx.x, l = blockIdx.y;
-    if (j >= K) return;
-    out[(size_t)l * K + j] = grad6[(size_t)l * stride6 + left_src[j]];
+sdf_fold_gather_kernel(const float* __restrict__ grad6, uint32_t stride6, const uint32_t* __restrict__ left_src, float* __restrict__ left_pts01,
+                       uint32_t cap, const uint32_t* __restrict__ counters, uint32_t B, float* __restrict__ out) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x, l = blockIdx.y;
+    if (j >= B) return;
+    const uint32_t K = counters[l];
+    if (j < K) out[(size_t)l * B + j] = grad6[(size_t)l * stride6 + left_src[(size_t)l * cap + j]];
+    else {
+        out[(size_t)l * B + j] = 0.0f;
+        float* dst = left_pts01 + ((size_t)l * cap + j) * 3u;
+        dst[0] = dst[1] = dst[2] = 2.0f;
+    }
 }
 }  // namespace
 
 extern "C" int n2m_sdf_fold_plan(const float* xyz, uint32_t M, float eps, float bound, uint32_t L, uint32_t max_level, float S, uint32_t H,
-                                 int align_corners, uint8_t* flags, float* left_pts01, uint32_t* left_src, uint32_t* counters, uint32_t parity,
-                                 void* stream) {
+                                 int align_corners, uint8_t* flags, float* left_pts01, uint32_t* left_src, uint32_t cap, uint32_t* counters,
+                                 uint32_t parity, void* stream) {
     const char* fn = "sdf_fold_plan";
     N2M_REQUIRE(xyz && flags && left_pts01 && left_src && counters, N2M_ENULL, "%s: NULL tensor", fn);
-    N2M_REQUIRE(L >= 1 && L <= kMaxLevels && max_level <= L && parity <= 1u && eps > 0.0f && bound > 0.0f, N2M_EINVAL, "%s: bad arguments", fn);
+    N2M_REQUIRE(L >= 1 && L <= kMaxLevels && max_level <= L && parity <= 1u && eps > 0.0f && bound > 0.0f && (uint64_t)cap >= 6ull * M, N2M_EINVAL,
+                "%s: bad arguments (cap must hold all 6 M copies)", fn);
     if (M == 0) return 0;
-    sdf_fold_plan_kernel<<<n2m_ceil_div(M, 256), 256, 0, (hipStream_t)stream>>>(xyz, M, eps, bound, max_level, make_levels(L, S, H), align_corners != 0,
-                                                                               flags, left_pts01, left_src, counters, parity);
+    sdf_fold_plan_kernel<<<n2m_ceil_div(M, 1024), 1024, 0, (hipStream_t)stream>>>(xyz, M, eps, bound, max_level, make_levels(L, S, H), align_corners != 0,
+                                                                                 flags, left_pts01, left_src, cap, counters, parity);
     N2M_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int n2m_sdf_fold_gather(const float* grad6, uint32_t M, uint32_t levels, const uint32_t* left_src, const uint32_t* counter, float* out,
-                                   void* stream) {
-    N2M_REQUIRE(grad6 && left_src && counter && out, N2M_ENULL, "sdf_fold_gather: NULL tensor");
-    if (M == 0 || levels == 0) return 0;
-    sdf_fold_gather_kernel<<<dim3(n2m_ceil_div(6u * M, 256), levels), 256, 0, (hipStream_t)stream>>>(grad6, 6u * M, left_src, counter, out);
+extern "C" int n2m_sdf_fold_gather(const float* grad6, uint32_t M, uint32_t levels, const uint32_t* left_src, float* left_pts01, uint32_t cap,
+                                   const uint32_t* counters, uint32_t B, float* out, void* stream) {
+    N2M_REQUIRE(grad6 && left_src && left_pts01 && counters && out, N2M_ENULL, "sdf_fold_gather: NULL tensor");
+    N2M_REQUIRE(B <= cap, N2M_EINVAL, "sdf_fold_gather: B %u exceeds the lists' capacity %u", B, cap);
+    if (M == 0 || levels == 0 || B == 0) return 0;
+    sdf_fold_gather_kernel<<<dim3(n2m_ceil_div(B, 256), levels), 256, 0, (hipStream_t)stream>>>(grad6, 6u * M, left_src, left_pts01, cap, counters, B, out);
     N2M_CHECK_LAUNCH();
     return 0;
+}
+
+// density table alone, every level with its OWN point list (inputs [L, level_stride, 3], grad1 [L, B]; points outside the unit cube pad a list)
+extern "C" int n2m_grid_encode_backward_binned_lists(const float* grad1, const float* inputs, uint32_t level_stride, const int32_t* host_offsets,
+                                                     float* grad_embeddings1, uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                                     uint32_t gridtype, int align_corners, uint32_t interp, float* found_inf, int overwrite,
+                                                     void* workspace, uint64_t workspace_bytes, void* stream) {
+    N2M_REQUIRE(grad1 && level_stride >= B && level_stride > 0, N2M_EINVAL, "grid_encode_backward_binned_lists: needs the gradient and level_stride >= B");
+    return binned_pair_entry(grad1, nullptr, inputs, host_offsets, grad_embeddings1, nullptr, B, L, max_level, S, H, gridtype, align_corners, interp,
+                             nullptr, 0.0f, 0.0f, 1.0f, nullptr, found_inf, 1.0f, 0.0f, overwrite, workspace, workspace_bytes, stream, 0, nullptr, nullptr,
+                             nullptr, nullptr, level_stride * 3u);
 }
 
 extern "C" int n2m_grid_encode_backward_binned_pair_fold(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,

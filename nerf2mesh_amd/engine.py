@@ -774,10 +774,9 @@ class Stage0Engine:
                          "alpha": f(cap), "d_sdf": f(cap), "x01": f(3 * cap), "eik": f((cap + 255) // 256 + 1), "varp": f((cap + 255) // 256 + 1),
                          "d_var": old["d_var"] if old is not None else torch.zeros(1, dtype=torch.float32, device=dev),      # (the Adam descriptor holds its address)
                          # folded copies (n2m_sdf_fold_*): per-sample flags, the compact list of the copies that keep the stacked pass
-                         "flags": torch.empty(cap, dtype=torch.uint8, device=dev), "left_pts": f(18 * cap),
-                         "left_src": torch.empty(6 * cap, dtype=torch.int32, device=dev), "left_g": f(16 * 6 * cap),
-                         "fold_cnt": old["fold_cnt"] if old is not None else torch.zeros(2, dtype=torch.int32, device=dev),
-                         "fold_host": old["fold_host"] if old is not None else torch.zeros(1, dtype=torch.int32).pin_memory()}
+                         "fold_cnt": old["fold_cnt"] if old is not None else torch.zeros(2, 32, dtype=torch.int32, device=dev),
+                         "fold_host": old["fold_host"] if old is not None else torch.zeros(32, dtype=torch.int32).pin_memory()}
+            self._sdf.pop("fold", None)
             self._sdf_cap = cap
         return self._sdf
 
@@ -814,16 +813,22 @@ class Stage0Engine:
             # finite-difference normals: six offset copies, one encode + one sigma_net evaluation for all of them
             L.call("n2m_sdf_offsets", _p(xyzs), M, eps, float(model.bound), _p(sb["pts"]), _p(sb["pts01"]), s)
             # Table backward of the copies: once epsilon is a fraction of the finest active cell, a copy nearly always lies in its centre
-            # sample's cell on every level -- those fold into the batch's own backward (n2m_grid_encode_backward_binned_pair_fold), the others
-            # (~30 % at the end of the schedule) take the stacked pass as a compact list whose length the host reads back (it is known long
-            # before the backward is enqueued: the plan only needs the samples)
+            # sample's cell on a given level -- those (copy, level) pairs fold into the batch's own backward
+            # (n2m_grid_encode_backward_binned_pair_fold), the others (2.4 % at the end of the schedule) take a density-only call over
+            # per-level lists whose lengths the host reads back (known long before the backward is enqueued: the plan only needs the samples)
             finest = self.H0 * 2.0 ** (self.S * (ml - 1))
             fold = self.sdf_fold and eps / (2.0 * float(model.bound)) * finest < 0.25
             if fold:
+                if "fold" not in sb:      # buffers of the fold, only once it is used: per-level flags and lists (capacity: every copy)
+                    c6 = 6 * self._sdf_cap
+                    sb["fold"] = {"cap": c6, "flags": torch.empty(16 * self._sdf_cap, dtype=torch.uint8, device=dev),
+                                  "pts": torch.empty(16 * c6 * 3, dtype=torch.float32, device=dev),
+                                  "src": torch.empty(16 * c6, dtype=torch.int32, device=dev), "g": torch.empty(16 * c6, dtype=torch.float32, device=dev)}
+                fb = sb["fold"]
                 par = self.global_step & 1
                 L.call("n2m_sdf_fold_plan", _p(xyzs), M, eps, float(model.bound), self.Lv, ml, self.S, self.H0, int(bool(e1.align_corners)),
-                       _p(sb["flags"]), _p(sb["left_pts"]), _p(sb["left_src"]), _p(sb["fold_cnt"]), par, s)
-                sb["fold_host"].copy_(sb["fold_cnt"][par:par + 1], non_blocking=True)
+                       _p(fb["flags"]), _p(fb["pts"]), _p(fb["src"]), fb["cap"], _p(sb["fold_cnt"]), par, s)
+                sb["fold_host"].copy_(sb["fold_cnt"][par], non_blocking=True)
                 fold_ready = torch.cuda.Event()
                 fold_ready.record()
             L.call("n2m_grid_encode_forward", _p(sb["pts01"]), _p(e1.embeddings), _p(e1.offsets), _p(sb["h6"]), M6, 3, 1, self.Lv, ml, self.S, self.H0,
@@ -856,18 +861,19 @@ class Stage0Engine:
                           _p(e1.embeddings) if tv_fold else None, tv_w, tv_wo, float(0.5 / model.bound), _p(seed) if tv_fold else None, _p(o.found_inf),
                           float(self.aff[0]), float(self.aff[1]), 1, _p(ws), ws.numel())
             if fold:
-                L.call("n2m_sdf_fold_gather", _p(sb["d_h6"]), M, ml, _p(sb["left_src"]), sb["fold_cnt"].data_ptr() + 4 * par, _p(sb["left_g"]), s)
-                L.call("n2m_grid_encode_backward_binned_pair_fold", *batch_args, _p(sb["flags"]), _p(sb["d_h6"]), eps, float(model.bound), s)
                 t0 = time.perf_counter()
                 while not fold_ready.query():
                     if time.perf_counter() - t0 > 5e-3:
                         fold_ready.synchronize()
                         break
-                K = int(sb["fold_host"][0])
-                self.last_fold_left = K
+                K = int(sb["fold_host"][:ml].max())
+                self.last_fold_left = int(sb["fold_host"][:ml].sum())
+                L.call("n2m_grid_encode_backward_binned_pair_fold", *batch_args, _p(fb["flags"]), _p(sb["d_h6"]), eps, float(model.bound), s)
                 if K > 0:
-                    L.call("n2m_grid_encode_backward_binned_pair", _p(sb["left_g"]), None, _p(sb["left_pts"]), self.ho.ctypes.data, _p(self.g1), None, K,
-                           *geo, None, 0.0, 0.0, 1.0, None, _p(o.found_inf), 1.0, 0.0, 0, _p(ws), ws.numel(), s)
+                    L.call("n2m_sdf_fold_gather", _p(sb["d_h6"]), M, ml, _p(fb["src"]), _p(fb["pts"]), fb["cap"],
+                           sb["fold_cnt"].data_ptr() + 128 * par, K, _p(fb["g"]), s)
+                    L.call("n2m_grid_encode_backward_binned_lists", _p(fb["g"]), _p(fb["pts"]), fb["cap"], self.ho.ctypes.data, _p(self.g1), K, self.Lv, ml,
+                           self.S, self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, _p(o.found_inf), 0, _p(ws), ws.numel(), s)
             else:
                 L.call("n2m_grid_encode_backward_binned_pair", *batch_args, s)
                 L.call("n2m_grid_encode_backward_binned_pair", _p(sb["d_h6"]), None, _p(sb["pts01"]), self.ho.ctypes.data, _p(self.g1), None, M6, *geo,

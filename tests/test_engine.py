@@ -98,7 +98,7 @@ def test_engine_runs_the_sdf_recipe_like_the_trainer(iters, steps):
     b, lb = _run(Stage0Engine, steps, **cfg)
     assert a.model.max_level == b.model.max_level == {30000: 4, 120: 10, 40: 16}[iters]
     if iters == 40:     # the end of the schedule runs with the finite-difference copies folded into the batch's table backward
-        assert 0 < b.last_fold_left < 0.6 * 6 * b.last_num_points
+        assert 0 < b.last_fold_left < 0.1 * 16 * 6 * b.last_num_points            # (copy, level) pairs that keep the lists call
     elif iters == 30000:
         assert not hasattr(b, "last_fold_left"), "epsilon 0.1 spans many cells: the stacked pass stays"
     assert a.samples_seen == b.samples_seen and a.rays_seen == b.rays_seen, "same batches, same sample counts"

@@ -1308,37 +1308,57 @@ def test_sdf_copies_folded_into_the_batch_backward_equal_the_stacked_pass(be, ep
     only_batch = a1.clone()
     copies(d6, pts01, 6 * M, a1)
     # ---- folded
-    flags = torch.empty(M, dtype=torch.uint8, device="cuda")
-    left_pts = torch.empty(6 * M, 3, device="cuda"); left_src = torch.empty(6 * M, dtype=torch.int32, device="cuda")
-    left_g = torch.empty(16 * 6 * M, device="cuda")
-    cnt = torch.tensor([0, 12345], dtype=torch.int32, device="cuda")
-    L.call("n2m_sdf_fold_plan", p(xyz), M, eps, bound, 16, max_level, S, H0, int(bool(e1.align_corners)), p(flags), p(left_pts), p(left_src), p(cnt), 0,
+    cap = 6 * M
+    flags = torch.zeros(16, M, dtype=torch.uint8, device="cuda")
+    left_pts = torch.empty(16, cap, 3, device="cuda"); left_src = torch.empty(16, cap, dtype=torch.int32, device="cuda")
+    left_g = torch.empty(16 * cap, device="cuda")
+    cnt = torch.zeros(2, 32, dtype=torch.int32, device="cuda")
+    cnt[1] = 12345
+    L.call("n2m_sdf_fold_plan", p(xyz), M, eps, bound, 16, max_level, S, H0, int(bool(e1.align_corners)), p(flags), p(left_pts), p(left_src), cap, p(cnt), 0,
            L.stream())
-    K = int(cnt[0])
-    assert int(cnt[1]) == 0, "the other parity's counter is cleared"
-    # (the level scales come from the library's own table through the plan; here the folded RESULT is what pins them -- a wrong flag puts a
-    # copy's weight on the wrong rows and the comparison with the stacked pass below fails)
-    fl = flags.int()
-    n_left = 6 * M - int(sum(((fl >> c) & 1).sum() for c in range(6)))
-    assert K == n_left
-    src = left_src[:K].long()
-    assert torch.equal(torch.sort(src)[0], torch.sort(torch.nonzero(((fl.unsqueeze(1) >> torch.arange(6, device="cuda")) & 1).reshape(-1) == 0).reshape(-1))[0])
-    assert torch.equal(left_pts[:K], pts01.view(-1, 3)[src]), "the listed copies carry n2m_sdf_offsets' own coordinates"
-    if eps == 1e-4 and max_level == 16:
-        assert 0.5 < (6 * M - K) / (6 * M) < 0.85, "most copies of a 1e-4 offset share their centre's cell on all 16 levels"
-    L.call("n2m_sdf_fold_gather", p(d6), M, max_level, p(left_src), p(cnt), p(left_g), L.stream())
-    assert torch.equal(left_g[:max_level * K].view(max_level, K), d6[:max_level, src])
+    Ks = cnt[0, :max_level].cpu().numpy()
+    assert int(cnt[1].abs().sum()) == 0, "the other parity's counters are cleared"
+    # the cell test, in torch, with the library's level scales (exp2f(level * S) * H - 1 in fp32): copy c folds on level l iff
+    # floor(p01 * scale + 0.5) of its moved axis equals the centre's
+    c01 = (xyz + bound) / (2 * bound)
+    folded_pairs = 0
+    for l in range(max_level):
+        scale = float(np.float32(np.exp2(np.float32(l) * np.float32(S)) * np.float32(H0)) - np.float32(1.0))
+        cc = torch.floor(c01 * scale + 0.5)
+        same = torch.stack([torch.floor(pts01[:, c, c >> 1] * scale + 0.5) == cc[:, c >> 1] for c in range(6)], 1)      # [M,6]
+        want = (same.int() << torch.arange(6, device="cuda")).sum(1)
+        diff = (flags[l].int() != want)
+        assert float(diff.float().mean()) <= 1e-3, f"level {l}: flags differ from the torch statement on {int(diff.sum())} samples"      # (the scale may differ by an ulp of exp2f: cells right on a boundary)
+        fl = flags[l].int()
+        K = int(Ks[l])
+        assert K == 6 * M - int(sum(((fl >> c) & 1).sum() for c in range(6)))
+        folded_pairs += 6 * M - K
+        src = left_src[l, :K].long()
+        listed = torch.nonzero(((fl.unsqueeze(1) >> torch.arange(6, device="cuda")) & 1).reshape(-1) == 0).reshape(-1)
+        assert torch.equal(torch.sort(src)[0], listed)
+        assert torch.equal(left_pts[l, :K], pts01.view(-1, 3)[src]), "the listed copies carry n2m_sdf_offsets' own coordinates"
+    frac = folded_pairs / (6 * M * max_level)
+    if eps == 1e-4:
+        assert frac > 0.9, "nearly all (copy, level) pairs of a 1e-4 offset share their centre's cell"
+    B = int(Ks.max())
     b1 = torch.empty(rows, 1, device="cuda"); b2 = torch.empty(rows, 2, device="cuda", dtype=torch.float16)
     L.call("n2m_grid_encode_backward_binned_pair_fold", *batch_args(b1, b2), p(flags), p(d6), eps, bound, L.stream())
-    if K > 0:
-        copies(left_g, left_pts, K, b1)
+    if B > 0:
+        L.call("n2m_sdf_fold_gather", p(d6), M, max_level, p(left_src), p(left_pts), cap, p(cnt), B, p(left_g), L.stream())
+        for l in range(max_level):
+            K = int(Ks[l])
+            assert torch.equal(left_g[l * B:l * B + K], d6[l, left_src[l, :K].long()])
+            assert float(left_g[l * B + K:(l + 1) * B].abs().max() if K < B else 0.0) == 0.0 and bool((left_pts[l, K:B] == 2.0).all())
+        L.call("n2m_grid_encode_backward_binned_lists", p(left_g), p(left_pts), cap, ho.ctypes.data, p(b1), B, *geo, p(finf), 0, p(ws), ws.numel(),
+               L.stream())
     torch.cuda.synchronize()
+    K = 6 * M * max_level - folded_pairs
     hi = int(np.asarray(e1.host_offsets)[max_level])
     lo = int(np.asarray(e1.host_offsets)[min(8, max_level)])
     assert torch.equal(a2[lo:hi], b2[lo:hi]), "colour table: untouched by the copies (levels one work item owns: bit-equal)"
     d = (a1[:hi] - b1[:hi]).abs()
     ref = float(a1[:hi].abs().max())
-    print(f"eps {eps} max_level {max_level}: folded {6 * M - K} of {6 * M} copies; max |diff| {float(d.max()):.3g} of {ref:.3g}")
+    print(f"eps {eps} max_level {max_level}: folded {folded_pairs} of {6 * M * max_level} (copy, level) pairs; max |diff| {float(d.max()):.3g} of {ref:.3g}")
     offs_ = np.asarray(e1.host_offsets)
     for l in range(max_level):
         dl = d[int(offs_[l]):int(offs_[l + 1])]
