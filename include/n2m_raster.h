@@ -72,10 +72,13 @@ int n2m_antialias_backward(const float* color, const float* rast, const float* p
  *   out: image [h0 w0, 3], depth / weights_sum / trig_id (id - 1 as float, -1 = empty) / loss_px [h0 w0]; partial [ceil(h0 w0 / 256)] =
  *        per-workgroup sums of loss_px (mean = sum(partial) / (h0 w0), summed by the caller in index order)
  *   d_alpha [h0 s, w0 s], d_rgb [h0 s, w0 s, 3] (both or neither): gradient of mean(loss_px) w.r.t. aa_alpha / aa_rgb; the caller scales
- *        them by its incoming gradient (the loss scale). */
+ *        them by its incoming gradient (the loss scale).
+ *   tri_err, tri_cnt [faces] f32 (both or neither): `update_triangles_errors` (nerf/renderer.py:924-943) in the same pass -- loss_px added to
+ *        tri_err[trig_id], 1 to tri_cnt[trig_id] for every pixel that shows a face (float atomics, like torch's scatter_add_). */
 int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const float* rast, uint32_t h0, uint32_t w0, uint32_t ssaa,
                     const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask, float* image, float* depth,
-                    float* weights_sum, float* trig_id, float* loss_px, float* d_alpha, float* d_rgb, float* partial, void* stream);
+                    float* weights_sum, float* trig_id, float* loss_px, float* d_alpha, float* d_rgb, float* partial, float* tri_err,
+                    float* tri_cnt, void* stream);
 
 #ifdef __cplusplus
 }

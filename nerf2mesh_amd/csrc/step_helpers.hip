@@ -103,7 +103,8 @@ stage1_head_kernel(const float* __restrict__ aa_alpha /*[h0 S, w0 S]*/, const fl
                    const float* __restrict__ rast /*[h0 S, w0 S, 4]*/, uint32_t h0, uint32_t w0, const float* __restrict__ gt /*[h0 w0, 4]*/,
                    const float* __restrict__ bg /*[h0 w0, 3] or NULL*/, float bg_scalar, float lambda_rgb, float lambda_mask,
                    float* __restrict__ image, float* __restrict__ depth, float* __restrict__ wsum, float* __restrict__ trig_id,
-                   float* __restrict__ loss_px, float* __restrict__ d_alpha, float* __restrict__ d_rgb, float* __restrict__ partial) {
+                   float* __restrict__ loss_px, float* __restrict__ d_alpha, float* __restrict__ d_rgb, float* __restrict__ partial,
+                   float* __restrict__ tri_err, float* __restrict__ tri_cnt) {
     __shared__ float wave_sum[4];
     const uint32_t n = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t N = h0 * w0, w = w0 * S;
@@ -155,6 +156,10 @@ stage1_head_kernel(const float* __restrict__ aa_alpha /*[h0 S, w0 S]*/, const fl
         l = lambda_rgb * ((e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) / 3.0f) + lambda_mask * (m * m);
         depth[n] = dp; wsum[n] = ws; loss_px[n] = l;
         trig_id[n] = rast[((size_t)(y * S) * w + (size_t)(x * S)) * 4 + 3] - 1.0f;      // nearest: the block's first sub-pixel
+        if (tri_err) {      // update_triangles_errors (nerf/renderer.py:924-943): the pixel's loss onto the face visible at it
+            const float t = trig_id[n];
+            if (t >= 0.0f) { unsafeAtomicAdd(tri_err + (uint32_t)t, l); unsafeAtomicAdd(tri_cnt + (uint32_t)t, 1.0f); }
+        }
         if (d_alpha) {
             // d mean / d image_c, d mean / d weights_sum (seed 1 / N; the caller scales by the incoming gradient)
             const float inv = 1.0f / (float)N;
@@ -617,20 +622,21 @@ extern "C" int n2m_sdf_alpha_backward(const float* d_alpha, const float* sdf, co
 extern "C" int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const float* rast, uint32_t h0, uint32_t w0, uint32_t ssaa,
                                const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask, float* image,
                                float* depth, float* weights_sum, float* trig_id, float* loss_px, float* d_alpha, float* d_rgb, float* partial,
-                               void* stream) {
+                               float* tri_err, float* tri_cnt, void* stream) {
     N2M_REQUIRE(aa_alpha && aa_rgb && rast && gt_rgba && image && depth && weights_sum && trig_id && loss_px && partial, N2M_ENULL,
                 "stage1_head: NULL tensor");
     N2M_REQUIRE((d_alpha == nullptr) == (d_rgb == nullptr), N2M_ENULL, "stage1_head: d_alpha and d_rgb come together");
+    N2M_REQUIRE((tri_err == nullptr) == (tri_cnt == nullptr), N2M_ENULL, "stage1_head: tri_err and tri_cnt come together");
     N2M_REQUIRE(ssaa == 1 || ssaa == 2, N2M_EUNSUPPORTED, "stage1_head: ssaa 1 or 2 (the reduction is the exact 2 x 2 mean of torch's bilinear minification)");
     N2M_REQUIRE(h0 > 0 && w0 > 0 && (uint64_t)h0 * w0 < (1ull << 31), N2M_EINVAL, "stage1_head: bad image size");
     hipStream_t s = (hipStream_t)stream;
     const uint32_t N = h0 * w0;
     if (ssaa == 1)
         stage1_head_kernel<1><<<n2m_ceil_div(N, 256), 256, 0, s>>>(aa_alpha, aa_rgb, rast, h0, w0, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask,
-                                                                  image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial);
+                                                                  image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial, tri_err, tri_cnt);
     else
         stage1_head_kernel<2><<<n2m_ceil_div(N, 256), 256, 0, s>>>(aa_alpha, aa_rgb, rast, h0, w0, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask,
-                                                                  image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial);
+                                                                  image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial, tri_err, tri_cnt);
     N2M_CHECK_LAUNCH();
     return 0;
 }

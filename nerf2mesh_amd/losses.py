@@ -57,7 +57,7 @@ class _stage1_head(Function):
     scaled by the incoming gradient in backward."""
 
     @staticmethod
-    def forward(ctx, aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb, lambda_mask):
+    def forward(ctx, aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb, lambda_mask, tri_err=None, tri_cnt=None):
         dev = aa_alpha.device
         aa_alpha, aa_rgb, rast = aa_alpha.float().contiguous(), aa_rgb.float().contiguous(), rast.float().contiguous()
         gt_rgba = gt_rgba.float().contiguous()
@@ -69,7 +69,8 @@ class _stage1_head(Function):
         need = any(ctx.needs_input_grad[:2])
         d_alpha, d_rgb = (torch.empty_like(aa_alpha), torch.empty_like(aa_rgb)) if need else (None, None)
         L.call("n2m_stage1_head", _p(aa_alpha), _p(aa_rgb), _p(rast), int(h0), int(w0), int(ssaa), _p(gt_rgba), _p(bg_t), bg_s, float(lambda_rgb),
-               float(lambda_mask), _p(image), _p(depth), _p(ws), _p(trig), _p(loss_px), _p(d_alpha), _p(d_rgb), _p(partial), L.stream())
+               float(lambda_mask), _p(image), _p(depth), _p(ws), _p(trig), _p(loss_px), _p(d_alpha), _p(d_rgb), _p(partial), _p(tri_err), _p(tri_cnt),
+               L.stream())
         ctx.grads = (d_alpha, d_rgb)
         loss = partial.sum() / N
         ctx.mark_non_differentiable(image, depth, ws, trig, loss_px)
@@ -79,10 +80,11 @@ class _stage1_head(Function):
     def backward(ctx, g, *unused):
         d_alpha, d_rgb = ctx.grads
         ctx.grads = None
-        return d_alpha * g, d_rgb * g, None, None, None, None, None, None, None, None
+        return d_alpha * g, d_rgb * g, None, None, None, None, None, None, None, None, None, None
 
 
-def stage1_head(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb=1.0, lambda_mask=0.0):
+def stage1_head(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb=1.0, lambda_mask=0.0, tri_err=None, tri_cnt=None):
     """(loss, image [N,3], depth [N], weights_sum [N], trig_id [N] float, loss_px [N]) of one stage-1 view from the two antialias outputs
-    (before their clamp) and the rasteriser's image: nerf/renderer.py:886-913 + the loss of nerf/utils.py:708-721, N = h0 * w0."""
-    return _stage1_head.apply(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb, lambda_mask)
+    (before their clamp) and the rasteriser's image: nerf/renderer.py:886-913 + the loss of nerf/utils.py:708-721, N = h0 * w0.
+    tri_err / tri_cnt [faces] f32: `update_triangles_errors` (nerf/renderer.py:924-943) done by the same launch."""
+    return _stage1_head.apply(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb, lambda_mask, tri_err, tri_cnt)

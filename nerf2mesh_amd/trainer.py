@@ -450,11 +450,9 @@ class Stage1Trainer:
             # mean) and its backward in ONE launch (losses.stage1_head) instead of ~40 full-image elementwise / resize launches
             from .losses import stage1_head
             rast, aa_alpha, aa_rgb = model._stage1_front(rays_d, self.mvps[v], self.H, self.W, shading)
+            te = (model.triangles_errors, model.triangles_errors_cnt) if opt.refine else (None, None)      # update_triangles_errors rides along
             loss, _, _, _, trig, loss_px = stage1_head(aa_alpha, aa_rgb, rast, rgba, bg, self.H, self.W, int(opt.ssaa), opt.lambda_rgb,
-                                                       max(opt.lambda_mask, 0.0))
-            if opt.refine:
-                model.triangles_errors_id = trig.view(self.H, self.W)
-                model.update_triangles_errors(loss_px)
+                                                       max(opt.lambda_mask, 0.0), *te)
         else:
             gt_mask = rgba[:, 3:]
             gt_rgb = rgba[:, :3] * gt_mask + bg * (1 - gt_mask)

@@ -92,6 +92,15 @@ def test_fused_image_head_equals_the_torch_graph(ssaa):
     assert close(lp2, loss_px.detach(), 2e-6) and abs(float(l2) - float(loss)) <= 2e-6 * float(loss)
     assert close(aa_alpha.grad, ga, 2e-6) and close(aa_rgb.grad, gr, 2e-6)
     assert float((aa_alpha.grad == 0).float().mean()) > 0.1, "the clamp masks were not exercised"
+    # update_triangles_errors (nerf/renderer.py:924-943) in the same launch: per-face sums of the pixel loss and pixel counts
+    n_faces = 50
+    err, cnt = torch.full((n_faces,), 0.5, device=dev), torch.full((n_faces,), 2.0, device=dev)
+    stage1_head(aa_alpha.detach(), aa_rgb.detach(), rast, gt, bg, h0, w0, ssaa, lam_rgb, lam_mask, err, cnt)
+    ids = trig.reshape(-1).long()
+    keep = ids >= 0
+    want_err = torch.full((n_faces,), 0.5, device=dev).scatter_add_(0, ids[keep], loss_px.detach()[keep])
+    want_cnt = torch.full((n_faces,), 2.0, device=dev).scatter_add_(0, ids[keep], torch.ones_like(loss_px.detach()[keep]))
+    assert torch.equal(cnt, want_cnt) and close(err, want_err, 1e-5)
 
 
 def test_stage1_step_with_and_without_the_fused_head():
