@@ -568,19 +568,25 @@ class NeRFRenderer(nn.Module):
         export.write_mlp_json(os.path.join(path, "mlp.json"), self)
         return out
 
-    def _stage1_front(self, rays_d, mvp, h0, w0, shading="full"):
-        """Everything of render_stage1 up to and including the two antialias calls (nerf/renderer.py:816-887): returns
-        (rast [1,h,w,4], alpha [1,h,w,1] and rgb [1,h,w,3] as antialias hands them out, BEFORE the clamp)."""
+    def stage1_dirs(self, rays_d, h0, w0):
+        """Unit view directions per rendered pixel (nerf/renderer.py:821-828: nearest upscale to the ssaa resolution, safe_normalize): a
+        function of the view alone, so a trainer that keeps its views resident may keep this too (Stage1Trainer does)."""
         rays_d = rays_d.contiguous().view(-1, 3)
-        device = rays_d.device
         ssaa = int(self.opt.ssaa)
         if ssaa > 1:
             h, w = int(h0 * ssaa), int(w0 * ssaa)
-            dirs = F.interpolate(rays_d.view(1, h0, w0, 3).permute(0, 3, 1, 2), (h, w), mode="nearest").permute(0, 2, 3, 1).reshape(-1, 3).contiguous()
-        else:
-            h, w = h0, w0
-            dirs = rays_d
-        dirs = safe_normalize(dirs)
+            rays_d = F.interpolate(rays_d.view(1, h0, w0, 3).permute(0, 3, 1, 2), (h, w), mode="nearest").permute(0, 2, 3, 1).reshape(-1, 3).contiguous()
+        return safe_normalize(rays_d)
+
+    def _stage1_front(self, rays_d, mvp, h0, w0, shading="full", dirs=None):
+        """Everything of render_stage1 up to and including the two antialias calls (nerf/renderer.py:816-887): returns
+        (rast [1,h,w,4], alpha [1,h,w,1] and rgb [1,h,w,3] as antialias hands them out, BEFORE the clamp).  dirs: stage1_dirs(rays_d, h0, w0)
+        when the caller has it already."""
+        device = rays_d.device
+        ssaa = int(self.opt.ssaa)
+        h, w = (int(h0 * ssaa), int(w0 * ssaa)) if ssaa > 1 else (h0, w0)
+        if dirs is None:
+            dirs = self.stage1_dirs(rays_d, h0, w0)
         vertices = self.vertices + self.vertices_offsets
         vertices_clip = to_clip(vertices, mvp).unsqueeze(0)
         rast, _ = dr.rasterize(self.glctx, vertices_clip, self.triangles, (h, w))

@@ -421,6 +421,7 @@ class Stage1Trainer:
         self.pix = (jj * W + ii).reshape(-1)
         self.laplacian = UniformLaplacian(model.triangles, model.vertices.shape[0])
         self.view_cache = {}          # per view: rays + ground-truth RGBA, resident in HBM like the reference's --preload
+        self._dirs = {}               # per view: unit directions at the ssaa resolution (30 MB per 800 x 800 view at ssaa 2)
         self.covered_seen = 0         # shaded (covered) full-resolution pixels so far: the unit of the stage-1 byte model
         self.fused_head = torch.device(device).type == "cuda" and int(opt.ssaa) in (1, 2)      # losses.stage1_head (False: the torch graph)
 
@@ -433,7 +434,9 @@ class Stage1Trainer:
     def preload(self):
         """Rays + ground truth of every view of this rank resident on the device before training (the reference's --preload)."""
         for v in self.views:
-            self._view(v)
+            rays_d = self._view(v)[1]
+            if self.fused_head and v not in self._dirs:
+                self._dirs[v] = self.model.stage1_dirs(rays_d, self.H, self.W).detach()
 
     def train_step(self):
         opt, model = self.opt, self.model
@@ -449,7 +452,10 @@ class Stage1Trainer:
             # everything behind the two antialias calls (clamp, alpha * rgb, depth, T, ssaa reduction, background blend, per-pixel loss,
             # mean) and its backward in ONE launch (losses.stage1_head) instead of ~40 full-image elementwise / resize launches
             from .losses import stage1_head
-            rast, aa_alpha, aa_rgb = model._stage1_front(rays_d, self.mvps[v], self.H, self.W, shading)
+            dirs = self._dirs.get(v)
+            if dirs is None:              # unit directions at the rendered resolution: per view, resident like the rays they come from
+                dirs = self._dirs[v] = model.stage1_dirs(rays_d, self.H, self.W).detach()
+            rast, aa_alpha, aa_rgb = model._stage1_front(rays_d, self.mvps[v], self.H, self.W, shading, dirs=dirs)
             te = (model.triangles_errors, model.triangles_errors_cnt) if opt.refine else (None, None)      # update_triangles_errors rides along
             loss, _, _, _, trig, loss_px = stage1_head(aa_alpha, aa_rgb, rast, rgba, bg, self.H, self.W, int(opt.ssaa), opt.lambda_rgb,
                                                        max(opt.lambda_mask, 0.0), *te)
