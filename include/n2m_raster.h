@@ -63,6 +63,12 @@ int n2m_antialias_backward(const float* color, const float* rast, const float* p
                            uint32_t H, uint32_t W, float pos_gradient_boost, float* grad_color, float* grad_pos,
                            void* stream);
 
+/* Rows of a [N, C] fp32 array by index -- the boolean-mask gather / scatter around the shading of a stage-1 frame (nerf/renderer.py:864,
+ * 875-881: `xyzs[mask]`, `rgbs[mask] = ...`) once the covered pixels are an index list: out[k, :] = x[idx[k], :] and dst[idx[k], :] = src[k, :]
+ * (idx int64 [K], unique for the scatter; rows of dst that are not listed keep their value). */
+int n2m_gather_rows(const float* x, const int64_t* idx, uint32_t K, uint32_t C, float* out, void* stream);
+int n2m_scatter_rows(const float* src, const int64_t* idx, uint32_t K, uint32_t C, float* dst, void* stream);
+
 /* Stage-1 image head, forward AND backward in one launch: what nerf/renderer.py:886-913 does with the two antialias outputs (clamp,
  * image = alpha * rgb, depth = alpha * z/w, T = 1 - alpha, ssaa reduction by `scale_img_hwc` = bilinear minification (exactly the 2 x 2
  * mean for ssaa 2) and nearest for the triangle id, image + T * bg, weights_sum = 1 - T) plus the per-pixel loss of nerf/utils.py:708-721

@@ -619,6 +619,36 @@ extern "C" int n2m_sdf_alpha_backward(const float* d_alpha, const float* sdf, co
     return 0;
 }
 
+// rows of a [N, C] fp32 array by index (stage 1: the covered pixels of a frame, nerf/renderer.py:864-881): out[k] = x[idx[k]] and its mirror
+// dst[idx[k]] = src[k] (idx unique: no atomics).  torch's index kernels spend 50 us per call on 0.7 M rows of three floats.
+template <bool SCATTER>
+__global__ void __launch_bounds__(256)
+rows_by_index_kernel(const float* __restrict__ in, const int64_t* __restrict__ idx, uint32_t K, uint32_t C, float* __restrict__ out) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= K) return;
+    const size_t r = (size_t)idx[k];
+    const float* src = in + (SCATTER ? (size_t)k : r) * C;
+    float* dst = out + (SCATTER ? r : (size_t)k) * C;
+    if (C == 3u) { const float a = src[0], b = src[1], c = src[2]; dst[0] = a; dst[1] = b; dst[2] = c; }
+    else for (uint32_t c = 0; c < C; ++c) dst[c] = src[c];
+}
+
+extern "C" int n2m_gather_rows(const float* x, const int64_t* idx, uint32_t K, uint32_t C, float* out, void* stream) {
+    N2M_REQUIRE(x && idx && out && C >= 1, N2M_ENULL, "gather_rows: NULL tensor");
+    if (K == 0) return 0;
+    rows_by_index_kernel<false><<<n2m_ceil_div(K, 256), 256, 0, (hipStream_t)stream>>>(x, idx, K, C, out);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_scatter_rows(const float* src, const int64_t* idx, uint32_t K, uint32_t C, float* dst, void* stream) {
+    N2M_REQUIRE(src && idx && dst && C >= 1, N2M_ENULL, "scatter_rows: NULL tensor");
+    if (K == 0) return 0;
+    rows_by_index_kernel<true><<<n2m_ceil_div(K, 256), 256, 0, (hipStream_t)stream>>>(src, idx, K, C, dst);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const float* rast, uint32_t h0, uint32_t w0, uint32_t ssaa,
                                const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask, float* image,
                                float* depth, float* weights_sum, float* trig_id, float* loss_px, float* d_alpha, float* d_rgb, float* partial,

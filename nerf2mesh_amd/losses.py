@@ -88,3 +88,54 @@ def stage1_head(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb=1.
     (before their clamp) and the rasteriser's image: nerf/renderer.py:886-913 + the loss of nerf/utils.py:708-721, N = h0 * w0.
     tri_err / tri_cnt [faces] f32: `update_triangles_errors` (nerf/renderer.py:924-943) done by the same launch."""
     return _stage1_head.apply(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb, lambda_mask, tri_err, tri_cnt)
+
+
+class _gather_rows(Function):
+    """x[idx] for a [N, C] fp32 array and an int64 index list (n2m_gather_rows); backward scatters into zeros (idx unique)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        x = x.float().contiguous()
+        out = torch.empty(idx.shape[0], x.shape[1], dtype=torch.float32, device=x.device)
+        L.call("n2m_gather_rows", _p(x), _p(idx), idx.shape[0], x.shape[1], _p(out), L.stream())
+        ctx.save_for_backward(idx)
+        ctx.n = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        g = g.float().contiguous()
+        d = torch.zeros(ctx.n, g.shape[1], dtype=torch.float32, device=g.device)
+        L.call("n2m_scatter_rows", _p(g), _p(idx), idx.shape[0], g.shape[1], _p(d), L.stream())
+        return d, None
+
+
+class _scatter_rows(Function):
+    """zeros(N, C) with rows idx set to src (n2m_scatter_rows; idx unique); backward gathers."""
+
+    @staticmethod
+    def forward(ctx, src, idx, n):
+        src = src.float().contiguous()
+        out = torch.zeros(n, src.shape[1], dtype=torch.float32, device=src.device)
+        L.call("n2m_scatter_rows", _p(src), _p(idx), idx.shape[0], src.shape[1], _p(out), L.stream())
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        g = g.float().contiguous()
+        d = torch.empty(idx.shape[0], g.shape[1], dtype=torch.float32, device=g.device)
+        L.call("n2m_gather_rows", _p(g), _p(idx), idx.shape[0], g.shape[1], _p(d), L.stream())
+        return d, None, None
+
+
+def gather_rows(x, idx):
+    """x[idx] ([N, C] fp32, idx int64 [K]) -- the covered pixels of a stage-1 frame (nerf/renderer.py:875-881)."""
+    return _gather_rows.apply(x, idx)
+
+
+def scatter_rows(src, idx, n):
+    """[n, C] zeros with rows idx (unique) set to src -- `rgbs[mask] = mask_rgbs` (nerf/renderer.py:881)."""
+    return _scatter_rows.apply(src, idx, n)

@@ -126,3 +126,29 @@ def test_stage1_step_with_and_without_the_fused_head():
     assert torch.equal(ca, cb) and float((ta - tb).abs().max()) <= 1e-5 * float(ta.abs().max())
     rel = lambda a, b: float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
     assert rel(va, vb) <= 1e-3 and rel(ea, eb) <= 1e-2          # (scaled fp16 path of the colour field: atomics order noise on top)
+
+
+def test_rows_by_index_kernels():
+    """n2m_gather_rows / n2m_scatter_rows (the boolean-mask gather / scatter around the stage-1 shading, nerf/renderer.py:875-881) against
+    torch indexing, forward and backward."""
+    import torch
+    from nerf2mesh_amd.losses import gather_rows, scatter_rows
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(2)
+    N = 100_003
+    mask = torch.rand(N, device=dev, generator=g) < 0.3
+    idx = torch.nonzero(mask).squeeze(1)
+    for C in (3, 1, 5):
+        x = torch.rand(N, C, device=dev, generator=g, requires_grad=True)
+        got = gather_rows(x, idx)
+        assert torch.equal(got, x.detach()[idx])
+        w = torch.rand_like(got)
+        (got * w).sum().backward()
+        want = torch.zeros(N, C, device=dev).index_copy(0, idx, w)
+        assert torch.equal(x.grad, want)
+        src = torch.rand(idx.numel(), C, device=dev, generator=g, requires_grad=True)
+        img = scatter_rows(src, idx, N)
+        assert torch.equal(img, torch.zeros(N, C, device=dev).index_copy(0, idx, src.detach()))
+        w2 = torch.rand(N, C, device=dev, generator=g)
+        (img * w2).sum().backward()
+        assert torch.equal(src.grad, w2[idx])
