@@ -63,6 +63,16 @@ int n2m_antialias_backward(const float* color, const float* rast, const float* p
                            uint32_t H, uint32_t W, float pos_gradient_boost, float* grad_color, float* grad_pos,
                            void* stream);
 
+/* Uniform-Laplacian smoothness of the stage-1 mesh, `laplacian_smooth_loss(verts, faces)` of nerf/utils.py:176-221: with L = D - A over the
+ * unique directed edges (diagonal = number of distinct neighbours), loss = mean_i || (L v)_i ||_2.  The adjacency as CSR (row_ptr [V + 1],
+ * col [E] int32, a vertex's neighbours in ascending order; symmetric).  forward: Lv [V, 3] = L v, norm [V], partial [ceil(V / 256)] =
+ * per-workgroup sums of the norms (loss = sum(partial) / V).  backward: d_verts [V, 3] from the saved Lv / norm and the incoming gradient
+ * (device scalar): d v_i = deg_i gL_i - sum_{j in N(i)} gL_j, gL_k = grad / V * Lv_k / norm_k (0 where the norm is 0). */
+int n2m_laplacian_forward(const float* verts, const int32_t* row_ptr, const int32_t* col, uint32_t V, float* Lv, float* norm, float* partial,
+                          void* stream);
+int n2m_laplacian_backward(const float* Lv, const float* norm, const int32_t* row_ptr, const int32_t* col, uint32_t V, const float* grad,
+                           float* d_verts, void* stream);
+
 /* Rows of a [N, C] fp32 array by index -- the boolean-mask gather / scatter around the shading of a stage-1 frame (nerf/renderer.py:864,
  * 875-881: `xyzs[mask]`, `rgbs[mask] = ...`) once the covered pixels are an index list: out[k, :] = x[idx[k], :] and dst[idx[k], :] = src[k, :]
  * (idx int64 [K], unique for the scatter; rows of dst that are not listed keep their value). */

@@ -619,6 +619,75 @@ extern "C" int n2m_sdf_alpha_backward(const float* d_alpha, const float* sdf, co
     return 0;
 }
 
+// ---- uniform-Laplacian smoothness of the stage-1 mesh (nerf/utils.py:176-221): loss = mean_i || deg_i v_i - sum_{j in N(i)} v_j ||_2 over the
+// unique directed edges, as CSR (row_ptr [V + 1], col [E], neighbours of a vertex in ascending order: a fixed summation order).  One launch
+// forward (L = D v - A v, its norms, per-workgroup sums of them), one backward: d v_i = deg_i gL_i - sum_{j in N(i)} gL_j with
+// gL_k = g / V * L_k / ||L_k|| (0 where the norm is 0, like torch's norm backward) -- the adjacency is symmetric, so the adjoint is the same walk.
+__global__ void __launch_bounds__(256)
+laplacian_forward_kernel(const float* __restrict__ v, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col, uint32_t V,
+                         float* __restrict__ Lv, float* __restrict__ norm, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    float n = 0.0f;
+    if (i < V) {
+        const int32_t b = row_ptr[i], e = row_ptr[i + 1];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int32_t k = b; k < e; ++k) {
+            const size_t j = (size_t)col[k] * 3u;
+            s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2];
+        }
+        const float d = (float)(e - b);
+        const float l0 = v[(size_t)i * 3u] * d - s0, l1 = v[(size_t)i * 3u + 1] * d - s1, l2 = v[(size_t)i * 3u + 2] * d - s2;
+        n = sqrtf((l0 * l0 + l1 * l1) + l2 * l2);
+        Lv[(size_t)i * 3u] = l0; Lv[(size_t)i * 3u + 1] = l1; Lv[(size_t)i * 3u + 2] = l2;
+        norm[i] = n;
+    }
+    const float w = n2m_wave_sum(n);
+    if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0u) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(256)
+laplacian_backward_kernel(const float* __restrict__ Lv, const float* __restrict__ norm, const int32_t* __restrict__ row_ptr,
+                          const int32_t* __restrict__ col, uint32_t V, const float* __restrict__ g, float* __restrict__ d_v) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= V) return;
+    const float gs = *g / (float)V;
+    auto gl = [&](size_t k, float (&o)[3]) {
+        const float n = norm[k];
+        const float f = n > 0.0f ? gs / n : 0.0f;
+        o[0] = Lv[k * 3u] * f; o[1] = Lv[k * 3u + 1] * f; o[2] = Lv[k * 3u + 2] * f;
+    };
+    const int32_t b = row_ptr[i], e = row_ptr[i + 1];
+    float s[3] = {0.f, 0.f, 0.f}, t[3];
+    for (int32_t k = b; k < e; ++k) {
+        gl((size_t)col[k], t);
+        s[0] += t[0]; s[1] += t[1]; s[2] += t[2];
+    }
+    gl((size_t)i, t);
+    const float d = (float)(e - b);
+    d_v[(size_t)i * 3u] = t[0] * d - s[0]; d_v[(size_t)i * 3u + 1] = t[1] * d - s[1]; d_v[(size_t)i * 3u + 2] = t[2] * d - s[2];
+}
+
+extern "C" int n2m_laplacian_forward(const float* verts, const int32_t* row_ptr, const int32_t* col, uint32_t V, float* Lv, float* norm,
+                                     float* partial, void* stream) {
+    N2M_REQUIRE(verts && row_ptr && col && Lv && norm && partial, N2M_ENULL, "laplacian_forward: NULL tensor");
+    if (V == 0) return 0;
+    laplacian_forward_kernel<<<n2m_ceil_div(V, 256), 256, 0, (hipStream_t)stream>>>(verts, row_ptr, col, V, Lv, norm, partial);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_laplacian_backward(const float* Lv, const float* norm, const int32_t* row_ptr, const int32_t* col, uint32_t V, const float* grad,
+                                      float* d_verts, void* stream) {
+    N2M_REQUIRE(Lv && norm && row_ptr && col && grad && d_verts, N2M_ENULL, "laplacian_backward: NULL tensor");
+    if (V == 0) return 0;
+    laplacian_backward_kernel<<<n2m_ceil_div(V, 256), 256, 0, (hipStream_t)stream>>>(Lv, norm, row_ptr, col, V, grad, d_verts);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
 // rows of a [N, C] fp32 array by index (stage 1: the covered pixels of a frame, nerf/renderer.py:864-881): out[k] = x[idx[k]] and its mirror
 // dst[idx[k]] = src[k] (idx unique: no atomics).  torch's index kernels spend 50 us per call on 0.7 M rows of three floats.
 template <bool SCATTER>

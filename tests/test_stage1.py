@@ -152,3 +152,30 @@ def test_rows_by_index_kernels():
         w2 = torch.rand(N, C, device=dev, generator=g)
         (img * w2).sum().backward()
         assert torch.equal(src.grad, w2[idx])
+
+
+def test_laplacian_kernels_equal_the_index_add_form():
+    """n2m_laplacian_forward / _backward (trainer.UniformLaplacian on the GPU) against the torch form of the same loss (two index_add
+    passes, norm, mean -- the form tests/test_stage1_reference.py pins to the unchanged laplacian_smooth_loss): value and gradient, on a
+    mesh with an isolated vertex and a vertex whose Laplacian is exactly zero (norm backward: 0 there)."""
+    import torch
+    from nerf2mesh_amd import synthetic as S
+    from nerf2mesh_amd.trainer import UniformLaplacian, _NeighbourSum
+    dev = torch.device("cuda")
+    v, f = S.scene_mesh(20000)
+    v = torch.as_tensor(v, dtype=torch.float32, device=dev)
+    f = torch.as_tensor(f, dtype=torch.int64, device=dev)
+    v = torch.cat([v, torch.zeros(1, 3, device=dev)])                        # an isolated vertex: degree 0, L v = 0
+    lap = UniformLaplacian(f, v.shape[0])
+    g = torch.Generator(device=dev).manual_seed(4)
+    x = (v + 1e-3 * torch.randn(v.shape, device=dev, generator=g)).requires_grad_()
+    got = lap(x)
+    (got * 3.0).backward()
+    gx = x.grad.clone(); x.grad = None
+    nb = _NeighbourSum.apply(x, lap.ii, lap.jj)
+    want = (x * lap.deg - nb).norm(dim=1).mean()
+    (want * 3.0).backward()
+    assert abs(float(got) - float(want)) <= 2e-6 * float(want)
+    # (L v = deg v - sum v_j cancels six digits on a smooth mesh: the two summation orders differ by 1e-7 in L, i.e. 1e-4 in its direction)
+    assert float((gx - x.grad).abs().max()) <= 2e-3 * float(x.grad.abs().max())
+    assert float(gx[-1].abs().max()) == 0.0 and bool(torch.isfinite(gx).all())
