@@ -90,11 +90,14 @@ int n2m_scatter_rows(const float* src, const int64_t* idx, uint32_t K, uint32_t 
  *   d_alpha [h0 s, w0 s], d_rgb [h0 s, w0 s, 3] (both or neither): gradient of mean(loss_px) w.r.t. aa_alpha / aa_rgb; the caller scales
  *        them by its incoming gradient (the loss scale).
  *   tri_err, tri_cnt [faces] f32 (both or neither): `update_triangles_errors` (nerf/renderer.py:924-943) in the same pass -- loss_px added to
- *        tri_err[trig_id], 1 to tri_cnt[trig_id] for every pixel that shows a face (float atomics, like torch's scatter_add_). */
+ *        tri_err[trig_id], 1 to tri_cnt[trig_id] for every pixel that shows a face (float atomics, like torch's scatter_add_).
+ *   packed_rgba != 0: the two antialias calls were ONE call on an [h0 s, w0 s, 4] image (RGB + alpha: the silhouette blend is per channel, so
+ *        the values are the same): aa_rgb = that image, aa_alpha = aa_rgb + 3, pixel stride 4 for both; d_rgb / d_alpha likewise point into
+ *        one [h0 s, w0 s, 4] gradient image. */
 int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const float* rast, uint32_t h0, uint32_t w0, uint32_t ssaa,
                     const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask, float* image, float* depth,
                     float* weights_sum, float* trig_id, float* loss_px, float* d_alpha, float* d_rgb, float* partial, float* tri_err,
-                    float* tri_cnt, void* stream);
+                    float* tri_cnt, int packed_rgba, void* stream);
 
 #ifdef __cplusplus
 }

@@ -104,7 +104,8 @@ stage1_head_kernel(const float* __restrict__ aa_alpha /*[h0 S, w0 S]*/, const fl
                    const float* __restrict__ bg /*[h0 w0, 3] or NULL*/, float bg_scalar, float lambda_rgb, float lambda_mask,
                    float* __restrict__ image, float* __restrict__ depth, float* __restrict__ wsum, float* __restrict__ trig_id,
                    float* __restrict__ loss_px, float* __restrict__ d_alpha, float* __restrict__ d_rgb, float* __restrict__ partial,
-                   float* __restrict__ tri_err, float* __restrict__ tri_cnt) {
+                   float* __restrict__ tri_err, float* __restrict__ tri_cnt, uint32_t sa /*floats per pixel of aa_alpha / d_alpha: 1, or 4 = channel 3 of an RGBA image*/,
+                   uint32_t sr /*of aa_rgb / d_rgb: 3, or 4*/) {
     __shared__ float wave_sum[4];
     const uint32_t n = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t N = h0 * w0, w = w0 * S;
@@ -119,12 +120,12 @@ stage1_head_kernel(const float* __restrict__ aa_alpha /*[h0 S, w0 S]*/, const fl
             for (int i = 0; i < S; ++i) {
                 const size_t p = (size_t)(y * S + j) * w + (x * S + i);
                 const int k = j * S + i;
-                const float ra = aa_alpha[p];
+                const float ra = aa_alpha[p * sa];
                 pass_a[k] = ra >= 0.0f && ra <= 1.0f;
                 a[k] = fminf(fmaxf(ra, 0.0f), 1.0f);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
-                    const float rc = aa_rgb[p * 3 + ch];
+                    const float rc = aa_rgb[p * sr + ch];
                     pass_c[k][ch] = rc >= 0.0f && rc <= 1.0f;
                     c[k][ch] = fminf(fmaxf(rc, 0.0f), 1.0f);
                 }
@@ -178,9 +179,9 @@ stage1_head_kernel(const float* __restrict__ aa_alpha /*[h0 S, w0 S]*/, const fl
                     for (int ch = 0; ch < 3; ++ch) {
                         const float dis = share * gi[ch];                               // d image_sub
                         da += dis * c[k][ch];
-                        d_rgb[p * 3 + ch] = pass_c[k][ch] ? dis * a[k] : 0.0f;
+                        d_rgb[p * sr + ch] = pass_c[k][ch] ? dis * a[k] : 0.0f;
                     }
-                    d_alpha[p] = pass_a[k] ? da : 0.0f;
+                    d_alpha[p * sa] = pass_a[k] ? da : 0.0f;
                 }
         }
     }
@@ -721,7 +722,7 @@ extern "C" int n2m_scatter_rows(const float* src, const int64_t* idx, uint32_t K
 extern "C" int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const float* rast, uint32_t h0, uint32_t w0, uint32_t ssaa,
                                const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask, float* image,
                                float* depth, float* weights_sum, float* trig_id, float* loss_px, float* d_alpha, float* d_rgb, float* partial,
-                               float* tri_err, float* tri_cnt, void* stream) {
+                               float* tri_err, float* tri_cnt, int packed_rgba, void* stream) {
     N2M_REQUIRE(aa_alpha && aa_rgb && rast && gt_rgba && image && depth && weights_sum && trig_id && loss_px && partial, N2M_ENULL,
                 "stage1_head: NULL tensor");
     N2M_REQUIRE((d_alpha == nullptr) == (d_rgb == nullptr), N2M_ENULL, "stage1_head: d_alpha and d_rgb come together");
@@ -732,10 +733,12 @@ extern "C" int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const
     const uint32_t N = h0 * w0;
     if (ssaa == 1)
         stage1_head_kernel<1><<<n2m_ceil_div(N, 256), 256, 0, s>>>(aa_alpha, aa_rgb, rast, h0, w0, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask,
-                                                                  image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial, tri_err, tri_cnt);
+                                                                  image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial, tri_err, tri_cnt, packed_rgba ? 4u : 1u,
+                                                                  packed_rgba ? 4u : 3u);
     else
         stage1_head_kernel<2><<<n2m_ceil_div(N, 256), 256, 0, s>>>(aa_alpha, aa_rgb, rast, h0, w0, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask,
-                                                                  image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial, tri_err, tri_cnt);
+                                                                  image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial, tri_err, tri_cnt, packed_rgba ? 4u : 1u,
+                                                                  packed_rgba ? 4u : 3u);
     N2M_CHECK_LAUNCH();
     return 0;
 }

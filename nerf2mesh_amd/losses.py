@@ -58,8 +58,11 @@ class _stage1_head(Function):
 
     @staticmethod
     def forward(ctx, aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb, lambda_mask, tri_err=None, tri_cnt=None):
-        dev = aa_alpha.device
-        aa_alpha, aa_rgb, rast = aa_alpha.float().contiguous(), aa_rgb.float().contiguous(), rast.float().contiguous()
+        # aa_alpha is None: aa_rgb is the [1, h, w, 4] output of ONE antialias call on RGB + alpha
+        dev = aa_rgb.device
+        packed = aa_alpha is None
+        aa_rgb, rast = aa_rgb.float().contiguous(), rast.float().contiguous()
+        aa_alpha = None if packed else aa_alpha.float().contiguous()
         gt_rgba = gt_rgba.float().contiguous()
         N = h0 * w0
         bg_t, bg_s = (bg.float().reshape(N, 3).contiguous(), 0.0) if torch.is_tensor(bg) else (None, float(bg))
@@ -67,10 +70,16 @@ class _stage1_head(Function):
         image, depth, ws, trig, loss_px = f(N, 3), f(N), f(N), f(N), f(N)
         partial = f((N + 255) // 256)
         need = any(ctx.needs_input_grad[:2])
-        d_alpha, d_rgb = (torch.empty_like(aa_alpha), torch.empty_like(aa_rgb)) if need else (None, None)
-        L.call("n2m_stage1_head", _p(aa_alpha), _p(aa_rgb), _p(rast), int(h0), int(w0), int(ssaa), _p(gt_rgba), _p(bg_t), bg_s, float(lambda_rgb),
-               float(lambda_mask), _p(image), _p(depth), _p(ws), _p(trig), _p(loss_px), _p(d_alpha), _p(d_rgb), _p(partial), _p(tri_err), _p(tri_cnt),
-               L.stream())
+        if packed:
+            d_rgb = torch.empty_like(aa_rgb) if need else None
+            pa, pda = aa_rgb.data_ptr() + 12, (d_rgb.data_ptr() + 12 if need else None)
+            d_alpha = None
+        else:
+            d_alpha, d_rgb = (torch.empty_like(aa_alpha), torch.empty_like(aa_rgb)) if need else (None, None)
+            pa, pda = _p(aa_alpha), _p(d_alpha)
+        L.call("n2m_stage1_head", pa, _p(aa_rgb), _p(rast), int(h0), int(w0), int(ssaa), _p(gt_rgba), _p(bg_t), bg_s, float(lambda_rgb),
+               float(lambda_mask), _p(image), _p(depth), _p(ws), _p(trig), _p(loss_px), pda, _p(d_rgb), _p(partial), _p(tri_err), _p(tri_cnt),
+               int(packed), L.stream())
         ctx.grads = (d_alpha, d_rgb)
         loss = partial.sum() / N
         ctx.mark_non_differentiable(image, depth, ws, trig, loss_px)
@@ -80,13 +89,14 @@ class _stage1_head(Function):
     def backward(ctx, g, *unused):
         d_alpha, d_rgb = ctx.grads
         ctx.grads = None
-        return d_alpha * g, d_rgb * g, None, None, None, None, None, None, None, None, None, None
+        return (d_alpha * g if d_alpha is not None else None), d_rgb * g, None, None, None, None, None, None, None, None, None, None
 
 
 def stage1_head(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb=1.0, lambda_mask=0.0, tri_err=None, tri_cnt=None):
     """(loss, image [N,3], depth [N], weights_sum [N], trig_id [N] float, loss_px [N]) of one stage-1 view from the two antialias outputs
     (before their clamp) and the rasteriser's image: nerf/renderer.py:886-913 + the loss of nerf/utils.py:708-721, N = h0 * w0.
-    tri_err / tri_cnt [faces] f32: `update_triangles_errors` (nerf/renderer.py:924-943) done by the same launch."""
+    tri_err / tri_cnt [faces] f32: `update_triangles_errors` (nerf/renderer.py:924-943) done by the same launch.
+    aa_alpha = None: aa_rgb is the [1, h, w, 4] output of ONE antialias call on the RGB + alpha image (same values per channel)."""
     return _stage1_head.apply(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb, lambda_mask, tri_err, tri_cnt)
 
 

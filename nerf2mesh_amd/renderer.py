@@ -578,10 +578,11 @@ class NeRFRenderer(nn.Module):
             rays_d = F.interpolate(rays_d.view(1, h0, w0, 3).permute(0, 3, 1, 2), (h, w), mode="nearest").permute(0, 2, 3, 1).reshape(-1, 3).contiguous()
         return safe_normalize(rays_d)
 
-    def _stage1_front(self, rays_d, mvp, h0, w0, shading="full", dirs=None):
+    def _stage1_front(self, rays_d, mvp, h0, w0, shading="full", dirs=None, packed=False):
         """Everything of render_stage1 up to and including the two antialias calls (nerf/renderer.py:816-887): returns
         (rast [1,h,w,4], alpha [1,h,w,1] and rgb [1,h,w,3] as antialias hands them out, BEFORE the clamp).  dirs: stage1_dirs(rays_d, h0, w0)
-        when the caller has it already."""
+        when the caller has it already.  packed: ONE antialias call on the [1,h,w,4] image RGB + alpha instead of the reference's two (the
+        silhouette blend works per channel: same values, one pass over the edges each way instead of two) -- returns (rast, None, rgba)."""
         device = rays_d.device
         ssaa = int(self.opt.ssaa)
         h, w = (int(h0 * ssaa), int(w0 * ssaa)) if ssaa > 1 else (h0, w0)
@@ -604,6 +605,9 @@ class NeRFRenderer(nn.Module):
             pts = gather_rows(xyzs if self.opt.enable_offset_nerf_grad else xyzs.detach(), idx)
             with torch.autocast(device_type="cuda", dtype=torch.float16, enabled=bool(self.opt.fp16)):
                 mask_rgbs, _ = self.rgb(pts, gather_rows(dirs, idx), None, shading)
+            if packed:
+                rgba = scatter_rows(torch.cat([mask_rgbs.float(), gather_rows(mask.view(-1, 1), idx)], dim=1), idx, h * w).view(1, h, w, 4)
+                return rast, None, dr.antialias(rgba, rast, vertices_clip, self.triangles, pos_gradient_boost=self.opt.pos_gradient_boost)
             rgbs = scatter_rows(mask_rgbs, idx, h * w)
         else:
             rgbs = torch.zeros(h * w, 3, device=device, dtype=torch.float32)

@@ -457,6 +457,7 @@ class Stage1Trainer:
         self._dirs = {}               # per view: unit directions at the ssaa resolution (30 MB per 800 x 800 view at ssaa 2)
         self.covered_seen = 0         # shaded (covered) full-resolution pixels so far: the unit of the stage-1 byte model
         self.fused_head = torch.device(device).type == "cuda" and int(opt.ssaa) in (1, 2)      # losses.stage1_head (False: the torch graph)
+        self.packed_aa = os.environ.get("N2M_S1_PACKED_AA", "1") != "0"      # one antialias call on RGB + alpha instead of two
 
     def _view(self, v):
         if v not in self.view_cache:
@@ -488,7 +489,7 @@ class Stage1Trainer:
             dirs = self._dirs.get(v)
             if dirs is None:              # unit directions at the rendered resolution: per view, resident like the rays they come from
                 dirs = self._dirs[v] = model.stage1_dirs(rays_d, self.H, self.W).detach()
-            rast, aa_alpha, aa_rgb = model._stage1_front(rays_d, self.mvps[v], self.H, self.W, shading, dirs=dirs)
+            rast, aa_alpha, aa_rgb = model._stage1_front(rays_d, self.mvps[v], self.H, self.W, shading, dirs=dirs, packed=self.packed_aa)
             te = (model.triangles_errors, model.triangles_errors_cnt) if opt.refine else (None, None)      # update_triangles_errors rides along
             loss, _, _, _, trig, loss_px = stage1_head(aa_alpha, aa_rgb, rast, rgba, bg, self.H, self.W, int(opt.ssaa), opt.lambda_rgb,
                                                        max(opt.lambda_mask, 0.0), *te)

@@ -92,6 +92,12 @@ def test_fused_image_head_equals_the_torch_graph(ssaa):
     assert close(lp2, loss_px.detach(), 2e-6) and abs(float(l2) - float(loss)) <= 2e-6 * float(loss)
     assert close(aa_alpha.grad, ga, 2e-6) and close(aa_rgb.grad, gr, 2e-6)
     assert float((aa_alpha.grad == 0).float().mean()) > 0.1, "the clamp masks were not exercised"
+    # the same head fed ONE [1,h,w,4] image (RGB + alpha, what a single antialias call on both hands out): same outputs, same gradients
+    rgba = torch.cat([aa_rgb.detach(), aa_alpha.detach()], -1).requires_grad_()
+    l3, im3, dp3, ws3, tr3, lp3 = stage1_head(None, rgba, rast, gt, bg, h0, w0, ssaa, lam_rgb, lam_mask)
+    (l3 * seed).backward()
+    assert torch.equal(im3, im2) and torch.equal(lp3, lp2) and torch.equal(ws3, ws2) and float(l3) == float(l2)
+    assert torch.equal(rgba.grad[..., :3], aa_rgb.grad) and torch.equal(rgba.grad[..., 3:], aa_alpha.grad)
     # update_triangles_errors (nerf/renderer.py:924-943) in the same launch: per-face sums of the pixel loss and pixel counts
     n_faces = 50
     err, cnt = torch.full((n_faces,), 0.5, device=dev), torch.full((n_faces,), 2.0, device=dev)
