@@ -177,6 +177,7 @@ class Stage0Engine:
         # accumulates are latency-bound work items (2 per CU, barriers between their phases) and move the optimizer's 0.3 GB at a third of the
         # rate the streaming n2m_adam_step reaches (backward 287 -> 399-434 us against Adam 93 -> 15 us; lookup 74 -> 88 us), DESIGN 4.11h.
         self.sdf_fold = os.environ.get("N2M_SDF_FOLD", "1") != "0"      # SDF recipe: finite-difference copies folded into the batch's table backward
+        self.sdf_tv_all = os.environ.get("N2M_SDF_TV_ALL", "1") != "0"  # SDF recipe, progressive phase: TV of all levels inside the batch's backward
         self.fuse_adam = None
         if world_size == 1 and not opt.sdf and self.Lv == 16 and os.environ.get("N2M_FUSE_ADAM", "0") == "1":
             fl, fr = ctypes.c_uint32(0), ctypes.c_uint32(0)
@@ -857,7 +858,18 @@ class Stage0Engine:
             tv_fold = opt.lambda_tv > 0 and ml == self.Lv
             tv_w, tv_wo = float(opt.lambda_tv), float(opt.lambda_tv * (10 if opt.bound > 1 else 1))
             geo = (self.Lv, ml, self.S, self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id)
-            batch_args = (_p(w["d_h1"]), _p(w["d_h2"]), _p(xyzs), self.ho.ctypes.data, _p(self.g1), _p(self.g2), M, *geo,
+            geo_batch = geo
+            if opt.lambda_tv > 0 and 6 <= ml < self.Lv and self.sdf_tv_all:
+                # progressive levels: the TV term covers ALL sixteen levels (grid.py:170-192 has no max_level).  Instead of the batch's backward
+                # over the active levels + the TV as its own 16-level pass (185 us), the batch's backward runs over all sixteen with the TV
+                # folded in and ZERO feature gradients on the inactive levels (the encoder's backward ignores them, grid.py:71-95): one pass
+                # on the 1-D XCD grid.  Pays from about six active levels on.
+                w["d_h1"][ml * M:16 * M].zero_()
+                w["d_h2"][2 * ml * M:32 * M].zero_()
+                geo_batch = (self.Lv, self.Lv) + geo[2:]
+                tv_fold = True
+                ws = L.workspace(dev, max(need, L.lib().n2m_grid_binned_pair_workspace_bytes(M, self.Lv, self.ho.ctypes.data)))
+            batch_args = (_p(w["d_h1"]), _p(w["d_h2"]), _p(xyzs), self.ho.ctypes.data, _p(self.g1), _p(self.g2), M, *geo_batch,
                           _p(e1.embeddings) if tv_fold else None, tv_w, tv_wo, float(0.5 / model.bound), _p(seed) if tv_fold else None, _p(o.found_inf),
                           float(self.aff[0]), float(self.aff[1]), 1, _p(ws), ws.numel())
             if fold:
