@@ -399,8 +399,10 @@ def main():
             roof_lookup = roofline_of("grid_encode_forward_packed")                          # north_star's hash-grid lookup (training launches only)
         for r in (roof, roof_lookup):       # a broken measurement must not pass as a number (an event pair that closed before its launch once did)
             if r is not None and r["frac"] is not None and not (0.0 < r["frac"] <= 1.0):
-                raise SystemExit(f"bench: implausible roofline entry {r['kernel']}: {r['achieved']:.0f} GB/s of {HBM_PEAK_GBS:.0f} -- "
-                                 "the per-kernel events do not bracket the launch")
+                # (flagged, not fatal: other ranks may be waiting in a collective behind this point)
+                print(f"[bench] ERROR: implausible roofline entry {r['kernel']}: {r['achieved']:.0f} GB/s of {HBM_PEAK_GBS:.0f} -- the per-kernel "
+                      "events do not bracket the launch; the entry is withdrawn", file=sys.stderr)
+                r.update(achieved=None, frac=None, note="WITHDRAWN: the measured duration is implausible (events did not bracket the launch)")
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
