@@ -106,3 +106,26 @@ def test_uniform_laplacian_matches_dense_operator_and_its_gradient():
         mine = lap32(v32)
         g_mine, = torch.autograd.grad(mine, v32)
         assert torch.allclose(mine, theirs, rtol=1e-5) and torch.allclose(g_mine, g_theirs, rtol=1e-4, atol=1e-6)
+
+
+def test_plain_lambda_lr_equals_torch_lambda_lr():
+    """trainer.LambdaLR (main.py:239's schedule without torch's per-step Python overhead) against torch.optim.lr_scheduler.LambdaLR:
+    same learning rates for every parameter group over the warm-up and the decay, same state after load_state_dict."""
+    import torch
+    from nerf2mesh_amd.trainer import LambdaLR
+    iters = 3000
+    f = lambda it: 0.01 + 0.99 * (it / 500) if it <= 500 else 0.1 ** ((it - 500) / (iters - 500))
+    def make():
+        p = [torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(3))]
+        return torch.optim.Adam([{"params": [p[0]], "lr": 1e-2}, {"params": [p[1]], "lr": 3e-4}])
+    a, b = make(), make()
+    sa, sb = torch.optim.lr_scheduler.LambdaLR(a, f), LambdaLR(b, f)
+    for it in range(1200):
+        for ga, gb in zip(a.param_groups, b.param_groups):
+            assert abs(ga["lr"] - gb["lr"]) <= 1e-15 + 1e-12 * ga["lr"], (it, ga["lr"], gb["lr"])
+        a.step(); sa.step(); sb.step()
+    assert sb.get_last_lr() == [g["lr"] for g in b.param_groups]
+    c = make()
+    sc = LambdaLR(c, f)
+    sc.load_state_dict(sb.state_dict())
+    assert [g["lr"] for g in c.param_groups] == [g["lr"] for g in b.param_groups]
