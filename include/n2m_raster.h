@@ -63,6 +63,12 @@ int n2m_antialias_backward(const float* color, const float* rast, const float* p
                            uint32_t H, uint32_t W, float pos_gradient_boost, float* grad_color, float* grad_pos,
                            void* stream);
 
+/* World -> clip space of the mesh, `torch.matmul(F.pad(vertices, (0, 1), value=1.0), mvp.T)` (nerf/renderer.py:858): clip [V, 4] =
+ * [v, 1] @ mvp^T (mvp [4, 4] row-major), and the gradient w.r.t. the vertices d_v = d_clip @ mvp[:, :3]; one launch each (a BLAS GEMM of
+ * this shape ran as a single workgroup: 2.7 ms for 159 k vertices; the broadcast torch form is seven launches forward, ten backward). */
+int n2m_to_clip(const float* vertices, const float* mvp, uint32_t V, float* clip, void* stream);
+int n2m_to_clip_backward(const float* d_clip, const float* mvp, uint32_t V, float* d_vertices, void* stream);
+
 /* Uniform-Laplacian smoothness of the stage-1 mesh, `laplacian_smooth_loss(verts, faces)` of nerf/utils.py:176-221: with L = D - A over the
  * unique directed edges (diagonal = number of distinct neighbours), loss = mean_i || (L v)_i ||_2.  The adjacency as CSR (row_ptr [V + 1],
  * col [E] int32, a vertex's neighbours in ascending order; symmetric).  forward: Lv [V, 3] = L v, norm [V], partial [ceil(V / 256)] =

@@ -620,6 +620,49 @@ extern "C" int n2m_sdf_alpha_backward(const float* d_alpha, const float* sdf, co
     return 0;
 }
 
+// ---- world -> clip space of the stage-1 mesh (nerf/renderer.py:858: [v, 1] @ mvp^T), value and gradient w.r.t. the vertices, one launch each.
+// Forward keeps the association of the broadcast form it replaces, ((v0 m_0 + v1 m_1) + v2 m_2) + m_3 per output column, no contraction.
+__global__ void __launch_bounds__(256)
+to_clip_kernel(const float* __restrict__ v, const float* __restrict__ mvp /*[4,4] row-major*/, uint32_t V, float* __restrict__ clip) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= V) return;
+    const float x = v[(size_t)i * 3u], y = v[(size_t)i * 3u + 1], z = v[(size_t)i * 3u + 2];
+    float4 o;
+    o.x = ((x * mvp[0] + y * mvp[1]) + z * mvp[2]) + mvp[3];
+    o.y = ((x * mvp[4] + y * mvp[5]) + z * mvp[6]) + mvp[7];
+    o.z = ((x * mvp[8] + y * mvp[9]) + z * mvp[10]) + mvp[11];
+    o.w = ((x * mvp[12] + y * mvp[13]) + z * mvp[14]) + mvp[15];
+    *reinterpret_cast<float4*>(clip + (size_t)i * 4u) = o;
+}
+
+__global__ void __launch_bounds__(256)
+to_clip_backward_kernel(const float* __restrict__ d_clip, const float* __restrict__ mvp, uint32_t V, float* __restrict__ d_v) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= V) return;
+    const float4 g = *reinterpret_cast<const float4*>(d_clip + (size_t)i * 4u);
+#pragma unroll
+    for (uint32_t a = 0; a < 3; ++a)
+        d_v[(size_t)i * 3u + a] = ((g.x * mvp[a] + g.y * mvp[4 + a]) + g.z * mvp[8 + a]) + g.w * mvp[12 + a];
+}
+
+extern "C" int n2m_to_clip(const float* vertices, const float* mvp, uint32_t V, float* clip, void* stream) {
+    N2M_REQUIRE(vertices && mvp && clip, N2M_ENULL, "to_clip: NULL tensor");
+    N2M_REQUIRE(((uintptr_t)clip & 15u) == 0, N2M_EINVAL, "to_clip: clip must be 16-byte aligned");
+    if (V == 0) return 0;
+    to_clip_kernel<<<n2m_ceil_div(V, 256), 256, 0, (hipStream_t)stream>>>(vertices, mvp, V, clip);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_to_clip_backward(const float* d_clip, const float* mvp, uint32_t V, float* d_vertices, void* stream) {
+    N2M_REQUIRE(d_clip && mvp && d_vertices, N2M_ENULL, "to_clip_backward: NULL tensor");
+    N2M_REQUIRE(((uintptr_t)d_clip & 15u) == 0, N2M_EINVAL, "to_clip_backward: d_clip must be 16-byte aligned");
+    if (V == 0) return 0;
+    to_clip_backward_kernel<<<n2m_ceil_div(V, 256), 256, 0, (hipStream_t)stream>>>(d_clip, mvp, V, d_vertices);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- uniform-Laplacian smoothness of the stage-1 mesh (nerf/utils.py:176-221): loss = mean_i || deg_i v_i - sum_{j in N(i)} v_j ||_2 over the
 // unique directed edges, as CSR (row_ptr [V + 1], col [E], neighbours of a vertex in ascending order: a fixed summation order).  One launch
 // forward (L = D v - A v, its norms, per-workgroup sums of them), one backward: d v_i = deg_i gL_i - sum_{j in N(i)} gL_j with

@@ -24,9 +24,32 @@ def safe_normalize(x, eps=1e-20):
     return x / torch.sqrt(torch.clamp(torch.sum(x * x, -1, keepdim=True), min=eps))   # nerf/utils.py:safe_normalize
 
 
+class _to_clip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vertices, mvp):
+        from . import _lib as L
+        vertices, mvp = vertices.float().contiguous(), mvp.float().contiguous()
+        clip = torch.empty(vertices.shape[0], 4, dtype=torch.float32, device=vertices.device)
+        L.call("n2m_to_clip", L.ptr(vertices), L.ptr(mvp), vertices.shape[0], L.ptr(clip), L.stream())
+        ctx.save_for_backward(mvp)
+        return clip
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib as L
+        mvp, = ctx.saved_tensors
+        g = g.float().contiguous()
+        d = torch.empty(g.shape[0], 3, dtype=torch.float32, device=g.device)
+        L.call("n2m_to_clip_backward", L.ptr(g), L.ptr(mvp), g.shape[0], L.ptr(d), L.stream())
+        return d, None
+
+
 def to_clip(vertices, mvp):
-    """[V,3] world -> [V,4] clip = [v,1] @ mvp^T (nerf/renderer.py:858), written as three broadcast FMAs: the BLAS library
-    runs this (V x 4) x (4 x 4) product as a single-workgroup GEMM (2.7 ms for 159k vertices, measured)."""
+    """[V,3] world -> [V,4] clip = [v,1] @ mvp^T (nerf/renderer.py:858).  On the GPU one launch each way (n2m_to_clip); elsewhere three
+    broadcast multiply-adds in the same association (the BLAS library runs this (V x 4) x (4 x 4) product as a single-workgroup GEMM:
+    2.7 ms for 159k vertices, measured)."""
+    if vertices.is_cuda and vertices.dim() == 2:
+        return _to_clip.apply(vertices, mvp)
     m = mvp.float()
     return (vertices[:, 0:1] * m[:, 0] + vertices[:, 1:2] * m[:, 1] + vertices[:, 2:3] * m[:, 2] + m[:, 3]).contiguous()
 
@@ -578,7 +601,7 @@ class NeRFRenderer(nn.Module):
             rays_d = F.interpolate(rays_d.view(1, h0, w0, 3).permute(0, 3, 1, 2), (h, w), mode="nearest").permute(0, 2, 3, 1).reshape(-1, 3).contiguous()
         return safe_normalize(rays_d)
 
-    def _stage1_front(self, rays_d, mvp, h0, w0, shading="full", dirs=None, packed=False):
+    def _stage1_front(self, rays_d, mvp, h0, w0, shading="full", dirs=None, packed=False, vertices=None):
         """Everything of render_stage1 up to and including the two antialias calls (nerf/renderer.py:816-887): returns
         (rast [1,h,w,4], alpha [1,h,w,1] and rgb [1,h,w,3] as antialias hands them out, BEFORE the clamp).  dirs: stage1_dirs(rays_d, h0, w0)
         when the caller has it already.  packed: ONE antialias call on the [1,h,w,4] image RGB + alpha instead of the reference's two (the
@@ -588,7 +611,8 @@ class NeRFRenderer(nn.Module):
         h, w = (int(h0 * ssaa), int(w0 * ssaa)) if ssaa > 1 else (h0, w0)
         if dirs is None:
             dirs = self.stage1_dirs(rays_d, h0, w0)
-        vertices = self.vertices + self.vertices_offsets
+        if vertices is None:          # (a caller that needs them elsewhere -- the trainer's smoothness loss -- passes its own sum in)
+            vertices = self.vertices + self.vertices_offsets
         vertices_clip = to_clip(vertices, mvp).unsqueeze(0)
         rast, _ = dr.rasterize(self.glctx, vertices_clip, self.triangles, (h, w))
         xyzs, _ = dr.interpolate(vertices.unsqueeze(0), rast, self.triangles)

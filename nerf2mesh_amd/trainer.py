@@ -482,6 +482,7 @@ class Stage1Trainer:
         bg = torch.rand(self.H * self.W, 3, device=self.device, generator=self.gen)
         self.optimizer.zero_grad(set_to_none=True)
         shading = "diffuse" if opt.diffuse_only else "full"                  # nerf/utils.py:669-672 (diffuse_step only gates stage 0)
+        verts = None
         if self.fused_head:
             # everything behind the two antialias calls (clamp, alpha * rgb, depth, T, ssaa reduction, background blend, per-pixel loss,
             # mean) and its backward in ONE launch (losses.stage1_head) instead of ~40 full-image elementwise / resize launches
@@ -489,7 +490,8 @@ class Stage1Trainer:
             dirs = self._dirs.get(v)
             if dirs is None:              # unit directions at the rendered resolution: per view, resident like the rays they come from
                 dirs = self._dirs[v] = model.stage1_dirs(rays_d, self.H, self.W).detach()
-            rast, aa_alpha, aa_rgb = model._stage1_front(rays_d, self.mvps[v], self.H, self.W, shading, dirs=dirs, packed=self.packed_aa)
+            verts = model.vertices + model.vertices_offsets            # once: the front half and the smoothness loss share it
+            rast, aa_alpha, aa_rgb = model._stage1_front(rays_d, self.mvps[v], self.H, self.W, shading, dirs=dirs, packed=self.packed_aa, vertices=verts)
             te = (model.triangles_errors, model.triangles_errors_cnt) if opt.refine else (None, None)      # update_triangles_errors rides along
             loss, _, _, _, trig, loss_px = stage1_head(aa_alpha, aa_rgb, rast, rgba, bg, self.H, self.W, int(opt.ssaa), opt.lambda_rgb,
                                                        max(opt.lambda_mask, 0.0), *te)
@@ -505,7 +507,7 @@ class Stage1Trainer:
             loss = loss.mean()
         self.covered_seen += getattr(model, "last_covered", 0)
         if opt.lambda_lap > 0:
-            loss = loss + opt.lambda_lap * self.laplacian(model.vertices + model.vertices_offsets)
+            loss = loss + opt.lambda_lap * self.laplacian(verts if verts is not None else model.vertices + model.vertices_offsets)
         if opt.lambda_offsets > 0:                                           # nerf/utils.py:772-789
             off = model.vertices_offsets
             if opt.bound > 1:       # inner mesh (cascade 0) + 0.1 x the outer cascades' meshes

@@ -185,3 +185,24 @@ def test_laplacian_kernels_equal_the_index_add_form():
     # (L v = deg v - sum v_j cancels six digits on a smooth mesh: the two summation orders differ by 1e-7 in L, i.e. 1e-4 in its direction)
     assert float((gx - x.grad).abs().max()) <= 2e-3 * float(x.grad.abs().max())
     assert float(gx[-1].abs().max()) == 0.0 and bool(torch.isfinite(gx).all())
+
+
+def test_to_clip_kernels_equal_the_broadcast_form():
+    """n2m_to_clip / _backward (renderer.to_clip on the GPU) against [v, 1] @ mvp^T written as three broadcast multiply-adds: same bits
+    forward (same association), gradient to fp32 rounding."""
+    import torch
+    from nerf2mesh_amd import synthetic as S
+    from nerf2mesh_amd.renderer import to_clip
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(6)
+    v = (torch.rand(70_001, 3, device=dev, generator=g) * 2 - 1).requires_grad_()
+    mvp = S.mvp_matrix(S.make_cameras(3, seed=0)[1], 800, 800).to(dev)
+    got = to_clip(v, mvp)
+    w = torch.rand_like(got)
+    (got * w).sum().backward()
+    gv = v.grad.clone(); v.grad = None
+    m = mvp.float()
+    want = (v[:, 0:1] * m[:, 0] + v[:, 1:2] * m[:, 1] + v[:, 2:3] * m[:, 2] + m[:, 3])
+    (want * w).sum().backward()
+    assert torch.equal(got, want.detach())
+    assert float((gv - v.grad).abs().max()) <= 2e-6 * float(v.grad.abs().max())
