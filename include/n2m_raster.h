@@ -69,15 +69,19 @@ int n2m_antialias_backward(const float* color, const float* rast, const float* p
 int n2m_to_clip(const float* vertices, const float* mvp, uint32_t V, float* clip, void* stream);
 int n2m_to_clip_backward(const float* d_clip, const float* mvp, uint32_t V, float* d_vertices, void* stream);
 
-/* Uniform-Laplacian smoothness of the stage-1 mesh, `laplacian_smooth_loss(verts, faces)` of nerf/utils.py:176-221: with L = D - A over the
- * unique directed edges (diagonal = number of distinct neighbours), loss = mean_i || (L v)_i ||_2.  The adjacency as CSR (row_ptr [V + 1],
- * col [E] int32, a vertex's neighbours in ascending order; symmetric).  forward: Lv [V, 3] = L v, norm [V], partial [ceil(V / 256)] =
- * per-workgroup sums of the norms (loss = sum(partial) / V).  backward: d_verts [V, 3] from the saved Lv / norm and the incoming gradient
- * (device scalar): d v_i = deg_i gL_i - sum_{j in N(i)} gL_j, gL_k = grad / V * Lv_k / norm_k (0 where the norm is 0). */
-int n2m_laplacian_forward(const float* verts, const int32_t* row_ptr, const int32_t* col, uint32_t V, float* Lv, float* norm, float* partial,
-                          void* stream);
-int n2m_laplacian_backward(const float* Lv, const float* norm, const int32_t* row_ptr, const int32_t* col, uint32_t V, const float* grad,
-                           float* d_verts, void* stream);
+/* The two mesh regularisers of stage 1.  Uniform-Laplacian smoothness, `laplacian_smooth_loss(verts, faces)` of nerf/utils.py:176-221: with
+ * L = D - A over the unique directed edges (diagonal = number of distinct neighbours), mean_i || (L v)_i ||_2; the adjacency as CSR (row_ptr
+ * [V + 1], col [E] int32, a vertex's neighbours in ascending order; symmetric).  Offset penalty (nerf/utils.py:772-789): mean_i |off_i|^2, or
+ * with bound > 1 the inner mesh's mean + 0.1 x the outer meshes' (vertices [0, n_in) inner).
+ * forward: Lv [V, 3] = L v, norm [V], partial [ceil(V / 256)] = per-workgroup sums of lam_lap / V * norm_i + w_i |off_i|^2 with w_i = w_in for
+ *   i < n_in, else w_out (the caller folds lambda_offsets and the group sizes into them; offsets = NULL: the smoothness term alone):
+ *   value = sum(partial).
+ * backward: d_verts [V, 3] from the saved Lv / norm and the incoming gradient (device scalar): d v_i = deg_i gL_i - sum_{j in N(i)} gL_j,
+ *   gL_k = grad lam_lap / V * Lv_k / norm_k (0 where the norm is 0); d_offsets [V, 3] = grad w_i 2 off_i (with offsets, else NULL). */
+int n2m_laplacian_forward(const float* verts, const int32_t* row_ptr, const int32_t* col, uint32_t V, const float* offsets, float lam_lap, float w_in,
+                          float w_out, uint32_t n_in, float* Lv, float* norm, float* partial, void* stream);
+int n2m_laplacian_backward(const float* Lv, const float* norm, const int32_t* row_ptr, const int32_t* col, uint32_t V, const float* grad, float lam_lap,
+                           const float* offsets, float w_in, float w_out, uint32_t n_in, float* d_verts, float* d_offsets, void* stream);
 
 /* Rows of a [N, C] fp32 array by index -- the boolean-mask gather / scatter around the shading of a stage-1 frame (nerf/renderer.py:864,
  * 875-881: `xyzs[mask]`, `rgbs[mask] = ...`) once the covered pixels are an index list: out[k, :] = x[idx[k], :] and dst[idx[k], :] = src[k, :]

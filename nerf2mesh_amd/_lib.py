@@ -110,8 +110,8 @@ SIGNATURES = {
     "n2m_antialias_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _vp, _vp, _vp],
     "n2m_to_clip": [_vp, _vp, _u32, _vp, _vp],
     "n2m_to_clip_backward": [_vp, _vp, _u32, _vp, _vp],
-    "n2m_laplacian_forward": [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp],
-    "n2m_laplacian_backward": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp],
+    "n2m_laplacian_forward": [_vp, _vp, _vp, _u32, _vp, _f32, _f32, _f32, _u32, _vp, _vp, _vp, _vp],
+    "n2m_laplacian_backward": [_vp, _vp, _vp, _vp, _u32, _vp, _f32, _vp, _f32, _f32, _u32, _vp, _vp, _vp],
     "n2m_gather_rows": [_vp, _vp, _u32, _u32, _vp, _vp],
     "n2m_scatter_rows": [_vp, _vp, _u32, _u32, _vp, _vp],
     "n2m_stage1_head": [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp],

@@ -663,16 +663,20 @@ extern "C" int n2m_to_clip_backward(const float* d_clip, const float* mvp, uint3
     return 0;
 }
 
-// ---- uniform-Laplacian smoothness of the stage-1 mesh (nerf/utils.py:176-221): loss = mean_i || deg_i v_i - sum_{j in N(i)} v_j ||_2 over the
-// unique directed edges, as CSR (row_ptr [V + 1], col [E], neighbours of a vertex in ascending order: a fixed summation order).  One launch
-// forward (L = D v - A v, its norms, per-workgroup sums of them), one backward: d v_i = deg_i gL_i - sum_{j in N(i)} gL_j with
-// gL_k = g / V * L_k / ||L_k|| (0 where the norm is 0, like torch's norm backward) -- the adjacency is symmetric, so the adjoint is the same walk.
+// ---- the two mesh regularisers of stage 1 in one launch each way.  Uniform-Laplacian smoothness (nerf/utils.py:176-221):
+// mean_i || deg_i v_i - sum_{j in N(i)} v_j ||_2 over the unique directed edges, as CSR (row_ptr [V + 1], col [E], neighbours of a vertex in
+// ascending order: a fixed summation order); offset penalty (nerf/utils.py:772-789): mean_i |off_i|^2, with bound > 1 the inner mesh's mean +
+// 0.1 x the outer meshes' (vertices [0, n_in) are the inner ones).  forward: L = D v - A v, its norms, per-workgroup sums of
+// lam_lap / V * norm_i + w_i |off_i|^2 (w = lam_off / count of the vertex's group [x 0.1]); backward: d v_i = deg_i gL_i - sum_{j in N(i)} gL_j
+// with gL_k = g lam_lap / V * L_k / ||L_k|| (0 where the norm is 0, like torch's norm backward; the adjacency is symmetric, so the adjoint is
+// the same walk) and d off_i = g w_i 2 off_i.
 __global__ void __launch_bounds__(256)
 laplacian_forward_kernel(const float* __restrict__ v, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col, uint32_t V,
+                         const float* __restrict__ off, float lam_lap, float w_in, float w_out, uint32_t n_in,
                          float* __restrict__ Lv, float* __restrict__ norm, float* __restrict__ partial) {
     __shared__ float red[4];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    float n = 0.0f;
+    float term = 0.0f;
     if (i < V) {
         const int32_t b = row_ptr[i], e = row_ptr[i + 1];
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -682,11 +686,16 @@ laplacian_forward_kernel(const float* __restrict__ v, const int32_t* __restrict_
         }
         const float d = (float)(e - b);
         const float l0 = v[(size_t)i * 3u] * d - s0, l1 = v[(size_t)i * 3u + 1] * d - s1, l2 = v[(size_t)i * 3u + 2] * d - s2;
-        n = sqrtf((l0 * l0 + l1 * l1) + l2 * l2);
+        const float n = sqrtf((l0 * l0 + l1 * l1) + l2 * l2);
         Lv[(size_t)i * 3u] = l0; Lv[(size_t)i * 3u + 1] = l1; Lv[(size_t)i * 3u + 2] = l2;
         norm[i] = n;
+        term = n * (lam_lap / (float)V);
+        if (off) {
+            const float o0 = off[(size_t)i * 3u], o1 = off[(size_t)i * 3u + 1], o2 = off[(size_t)i * 3u + 2];
+            term += ((o0 * o0 + o1 * o1) + o2 * o2) * (i < n_in ? w_in : w_out);
+        }
     }
-    const float w = n2m_wave_sum(n);
+    const float w = n2m_wave_sum(term);
     if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = w;
     __syncthreads();
     if (threadIdx.x == 0u) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -694,10 +703,11 @@ laplacian_forward_kernel(const float* __restrict__ v, const int32_t* __restrict_
 
 __global__ void __launch_bounds__(256)
 laplacian_backward_kernel(const float* __restrict__ Lv, const float* __restrict__ norm, const int32_t* __restrict__ row_ptr,
-                          const int32_t* __restrict__ col, uint32_t V, const float* __restrict__ g, float* __restrict__ d_v) {
+                          const int32_t* __restrict__ col, uint32_t V, const float* __restrict__ g, float lam_lap,
+                          const float* __restrict__ off, float w_in, float w_out, uint32_t n_in, float* __restrict__ d_v, float* __restrict__ d_off) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= V) return;
-    const float gs = *g / (float)V;
+    const float gs = *g * (lam_lap / (float)V);
     auto gl = [&](size_t k, float (&o)[3]) {
         const float n = norm[k];
         const float f = n > 0.0f ? gs / n : 0.0f;
@@ -712,22 +722,31 @@ laplacian_backward_kernel(const float* __restrict__ Lv, const float* __restrict_
     gl((size_t)i, t);
     const float d = (float)(e - b);
     d_v[(size_t)i * 3u] = t[0] * d - s[0]; d_v[(size_t)i * 3u + 1] = t[1] * d - s[1]; d_v[(size_t)i * 3u + 2] = t[2] * d - s[2];
+    if (d_off) {
+        const float f = *g * (i < n_in ? w_in : w_out) * 2.0f;
+#pragma unroll
+        for (uint32_t a = 0; a < 3; ++a) d_off[(size_t)i * 3u + a] = off[(size_t)i * 3u + a] * f;
+    }
 }
 
-extern "C" int n2m_laplacian_forward(const float* verts, const int32_t* row_ptr, const int32_t* col, uint32_t V, float* Lv, float* norm,
-                                     float* partial, void* stream) {
+extern "C" int n2m_laplacian_forward(const float* verts, const int32_t* row_ptr, const int32_t* col, uint32_t V, const float* offsets, float lam_lap,
+                                     float w_in, float w_out, uint32_t n_in, float* Lv, float* norm, float* partial, void* stream) {
     N2M_REQUIRE(verts && row_ptr && col && Lv && norm && partial, N2M_ENULL, "laplacian_forward: NULL tensor");
     if (V == 0) return 0;
-    laplacian_forward_kernel<<<n2m_ceil_div(V, 256), 256, 0, (hipStream_t)stream>>>(verts, row_ptr, col, V, Lv, norm, partial);
+    laplacian_forward_kernel<<<n2m_ceil_div(V, 256), 256, 0, (hipStream_t)stream>>>(verts, row_ptr, col, V, offsets, lam_lap, w_in, w_out, n_in, Lv, norm,
+                                                                                   partial);
     N2M_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int n2m_laplacian_backward(const float* Lv, const float* norm, const int32_t* row_ptr, const int32_t* col, uint32_t V, const float* grad,
-                                      float* d_verts, void* stream) {
+                                      float lam_lap, const float* offsets, float w_in, float w_out, uint32_t n_in, float* d_verts, float* d_offsets,
+                                      void* stream) {
     N2M_REQUIRE(Lv && norm && row_ptr && col && grad && d_verts, N2M_ENULL, "laplacian_backward: NULL tensor");
+    N2M_REQUIRE((offsets == nullptr) == (d_offsets == nullptr), N2M_ENULL, "laplacian_backward: offsets and d_offsets come together");
     if (V == 0) return 0;
-    laplacian_backward_kernel<<<n2m_ceil_div(V, 256), 256, 0, (hipStream_t)stream>>>(Lv, norm, row_ptr, col, V, grad, d_verts);
+    laplacian_backward_kernel<<<n2m_ceil_div(V, 256), 256, 0, (hipStream_t)stream>>>(Lv, norm, row_ptr, col, V, grad, lam_lap, offsets, w_in, w_out, n_in,
+                                                                                    d_verts, d_offsets);
     N2M_CHECK_LAUNCH();
     return 0;
 }

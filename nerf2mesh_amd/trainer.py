@@ -365,33 +365,50 @@ class UniformLaplacian:
 
     def __call__(self, verts):
         if verts.is_cuda and verts.dtype == torch.float32:
-            return _LaplacianLoss.apply(verts, self.row_ptr, self.col)
+            return _MeshRegularisers.apply(verts, None, self.row_ptr, self.col, 1.0, 0.0, 0.0, 0)
         nb = _NeighbourSum.apply(verts, self.ii, self.jj)
         return (verts * self.deg - nb).norm(dim=1).mean()
 
+    def regularisers(self, verts, offsets, lam_lap, lam_off, n_in=None):
+        """lam_lap * laplacian_smooth_loss(verts) + lam_off * the offset penalty of nerf/utils.py:772-789 (n_in: vertices of the inner mesh when
+        bound > 1 -- the outer meshes' mean counts a tenth) as ONE value with one launch each way (n2m_laplacian_*)."""
+        V = verts.shape[0]
+        if n_in is None or n_in >= V or n_in <= 0:
+            n_in, w_in, w_out = V, lam_off / V, 0.0
+        else:
+            w_in, w_out = lam_off / n_in, 0.1 * lam_off / (V - n_in)
+        return _MeshRegularisers.apply(verts, offsets if lam_off > 0 else None, self.row_ptr, self.col, float(lam_lap), float(w_in), float(w_out), int(n_in))
 
-class _LaplacianLoss(torch.autograd.Function):
-    """mean_i || deg_i v_i - sum_{j in N(i)} v_j || through n2m_laplacian_forward / _backward (neighbour sums in the CSR's fixed order)."""
+
+class _MeshRegularisers(torch.autograd.Function):
+    """lam_lap * mean_i || deg_i v_i - sum_{j in N(i)} v_j || [+ sum_i w_i |off_i|^2] through n2m_laplacian_forward / _backward (neighbour sums in
+    the CSR's fixed order)."""
 
     @staticmethod
-    def forward(ctx, verts, row_ptr, col):
+    def forward(ctx, verts, offsets, row_ptr, col, lam_lap, w_in, w_out, n_in):
         from . import _lib as L
         verts = verts.contiguous()
+        offsets = offsets.contiguous() if offsets is not None else None
         V = verts.shape[0]
         Lv, norm = torch.empty_like(verts), torch.empty(V, dtype=torch.float32, device=verts.device)
         partial = torch.empty((V + 255) // 256, dtype=torch.float32, device=verts.device)
-        L.call("n2m_laplacian_forward", L.ptr(verts), L.ptr(row_ptr), L.ptr(col), V, L.ptr(Lv), L.ptr(norm), L.ptr(partial), L.stream())
-        ctx.save_for_backward(Lv, norm, row_ptr, col)
-        return partial.sum() / V
+        L.call("n2m_laplacian_forward", L.ptr(verts), L.ptr(row_ptr), L.ptr(col), V, L.ptr(offsets), lam_lap, w_in, w_out, n_in, L.ptr(Lv), L.ptr(norm),
+               L.ptr(partial), L.stream())
+        ctx.save_for_backward(Lv, norm, row_ptr, col, offsets)
+        ctx.args = (lam_lap, w_in, w_out, n_in)
+        return partial.sum()
 
     @staticmethod
     def backward(ctx, g):
         from . import _lib as L
-        Lv, norm, row_ptr, col = ctx.saved_tensors
+        Lv, norm, row_ptr, col, offsets = ctx.saved_tensors
+        lam_lap, w_in, w_out, n_in = ctx.args
         g = g.float().contiguous()
         d = torch.empty_like(Lv)
-        L.call("n2m_laplacian_backward", L.ptr(Lv), L.ptr(norm), L.ptr(row_ptr), L.ptr(col), Lv.shape[0], L.ptr(g), L.ptr(d), L.stream())
-        return d, None, None
+        d_off = torch.empty_like(Lv) if offsets is not None else None
+        L.call("n2m_laplacian_backward", L.ptr(Lv), L.ptr(norm), L.ptr(row_ptr), L.ptr(col), Lv.shape[0], L.ptr(g), lam_lap, L.ptr(offsets), w_in, w_out,
+               n_in, L.ptr(d), L.ptr(d_off), L.stream())
+        return d, d_off, None, None, None, None, None, None
 
 
 class _NeighbourSum(torch.autograd.Function):
@@ -506,9 +523,16 @@ class Stage1Trainer:
                 model.update_triangles_errors(loss.detach())
             loss = loss.mean()
         self.covered_seen += getattr(model, "last_covered", 0)
-        if opt.lambda_lap > 0:
+        if verts is not None and verts.is_cuda and opt.lambda_lap > 0 and opt.lambda_offsets > 0:
+            # both mesh regularisers (nerf/utils.py:761-789) as one value, one launch each way
+            loss = loss + self.laplacian.regularisers(verts, model.vertices_offsets, opt.lambda_lap, opt.lambda_offsets,
+                                                      int(model.v_cumsum[1]) if opt.bound > 1 else None)
+            reg_done = True
+        else:
+            reg_done = False
+        if opt.lambda_lap > 0 and not reg_done:
             loss = loss + opt.lambda_lap * self.laplacian(verts if verts is not None else model.vertices + model.vertices_offsets)
-        if opt.lambda_offsets > 0:                                           # nerf/utils.py:772-789
+        if opt.lambda_offsets > 0 and not reg_done:                          # nerf/utils.py:772-789
             off = model.vertices_offsets
             if opt.bound > 1:       # inner mesh (cascade 0) + 0.1 x the outer cascades' meshes
                 n_in = int(model.v_cumsum[1])

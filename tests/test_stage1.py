@@ -185,6 +185,22 @@ def test_laplacian_kernels_equal_the_index_add_form():
     # (L v = deg v - sum v_j cancels six digits on a smooth mesh: the two summation orders differ by 1e-7 in L, i.e. 1e-4 in its direction)
     assert float((gx - x.grad).abs().max()) <= 2e-3 * float(x.grad.abs().max())
     assert float(gx[-1].abs().max()) == 0.0 and bool(torch.isfinite(gx).all())
+    # both regularisers of the step as one value (nerf/utils.py:761-789): lam_lap * smoothness + lam_off * offset penalty, plain and with the
+    # inner / outer split of bound > 1
+    off = (1e-3 * torch.randn(v.shape, device=dev, generator=g)).requires_grad_()
+    for n_in in (None, 5000):
+        x.grad = None; off.grad = None
+        got = lap.regularisers(x, off, 0.1, 0.2, n_in)
+        (got * 3.0).backward()
+        gx2, go2 = x.grad.clone(), off.grad.clone()
+        x.grad = None; off.grad = None
+        nb = _NeighbourSum.apply(x, lap.ii, lap.jj)
+        pen = (off ** 2).sum(-1).mean() if n_in is None else (off[:n_in] ** 2).sum(-1).mean() + 0.1 * (off[n_in:] ** 2).sum(-1).mean()
+        want = 0.1 * (x * lap.deg - nb).norm(dim=1).mean() + 0.2 * pen
+        (want * 3.0).backward()
+        assert abs(float(got) - float(want)) <= 3e-6 * float(want)
+        assert float((gx2 - x.grad).abs().max()) <= 2e-3 * float(x.grad.abs().max())
+        assert float((go2 - off.grad).abs().max()) <= 2e-6 * float(off.grad.abs().max())
 
 
 def test_to_clip_kernels_equal_the_broadcast_form():
