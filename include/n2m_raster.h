@@ -103,11 +103,13 @@ int n2m_scatter_rows(const float* src, const int64_t* idx, uint32_t K, uint32_t 
  *        tri_err[trig_id], 1 to tri_cnt[trig_id] for every pixel that shows a face (float atomics, like torch's scatter_add_).
  *   packed_rgba != 0: the two antialias calls were ONE call on an [h0 s, w0 s, 4] image (RGB + alpha: the silhouette blend is per channel, so
  *        the values are the same): aa_rgb = that image, aa_alpha = aa_rgb + 3, pixel stride 4 for both; d_rgb / d_alpha likewise point into
- *        one [h0 s, w0 s, 4] gradient image. */
+ *        one [h0 s, w0 s, 4] gradient image.
+ *   seed (device scalar or NULL): factor on d_alpha / d_rgb -- the loss scale, when the caller knows that the gradient flowing into the mean
+ *        is exactly that scalar (it then skips its own multiplication of the two full-resolution images). */
 int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const float* rast, uint32_t h0, uint32_t w0, uint32_t ssaa,
                     const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask, float* image, float* depth,
                     float* weights_sum, float* trig_id, float* loss_px, float* d_alpha, float* d_rgb, float* partial, float* tri_err,
-                    float* tri_cnt, int packed_rgba, void* stream);
+                    float* tri_cnt, int packed_rgba, const float* seed, void* stream);
 
 #ifdef __cplusplus
 }

@@ -114,7 +114,7 @@ SIGNATURES = {
     "n2m_laplacian_backward": [_vp, _vp, _vp, _vp, _u32, _vp, _f32, _vp, _f32, _f32, _u32, _vp, _vp, _vp],
     "n2m_gather_rows": [_vp, _vp, _u32, _u32, _vp, _vp],
     "n2m_scatter_rows": [_vp, _vp, _u32, _u32, _vp, _vp],
-    "n2m_stage1_head": [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp],
+    "n2m_stage1_head": [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp],
     "n2m_prof_enable": [_int],
     "n2m_prof_reset": [],
     "n2m_prof_read": [_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],

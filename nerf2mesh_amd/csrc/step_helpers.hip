@@ -105,7 +105,7 @@ stage1_head_kernel(const float* __restrict__ aa_alpha /*[h0 S, w0 S]*/, const fl
                    float* __restrict__ image, float* __restrict__ depth, float* __restrict__ wsum, float* __restrict__ trig_id,
                    float* __restrict__ loss_px, float* __restrict__ d_alpha, float* __restrict__ d_rgb, float* __restrict__ partial,
                    float* __restrict__ tri_err, float* __restrict__ tri_cnt, uint32_t sa /*floats per pixel of aa_alpha / d_alpha: 1, or 4 = channel 3 of an RGBA image*/,
-                   uint32_t sr /*of aa_rgb / d_rgb: 3, or 4*/) {
+                   uint32_t sr /*of aa_rgb / d_rgb: 3, or 4*/, const float* __restrict__ seed /*factor on the gradients (the loss scale), or NULL*/) {
     __shared__ float wave_sum[4];
     const uint32_t n = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t N = h0 * w0, w = w0 * S;
@@ -163,7 +163,7 @@ stage1_head_kernel(const float* __restrict__ aa_alpha /*[h0 S, w0 S]*/, const fl
         }
         if (d_alpha) {
             // d mean / d image_c, d mean / d weights_sum (seed 1 / N; the caller scales by the incoming gradient)
-            const float inv = 1.0f / (float)N;
+            const float inv = (seed ? *seed : 1.0f) / (float)N;
             float gi[3], gT = -(inv * lambda_mask * 2.0f * m);                         // weights_sum = 1 - T
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) { gi[ch] = inv * lambda_rgb * (2.0f * e[ch] / 3.0f); gT += gi[ch] * bgc[ch]; }
@@ -784,7 +784,7 @@ extern "C" int n2m_scatter_rows(const float* src, const int64_t* idx, uint32_t K
 extern "C" int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const float* rast, uint32_t h0, uint32_t w0, uint32_t ssaa,
                                const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask, float* image,
                                float* depth, float* weights_sum, float* trig_id, float* loss_px, float* d_alpha, float* d_rgb, float* partial,
-                               float* tri_err, float* tri_cnt, int packed_rgba, void* stream) {
+                               float* tri_err, float* tri_cnt, int packed_rgba, const float* seed, void* stream) {
     N2M_REQUIRE(aa_alpha && aa_rgb && rast && gt_rgba && image && depth && weights_sum && trig_id && loss_px && partial, N2M_ENULL,
                 "stage1_head: NULL tensor");
     N2M_REQUIRE((d_alpha == nullptr) == (d_rgb == nullptr), N2M_ENULL, "stage1_head: d_alpha and d_rgb come together");
@@ -796,11 +796,11 @@ extern "C" int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const
     if (ssaa == 1)
         stage1_head_kernel<1><<<n2m_ceil_div(N, 256), 256, 0, s>>>(aa_alpha, aa_rgb, rast, h0, w0, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask,
                                                                   image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial, tri_err, tri_cnt, packed_rgba ? 4u : 1u,
-                                                                  packed_rgba ? 4u : 3u);
+                                                                  packed_rgba ? 4u : 3u, seed);
     else
         stage1_head_kernel<2><<<n2m_ceil_div(N, 256), 256, 0, s>>>(aa_alpha, aa_rgb, rast, h0, w0, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask,
                                                                   image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial, tri_err, tri_cnt, packed_rgba ? 4u : 1u,
-                                                                  packed_rgba ? 4u : 3u);
+                                                                  packed_rgba ? 4u : 3u, seed);
     N2M_CHECK_LAUNCH();
     return 0;
 }

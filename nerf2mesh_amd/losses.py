@@ -57,7 +57,7 @@ class _stage1_head(Function):
     scaled by the incoming gradient in backward."""
 
     @staticmethod
-    def forward(ctx, aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb, lambda_mask, tri_err=None, tri_cnt=None):
+    def forward(ctx, aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb, lambda_mask, tri_err=None, tri_cnt=None, seed=None):
         # aa_alpha is None: aa_rgb is the [1, h, w, 4] output of ONE antialias call on RGB + alpha
         dev = aa_rgb.device
         packed = aa_alpha is None
@@ -79,8 +79,9 @@ class _stage1_head(Function):
             pa, pda = _p(aa_alpha), _p(d_alpha)
         L.call("n2m_stage1_head", pa, _p(aa_rgb), _p(rast), int(h0), int(w0), int(ssaa), _p(gt_rgba), _p(bg_t), bg_s, float(lambda_rgb),
                float(lambda_mask), _p(image), _p(depth), _p(ws), _p(trig), _p(loss_px), pda, _p(d_rgb), _p(partial), _p(tri_err), _p(tri_cnt),
-               int(packed), L.stream())
+               int(packed), _p(seed), L.stream())
         ctx.grads = (d_alpha, d_rgb)
+        ctx.seeded = seed is not None
         loss = partial.sum() / N
         ctx.mark_non_differentiable(image, depth, ws, trig, loss_px)
         return loss, image, depth, ws, trig, loss_px
@@ -89,15 +90,19 @@ class _stage1_head(Function):
     def backward(ctx, g, *unused):
         d_alpha, d_rgb = ctx.grads
         ctx.grads = None
-        return (d_alpha * g if d_alpha is not None else None), d_rgb * g, None, None, None, None, None, None, None, None, None, None
+        if ctx.seeded:        # the kernel has applied the incoming gradient already (the caller vouches that it IS the seed)
+            return d_alpha, d_rgb, None, None, None, None, None, None, None, None, None, None, None
+        return (d_alpha * g if d_alpha is not None else None), d_rgb * g, None, None, None, None, None, None, None, None, None, None, None
 
 
-def stage1_head(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb=1.0, lambda_mask=0.0, tri_err=None, tri_cnt=None):
+def stage1_head(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb=1.0, lambda_mask=0.0, tri_err=None, tri_cnt=None, seed=None):
     """(loss, image [N,3], depth [N], weights_sum [N], trig_id [N] float, loss_px [N]) of one stage-1 view from the two antialias outputs
     (before their clamp) and the rasteriser's image: nerf/renderer.py:886-913 + the loss of nerf/utils.py:708-721, N = h0 * w0.
     tri_err / tri_cnt [faces] f32: `update_triangles_errors` (nerf/renderer.py:924-943) done by the same launch.
-    aa_alpha = None: aa_rgb is the [1, h, w, 4] output of ONE antialias call on the RGB + alpha image (same values per channel)."""
-    return _stage1_head.apply(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb, lambda_mask, tri_err, tri_cnt)
+    aa_alpha = None: aa_rgb is the [1, h, w, 4] output of ONE antialias call on the RGB + alpha image (same values per channel).
+    seed (device scalar): the gradient that WILL flow into the returned loss -- the loss scale, when the loss enters the total with weight 1 and
+    the total is differentiated with `gradient = seed` (FusedAdamAMP.backward); the kernel then writes the scaled gradients itself."""
+    return _stage1_head.apply(aa_alpha, aa_rgb, rast, gt_rgba, bg, h0, w0, ssaa, lambda_rgb, lambda_mask, tri_err, tri_cnt, seed)
 
 
 class _gather_rows(Function):

@@ -455,6 +455,16 @@ class Stage1Trainer:
             encc = model.encoder_color
             if hasattr(encc, "half_table"):
                 self.optimizer.shadows[encc.embeddings] = lambda: encc.half_table()
+            # as in stage 0: the colour table's gradient stays fp16 (the binned backward writes it, Adam reads it: no fp32 copy), the weight
+            # gradients live in one persistent buffer Adam clears, and the kernels that produce them raise found_inf themselves -- the
+            # foreach inf check then only covers the vertex offsets (it was a 35 us pass over the 49 MB fp32 table gradient)
+            self._amp = {}
+            self.optimizer.half_grads[encc.embeddings] = lambda: self._amp.get("color", {}).get("grad_half")
+            self._mlp_params = [p for m in (model.sigma_net, model.color_net, model.specular_net) for p in m.parameters()]
+            self._amp_mlp = bool(getattr(opt, "fused_mlp", False)) and len(self._mlp_params) == 7
+            if self._amp_mlp:
+                for i, p in enumerate(self._mlp_params):
+                    self.optimizer.ext_grads[p] = lambda i=i: (self._amp.get("mlp", {}).get("dw_views") or [None] * 7)[i]
         else:
             self.optimizer = torch.optim.Adam(params, eps=1e-15, fused=(torch.device(device).type == "cuda"))
         iters = opt.iters
@@ -510,8 +520,9 @@ class Stage1Trainer:
             verts = model.vertices + model.vertices_offsets            # once: the front half and the smoothness loss share it
             rast, aa_alpha, aa_rgb = model._stage1_front(rays_d, self.mvps[v], self.H, self.W, shading, dirs=dirs, packed=self.packed_aa, vertices=verts)
             te = (model.triangles_errors, model.triangles_errors_cnt) if opt.refine else (None, None)      # update_triangles_errors rides along
+            # (seed: with FusedAdamAMP the total loss is differentiated with gradient = loss scale and this term enters it with weight 1)
             loss, _, _, _, trig, loss_px = stage1_head(aa_alpha, aa_rgb, rast, rgba, bg, self.H, self.W, int(opt.ssaa), opt.lambda_rgb,
-                                                       max(opt.lambda_mask, 0.0), *te)
+                                                       max(opt.lambda_mask, 0.0), *te, seed=self.optimizer.scale if self.amp_adam else None)
         else:
             gt_mask = rgba[:, 3:]
             gt_rgb = rgba[:, :3] * gt_mask + bg * (1 - gt_mask)
@@ -541,8 +552,19 @@ class Stage1Trainer:
                 loss_offsets = (off ** 2).sum(-1).mean()
             loss = loss + opt.lambda_offsets * loss_offsets
         if self.amp_adam:
-            self.optimizer.backward(loss)
-            self.optimizer.step()
+            o = self.optimizer
+            fused_field = bool(getattr(opt, "fused_mlp", False))
+            self._amp = {"color": dict(found_inf=o.found_inf, flagged=False, keep_half=fused_field)}
+            model.encoder_color.amp_request = self._amp["color"]
+            if self._amp_mlp:
+                self._amp["mlp"] = dict(found_inf=o.found_inf, flagged=False, persistent_dw=True)
+                model.amp_request = self._amp["mlp"]
+            o.backward(loss)
+            model.encoder_color.amp_request = model.amp_request = None
+            flagged = [model.encoder_color.embeddings] if self._amp["color"]["flagged"] else []
+            if "mlp" in self._amp and self._amp["mlp"]["flagged"]:
+                flagged += self._mlp_params
+            o.step(flagged=flagged)
         else:
             self.scaler.scale(loss).backward()
             if self.sync is not None:

@@ -22,10 +22,15 @@ def test_render_stage1_and_step(fused):
     for _ in range(500):
         tr.scheduler.step()               # past the warm-up, so that a dozen steps are enough to see the loss move
     assert abs(tr.optimizer.param_groups[0]["lr"] - opt.lr) < 1e-9
+    w0_color = tr.model.color_net.net[0].weight.detach().clone()
     losses = [float(tr.train_step().detach()) for _ in range(12)]
     m = tr.model
     assert m.vertices_offsets.grad is not None and m.vertices_offsets.grad.abs().sum() > 0, "no gradient reached the vertices"
-    assert m.encoder_color.embeddings.grad.abs().sum() > 0 and m.color_net.net[0].weight.grad.abs().sum() > 0
+    if fused:       # fused field: the colour table's gradient is the fp16 buffer the optimizer read, the weight gradients a buffer it cleared
+        assert tr._amp["color"]["grad_half"].float().abs().sum() > 0
+        assert float((m.color_net.net[0].weight - w0_color).abs().sum()) > 0, "the colour MLP did not move"
+    else:
+        assert m.encoder_color.embeddings.grad.abs().sum() > 0 and m.color_net.net[0].weight.grad.abs().sum() > 0
     assert m.encoder.embeddings.grad is None or m.encoder.embeddings.grad.abs().sum() == 0     # density branch is not used in stage 1
     assert m.triangles_errors_cnt.sum() > 0
     assert sum(losses[-4:]) < sum(losses[:4]), losses
@@ -125,8 +130,8 @@ def test_stage1_step_with_and_without_the_fused_head():
         tr.fused_head = fused
         loss = float(tr.train_step().detach())
         m = tr.model
-        outs.append((loss, m.vertices_offsets.grad.clone(), m.encoder_color.embeddings.grad.clone().float(), m.triangles_errors.clone(),
-                     m.triangles_errors_cnt.clone()))
+        ecol = tr._amp["color"]["grad_half"] if m.encoder_color.embeddings.grad is None else m.encoder_color.embeddings.grad   # (fp16, read by the optimizer)
+        outs.append((loss, m.vertices_offsets.grad.clone(), ecol.clone().float(), m.triangles_errors.clone(), m.triangles_errors_cnt.clone()))
     (la, va, ea, ta, ca), (lb, vb, eb, tb, cb) = outs
     assert abs(la - lb) <= 1e-5 * abs(la)
     assert torch.equal(ca, cb) and float((ta - tb).abs().max()) <= 1e-5 * float(ta.abs().max())
