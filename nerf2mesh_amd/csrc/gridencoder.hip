@@ -2811,12 +2811,17 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
 
 // ---- SDF recipe: which (copy, level) pairs fold into their centre sample (FoldArgs), and the others as one compact list per level
 namespace {
-__global__ void __launch_bounds__(1024)
+constexpr uint32_t kFoldThreads = 512u;                    // 2^18 samples = 512 workgroups: two per CU, no half-empty second round
+__global__ void __launch_bounds__(kFoldThreads)
 sdf_fold_plan_kernel(const float* __restrict__ xyz, uint32_t M, float eps, float bound, uint32_t max_level, LevelTable lv, bool align_corners,
                      uint8_t* __restrict__ flags /*[L, M]*/, float* __restrict__ left_pts01 /*[L, cap, 3]*/, uint32_t* __restrict__ left_src /*[L, cap]*/,
                      uint32_t cap, uint32_t* __restrict__ counters /*[2][kMaxLevels]*/, uint32_t parity) {
-    __shared__ uint32_t wave_tot[16], wave_base[16];
-    const uint32_t tid = threadIdx.x, m = blockIdx.x * 1024u + tid, lane = tid & 63u, wid = tid >> 6;
+    // two barriers per workgroup, not three per level (the first version: 54 us for 2^18 samples): every wave scans all levels' counts first
+    // (lane totals in LDS), then thread l places level l's sixteen wave totals with ONE atomic, then everybody writes its entries
+    constexpr uint32_t kFoldLevels = 16u;                  // (loops unrolled over a constant bound: per-level values stay in registers)
+    constexpr uint32_t kWaves = kFoldThreads / 64u;
+    __shared__ uint32_t wave_tot[kFoldLevels][kWaves], wave_base[kFoldLevels][kWaves];
+    const uint32_t tid = threadIdx.x, m = blockIdx.x * kFoldThreads + tid, lane = tid & 63u, wid = tid >> 6;
     if (blockIdx.x == 0u && tid < kMaxLevels) counters[(parity ^ 1u) * kMaxLevels + tid] = 0u;      // the other step's counters: nobody reads them any more
     float x[3] = {0.f, 0.f, 0.f}, p01[6], c01[3] = {2.f, 2.f, 2.f};
     bool centre_in = false;
@@ -2835,7 +2840,12 @@ sdf_fold_plan_kernel(const float* __restrict__ xyz, uint32_t M, float eps, float
         p01[c] = (pw + bound) / (2.0f * bound);
     }
     const float half = align_corners ? 0.0f : 0.5f;
-    for (uint32_t l = 0; l < max_level; ++l) {
+    unsigned long long fl_all[2] = {0ull, 0ull};          // 6 bits per level, levels 0..9 | 10..15
+    uint32_t before[kFoldLevels];                          // this thread's offset inside its wave's part of each level's list
+#pragma unroll
+    for (uint32_t l = 0; l < kFoldLevels; ++l) {
+        before[l] = 0u;
+        if (l >= max_level) continue;                      // (block-uniform)
         const float scale = lv.scale[l];
         uint32_t fl = 0u;
         if (centre_in) {
@@ -2845,31 +2855,37 @@ sdf_fold_plan_kernel(const float* __restrict__ xyz, uint32_t M, float eps, float
         }
         const uint32_t n_left = m < M ? 6u - (uint32_t)__builtin_popcount(fl) : 0u;
         if (m < M) flags[(size_t)l * M + m] = (uint8_t)fl;
-        // this level's list of the other copies (order: by workgroup arrival -- the sums they feed are order-free fixed point or float atomics)
+        fl_all[l / 10u] |= (unsigned long long)fl << (6u * (l % 10u));
         const uint32_t incl = n2m_wave_scan_add_u32(n_left, 0);
-        if (lane == 63u) wave_tot[wid] = incl;
-        __syncthreads();
-        if (tid == 0u) {
-            uint32_t run = 0u;
-            for (uint32_t w = 0; w < 16u; ++w) { wave_base[w] = run; run += wave_tot[w]; }
-            const uint32_t base = run != 0u ? atomicAdd(counters + parity * kMaxLevels + l, run) : 0u;
-            for (uint32_t w = 0; w < 16u; ++w) wave_base[w] += base;
-        }
-        __syncthreads();
-        uint32_t j = wave_base[wid] + incl - n_left;
-        if (m < M) {
+        before[l] = incl - n_left;
+        if (lane == 63u) wave_tot[l][wid] = incl;
+    }
+    __syncthreads();
+    if (tid < max_level) {                                 // level tid: its sixteen wave totals, one atomic for the workgroup
+        uint32_t run = 0u;
+        for (uint32_t w = 0; w < kWaves; ++w) { wave_base[tid][w] = run; run += wave_tot[tid][w]; }
+        const uint32_t base = run != 0u ? atomicAdd(counters + parity * kMaxLevels + tid, run) : 0u;
+        for (uint32_t w = 0; w < kWaves; ++w) wave_base[tid][w] += base;
+    }
+    __syncthreads();
+    if (m >= M) return;
+    // the lists (order: by workgroup arrival -- the sums they feed are order-free fixed point or float atomics)
 #pragma unroll
-            for (uint32_t c = 0; c < 6; ++c) {
-                if ((fl >> c) & 1u) continue;
-                float* dst = left_pts01 + ((size_t)l * cap + j) * 3u;
+    for (uint32_t l = 0; l < kFoldLevels; ++l) {
+        if (l >= max_level) continue;
+        const uint32_t fl = (uint32_t)(fl_all[l / 10u] >> (6u * (l % 10u))) & 63u;
+        if (fl == 63u) continue;
+        uint32_t j = wave_base[l][wid] + before[l];
 #pragma unroll
-                for (uint32_t a = 0; a < 3; ++a)      // the other axes: n2m_sdf_offsets clamps them too
-                    dst[a] = a == (c >> 1) ? p01[c] : (fminf(fmaxf(x[a] + 0.0f, -bound), bound) + bound) / (2.0f * bound);
-                left_src[(size_t)l * cap + j] = m * 6u + c;
-                ++j;
-            }
+        for (uint32_t c = 0; c < 6; ++c) {
+            if ((fl >> c) & 1u) continue;
+            float* dst = left_pts01 + ((size_t)l * cap + j) * 3u;
+#pragma unroll
+            for (uint32_t a = 0; a < 3; ++a)      // the other axes: n2m_sdf_offsets clamps them too
+                dst[a] = a == (c >> 1) ? p01[c] : (fminf(fmaxf(x[a] + 0.0f, -bound), bound) + bound) / (2.0f * bound);
+            left_src[(size_t)l * cap + j] = m * 6u + c;
+            ++j;
         }
-        __syncthreads();
     }
 }
 
@@ -2894,10 +2910,10 @@ extern "C" int n2m_sdf_fold_plan(const float* xyz, uint32_t M, float eps, float 
                                  uint32_t parity, void* stream) {
     const char* fn = "sdf_fold_plan";
     N2M_REQUIRE(xyz && flags && left_pts01 && left_src && counters, N2M_ENULL, "%s: NULL tensor", fn);
-    N2M_REQUIRE(L >= 1 && L <= kMaxLevels && max_level <= L && parity <= 1u && eps > 0.0f && bound > 0.0f && (uint64_t)cap >= 6ull * M, N2M_EINVAL,
+    N2M_REQUIRE(L >= 1 && L <= kMaxLevels && max_level <= L && max_level <= 16u && parity <= 1u && eps > 0.0f && bound > 0.0f && (uint64_t)cap >= 6ull * M, N2M_EINVAL,
                 "%s: bad arguments (cap must hold all 6 M copies)", fn);
     if (M == 0) return 0;
-    sdf_fold_plan_kernel<<<n2m_ceil_div(M, 1024), 1024, 0, (hipStream_t)stream>>>(xyz, M, eps, bound, max_level, make_levels(L, S, H), align_corners != 0,
+    sdf_fold_plan_kernel<<<n2m_ceil_div(M, kFoldThreads), kFoldThreads, 0, (hipStream_t)stream>>>(xyz, M, eps, bound, max_level, make_levels(L, S, H), align_corners != 0,
                                                                                  flags, left_pts01, left_src, cap, counters, parity);
     N2M_CHECK_LAUNCH();
     return 0;

@@ -215,7 +215,7 @@ sdf_offsets_kernel(const float* __restrict__ xyz, uint32_t M, float eps, float b
             const float off = (a == (k >> 1)) ? ((k & 1) ? -eps : eps) : 0.0f;
             const float p = fminf(fmaxf(x[a] + off, -bound), bound);
             pts[o + a] = p;
-            pts01[o + a] = (p + bound) / (2.0f * bound);
+            if (pts01) pts01[o + a] = (p + bound) / (2.0f * bound);
         }
     }
 }
@@ -587,7 +587,7 @@ extern "C" int n2m_photo_loss_backward(const float* image, const float* weights_
 }
 
 extern "C" int n2m_sdf_offsets(const float* xyz, uint32_t M, float eps, float bound, float* pts, float* pts01, void* stream) {
-    N2M_REQUIRE(xyz && pts && pts01, N2M_ENULL, "sdf_offsets: NULL tensor");
+    N2M_REQUIRE(xyz && pts, N2M_ENULL, "sdf_offsets: NULL tensor");      // pts01 = NULL: a caller that encodes from its own lists (n2m_sdf_fold_*)
     N2M_REQUIRE(eps > 0.0f && bound > 0.0f, N2M_EINVAL, "sdf_offsets: eps and bound must be positive");
     if (M == 0) return 0;
     sdf_offsets_kernel<<<n2m_ceil_div(M, 256), 256, 0, (hipStream_t)stream>>>(xyz, M, eps, bound, pts, pts01);
