@@ -2135,6 +2135,482 @@ bin_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, LevelTable lv, u
     }
 }
 
+// =====================================================================================================================================
+// Partition-major update log (round 4).  The tile-major log above keeps every tile's entries together (one contiguous segment per tile,
+// sorted by partition) and leaves the gathering to the accumulate: a work item walks one SHORT run per tile (64-130 entries = a 128 B +
+// a 256 B piece somewhere in a 170 MB log) -- DRAM efficiency on short scattered READS, which a wave has to wait for, is what that
+// kernel costs, and it forces 1024-sample tiles (shorter runs lost more in the accumulate than they won in the fill).  Here the
+// scatter is moved to the WRITE side, which nobody waits for: every (level, partition) owns one contiguous region of the log, a fill
+// workgroup reserves room for its tile's run with ONE returning atomic per partition (cursor[level][partition] += n) and stores the
+// run there; the accumulate then streams ONE contiguous array per partition -- no directory, no per-tile round trips -- and tiles can
+// be as small as the fill likes: 512-sample tiles = two independent fill workgroups per CU whose phases (stencil gathers | LDS sort |
+// stores) overlap each other, which is what the barrier-serialised 1024-thread workgroup could not do.  The order of the runs inside
+// a region depends on the atomics' order; the sum is 64-bit fixed point, i.e. exact and order-independent as before.
+//   Region capacity is 2 x the partition's expected share (+ slack): a run that does not fit goes to ONE shared overflow log
+// (bump-allocated records {level | partition | row, value, value}); a work item whose cursor passed its capacity scans that log for
+// its records.  Never taken by marched samples (hashed rows are uniform, dense levels deal 16-row blocks round-robin); a batch with
+// every sample in one cell takes it and stays exact.  The overflow log holds every entry of the pass, so nothing can be dropped.
+struct PmPlan {
+    uint32_t cur_base[kMaxLevels];      // first cursor word of the level (one u32 per partition)
+    uint32_t home_cap[kMaxLevels];      // entries one partition's region holds
+    uint32_t home_base[kMaxLevels];     // first entry of the level's regions: partition p at home_base + p * home_cap
+    uint32_t max_parts, cursors;        // largest partition count of a level (LDS sizing), cursor words in all
+    uint32_t ovf_cap;                   // records the overflow log holds (= every entry of the pass)
+};
+
+// TS = samples per tile = threads per workgroup.  LDS (dynamic): three u32 staging arrays of 8 TS entries, then
+// cnt[2][MP] start[MP] delta[MP] ovfb[MP] with MP = pm.max_parts rounded up to 128.
+template <int TV, bool FOLD, uint32_t TS>
+__global__ void __launch_bounds__(TS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Float16* __restrict__ grad2 /*[L,Bstride,2]*/,
+                    const float* __restrict__ inputs, TvParams tv, const float* __restrict__ tv_terms, uint32_t B, uint32_t Bstride, BinPlan plan,
+                    PmPlan pm, LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max /*[2][32]*/,
+                    uint32_t* __restrict__ cursors, uint32_t* __restrict__ ovf_cursor, uint16_t* __restrict__ log_rel, uint32_t* __restrict__ log_v1,
+                    uint32_t* __restrict__ log_v2, uint32_t* __restrict__ ovf_key, uint32_t* __restrict__ ovf_v1, uint32_t* __restrict__ ovf_v2,
+                    float* __restrict__ found_inf, float in_scale, float in_offset, float* __restrict__ clear1, _Float16* __restrict__ clear2,
+                    uint32_t clear_mask1, uint32_t clear_mask2, uint32_t merge_levels, uint32_t groups_x, uint32_t slot_begin,
+                    unsigned long long* __restrict__ lm_ready, unsigned long long lm_token, uint32_t in_level_stride, FoldArgs fold) {
+    constexpr uint32_t D = 3, kWaves = TS / 64u, kEntries = TS * 8u;
+    constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    // Workgroup 0 (always resident first) clears the level maxima, the cursors and the overflow cursor, then publishes this launch's
+    // token; a workgroup waits for the token before its first reservation (a whole entries phase later: never seen to spin).
+    if (blockIdx.x == 0u && blockIdx.y == 0u) {
+        if (threadIdx.x < 2u * kMaxLevels) level_max[threadIdx.x] = 0u;
+        for (uint32_t i = threadIdx.x; i < pm.cursors; i += TS) cursors[i] = 0u;
+        if (threadIdx.x == 0u) *ovf_cursor = 0u;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0u) __hip_atomic_store(lm_ready, lm_token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    extern __shared__ __attribute__((aligned(16))) uint32_t pm_lds[];
+    const uint32_t MP = (pm.max_parts + 127u) & ~127u;
+    uint32_t* stage_v1 = pm_lds;
+    uint32_t* stage_v2 = stage_v1 + kEntries;
+    uint32_t* stage_e = stage_v2 + kEntries;             // partition << 16 | row in partition
+    uint32_t* cnt2 = stage_e + kEntries;                 // [2][MP]
+    uint32_t* start = cnt2 + 2u * MP;                    // first position of the partition's run in the sorted tile
+    uint32_t* delta = start + MP;                        // log index of an entry = delta[partition] + its position in the tile
+    uint32_t* ovfb = delta + MP;                         // overflowing runs only: first record of the run's tail in the overflow log
+    __shared__ uint32_t wave_max[2][kWaves], tile_ovf[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    uint32_t level = blockIdx.y, group = blockIdx.x, n_groups = gridDim.x;
+    if (groups_x != 0u) {                                // XCD-aware 1-D grid: see bin_fill_pair_kernel
+        const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+        const uint32_t ls = k / groups_x;
+        const uint32_t slot = slot_begin + ls;
+        group = k - ls * groups_x;
+        n_groups = groups_x;
+        const uint32_t pairi = xcd + 8u * (slot >> 1);
+        level = (slot & 1u) ? pairi : plan.levels - 1u - pairi;
+        if (level >= plan.levels || pairi > plan.levels - 1u - pairi || ((slot & 1u) && pairi == plan.levels - 1u - pairi)) return;
+    }
+    const uint32_t parts = plan.parts[level], size = plan.size[level];
+    for (uint32_t i = tid; i < 2u * MP; i += TS) cnt2[i] = 0u;
+    if (tid < 2u) tile_ovf[tid] = 0u;
+    if ((clear_mask1 | clear_mask2) >> level & 1u) {     // overwrite mode: levels that receive atomics start from zero
+        const uint32_t per = (size + n_groups - 1) / n_groups, lo = min(size, group * per), hi = min(size, lo + per);
+        const size_t r0 = plan.row0[level];
+        if (clear_mask1 >> level & 1u)
+            for (uint32_t i = lo + tid; i < hi; i += TS) clear1[r0 + i] = 0.0f;
+        if (clear_mask2 >> level & 1u)
+            for (uint32_t i = lo + tid; i < hi; i += TS) reinterpret_cast<uint32_t*>(clear2)[r0 + i] = 0u;
+    }
+    const float scale = lv.scale[level];
+    const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
+    const PartMap pmap(parts, 0, kLog2P, !ix.hashed && parts > 1u);
+    const bool fast_hash = ix.hashed && ix.pow2, fast_dense = !ix.hashed && !ix.wrap;
+    const uint32_t cap = pm.home_cap[level], region0 = pm.home_base[level];
+    uint32_t* __restrict__ cur_l = cursors + pm.cur_base[level];
+    float vmax1 = 0.0f, vmax2 = 0.0f;
+    bool token_seen = false;
+    const uint32_t dbg = g_fill_timing_on;               // measurement switches (tools/pm_lab.sh; wrong results when set)
+
+    uint32_t tile = group;
+    float nx[D] = {2.f, 2.f, 2.f}, ng1 = 0.0f, ntv = 0.0f;
+    h2 ng2 = {(_Float16)0, (_Float16)0};
+    auto request = [&](uint32_t t) {
+        const uint32_t s = t * TS + tid;
+        nx[0] = nx[1] = nx[2] = 2.f;
+        if (t < plan.tiles && s < B) {
+            load_point<D>(inputs + (size_t)level * in_level_stride, s, nx);
+#pragma unroll
+            for (uint32_t d = 0; d < D; ++d) nx[d] = nx[d] * in_scale + in_offset;
+            ng1 = grad1 ? grad1[(size_t)level * Bstride + s] : 0.0f;
+            if (grad2) ng2 = *reinterpret_cast<const h2*>(grad2 + ((size_t)level * Bstride + s) * 2);
+            else ng2 = h2{(_Float16)0, (_Float16)0};
+            if (TV == 2) ntv = tv_terms[(size_t)level * Bstride + s];
+        }
+    };
+    request(tile);
+    __syncthreads();
+
+    for (uint32_t it = 0; tile < plan.tiles; tile += n_groups, ++it) {
+        uint32_t* cnt = cnt2 + (it & 1u) * MP;
+        uint32_t* cnt_next = cnt2 + ((it & 1u) ^ 1u) * MP;
+        float x[D] = {nx[0], nx[1], nx[2]};
+        const float g1 = ng1, tvg = ntv;
+        const h2 g2 = ng2;
+        request(tile + n_groups);
+
+        uint32_t e_pr[8], e_v1[8], e_v2[8], e_slot[8];
+        float f1[8], f2x[8], f2y[8];
+        uint32_t cell[D] = {0u, 0u, 0u};
+        uint32_t vmask = 0;
+        const bool inside = !outside_unit_cube<D>(x);
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) { f1[c] = 0.f; f2x[c] = 0.f; f2y[c] = 0.f; e_pr[c] = 0u; }
+        if (inside) {
+            const float g2x = (float)g2.x, g2y = (float)g2.y;
+            const float a1 = fabsf(g1), a2 = fmaxf(fabsf(g2x), fabsf(g2y));
+            vmax1 = fmaxf(vmax1, a1 <= 3.0e38f ? a1 : 1.0f);
+            vmax2 = fmaxf(vmax2, a2 <= 3.0e38f ? a2 : 1.0f);
+            const bool bad2 = !(fabsf(g2x) <= 3.0e38f) || !(fabsf(g2y) <= 3.0e38f);
+            if ((!(a1 <= 3.0e38f) || bad2) && found_inf) *found_inf = 1.0f;
+            if (bad2) vmax2 = fmaxf(vmax2, 1.0f);
+            const PairCtx cx{tv, tv.table ? tv.table + (size_t)plan.row0[level] * tv.stride : nullptr, scale, lv.resolution[level], align_corners, interp};
+            if (fast_hash) pair_entries<TV, 1, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
+            else if (fast_dense && parts > 1u) pair_entries<TV, 2, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
+            else if (fast_dense) pair_entries<TV, 2, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
+            else pair_entries<TV, 0, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
+            if constexpr (FOLD) {
+                const uint32_t sidx = tile * TS + tid;
+                const uint32_t fl = fold.flags[(size_t)level * B + sidx];
+                if (fl != 0u) fold_copies(fold, sidx, level, x, scale, align_corners, interp, fl, f1, vmax1, found_inf);
+            }
+        }
+        bool keep = inside;
+        if (level < merge_levels && !(dbg & 64u)) {
+            keep = merge_runs(inside, cell, f1, f2x, f2y, lane) && inside;
+            if (keep) {
+                float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                for (uint32_t c = 0; c < 8; ++c) { m1 = fmaxf(m1, fabsf(f1[c])); m2 = fmaxf(m2, fmaxf(fabsf(f2x[c]), fabsf(f2y[c]))); }
+                vmax1 = fmaxf(vmax1, m1 <= 3.0e38f ? m1 : 1.0f);
+                vmax2 = fmaxf(vmax2, m2 <= 65504.0f ? m2 : 65504.0f);
+                if ((!(m1 <= 3.0e38f) || !(m2 <= 65504.0f)) && found_inf) *found_inf = 1.0f;
+            }
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) {
+            h2 p2;
+            p2.x = (_Float16)f2x[c];
+            p2.y = (_Float16)f2y[c];
+            e_v1[c] = __float_as_uint(f1[c]);
+            e_v2[c] = __builtin_bit_cast(uint32_t, p2);
+            if (keep && ((e_v1[c] << 1) | (e_v2[c] & 0x7FFF7FFFu)) != 0u) vmask |= 1u << c;
+        }
+        // slot of every entry inside its partition's run of this tile
+        if (dbg & 16u) {
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c) e_slot[c] = c;
+        } else if (parts == 1u) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c) {
+                const bool v = (vmask >> c) & 1u;
+                const unsigned long long m = __ballot(v);
+                uint32_t base = 0;
+                if (lane == 0 && m) base = atomicAdd(&cnt[0], (uint32_t)__popcll(m));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                e_slot[c] = base + (uint32_t)__popcll(m & below);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c)
+                if ((vmask >> c) & 1u) e_slot[c] = atomicAdd(&cnt[e_pr[c] >> 16], 1u);
+        }
+        __syncthreads();                                                     // (1) counters complete
+
+        // Run starts: EVERY wave scans the counters itself (128 per step, two per lane) and writes the same values -- a wave reads
+        // back what it has written itself (LDS operations of a wave complete in order), so no barrier separates scan and staging.
+        // Wave 0 also reserves the runs' room in the partitions' regions.
+        uint32_t total = 0;
+        uint32_t q0 = 0u, q1 = 0u, ra0 = 0u, ra1 = 0u, rs0 = 0u, rs1 = 0u;     // wave 0: the first 128 partitions' reservation (in flight over the staging)
+        for (uint32_t c0 = 0; c0 < parts; c0 += 128u) {
+            const uint32_t i0 = c0 + 2u * lane, i1 = i0 + 1u;
+            const uint32_t a0 = i0 < parts ? cnt[i0] : 0u, a1c = i1 < parts ? cnt[i1] : 0u;
+            const uint32_t incl = n2m_wave_scan_add_u32(a0 + a1c, (int)lane);
+            const uint32_t s0 = total + incl - (a0 + a1c), s1 = s0 + a0;
+            if (i0 < parts) start[i0] = s0;
+            if (i1 < parts) start[i1] = s1;
+            total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (wid == 0u && c0 == 0u) {
+                if (!token_seen) {
+                    while (__hip_atomic_load(lm_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != lm_token) __builtin_amdgcn_s_sleep(8);
+                    token_seen = true;
+                }
+                ra0 = a0; ra1 = a1c; rs0 = s0; rs1 = s1;
+                if (a0 && !(dbg & 32u)) q0 = atomicAdd(cur_l + i0, a0);
+                if (a1c && !(dbg & 32u)) q1 = atomicAdd(cur_l + i1, a1c);
+            }
+        }
+        if (!(dbg & 8u))
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c)
+            if ((vmask >> c) & 1u) {
+                const uint32_t pos = start[e_pr[c] >> 16] + e_slot[c];
+                stage_v1[pos] = e_v1[c];
+                stage_v2[pos] = e_v2[c];
+                stage_e[pos] = e_pr[c];
+            }
+        for (uint32_t i = tid; i < parts; i += TS) cnt_next[i] = 0;
+        if (tid == 0u) tile_ovf[(it & 1u) ^ 1u] = 0u;
+        if (wid == 0u) {
+            bool ovf_here = false;
+            auto finish = [&](uint32_t i, uint32_t a, uint32_t s, uint32_t q) {
+                if (a == 0u) return;
+                delta[i] = region0 + i * cap + q - s;
+                if (q + a > cap) {                       // (part of) the run does not fit its region: the shared overflow log takes the rest
+                    ovfb[i] = atomicAdd(ovf_cursor, min(a, q + a - cap));
+                    ovf_here = true;
+                }
+            };
+            finish(2u * lane, ra0, rs0, q0);
+            finish(2u * lane + 1u, ra1, rs1, q1);
+            for (uint32_t c0 = 128u; c0 < parts; c0 += 128u) {             // tables with more than 128 partitions per level
+                const uint32_t i0 = c0 + 2u * lane, i1 = i0 + 1u;
+                const uint32_t a0 = i0 < parts ? cnt[i0] : 0u, a1c = i1 < parts ? cnt[i1] : 0u;
+                uint32_t p0 = 0u, p1 = 0u;
+                if (a0) p0 = atomicAdd(cur_l + i0, a0);
+                if (a1c) p1 = atomicAdd(cur_l + i1, a1c);
+                finish(i0, a0, a0 ? start[i0] : 0u, p0);
+                finish(i1, a1c, a1c ? start[i1] : 0u, p1);
+            }
+            if (__ballot(ovf_here) != 0ull && lane == 0u) tile_ovf[it & 1u] = 1u;
+        }
+        __syncthreads();                                                     // (2) tile staged, regions reserved
+
+        if (dbg & 12u) {
+        } else if (tile_ovf[it & 1u] == 0u) {
+            // plain (cache-allocating) stores: a run is a 64-256 byte piece at an arbitrary offset of its region -- neighbouring runs complete
+            // each other's lines in L2 (measured: streaming stores 190 us, plain 172 us per fill at 512-sample tiles)
+            if (!(dbg & 2u)) {              // (measurement switch: bit 1 = streaming stores)
+                for (uint32_t i = tid; i < total; i += TS) {
+                    const uint32_t e = stage_e[i], d = delta[e >> 16] + i;
+                    if (log_v1) log_v1[d] = stage_v1[i];
+                    if (log_v2) log_v2[d] = stage_v2[i];
+                    log_rel[d] = (uint16_t)e;
+                }
+            } else {
+                for (uint32_t i = tid; i < total; i += TS) {
+                    const uint32_t e = stage_e[i], d = delta[e >> 16] + i;
+                    if (log_v1) __builtin_nontemporal_store(stage_v1[i], &log_v1[d]);
+                    if (log_v2) __builtin_nontemporal_store(stage_v2[i], &log_v2[d]);
+                    __builtin_nontemporal_store((uint16_t)e, &log_rel[d]);
+                }
+            }
+        } else {
+            for (uint32_t i = tid; i < total; i += TS) {
+                const uint32_t e = stage_e[i], p = e >> 16;
+                const uint32_t st = start[p];
+                const uint32_t qr = delta[p] + st - (region0 + p * cap);           // where the run starts in its region
+                const uint32_t qi = qr + (i - st);                                  // this entry's place in the partition's stream
+                if (qi < cap) {
+                    const uint32_t d = delta[p] + i;
+                    if (log_v1) log_v1[d] = stage_v1[i];
+                    if (log_v2) log_v2[d] = stage_v2[i];
+                    log_rel[d] = (uint16_t)e;
+                } else {
+                    const uint32_t o = ovfb[p] + qi - max(qr, cap);
+                    if (o < pm.ovf_cap) {
+                        ovf_key[o] = (level << 27) | e;
+                        if (ovf_v1) ovf_v1[o] = stage_v1[i];
+                        if (ovf_v2) ovf_v2[o] = stage_v2[i];
+                    }
+                }
+            }
+        }
+        // no barrier here: the next tile writes the stage / start / delta only after its barrier (1)
+    }
+
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        vmax1 = fmaxf(vmax1, __shfl_xor(vmax1, o, 64));
+        vmax2 = fmaxf(vmax2, __shfl_xor(vmax2, o, 64));
+    }
+    if (lane == 0) { wave_max[0][wid] = __float_as_uint(vmax1); wave_max[1][wid] = __float_as_uint(vmax2); }
+    __syncthreads();
+    if (tid < 2u) {
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kWaves; ++w) m = max(m, wave_max[tid][w]);
+        uint32_t* dst = level_max + tid * kMaxLevels + level;
+        while (__hip_atomic_load(lm_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != lm_token) __builtin_amdgcn_s_sleep(8);
+        if (m > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, m);
+    }
+}
+
+// One work item = (level, SUB adjacent partitions[, slice grp of Gl]): streams the partitions' regions (contiguous arrays) into the
+// 64-bit fixed-point LDS accumulator, then flushes like bin_accumulate_kernel.
+template <typename T, uint32_t C, uint32_t P, uint32_t SUB>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, LevelTable lv, uint32_t gridtype, bool align_corners,
+                     const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ ovf_cursor,
+                     const uint16_t* __restrict__ log_rel, const uint32_t* __restrict__ log_val, const uint32_t* __restrict__ ovf_key,
+                     const uint32_t* __restrict__ ovf_val, float* __restrict__ found_inf, bool overwrite, uint32_t dbg, float inf_bound) {
+    constexpr uint32_t kLog2P = 31u - __builtin_clz(P);
+    extern __shared__ __attribute__((aligned(16))) unsigned long long bin_acc[];   // SUB * P * C
+    __shared__ uint32_t nonfinite_seen;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t total_items = plan.item_prefix[plan.levels];
+    for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x) {
+        uint32_t level = 0;
+        while (item >= plan.item_prefix[level + 1]) ++level;
+        const uint32_t vm_v = __hip_atomic_load(level_max + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t Gl = plan.groups[level];
+        const bool store_all = overwrite && Gl == 1u;
+        if (!store_all && (uint32_t)__builtin_amdgcn_readfirstlane((int)vm_v) == 0u) continue;
+        const uint32_t local = item - plan.item_prefix[level];
+        const uint32_t part0 = (local / Gl) * SUB, grp = local - (local / Gl) * Gl;
+        const uint32_t parts = plan.parts[level], size = plan.size[level];
+        const uint32_t part_end = min(part0 + SUB, parts);
+        const Indexer<3> ix(size, lv.resolution[level], gridtype, align_corners);
+        const bool interleaved = !ix.hashed && parts > 1u;
+        const uint32_t row0 = plan.row0[level];
+        const uint32_t n_blocks = (size + 15u) >> 4;
+        auto rows_of = [&](uint32_t part) {
+            const uint32_t my_blocks = interleaved ? (part < n_blocks ? (n_blocks - part + parts - 1) / parts : 0u)
+                                                   : min(P / 16u, n_blocks - min(n_blocks, part * (P / 16u)));
+            return my_blocks << 4;
+        };
+        auto global_row = [&](uint32_t u, uint32_t rel) {
+            return interleaved ? ((((rel >> 4) * parts + part0 + u) << 4) | (rel & 15u)) : (((part0 + u) << kLog2P) + rel);
+        };
+        T* __restrict__ gtab = grad_table + (size_t)row0 * C;
+        // the cursors through the vector memory path, requested before the accumulator is cleared
+        uint32_t n_all[SUB];
+#pragma unroll
+        for (uint32_t u = 0; u < SUB; ++u)
+            n_all[u] = part0 + u < part_end ? __hip_atomic_load(cursors + pm.cur_base[level] + part0 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        for (uint32_t i = tid; i < SUB * P * C; i += 1024) bin_acc[i] = 0ull;
+        if (tid == 0) nonfinite_seen = 0u;
+        __syncthreads();
+        const uint32_t vm = (uint32_t)__builtin_amdgcn_readfirstlane((int)vm_v);
+        int ex = 37 - ((int)((vm >> 23) & 255u) - 127);
+        ex = ex < -126 ? -126 : (ex > 126 ? 126 : ex);
+        const float scale = __uint_as_float((uint32_t)(ex + 127) << 23);
+        const float inv = __uint_as_float((uint32_t)(127 - ex) << 23);
+        const uint32_t cap = pm.home_cap[level];
+        auto walk = [&](auto&& body) {
+            if (vm == 0u) return;
+#pragma unroll
+            for (uint32_t u = 0; u < SUB; ++u) {
+                const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_all[u]);
+                const uint32_t n = min(nu, cap);
+                // slice of this tile group: boundaries on multiples of 4 entries (the last slice ends at n)
+                const uint32_t lo = Gl == 1u ? 0u : (uint32_t)(((uint64_t)n * grp / Gl) & ~3ull);
+                const uint32_t hi = (Gl == 1u || grp + 1u == Gl) ? n : (uint32_t)(((uint64_t)n * (grp + 1u) / Gl) & ~3ull);
+                const size_t base = (size_t)pm.home_base[level] + (size_t)(part0 + u) * cap;
+                const uint16_t* __restrict__ rp = log_rel + base;
+                const uint32_t* __restrict__ vp = log_val + base;
+                for (uint32_t i0 = lo + tid; i0 < hi; i0 += 4096u) {
+                    uint32_t r[4], v[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const uint32_t i = i0 + k * 1024u;
+                        r[k] = 0u; v[k] = 0u;
+                        if (i < hi) { r[k] = rp[i]; v[k] = vp[i]; }
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k)
+                        if (i0 + k * 1024u < hi) body(r[k], u, v[k]);
+                }
+                if (nu > cap && grp == 0u) {             // records of this partition in the shared overflow log
+                    const uint32_t n_ovf = min(__hip_atomic_load(ovf_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), pm.ovf_cap);
+                    const uint32_t want = (level << 11) | (part0 + u);
+                    for (uint32_t i = tid; i < n_ovf; i += 1024u) {
+                        const uint32_t k = ovf_key[i];
+                        if ((k >> 16) == want) body(k & 0xFFFFu, u, ovf_val[i]);
+                    }
+                }
+            }
+        };
+        auto bypass = [&](uint32_t rel0, uint32_t u, uint32_t bits) {
+            if constexpr (sizeof(T) == 4) unsafeAtomicAdd(gtab + global_row(u, rel0), __uint_as_float(bits));
+            else {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(gtab + (size_t)global_row(u, rel0) * 2u),
+                                                                __builtin_bit_cast(h2, bits));
+            }
+        };
+        auto finite = [&](uint32_t bits) {
+            if constexpr (sizeof(T) == 4) return fabsf(__uint_as_float(bits)) <= 3.0e38f;
+            else {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 p = __builtin_bit_cast(h2, bits);
+                return fabsf((float)p.x) <= 3.0e38f && fabsf((float)p.y) <= 3.0e38f;
+            }
+        };
+        walk([&](uint32_t rel0, uint32_t u, uint32_t bits) {
+            const uint32_t rel = rel0 + u * P;
+            if (!finite(bits)) {
+                if (store_all) nonfinite_seen = 1u;
+                else bypass(rel0, u, bits);
+                return;
+            }
+            if constexpr (sizeof(T) == 4) {
+                if (bits << 1) __hip_atomic_fetch_add(&bin_acc[rel], (unsigned long long)to_fixed(__uint_as_float(bits), scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 p = __builtin_bit_cast(h2, bits);
+                const float v0 = (float)p.x, v1 = (float)p.y;
+                if (v0 != 0.f) __hip_atomic_fetch_add(&bin_acc[rel * 2u], (unsigned long long)to_fixed(v0, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (v1 != 0.f) __hip_atomic_fetch_add(&bin_acc[rel * 2u + 1u], (unsigned long long)to_fixed(v1, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        });
+        __syncthreads();
+        const bool second_walk = store_all && nonfinite_seen != 0u;
+        for (uint32_t rel = tid; rel < ((dbg & 2u) ? 0u : SUB * P); rel += 1024) {
+            const uint32_t u = rel >> kLog2P, rel0 = rel & (P - 1u);
+            if (part0 + u >= part_end || rel0 >= rows_of(part0 + u)) continue;
+            const uint32_t row = global_row(u, rel0);
+            if (row >= size) continue;
+            if constexpr (sizeof(T) == 4) {
+                const long long a = (long long)bin_acc[rel];
+                if (a != 0 || store_all) {
+                    const float f = (float)a * inv;
+                    if (!(fabsf(f) <= (inf_bound > 0.0f ? inf_bound : 3.0e38f)) && found_inf) *found_inf = 1.0f;
+                    if (store_all) gtab[row] = f;
+                    else if (Gl == 1u) gtab[row] += f;
+                    else unsafeAtomicAdd(gtab + row, f);
+                }
+            } else {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const long long a0 = (long long)bin_acc[rel * 2u], a1 = (long long)bin_acc[rel * 2u + 1u];
+                if ((a0 | a1) != 0 || store_all) {
+                    const float f0 = (float)a0 * inv, f1 = (float)a1 * inv;
+                    const float b16 = inf_bound > 0.0f ? inf_bound : 65504.0f;
+                    if (!(fabsf(f0) <= b16 && fabsf(f1) <= b16) && found_inf) *found_inf = 1.0f;
+                    h2* dst = reinterpret_cast<h2*>(gtab + (size_t)row * 2u);
+                    if (store_all) {
+                        h2 o;
+                        o.x = (_Float16)f0;
+                        o.y = (_Float16)f1;
+                        *dst = o;
+                    } else if (Gl == 1u) {
+                        h2 o = *dst;
+                        o.x = (_Float16)((float)o.x + f0);
+                        o.y = (_Float16)((float)o.y + f1);
+                        *dst = o;
+                    } else {
+                        h2 val;
+                        val.x = (_Float16)f0;
+                        val.y = (_Float16)f1;
+                        (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)dst, val);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (second_walk) {
+            __threadfence();
+            walk([&](uint32_t rel0, uint32_t u, uint32_t bits) { if (!finite(bits)) bypass(rel0, u, bits); });
+            __syncthreads();
+        }
+    }
+}
+
 // grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]; accumulates in T like the reference (:357-365)
 template <typename T, uint32_t D, uint32_t C>
 __global__ void grid_input_backward_kernel(const T* __restrict__ grad, const T* __restrict__ dy_dx, T* __restrict__ grad_inputs,
@@ -2399,6 +2875,209 @@ int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table
 }
 
 
+
+// ---- partition-major log: layout and launches (kernels: pm_fill_pair_kernel, pm_accumulate_kernel)
+struct PmLayout {
+    PmPlan pm;
+    size_t home_entries, bytes;
+    bool ok;
+};
+
+// Bc = samples of a pass.  Region capacity = 2 x the partition's expected share of the level's 8 Bc entries + slack, never more than
+// all of them (small batches: no overflow possible at all).
+PmLayout make_pm_plan(uint32_t Bc, const BinPlan& plan) {
+    PmLayout o{};
+    o.ok = true;
+    uint64_t home = 0;
+    uint32_t cur = 0, mp = 1;
+    const uint64_t all = ((uint64_t)8 * Bc + 255u) & ~(uint64_t)255u;
+    for (uint32_t l = 0; l < plan.levels; ++l) {
+        const uint32_t parts = plan.parts[l];
+        uint64_t cap = (2u * (((uint64_t)8 * Bc + parts - 1) / parts) + 2048u + 255u) & ~(uint64_t)255u;
+        if (cap > all) cap = all;
+        o.pm.cur_base[l] = cur;
+        o.pm.home_cap[l] = (uint32_t)cap;
+        o.pm.home_base[l] = (uint32_t)home;
+        home += cap * parts;
+        cur += parts;
+        mp = parts > mp ? parts : mp;
+    }
+    o.pm.max_parts = mp;
+    o.pm.cursors = cur;
+    const uint64_t ovf = (uint64_t)plan.levels * 8u * Bc;
+    o.pm.ovf_cap = (uint32_t)ovf;
+    if (home >= (1ull << 32) || ovf >= (1ull << 32) || mp > kMaxPartsPerLevel) o.ok = false;
+    o.home_entries = (size_t)home;
+    const size_t r = 255;
+    o.bytes = kBinHeaderBytes + (((size_t)cur * 4 + r) & ~r) + ((home * 4 + r) & ~r) * 2 + ((home * 2 + r) & ~r) + (((size_t)ovf * 4 + r) & ~r) * 3;
+    return o;
+}
+
+static uint32_t pm_tile_samples() {
+    static const uint32_t ts = [] {
+        const char* e = getenv("N2M_PM_TS");
+        const uint32_t v = e ? (uint32_t)atoi(e) : 512u;
+        return (v == 256u || v == 512u || v == 1024u) ? v : 512u;
+    }();
+    return ts;
+}
+static bool pm_enabled() {
+    static const bool on = getenv("N2M_BIN_PM") == nullptr || atoi(getenv("N2M_BIN_PM")) != 0;
+    return on;
+}
+
+template <uint32_t TS>
+int launch_pm_fill(dim3 grid, size_t lds, hipStream_t s, bool fold_on, int tvmode, const float* g1, const _Float16* g2, const float* x, TvParams tv,
+                   const float* tvt, uint32_t Bc, uint32_t B, const BinPlan& plan, const PmPlan& pm, const LevelTable& lv, uint32_t gridtype, bool align,
+                   uint32_t interp, uint32_t* level_max, uint32_t* cursors, uint32_t* ovf_cursor, uint16_t* log_rel, uint32_t* log_v1, uint32_t* log_v2,
+                   uint32_t* ovf_key, uint32_t* ovf_v1, uint32_t* ovf_v2, float* found_inf, float in_scale, float in_offset, float* clear1,
+                   _Float16* clear2, uint32_t cm1, uint32_t cm2, uint32_t merge_levels, uint32_t groups_x, uint32_t slot_begin,
+                   unsigned long long* lm_ready, unsigned long long lm_token, uint32_t in_level_stride, const FoldArgs& fo) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int cap = 160 * 1024 - 1024;
+        (void)hipFuncSetAttribute((const void*)pm_fill_pair_kernel<0, false, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)pm_fill_pair_kernel<1, false, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)pm_fill_pair_kernel<2, false, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)pm_fill_pair_kernel<0, true, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)pm_fill_pair_kernel<1, true, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        attr_set = true;
+    }
+#define N2M_PM_ARGS g1, g2, x, tv, tvt, Bc, B, plan, pm, lv, gridtype, align, interp, level_max, cursors, ovf_cursor, log_rel, log_v1, log_v2, ovf_key, ovf_v1, \
+                    ovf_v2, found_inf, in_scale, in_offset, clear1, clear2, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token, in_level_stride, fo
+    if (fold_on) {
+        if (tvmode == 1) pm_fill_pair_kernel<1, true, TS><<<grid, TS, lds, s>>>(N2M_PM_ARGS);
+        else pm_fill_pair_kernel<0, true, TS><<<grid, TS, lds, s>>>(N2M_PM_ARGS);
+    } else if (tvmode == 1) pm_fill_pair_kernel<1, false, TS><<<grid, TS, lds, s>>>(N2M_PM_ARGS);
+    else if (tvmode == 2) pm_fill_pair_kernel<2, false, TS><<<grid, TS, lds, s>>>(N2M_PM_ARGS);
+    else pm_fill_pair_kernel<0, false, TS><<<grid, TS, lds, s>>>(N2M_PM_ARGS);
+#undef N2M_PM_ARGS
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+// returns -1 when the partition-major path does not cover the call (the caller then runs the tile-major path)
+int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float* inputs, TvParams tv, float* table1, _Float16* table2, uint32_t B,
+                          uint32_t max_level, const int32_t* host_offsets, const LevelTable& lv, uint32_t gridtype, bool align, uint32_t interp,
+                          void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn, float* found_inf, float in_scale,
+                          float in_offset, bool overwrite, uint32_t L, int half, const float* tv_terms, const FoldArgs* fold, uint32_t in_level_stride) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)pm_accumulate_kernel<float, 1, kPairP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
+        (void)hipFuncSetAttribute((const void*)pm_accumulate_kernel<_Float16, 2, kPairP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
+        attr_set = true;
+    }
+    const uint32_t TS = pm_tile_samples();
+    N2M_REQUIRE(in_level_stride == 0 || B <= kBinChunk, N2M_EINVAL, "%s: per-level point lists need one pass (B <= %u)", fn, kBinChunk);
+    for (uint32_t b0 = 0; b0 < B; b0 += kBinChunk) {
+        const uint32_t Bc = B - b0 < kBinChunk ? B - b0 : kBinChunk;
+        BinLayout lay = make_bin_plan(Bc, 2, max_level, host_offsets, false, kPairP, 2);
+        N2M_REQUIRE(lay.ok, N2M_EUNSUPPORTED, "%s: table layout not supported by the binned path", fn);
+        lay.plan.tiles = (Bc + TS - 1) / TS;
+        const PmLayout pl = make_pm_plan(Bc, lay.plan);
+        if (!pl.ok) return -1;
+        N2M_REQUIRE(workspace_bytes >= pl.bytes, N2M_EINVAL, "%s: workspace too small (%zu < %zu bytes)", fn, workspace_bytes, pl.bytes);
+        const size_t r = 255;
+        char* w = (char*)workspace;
+        uint32_t* level_max = (uint32_t*)w;
+        unsigned long long* lm_ready = (unsigned long long*)(w + 256);
+        uint32_t* ovf_cursor = (uint32_t*)(w + 264);
+        uint32_t* cursors = (uint32_t*)(w + kBinHeaderBytes);
+        w += kBinHeaderBytes + (((size_t)pl.pm.cursors * 4 + r) & ~r);
+        uint32_t* log_v1 = (uint32_t*)w; w += (pl.home_entries * 4 + r) & ~r;
+        uint32_t* log_v2 = (uint32_t*)w; w += (pl.home_entries * 4 + r) & ~r;
+        uint16_t* log_rel = (uint16_t*)w; w += (pl.home_entries * 2 + r) & ~r;
+        uint32_t* ovf_key = (uint32_t*)w; w += ((size_t)pl.pm.ovf_cap * 4 + r) & ~r;
+        uint32_t* ovf_v1 = (uint32_t*)w; w += ((size_t)pl.pm.ovf_cap * 4 + r) & ~r;
+        uint32_t* ovf_v2 = (uint32_t*)w;
+        static std::atomic<unsigned long long> launch_counter{1};
+        const unsigned long long lm_token = (0x6e326d50ull << 32) | (launch_counter.fetch_add(1) & 0xFFFFFFFFull);
+        const bool ow = overwrite && b0 == 0;
+        const bool both = grad1 != nullptr, has2 = grad2 != nullptr;
+        const float* g1 = both ? grad1 + (size_t)b0 : nullptr;
+        if (!both) { log_v1 = nullptr; ovf_v1 = nullptr; }
+        const _Float16* g2 = has2 ? grad2 + (size_t)b0 * 2 : nullptr;
+        if (!has2) { log_v2 = nullptr; ovf_v2 = nullptr; }
+        const float* x = inputs + (size_t)b0 * 3;
+        auto in_half = [&](uint32_t l) { return half == 0 || (half == 1 ? l >= 8u : l < 8u); };
+        BinPlan plan1 = lay.plan, plan2 = lay.plan;
+        uint32_t items1 = 0, items2 = 0, cm1 = 0, cm2 = 0;
+        for (uint32_t l = 0; l < max_level; ++l) {
+            const uint32_t pairs = (plan1.parts[l] + 1u) / 2u;
+            const uint64_t per_item = (uint64_t)8 * Bc / pairs;
+            uint32_t g = (uint32_t)((per_item + 65535u) / 65536u);
+            g = g < 1u ? 1u : (g > 64u ? 64u : g);
+            uint32_t g2n = lay.plan.groups[l];                      // (make_bin_plan clamped it to ITS tile count)
+            plan1.groups[l] = g;
+            plan2.groups[l] = g2n;
+            plan1.item_prefix[l] = items1;
+            plan2.item_prefix[l] = items2;
+            if (!in_half(l)) continue;
+            items1 += pairs * g;
+            items2 += lay.plan.parts[l] * g2n;
+            if (ow && g > 1u && both) cm1 |= 1u << l;
+            if (ow && g2n > 1u && has2) cm2 |= 1u << l;
+        }
+        plan1.item_prefix[max_level] = items1;
+        plan2.item_prefix[max_level] = items2;
+        if (ow && max_level < L) {
+            const size_t t0 = (size_t)host_offsets[max_level], t1 = (size_t)host_offsets[L];
+            if (both) N2M_HIP(hipMemsetAsync(table1 + t0, 0, (t1 - t0) * sizeof(float), s));
+            if (has2) N2M_HIP(hipMemsetAsync(table2 + t0 * 2u, 0, (t1 - t0) * 2u * sizeof(_Float16), s));
+        }
+        static const uint32_t merge_env = getenv("N2M_BIN_MERGE_LEVELS") ? (uint32_t)atoi(getenv("N2M_BIN_MERGE_LEVELS")) : kPairMergeLevels;
+        const uint32_t merge_levels = has2 ? merge_env : kMaxLevels;
+        static const bool xcd_map = getenv("N2M_FILL_NO_XCD") == nullptr;
+        static const uint32_t tiles_per_wg = getenv("N2M_PM_TILES") ? (uint32_t)atoi(getenv("N2M_PM_TILES")) : kPairTilesPerWg;
+        dim3 grid((lay.plan.tiles + tiles_per_wg - 1) / tiles_per_wg, max_level);
+        uint32_t groups_x = 0, slot_begin = 0;
+        N2M_REQUIRE(half == 0 || (xcd_map && max_level == 16u && (half == 1 || half == 2)), N2M_EUNSUPPORTED,
+                    "%s: level halves need max_level == 16 and the XCD-aware fill", fn);
+        if (xcd_map && (max_level == 16u || half != 0)) {
+            groups_x = grid.x;
+            uint32_t slots = 2u * ((max_level + 15u) / 16u);
+            if (half != 0) { slot_begin = (uint32_t)half - 1u; slots = 1u; }
+            grid = dim3(8u * slots * groups_x, 1);
+        }
+        const float* tvt = tv_terms ? tv_terms + (size_t)b0 : nullptr;
+        FoldArgs fo{};
+        if (fold) {
+            N2M_REQUIRE(both && !tvt && B <= kBinChunk && half == 0 && in_level_stride == 0, N2M_EINVAL,
+                        "%s: folded copies need the density gradient, one pass (B <= %u), all levels and one point list", fn, kBinChunk);
+            fo = *fold;
+            fo.stride6 = 6u * B;
+        }
+        const uint32_t MP = (pl.pm.max_parts + 127u) & ~127u;
+        const size_t lds = (size_t)TS * 8u * 12u + (size_t)MP * 5u * 4u;
+        const int tvmode = tv.table ? 1 : (tvt ? 2 : 0);
+        int rc;
+#define N2M_PM_CALL(TSV) launch_pm_fill<TSV>(grid, lds, s, fold != nullptr, tvmode, g1, g2, x, tv, tvt, Bc, B, lay.plan, pl.pm, lv, gridtype, align, interp, level_max, \
+                                             cursors, ovf_cursor, log_rel, log_v1, log_v2, ovf_key, ovf_v1, ovf_v2, found_inf, in_scale, in_offset,                   \
+                                             ow ? table1 : nullptr, ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token,      \
+                                             in_level_stride, fo)
+        if (TS == 256u) rc = N2M_PM_CALL(256);
+        else if (TS == 1024u) rc = N2M_PM_CALL(1024);
+        else rc = N2M_PM_CALL(512);
+#undef N2M_PM_CALL
+        if (rc) return rc;
+        static const uint32_t acc_cap = getenv("N2M_ACC_GRID") ? (uint32_t)atoi(getenv("N2M_ACC_GRID")) : 4096u;
+        static const uint32_t acc_dbg = getenv("N2M_ACC_DEBUG") ? (uint32_t)atoi(getenv("N2M_ACC_DEBUG")) : 0u;
+        const float odiv = g_cfg_overflow_div.load();
+        if (both) {
+            pm_accumulate_kernel<float, 1, kPairP, 2><<<items1 < acc_cap ? items1 : acc_cap, 1024, kPairP * 16, s>>>(
+                table1, plan1, pl.pm, lv, gridtype, align, level_max, cursors, ovf_cursor, log_rel, log_v1, ovf_key, ovf_v1, found_inf, ow, acc_dbg, 3.0e38f / odiv);
+            N2M_CHECK_LAUNCH();
+        }
+        if (has2) {
+            pm_accumulate_kernel<_Float16, 2, kPairP, 1><<<items2 < acc_cap ? items2 : acc_cap, 1024, kPairP * 16, s>>>(
+                table2, plan2, pl.pm, lv, gridtype, align, level_max + kMaxLevels, cursors, ovf_cursor, log_rel, log_v2, ovf_key, ovf_v2, found_inf, ow, acc_dbg,
+                65504.0f / odiv);
+            N2M_CHECK_LAUNCH();
+        }
+    }
+    return 0;
+}
+
 int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* inputs, TvParams tv, float* table1, _Float16* table2, uint32_t B,
                        uint32_t max_level, const int32_t* host_offsets, const LevelTable& lv, uint32_t gridtype, bool align, uint32_t interp,
                        void* workspace, size_t workspace_bytes, hipStream_t s, const char* fn, float* found_inf, float in_scale,
@@ -2417,6 +3096,11 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<float, 1, kPairP, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
         (void)hipFuncSetAttribute((const void*)bin_accumulate_kernel<_Float16, 2, kPairP, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
         attr_set = true;
+    }
+    if (pm_enabled() && !fuse1 && !fuse2) {                     // partition-major log (round 4); -1: layout not covered, tile-major path below
+        const int rc = launch_binned_pair_pm(grad1, grad2, inputs, tv, table1, table2, B, max_level, host_offsets, lv, gridtype, align, interp, workspace,
+                                             workspace_bytes, s, fn, found_inf, in_scale, in_offset, overwrite, L, half, tv_terms, fold, in_level_stride);
+        if (rc != -1) return rc;
     }
     N2M_REQUIRE(in_level_stride == 0 || B <= kBinChunk, N2M_EINVAL, "%s: per-level point lists need one pass (B <= %u)", fn, kBinChunk);
     for (uint32_t b0 = 0; b0 < B; b0 += kBinChunk) {
@@ -2738,7 +3422,9 @@ extern "C" uint64_t n2m_grid_binned_pair_workspace_bytes(uint32_t B, uint32_t ma
     if (!host_offsets || B == 0) return 0;
     if (B > kBinChunk) B = kBinChunk;
     const BinLayout lay = make_bin_plan(B, 2, max_level, host_offsets, false, kPairP, 2);
-    return lay.ok ? (uint64_t)lay.bytes : 0;
+    if (!lay.ok) return 0;
+    const PmLayout pl = make_pm_plan(B, lay.plan);          // the partition-major layout needs more room (regions at twice the expected fill + overflow log)
+    return (uint64_t)(pl.ok && pl.bytes > lay.bytes ? pl.bytes : lay.bytes);
 }
 
 static int binned_pair_entry(const float* grad1, const void* grad2, const float* inputs, const int32_t* host_offsets,

@@ -1416,3 +1416,49 @@ def test_binned_pair_backward_with_a_level_cap_equals_the_scatter_backward(be, B
                 assert d <= tol, f"{name}, level {l}: max |diff| {d:.3g} against the scatter backward (values up to {float(ref.abs().max()):.3g})"
         assert float(g1[hi:].abs().max()) == 0.0 and float(g2[hi:].float().abs().max()) == 0.0, "overwrite mode defines the untouched levels as zero"
         assert float(g2[:hi].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("hot_fraction", [1.0, 0.5])
+def test_binned_pair_backward_with_a_hot_cell_takes_the_overflow_log(be, hot_fraction):
+    """The partition-major update log gives every (level, partition) a region of twice its expected share; a batch whose samples pile up
+    in one cell (here: 2^17 samples, all or half of them inside a cube of 1e-5) overruns the regions of the eight rows' partitions on every
+    level, and the rest goes through the shared overflow log.  The sums stay exact: fp32 table against the scatter backward
+    n2m_grid_encode_backward (which shares no code with the binned path), fp16 table against the same scatter run in fp32 (each product is
+    rounded to half first, like the reference's: 2^-11 relative)."""
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L
+    from nerf2mesh_amd.gridencoder import GridEncoder, _host_offsets
+    p = L.ptr
+    B = 2 ** 17
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.rand(B, 3, device="cuda", generator=g)
+    n_hot = int(B * hot_fraction)
+    x[:n_hot] = torch.tensor([0.3712, 0.6161, 0.4443], device="cuda") + 1e-5 * torch.rand(n_hot, 3, device="cuda", generator=g)
+    x = x[torch.randperm(B, device="cuda", generator=g)].contiguous()
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    e2 = GridEncoder(level_dim=2, desired_resolution=2048).cuda()
+    rows = e1.embeddings.shape[0]
+    ho = _host_offsets(e1)
+    S, H0 = float(np.log2(e1.per_level_scale)), int(e1.base_resolution)
+    d1 = torch.randn(16, B, device="cuda", generator=g) * 1e-3
+    d2f = torch.randn(16, B, 2, device="cuda", generator=g) * 0.01
+    d2 = d2f.half()
+    need = L.lib().n2m_grid_binned_pair_workspace_bytes(B, 16, ho.ctypes.data)
+    ws = L.workspace(x.device, need)
+    L.grid_backward_config(1, 1.0)
+    finf = torch.zeros((), device="cuda")
+    geo = (16, 16, S, H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id)
+    ref1 = torch.zeros(rows, 1, device="cuda"); ref2 = torch.zeros(rows, 2, device="cuda")
+    L.call("n2m_grid_encode_backward", p(d1), p(x), p(e1.embeddings.detach()), p(e1.offsets), p(ref1), B, 3, 1, 16, 16, S, H0, None, None, e1.gridtype_id,
+           int(bool(e1.align_corners)), e1.interp_id, L.F32, L.stream())
+    L.call("n2m_grid_encode_backward", p(d2.float().contiguous()), p(x), p(e2.embeddings.detach().float().contiguous()), p(e2.offsets), p(ref2), B, 3, 2, 16, 16,
+           S, H0, None, None, e2.gridtype_id, int(bool(e2.align_corners)), e2.interp_id, L.F32, L.stream())
+    for overwrite in (0, 1):
+        g1 = torch.full((rows, 1), 7.0 * overwrite, device="cuda"); g2 = torch.full((rows, 2), 7.0 * overwrite, device="cuda", dtype=torch.float16)
+        L.call("n2m_grid_encode_backward_binned_pair", p(d1), p(d2), p(x), ho.ctypes.data, p(g1), p(g2), B, *geo, None, 0.0, 0.0, 1.0, None, p(finf),
+               1.0, 0.0, overwrite, p(ws), ws.numel(), L.stream())
+        torch.cuda.synchronize()
+        assert float(finf) == 0.0
+        # a hot row sums ~1e5 terms: the scatter adds them in fp32 arrival order (relative error ~1e-4 of the row), the binned sum is exact
+        np.testing.assert_allclose(g1.cpu().numpy(), ref1.cpu().numpy(), rtol=2e-3, atol=2e-5 * float(ref1.abs().max()))
+        np.testing.assert_allclose(g2.float().cpu().numpy(), ref2.cpu().numpy(), rtol=4e-3, atol=2e-3 * float(ref2.abs().max()))

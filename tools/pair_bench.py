@@ -14,6 +14,7 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--levels", action="store_true")
 ap.add_argument("--B", type=int, default=2 ** 18)
 ap.add_argument("--uniform", action="store_true", help="incoherent inputs U[0,1)^3 instead of ray samples")
+ap.add_argument("--add", action="store_true", help="add onto the tables (overwrite = 0) instead of the training step's overwrite mode")
 args = ap.parse_args()
 dev = torch.device("cuda")
 
@@ -46,11 +47,11 @@ emb = e1.embeddings.detach()
 def run(tv, ml=16):
     tvp = (emb, 1e-8, 1e-8, 1.0, None) if tv else None
     for _ in range(3):
-        assert binned_backward_pair(e1, e2, g1, g2, x, t1, t2, ml, tv=tvp)
+        assert binned_backward_pair(e1, e2, g1, g2, x, t1, t2, ml, tv=tvp, overwrite=not args.add)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(args.reps):
-        binned_backward_pair(e1, e2, g1, g2, x, t1, t2, ml, tv=tvp)
+        binned_backward_pair(e1, e2, g1, g2, x, t1, t2, ml, tv=tvp, overwrite=not args.add)
     b.record(); torch.cuda.synchronize()
     return 1e3 * a.elapsed_time(b) / args.reps
 
