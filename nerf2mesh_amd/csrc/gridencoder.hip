@@ -1315,7 +1315,14 @@ constexpr uint32_t kPairMergeLevels = 9;             // levels (from the coarses
 // corners 100 / 010 / 001, -1 neighbours cost one subtraction each (was: seven generic Indexer::row calls per sample and level).
 struct PairCtx {
     TvParams tv; const float* tv_tab; float scale; uint32_t resolution; bool align_corners; uint32_t interp;
+    float tv_w_in, tv_w_out;      // the TV weight of an inner / outer sample: (weight [* *scale_ptr]) / 6, the reference's operations once per kernel
 };
+// (w = inner ? weight : weight_outer; w *= *scale_ptr; w /= 2 D -- an IEEE division, ten instructions, per (sample, level) until round 4)
+__device__ __forceinline__ PairCtx make_pair_ctx(const TvParams& tv, const float* tv_tab, float scale, uint32_t resolution, bool align_corners, uint32_t interp) {
+    float wi = tv.weight, wo = tv.weight_outer;
+    if (tv.table && tv.scale_ptr) { const float s = *tv.scale_ptr; wi *= s; wo *= s; }
+    return PairCtx{tv, tv_tab, scale, resolution, align_corners, interp, wi / 6.0f, wo / 6.0f};
+}
 
 // TV term of one (sample, level): gridencoder.cu:505-609 on the cell floor(x * scale + 0.5) -- vertex 000 of the interpolation cell.  One
 // function for the fill that computes it in place (TV mode 1) and for the stand-alone pre-pass n2m_grid_tv_terms (whose result the fill
@@ -1328,9 +1335,7 @@ __device__ __forceinline__ float pair_tv_value(const PairCtx& cx, const Indexer<
     auto comb = [&](uint32_t a, uint32_t b, uint32_t c) { return IMODE == 1 ? ((a ^ b ^ c) & ix.mask) : (a + b + c); };
     float tvv = 0.0f;
         const bool inner = fmaxf(fmaxf(fabsf(x[0] - 0.5f), fabsf(x[1] - 0.5f)), fabsf(x[2] - 0.5f)) <= cx.tv.inner01;
-        float w = (inner ? cx.tv.weight : cx.tv.weight_outer);
-        if (cx.tv.scale_ptr) w *= *cx.tv.scale_ptr;
-        w /= (float)(2 * D);
+        const float w = inner ? cx.tv_w_in : cx.tv_w_out;
         if constexpr (IMODE == 0) tvv = tv_term(cx.tv_tab, ix, cell, rows[0], cx.resolution, w, cx.tv.stride);
         else {
             // gridencoder.cu:505-609, neighbours in the reference's order: +x -x +y -y +z -z; out-of-grid ones are skipped
@@ -1373,7 +1378,9 @@ __device__ __forceinline__ float pair_tv_value(const PairCtx& cx, const Indexer<
 #pragma unroll
             for (uint32_t k = 0; k < 6; ++k)
                 if (nb_ok[k]) { const float dv = centre - nb[k]; sum += dv; sq += dv * dv; }
-            tvv = w * sum * (1.0f / sqrtf(sq + 1e-9f));
+            // rsqrtf like the reference (gridencoder.cu:606; an approximate intrinsic there too): v_rsq_f32, 1 ulp -- IEEE sqrt + IEEE division
+            // were ~22 instructions per (sample, level) in a kernel whose SIMDs are busy issuing VALU work more than half of the time
+            tvv = w * sum * __builtin_amdgcn_rsqf(sq + 1e-9f);
         }
     return tvv;
 }
@@ -1464,6 +1471,7 @@ __device__ __forceinline__ bool merge_runs(bool inside, const uint32_t (&cell)[3
 #pragma unroll
     for (int d = 1; d <= 8; d <<= 1) {
         const bool take = dist >= (uint32_t)d;
+        if (__ballot(take) == 0ull) break;                           // no run of this wave is longer than d lanes: the later steps add nothing
 #pragma unroll
         for (uint32_t c = 0; c < 8; ++c) {
             const float a = dpp_row_shr(f1[c], d), b = dpp_row_shr(f2x[c], d), e = dpp_row_shr(f2y[c], d);
@@ -1491,7 +1499,7 @@ tv_terms_kernel(const float* __restrict__ inputs, TvParams tv, uint32_t B, uint3
     if (!outside_unit_cube<D>(x)) {
         const uint32_t size = plan.size[level];
         const Indexer<D> ix(size, lv.resolution[level], gridtype, align_corners);
-        const PairCtx cx{tv, tv.table + (size_t)plan.row0[level] * tv.stride, lv.scale[level], lv.resolution[level], align_corners, interp};
+        const PairCtx cx = make_pair_ctx(tv, tv.table + (size_t)plan.row0[level] * tv.stride, lv.scale[level], lv.resolution[level], align_corners, interp);
         const bool fast_hash = ix.hashed && ix.pow2, fast_dense = !ix.hashed && !ix.wrap;
         uint32_t cell[D];
         float frac[D], dfrac[D];
@@ -1694,7 +1702,7 @@ bin_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Flo
             const bool bad2 = !(fabsf(g2x) <= 3.0e38f) || !(fabsf(g2y) <= 3.0e38f);
             if ((!(a1 <= 3.0e38f) || bad2) && found_inf) *found_inf = 1.0f;
             if (bad2) vmax2 = fmaxf(vmax2, 1.0f);
-            const PairCtx cx{tv, tv.table ? tv.table + (size_t)plan.row0[level] * tv.stride : nullptr, scale, lv.resolution[level], align_corners, interp};
+            const PairCtx cx = make_pair_ctx(tv, tv.table ? tv.table + (size_t)plan.row0[level] * tv.stride : nullptr, scale, lv.resolution[level], align_corners, interp);
             // one straight-line body per index mode (wave-uniform per level) instead of three-way branches around every row
             if (fast_hash) pair_entries<TV, 1, false>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
             else if (fast_dense && parts > 1u) pair_entries<TV, 2, true>(cx, ix, pm, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
@@ -2158,10 +2166,90 @@ struct PmPlan {
     uint32_t ovf_cap;                   // records the overflow log holds (= every entry of the pass)
 };
 
+// Lean form of pair_entries for pm_fill_pair_kernel (the fill's SIMDs issue VALU work more than half of the time: ~815 instructions per
+// (sample, level) before this): the colour products leave as PACKED halves (no f32 round trip on the levels that do not merge runs),
+// smoothstep only when asked for (a uniform branch instead of a select over both forms), the partition key in two instructions.
+template <int TV, int IMODE, bool ILV>
+__device__ __forceinline__ void pm_entries(const PairCtx& cx, const Indexer<3>& ix, const PartMap& pm, const float (&x)[3], float g1,
+                                           float g2x, float g2y, float a1, float& vmax1, uint32_t (&e_pr)[8], float (&f1)[8],
+                                           uint32_t (&p2)[8], uint32_t (&cell)[3], float tv_given, float& tv_out) {
+    constexpr uint32_t D = 3;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    float frac[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) {
+        float p = x[d] * cx.scale + (cx.align_corners ? 0.0f : 0.5f);
+        cell[d] = (uint32_t)floorf(p);
+        frac[d] = p - (float)cell[d];
+    }
+    if (cx.interp == 1) {
+        asm volatile("" ::: "memory");                                   // (keeps this a branch: linear interpolation is what nerf2mesh runs)
+#pragma unroll
+        for (uint32_t d = 0; d < D; ++d) frac[d] = frac[d] * frac[d] * (3.0f - 2.0f * frac[d]);
+    }
+    const uint32_t sy = IMODE == 1 ? kPrimes[1] : ix.stride[1], sz = IMODE == 1 ? kPrimes[2] : ix.stride[2];
+    const uint32_t tx[2] = {cell[0], cell[0] + 1u};
+    const uint32_t ty0 = cell[1] * sy, tz0 = cell[2] * sz;
+    const uint32_t ty[2] = {ty0, ty0 + sy}, tz[2] = {tz0, tz0 + sz};
+    auto comb = [&](uint32_t a, uint32_t b, uint32_t c) { return IMODE == 1 ? ((a ^ b ^ c) & ix.mask) : (a + b + c); };
+    uint32_t rows[8];
+#pragma unroll
+    for (uint32_t corner = 0; corner < 8; ++corner) {
+        const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
+        if constexpr (IMODE != 0) rows[corner] = comb(tx[i], ty[j], tz[k]);
+        else {
+            const uint32_t v[D] = {cell[0] + i, cell[1] + j, cell[2] + k};
+            rows[corner] = ix.row(v);
+        }
+    }
+    float tvv = 0.0f;
+    if constexpr (TV != 0) {
+        if constexpr (TV == 1) tvv = pair_tv_value<IMODE>(cx, ix, x, cell, rows, tx, ty, tz, sy, sz);
+        else tvv = tv_given;
+        const float a = fabsf(tvv);
+        vmax1 = fmaxf(vmax1, (a1 <= 3.0e38f ? a1 : 1.0f) + (a <= 3.0e38f ? a : 1.0f));
+    }
+    tv_out = tvv;
+    const float wx[2] = {1 - frac[0], frac[0]}, wy[2] = {1 - frac[1], frac[1]}, wz[2] = {1 - frac[2], frac[2]};
+#pragma unroll
+    for (uint32_t corner = 0; corner < 8; ++corner) {
+        const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
+        const float w = (wx[i] * wy[j]) * wz[k];                     // forward's association
+        float p1 = w * g1;
+        if (TV != 0 && corner == 0) p1 += tvv;
+        f1[corner] = p1;
+        float pa = w * g2x, pb = w * g2y;                            // rounded to fp32, THEN to half (gridencoder.cu:326; see half_product)
+        asm volatile("" : "+v"(pa), "+v"(pb));
+        h2 hp;
+        hp.x = (_Float16)pa;
+        hp.y = (_Float16)pb;
+        p2[corner] = __builtin_bit_cast(uint32_t, hp);
+        const uint32_t row = rows[corner];
+        if constexpr (IMODE == 0) {
+            uint32_t part_, rel_;
+            pm.split(row, part_, rel_);
+            e_pr[corner] = (part_ << 16) | rel_;
+        } else if constexpr (ILV) {
+            const uint32_t blk = row >> 4;
+            const uint32_t q = __umulhi(blk, pm.magic);
+            e_pr[corner] = ((blk - q * pm.parts) << 16) | (q << 4) | (row & 15u);
+        } else {
+            // (row >> log2p) << 16 | row & (2^log2p - 1)  ==  row + (row >> log2p) * (65536 - 2^log2p)
+            e_pr[corner] = row + (row >> pm.log2p) * (65536u - (1u << pm.log2p));
+        }
+    }
+}
+
 // TS = samples per tile = threads per workgroup.  LDS (dynamic): three u32 staging arrays of 8 TS entries, then
 // cnt[2][MP] start[MP] delta[MP] ovfb[MP] with MP = pm.max_parts rounded up to 128.
+#ifndef N2M_PM_WAVES
+#define N2M_PM_WAVES 4
+#endif
+#ifndef N2M_PM_PREFETCH_LATE
+#define N2M_PM_PREFETCH_LATE 0
+#endif
 template <int TV, bool FOLD, uint32_t TS>
-__global__ void __launch_bounds__(TS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(TS) __attribute__((amdgpu_waves_per_eu(N2M_PM_WAVES, N2M_PM_WAVES)))
 pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Float16* __restrict__ grad2 /*[L,Bstride,2]*/,
                     const float* __restrict__ inputs, TvParams tv, const float* __restrict__ tv_terms, uint32_t B, uint32_t Bstride, BinPlan plan,
                     PmPlan pm, LevelTable lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max /*[2][32]*/,
@@ -2224,18 +2312,21 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
     uint32_t* __restrict__ cur_l = cursors + pm.cur_base[level];
     float vmax1 = 0.0f, vmax2 = 0.0f;
     bool token_seen = false;
+    const PairCtx cx = make_pair_ctx(tv, tv.table ? tv.table + (size_t)plan.row0[level] * tv.stride : nullptr, scale, lv.resolution[level], align_corners, interp);
     const uint32_t dbg = g_fill_timing_on;               // measurement switches (tools/pm_lab.sh; wrong results when set)
 
     uint32_t tile = group;
     float nx[D] = {2.f, 2.f, 2.f}, ng1 = 0.0f, ntv = 0.0f;
     h2 ng2 = {(_Float16)0, (_Float16)0};
+    // the next tile's inputs, RAW: the affine input map is applied when they are consumed, a tile later.  (Until round 4 the map sat here,
+    // right behind the loads -- the compiler put s_waitcnt vmcnt(0) between them and the "prefetch" was a full DRAM round trip at the top of
+    // every tile, draining the previous tile's log stores with it.)
+    bool nvalid = false;
     auto request = [&](uint32_t t) {
         const uint32_t s = t * TS + tid;
-        nx[0] = nx[1] = nx[2] = 2.f;
-        if (t < plan.tiles && s < B) {
+        nvalid = t < plan.tiles && s < B;
+        if (nvalid) {
             load_point<D>(inputs + (size_t)level * in_level_stride, s, nx);
-#pragma unroll
-            for (uint32_t d = 0; d < D; ++d) nx[d] = nx[d] * in_scale + in_offset;
             ng1 = grad1 ? grad1[(size_t)level * Bstride + s] : 0.0f;
             if (grad2) ng2 = *reinterpret_cast<const h2*>(grad2 + ((size_t)level * Bstride + s) * 2);
             else ng2 = h2{(_Float16)0, (_Float16)0};
@@ -2248,18 +2339,23 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
     for (uint32_t it = 0; tile < plan.tiles; tile += n_groups, ++it) {
         uint32_t* cnt = cnt2 + (it & 1u) * MP;
         uint32_t* cnt_next = cnt2 + ((it & 1u) ^ 1u) * MP;
-        float x[D] = {nx[0], nx[1], nx[2]};
+        float x[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; ++d) x[d] = nvalid ? nx[d] * in_scale + in_offset : 2.0f;
         const float g1 = ng1, tvg = ntv;
         const h2 g2 = ng2;
+#if !N2M_PM_PREFETCH_LATE
         request(tile + n_groups);
+#endif
 
         uint32_t e_pr[8], e_v1[8], e_v2[8], e_slot[8];
-        float f1[8], f2x[8], f2y[8];
+        float f1[8];
         uint32_t cell[D] = {0u, 0u, 0u};
         uint32_t vmask = 0;
         const bool inside = !outside_unit_cube<D>(x);
+        bool gnz = false, tvnz = false;                  // any gradient / a TV term to deliver for this sample on this level
 #pragma unroll
-        for (uint32_t c = 0; c < 8; ++c) { f1[c] = 0.f; f2x[c] = 0.f; f2y[c] = 0.f; e_pr[c] = 0u; }
+        for (uint32_t c = 0; c < 8; ++c) { f1[c] = 0.f; e_v2[c] = 0u; e_pr[c] = 0u; }
         if (inside) {
             const float g2x = (float)g2.x, g2y = (float)g2.y;
             const float a1 = fabsf(g1), a2 = fmaxf(fabsf(g2x), fabsf(g2y));
@@ -2268,21 +2364,28 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
             const bool bad2 = !(fabsf(g2x) <= 3.0e38f) || !(fabsf(g2y) <= 3.0e38f);
             if ((!(a1 <= 3.0e38f) || bad2) && found_inf) *found_inf = 1.0f;
             if (bad2) vmax2 = fmaxf(vmax2, 1.0f);
-            const PairCtx cx{tv, tv.table ? tv.table + (size_t)plan.row0[level] * tv.stride : nullptr, scale, lv.resolution[level], align_corners, interp};
-            if (fast_hash) pair_entries<TV, 1, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
-            else if (fast_dense && parts > 1u) pair_entries<TV, 2, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
-            else if (fast_dense) pair_entries<TV, 2, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
-            else pair_entries<TV, 0, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, f2x, f2y, cell, tvg);
+            gnz = (g1 != 0.0f) | ((__builtin_bit_cast(uint32_t, g2) & 0x7FFF7FFFu) != 0u);
+            float tvv = 0.0f;
+            if (fast_hash) pm_entries<TV, 1, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+            else if (fast_dense && parts > 1u) pm_entries<TV, 2, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+            else if (fast_dense) pm_entries<TV, 2, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+            else pm_entries<TV, 0, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+            tvnz = tvv != 0.0f;
             if constexpr (FOLD) {
                 const uint32_t sidx = tile * TS + tid;
                 const uint32_t fl = fold.flags[(size_t)level * B + sidx];
-                if (fl != 0u) fold_copies(fold, sidx, level, x, scale, align_corners, interp, fl, f1, vmax1, found_inf);
+                if (fl != 0u) { fold_copies(fold, sidx, level, x, scale, align_corners, interp, fl, f1, vmax1, found_inf); gnz = true; }
             }
         }
-        bool keep = inside;
-        if (level < merge_levels && !(dbg & 64u)) {
-            keep = merge_runs(inside, cell, f1, f2x, f2y, lane) && inside;
-            if (keep) {
+#if N2M_PM_PREFETCH_LATE
+        request(tile + n_groups);                        // behind the stencil gathers: the vector memory counter is in order, a wait for a gather also waits for every older load
+#endif
+        if (level < merge_levels && !(dbg & 64u)) {      // block-uniform: same-cell runs of consecutive samples become one entry per vertex
+            float f2x[8], f2y[8];
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c) { const h2 p = __builtin_bit_cast(h2, e_v2[c]); f2x[c] = (float)p.x; f2y[c] = (float)p.y; }
+            const bool keep = merge_runs(inside, cell, f1, f2x, f2y, lane) && inside;
+            if (keep) {                                  // a run's sum can exceed every one of its terms
                 float m1 = 0.f, m2 = 0.f;
 #pragma unroll
                 for (uint32_t c = 0; c < 8; ++c) { m1 = fmaxf(m1, fabsf(f1[c])); m2 = fmaxf(m2, fmaxf(fabsf(f2x[c]), fabsf(f2y[c]))); }
@@ -2290,15 +2393,21 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
                 vmax2 = fmaxf(vmax2, m2 <= 65504.0f ? m2 : 65504.0f);
                 if ((!(m1 <= 3.0e38f) || !(m2 <= 65504.0f)) && found_inf) *found_inf = 1.0f;
             }
-        }
 #pragma unroll
-        for (uint32_t c = 0; c < 8; ++c) {
-            h2 p2;
-            p2.x = (_Float16)f2x[c];
-            p2.y = (_Float16)f2y[c];
-            e_v1[c] = __float_as_uint(f1[c]);
-            e_v2[c] = __builtin_bit_cast(uint32_t, p2);
-            if (keep && ((e_v1[c] << 1) | (e_v2[c] & 0x7FFF7FFFu)) != 0u) vmask |= 1u << c;
+            for (uint32_t c = 0; c < 8; ++c) {
+                h2 p2;
+                p2.x = (_Float16)f2x[c];
+                p2.y = (_Float16)f2y[c];
+                e_v1[c] = __float_as_uint(f1[c]);
+                e_v2[c] = __builtin_bit_cast(uint32_t, p2);
+                if (keep && ((e_v1[c] << 1) | (e_v2[c] & 0x7FFF7FFFu)) != 0u) vmask |= 1u << c;
+            }
+        } else {
+            // no merging on this level: a sample with a gradient delivers its eight entries (a vertex of weight zero: an explicit zero the
+            // accumulate skips), a sample without one at most its TV term on vertex 000
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c) e_v1[c] = __float_as_uint(f1[c]);
+            vmask = !inside ? 0u : (gnz ? 0xFFu : (tvnz ? 1u : 0u));
         }
         // slot of every entry inside its partition's run of this tile
         if (dbg & 16u) {
@@ -2341,19 +2450,26 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
                     token_seen = true;
                 }
                 ra0 = a0; ra1 = a1c; rs0 = s0; rs1 = s1;
-                if (a0 && !(dbg & 32u)) q0 = atomicAdd(cur_l + i0, a0);
-                if (a1c && !(dbg & 32u)) q1 = atomicAdd(cur_l + i1, a1c);
+                if (dbg & 32u) { q0 = min(tile * 36u, cap - min(cap, a0)); q1 = min(tile * 36u, cap - min(cap, a1c)); }    // (measurement: a reservation without its round trip)
+                else {
+                    if (a0) q0 = atomicAdd(cur_l + i0, a0);
+                    if (a1c) q1 = atomicAdd(cur_l + i1, a1c);
+                }
             }
         }
-        if (!(dbg & 8u))
+        if (!(dbg & 8u)) {
+            uint32_t pos[8];
 #pragma unroll
-        for (uint32_t c = 0; c < 8; ++c)
-            if ((vmask >> c) & 1u) {
-                const uint32_t pos = start[e_pr[c] >> 16] + e_slot[c];
-                stage_v1[pos] = e_v1[c];
-                stage_v2[pos] = e_v2[c];
-                stage_e[pos] = e_pr[c];
-            }
+            for (uint32_t c = 0; c < 8; ++c) pos[c] = start[e_pr[c] >> 16];          // (all eight lookups in flight; a dropped entry reads partition 0's)
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c)
+                if ((vmask >> c) & 1u) {
+                    const uint32_t at = pos[c] + e_slot[c];
+                    stage_v1[at] = e_v1[c];
+                    stage_v2[at] = e_v2[c];
+                    stage_e[at] = e_pr[c];
+                }
+        }
         for (uint32_t i = tid; i < parts; i += TS) cnt_next[i] = 0;
         if (tid == 0u) tile_ovf[(it & 1u) ^ 1u] = 0u;
         if (wid == 0u) {
@@ -2383,23 +2499,34 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
 
         if (dbg & 12u) {
         } else if (tile_ovf[it & 1u] == 0u) {
-            // plain (cache-allocating) stores: a run is a 64-256 byte piece at an arbitrary offset of its region -- neighbouring runs complete
-            // each other's lines in L2 (measured: streaming stores 190 us, plain 172 us per fill at 512-sample tiles)
-            if (!(dbg & 2u)) {              // (measurement switch: bit 1 = streaming stores)
-                for (uint32_t i = tid; i < total; i += TS) {
-                    const uint32_t e = stage_e[i], d = delta[e >> 16] + i;
-                    if (log_v1) log_v1[d] = stage_v1[i];
-                    if (log_v2) log_v2[d] = stage_v2[i];
-                    log_rel[d] = (uint16_t)e;
-                }
-            } else {
-                for (uint32_t i = tid; i < total; i += TS) {
-                    const uint32_t e = stage_e[i], d = delta[e >> 16] + i;
-                    if (log_v1) __builtin_nontemporal_store(stage_v1[i], &log_v1[d]);
-                    if (log_v2) __builtin_nontemporal_store(stage_v2[i], &log_v2[d]);
-                    __builtin_nontemporal_store((uint16_t)e, &log_rel[d]);
-                }
+            // A thread moves up to eight entries.  All their LDS reads are issued together, then the eight lookups of the runs' places, then
+            // the stores: as a loop (one entry per trip: read -> wait -> lookup -> wait -> store) the copy was 2 dependent LDS round trips
+            // per entry, serial -- the "cost of the log stores" of the earlier ablations was this latency chain, not the stores.
+            // Plain (cache-allocating) stores: a run is a 64-256 byte piece at an arbitrary offset of its region, neighbouring runs complete
+            // each other's lines in L2 (streaming stores: 190 us per fill instead of 172).  Byte offsets in 32 bits (the host checks that the
+            // regions end below 2^30 entries): the stores take the arrays' bases from scalar registers.
+            uint32_t ce[8], cv1[8], cv2[8], cd[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) {
+                const uint32_t i = tid + q * TS;
+                ce[q] = 0u; cv1[q] = 0u; cv2[q] = 0u;
+                if (i < total) { ce[q] = stage_e[i]; cv1[q] = stage_v1[i]; cv2[q] = stage_v2[i]; }
             }
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) cd[q] = delta[ce[q] >> 16] + tid + q * TS;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q)
+                if (tid + q * TS < total) {
+                    if (dbg & 2u) {                  // (measurement switch: streaming stores)
+                        if (log_v1) __builtin_nontemporal_store(cv1[q], &log_v1[cd[q]]);
+                        if (log_v2) __builtin_nontemporal_store(cv2[q], &log_v2[cd[q]]);
+                        __builtin_nontemporal_store((uint16_t)ce[q], &log_rel[cd[q]]);
+                    } else {
+                        if (log_v1) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(log_v1) + (cd[q] << 2)) = cv1[q];
+                        if (log_v2) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(log_v2) + (cd[q] << 2)) = cv2[q];
+                        *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(log_rel) + (cd[q] << 1)) = (uint16_t)ce[q];
+                    }
+                }
         } else {
             for (uint32_t i = tid; i < total; i += TS) {
                 const uint32_t e = stage_e[i], p = e >> 16;
@@ -2443,26 +2570,38 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
 
 // One work item = (level, SUB adjacent partitions[, slice grp of Gl]): streams the partitions' regions (contiguous arrays) into the
 // 64-bit fixed-point LDS accumulator, then flushes like bin_accumulate_kernel.
+// Levels whose partitions are split over Gl > 1 work items (the small dense levels; every level of a batch above 2^19 samples): the
+// slices of a region are cut by entry index, i.e. by the order in which the fill's reservations happened to arrive, so their partial sums
+// differ from run to run.  They are therefore never added as floats: every slice leaves its accumulator -- integers -- in a scratch
+// slot, the last of the Gl items to arrive (a ticket per partition group) adds the slots and flushes the rows with plain stores.  Integer
+// sums are exact whatever the cut: the whole table backward is bit-reproducible run to run (the tile-major path ends these levels in
+// float atomics), and the fill no longer clears rows for atomics to land on.
+struct PmSplit {
+    uint32_t slot0[kMaxLevels];         // first scratch slot of the level's work items (slot = SUB * P * C u64; levels with Gl > 1 only)
+    uint32_t tick0[kMaxLevels];         // first ticket of the level's partition groups
+};
+
 template <typename T, uint32_t C, uint32_t P, uint32_t SUB>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
-pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, LevelTable lv, uint32_t gridtype, bool align_corners,
+pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, PmSplit sp, LevelTable lv, uint32_t gridtype, bool align_corners,
                      const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ ovf_cursor,
                      const uint16_t* __restrict__ log_rel, const uint32_t* __restrict__ log_val, const uint32_t* __restrict__ ovf_key,
-                     const uint32_t* __restrict__ ovf_val, float* __restrict__ found_inf, bool overwrite, uint32_t dbg, float inf_bound) {
+                     const uint32_t* __restrict__ ovf_val, unsigned long long* __restrict__ slots, uint32_t* __restrict__ tickets,
+                     float* __restrict__ found_inf, bool overwrite, uint32_t dbg, float inf_bound) {
     constexpr uint32_t kLog2P = 31u - __builtin_clz(P);
+    constexpr uint32_t kSlot = SUB * P * C;
     extern __shared__ __attribute__((aligned(16))) unsigned long long bin_acc[];   // SUB * P * C
-    __shared__ uint32_t nonfinite_seen;
+    __shared__ uint32_t nonfinite_seen, arrival;
     const uint32_t tid = threadIdx.x;
     const uint32_t total_items = plan.item_prefix[plan.levels];
     for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x) {
         uint32_t level = 0;
         while (item >= plan.item_prefix[level + 1]) ++level;
         const uint32_t vm_v = __hip_atomic_load(level_max + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t Gl = plan.groups[level];
-        const bool store_all = overwrite && Gl == 1u;
-        if (!store_all && (uint32_t)__builtin_amdgcn_readfirstlane((int)vm_v) == 0u) continue;
+        const uint32_t Gplan = plan.groups[level];          // slices the launch provides per partition group (sized for unmerged entries)
+        if (!overwrite && (uint32_t)__builtin_amdgcn_readfirstlane((int)vm_v) == 0u) continue;     // no non-zero finite update in this level
         const uint32_t local = item - plan.item_prefix[level];
-        const uint32_t part0 = (local / Gl) * SUB, grp = local - (local / Gl) * Gl;
+        const uint32_t ip = local / Gplan, part0 = ip * SUB, grp = local - ip * Gplan;
         const uint32_t parts = plan.parts[level], size = plan.size[level];
         const uint32_t part_end = min(part0 + SUB, parts);
         const Indexer<3> ix(size, lv.resolution[level], gridtype, align_corners);
@@ -2483,7 +2622,16 @@ pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, LevelT
 #pragma unroll
         for (uint32_t u = 0; u < SUB; ++u)
             n_all[u] = part0 + u < part_end ? __hip_atomic_load(cursors + pm.cur_base[level] + part0 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        for (uint32_t i = tid; i < SUB * P * C; i += 1024) bin_acc[i] = 0ull;
+        // Slices actually used: one per 2^16 (C = 2: 2^15) entries the regions HOLD.  Same-cell runs merged by the fill leave the coarse levels of a
+        // marched batch with a sixteenth of the entries the launch had to provide for; every slice costs a 64 KB slot round trip, and
+        // 135 of them took this kernel from 37 to 93 us.  The items beyond Gl find nothing to do.
+        uint32_t n_tot = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < SUB; ++u) n_tot += min((uint32_t)__builtin_amdgcn_readfirstlane((int)n_all[u]), pm.home_cap[level]);
+        constexpr uint32_t kSliceLog2 = SUB == 2u ? 16u : 15u;            // a slice = at most twice what an item of the hashed levels holds at 2^18 samples
+        const uint32_t Gl = min(Gplan, max(1u, (n_tot + (1u << kSliceLog2) - 1u) >> kSliceLog2));
+        if (grp >= Gl) continue;
+        for (uint32_t i = tid; i < kSlot; i += 1024) bin_acc[i] = 0ull;
         if (tid == 0) nonfinite_seen = 0u;
         __syncthreads();
         const uint32_t vm = (uint32_t)__builtin_amdgcn_readfirstlane((int)vm_v);
@@ -2492,15 +2640,16 @@ pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, LevelT
         const float scale = __uint_as_float((uint32_t)(ex + 127) << 23);
         const float inv = __uint_as_float((uint32_t)(127 - ex) << 23);
         const uint32_t cap = pm.home_cap[level];
-        auto walk = [&](auto&& body) {
+        // walk(body, whole): body(rel0, u, bits) for every entry of this item's slice (whole: of the complete regions) + overflow records
+        auto walk = [&](auto&& body, bool whole) {
             if (vm == 0u) return;
 #pragma unroll
             for (uint32_t u = 0; u < SUB; ++u) {
                 const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_all[u]);
                 const uint32_t n = min(nu, cap);
-                // slice of this tile group: boundaries on multiples of 4 entries (the last slice ends at n)
-                const uint32_t lo = Gl == 1u ? 0u : (uint32_t)(((uint64_t)n * grp / Gl) & ~3ull);
-                const uint32_t hi = (Gl == 1u || grp + 1u == Gl) ? n : (uint32_t)(((uint64_t)n * (grp + 1u) / Gl) & ~3ull);
+                // slice of this group: boundaries on multiples of 4 entries (the last slice ends at n)
+                const uint32_t lo = (Gl == 1u || whole) ? 0u : (uint32_t)(((uint64_t)n * grp / Gl) & ~3ull);
+                const uint32_t hi = (Gl == 1u || whole || grp + 1u == Gl) ? n : (uint32_t)(((uint64_t)n * (grp + 1u) / Gl) & ~3ull);
                 const size_t base = (size_t)pm.home_base[level] + (size_t)(part0 + u) * cap;
                 const uint16_t* __restrict__ rp = log_rel + base;
                 const uint32_t* __restrict__ vp = log_val + base;
@@ -2516,7 +2665,7 @@ pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, LevelT
                     for (uint32_t k = 0; k < 4; ++k)
                         if (i0 + k * 1024u < hi) body(r[k], u, v[k]);
                 }
-                if (nu > cap && grp == 0u) {             // records of this partition in the shared overflow log
+                if (nu > cap && (grp == 0u || whole)) {  // records of this partition in the shared overflow log
                     const uint32_t n_ovf = min(__hip_atomic_load(ovf_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), pm.ovf_cap);
                     const uint32_t want = (level << 11) | (part0 + u);
                     for (uint32_t i = tid; i < n_ovf; i += 1024u) {
@@ -2526,6 +2675,8 @@ pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, LevelT
                 }
             }
         };
+        // inf / nan entries bypass the fixed-point sum and go to the table as they are -- AFTER the rows have been stored: the first walk
+        // only notes that there are any, a second walk (never taken in a healthy run) adds them onto the stored sums
         auto bypass = [&](uint32_t rel0, uint32_t u, uint32_t bits) {
             if constexpr (sizeof(T) == 4) unsafeAtomicAdd(gtab + global_row(u, rel0), __uint_as_float(bits));
             else {
@@ -2544,11 +2695,7 @@ pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, LevelT
         };
         walk([&](uint32_t rel0, uint32_t u, uint32_t bits) {
             const uint32_t rel = rel0 + u * P;
-            if (!finite(bits)) {
-                if (store_all) nonfinite_seen = 1u;
-                else bypass(rel0, u, bits);
-                return;
-            }
+            if (!finite(bits)) { nonfinite_seen = 1u; return; }
             if constexpr (sizeof(T) == 4) {
                 if (bits << 1) __hip_atomic_fetch_add(&bin_acc[rel], (unsigned long long)to_fixed(__uint_as_float(bits), scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
@@ -2558,9 +2705,41 @@ pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, LevelT
                 if (v0 != 0.f) __hip_atomic_fetch_add(&bin_acc[rel * 2u], (unsigned long long)to_fixed(v0, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (v1 != 0.f) __hip_atomic_fetch_add(&bin_acc[rel * 2u + 1u], (unsigned long long)to_fixed(v1, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-        });
+        }, false);
         __syncthreads();
-        const bool second_walk = store_all && nonfinite_seen != 0u;
+        bool second_walk = nonfinite_seen != 0u;
+        if (Gl > 1u) {
+            // leave the slice's sums in its slot; the last of the group's items to arrive adds all slots
+            unsigned long long* __restrict__ mine = slots + (size_t)(sp.slot0[level] + local) * kSlot;
+            uint32_t* __restrict__ ticket = tickets + sp.tick0[level] + ip;
+            // Hand-over between workgroups WITHOUT cache-wide fences (a release / acquire fence at agent scope writes back and invalidates a
+            // whole L2: 16 waves x 70 items of that turned 90 us of accumulates into 470): the slots are written and read with agent-scope
+            // (write-through / cache-bypassing) accesses, every wave waits for its own stores to be acknowledged, then the barrier, then
+            // the ticket -- whoever draws the last ticket finds all slots in memory.
+            for (uint32_t i = tid; i < kSlot; i += 1024) __hip_atomic_store(&mine[i], bin_acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0): this wave's slot stores have reached memory
+            __syncthreads();
+            if (tid == 0) arrival = __hip_atomic_fetch_add(ticket, second_walk ? 0x10001u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (high half: slices with inf / nan entries)
+            __syncthreads();
+            const uint32_t arr = arrival;
+            if ((arr & 0xFFFFu) != Gl - 1u) continue;                        // (uniform) not the last one: the next item's clear follows its own barrier
+            second_walk = second_walk || (arr >> 16) != 0u;
+            if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
+            unsigned long long* __restrict__ first = slots + (size_t)(sp.slot0[level] + ip * Gplan) * kSlot;
+            {   // all of a slot's loads of this thread in flight together (they bypass the caches: one memory round trip per slot, not per value)
+                unsigned long long sum[kSlot / 1024u];
+#pragma unroll
+                for (uint32_t k = 0; k < kSlot / 1024u; ++k) sum[k] = 0ull;
+                for (uint32_t g = 0; g < Gl; ++g) {
+#pragma unroll
+                    for (uint32_t k = 0; k < kSlot / 1024u; ++k)
+                        sum[k] += __hip_atomic_load(first + (size_t)g * kSlot + tid + k * 1024u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < kSlot / 1024u; ++k) bin_acc[tid + k * 1024u] = sum[k];
+            }
+            __syncthreads();
+        }
         for (uint32_t rel = tid; rel < ((dbg & 2u) ? 0u : SUB * P); rel += 1024) {
             const uint32_t u = rel >> kLog2P, rel0 = rel & (P - 1u);
             if (part0 + u >= part_end || rel0 >= rows_of(part0 + u)) continue;
@@ -2568,44 +2747,37 @@ pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, LevelT
             if (row >= size) continue;
             if constexpr (sizeof(T) == 4) {
                 const long long a = (long long)bin_acc[rel];
-                if (a != 0 || store_all) {
+                if (a != 0 || overwrite) {
                     const float f = (float)a * inv;
                     if (!(fabsf(f) <= (inf_bound > 0.0f ? inf_bound : 3.0e38f)) && found_inf) *found_inf = 1.0f;
-                    if (store_all) gtab[row] = f;
-                    else if (Gl == 1u) gtab[row] += f;
-                    else unsafeAtomicAdd(gtab + row, f);
+                    if (overwrite) gtab[row] = f;
+                    else gtab[row] += f;
                 }
             } else {
                 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                 const long long a0 = (long long)bin_acc[rel * 2u], a1 = (long long)bin_acc[rel * 2u + 1u];
-                if ((a0 | a1) != 0 || store_all) {
+                if ((a0 | a1) != 0 || overwrite) {
                     const float f0 = (float)a0 * inv, f1 = (float)a1 * inv;
                     const float b16 = inf_bound > 0.0f ? inf_bound : 65504.0f;
-                    if (!(fabsf(f0) <= b16 && fabsf(f1) <= b16) && found_inf) *found_inf = 1.0f;
+                    if (!(fabsf(f0) <= b16 && fabsf(f1) <= b16) && found_inf) *found_inf = 1.0f;       // rounds to inf in fp16 (or could, summed over ranks)
                     h2* dst = reinterpret_cast<h2*>(gtab + (size_t)row * 2u);
-                    if (store_all) {
-                        h2 o;
-                        o.x = (_Float16)f0;
+                    h2 o;
+                    if (overwrite) {
+                        o.x = (_Float16)f0;          // == (half)(0 + f): the sum below starts from +0
                         o.y = (_Float16)f1;
-                        *dst = o;
-                    } else if (Gl == 1u) {
-                        h2 o = *dst;
+                    } else {
+                        o = *dst;
                         o.x = (_Float16)((float)o.x + f0);
                         o.y = (_Float16)((float)o.y + f1);
-                        *dst = o;
-                    } else {
-                        h2 val;
-                        val.x = (_Float16)f0;
-                        val.y = (_Float16)f1;
-                        (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)dst, val);
                     }
+                    *dst = o;
                 }
             }
         }
         __syncthreads();
         if (second_walk) {
-            __threadfence();
-            walk([&](uint32_t rel0, uint32_t u, uint32_t bits) { if (!finite(bits)) bypass(rel0, u, bits); });
+            __threadfence();                                               // the stores above before the atomics below
+            walk([&](uint32_t rel0, uint32_t u, uint32_t bits) { if (!finite(bits)) bypass(rel0, u, bits); }, Gl > 1u);
             __syncthreads();
         }
     }
@@ -2879,7 +3051,7 @@ int launch_binned(const T* grad, const float* inputs, TvParams tv, T* grad_table
 // ---- partition-major log: layout and launches (kernels: pm_fill_pair_kernel, pm_accumulate_kernel)
 struct PmLayout {
     PmPlan pm;
-    size_t home_entries, bytes;
+    size_t home_entries, slot_count, bytes;
     bool ok;
 };
 
@@ -2903,13 +3075,24 @@ PmLayout make_pm_plan(uint32_t Bc, const BinPlan& plan) {
         mp = parts > mp ? parts : mp;
     }
     o.pm.max_parts = mp;
-    o.pm.cursors = cur;
+    o.pm.cursors = 2u * cur;               // cursors, then the tickets of the split levels (workgroup 0 of the fill clears both)
     const uint64_t ovf = (uint64_t)plan.levels * 8u * Bc;
     o.pm.ovf_cap = (uint32_t)ovf;
-    if (home >= (1ull << 32) || ovf >= (1ull << 32) || mp > kMaxPartsPerLevel) o.ok = false;
+    if (home >= (1ull << 30) || ovf >= (1ull << 32) || mp > kMaxPartsPerLevel) o.ok = false;      // (fill: byte offsets of an entry in 32 bits)
     o.home_entries = (size_t)home;
+    // scratch slots of the levels whose partitions are split over several work items (64 KB each): the larger of the two tables' needs
+    uint64_t split1 = 0, split2 = 0;
+    for (uint32_t l = 0; l < plan.levels; ++l) {
+        const uint32_t pairs = (plan.parts[l] + 1u) / 2u;
+        uint32_t g1 = (uint32_t)(((uint64_t)8 * Bc / pairs + 65535u) / 65536u);
+        g1 = g1 < 1u ? 1u : (g1 > 64u ? 64u : g1);
+        if (g1 > 1u) split1 += (uint64_t)pairs * g1;
+        if (plan.groups[l] > 1u) split2 += (uint64_t)plan.parts[l] * plan.groups[l];
+    }
+    o.slot_count = (size_t)(split1 > split2 ? split1 : split2);
     const size_t r = 255;
-    o.bytes = kBinHeaderBytes + (((size_t)cur * 4 + r) & ~r) + ((home * 4 + r) & ~r) * 2 + ((home * 2 + r) & ~r) + (((size_t)ovf * 4 + r) & ~r) * 3;
+    o.bytes = kBinHeaderBytes + (((size_t)cur * 8 + r) & ~r) + ((home * 4 + r) & ~r) * 2 + ((home * 2 + r) & ~r) + (((size_t)ovf * 4 + r) & ~r) * 3 +
+              o.slot_count * (size_t)kPairP * 16u;
     return o;
 }
 
@@ -2983,13 +3166,15 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
         unsigned long long* lm_ready = (unsigned long long*)(w + 256);
         uint32_t* ovf_cursor = (uint32_t*)(w + 264);
         uint32_t* cursors = (uint32_t*)(w + kBinHeaderBytes);
+        uint32_t* tickets = cursors + pl.pm.cursors / 2u;
         w += kBinHeaderBytes + (((size_t)pl.pm.cursors * 4 + r) & ~r);
         uint32_t* log_v1 = (uint32_t*)w; w += (pl.home_entries * 4 + r) & ~r;
         uint32_t* log_v2 = (uint32_t*)w; w += (pl.home_entries * 4 + r) & ~r;
         uint16_t* log_rel = (uint16_t*)w; w += (pl.home_entries * 2 + r) & ~r;
         uint32_t* ovf_key = (uint32_t*)w; w += ((size_t)pl.pm.ovf_cap * 4 + r) & ~r;
         uint32_t* ovf_v1 = (uint32_t*)w; w += ((size_t)pl.pm.ovf_cap * 4 + r) & ~r;
-        uint32_t* ovf_v2 = (uint32_t*)w;
+        uint32_t* ovf_v2 = (uint32_t*)w; w += ((size_t)pl.pm.ovf_cap * 4 + r) & ~r;
+        unsigned long long* slots = (unsigned long long*)w;
         static std::atomic<unsigned long long> launch_counter{1};
         const unsigned long long lm_token = (0x6e326d50ull << 32) | (launch_counter.fetch_add(1) & 0xFFFFFFFFull);
         const bool ow = overwrite && b0 == 0;
@@ -3001,7 +3186,9 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
         const float* x = inputs + (size_t)b0 * 3;
         auto in_half = [&](uint32_t l) { return half == 0 || (half == 1 ? l >= 8u : l < 8u); };
         BinPlan plan1 = lay.plan, plan2 = lay.plan;
-        uint32_t items1 = 0, items2 = 0, cm1 = 0, cm2 = 0;
+        uint32_t items1 = 0, items2 = 0, slots1 = 0, slots2 = 0;
+        const uint32_t cm1 = 0, cm2 = 0;                      // (no rows to clear: split levels end in stores too)
+        PmSplit sp1{}, sp2{};
         for (uint32_t l = 0; l < max_level; ++l) {
             const uint32_t pairs = (plan1.parts[l] + 1u) / 2u;
             const uint64_t per_item = (uint64_t)8 * Bc / pairs;
@@ -3012,12 +3199,15 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
             plan2.groups[l] = g2n;
             plan1.item_prefix[l] = items1;
             plan2.item_prefix[l] = items2;
+            sp1.slot0[l] = slots1; sp2.slot0[l] = slots2;
+            sp1.tick0[l] = sp2.tick0[l] = pl.pm.cur_base[l];            // (a ticket per partition group: never more than partitions)
             if (!in_half(l)) continue;
             items1 += pairs * g;
             items2 += lay.plan.parts[l] * g2n;
-            if (ow && g > 1u && both) cm1 |= 1u << l;
-            if (ow && g2n > 1u && has2) cm2 |= 1u << l;
+            if (g > 1u) slots1 += pairs * g;
+            if (g2n > 1u) slots2 += lay.plan.parts[l] * g2n;
         }
+        N2M_REQUIRE(slots1 <= pl.slot_count && slots2 <= pl.slot_count, N2M_EINVAL, "%s: scratch slots of the split levels exceed the layout", fn);
         plan1.item_prefix[max_level] = items1;
         plan2.item_prefix[max_level] = items2;
         if (ow && max_level < L) {
@@ -3065,13 +3255,14 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
         const float odiv = g_cfg_overflow_div.load();
         if (both) {
             pm_accumulate_kernel<float, 1, kPairP, 2><<<items1 < acc_cap ? items1 : acc_cap, 1024, kPairP * 16, s>>>(
-                table1, plan1, pl.pm, lv, gridtype, align, level_max, cursors, ovf_cursor, log_rel, log_v1, ovf_key, ovf_v1, found_inf, ow, acc_dbg, 3.0e38f / odiv);
+                table1, plan1, pl.pm, sp1, lv, gridtype, align, level_max, cursors, ovf_cursor, log_rel, log_v1, ovf_key, ovf_v1, slots, tickets, found_inf, ow, acc_dbg,
+                3.0e38f / odiv);
             N2M_CHECK_LAUNCH();
         }
         if (has2) {
             pm_accumulate_kernel<_Float16, 2, kPairP, 1><<<items2 < acc_cap ? items2 : acc_cap, 1024, kPairP * 16, s>>>(
-                table2, plan2, pl.pm, lv, gridtype, align, level_max + kMaxLevels, cursors, ovf_cursor, log_rel, log_v2, ovf_key, ovf_v2, found_inf, ow, acc_dbg,
-                65504.0f / odiv);
+                table2, plan2, pl.pm, sp2, lv, gridtype, align, level_max + kMaxLevels, cursors, ovf_cursor, log_rel, log_v2, ovf_key, ovf_v2, slots, tickets, found_inf, ow,
+                acc_dbg, 65504.0f / odiv);
             N2M_CHECK_LAUNCH();
         }
     }

@@ -13,9 +13,15 @@ def _run(cls, steps, **over):
     torch.manual_seed(0)
     kw = dict(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=True)
     kw.update(over)
+    perturb = kw.pop("perturb", 0.0)
     opt = make_options(**kw)
     dev = torch.device("cuda", 0)
     model = NeRFNetwork(opt)
+    if perturb:                                                  # a rounding-sized nudge of every parameter: the yardstick of a chaotic recipe
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(1)
+            for q in model.parameters():
+                q.mul_(1.0 + perturb * torch.randn(q.shape, generator=g).to(q.device))
     if opt.scene == "garden":
         model.update_aabb(synthetic.pts_aabb("garden"))          # main.py:234-235
     tr = cls(model, opt, synthetic.make_cameras(6, seed=0), dev, seed=0)
@@ -102,9 +108,16 @@ def test_engine_runs_the_sdf_recipe_like_the_trainer(iters, steps):
     elif iters == 30000:
         assert not hasattr(b, "last_fold_left"), "epsilon 0.1 spans many cells: the stacked pass stays"
     assert a.samples_seen == b.samples_seen and a.rays_seen == b.rays_seen, "same batches, same sample counts"
-    a2, la2 = _run(Stage0Trainer, steps, **cfg)
-    # yardstick for the loss curve as for the parameters: two runs of the trainer (late in the schedule the normals are finite differences of
-    # an fp16 sdf over eps = 1e-4, which amplifies the fp16 / atomic-order noise of the table gradients within a few steps)
+    # yardstick for the loss curve as for the parameters: a second run of the trainer whose parameters start ten fp32 roundings apart (relative
+    # 1e-6).  Until round 4 two plain trainer runs served: they differed by the float atomics of the table backward, which late in the schedule
+    # (normals = finite differences of an fp16 sdf over eps = 1e-4) grow by orders of magnitude within a few steps.  The partition-major table
+    # backward is bit-reproducible, two plain runs now agree to ~1e-5 -- while executor and trainer still differ by fp32 association (the
+    # folded copies, section 4.11i of DESIGN.md), which the recipe amplifies exactly like any other rounding-sized difference.
+    # (measured at iters = 40: density table trainer-vs-engine 0.05 under either log layout; two tile-major trainer runs 0.05; two partition-major
+    #  trainer runs 0.001; a 1e-7 nudge 0.01, a 1e-6 nudge 0.05-0.1.)  Before the recipe turns chaotic the two must agree closely: the first
+    # fifteen losses to 1e-6.
+    a2, la2 = _run(Stage0Trainer, steps, perturb=1e-6, **cfg)
+    assert float(np.abs(np.array(la[:15]) - np.array(lb[:15])).max()) <= 1e-6 * max(1.0, float(np.abs(la).max())), "loss curves part before the chaotic phase"
     noise = float(np.abs(np.array(la) - np.array(la2)).max())
     print(f"loss curves: trainer-vs-engine max diff {np.abs(np.array(la) - np.array(lb)).max():.3g}, trainer-vs-trainer {noise:.3g}")
     assert float(np.abs(np.array(la) - np.array(lb)).max()) <= 5 * noise + 2e-3 * float(np.abs(la).max())
@@ -193,26 +206,30 @@ def test_optimizer_pass_inside_the_table_backward_is_the_separate_pass(monkeypat
     (N2M_FUSE_ADAM=0): same arithmetic element for element.  One step from the same state: parameter, both moments and the packed rows of
     every level that takes the fused pass are BIT-equal (their gradient sums are fixed-point, order-free); the small dense levels differ
     by their float atomics as two runs of the unfused path do.  Odd / even step counts end in either buffer set: the model and the
-    optimizer must name the current one."""
+    optimizer must name the current one.  (The fused pass runs on the tile-major log: n2m_grid_encode_backward_binned_pair_adam.)"""
     from nerf2mesh_amd.engine import Stage0Engine
     monkeypatch.setenv("N2M_FUSE_ADAM", "0")
     a, la = _run(Stage0Engine, steps, diffuse_step=4)
     a2, _ = _run(Stage0Engine, steps, diffuse_step=4)
     monkeypatch.setenv("N2M_FUSE_ADAM", "1")
     b, lb = _run(Stage0Engine, steps, diffuse_step=4)
+    b2, _ = _run(Stage0Engine, steps, diffuse_step=4)
     assert a.fuse_adam is None and b.fuse_adam is not None
     r0 = b.fuse_adam["first_row"]
     assert 0 < r0 < 0.1 * b.rows, "the hashed levels (94 % of the rows) take the fused pass"
-    sa, sa2, sb = _table_state(a), _table_state(a2), _table_state(b)
+    sa, sa2, sb, sb2 = _table_state(a), _table_state(a2), _table_state(b), _table_state(b2)
     np.testing.assert_allclose(la, lb, rtol=2e-4, atol=1e-7)
     for name in ("density", "colour"):
-        for which, x, x2, y in zip(("param", "exp_avg", "exp_avg_sq"), sa[name], sa2[name], sb[name]):
+        for which, x, x2, y, y2 in zip(("param", "exp_avg", "exp_avg_sq"), sa[name], sa2[name], sb[name], sb2[name]):
             if steps == 1:
                 assert torch.equal(x[r0:], y[r0:]), f"{name} {which}: fused rows differ after one step"
             rel = lambda p, q: ((p - q).norm() / p.norm().clamp_min(1e-30)).item()
-            d_ab, d_aa = rel(x, y), rel(x, x2)
-            print(f"{name:8s} {which:10s} fused-vs-unfused {d_ab:.3g}   unfused-vs-unfused {d_aa:.3g}")
-            assert d_ab <= 10 * d_aa + 1e-6
+            d_ab, d_aa, d_bb = rel(x, y), rel(x, x2), rel(y, y2)
+            print(f"{name:8s} {which:10s} fused-vs-unfused {d_ab:.3g}   unfused-vs-unfused {d_aa:.3g}   fused-vs-fused {d_bb:.3g}")
+            # the unfused pass (partition-major log since round 4) is bit-reproducible; the fused one ends its split dense levels in float
+            # atomics: two fused runs are the yardstick
+            assert d_aa == 0.0, "the table backward is bit-reproducible run to run"
+            assert d_ab <= 10 * d_bb + 1e-6
     if steps == 1:
         assert torch.equal(sa["packed"][r0:], sb["packed"][r0:])
     # the packed copy the lookup reads IS the parameters (fp32 density, colour rounded to fp16), whichever buffer set is current
