@@ -2314,6 +2314,7 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
     bool token_seen = false;
     const PairCtx cx = make_pair_ctx(tv, tv.table ? tv.table + (size_t)plan.row0[level] * tv.stride : nullptr, scale, lv.resolution[level], align_corners, interp);
     const uint32_t dbg = g_fill_timing_on;               // measurement switches (tools/pm_lab.sh; wrong results when set)
+    if ((dbg >> 8) != 0u && level != (dbg >> 8) - 1u) return;          // (measurement: one level alone, tools/pm_levels.sh)
 
     uint32_t tile = group;
     float nx[D] = {2.f, 2.f, 2.f}, ng1 = 0.0f, ntv = 0.0f;

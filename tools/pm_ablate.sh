@@ -4,7 +4,7 @@ set -u
 R=$(pwd); cd /tmp && export TMPDIR=/tmp
 for cfg in "$@"; do
   rm -rf /tmp/prof_pm
-  env N2M_BIN_PM=1 $cfg timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pm -- python $R/tools/pair_bench.py --reps 30 > /tmp/prof_pm.log 2>&1
+  env N2M_BIN_PM=1 $cfg timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pm -- python $R/tools/pair_bench.py --reps ${REPS:-30} > /tmp/prof_pm.log 2>&1
   python - "$cfg" <<PY
 import csv, glob, sys
 f = glob.glob('/tmp/prof_pm/**/*kernel_stats.csv', recursive=True)
