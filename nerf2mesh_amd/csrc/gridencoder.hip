@@ -2583,8 +2583,8 @@ struct PmSplit {
 };
 
 template <typename T, uint32_t C, uint32_t P, uint32_t SUB>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
-pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, PmSplit sp, LevelTable lv, uint32_t gridtype, bool align_corners,
+__device__ __forceinline__ void pm_accumulate_items(uint32_t first_item, uint32_t item_stride, T* __restrict__ grad_table, const BinPlan& plan,
+                     const PmPlan& pm, const PmSplit& sp, const LevelTable& lv, uint32_t gridtype, bool align_corners,
                      const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ ovf_cursor,
                      const uint16_t* __restrict__ log_rel, const uint32_t* __restrict__ log_val, const uint32_t* __restrict__ ovf_key,
                      const uint32_t* __restrict__ ovf_val, unsigned long long* __restrict__ slots, uint32_t* __restrict__ tickets,
@@ -2595,7 +2595,7 @@ pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, PmSpli
     __shared__ uint32_t nonfinite_seen, arrival;
     const uint32_t tid = threadIdx.x;
     const uint32_t total_items = plan.item_prefix[plan.levels];
-    for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x) {
+    for (uint32_t item = first_item; item < total_items; item += item_stride) {
         uint32_t level = 0;
         while (item >= plan.item_prefix[level + 1]) ++level;
         const uint32_t vm_v = __hip_atomic_load(level_max + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2782,6 +2782,38 @@ pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, PmSpli
             __syncthreads();
         }
     }
+}
+
+// One table alone / both tables in ONE launch: workgroups [0, nb1) walk the fp32 table's items, the others the fp16 table's (own tickets, own
+// scratch slots).  Two launches meant a kernel boundary (~5 us) and two tails -- 1 494 items on 512 workgroup slots each.
+template <typename T, uint32_t C, uint32_t P, uint32_t SUB>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, PmSplit sp, LevelTable lv, uint32_t gridtype, bool align_corners,
+                     const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ ovf_cursor,
+                     const uint16_t* __restrict__ log_rel, const uint32_t* __restrict__ log_val, const uint32_t* __restrict__ ovf_key,
+                     const uint32_t* __restrict__ ovf_val, unsigned long long* __restrict__ slots, uint32_t* __restrict__ tickets,
+                     float* __restrict__ found_inf, bool overwrite, uint32_t dbg, float inf_bound) {
+    pm_accumulate_items<T, C, P, SUB>(blockIdx.x, gridDim.x, grad_table, plan, pm, sp, lv, gridtype, align_corners, level_max, cursors, ovf_cursor, log_rel, log_val,
+                                      ovf_key, ovf_val, slots, tickets, found_inf, overwrite, dbg, inf_bound);
+}
+
+struct PmBoth {
+    BinPlan plan1, plan2;
+    PmSplit sp1, sp2;
+};
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+pm_accumulate_both_kernel(float* __restrict__ table1, _Float16* __restrict__ table2, PmBoth pb, PmPlan pm, LevelTable lv, uint32_t gridtype, bool align_corners,
+                          const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ ovf_cursor,
+                          const uint16_t* __restrict__ log_rel, const uint32_t* __restrict__ log_v1, const uint32_t* __restrict__ log_v2,
+                          const uint32_t* __restrict__ ovf_key, const uint32_t* __restrict__ ovf_v1, const uint32_t* __restrict__ ovf_v2,
+                          unsigned long long* __restrict__ slots1, unsigned long long* __restrict__ slots2, uint32_t* __restrict__ tickets1,
+                          uint32_t* __restrict__ tickets2, float* __restrict__ found_inf, bool overwrite, uint32_t dbg, float bound1, float bound2, uint32_t nb1) {
+    if (blockIdx.x < nb1)
+        pm_accumulate_items<float, 1, kPairP, 2>(blockIdx.x, nb1, table1, pb.plan1, pm, pb.sp1, lv, gridtype, align_corners, level_max, cursors, ovf_cursor, log_rel,
+                                                 log_v1, ovf_key, ovf_v1, slots1, tickets1, found_inf, overwrite, dbg, bound1);
+    else
+        pm_accumulate_items<_Float16, 2, kPairP, 1>(blockIdx.x - nb1, gridDim.x - nb1, table2, pb.plan2, pm, pb.sp2, lv, gridtype, align_corners, level_max + kMaxLevels,
+                                                    cursors, ovf_cursor, log_rel, log_v2, ovf_key, ovf_v2, slots2, tickets2, found_inf, overwrite, dbg, bound2);
 }
 
 // grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]; accumulates in T like the reference (:357-365)
@@ -3076,7 +3108,7 @@ PmLayout make_pm_plan(uint32_t Bc, const BinPlan& plan) {
         mp = parts > mp ? parts : mp;
     }
     o.pm.max_parts = mp;
-    o.pm.cursors = 2u * cur;               // cursors, then the tickets of the split levels (workgroup 0 of the fill clears both)
+    o.pm.cursors = 3u * cur;               // cursors, then the tickets of the split levels, one set per table (workgroup 0 of the fill clears all)
     const uint64_t ovf = (uint64_t)plan.levels * 8u * Bc;
     o.pm.ovf_cap = (uint32_t)ovf;
     if (home >= (1ull << 30) || ovf >= (1ull << 32) || mp > kMaxPartsPerLevel) o.ok = false;      // (fill: byte offsets of an entry in 32 bits)
@@ -3090,9 +3122,9 @@ PmLayout make_pm_plan(uint32_t Bc, const BinPlan& plan) {
         if (g1 > 1u) split1 += (uint64_t)pairs * g1;
         if (plan.groups[l] > 1u) split2 += (uint64_t)plan.parts[l] * plan.groups[l];
     }
-    o.slot_count = (size_t)(split1 > split2 ? split1 : split2);
+    o.slot_count = (size_t)(split1 + split2);                  // (both tables' items run in one launch)
     const size_t r = 255;
-    o.bytes = kBinHeaderBytes + (((size_t)cur * 8 + r) & ~r) + ((home * 4 + r) & ~r) * 2 + ((home * 2 + r) & ~r) + (((size_t)ovf * 4 + r) & ~r) * 3 +
+    o.bytes = kBinHeaderBytes + (((size_t)cur * 12 + r) & ~r) + ((home * 4 + r) & ~r) * 2 + ((home * 2 + r) & ~r) + (((size_t)ovf * 4 + r) & ~r) * 3 +
               o.slot_count * (size_t)kPairP * 16u;
     return o;
 }
@@ -3149,6 +3181,7 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)pm_accumulate_kernel<float, 1, kPairP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
         (void)hipFuncSetAttribute((const void*)pm_accumulate_kernel<_Float16, 2, kPairP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
+        (void)hipFuncSetAttribute((const void*)pm_accumulate_both_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPairP * 16));
         attr_set = true;
     }
     const uint32_t TS = pm_tile_samples();
@@ -3167,7 +3200,8 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
         unsigned long long* lm_ready = (unsigned long long*)(w + 256);
         uint32_t* ovf_cursor = (uint32_t*)(w + 264);
         uint32_t* cursors = (uint32_t*)(w + kBinHeaderBytes);
-        uint32_t* tickets = cursors + pl.pm.cursors / 2u;
+        uint32_t* tickets = cursors + pl.pm.cursors / 3u;
+        uint32_t* tickets2 = tickets + pl.pm.cursors / 3u;
         w += kBinHeaderBytes + (((size_t)pl.pm.cursors * 4 + r) & ~r);
         uint32_t* log_v1 = (uint32_t*)w; w += (pl.home_entries * 4 + r) & ~r;
         uint32_t* log_v2 = (uint32_t*)w; w += (pl.home_entries * 4 + r) & ~r;
@@ -3208,7 +3242,8 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
             if (g > 1u) slots1 += pairs * g;
             if (g2n > 1u) slots2 += lay.plan.parts[l] * g2n;
         }
-        N2M_REQUIRE(slots1 <= pl.slot_count && slots2 <= pl.slot_count, N2M_EINVAL, "%s: scratch slots of the split levels exceed the layout", fn);
+        N2M_REQUIRE((size_t)slots1 + slots2 <= pl.slot_count, N2M_EINVAL, "%s: scratch slots of the split levels exceed the layout", fn);
+        unsigned long long* slots_t2 = slots + (size_t)slots1 * (kPairP * 2u);
         plan1.item_prefix[max_level] = items1;
         plan2.item_prefix[max_level] = items2;
         if (ow && max_level < L) {
@@ -3254,15 +3289,25 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
         static const uint32_t acc_cap = getenv("N2M_ACC_GRID") ? (uint32_t)atoi(getenv("N2M_ACC_GRID")) : 4096u;
         static const uint32_t acc_dbg = getenv("N2M_ACC_DEBUG") ? (uint32_t)atoi(getenv("N2M_ACC_DEBUG")) : 0u;
         const float odiv = g_cfg_overflow_div.load();
+        const uint32_t nb1 = items1 < acc_cap ? items1 : acc_cap, nb2 = items2 < acc_cap ? items2 : acc_cap;
+        static const bool one_launch = getenv("N2M_PM_ACC_SPLIT") == nullptr;
+        if (both && has2 && one_launch) {
+            PmBoth pb{plan1, plan2, sp1, sp2};
+            pm_accumulate_both_kernel<<<nb1 + nb2, 1024, kPairP * 16, s>>>(table1, table2, pb, pl.pm, lv, gridtype, align, level_max, cursors, ovf_cursor, log_rel, log_v1,
+                                                                           log_v2, ovf_key, ovf_v1, ovf_v2, slots, slots_t2, tickets, tickets2, found_inf, ow, acc_dbg,
+                                                                           3.0e38f / odiv, 65504.0f / odiv, nb1);
+            N2M_CHECK_LAUNCH();
+            continue;
+        }
         if (both) {
-            pm_accumulate_kernel<float, 1, kPairP, 2><<<items1 < acc_cap ? items1 : acc_cap, 1024, kPairP * 16, s>>>(
+            pm_accumulate_kernel<float, 1, kPairP, 2><<<nb1, 1024, kPairP * 16, s>>>(
                 table1, plan1, pl.pm, sp1, lv, gridtype, align, level_max, cursors, ovf_cursor, log_rel, log_v1, ovf_key, ovf_v1, slots, tickets, found_inf, ow, acc_dbg,
                 3.0e38f / odiv);
             N2M_CHECK_LAUNCH();
         }
         if (has2) {
-            pm_accumulate_kernel<_Float16, 2, kPairP, 1><<<items2 < acc_cap ? items2 : acc_cap, 1024, kPairP * 16, s>>>(
-                table2, plan2, pl.pm, sp2, lv, gridtype, align, level_max + kMaxLevels, cursors, ovf_cursor, log_rel, log_v2, ovf_key, ovf_v2, slots, tickets, found_inf, ow,
+            pm_accumulate_kernel<_Float16, 2, kPairP, 1><<<nb2, 1024, kPairP * 16, s>>>(
+                table2, plan2, pl.pm, sp2, lv, gridtype, align, level_max + kMaxLevels, cursors, ovf_cursor, log_rel, log_v2, ovf_key, ovf_v2, slots_t2, tickets2, found_inf, ow,
                 acc_dbg, 65504.0f / odiv);
             N2M_CHECK_LAUNCH();
         }
