@@ -20,9 +20,11 @@ steps 306.. as rounds 1-2 reported) and says so in `config.shading`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant HIP kernel of the step: algorithmic bytes per launch / mean launch duration, measured with
-                  hipEvents recorded on the launch stream inside the timed region (n2m_prof_*), against the 8 TB/s HBM peak
-  cpu_baseline -- the CPU oracle (oracle/n2m_oracle.c, OpenMP over all host cores) + PyTorch-CPU MLPs timed on a bounded
-                  sample of the same workload (rank 0, N=1 only)
+                  hipEvents attached to the kernel dispatches on the launch stream inside the timed region (n2m_prof_*), against the
+                  8 TB/s HBM peak and against a stream copy timed in the same process (peak_measured)
+  cpu_baseline -- the CPU oracle (oracle/n2m_oracle.c, OpenMP, 32 threads) + PyTorch-CPU MLPs timed on a bounded sample of the same
+                  workload (rank 0, N=1 only); cpu_baseline_reference -- the same iteration on the reference's own kernels compiled for the
+                  host (oracle/_ref, one core)
 """
 import argparse
 import json
@@ -43,7 +45,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured floa
 
 # device kernels behind each library entry point, for the PMC traffic lookup: (substrings of the kernel names, how their
 # per-launch byte counts combine into one call of the entry point)
-_DEVICE_KERNELS = {"grid_encode_backward": (("bin_fill_pair_kernel", "bin_accumulate_kernel"), "sum"),     # one call = fill + both accumulates
+_DEVICE_KERNELS = {"grid_encode_backward": (("pm_fill_pair_kernel", "pm_accumulate_both_kernel"), "sum"),     # one call = fill + the accumulate of both tables
                    "grid_encode_forward_packed": (("grid_forward3_packed_kernel",), "sum"),                  # one call = both tables (packed copy)
                    "adam_step": (("adam_kernel",), "sum"),
                    "mlp_backward": (("field_backward_pc_kernel<true, true>", "field_backward_pc_kernelILb1ELb1", "dw_finalize_kernel"), "sum"),
@@ -130,6 +132,95 @@ def cpu_baseline(n_rays=32768, reps=4, threads=None):
     return {"value": M / best, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"1 stage-0 iteration (march+2 encodes+MLPs+composite fwd/bwd+TV, no Adam/occupancy refresh) on {n_rays} rays = "
                       f"{M} samples, best of {reps}; oracle C/OpenMP + torch-CPU MLPs"}
+
+
+def cpu_baseline_reference(n_rays=2048, reps=2):
+    """The same iteration on the REFERENCE's own kernels: raymarching.cu / gridencoder.cu compiled for the host by oracle/build_ref.py
+    (oracle/_ref: every arithmetic statement is the reference's; a launch is a serial sweep over blockIdx / threadIdx, so this is ONE core)
+    + torch-CPU MLPs.  kind = "reference".  Bounded: ~n_rays rays of the same synthetic workload."""
+    from oracle import build_ref
+    from oracle import oracle as orc
+    from nerf2mesh_amd import synthetic as S
+    if not build_ref.available():
+        return {"value": None, "unit": "samples/s", "cores": 1, "kind": "reference", "sample": "oracle/_ref is not built on this box"}
+    rm, ge, _ = build_ref.load()
+    torch.set_num_threads(1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    poses = S.make_cameras(100, seed=0)
+    bits = orc.packbits(S.scene_density_grid(H=128).numpy(), 10.0)
+    o, d = S.random_rays(poses, n_rays, torch.Generator().manual_seed(1))
+    N = n_rays
+    aabb = t(np.array([-1, -1, -1, 1, 1, 1], np.float32))
+    pls = float(np.exp2(np.log2(2048 / 16) / 15))
+    offs = t(orc.level_offsets(3, 16, pls, 16, 19))
+    S_ = float(np.log2(pls))
+    rng = np.random.default_rng(0)
+    rows = int(offs[-1])
+    emb1 = t((rng.random((rows, 1), dtype=np.float32) * 2 - 1) * 1e-4)
+    emb2 = t(((rng.random((rows, 2), dtype=np.float32) * 2 - 1) * 1e-4).astype(np.float16))      # the colour table is cast to half (grid.py:45)
+    sigma_net = torch.nn.Sequential(torch.nn.Linear(19, 32, bias=False), torch.nn.ReLU(), torch.nn.Linear(32, 1, bias=False))
+    color_net = torch.nn.Sequential(torch.nn.Linear(35, 64, bias=False), torch.nn.ReLU(), torch.nn.Linear(64, 64, bias=False),
+                                    torch.nn.ReLU(), torch.nn.Linear(64, 6, bias=False))
+    spec_net = torch.nn.Sequential(torch.nn.Linear(6, 32, bias=False), torch.nn.ReLU(), torch.nn.Linear(32, 3, bias=False))
+    best, M = None, 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        nears, fars = torch.zeros(N), torch.zeros(N)
+        rm.near_far_from_aabb(o, d, aabb, N, 0.05, nears, fars)
+        noises = torch.rand(N)
+        rays, counter = torch.zeros(N, 2, dtype=torch.int32), torch.zeros(1, dtype=torch.int32)
+        margs = (o, d, t(bits), 1.0, False, 0.0, 1024, N, 1, 128, nears, fars)
+        rm.march_rays_train(*margs, None, None, None, rays, counter, noises)
+        M = int(counter[0])
+        xyzs, dirs, ts = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+        rm.march_rays_train(*margs, xyzs, dirs, ts, rays, counter, noises)
+        x01 = (xyzs + 1) / 2
+        f1 = torch.zeros(16, M, 1); f2 = torch.zeros(16, M, 2, dtype=torch.float16)
+        ge.grid_encode_forward(x01, emb1, offs, f1, M, 3, 1, 16, 16, S_, 16, None, 0, False, 0)
+        ge.grid_encode_forward(x01, emb2, offs, f2, M, 3, 2, 16, 16, S_, 16, None, 0, False, 0)
+        h1 = f1.permute(1, 0, 2).reshape(M, 16).requires_grad_(True)
+        h2 = f2.permute(1, 0, 2).reshape(M, 32).float().requires_grad_(True)
+        sig = torch.exp(sigma_net(torch.cat([xyzs, h1], -1))[:, 0])
+        geo = torch.sigmoid(color_net(torch.cat([xyzs, h2], -1)))
+        dn = dirs / dirs.norm(dim=-1, keepdim=True)
+        spec = torch.sigmoid(spec_net(torch.cat([dn, geo[:, 3:]], -1)))
+        rgb = (spec + geo[:, :3]).clamp(0, 1)
+        w, ws, dp, im = torch.zeros(M), torch.zeros(N), torch.zeros(N), torch.zeros(N, 3)
+        sd, rd = sig.detach().contiguous(), rgb.detach().contiguous()
+        rm.composite_rays_train_forward(sd, rd, ts, rays, M, N, 1e-4, False, w, ws, dp, im)
+        gi = (2 * (im - 0.5) / im.numel()).contiguous()
+        gs, gr = torch.zeros(M), torch.zeros(M, 3)
+        rm.composite_rays_train_backward(torch.zeros(M), torch.zeros(N), torch.zeros(N), gi, sd, rd, ts, rays, ws, dp, im, M, N, 1e-4, False, gs, gr)
+        torch.autograd.backward([sig, rgb], [gs, gr])
+        g1, g2 = torch.zeros_like(emb1), torch.zeros_like(emb2)
+        d1 = h1.grad.reshape(M, 16, 1).permute(1, 0, 2).contiguous()
+        d2 = h2.grad.reshape(M, 16, 2).permute(1, 0, 2).contiguous().half()
+        ge.grid_encode_backward(d1, x01, emb1, offs, g1, M, 3, 1, 16, 16, S_, 16, None, None, 0, False, 0)
+        ge.grid_encode_backward(d2, x01, emb2, offs, g2, M, 3, 2, 16, 16, S_, 16, None, None, 0, False, 0)
+        ge.grad_total_variation(x01, emb1, g1, offs, 1e-8, M, 3, 1, 16, S_, 16, 0, False)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": M / best, "unit": "samples/s", "cores": 1, "kind": "reference",
+            "sample": f"1 stage-0 iteration (march+2 encodes+MLPs+composite fwd/bwd+TV, no Adam/occupancy refresh) on {n_rays} rays = {M} samples, "
+                      f"best of {reps}: {best:.2f} s; the reference's raymarching.cu / gridencoder.cu compiled for the host (oracle/_ref, serial sweep) "
+                      "+ torch-CPU MLPs on one thread"}
+
+
+def measured_stream_peak(device, mbytes=1024, reps=20):
+    """GB/s of a device-to-device copy of `mbytes` MB (read + write counted), torch's vectorised copy kernel, in THIS process on THIS
+    device: the practical streaming ceiling the nominal 8 TB/s is never reached at (SURVEY 8d asks for it as a second denominator)."""
+    n = mbytes * (1 << 20) // 4
+    a = torch.empty(n, dtype=torch.float32, device=device).normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def cpu_baseline_stage1(v, f, reps=2):
@@ -254,9 +345,10 @@ def main():
                     "instead of the steady-state step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel hipEvents in the timed region")
-    ap.add_argument("--prof-every", type=int, default=16, help="time every n-th launch of each kernel with hipEvents (1 = all).  An event pair costs the "
-                    "stream 3-7 us of queue latency: every 4th launch of ten kernels was 14 us per step (0.630 against 0.616 ms without events), "
-                    "every 16th is 5 us -- still 12 samples per kernel over the default 200 steps")
+    ap.add_argument("--prof-every", type=int, default=None, help="time every n-th launch of each kernel with hipEvents (1 = all); default "
+                    "max(1, steps // 12): at least a dozen samples per kernel whatever --steps is (the driver runs 20).  The events of the step's "
+                    "kernels ride on the kernel dispatches themselves (hipExtLaunchKernel start / stop events, N2M_PROF_K in csrc/n2m_common.hpp): no "
+                    "marker packets in the queue, the durations are the dispatches' own timestamps like rocprofv3's")
     ap.add_argument("--stage", type=int, default=0, choices=[0, 1], help="0: stage-0 volume rendering (the headline metric); "
                     "1: stage-1 mesh/texture refinement step (BASELINE config 3)")
     ap.add_argument("--autograd", action="store_true", help="A/B: drive the step through torch.autograd (trainer.Stage0Trainer) instead of the step "
@@ -278,6 +370,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     if args.pretrain is None:
         args.pretrain = 300 if args.diffuse else 1000
+    if args.prof_every is None:
+        args.prof_every = max(1, args.steps // 12)
+        if args.prof_every > 1 and args.prof_every % 2 == 0:
+            args.prof_every += 1       # odd: every 16th launch of a kernel is always the same phase of the 16-step occupancy-refresh cycle
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become the launcher -- one rank per GPU under torch.distributed.run, exactly
         # the command the driver uses (the JSON line then reports n_gpus = the rank count that actually ran)
@@ -383,13 +479,24 @@ def main():
                                  "GBps": (by / n) / (ms / n * 1e-3) / 1e9 if ms > 0 else None,
                                  "ms_per_step": (ms / n) * seen / args.steps,                    # mean timed duration x launches per step
                                  "stream": "side (overlaps the main stream: not part of the step's critical path)" if name in side_stream else "main"}
+    try:
+        peak_measured = measured_stream_peak(device)
+    except Exception as e:
+        print(f"[bench] stream-copy peak not measured: {e!r}", file=sys.stderr)
+        peak_measured = None
+
     def roofline_of(name):
         k = kernels[name]
         traffic, source = pmc_traffic(name)
+        if k["launches"] < 8:
+            print(f"[bench] WARNING: {name}: only {k['launches']} timed launches in {args.steps} steps -- lower --prof-every", file=sys.stderr)
         return {"kernel": name, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (k["GBps"] / HBM_PEAK_GBS) if k["GBps"] else None, "traffic": traffic, "traffic_source": source,
-                "avg_us": k["avg_us"], "algo_bytes_per_launch": k["algo_bytes_per_launch"],
-                "note": "achieved = algorithmic bytes per launch (SURVEY.md 8d; cache hits count) / mean hipEvent duration over the timed region"}
+                "peak_measured": peak_measured, "frac_of_measured": (k["GBps"] / peak_measured) if (k["GBps"] and peak_measured) else None,
+                "launches": k["launches"], "avg_us": k["avg_us"], "algo_bytes_per_launch": k["algo_bytes_per_launch"],
+                "note": "achieved = algorithmic bytes per launch (SURVEY.md 8d; cache hits count) / mean duration of the entry point's kernels over the "
+                        "timed region (hipEvents attached to the dispatches: start of the first kernel to end of the last); peak = nominal HBM3E, "
+                        "peak_measured = a 1 GB device-to-device copy (read + write) timed in this process after the timed region"}
     roof = roof_lookup = None
     main_ms = sum(k["ms_per_step"] for k in kernels.values() if k["stream"] == "main")
     side_ms = sum(k["ms_per_step"] for k in kernels.values() if k["stream"] != "main")
@@ -404,12 +511,16 @@ def main():
                       "events do not bracket the launch; the entry is withdrawn", file=sys.stderr)
                 r.update(achieved=None, frac=None, note="WITHDRAWN: the measured duration is implausible (events did not bracket the launch)")
 
-    cpu = None
+    cpu = cpu_ref = None
     if world == 1 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline()
         except Exception as e:   # the baseline is a reported extra; never lose the GPU number over it
             cpu = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+        try:
+            cpu_ref = cpu_baseline_reference()
+        except Exception as e:
+            cpu_ref = {"value": None, "unit": "samples/s", "cores": 1, "kind": "reference", "sample": f"failed: {e!r}"}
 
     try:
         psnr = tr.eval_psnr()
@@ -436,13 +547,13 @@ def main():
                    "driver": "engine.Stage0Engine (fixed launch sequence)" if use_engine else "trainer.Stage0Trainer (torch.autograd)", "pretrain_steps": args.pretrain, "samples_per_step_per_gpu": samples / args.steps / world,
                    "rays_per_step_per_gpu": rays / args.steps / world, "params": 18367240},
         "roofline": roof, "roofline_lookup": roof_lookup, "kernels": kernels,
-        "kernels_note": (f"per-kernel hipEvent pairs on every {args.prof_every}-th launch; ms_per_step = mean timed duration x launches seen / steps. "
-                         f"Main-stream entries sum to {main_ms:.3f} ms/step (an event pair adds 3-7 us of queue latency around what it encloses, "
-                         f"profiles/r02_trace_vs_events.txt; small launches without events -- composite+loss, bookkeeping -- are not listed); "
+        "kernels_note": (f"per-kernel hipEvents on every {args.prof_every}-th launch (kernel ids staggered), attached to the kernel dispatches of the "
+                         f"step's entry points; ms_per_step = mean timed duration x launches seen / steps. "
+                         f"Main-stream entries sum to {main_ms:.3f} ms/step (small launches without events -- bookkeeping -- are not listed); "
                          f"side-stream entries ({side_ms:.3f} ms/step: next-but-one batch's ray generation and march) run beside the main stream's "
                          "Adam / forward and are NOT part of the step time; grid_encode_forward (unpacked) = the occupancy refresh's density query, "
                          "once per 16 steps") if kernels else None,
-        "cpu_baseline": cpu, "psnr_view0_quarter_res": psnr,
+        "cpu_baseline": cpu, "cpu_baseline_reference": cpu_ref, "psnr_view0_quarter_res": psnr,
         "loss_mean": float(tr.loss_acc / max(tr.global_step, 1)),
     }
     print(json.dumps(line))

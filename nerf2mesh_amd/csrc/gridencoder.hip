@@ -3162,11 +3162,11 @@ int launch_pm_fill(dim3 grid, size_t lds, hipStream_t s, bool fold_on, int tvmod
 #define N2M_PM_ARGS g1, g2, x, tv, tvt, Bc, B, plan, pm, lv, gridtype, align, interp, level_max, cursors, ovf_cursor, log_rel, log_v1, log_v2, ovf_key, ovf_v1, \
                     ovf_v2, found_inf, in_scale, in_offset, clear1, clear2, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token, in_level_stride, fo
     if (fold_on) {
-        if (tvmode == 1) pm_fill_pair_kernel<1, true, TS><<<grid, TS, lds, s>>>(N2M_PM_ARGS);
-        else pm_fill_pair_kernel<0, true, TS><<<grid, TS, lds, s>>>(N2M_PM_ARGS);
-    } else if (tvmode == 1) pm_fill_pair_kernel<1, false, TS><<<grid, TS, lds, s>>>(N2M_PM_ARGS);
-    else if (tvmode == 2) pm_fill_pair_kernel<2, false, TS><<<grid, TS, lds, s>>>(N2M_PM_ARGS);
-    else pm_fill_pair_kernel<0, false, TS><<<grid, TS, lds, s>>>(N2M_PM_ARGS);
+        if (tvmode == 1) N2M_LAUNCH((pm_fill_pair_kernel<1, true, TS>), grid, TS, lds, s, N2M_PM_ARGS);
+        else N2M_LAUNCH((pm_fill_pair_kernel<0, true, TS>), grid, TS, lds, s, N2M_PM_ARGS);
+    } else if (tvmode == 1) N2M_LAUNCH((pm_fill_pair_kernel<1, false, TS>), grid, TS, lds, s, N2M_PM_ARGS);
+    else if (tvmode == 2) N2M_LAUNCH((pm_fill_pair_kernel<2, false, TS>), grid, TS, lds, s, N2M_PM_ARGS);
+    else N2M_LAUNCH((pm_fill_pair_kernel<0, false, TS>), grid, TS, lds, s, N2M_PM_ARGS);
 #undef N2M_PM_ARGS
     N2M_CHECK_LAUNCH();
     return 0;
@@ -3293,20 +3293,20 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
         static const bool one_launch = getenv("N2M_PM_ACC_SPLIT") == nullptr;
         if (both && has2 && one_launch) {
             PmBoth pb{plan1, plan2, sp1, sp2};
-            pm_accumulate_both_kernel<<<nb1 + nb2, 1024, kPairP * 16, s>>>(table1, table2, pb, pl.pm, lv, gridtype, align, level_max, cursors, ovf_cursor, log_rel, log_v1,
+            N2M_LAUNCH(pm_accumulate_both_kernel, nb1 + nb2, 1024, kPairP * 16, s, table1, table2, pb, pl.pm, lv, gridtype, align, level_max, cursors, ovf_cursor, log_rel, log_v1,
                                                                            log_v2, ovf_key, ovf_v1, ovf_v2, slots, slots_t2, tickets, tickets2, found_inf, ow, acc_dbg,
                                                                            3.0e38f / odiv, 65504.0f / odiv, nb1);
             N2M_CHECK_LAUNCH();
             continue;
         }
         if (both) {
-            pm_accumulate_kernel<float, 1, kPairP, 2><<<nb1, 1024, kPairP * 16, s>>>(
+            N2M_LAUNCH((pm_accumulate_kernel<float, 1, kPairP, 2>), nb1, 1024, kPairP * 16, s, 
                 table1, plan1, pl.pm, sp1, lv, gridtype, align, level_max, cursors, ovf_cursor, log_rel, log_v1, ovf_key, ovf_v1, slots, tickets, found_inf, ow, acc_dbg,
                 3.0e38f / odiv);
             N2M_CHECK_LAUNCH();
         }
         if (has2) {
-            pm_accumulate_kernel<_Float16, 2, kPairP, 1><<<nb2, 1024, kPairP * 16, s>>>(
+            N2M_LAUNCH((pm_accumulate_kernel<_Float16, 2, kPairP, 1>), nb2, 1024, kPairP * 16, s, 
                 table2, plan2, pl.pm, sp2, lv, gridtype, align, level_max + kMaxLevels, cursors, ovf_cursor, log_rel, log_v2, ovf_key, ovf_v2, slots_t2, tickets2, found_inf, ow,
                 acc_dbg, 65504.0f / odiv);
             N2M_CHECK_LAUNCH();
@@ -3338,6 +3338,7 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         const int rc = launch_binned_pair_pm(grad1, grad2, inputs, tv, table1, table2, B, max_level, host_offsets, lv, gridtype, align, interp, workspace,
                                              workspace_bytes, s, fn, found_inf, in_scale, in_offset, overwrite, L, half, tv_terms, fold, in_level_stride);
         if (rc != -1) return rc;
+        n2m_prof_fall_back_to_markers(s);                      // the tile-major launches below are plain ones
     }
     N2M_REQUIRE(in_level_stride == 0 || B <= kBinChunk, N2M_EINVAL, "%s: per-level point lists need one pass (B <= %u)", fn, kBinChunk);
     for (uint32_t b0 = 0; b0 < B; b0 += kBinChunk) {
@@ -3726,7 +3727,9 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
     N2M_REQUIRE(!(tv_terms && tv_embeddings), N2M_EINVAL, "%s: either the TV table (computed in place) or precomputed TV terms", fn);
     N2M_REQUIRE(!tv_terms || (grad1 && max_level == L), N2M_EINVAL, "%s: TV terms ride on the density table's entries and need max_level == L", fn);
     // (+ the TV stencil's reads when it is evaluated in place; precomputed terms: 4 B per (sample, level), the stencil is n2m_grid_tv_terms')
-    N2M_PROF(N2M_K_GRID_BWD, s, (double)B * (12.0 + lvls * esz + 2.0 * lvls * 8 * esz + (tv_embeddings ? lvls * 7 * 4.0 : 0.0) + (tv_terms ? lvls * 4.0 : 0.0)));
+    // (kernel-attached events on the partition-major path, whose launches go through N2M_LAUNCH; marker events around the tile-major one)
+    N2mProfScope prof_scope__(N2M_K_GRID_BWD, s, (double)B * (12.0 + lvls * esz + 2.0 * lvls * 8 * esz + (tv_embeddings ? lvls * 7 * 4.0 : 0.0) + (tv_terms ? lvls * 4.0 : 0.0)),
+                              pm_enabled() && !fuse1 && !fuse2);
     return launch_binned_pair(grad1, (const _Float16*)grad2, inputs, tv, grad_embeddings1, (_Float16*)grad_embeddings2, B, max_level, host_offsets, lv,
                               gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf, in_scale, in_offset, overwrite != 0, L,
                               half, tv_terms, fuse1, fuse2, fold, in_level_stride);
@@ -4035,14 +4038,14 @@ extern "C" int n2m_grid_encode_forward_packed(const float* inputs, const void* p
     const LevelTable lv = make_levels(L, S, H);
     // algorithmic bytes of both encoders' forward (588 B/sample each at L = 16, one 12-byte input read shared)
     // (one scope object for the whole launch: its destructor records the closing event)
-    N2M_PROF(outputs2 ? N2M_K_GRID_FWD_PACKED : N2M_K_GRID_FWD, s,
+    N2M_PROF_K(outputs2 ? N2M_K_GRID_FWD_PACKED : N2M_K_GRID_FWD, s,
              outputs2 ? (double)B * (12.0 + (double)max_level * 8 * (4 + 4) + (double)max_level * (4 + 4))
                       : (double)B * (12.0 + (double)max_level * 8 * 4 + (double)max_level * 4));
     const uint32_t n_tiles = n2m_ceil_div(B, 256);
     static const uint32_t xg_env = getenv("N2M_FWD_XCD_GROUP") ? (uint32_t)atoi(getenv("N2M_FWD_XCD_GROUP")) : 4u;     // A/B switch: 0 = level-major grid
     const uint32_t xg = (max_level == 16u && (xg_env == 1u || xg_env == 2u || xg_env == 4u)) ? xg_env : 0u;
     const uint32_t blocks = xg ? 8u * (16u / (8u / xg)) * n2m_ceil_div(n_tiles, xg) : n_tiles * max_level;
-    grid_forward3_packed_kernel<<<blocks, 256, 0, s>>>(inputs, (const uint2*)packed, offsets, outputs1, (_Float16*)outputs2, B,
+    N2M_LAUNCH(grid_forward3_packed_kernel, blocks, 256, 0, s, inputs, (const uint2*)packed, offsets, outputs1, (_Float16*)outputs2, B,
                                                        max_level, lv, gridtype, align_corners != 0, interp, n_tiles, in_scale,
                                                        in_offset, xg);
     N2M_CHECK_LAUNCH();

@@ -1187,11 +1187,11 @@ static int field_forward_impl(const float* xyz, const float* dirs, const float* 
     a.M = M; a.shading = shading; a.sigma = sigma; a.rgb = rgb; a.specular = specular;
     a.spec_sq_partial = (color && shading != 0) ? spec_sq_partial : nullptr;
     hipStream_t s = (hipStream_t)stream;
-    N2M_PROF(N2M_K_MLP_FWD, s, (double)M * (12 + 64 + 4 + (color ? 64 + 12 + 12 + 12 : 0)));
+    N2M_PROF_K(N2M_K_MLP_FWD, s, (double)M * (12 + 64 + 4 + (color ? 64 + 12 + 12 + 12 : 0)));
     const size_t smem = (size_t)FWD_HALVES * 2;
-    if (color && density) field_forward_kernel<true, true><<<persistent_grid(M) * 2, 256, smem, s>>>(a);
-    else if (color) field_forward_kernel<false, true><<<persistent_grid(M) * 2, 256, smem, s>>>(a);
-    else field_forward_kernel<true, false><<<persistent_grid(M) * 2, 256, smem, s>>>(a);
+    if (color && density) N2M_LAUNCH((field_forward_kernel<true, true>), persistent_grid(M) * 2, 256, smem, s, a);
+    else if (color) N2M_LAUNCH((field_forward_kernel<false, true>), persistent_grid(M) * 2, 256, smem, s, a);
+    else N2M_LAUNCH((field_forward_kernel<true, false>), persistent_grid(M) * 2, 256, smem, s, a);
     N2M_CHECK_LAUNCH();
     return 0;
 }
@@ -1249,7 +1249,7 @@ static int field_backward_impl(const float* xyz, const float* dirs, const float*
     static const int dbg = getenv("N2M_FIELD_DEBUG") ? atoi(getenv("N2M_FIELD_DEBUG")) : 0;
     a.dbg = dbg;
     hipStream_t s = (hipStream_t)stream;
-    N2M_PROF(N2M_K_MLP_BWD, s, (double)M * (12 + 64 + 4 + 64 + (color ? 64 + 12 + 24 + 64 : 0)));
+    N2M_PROF_K(N2M_K_MLP_BWD, s, (double)M * (12 + 64 + 4 + 64 + (color ? 64 + 12 + 24 + 64 : 0)));
     static const bool single_wave = getenv("N2M_FIELD_BWD_SINGLE") != nullptr;     // A/B switch: the one-wave-per-SIMD kernel
     if (!single_wave) {
         const size_t smem = (size_t)BWD_PC_HALVES * 2;
@@ -1257,21 +1257,21 @@ static int field_backward_impl(const float* xyz, const float* dirs, const float*
         float* part = dw_scratch(s);
         N2M_REQUIRE(part != nullptr, (int)hipErrorOutOfMemory, "field_backward: no memory for the weight-gradient scratch");
         a.dw_partial = part;
-        if (color && density) field_backward_pc_kernel<true, true><<<grid, 512, smem, s>>>(a);
-        else if (color) field_backward_pc_kernel<false, true><<<grid, 512, smem, s>>>(a);
-        else field_backward_pc_kernel<true, false><<<grid, 512, smem, s>>>(a);
+        if (color && density) N2M_LAUNCH((field_backward_pc_kernel<true, true>), grid, 512, smem, s, a);
+        else if (color) N2M_LAUNCH((field_backward_pc_kernel<false, true>), grid, 512, smem, s, a);
+        else N2M_LAUNCH((field_backward_pc_kernel<true, false>), grid, 512, smem, s, a);
         N2M_CHECK_LAUNCH();
         DwOut o;
         for (int i = 0; i < 7; ++i) o.dw[i] = dw[i];
         const uint32_t mask = (density ? 0x03u : 0u) | (color ? 0x1Cu : 0u) | (color && shading != 0 ? 0x60u : 0u);
-        if (!(dbg & 2)) dw_finalize_kernel<<<(kDwTotal + 63) / 64, 1024, 0, s>>>(part, grid, o, mask, found_inf);
+        if (!(dbg & 2)) N2M_LAUNCH(dw_finalize_kernel, (kDwTotal + 63) / 64, 1024, 0, s, part, grid, o, mask, found_inf);
         N2M_CHECK_LAUNCH();
         return 0;
     }
     const size_t smem = (size_t)BWD_HALVES * 2;
-    if (color && density) field_backward_kernel<true, true><<<persistent_grid(M), 256, smem, s>>>(a);
-    else if (color) field_backward_kernel<false, true><<<persistent_grid(M), 256, smem, s>>>(a);
-    else field_backward_kernel<true, false><<<persistent_grid(M), 256, smem, s>>>(a);
+    if (color && density) N2M_LAUNCH((field_backward_kernel<true, true>), persistent_grid(M), 256, smem, s, a);
+    else if (color) N2M_LAUNCH((field_backward_kernel<false, true>), persistent_grid(M), 256, smem, s, a);
+    else N2M_LAUNCH((field_backward_kernel<true, false>), persistent_grid(M), 256, smem, s, a);
     N2M_CHECK_LAUNCH();
     return 0;
 }

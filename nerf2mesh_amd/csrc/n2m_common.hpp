@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -46,10 +47,29 @@ static inline uint32_t n2m_ceil_div(uint64_t a, uint64_t b) { return (uint32_t)(
 struct N2mProfScope {
     int slot;
     hipStream_t stream;
-    N2mProfScope(int kernel_id, hipStream_t s, double algo_bytes);
+    bool kernel_events;
+    N2mProfScope(int kernel_id, hipStream_t s, double algo_bytes, bool kernel_events = false);
     ~N2mProfScope();
 };
 #define N2M_PROF(kernel_id, stream, bytes) N2mProfScope prof_scope__((kernel_id), (stream), (double)(bytes))
+// N2M_PROF_K + N2M_LAUNCH: the event pair rides ON the kernel dispatches of the entry (hipExtLaunchKernel: start of the first kernel, end of
+// the last) instead of in marker packets around them.  A marker pair serialises the queue and adds 10-30 us to what it brackets (round 4:
+// 237 us by markers for a table backward whose two kernels take 203 us in the rocprofv3 trace of the same run); kernel-attached events
+// read the dispatch's own timestamps, like the tracer does, and add no packet.  Every launch inside an N2M_PROF_K entry goes through
+// N2M_LAUNCH (template kernels in parentheses).
+#define N2M_PROF_K(kernel_id, stream, bytes) N2mProfScope prof_scope__((kernel_id), (stream), (double)(bytes), true)
+struct N2mProfLaunchState { hipEvent_t a, b; int armed; };        // armed: 0 off, 1 the entry's first launch is still to come, 2 later launches, 3 markers
+N2mProfLaunchState& n2m_prof_launch_state();
+void n2m_prof_fall_back_to_markers(hipStream_t s);       // an N2M_PROF_K entry that ends up on plain launches: marker events from here on
+#define N2M_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                                         \
+    do {                                                                                                                            \
+        N2mProfLaunchState& pl__ = n2m_prof_launch_state();                                                                         \
+        if (pl__.armed) {                                                                                                           \
+            hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), (uint32_t)(shmem), (stream), pl__.armed == 1 ? pl__.a : nullptr, \
+                                  pl__.b, 0, __VA_ARGS__);                                                                          \
+            pl__.armed = 2;                                                                                                         \
+        } else kernel<<<(grid), (block), (shmem), (stream)>>>(__VA_ARGS__);                                                         \
+    } while (0)
 
 // ------------------------------------------------------------------------------------------- device bits
 #define N2M_WAVE 64

@@ -1547,14 +1547,14 @@ extern "C" int n2m_march_rays_train_fused(const float* rays_o, const float* rays
     const uint32_t blocks = n2m_ceil_div(N, 4);
     N2M_HIP(hipMemsetAsync(group_total, 0, march_group_bytes(N), s));
     {
-        N2M_PROF(N2M_K_MARCH_COUNT, s, 52.0 * N);
-        march_train_record_kernel<<<blocks, 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C, H, nears, fars, rays,
+        N2M_PROF_K(N2M_K_MARCH_COUNT, s, 52.0 * N);
+        N2M_LAUNCH(march_train_record_kernel, blocks, 256, 0, s, rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C, H, nears, fars, rays,
                                                          noises, serial_resolve(), recs, n_recs, group_total);
         N2M_CHECK_LAUNCH();
     }
     {
-        N2M_PROF(N2M_K_MARCH_WRITE, s, 44.0 * N);   // + 32 B per sample, added by the caller who knows M
-        march_train_replay_kernel<<<blocks, 256, 0, s>>>(rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C, H, nears, fars, xyzs,
+        N2M_PROF_K(N2M_K_MARCH_WRITE, s, 44.0 * N);   // + 32 B per sample, added by the caller who knows M
+        N2M_LAUNCH(march_train_replay_kernel, blocks, 256, 0, s, rays_o, rays_d, grid, bound, contract != 0, dt_gamma, max_steps, N, C, H, nears, fars, xyzs,
                                                          dirs, ts, rays, counter, noises, max_points, serial_resolve(), recs, n_recs, group_total);
         N2M_CHECK_LAUNCH();
     }
@@ -1618,18 +1618,18 @@ extern "C" int n2m_composite_loss_train_ex(const float* sigmas, const float* rgb
     if (M > 0) { N2M_NOTNULL(sigmas); N2M_NOTNULL(rgbs); N2M_NOTNULL(ts); N2M_NOTNULL(grad_sigmas); N2M_NOTNULL(grad_rgbs); }
     if (N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    N2M_PROF(N2M_K_COMPOSITE_FWD, s, 28.0 * M + 28.0 * N + 44.0 * M + 48.0 * N);     // forward + backward of SURVEY 8d, one launch
+    N2M_PROF_K(N2M_K_COMPOSITE_FWD, s, 28.0 * M + 28.0 * N + 44.0 * M + 48.0 * N);     // forward + backward of SURVEY 8d, one launch
     if (alpha_mode) {
         N2M_REQUIRE(lambda_entropy <= 0.0f, N2M_EUNSUPPORTED, "composite_loss_train: alpha mode with the entropy term is not built");
-        composite_loss_train_kernel<false, true><<<n2m_ceil_div(N, 16), 1024, 0, s>>>(sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar,
+        N2M_LAUNCH((composite_loss_train_kernel<false, true>), n2m_ceil_div(N, 16), 1024, 0, s, sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar,
                                                                                      lambda_rgb, lambda_mask, grad_loss, weights_sum, image, grad_sigmas,
                                                                                      grad_rgbs, partial, ticket, loss, loss_sum, 0.0f);
     } else if (lambda_entropy > 0.0f)
-        composite_loss_train_kernel<true><<<n2m_ceil_div(N, 16), 1024, 0, s>>>(sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar,
+        N2M_LAUNCH((composite_loss_train_kernel<true>), n2m_ceil_div(N, 16), 1024, 0, s, sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar,
                                                                               lambda_rgb, lambda_mask, grad_loss, weights_sum, image, grad_sigmas,
                                                                               grad_rgbs, partial, ticket, loss, loss_sum, lambda_entropy);
     else
-        composite_loss_train_kernel<false><<<n2m_ceil_div(N, 16), 1024, 0, s>>>(sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar,
+        N2M_LAUNCH((composite_loss_train_kernel<false>), n2m_ceil_div(N, 16), 1024, 0, s, sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar,
                                                                                lambda_rgb, lambda_mask, grad_loss, weights_sum, image, grad_sigmas,
                                                                                grad_rgbs, partial, ticket, loss, loss_sum, 0.0f);
     N2M_CHECK_LAUNCH();

@@ -40,10 +40,21 @@ const char* kNames[N2M_K_COUNT] = {"grid_encode_forward", "grid_encode_backward"
                                    "interpolate_forward", "interpolate_backward", "antialias_forward", "antialias_backward", "rasterize_backward"};
 }  // namespace
 
-N2mProfScope::N2mProfScope(int kernel_id, hipStream_t s, double algo_bytes) : slot(-1), stream(s) {
+N2mProfLaunchState& n2m_prof_launch_state() {
+    static thread_local N2mProfLaunchState st{nullptr, nullptr, 0};
+    return st;
+}
+
+void n2m_prof_fall_back_to_markers(hipStream_t s) {
+    N2mProfLaunchState& st = n2m_prof_launch_state();
+    if (st.armed == 1) { (void)hipEventRecord(st.a, s); st.armed = 3; }
+}
+
+N2mProfScope::N2mProfScope(int kernel_id, hipStream_t s, double algo_bytes, bool kernel_events_) : slot(-1), stream(s), kernel_events(kernel_events_) {
     if (g_every == 0) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    if ((g_seen[kernel_id]++ % (uint64_t)g_every) != 0) return;       // sampled timing: keeps the event overhead out of the step
+    // sampled timing: every g_every-th launch of a kernel id, the ids staggered so that one step does not carry every entry's events
+    if (((g_seen[kernel_id]++ + (uint64_t)kernel_id * 3u) % (uint64_t)g_every) != 0) return;
     if (g_used >= kPool) {
         g_untimed[kernel_id]++;
         return;
@@ -56,11 +67,22 @@ N2mProfScope::N2mProfScope(int kernel_id, hipStream_t s, double algo_bytes) : sl
     slot = g_used++;
     g_slots[slot].kernel = kernel_id;
     g_slots[slot].bytes = algo_bytes;
-    (void)hipEventRecord(g_slots[slot].a, stream);
+    if (kernel_events) {
+        N2mProfLaunchState& st = n2m_prof_launch_state();
+        st.a = g_slots[slot].a; st.b = g_slots[slot].b; st.armed = 1;
+    } else (void)hipEventRecord(g_slots[slot].a, stream);
 }
 
 N2mProfScope::~N2mProfScope() {
-    if (slot >= 0) (void)hipEventRecord(g_slots[slot].b, stream);
+    if (slot < 0) return;
+    if (kernel_events) {
+        N2mProfLaunchState& st = n2m_prof_launch_state();
+        if (st.armed == 1) {                                         // the entry launched nothing (empty batch): a defined, empty interval
+            (void)hipEventRecord(g_slots[slot].a, stream);
+            (void)hipEventRecord(g_slots[slot].b, stream);
+        } else if (st.armed == 3) (void)hipEventRecord(g_slots[slot].b, stream);
+        st.armed = 0;
+    } else (void)hipEventRecord(g_slots[slot].b, stream);
 }
 
 extern "C" int n2m_prof_enable(int on) {

@@ -860,8 +860,8 @@ extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, f
         double bytes = 0;
         for (uint32_t k = 0; k < d->count; ++k)
             bytes += (double)d->numel[k] * (24.0 + (d->grad_is_half[k] ? 2.0 : 4.0) + (t.shadow_mode[k] == 1 ? 2.0 : (t.shadow_mode[k] == 2 ? 4.0 : (t.shadow_mode[k] == 3 ? 2.0 : 0.0))));
-        N2M_PROF(N2M_K_ADAM, (hipStream_t)stream, bytes);
-        adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(t, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, scale,
+        N2M_PROF_K(N2M_K_ADAM, (hipStream_t)stream, bytes);
+        N2M_LAUNCH(adam_kernel, blocks, 256, 0, (hipStream_t)stream, t, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, scale,
                                                              found_inf, bias);
     }
     N2M_CHECK_LAUNCH();
