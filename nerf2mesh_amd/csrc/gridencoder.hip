@@ -3739,7 +3739,7 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
 namespace {
 constexpr uint32_t kFoldThreads = 512u;                    // 2^18 samples = 512 workgroups: two per CU, no half-empty second round
 __global__ void __launch_bounds__(kFoldThreads)
-sdf_fold_plan_kernel(const float* __restrict__ xyz, uint32_t M, float eps, float bound, uint32_t max_level, LevelTable lv, bool align_corners,
+sdf_fold_plan_kernel(const float* __restrict__ xyz, uint32_t M, float eps, float bound, uint32_t max_level, uint32_t L, LevelTable lv, bool align_corners,
                      uint8_t* __restrict__ flags /*[L, M]*/, float* __restrict__ left_pts01 /*[L, cap, 3]*/, uint32_t* __restrict__ left_src /*[L, cap]*/,
                      uint32_t cap, uint32_t* __restrict__ counters /*[2][kMaxLevels]*/, uint32_t parity) {
     // two barriers per workgroup, not three per level (the first version: 54 us for 2^18 samples): every wave scans all levels' counts first
@@ -3771,7 +3771,10 @@ sdf_fold_plan_kernel(const float* __restrict__ xyz, uint32_t M, float eps, float
 #pragma unroll
     for (uint32_t l = 0; l < kFoldLevels; ++l) {
         before[l] = 0u;
-        if (l >= max_level) continue;                      // (block-uniform)
+        if (l >= max_level) {                              // (block-uniform) a level above the active ones folds nothing: its flags are DEFINED as zero --
+            if (l < L && m < M) flags[(size_t)l * M + m] = 0u;      // a fold call over all L levels (TV on every level while the levels are progressive) reads them
+            continue;
+        }
         const float scale = lv.scale[l];
         uint32_t fl = 0u;
         if (centre_in) {
@@ -3839,7 +3842,7 @@ extern "C" int n2m_sdf_fold_plan(const float* xyz, uint32_t M, float eps, float 
     N2M_REQUIRE(L >= 1 && L <= kMaxLevels && max_level <= L && max_level <= 16u && parity <= 1u && eps > 0.0f && bound > 0.0f && (uint64_t)cap >= 6ull * M, N2M_EINVAL,
                 "%s: bad arguments (cap must hold all 6 M copies)", fn);
     if (M == 0) return 0;
-    sdf_fold_plan_kernel<<<n2m_ceil_div(M, kFoldThreads), kFoldThreads, 0, (hipStream_t)stream>>>(xyz, M, eps, bound, max_level, make_levels(L, S, H), align_corners != 0,
+    sdf_fold_plan_kernel<<<n2m_ceil_div(M, kFoldThreads), kFoldThreads, 0, (hipStream_t)stream>>>(xyz, M, eps, bound, max_level, L, make_levels(L, S, H), align_corners != 0,
                                                                                  flags, left_pts01, left_src, cap, counters, parity);
     N2M_CHECK_LAUNCH();
     return 0;

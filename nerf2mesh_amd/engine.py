@@ -818,7 +818,8 @@ class Stage0Engine:
             # (n2m_grid_encode_backward_binned_pair_fold), the others (2.4 % at the end of the schedule) take a density-only call over
             # per-level lists whose lengths the host reads back (known long before the backward is enqueued: the plan only needs the samples)
             finest = self.H0 * 2.0 ** (self.S * (ml - 1))
-            fold = self.sdf_fold and eps / (2.0 * float(model.bound)) * finest < 0.25
+            # (the fold and the lists call are one-pass paths of the table backward: batches above 2^20 samples keep the stacked pass)
+            fold = self.sdf_fold and eps / (2.0 * float(model.bound)) * finest < 0.25 and M <= (1 << 20)
             if fold:
                 if "fold" not in sb:      # buffers of the fold, only once it is used: per-level flags and lists (capacity: every copy)
                     c6 = 6 * self._sdf_cap
@@ -827,6 +828,9 @@ class Stage0Engine:
                                   "src": torch.empty(16 * c6, dtype=torch.int32, device=dev), "g": torch.empty(16 * c6, dtype=torch.float32, device=dev)}
                 fb = sb["fold"]
                 par = self.global_step & 1
+                # the plan kernel adds onto this parity's counters and clears the other parity's for the next step -- which only holds while
+                # every step runs the plan; a step without it (no samples, the fold condition off for a step) would leave counts behind
+                sb["fold_cnt"][par].zero_()
                 L.call("n2m_sdf_fold_plan", _p(xyzs), M, eps, float(model.bound), self.Lv, ml, self.S, self.H0, int(bool(e1.align_corners)),
                        _p(fb["flags"]), _p(fb["pts"]), _p(fb["src"]), fb["cap"], _p(sb["fold_cnt"]), par, s)
                 sb["fold_host"].copy_(sb["fold_cnt"][par], non_blocking=True)
@@ -881,6 +885,7 @@ class Stage0Engine:
                 K = int(sb["fold_host"][:ml].max())
                 self.last_fold_left = int(sb["fold_host"][:ml].sum())
                 L.call("n2m_grid_encode_backward_binned_pair_fold", *batch_args, _p(fb["flags"]), _p(sb["d_h6"]), eps, float(model.bound), s)
+                assert K <= (1 << 20), "a level's list of unfolded copies exceeds the one-pass limit of the lists call"     # (K <= 6 M / ... : M <= 2^20 keeps ~10 % of 6 M below it)
                 if K > 0:
                     L.call("n2m_sdf_fold_gather", _p(sb["d_h6"]), M, ml, _p(fb["src"]), _p(fb["pts"]), fb["cap"],
                            sb["fold_cnt"].data_ptr() + 128 * par, K, _p(fb["g"]), s)

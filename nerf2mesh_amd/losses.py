@@ -1,4 +1,6 @@
 """Fused loss heads of the training step (C ABI: include/n2m_hip.h, "training-step helpers")."""
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -82,6 +84,7 @@ class _stage1_head(Function):
                int(packed), _p(seed), L.stream())
         ctx.grads = (d_alpha, d_rgb)
         ctx.seeded = seed is not None
+        ctx.seed_ref = seed
         loss = partial.sum() / N
         ctx.mark_non_differentiable(image, depth, ws, trig, loss_px)
         return loss, image, depth, ws, trig, loss_px
@@ -90,7 +93,11 @@ class _stage1_head(Function):
     def backward(ctx, g, *unused):
         d_alpha, d_rgb = ctx.grads
         ctx.grads = None
-        if ctx.seeded:        # the kernel has applied the incoming gradient already (the caller vouches that it IS the seed)
+        if ctx.seeded:
+            # the kernel has applied the incoming gradient already -- which is only right when `g` IS the seed: the head loss enters the total
+            # with weight 1 and the total is differentiated with gradient = seed.  N2M_DEBUG_SEED=1 checks it (a host sync per step).
+            if os.environ.get("N2M_DEBUG_SEED") and ctx.seed_ref is not None:
+                assert torch.allclose(g.float().reshape(()), ctx.seed_ref.float().reshape(())), "stage1_head: the incoming gradient is not the seed it was given"
             return d_alpha, d_rgb, None, None, None, None, None, None, None, None, None, None, None
         return (d_alpha * g if d_alpha is not None else None), d_rgb * g, None, None, None, None, None, None, None, None, None, None, None
 

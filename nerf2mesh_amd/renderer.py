@@ -152,13 +152,15 @@ class NeRFRenderer(nn.Module):
                                                   expect_points=expect_points)
 
     def render(self, rays_o, rays_d, index=None, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-4,
-               cam_near_far=None, shading="full", ticket=None, blend_bg=True, **kwargs):
+               cam_near_far=None, shading="full", ticket=None, blend_bg=True, nears_fars=None, **kwargs):
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         N, device = rays_o.shape[0], rays_o.device
 
-        if ticket is None:
+        if ticket is None and nears_fars is not None:
+            nears, fars = nears_fars                       # the batch kernel's: aabb slab test + the per-view clamp (as march_ahead takes them)
+        elif ticket is None:
             nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
             if cam_near_far is not None:
                 nears = torch.maximum(nears, cam_near_far[:, 0])

@@ -174,6 +174,7 @@ class Stage0Trainer:
         if self._next is None:
             self._next = self._prepare()
         rays_o, rays_d, images, ticket, bg_color, noises = self._next
+        nears_fars = self._nears_fars                      # of THIS batch (batch() sets it; the overlapped preparation below replaces it)
         self._next = None
         self.global_step += 1
         self.optimizer.zero_grad(set_to_none=True)
@@ -202,8 +203,10 @@ class Stage0Trainer:
             adapted = True
             self._next = self._prepare_overlapped()
 
+        # (without the pipelined march the per-view near / far clamp of --enable_cam_near_far has to reach render() itself)
         out = model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, shading=shading, dt_gamma=opt.dt_gamma,
-                           max_steps=opt.max_steps, ticket=ticket, blend_bg=not self.fused_loss)
+                           max_steps=opt.max_steps, ticket=ticket, blend_bg=not self.fused_loss,
+                           nears_fars=nears_fars if ticket is None else None)
         if self.fused_loss:
             # background blend + ground-truth compositing + rgb/mask MSE + mean in one kernel (nerf/utils.py:658-683)
             loss = photo_loss(out["image"], out["weights_sum"], images, bg_color, opt.lambda_rgb, max(opt.lambda_mask, 0.0))

@@ -1309,7 +1309,7 @@ def test_sdf_copies_folded_into_the_batch_backward_equal_the_stacked_pass(be, ep
     copies(d6, pts01, 6 * M, a1)
     # ---- folded
     cap = 6 * M
-    flags = torch.zeros(16, M, dtype=torch.uint8, device="cuda")
+    flags = torch.full((16, M), 0x3F, dtype=torch.uint8, device="cuda")       # garbage: the plan defines the flags of ALL 16 levels
     left_pts = torch.empty(16, cap, 3, device="cuda"); left_src = torch.empty(16, cap, dtype=torch.int32, device="cuda")
     left_g = torch.empty(16 * cap, device="cuda")
     cnt = torch.zeros(2, 32, dtype=torch.int32, device="cuda")
@@ -1318,6 +1318,9 @@ def test_sdf_copies_folded_into_the_batch_backward_equal_the_stacked_pass(be, ep
            L.stream())
     Ks = cnt[0, :max_level].cpu().numpy()
     assert int(cnt[1].abs().sum()) == 0, "the other parity's counters are cleared"
+    # levels above the active ones fold nothing: a fold call over all 16 levels (progressive levels + TV on every level, engine._step_sdf) reads
+    # their flags, and a garbage flag would add the copies' gradients onto rows the reference leaves to the TV term alone
+    assert int(flags[max_level:].max() if max_level < 16 else 0) == 0
     # the cell test, in torch, with the library's level scales (exp2f(level * S) * H - 1 in fp32): copy c folds on level l iff
     # floor(p01 * scale + 0.5) of its moved axis equals the centre's
     c01 = (xyz + bound) / (2 * bound)
