@@ -122,8 +122,8 @@ int n2m_march_rays_train_fused(const float* rays_o, const float* rays_d, const u
                                int32_t* rays, int32_t* counter, const float* noises, uint32_t max_points,
                                void* workspace, uint64_t workspace_bytes, void* stream);
 
-/* Process-wide settings of the binned table backward (all n2m_grid_encode_backward_binned* / n2m_grad_total_variation_binned calls that
- * follow).  tv_stride: floats between consecutive rows of the TV table (1 = an fp32 [rows,1] tensor as in gridencoder.h:15; 2 = the
+/* Settings of the binned table backward for the CALLING THREAD (all n2m_grid_encode_backward_binned* / n2m_grad_total_variation_binned calls
+ * this thread makes afterwards; thread-local, default (1, 1.0) -- state them before each call and no other engine in the process can interfere).  tv_stride: floats between consecutive rows of the TV table (1 = an fp32 [rows,1] tensor as in gridencoder.h:15; 2 = the
  * density column of the packed {fp32, half2} table n2m_grid_encode_forward_packed reads -- a caller that shards the optimizer over ranks
  * keeps only that copy complete).  overflow_div: a gradient row whose magnitude exceeds max_of_type / overflow_div raises found_inf;
  * a caller that sums the tables over W ranks passes W, so that an overflow only the cross-rank sum would produce is caught before it. */

@@ -2996,8 +2996,13 @@ void launch_tv(const TvArgs& a) {
 // gradient overflow check.  A multi-GPU caller that SUMS gradient tables over W ranks sets the margin to W: a row whose local sum exceeds
 // max / W could overflow in the cross-rank sum, so it raises found_inf already (GradScaler then skips and backs off one notch early
 // instead of never seeing an overflow that only the reduction produces).
-static std::atomic<uint32_t> g_cfg_tv_stride{1};
-static std::atomic<float> g_cfg_overflow_div{1.0f};
+// Settings of the CALLING THREAD's next table-backward calls (n2m_grid_backward_config).  Thread-local since round 4: as process-wide atomics two
+// engines stepping on two threads could read each other's values between the setter and the call it precedes; a thread that restates them
+// before each call (every caller in nerf2mesh_amd/ does) cannot be raced.
+struct ThreadCfg { uint32_t v; uint32_t load() const { return v; } };
+struct ThreadCfgF { float v; float load() const { return v; } };
+static thread_local ThreadCfg g_cfg_tv_stride{1};
+static thread_local ThreadCfgF g_cfg_overflow_div{1.0f};
 
 constexpr size_t kBinHeaderBytes = 512;          // [level maxima 2 x 32 words][ready token 8 B][pad]
 
@@ -4067,8 +4072,8 @@ extern "C" int n2m_debug_fill_times(int on, unsigned long long* out) {
 
 extern "C" int n2m_grid_backward_config(int tv_stride, float overflow_div) {
     N2M_REQUIRE((tv_stride == 1 || tv_stride == 2) && overflow_div >= 1.0f, N2M_EINVAL, "grid_backward_config: tv_stride 1 or 2, overflow_div >= 1");
-    g_cfg_tv_stride = (uint32_t)tv_stride;
-    g_cfg_overflow_div = overflow_div;
+    g_cfg_tv_stride.v = (uint32_t)tv_stride;
+    g_cfg_overflow_div.v = overflow_div;
     return 0;
 }
 

@@ -163,7 +163,7 @@ class Stage0Engine:
                 self.g1s = {"c": f32(self._Cs, 1), "f": f32(self._Fs, 1)}
                 self.g2s = {"c": f16(self._Cs, 2), "f": f16(self._Fs, 2)}
                 self._inplace_gather = dist.get_backend() == "nccl"      # RCCL gathers in place; gloo (tests) gets a copy of the shard
-        # process-wide settings of the binned backward, stated before every backward of this engine (train_step): sharded -> the TV stencil
+        # per-thread settings of the binned backward, stated before every backward of this engine (train_step): sharded -> the TV stencil
         # reads the density column of the packed table (row stride 2); W ranks -> gradients are SUMMED, so a local fp16 row above max / W
         # raises found_inf already
         self._bwd_cfg = (2 if self.shard else 1, float(world_size))

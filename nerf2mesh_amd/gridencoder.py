@@ -143,7 +143,7 @@ def binned_backward(enc, grad_lm, x01, grad_embeddings, max_level, tv=None, foun
         return False
     ws = L.workspace(x01.device, need, ws_slot)
     tv_emb, tv_w, tv_wo, tv_in, tv_scale = tv if tv is not None else (None, 0.0, 0.0, 1.0, None)
-    L.grid_backward_config(1, 1.0)          # process-wide setting: state it per call (a sharded engine may have left its own)
+    L.grid_backward_config(1, 1.0)          # per-thread setting: stated per call (a sharded engine on this thread may have left its own)
     L.call("n2m_grid_encode_backward_binned", _p(grad_lm), _p(x01), ho.ctypes.data, _p(grad_embeddings), B, 3, C, enc.num_levels, max_level,
            float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), enc.interp_id, dt,
            _p(tv_emb), float(tv_w), float(tv_wo), float(tv_in), _p(tv_scale), _p(found_inf), _p(ws), ws.numel(), L.stream())
@@ -178,7 +178,7 @@ def binned_backward_pair(enc1, enc2, grad1_lm, grad2_lm, x01, g1, g2, max_level,
         return False
     ws = L.workspace(x01.device, need)
     tv_emb, tv_w, tv_wo, tv_in, tv_scale = tv if tv is not None else (None, 0.0, 0.0, 1.0, None)
-    L.grid_backward_config(1, 1.0)          # process-wide setting: state it per call (a sharded engine may have left its own)
+    L.grid_backward_config(1, 1.0)          # per-thread setting: stated per call (a sharded engine on this thread may have left its own)
     L.call("n2m_grid_encode_backward_binned_pair", _p(grad1_lm), _p(grad2_lm), _p(x01), ho.ctypes.data, _p(g1), _p(g2), B, enc1.num_levels,
            max_level, float(np.log2(enc1.per_level_scale)), int(enc1.base_resolution), enc1.gridtype_id, int(bool(enc1.align_corners)),
            enc1.interp_id, _p(tv_emb), float(tv_w), float(tv_wo), float(tv_in), _p(tv_scale), _p(found_inf), float(in_affine[0]),
@@ -193,7 +193,7 @@ def binned_tv(enc, x01, emb, grad, weight, weight_outer=None, inner01=1.0, scale
     if need == 0:
         return False
     ws = L.workspace(x01.device, need)
-    L.grid_backward_config(1, 1.0)          # process-wide setting: state it per call (a sharded engine may have left its own)
+    L.grid_backward_config(1, 1.0)          # per-thread setting: stated per call (a sharded engine on this thread may have left its own)
     L.call("n2m_grad_total_variation_binned", _p(x01), _p(emb), _p(grad), ho.ctypes.data, float(weight),
            float(weight if weight_outer is None else weight_outer), float(inner01), _p(scale), B, 3, C, enc.num_levels,
            float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), _p(ws), ws.numel(),
