@@ -293,6 +293,14 @@ int n2m_grid_encode_forward_packed(const float* inputs, const void* packed, cons
                                    void* outputs2, uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H,
                                    uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
                                    void* stream);
+/* The same lookup for the levels [level_begin, level_begin + n_levels) only (the rows of outputs1 / outputs2 of those levels, bit-identical
+ * to the full call's).  For a caller whose packed rows arrive in level chunks -- multi-GPU with the optimizer sharded over the ranks
+ * (nerf/utils.py:517-519 is the reference's DDP wrapper): every rank refreshes its own rows, the others' arrive by all-gather,
+ * coarse levels first, and the lookup of the half that has landed runs while the other half is still on the wire. */
+int n2m_grid_encode_forward_packed_levels(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1,
+                                          void* outputs2, uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                          uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
+                                          uint32_t level_begin, uint32_t n_levels, void* stream);
 
 /* Both encoders of nerf2mesh's field in one call: the density table (fp32, C=1) and the colour table (fp16, C=2) share
  * their level geometry and are queried at the same inputs (nerf/network.py:92-108), so the index arithmetic and the partition

@@ -436,14 +436,17 @@ __global__ void __launch_bounds__(256)
 grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __restrict__ packed, const int32_t* __restrict__ offsets,
                             float* __restrict__ out1, _Float16* __restrict__ out2, uint32_t B, uint32_t max_level, LevelTable lv,
                             uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t n_tiles, float in_scale, float in_offset,
-                            uint32_t xcd_group) {
+                            uint32_t xcd_group, uint32_t level_begin = 0u, uint32_t n_levels = 16u) {
     __builtin_amdgcn_s_setprio(3);      // runs beside the next batch's marcher (second stream): win the issue arbitration
     constexpr uint32_t D = 3;
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     uint32_t level, tile;
+    // (level_begin, n_levels): the levels this launch covers -- all of them, or one half of them when the packed rows arrive in two
+    // chunks from the other ranks (n2m_grid_encode_forward_packed_levels); max_level then bounds level_begin + n_levels
     if (xcd_group == 0u) {
         level = blockIdx.x / n_tiles;
         tile = blockIdx.x - level * n_tiles;
+        level += level_begin;
     } else {
         // XCD groups (max_level == 16).  Workgroup b runs on XCD b % 8 (observed dispatch rule; a wrong guess costs speed only).  The
         // kernel is bound by the L2s' request rate (tools/fwd_lab.hip: random 16-byte gathers from an L2-resident table run at 256 G
@@ -451,14 +454,14 @@ grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __res
         // L2 that works on a level also pulls that level's whole 4 MB table through the fabric.  g = 4 XCDs per level is the measured
         // optimum: group k = xcd / 4 owns eight levels (pairs p, 15 - p: coarse with fine) and walks them one after the other, its four
         // XCDs splitting the tiles.  67.8 -> 65.3 us stand-alone (8 XCDs per level -> 4; 2: 69.1, 1: 73.2).
-        const uint32_t g = xcd_group, groups = 8u / g, per_group = 16u / groups;
+        const uint32_t g = xcd_group, groups = 8u / g, per_group = n_levels / groups;
         const uint32_t xcd = blockIdx.x & 7u, k = xcd / g, j = xcd - k * g, i = blockIdx.x >> 3;
         const uint32_t tiles_per_xcd = (n_tiles + g - 1u) / g;
         const uint32_t li = i / tiles_per_xcd;
         tile = (i - li * tiles_per_xcd) * g + j;
         if (li >= per_group || tile >= n_tiles) return;
         const uint32_t pair = k + groups * (li >> 1);
-        level = (li & 1u) ? 15u - pair : pair;
+        level = level_begin + ((li & 1u) ? n_levels - 1u - pair : pair);
     }
     if (level >= max_level) return;
     const uint32_t b = tile * 256 + threadIdx.x;
@@ -4031,9 +4034,33 @@ extern "C" int n2m_grid_encode_forward_pair(const float* inputs, const float* em
     return 0;
 }
 
+static int forward_packed(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1, void* outputs2, uint32_t B, uint32_t L,
+                          uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
+                          void* stream, uint32_t level_begin, uint32_t n_levels);
+
 extern "C" int n2m_grid_encode_forward_packed(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1, void* outputs2,
                                               uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
                                               int align_corners, uint32_t interp, float in_scale, float in_offset, void* stream) {
+    return forward_packed(inputs, packed, offsets, outputs1, outputs2, B, L, max_level, S, H, gridtype, align_corners, interp, in_scale, in_offset, stream, 0u,
+                          max_level);
+}
+
+// Levels [level_begin, level_begin + n_levels) only: the rows of outputs1 / outputs2 of those levels, bit-identical to the full call's.  For a
+// caller whose packed rows arrive in level chunks (sharded optimizer: each rank refreshes its own rows, the others' come by all-gather): the
+// lookup of the coarse half runs while the fine half's rows are still on the wire.
+extern "C" int n2m_grid_encode_forward_packed_levels(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1, void* outputs2,
+                                                     uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
+                                                     int align_corners, uint32_t interp, float in_scale, float in_offset, uint32_t level_begin,
+                                                     uint32_t n_levels, void* stream) {
+    N2M_REQUIRE(n_levels >= 1 && level_begin + n_levels <= max_level, N2M_EINVAL,
+                "grid_encode_forward_packed_levels: levels [%u, %u) outside [0, %u)", level_begin, level_begin + n_levels, max_level);
+    return forward_packed(inputs, packed, offsets, outputs1, outputs2, B, L, max_level, S, H, gridtype, align_corners, interp, in_scale, in_offset, stream,
+                          level_begin, n_levels);
+}
+
+static int forward_packed(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1, void* outputs2, uint32_t B, uint32_t L,
+                          uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
+                          void* stream, uint32_t level_begin, uint32_t n_levels) {
     const char* fn = "grid_encode_forward_packed";
     if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
     // outputs2 == NULL: the density encoder alone from the packed rows.  (Built for the occupancy refresh's 2 M-point query and measured
@@ -4047,15 +4074,16 @@ extern "C" int n2m_grid_encode_forward_packed(const float* inputs, const void* p
     // algorithmic bytes of both encoders' forward (588 B/sample each at L = 16, one 12-byte input read shared)
     // (one scope object for the whole launch: its destructor records the closing event)
     N2M_PROF_K(outputs2 ? N2M_K_GRID_FWD_PACKED : N2M_K_GRID_FWD, s,
-             outputs2 ? (double)B * (12.0 + (double)max_level * 8 * (4 + 4) + (double)max_level * (4 + 4))
-                      : (double)B * (12.0 + (double)max_level * 8 * 4 + (double)max_level * 4));
+             outputs2 ? (double)B * (12.0 + (double)n_levels * 8 * (4 + 4) + (double)n_levels * (4 + 4))
+                      : (double)B * (12.0 + (double)n_levels * 8 * 4 + (double)n_levels * 4));
     const uint32_t n_tiles = n2m_ceil_div(B, 256);
     static const uint32_t xg_env = getenv("N2M_FWD_XCD_GROUP") ? (uint32_t)atoi(getenv("N2M_FWD_XCD_GROUP")) : 4u;     // A/B switch: 0 = level-major grid
-    const uint32_t xg = (max_level == 16u && (xg_env == 1u || xg_env == 2u || xg_env == 4u)) ? xg_env : 0u;
-    const uint32_t blocks = xg ? 8u * (16u / (8u / xg)) * n2m_ceil_div(n_tiles, xg) : n_tiles * max_level;
+    // XCD groups: every group of 8 / xg XCD sets owns n_levels / groups levels in pairs (coarse with fine): 16 levels, or a half of 8
+    const uint32_t xg = ((n_levels == 16u || n_levels == 8u) && (xg_env == 1u || xg_env == 2u || xg_env == 4u) && n_levels % (2u * (8u / xg_env)) == 0u) ? xg_env : 0u;
+    const uint32_t blocks = xg ? 8u * (n_levels / (8u / xg)) * n2m_ceil_div(n_tiles, xg) : n_tiles * n_levels;
     N2M_LAUNCH(grid_forward3_packed_kernel, blocks, 256, 0, s, inputs, (const uint2*)packed, offsets, outputs1, (_Float16*)outputs2, B,
-                                                       max_level, lv, gridtype, align_corners != 0, interp, n_tiles, in_scale,
-                                                       in_offset, xg);
+                                                       level_begin + n_levels, lv, gridtype, align_corners != 0, interp, n_tiles, in_scale,
+                                                       in_offset, xg, level_begin, n_levels);
     N2M_CHECK_LAUNCH();
     return 0;
 }

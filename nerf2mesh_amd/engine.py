@@ -163,6 +163,7 @@ class Stage0Engine:
                 self.g1s = {"c": f32(self._Cs, 1), "f": f32(self._Fs, 1)}
                 self.g2s = {"c": f16(self._Cs, 2), "f": f16(self._Fs, 2)}
                 self._inplace_gather = dist.get_backend() == "nccl"      # RCCL gathers in place; gloo (tests) gets a copy of the shard
+                self.chunked_gather = os.environ.get("N2M_CHUNKED_GATHER", "1") != "0"      # A/B: wait for both chunks right behind Adam
         # per-thread settings of the binned backward, stated before every backward of this engine (train_step): sharded -> the TV stencil
         # reads the density column of the packed table (row stride 2); W ranks -> gradients are SUMMED, so a local fp16 row above max / W
         # raises found_inf already
@@ -517,18 +518,30 @@ class Stage0Engine:
         return d
 
     def _gather_packed(self):
-        """All-gather of the packed rows after the sharded Adam (each rank has refreshed its own rows); waited for at once: the next
-        kernel on the stream is the forward that reads them."""
+        """All-gather of the packed rows after the sharded Adam (each rank has refreshed its own rows), as two chunks: the coarse half of the
+        levels (32 % of the bytes) first, then the fine half.  Nothing is waited for here: the next step's lookup waits for the coarse chunk,
+        looks its eight levels up (n2m_grid_encode_forward_packed_levels) while the fine chunk is still on the wire, then waits for that one
+        (_wait_gather); everything else that reads the packed table or writes this rank's rows waits for both first."""
         import torch.distributed as dist
         flat = self._packed.view(-1)                 # [rows * 2] fp32 words, 8 bytes per row
-        works = []
-        for h, (row0, n) in self._shard_ranges().items():
+        self._gathers = {}
+        for h in ("c", "f"):
+            row0, n = self._shard_ranges()[h]
             lo = 0 if h == "c" else self._split
             out = flat[lo * 2:(lo + self.world * n) * 2]
             mine = flat[row0 * 2:(row0 + n) * 2]
-            works.append(dist.all_gather_into_tensor(out, mine if self._inplace_gather else mine.clone(), async_op=True))
-        for w in works:
-            w.wait()
+            self._gathers[h] = dist.all_gather_into_tensor(out, mine if self._inplace_gather else mine.clone(), async_op=True)
+        if not self.chunked_gather:
+            self._wait_gather()
+
+    def _wait_gather(self, which=("c", "f")):
+        g = getattr(self, "_gathers", None)
+        if not g:
+            return
+        for h in which:
+            w = g.pop(h, None)
+            if w is not None:
+                w.wait()
 
     @torch.no_grad()
     def sync_parameters(self, density_only=False, moments=False):
@@ -537,6 +550,7 @@ class Stage0Engine:
         steps: 24.5 MB) and to be called before a checkpoint, an export, an evaluation or a comparison."""
         if not self.shard:
             return
+        self._wait_gather()
         # COLLECTIVE: every rank must call it at the same step.  A repeat at the same step is a no-op (so a rank may evaluate or save on
         # its own after all ranks have synchronised once -- bench.py's rank 0 does).  moments=True also gathers Adam's exp_avg / exp_avg_sq
         # of both tables (each rank has only advanced its own rows): what a checkpoint needs -- FusedAdamAMP.state_dict() of a sharded
@@ -561,6 +575,7 @@ class Stage0Engine:
 
     def _optimizer_step(self, full, lr_factor, loss_out=None, fused=None):
         o = self.optimizer
+        self._wait_gather()          # (a step without samples ran no lookup: the rows the last gather sends must not be rewritten under it)
         desc, participants, groups = self._adam_desc(full, dense_only=fused is not None)
         for k, gi in enumerate(groups):
             desc.lr[k] = float(o.param_groups[gi]["initial_lr"]) * lr_factor
@@ -632,8 +647,17 @@ class Stage0Engine:
             return self._step_sdf(b, M, N, w, xyzs, dirs, ts, shading, seed, pk)
         # ---- forward
         if M > 0:
-            L.call("n2m_grid_encode_forward_packed", _p(xyzs), _p(pk), _p(e1.offsets), _p(w["h1"]), _p(w["h2"]), M, self.Lv, self.Lv, self.S,
-                   self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, float(self.aff[0]), float(self.aff[1]), s)
+            fwd = (_p(xyzs), _p(pk), _p(e1.offsets), _p(w["h1"]), _p(w["h2"]), M, self.Lv, self.Lv, self.S, self.H0, e1.gridtype_id,
+                   int(bool(e1.align_corners)), e1.interp_id, float(self.aff[0]), float(self.aff[1]))
+            if self.shard and getattr(self, "_gathers", None) and self.Lv == 16:
+                # the packed rows of the other ranks are still arriving: coarse half first, its lookup runs under the fine half's transfer
+                self._wait_gather(("c",))
+                L.call("n2m_grid_encode_forward_packed_levels", *fwd, 0, 8, s)
+                self._wait_gather(("f",))
+                L.call("n2m_grid_encode_forward_packed_levels", *fwd, 8, 8, s)
+            else:
+                self._wait_gather()
+                L.call("n2m_grid_encode_forward_packed", *fwd, s)
             self._mid_step_fill()
             tv_terms = None
 
@@ -805,6 +829,7 @@ class Stage0Engine:
                 w["h1"][ml * M:16 * M].zero_()
                 w["h2"][2 * ml * M:32 * M].zero_()
                 sb["h6"][ml * M6:16 * M6].zero_()
+            self._wait_gather()
             L.call("n2m_grid_encode_forward_packed", _p(xyzs), _p(pk), _p(e1.offsets), _p(w["h1"]), _p(w["h2"]), M, self.Lv, ml, self.S,
                    self.H0, e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, float(self.aff[0]), float(self.aff[1]), s)
             self._mid_step_fill()

@@ -451,7 +451,10 @@ class Stage1Trainer:
         # main.py:221 Adam(eps=1e-15) + nerf/utils.py:506 GradScaler, as in stage 0: optim.FusedAdamAMP does both in two launches (torch:
         # unscale + inf check + four multi-tensor Adam launches, 0.35 ms of host time per step of a step that is host-bound) and refreshes
         # the colour table's fp16 working copy in the same pass
-        self.amp_adam = torch.device(device).type == "cuda" and bool(opt.fp16) and world_size == 1
+        # (multi-GPU, SURVEY 8e: views shard over the ranks, the gradients are SUMMED with 1 / world folded into the loss scale like stage 0 --
+        #  round 3 dropped back to torch's Adam + GradScaler there)
+        self.world, self.rank = world_size, rank
+        self.amp_adam = torch.device(device).type == "cuda" and bool(opt.fp16)
         if self.amp_adam:
             from .optim import FusedAdamAMP
             self.optimizer = FusedAdamAMP(params, eps=1e-15, amp=True)
@@ -489,6 +492,37 @@ class Stage1Trainer:
         self.fused_head = torch.device(device).type == "cuda" and int(opt.ssaa) in (1, 2)      # losses.stage1_head (False: the torch graph)
         self.packed_aa = os.environ.get("N2M_S1_PACKED_AA", "1") != "0"      # one antialias call on RGB + alpha instead of two
 
+    @torch.no_grad()
+    def sync_refine_state(self):
+        """Views shard over the ranks, so every rank has accumulated the per-face errors of ITS views only (update_triangles_errors,
+        nerf/renderer.py:924-943): sum both accumulators over the ranks before rank 0 refines the mesh (nerf/utils.py:1204-1207).  Collective."""
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.model.triangles_errors, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self.model.triangles_errors_cnt, op=dist.ReduceOp.SUM)
+
+    @torch.no_grad()
+    def broadcast_mesh(self, src=0):
+        """After rank `src` has refined / decimated the mesh (refine_and_decimate, nerf/renderer.py:168-296: pymeshlab, outside this library) the
+        other ranks take its vertices and faces, re-initialise stage 1 on them and rebuild what depends on the mesh (the optimizer over
+        the new vertex offsets -- nerf/utils.py:1209-1211 does the same -- and the Laplacian).  Collective."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        model, dev = self.model, self.device
+        n = torch.tensor([model.vertices.shape[0], model.triangles.shape[0]], dtype=torch.int64, device=dev)
+        dist.broadcast(n, src=src)
+        nv, nf = int(n[0]), int(n[1])
+        mine = self.rank == src
+        v = model.vertices.detach().float().contiguous() if mine else torch.empty(nv, 3, dtype=torch.float32, device=dev)
+        f = model.triangles.detach().to(torch.int32).contiguous() if mine else torch.empty(nf, 3, dtype=torch.int32, device=dev)
+        dist.broadcast(v, src=src)
+        dist.broadcast(f, src=src)
+        step, covered, views = self.global_step, self.covered_seen, (self.view_cache, self._dirs)
+        self.__init__(model, self.opt, self.poses, v, f, dev, self.H, self.W, self.rank, self.world)      # fresh offsets, accumulators, optimizer, schedule, Laplacian
+        self.global_step, self.covered_seen = step, covered
+        self.view_cache, self._dirs = views                  # rays / ground truth / directions do not depend on the mesh
+
     def _view(self, v):
         if v not in self.view_cache:
             rays_o, rays_d = synthetic.rays_from_pixels(self.poses, torch.full_like(self.pix, v), self.pix, self.H, self.W)
@@ -524,8 +558,13 @@ class Stage1Trainer:
             rast, aa_alpha, aa_rgb = model._stage1_front(rays_d, self.mvps[v], self.H, self.W, shading, dirs=dirs, packed=self.packed_aa, vertices=verts)
             te = (model.triangles_errors, model.triangles_errors_cnt) if opt.refine else (None, None)      # update_triangles_errors rides along
             # (seed: with FusedAdamAMP the total loss is differentiated with gradient = loss scale and this term enters it with weight 1)
+            # (multi-GPU: the gradient that flows into the loss is scale / world -- FusedAdamAMP.backward(loss, world) -- and the head must be
+            #  handed exactly that)
+            seed = None
+            if self.amp_adam:
+                seed = self.optimizer.scale if self.world == 1 else self.optimizer.scale / self.world
             loss, _, _, _, trig, loss_px = stage1_head(aa_alpha, aa_rgb, rast, rgba, bg, self.H, self.W, int(opt.ssaa), opt.lambda_rgb,
-                                                       max(opt.lambda_mask, 0.0), *te, seed=self.optimizer.scale if self.amp_adam else None)
+                                                       max(opt.lambda_mask, 0.0), *te, seed=seed)
         else:
             gt_mask = rgba[:, 3:]
             gt_rgb = rgba[:, :3] * gt_mask + bg * (1 - gt_mask)
@@ -562,11 +601,18 @@ class Stage1Trainer:
             if self._amp_mlp:
                 self._amp["mlp"] = dict(found_inf=o.found_inf, flagged=False, persistent_dw=True)
                 model.amp_request = self._amp["mlp"]
-            o.backward(loss)
+            o.backward(loss, self.world)
             model.encoder_color.amp_request = model.amp_request = None
             flagged = [model.encoder_color.embeddings] if self._amp["color"]["flagged"] else []
             if "mlp" in self._amp and self._amp["mlp"]["flagged"]:
                 flagged += self._mlp_params
+            if self.sync is not None:
+                # one SUM all-reduce per large gradient in its own dtype (the colour table's stays fp16) + one small bucket with the MLP
+                # weights' gradients and the inf flag; a sum of finite values can overflow, so the reduced gradients are checked again
+                ce = model.encoder_color.embeddings
+                mlp = [self._amp["mlp"]["dw_flat"]] if "dw_flat" in self._amp.get("mlp", {}) else [p.grad for p in self._mlp_params]
+                self.sync.all_reduce_sum([self._amp["color"].get("grad_half"), ce.grad, model.vertices_offsets.grad], mlp + [o.found_inf])
+                flagged = []
             o.step(flagged=flagged)
         else:
             self.scaler.scale(loss).backward()

@@ -551,6 +551,36 @@ def test_grid_encode_forward_pair_is_bit_identical_to_two_calls(be):
                 assert torch.equal(a1, b1) and torch.equal(a2.view(torch.int16), b2.view(torch.int16))
 
 
+def test_packed_forward_in_level_halves_is_the_full_call(be):
+    """n2m_grid_encode_forward_packed_levels (the lookup of a sharded step whose packed rows arrive in two level chunks): levels [0, 8) and
+    [8, 16) written by two calls == the one full call, bit for bit, on both outputs; a call leaves the other levels' rows alone."""
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L
+    from nerf2mesh_amd.gridencoder import GridEncoder
+    p = L.ptr
+    B = 100003
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = (torch.rand(B, 3, device="cuda", generator=g) * 2.2 - 1.1).contiguous()           # some points outside [-1, 1]
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    e2 = GridEncoder(level_dim=2, desired_resolution=2048).cuda()
+    rows = e1.embeddings.shape[0]
+    packed = torch.empty(rows, 2, dtype=torch.float32, device="cuda")
+    packed[:, 0] = e1.embeddings.detach()[:, 0]
+    packed[:, 1] = e2.embeddings.detach().half().view(torch.float32)[:, 0]
+    geo = (16, 16, float(np.log2(e1.per_level_scale)), int(e1.base_resolution), e1.gridtype_id, int(bool(e1.align_corners)), e1.interp_id, 0.5, 0.5)
+    a1 = torch.empty(16, B, device="cuda"); a2 = torch.empty(16, B, 2, device="cuda", dtype=torch.float16)
+    L.call("n2m_grid_encode_forward_packed", p(x), p(packed), p(e1.offsets), p(a1), p(a2), B, *geo, L.stream())
+    b1 = torch.full_like(a1, 7.0); b2 = torch.full_like(a2, 7.0)
+    L.call("n2m_grid_encode_forward_packed_levels", p(x), p(packed), p(e1.offsets), p(b1), p(b2), B, *geo, 0, 8, L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(b1[:8], a1[:8]) and torch.equal(b2[:8], a2[:8]) and bool((b1[8:] == 7.0).all()) and bool((b2[8:] == 7.0).all())
+    L.call("n2m_grid_encode_forward_packed_levels", p(x), p(packed), p(e1.offsets), p(b1), p(b2), B, *geo, 8, 8, L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(b1, a1) and torch.equal(b2, a2)
+    with pytest.raises(RuntimeError):
+        L.call("n2m_grid_encode_forward_packed_levels", p(x), p(packed), p(e1.offsets), p(b1), p(b2), B, *geo, 12, 8, L.stream())
+
+
 def test_grid_backward_linearity_full_size(be):
     """Size-independent property at the BASELINE size (B = 2^18, lego tables): backward is linear in grad and
     sum(grad_embeddings) == sum_b sum_l grad[b,l] (the 8 interpolation weights of a sample sum to 1)."""
