@@ -2583,6 +2583,7 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
 struct PmSplit {
     uint32_t slot0[kMaxLevels];         // first scratch slot of the level's work items (slot = SUB * P * C u64; levels with Gl > 1 only)
     uint32_t tick0[kMaxLevels];         // first ticket of the level's partition groups
+    uint32_t slice_log2;                // entries per slice: 2^16 (C = 2: 2^15) when the launch has plenty of partition groups, 2^13 when it has few
 };
 
 template <typename T, uint32_t C, uint32_t P, uint32_t SUB>
@@ -2632,7 +2633,9 @@ __device__ __forceinline__ void pm_accumulate_items(uint32_t first_item, uint32_
         uint32_t n_tot = 0;
 #pragma unroll
         for (uint32_t u = 0; u < SUB; ++u) n_tot += min((uint32_t)__builtin_amdgcn_readfirstlane((int)n_all[u]), pm.home_cap[level]);
-        constexpr uint32_t kSliceLog2 = SUB == 2u ? 16u : 15u;            // a slice = at most twice what an item of the hashed levels holds at 2^18 samples
+        // (a slice = at most twice what an item of the hashed levels holds at 2^18 samples; a call over a few dense levels -- the SDF recipe's
+        //  early schedule: 4 levels, 18 partition groups, 1.5 M stacked samples -- gets 2^13-entry slices, or 200 items would serve 256 CUs)
+        const uint32_t kSliceLog2 = sp.slice_log2;
         const uint32_t Gl = min(Gplan, max(1u, (n_tot + (1u << kSliceLog2) - 1u) >> kSliceLog2));
         if (grp >= Gl) continue;
         for (uint32_t i = tid; i < kSlot; i += 1024) bin_acc[i] = 0ull;
@@ -3201,6 +3204,13 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
         lay.plan.tiles = (Bc + TS - 1) / TS;
         const PmLayout pl = make_pm_plan(Bc, lay.plan);
         if (!pl.ok) return -1;
+        {   // A call over a few small dense levels only (the SDF recipe's early schedule: 4-5 levels, 18-45 partition pairs, 1.5 M stacked
+            // samples whose entries pile onto a few thousand rows) stays on the tile-major path: measured 127 + 196 us here against 99 + 69 us
+            // there (tile groups split such a level 64 ways by construction; slices of a region cannot).
+            uint32_t pairs_all = 0;
+            for (uint32_t l = 0; l < max_level; ++l) pairs_all += (lay.plan.parts[l] + 1u) / 2u;
+            if (pairs_all < 64u) return -1;
+        }
         N2M_REQUIRE(workspace_bytes >= pl.bytes, N2M_EINVAL, "%s: workspace too small (%zu < %zu bytes)", fn, workspace_bytes, pl.bytes);
         const size_t r = 255;
         char* w = (char*)workspace;
@@ -3251,6 +3261,13 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
             if (g2n > 1u) slots2 += lay.plan.parts[l] * g2n;
         }
         N2M_REQUIRE((size_t)slots1 + slots2 <= pl.slot_count, N2M_EINVAL, "%s: scratch slots of the split levels exceed the layout", fn);
+        {   // partition groups of the launched levels: few of them = short slices (see pm_accumulate_items)
+            uint32_t groups1 = 0, groups2 = 0;
+            for (uint32_t l = 0; l < max_level; ++l)
+                if (in_half(l)) { groups1 += (plan1.parts[l] + 1u) / 2u; groups2 += plan2.parts[l]; }
+            sp1.slice_log2 = groups1 < 256u ? 13u : 16u;
+            sp2.slice_log2 = groups2 < 512u ? 13u : 15u;
+        }
         unsigned long long* slots_t2 = slots + (size_t)slots1 * (kPairP * 2u);
         plan1.item_prefix[max_level] = items1;
         plan2.item_prefix[max_level] = items2;
