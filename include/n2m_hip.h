@@ -129,6 +129,12 @@ int n2m_march_rays_train_fused(const float* rays_o, const float* rays_d, const u
  * a caller that sums the tables over W ranks passes W, so that an overflow only the cross-rank sum would produce is caught before it. */
 int n2m_grid_backward_config(int tv_stride, float overflow_div);
 
+/* event: a hipEvent_t (or NULL).  The calling thread's NEXT n2m_grid_encode_backward_binned_pair* call records it on its stream between its
+ * fill and its accumulate kernels (one-shot; behind the call when the path taken has no such point).  What a step executor hands to a
+ * second stream as its go-ahead: work that needs neither this step's gradients nor its updated parameters (the next batch's ray generation
+ * and march, nerf/provider.py:302-330 + raymarching.py:195-262) starts beside the accumulate. */
+int n2m_grid_backward_mid_event(void* event);
+
 /* Measurement aid for the shared fill of n2m_grid_encode_backward_binned_pair: on != 0 arms shader-clock stamps in one of its workgroups
  * (first 8 tile iterations x 6 phase boundaries) and in two work items of each accumulate kernel (5 boundaries); out (may be NULL,
  * else 116 words) receives the stamps of the last armed launch.  Synchronises. */

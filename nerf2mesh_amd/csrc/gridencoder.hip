@@ -3153,6 +3153,15 @@ static bool pm_enabled() {
     return on;
 }
 
+// An event the NEXT table backward of this thread records between its fill and its accumulate (n2m_grid_backward_mid_event): the step
+// executor's go-ahead for the side stream.  The next batch's ray generation and march then start beside the accumulate instead of beside
+// the optimizer update and are mostly over when the next step's lookup starts (the lookup ran 10 us longer with the marcher beside it).
+static thread_local hipEvent_t g_mid_event = nullptr;
+extern "C" int n2m_grid_backward_mid_event(void* event) {
+    g_mid_event = (hipEvent_t)event;
+    return 0;
+}
+
 template <uint32_t TS>
 int launch_pm_fill(dim3 grid, size_t lds, hipStream_t s, bool fold_on, int tvmode, const float* g1, const _Float16* g2, const float* x, TvParams tv,
                    const float* tvt, uint32_t Bc, uint32_t B, const BinPlan& plan, const PmPlan& pm, const LevelTable& lv, uint32_t gridtype, bool align,
@@ -3311,6 +3320,10 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
         else rc = N2M_PM_CALL(512);
 #undef N2M_PM_CALL
         if (rc) return rc;
+        if (g_mid_event) {                                  // (one-shot: the caller arms it per call)
+            (void)hipEventRecord(g_mid_event, s);
+            g_mid_event = nullptr;
+        }
         static const uint32_t acc_cap = getenv("N2M_ACC_GRID") ? (uint32_t)atoi(getenv("N2M_ACC_GRID")) : 4096u;
         static const uint32_t acc_dbg = getenv("N2M_ACC_DEBUG") ? (uint32_t)atoi(getenv("N2M_ACC_DEBUG")) : 0u;
         const float odiv = g_cfg_overflow_div.load();
@@ -3755,9 +3768,14 @@ static int binned_pair_entry(const float* grad1, const void* grad2, const float*
     // (kernel-attached events on the partition-major path, whose launches go through N2M_LAUNCH; marker events around the tile-major one)
     N2mProfScope prof_scope__(N2M_K_GRID_BWD, s, (double)B * (12.0 + lvls * esz + 2.0 * lvls * 8 * esz + (tv_embeddings ? lvls * 7 * 4.0 : 0.0) + (tv_terms ? lvls * 4.0 : 0.0)),
                               pm_enabled() && !fuse1 && !fuse2);
-    return launch_binned_pair(grad1, (const _Float16*)grad2, inputs, tv, grad_embeddings1, (_Float16*)grad_embeddings2, B, max_level, host_offsets, lv,
-                              gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf, in_scale, in_offset, overwrite != 0, L,
-                              half, tv_terms, fuse1, fuse2, fold, in_level_stride);
+    const int rc = launch_binned_pair(grad1, (const _Float16*)grad2, inputs, tv, grad_embeddings1, (_Float16*)grad_embeddings2, B, max_level, host_offsets, lv,
+                                      gridtype, align_corners != 0, interp, workspace, (size_t)workspace_bytes, s, fn, found_inf, in_scale, in_offset, overwrite != 0, L,
+                                      half, tv_terms, fuse1, fuse2, fold, in_level_stride);
+    if (g_mid_event) {                                      // a path without a point between fill and accumulate: behind the call
+        (void)hipEventRecord(g_mid_event, s);
+        g_mid_event = nullptr;
+    }
+    return rc;
 }
 
 // ---- SDF recipe: which (copy, level) pairs fold into their centre sample (FoldArgs), and the others as one compact list per level

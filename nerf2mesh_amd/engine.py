@@ -108,7 +108,11 @@ class Stage0Engine:
         self.split_backward = True            # multi-rank: table backward in two level halves, the first half's all-reduce under the second
         self.overlap = True                   # next batch on the side stream (False: everything on the main stream, same results)
         self.single_pass = os.environ.get("N2M_MARCH_PASSES", "1") != "2"      # one-launch marcher (A/B: N2M_MARCH_PASSES=2)
-        self.marker_at = int(os.environ.get("N2M_MARKER_AT", "0"))             # side-stream go-ahead: 0 before Adam, 1 before the table backward, 2 before the field backward
+        # side-stream go-ahead: 0 before Adam (default), 1 before the table backward, 2 before the field backward, 3 between the table backward's
+        # fill and its accumulate (n2m_grid_backward_mid_event).  Measured (round 4, 200 steps): 3 takes the marcher off the lookup (71.4 ->
+        # 67.8 us) and off Adam (99 -> 91) but doubles the accumulate beside it (backward 235 -> 301 us): 0.569 -> 0.613 ms/step.
+        self.marker_at = int(os.environ.get("N2M_MARKER_AT", "0"))
+        self._mid_events = None
 
         e1, e2 = model.encoder, model.encoder_color
         self.rows = e1.embeddings.shape[0]
@@ -747,7 +751,17 @@ class Stage0Engine:
                 early = self.sync.all_reduce_sum_begin([self.g1[split:], self.g2[split:]], [])
                 backward(2)
             else:
+                mid = self.marker_at == 3 and fused is None and tv_terms is None
+                if mid:
+                    if self._mid_events is None:          # a few events, created (= recorded once) up front, re-recorded by the library
+                        self._mid_events = [torch.cuda.Event() for _ in range(4)]
+                        for e in self._mid_events:
+                            e.record()
+                    ev = self._mid_events[self.global_step % len(self._mid_events)]
+                    L.call("n2m_grid_backward_mid_event", ctypes.c_void_p(ev.cuda_event))
                 backward(0)
+                if mid:
+                    self._marker = ev
         else:
             # no sample in the batch: every gradient is zero (the reduction below still takes part on every rank)
             self.g1.zero_()
@@ -775,7 +789,7 @@ class Stage0Engine:
             self.sync.all_reduce_sum_end(token)
         # ONE event per step on the main stream (an event record is a marker packet the queue idles ~6 us behind, measured): behind the
         # last kernel that reads this batch's buffers and in front of the optimizer update -- the side stream's go-ahead
-        if self.marker_at == 0 or M == 0:
+        if self.marker_at == 0 or M == 0 or (self.marker_at == 3 and not (M > 0 and self.sync is None and fused is None and tv_terms is None)):
             self._marker = torch.cuda.Event()
             self._marker.record()
         # ---- Adam + loss-scale bookkeeping, LR schedule (main.py:239)

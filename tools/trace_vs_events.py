@@ -15,7 +15,7 @@ for r in csv.reader(open(sys.argv[1])):
 rows.sort()
 line = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
 K = int(line["steps"])
-GROUPS = {"grid_encode_backward": ("bin_fill_pair_kernel", "bin_accumulate_kernel"), "grid_encode_forward_packed": ("grid_forward3_packed_kernel",),
+GROUPS = {"grid_encode_backward": ("pm_fill_pair_kernel", "pm_accumulate_both_kernel", "pm_accumulate_kernel", "bin_fill_pair_kernel", "bin_accumulate_kernel"), "grid_encode_forward_packed": ("grid_forward3_packed_kernel",),
           "mlp_backward": ("field_backward",), "adam_step": ("adam_kernel",), "mlp_forward": ("field_forward_kernel",),
           "composite_rays_train_forward": ("composite_loss_train_kernel",)}
 adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
