@@ -346,7 +346,7 @@ int n2m_grid_encode_backward_binned_pair_half(const float* grad1, const void* gr
  * (n2m_grid_pair_fuse_plan: all levels from first_level on, for batches up to max_samples) the flush holds the final gradient row in registers;
  * n2m_grid_encode_backward_binned_pair_adam lets it do what n2m_adam_step would do for that row -- same arithmetic, element for element --
  * instead of storing the gradient for a later pass: the 98 MB gradient round trip disappears.  MEASURED SLOWER than the separate pass on
- * MI355X (the accumulates move the optimizer state at a third of n2m_adam_step's rate: step 0.632 -> 0.682 ms, DESIGN.md 4.11g-iv); the
+ * MI355X (the accumulates move the optimizer state at a third of n2m_adam_step's rate: step 0.632 -> 0.682 ms, DESIGN.md section 7); the
  * engine uses it only with N2M_FUSE_ADAM=1.  GradScaler's skip is all-or-nothing and the verdict is known only when the last item has flushed, so
  * the update is written BESIDE the old state: parameter and both moments of the two tables exist twice, the flush reads the *_in buffers and
  * writes the *_out buffers (and its column of the packed table).  Rows below first_row (small dense levels, split over tile groups) and all

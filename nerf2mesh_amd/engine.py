@@ -180,7 +180,7 @@ class Stage0Engine:
         # .data / optimizer.state always name the current one, so nothing outside the step sees the double buffering.  The TV stencil reads
         # the density column of the packed table.  Same bits as the separate pass (tests/test_engine.py), but the step LOSES 50-85 us: the
         # accumulates are latency-bound work items (2 per CU, barriers between their phases) and move the optimizer's 0.3 GB at a third of the
-        # rate the streaming n2m_adam_step reaches (backward 287 -> 399-434 us against Adam 93 -> 15 us; lookup 74 -> 88 us), DESIGN 4.11h.
+        # rate the streaming n2m_adam_step reaches (backward 287 -> 399-434 us against Adam 93 -> 15 us; lookup 74 -> 88 us), DESIGN section 7.
         self.sdf_fold = os.environ.get("N2M_SDF_FOLD", "1") != "0"      # SDF recipe: finite-difference copies folded into the batch's table backward
         self.sdf_tv_all = os.environ.get("N2M_SDF_TV_ALL", "1") != "0"  # SDF recipe, progressive phase: TV of all levels inside the batch's backward
         self.fuse_adam = None

@@ -112,7 +112,7 @@ def test_engine_runs_the_sdf_recipe_like_the_trainer(iters, steps):
     # 1e-6).  Until round 4 two plain trainer runs served: they differed by the float atomics of the table backward, which late in the schedule
     # (normals = finite differences of an fp16 sdf over eps = 1e-4) grow by orders of magnitude within a few steps.  The partition-major table
     # backward is bit-reproducible, two plain runs now agree to ~1e-5 -- while executor and trainer still differ by fp32 association (the
-    # folded copies, section 4.11i of DESIGN.md), which the recipe amplifies exactly like any other rounding-sized difference.
+    # folded copies, section 4.4 of DESIGN.md), which the recipe amplifies exactly like any other rounding-sized difference.
     # (measured at iters = 40: density table trainer-vs-engine 0.05 under either log layout; two tile-major trainer runs 0.05; two partition-major
     #  trainer runs 0.001; a 1e-7 nudge 0.01, a 1e-6 nudge 0.05-0.1.)  Before the recipe turns chaotic the two must agree closely: the first
     # fifteen losses to 1e-6.
