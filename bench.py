@@ -370,6 +370,17 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     if args.pretrain is None:
         args.pretrain = 300 if args.diffuse else 1000
+        # The occupancy refresh runs every 16th step (nerf/utils.py:1155-1156) and costs more than a whole plain step: a short timed window
+        # holds 1/16 of its steps as refresh steps only if it is placed accordingly -- the driver's 20 steps behind 1000 + 5 would hold
+        # TWO (10 % instead of the long-run 6.25 %).  The default pre-training length is therefore shifted by up to 15 iterations so that
+        # the window holds round(steps / 16) refresh steps; `config.refresh_steps_in_window` says how many it held.
+        if args.stage == 0:
+            want = int(round(args.steps / 16.0))
+            for shift in range(16):
+                first = args.pretrain + shift + args.warmup + 1
+                if sum(1 for j in range(first, first + args.steps) if (j - 1) % 16 == 0) == want:
+                    args.pretrain += shift
+                    break
     if args.prof_every is None:
         args.prof_every = max(1, args.steps // 12)
         if args.prof_every > 1 and args.prof_every % 2 == 0:
@@ -540,6 +551,8 @@ def main():
                    "sdf_schedule": (f"max_level {model.max_level}, normal epsilon {opt.normal_anneal_epsilon:.2g}, cos_anneal_ratio {opt.cos_anneal_ratio:.2g}"
                                     if args.recipe == "sdf" else None),
                    "shading": shading, "timed_steps": [first_timed, first_timed + args.steps - 1], "diffuse_step": int(opt.diffuse_step),
+                   "refresh_steps_in_window": sum(1 for j in range(first_timed, first_timed + args.steps) if (j - 1) % int(opt.update_extra_interval) == 0),
+                   "refresh_share_long_run": 1.0 / int(opt.update_extra_interval),
                    "parallelism": (f"dp{world} (rays sharded; table gradients reduce-scattered, Adam sharded over the ranks, packed rows all-gathered; "
                                    f"{dist.get_backend()})" if getattr(tr, "shard", False) else
                                    f"dp{world} (rays sharded, grad all-reduce over {dist.get_backend()})") if world > 1 else "single GPU",
