@@ -260,8 +260,11 @@ def bench_stage1(args, rank, world, device):
     v, f = synthetic.scene_mesh(300000)
     tr = Stage1Trainer(NeRFNetwork(opt), opt, synthetic.make_cameras(100, seed=0), v, f, device, rank=rank, world_size=world)
     tr.preload()                     # rays + ground truth of all views on the device, as the reference's --preload
+    from nerf2mesh_amd.engine_stage1 import Stage1Engine
+    use_engine = not args.autograd and Stage1Engine.supported(tr)
+    stepper = Stage1Engine(tr) if use_engine else tr      # the fixed launch sequence (engine_stage1.py) or the autograd trainer (--autograd, multi-rank)
     for _ in range(args.warmup):
-        tr.train_step()
+        stepper.train_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -270,7 +273,7 @@ def bench_stage1(args, rank, world, device):
     c0 = tr.covered_seen
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tr.train_step()
+        stepper.train_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -325,6 +328,7 @@ def bench_stage1(args, rank, world, device):
                                                                        f"{v.shape[0]} vertices, ssaa 2, refine error tracking on",
                                                           "covered_pixels_per_view": cov, "coverage": cov / HW,
                                                           "image_head": "fused (n2m_stage1_head)" if tr.fused_head else "torch graph",
+                                                          "driver": "engine_stage1.Stage1Engine (fixed launch sequence)" if use_engine else "trainer.Stage1Trainer (torch.autograd)",
                                                           "parallelism": f"views sharded over {world} GPU(s)",
                                                           "parity": "caller pinned to the unchanged reference Python (tests/test_stage1_reference.py); the "
                                                                     "rasterize / interpolate / antialias operators themselves UNPINNED: nvdiffrast is not "
