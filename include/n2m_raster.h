@@ -43,6 +43,11 @@ int n2m_interpolate_forward(const float* attr, const float* rast, const int32_t*
 int n2m_interpolate_backward(const float* attr, const float* rast, const int32_t* tri, const float* d_out, uint32_t V,
                              uint32_t F, uint32_t A, uint32_t H, uint32_t W, float* grad_attr, float* grad_rast,
                              void* stream);
+/* The same with d_out pixels `d_out_stride` floats apart (>= A): the gradient of one channel of a wider image (the coverage channel of an RGBA
+ * gradient, say) without an extraction pass.  Only covered pixels are read. */
+int n2m_interpolate_backward_strided(const float* attr, const float* rast, const int32_t* tri, const float* d_out, uint32_t d_out_stride,
+                                     uint32_t V, uint32_t F, uint32_t A, uint32_t H, uint32_t W, float* grad_attr, float* grad_rast,
+                                     void* stream);
 
 /* Edge -> opposite-vertex hash used by antialias.  table: [capacity] entries of 4 x i32 (va, vb, op0, op1), capacity a
  * power of two >= 4*F (caller allocates 16*capacity bytes; contents are overwritten). */
@@ -62,6 +67,11 @@ int n2m_antialias_backward(const float* color, const float* rast, const float* p
                            const int32_t* table, uint32_t capacity, const float* d_out, uint32_t V, uint32_t F, uint32_t C,
                            uint32_t H, uint32_t W, float pos_gradient_boost, float* grad_color, float* grad_pos,
                            void* stream);
+/* The same when grad_color (a buffer other than d_out) ALREADY holds a copy of d_out: the identity part of the operator costs no pass. */
+int n2m_antialias_backward_seeded(const float* color, const float* rast, const float* pos, const int32_t* tri,
+                                  const int32_t* table, uint32_t capacity, const float* d_out, uint32_t V, uint32_t F, uint32_t C,
+                                  uint32_t H, uint32_t W, float pos_gradient_boost, float* grad_color, float* grad_pos,
+                                  void* stream);
 
 /* World -> clip space of the mesh, `torch.matmul(F.pad(vertices, (0, 1), value=1.0), mvp.T)` (nerf/renderer.py:858): clip [V, 4] =
  * [v, 1] @ mvp^T (mvp [4, 4] row-major), and the gradient w.r.t. the vertices d_v = d_clip @ mvp[:, :3]; one launch each (a BLAS GEMM of
@@ -82,12 +92,24 @@ int n2m_laplacian_forward(const float* verts, const int32_t* row_ptr, const int3
                           float w_out, uint32_t n_in, float* Lv, float* norm, float* partial, void* stream);
 int n2m_laplacian_backward(const float* Lv, const float* norm, const int32_t* row_ptr, const int32_t* col, uint32_t V, const float* grad, float lam_lap,
                            const float* offsets, float w_in, float w_out, uint32_t n_in, float* d_verts, float* d_offsets, void* stream);
+/* The same two gradients ADDED onto d_verts, which already holds the rendering gradient of the vertex positions: with verts = base + offsets
+ * (nerf/renderer.py:855) all three are the offsets' gradient, so d_verts <- (d_verts + smoothness) + offset penalty in one pass; found_inf
+ * (device float, optional) is raised when the sum is not finite -- the check torch.amp's unscale_ would make on that gradient. */
+int n2m_laplacian_backward_acc(const float* Lv, const float* norm, const int32_t* row_ptr, const int32_t* col, uint32_t V, const float* grad,
+                               float lam_lap, const float* offsets, float w_in, float w_out, uint32_t n_in, float* d_verts, float* found_inf,
+                               void* stream);
 
 /* Rows of a [N, C] fp32 array by index -- the boolean-mask gather / scatter around the shading of a stage-1 frame (nerf/renderer.py:864,
  * 875-881: `xyzs[mask]`, `rgbs[mask] = ...`) once the covered pixels are an index list: out[k, :] = x[idx[k], :] and dst[idx[k], :] = src[k, :]
  * (idx int64 [K], unique for the scatter; rows of dst that are not listed keep their value). */
 int n2m_gather_rows(const float* x, const int64_t* idx, uint32_t K, uint32_t C, float* out, void* stream);
 int n2m_scatter_rows(const float* src, const int64_t* idx, uint32_t K, uint32_t C, float* dst, void* stream);
+/* The same over rows that are `*_stride` floats apart (>= C): the C leading floats of each row move, the rest of the row keeps its value --
+ * the RGB of an RGBA image without a repacking copy either side. */
+int n2m_gather_rows_strided(const float* x, const int64_t* idx, uint32_t K, uint32_t C, uint32_t x_stride, float* out, uint32_t out_stride,
+                            void* stream);
+int n2m_scatter_rows_strided(const float* src, const int64_t* idx, uint32_t K, uint32_t C, uint32_t src_stride, float* dst, uint32_t dst_stride,
+                             void* stream);
 
 /* Stage-1 image head, forward AND backward in one launch: what nerf/renderer.py:886-913 does with the two antialias outputs (clamp,
  * image = alpha * rgb, depth = alpha * z/w, T = 1 - alpha, ssaa reduction by `scale_img_hwc` = bilinear minification (exactly the 2 x 2
@@ -105,11 +127,13 @@ int n2m_scatter_rows(const float* src, const int64_t* idx, uint32_t K, uint32_t 
  *        the values are the same): aa_rgb = that image, aa_alpha = aa_rgb + 3, pixel stride 4 for both; d_rgb / d_alpha likewise point into
  *        one [h0 s, w0 s, 4] gradient image.
  *   seed (device scalar or NULL): factor on d_alpha / d_rgb -- the loss scale, when the caller knows that the gradient flowing into the mean
- *        is exactly that scalar (it then skips its own multiplication of the two full-resolution images). */
+ *        is exactly that scalar (it then skips its own multiplication of the two full-resolution images).
+ *   d_copy (packed layout only, or NULL): a second [h0 s, w0 s, 4] image that receives the same gradient -- what n2m_antialias_backward_seeded
+ *        takes as its pre-filled grad_color, in place of a copy pass over the image. */
 int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const float* rast, uint32_t h0, uint32_t w0, uint32_t ssaa,
                     const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask, float* image, float* depth,
                     float* weights_sum, float* trig_id, float* loss_px, float* d_alpha, float* d_rgb, float* partial, float* tri_err,
-                    float* tri_cnt, int packed_rgba, const float* seed, void* stream);
+                    float* tri_cnt, int packed_rgba, const float* seed, float* d_copy, void* stream);
 
 #ifdef __cplusplus
 }

@@ -107,16 +107,21 @@ SIGNATURES = {
     "n2m_rasterize_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp],
     "n2m_interpolate_forward": [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp],
     "n2m_interpolate_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    "n2m_interpolate_backward_strided": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "n2m_antialias_build_topology": [_vp, _u32, _vp, _u32, _vp],
     "n2m_antialias_forward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp],
     "n2m_antialias_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _vp, _vp, _vp],
+    "n2m_antialias_backward_seeded": [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _vp, _vp, _vp],
     "n2m_to_clip": [_vp, _vp, _u32, _vp, _vp],
     "n2m_to_clip_backward": [_vp, _vp, _u32, _vp, _vp],
     "n2m_laplacian_forward": [_vp, _vp, _vp, _u32, _vp, _f32, _f32, _f32, _u32, _vp, _vp, _vp, _vp],
     "n2m_laplacian_backward": [_vp, _vp, _vp, _vp, _u32, _vp, _f32, _vp, _f32, _f32, _u32, _vp, _vp, _vp],
+    "n2m_laplacian_backward_acc": [_vp, _vp, _vp, _vp, _u32, _vp, _f32, _vp, _f32, _f32, _u32, _vp, _vp, _vp],
     "n2m_gather_rows": [_vp, _vp, _u32, _u32, _vp, _vp],
+    "n2m_gather_rows_strided": [_vp, _vp, _u32, _u32, _u32, _vp, _u32, _vp],
+    "n2m_scatter_rows_strided": [_vp, _vp, _u32, _u32, _u32, _vp, _u32, _vp],
     "n2m_scatter_rows": [_vp, _vp, _u32, _u32, _vp, _vp],
-    "n2m_stage1_head": [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp],
+    "n2m_stage1_head": [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp],
     "n2m_prof_enable": [_int],
     "n2m_prof_reset": [],
     "n2m_prof_read": [_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],

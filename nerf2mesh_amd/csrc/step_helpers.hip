@@ -105,7 +105,8 @@ stage1_head_kernel(const float* __restrict__ aa_alpha /*[h0 S, w0 S]*/, const fl
                    float* __restrict__ image, float* __restrict__ depth, float* __restrict__ wsum, float* __restrict__ trig_id,
                    float* __restrict__ loss_px, float* __restrict__ d_alpha, float* __restrict__ d_rgb, float* __restrict__ partial,
                    float* __restrict__ tri_err, float* __restrict__ tri_cnt, uint32_t sa /*floats per pixel of aa_alpha / d_alpha: 1, or 4 = channel 3 of an RGBA image*/,
-                   uint32_t sr /*of aa_rgb / d_rgb: 3, or 4*/, const float* __restrict__ seed /*factor on the gradients (the loss scale), or NULL*/) {
+                   uint32_t sr /*of aa_rgb / d_rgb: 3, or 4*/, const float* __restrict__ seed /*factor on the gradients (the loss scale), or NULL*/,
+                   float* __restrict__ d_copy /*packed layout only: a second copy of the RGBA gradient image, or NULL*/) {
     __shared__ float wave_sum[4];
     const uint32_t n = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t N = h0 * w0, w = w0 * S;
@@ -174,14 +175,23 @@ stage1_head_kernel(const float* __restrict__ aa_alpha /*[h0 S, w0 S]*/, const fl
                 for (int i = 0; i < S; ++i) {
                     const size_t p = (size_t)(y * S + j) * w + (x * S + i);
                     const int k = j * S + i;
-                    float da = -(share * gT);                                           // T_sub = 1 - alpha
+                    float da = -(share * gT), dc[3];                                    // T_sub = 1 - alpha
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
                         const float dis = share * gi[ch];                               // d image_sub
                         da += dis * c[k][ch];
-                        d_rgb[p * sr + ch] = pass_c[k][ch] ? dis * a[k] : 0.0f;
+                        dc[ch] = pass_c[k][ch] ? dis * a[k] : 0.0f;
                     }
-                    d_alpha[p * sa] = pass_a[k] ? da : 0.0f;
+                    da = pass_a[k] ? da : 0.0f;
+                    if (sr == 4u && sa == 4u) {                                         // one RGBA image: a 16-byte store (and its copy)
+                        const float4 g4 = make_float4(dc[0], dc[1], dc[2], da);
+                        reinterpret_cast<float4*>(d_rgb)[p] = g4;
+                        if (d_copy) reinterpret_cast<float4*>(d_copy)[p] = g4;
+                    } else {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) d_rgb[p * sr + ch] = dc[ch];
+                        d_alpha[p * sa] = da;
+                    }
                 }
         }
     }
@@ -701,10 +711,12 @@ laplacian_forward_kernel(const float* __restrict__ v, const int32_t* __restrict_
     if (threadIdx.x == 0u) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+template <bool ACC>
 __global__ void __launch_bounds__(256)
 laplacian_backward_kernel(const float* __restrict__ Lv, const float* __restrict__ norm, const int32_t* __restrict__ row_ptr,
                           const int32_t* __restrict__ col, uint32_t V, const float* __restrict__ g, float lam_lap,
-                          const float* __restrict__ off, float w_in, float w_out, uint32_t n_in, float* __restrict__ d_v, float* __restrict__ d_off) {
+                          const float* __restrict__ off, float w_in, float w_out, uint32_t n_in, float* __restrict__ d_v, float* __restrict__ d_off,
+                          float* __restrict__ found_inf) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= V) return;
     const float gs = *g * (lam_lap / (float)V);
@@ -721,6 +733,19 @@ laplacian_backward_kernel(const float* __restrict__ Lv, const float* __restrict_
     }
     gl((size_t)i, t);
     const float d = (float)(e - b);
+    if (ACC) {
+        // d_v holds the rendering gradient of the vertices: the sum ((d_v + smoothness) + offset penalty), in that order, and the non-finite flag
+        const float f = *g * (i < n_in ? w_in : w_out) * 2.0f;
+        bool bad = false;
+#pragma unroll
+        for (uint32_t a = 0; a < 3; ++a) {
+            const float r = (d_v[(size_t)i * 3u + a] + (t[a] * d - s[a])) + off[(size_t)i * 3u + a] * f;
+            d_v[(size_t)i * 3u + a] = r;
+            bad |= !isfinite(r);
+        }
+        if (bad && found_inf) *found_inf = 1.0f;
+        return;
+    }
     d_v[(size_t)i * 3u] = t[0] * d - s[0]; d_v[(size_t)i * 3u + 1] = t[1] * d - s[1]; d_v[(size_t)i * 3u + 2] = t[2] * d - s[2];
     if (d_off) {
         const float f = *g * (i < n_in ? w_in : w_out) * 2.0f;
@@ -745,8 +770,22 @@ extern "C" int n2m_laplacian_backward(const float* Lv, const float* norm, const 
     N2M_REQUIRE(Lv && norm && row_ptr && col && grad && d_verts, N2M_ENULL, "laplacian_backward: NULL tensor");
     N2M_REQUIRE((offsets == nullptr) == (d_offsets == nullptr), N2M_ENULL, "laplacian_backward: offsets and d_offsets come together");
     if (V == 0) return 0;
-    laplacian_backward_kernel<<<n2m_ceil_div(V, 256), 256, 0, (hipStream_t)stream>>>(Lv, norm, row_ptr, col, V, grad, lam_lap, offsets, w_in, w_out, n_in,
-                                                                                    d_verts, d_offsets);
+    laplacian_backward_kernel<false><<<n2m_ceil_div(V, 256), 256, 0, (hipStream_t)stream>>>(Lv, norm, row_ptr, col, V, grad, lam_lap, offsets, w_in, w_out,
+                                                                                           n_in, d_verts, d_offsets, nullptr);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+// The same gradients ADDED onto `d_verts` (which already holds the rendering gradient of the vertex positions): with vertices = base + offsets all
+// three land on the offsets (nerf/renderer.py:855, nerf/utils.py:761-789), so d_verts <- (d_verts + smoothness) + offset penalty in one pass, and
+// `found_inf` (optional) is raised when the sum is not finite -- the check torch.amp's unscale_ would make on that gradient.
+extern "C" int n2m_laplacian_backward_acc(const float* Lv, const float* norm, const int32_t* row_ptr, const int32_t* col, uint32_t V, const float* grad,
+                                          float lam_lap, const float* offsets, float w_in, float w_out, uint32_t n_in, float* d_verts, float* found_inf,
+                                          void* stream) {
+    N2M_REQUIRE(Lv && norm && row_ptr && col && grad && d_verts && offsets, N2M_ENULL, "laplacian_backward_acc: NULL tensor");
+    if (V == 0) return 0;
+    laplacian_backward_kernel<true><<<n2m_ceil_div(V, 256), 256, 0, (hipStream_t)stream>>>(Lv, norm, row_ptr, col, V, grad, lam_lap, offsets, w_in, w_out,
+                                                                                          n_in, d_verts, nullptr, found_inf);
     N2M_CHECK_LAUNCH();
     return 0;
 }
@@ -755,12 +794,13 @@ extern "C" int n2m_laplacian_backward(const float* Lv, const float* norm, const 
 // dst[idx[k]] = src[k] (idx unique: no atomics).  torch's index kernels spend 50 us per call on 0.7 M rows of three floats.
 template <bool SCATTER>
 __global__ void __launch_bounds__(256)
-rows_by_index_kernel(const float* __restrict__ in, const int64_t* __restrict__ idx, uint32_t K, uint32_t C, float* __restrict__ out) {
+rows_by_index_kernel(const float* __restrict__ in, const int64_t* __restrict__ idx, uint32_t K, uint32_t C, uint32_t in_stride, uint32_t out_stride,
+                     float* __restrict__ out) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= K) return;
     const size_t r = (size_t)idx[k];
-    const float* src = in + (SCATTER ? (size_t)k : r) * C;
-    float* dst = out + (SCATTER ? r : (size_t)k) * C;
+    const float* src = in + (SCATTER ? (size_t)k : r) * in_stride;
+    float* dst = out + (SCATTER ? r : (size_t)k) * out_stride;
     if (C == 3u) { const float a = src[0], b = src[1], c = src[2]; dst[0] = a; dst[1] = b; dst[2] = c; }
     else for (uint32_t c = 0; c < C; ++c) dst[c] = src[c];
 }
@@ -768,7 +808,7 @@ rows_by_index_kernel(const float* __restrict__ in, const int64_t* __restrict__ i
 extern "C" int n2m_gather_rows(const float* x, const int64_t* idx, uint32_t K, uint32_t C, float* out, void* stream) {
     N2M_REQUIRE(x && idx && out && C >= 1, N2M_ENULL, "gather_rows: NULL tensor");
     if (K == 0) return 0;
-    rows_by_index_kernel<false><<<n2m_ceil_div(K, 256), 256, 0, (hipStream_t)stream>>>(x, idx, K, C, out);
+    rows_by_index_kernel<false><<<n2m_ceil_div(K, 256), 256, 0, (hipStream_t)stream>>>(x, idx, K, C, C, C, out);
     N2M_CHECK_LAUNCH();
     return 0;
 }
@@ -776,7 +816,28 @@ extern "C" int n2m_gather_rows(const float* x, const int64_t* idx, uint32_t K, u
 extern "C" int n2m_scatter_rows(const float* src, const int64_t* idx, uint32_t K, uint32_t C, float* dst, void* stream) {
     N2M_REQUIRE(src && idx && dst && C >= 1, N2M_ENULL, "scatter_rows: NULL tensor");
     if (K == 0) return 0;
-    rows_by_index_kernel<true><<<n2m_ceil_div(K, 256), 256, 0, (hipStream_t)stream>>>(src, idx, K, C, dst);
+    rows_by_index_kernel<true><<<n2m_ceil_div(K, 256), 256, 0, (hipStream_t)stream>>>(src, idx, K, C, C, C, dst);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+// the same with row strides: C leading floats of rows that are `x_stride` / `out_stride` floats apart (the RGB of an RGBA image, say)
+extern "C" int n2m_gather_rows_strided(const float* x, const int64_t* idx, uint32_t K, uint32_t C, uint32_t x_stride, float* out, uint32_t out_stride,
+                                       void* stream) {
+    N2M_REQUIRE(x && idx && out && C >= 1, N2M_ENULL, "gather_rows_strided: NULL tensor");
+    N2M_REQUIRE(x_stride >= C && out_stride >= C, N2M_EINVAL, "gather_rows_strided: a row stride below the row length");
+    if (K == 0) return 0;
+    rows_by_index_kernel<false><<<n2m_ceil_div(K, 256), 256, 0, (hipStream_t)stream>>>(x, idx, K, C, x_stride, out_stride, out);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_scatter_rows_strided(const float* src, const int64_t* idx, uint32_t K, uint32_t C, uint32_t src_stride, float* dst, uint32_t dst_stride,
+                                        void* stream) {
+    N2M_REQUIRE(src && idx && dst && C >= 1, N2M_ENULL, "scatter_rows_strided: NULL tensor");
+    N2M_REQUIRE(src_stride >= C && dst_stride >= C, N2M_EINVAL, "scatter_rows_strided: a row stride below the row length");
+    if (K == 0) return 0;
+    rows_by_index_kernel<true><<<n2m_ceil_div(K, 256), 256, 0, (hipStream_t)stream>>>(src, idx, K, C, src_stride, dst_stride, dst);
     N2M_CHECK_LAUNCH();
     return 0;
 }
@@ -784,23 +845,26 @@ extern "C" int n2m_scatter_rows(const float* src, const int64_t* idx, uint32_t K
 extern "C" int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const float* rast, uint32_t h0, uint32_t w0, uint32_t ssaa,
                                const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb, float lambda_mask, float* image,
                                float* depth, float* weights_sum, float* trig_id, float* loss_px, float* d_alpha, float* d_rgb, float* partial,
-                               float* tri_err, float* tri_cnt, int packed_rgba, const float* seed, void* stream) {
+                               float* tri_err, float* tri_cnt, int packed_rgba, const float* seed, float* d_copy, void* stream) {
     N2M_REQUIRE(aa_alpha && aa_rgb && rast && gt_rgba && image && depth && weights_sum && trig_id && loss_px && partial, N2M_ENULL,
                 "stage1_head: NULL tensor");
     N2M_REQUIRE((d_alpha == nullptr) == (d_rgb == nullptr), N2M_ENULL, "stage1_head: d_alpha and d_rgb come together");
     N2M_REQUIRE((tri_err == nullptr) == (tri_cnt == nullptr), N2M_ENULL, "stage1_head: tri_err and tri_cnt come together");
     N2M_REQUIRE(ssaa == 1 || ssaa == 2, N2M_EUNSUPPORTED, "stage1_head: ssaa 1 or 2 (the reduction is the exact 2 x 2 mean of torch's bilinear minification)");
     N2M_REQUIRE(h0 > 0 && w0 > 0 && (uint64_t)h0 * w0 < (1ull << 31), N2M_EINVAL, "stage1_head: bad image size");
+    N2M_REQUIRE(!packed_rgba || !d_rgb || (d_alpha == d_rgb + 3 && ((uintptr_t)d_rgb & 15u) == 0), N2M_EINVAL,
+                "stage1_head: packed gradients are ONE 16-byte aligned [h, w, 4] image (d_alpha = d_rgb + 3)");
+    N2M_REQUIRE(!d_copy || (packed_rgba && d_rgb && ((uintptr_t)d_copy & 15u) == 0), N2M_EINVAL, "stage1_head: d_copy goes with the packed gradient image");
     hipStream_t s = (hipStream_t)stream;
     const uint32_t N = h0 * w0;
     if (ssaa == 1)
         stage1_head_kernel<1><<<n2m_ceil_div(N, 256), 256, 0, s>>>(aa_alpha, aa_rgb, rast, h0, w0, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask,
                                                                   image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial, tri_err, tri_cnt, packed_rgba ? 4u : 1u,
-                                                                  packed_rgba ? 4u : 3u, seed);
+                                                                  packed_rgba ? 4u : 3u, seed, d_copy);
     else
         stage1_head_kernel<2><<<n2m_ceil_div(N, 256), 256, 0, s>>>(aa_alpha, aa_rgb, rast, h0, w0, gt_rgba, bg, bg_scalar, lambda_rgb, lambda_mask,
                                                                   image, depth, weights_sum, trig_id, loss_px, d_alpha, d_rgb, partial, tri_err, tri_cnt, packed_rgba ? 4u : 1u,
-                                                                  packed_rgba ? 4u : 3u, seed);
+                                                                  packed_rgba ? 4u : 3u, seed, d_copy);
     N2M_CHECK_LAUNCH();
     return 0;
 }

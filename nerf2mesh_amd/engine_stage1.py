@@ -47,15 +47,20 @@ class Stage1Engine:
         self.h, self.w = tr.H * ssaa, tr.W * ssaa
         hw, N, V = self.h * self.w, tr.H * tr.W, model.vertices.shape[0]
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        self.verts, self.clip, self.d_clip, self.d_verts, self.d_reg, self.d_off = f(V, 3), f(V, 4), f(V, 4), f(V, 3), f(V, 3), f(V, 3)
-        self.Lv, self.norm, self.reg_partial = f(V, 3), f(V), f((V + 255) // 256)
+        self.verts, self.clip, self.d_clip, self.d_verts = f(V, 3), f(V, 4), f(V, 4), f(V, 3)
+        self.verts1 = torch.ones(V, 4, dtype=torch.float32, device=dev)                       # [vertex | 1]: position and coverage interpolate together
+        self.Lv, self.norm = f(V, 3), f(V)
         self.ones = torch.ones(V, 1, dtype=torch.float32, device=dev)
         self.zbuf = torch.empty(hw, dtype=torch.int64, device=dev)
-        self.rast, self.xyz, self.mask = f(self.h, self.w, 4), f(hw, 3), f(hw, 1)
+        self.rast = f(self.h, self.w, 4)
         self.rgba, self.aa, self.d_aa, self.d_rgba = f(hw, 4), f(hw, 4), f(hw, 4), f(hw, 4)
-        self.d_mask, self.d_rast = f(hw, 1), f(self.h, self.w, 4)
+        self.d_rast = f(self.h, self.w, 4)
         self.image, self.depth, self.ws, self.trig, self.loss_px = f(N, 3), f(N), f(N), f(N), f(N)
-        self.partial = f((N + 255) // 256)
+        nb_head, nb_reg = (N + 255) // 256, (V + 255) // 256
+        self.partials = f(nb_head + nb_reg)                # [image head's | regularisers'] workgroup sums: ONE reduction gives the step's loss
+        self.partial, self.reg_partial = self.partials[:nb_head], self.partials[nb_head:]
+        self.half = torch.tensor(0.5, dtype=torch.float32, device=dev)
+        self.zero = torch.zeros((), dtype=torch.float32, device=dev)
         self.cap = 0
         enc = model.encoder_color
         self.enc = enc
@@ -73,6 +78,7 @@ class Stage1Engine:
             o += p.numel()
         self.table = dr._topology(model.triangles)
         self.bound = float(model.bound)
+        self.pow2_bound = float(np.log2(self.bound)).is_integer()
         # the optimizer reads the executor's buffers
         opt_ = tr.optimizer
         opt_.half_grads[enc.embeddings] = lambda: self.g2
@@ -85,8 +91,7 @@ class Stage1Engine:
             self.cap = cap = int(K * 1.25) + 4096
             dev = self.device
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-            self.pts, self.dsel, self.x01, self.rgb, self.spec, self.rows4, self.d_rows4 = f(cap, 3), f(cap, 3), f(cap, 3), f(cap, 3), f(cap, 3), f(cap, 4), f(cap, 4)
-            self.d_rgb = f(cap, 3)
+            self.pts, self.dsel, self.x01, self.rgb, self.spec, self.d_rgb = f(cap, 3), f(cap, 3), f(cap, 3), f(cap, 3), f(cap, 3), f(cap, 3)
             self.h2 = torch.empty(self.levels * cap * 2, dtype=torch.float16, device=dev)
             self.d_h2 = torch.empty(self.levels * cap * 2, dtype=torch.float16, device=dev)
 
@@ -112,49 +117,47 @@ class Stage1Engine:
             torch.add(model.vertices, model.vertices_offsets.detach(), out=self.verts)
             L.call("n2m_to_clip", _p(self.verts), _p(mvp), V, _p(self.clip), s)
             L.call("n2m_rasterize_forward", _p(self.clip), _p(tri), V, F, h, w, _p(self.zbuf), _p(self.rast), s)
-            L.call("n2m_interpolate_forward", _p(self.verts), _p(self.rast), _p(tri), V, F, 3, h, w, _p(self.xyz), s)
-            L.call("n2m_interpolate_forward", _p(self.ones), _p(self.rast), _p(tri), V, F, 1, h, w, _p(self.mask), s)
-            idx = torch.nonzero(self.mask.view(-1) > 0, as_tuple=False).squeeze(1)          # the step's one host read (sizes the shading kernels)
+            # positions AND coverage of every pixel in one pass, straight into the RGBA image: its alpha channel IS the coverage (0 where nothing
+            # is covered, like the other three), and the RGB of the covered pixels overwrites their positions once those have been gathered
+            self.verts1[:, :3] = self.verts
+            L.call("n2m_interpolate_forward", _p(self.verts1), _p(self.rast), _p(tri), V, F, 4, h, w, _p(self.rgba), s)
+            idx = torch.nonzero(self.rgba[:, 3] > 0, as_tuple=False).squeeze(1)                 # the step's one host read (sizes the shading kernels)
             K = int(idx.numel())
             model.last_covered = K
             tr.covered_seen += K
-            self.rgba.zero_()
             if K > 0:
                 self._grow(K)
-                pts, dsel, x01, rgb, rows4 = self.pts[:K], self.dsel[:K], self.x01[:K], self.rgb[:K], self.rows4[:K]
-                L.call("n2m_gather_rows", _p(self.xyz), _p(idx), K, 3, _p(pts), s)
+                pts, dsel, x01, rgb = self.pts[:K], self.dsel[:K], self.x01[:K], self.rgb[:K]
+                L.call("n2m_gather_rows_strided", _p(self.rgba), _p(idx), K, 3, 4, _p(pts), 3, s)
                 L.call("n2m_gather_rows", _p(dirs), _p(idx), K, 3, _p(dsel), s)
                 # ---- colour field of the covered pixels (nerf/renderer.py:875-881, nerf/network.py:159-189 under autocast)
-                torch.add(pts, self.bound, out=x01)
-                x01.div_(2.0 * self.bound)                                                   # grid.py:156
+                if self.pow2_bound:
+                    torch.add(self.half, pts, alpha=0.5 / self.bound, out=x01)               # == (x + bound) / (2 bound) bit for bit (grid.py:156)
+                else:
+                    torch.add(pts, self.bound, out=x01)
+                    x01.div_(2.0 * self.bound)
                 emb2h = self.enc.half_table()
                 L.call("n2m_grid_encode_forward", _p(x01), _p(emb2h), _p(self.enc.offsets), _p(self.h2), K, 3, 2, self.levels, self.levels, self.geo[0],
                        self.geo[1], None, self.geo[2], self.geo[3], self.geo[4], L.F16, s)
                 ws_ = [p.detach() for p in self.mlp]
                 L.call("n2m_field_forward", _p(pts), _p(dsel) if shading != 0 else None, None, _p(self.h2), *[_p(p) for p in ws_], K, shading, 0, None, _p(rgb),
                        _p(self.spec) if shading != 0 else None, s)
-                # RGB + coverage of the covered pixels into the [h, w, 4] image the ONE antialias call works on
-                rows4[:, :3] = rgb
-                L.call("n2m_gather_rows", _p(self.mask), _p(idx), K, 1, _p(self.d_rgb), s)           # (scratch: coverage values of the covered pixels)
-                rows4[:, 3] = self.d_rgb.view(-1)[:K]
-                L.call("n2m_scatter_rows", _p(rows4), _p(idx), K, 4, _p(self.rgba), s)
+                L.call("n2m_scatter_rows_strided", _p(rgb), _p(idx), K, 3, 3, _p(self.rgba), 4, s)
             L.call("n2m_antialias_forward", _p(self.rgba), _p(self.rast), _p(self.clip), _p(tri), _p(self.table), self.table.shape[0], V, F, 4, h, w,
                    _p(self.aa), s)
             # ---- image head: loss, face errors, and d loss / d antialias output (scaled by the loss scale) in one launch
             te = (model.triangles_errors, model.triangles_errors_cnt) if opt.refine else (None, None)
             L.call("n2m_stage1_head", self.aa.data_ptr() + 12, _p(self.aa), _p(self.rast), h0, w0, int(opt.ssaa), _p(rgba_gt), _p(bg), 0.0, float(opt.lambda_rgb),
                    float(max(opt.lambda_mask, 0.0)), _p(self.image), _p(self.depth), _p(self.ws), _p(self.trig), _p(self.loss_px), self.d_aa.data_ptr() + 12,
-                   _p(self.d_aa), _p(self.partial), _p(te[0]), _p(te[1]), 1, _p(o.scale), s)
+                   _p(self.d_aa), _p(self.partial), _p(te[0]), _p(te[1]), 1, _p(o.scale), _p(self.d_rgba), s)
             # ---- backward
             self.d_clip.zero_()
-            L.call("n2m_antialias_backward", _p(self.rgba), _p(self.rast), _p(self.clip), _p(tri), _p(self.table), self.table.shape[0], _p(self.d_aa), V, F, 4, h, w,
+            L.call("n2m_antialias_backward_seeded", _p(self.rgba), _p(self.rast), _p(self.clip), _p(tri), _p(self.table), self.table.shape[0], _p(self.d_aa), V, F, 4, h, w,
                    float(opt.pos_gradient_boost), _p(self.d_rgba), _p(self.d_clip), s)
             self._live = [False] * 7
             if K > 0:
-                d_rows4 = self.d_rows4[:K]
-                L.call("n2m_gather_rows", _p(self.d_rgba), _p(idx), K, 4, _p(d_rows4), s)
                 d_rgb = self.d_rgb[:K]
-                d_rgb.copy_(d_rows4[:, :3])
+                L.call("n2m_gather_rows_strided", _p(self.d_rgba), _p(idx), K, 3, 4, _p(d_rgb), 3, s)
                 L.call("n2m_field_backward", _p(pts), _p(dsel) if shading != 0 else None, None, _p(self.h2), *[_p(p) for p in ws_], K, shading, 0, None, _p(d_rgb),
                        None, None, _p(self.d_h2), *[_p(g) for g in self.dw_views], _p(o.found_inf), s)
                 self._live = [False, False, True, True, True, shading != 0, shading != 0]
@@ -165,9 +168,8 @@ class Stage1Engine:
                        self.geo[0], self.geo[1], self.geo[2], self.geo[3], self.geo[4], None, 0.0, 0.0, 1.0, None, _p(o.found_inf), 1.0, 0.0, 1, _p(wsb),
                        wsb.numel(), s)
                 # coverage: its gradient reaches the vertex positions through the barycentrics (the interpolated attribute is the constant 1)
-                self.d_mask.zero_()
-                L.call("n2m_scatter_rows", _p(d_rows4[:, 3].contiguous()), _p(idx), K, 1, _p(self.d_mask), s)
-                L.call("n2m_interpolate_backward", _p(self.ones), _p(self.rast), _p(tri), _p(self.d_mask), V, F, 1, h, w, None, _p(self.d_rast), s)
+                L.call("n2m_interpolate_backward_strided", _p(self.ones), _p(self.rast), _p(tri), self.d_rgba.data_ptr() + 12, 4, V, F, 1, h, w, None,
+                       _p(self.d_rast), s)
                 L.call("n2m_rasterize_backward", _p(self.clip), _p(tri), _p(self.rast), _p(self.d_rast), V, F, h, w, _p(self.d_clip), s)
             else:
                 self.g2.zero_()
@@ -180,15 +182,17 @@ class Stage1Engine:
             else:
                 w_in, w_out = float(opt.lambda_offsets) / n_in, 0.1 * float(opt.lambda_offsets) / (V - n_in)
             lap = tr.laplacian
-            L.call("n2m_laplacian_forward", _p(self.verts), _p(lap.row_ptr), _p(lap.col), V, _p(off), float(opt.lambda_lap), w_in, w_out, n_in, _p(self.Lv),
-                   _p(self.norm), _p(self.reg_partial), s)
-            L.call("n2m_laplacian_backward", _p(self.Lv), _p(self.norm), _p(lap.row_ptr), _p(lap.col), V, _p(o.scale), float(opt.lambda_lap), _p(off), w_in, w_out,
-                   n_in, _p(self.d_reg), _p(self.d_off), s)
-            self.d_verts.add_(self.d_reg).add_(self.d_off)
+            Npx = float(h0 * w0)
+            # the VALUE's weights carry a factor h0 w0, so that (image-head sums + regulariser sums) / (h0 w0) is the loss in one reduction
+            L.call("n2m_laplacian_forward", _p(self.verts), _p(lap.row_ptr), _p(lap.col), V, _p(off), float(opt.lambda_lap) * Npx, w_in * Npx, w_out * Npx, n_in,
+                   _p(self.Lv), _p(self.norm), _p(self.reg_partial), s)
+            # d offsets = rendering gradient of the vertices + smoothness + offset penalty, and its non-finite check, in one pass
+            L.call("n2m_laplacian_backward_acc", _p(self.Lv), _p(self.norm), _p(lap.row_ptr), _p(lap.col), V, _p(o.scale), float(opt.lambda_lap), _p(off), w_in,
+                   w_out, n_in, _p(self.d_verts), _p(o.found_inf), s)
             model.vertices_offsets.grad = self.d_verts
-            loss = self.partial.sum() / (h0 * w0) + self.reg_partial.sum()
+            loss = self.partials.sum() / Npx
             # ---- optimizer: colour table (fp16 gradient) and weight gradients were checked by the kernels that produced them
-            flagged = ([self.enc.embeddings] + [p for p, lv in zip(self.mlp, self._live) if lv]) if K > 0 else []
+            flagged = [model.vertices_offsets] + (([self.enc.embeddings] + [p for p, lv in zip(self.mlp, self._live) if lv]) if K > 0 else [])
             o.step(flagged=flagged)
         tr.scheduler.step()
         return loss

@@ -81,7 +81,7 @@ class _stage1_head(Function):
             pa, pda = _p(aa_alpha), _p(d_alpha)
         L.call("n2m_stage1_head", pa, _p(aa_rgb), _p(rast), int(h0), int(w0), int(ssaa), _p(gt_rgba), _p(bg_t), bg_s, float(lambda_rgb),
                float(lambda_mask), _p(image), _p(depth), _p(ws), _p(trig), _p(loss_px), pda, _p(d_rgb), _p(partial), _p(tri_err), _p(tri_cnt),
-               int(packed), _p(seed), L.stream())
+               int(packed), _p(seed), None, L.stream())
         ctx.grads = (d_alpha, d_rgb)
         ctx.seeded = seed is not None
         ctx.seed_ref = seed

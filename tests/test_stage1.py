@@ -165,6 +165,58 @@ def test_rows_by_index_kernels():
         assert torch.equal(src.grad, w2[idx])
 
 
+def test_strided_rows_and_accumulating_laplacian_backward():
+    """The C-ABI entries the stage-1 executor adds: n2m_gather_rows_strided / n2m_scatter_rows_strided (RGB of an RGBA image by index, the
+    fourth channel untouched) against torch indexing, bit for bit; n2m_laplacian_backward_acc == base + n2m_laplacian_backward's two outputs
+    summed in that order, bit for bit, and its non-finite flag."""
+    import torch
+    from nerf2mesh_amd import _lib as L
+    from nerf2mesh_amd import synthetic as S
+    from nerf2mesh_amd.trainer import UniformLaplacian
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(4)
+    N = 70_001
+    idx = torch.nonzero(torch.rand(N, device=dev, generator=g) < 0.4).squeeze(1)
+    K, s = int(idx.numel()), L.stream()
+    img = torch.rand(N, 4, device=dev, generator=g)
+    out = torch.full((K, 3), -1.0, device=dev)
+    L.call("n2m_gather_rows_strided", L.ptr(img), L.ptr(idx), K, 3, 4, L.ptr(out), 3, s)
+    assert torch.equal(out, img[idx, :3])
+    rows = torch.rand(K, 3, device=dev, generator=g)
+    dst = img.clone()
+    L.call("n2m_scatter_rows_strided", L.ptr(rows), L.ptr(idx), K, 3, 3, L.ptr(dst), 4, s)
+    want = img.clone()
+    want[idx, :3] = rows
+    assert torch.equal(dst, want)                                      # alpha channel and unlisted rows untouched
+    with pytest.raises(RuntimeError):
+        L.call("n2m_gather_rows_strided", L.ptr(img), L.ptr(idx), K, 3, 2, L.ptr(out), 3, s)
+
+    v, f = S.scene_mesh(3000)
+    verts = torch.as_tensor(v, dtype=torch.float32, device=dev)
+    lap = UniformLaplacian(torch.as_tensor(f, dtype=torch.int64, device=dev), verts.shape[0])
+    V = verts.shape[0]
+    off = 0.01 * torch.randn(V, 3, device=dev, generator=g)
+    Lv, norm, part = torch.empty(V, 3, device=dev), torch.empty(V, device=dev), torch.empty((V + 255) // 256, device=dev)
+    n_in, w_in, w_out, lam = V // 2, 0.1 / (V // 2), 0.01 / (V - V // 2), 0.05
+    moved = verts + off
+    L.call("n2m_laplacian_forward", L.ptr(moved), L.ptr(lap.row_ptr), L.ptr(lap.col), V, L.ptr(off), lam, w_in, w_out, n_in, L.ptr(Lv), L.ptr(norm),
+           L.ptr(part), s)
+    seed = torch.tensor(1024.0, device=dev)
+    d_v, d_o = torch.empty(V, 3, device=dev), torch.empty(V, 3, device=dev)
+    L.call("n2m_laplacian_backward", L.ptr(Lv), L.ptr(norm), L.ptr(lap.row_ptr), L.ptr(lap.col), V, L.ptr(seed), lam, L.ptr(off), w_in, w_out, n_in,
+           L.ptr(d_v), L.ptr(d_o), s)
+    base = torch.randn(V, 3, device=dev, generator=g)
+    acc, flag = base.clone(), torch.zeros(1, device=dev)
+    L.call("n2m_laplacian_backward_acc", L.ptr(Lv), L.ptr(norm), L.ptr(lap.row_ptr), L.ptr(lap.col), V, L.ptr(seed), lam, L.ptr(off), w_in, w_out, n_in,
+           L.ptr(acc), L.ptr(flag), s)
+    assert torch.equal(acc, (base + d_v) + d_o) and float(flag) == 0.0
+    acc = base.clone()
+    acc[17, 1] = float("inf")
+    L.call("n2m_laplacian_backward_acc", L.ptr(Lv), L.ptr(norm), L.ptr(lap.row_ptr), L.ptr(lap.col), V, L.ptr(seed), lam, L.ptr(off), w_in, w_out, n_in,
+           L.ptr(acc), L.ptr(flag), s)
+    assert float(flag) == 1.0
+
+
 def test_laplacian_kernels_equal_the_index_add_form():
     """n2m_laplacian_forward / _backward (trainer.UniformLaplacian on the GPU) against the torch form of the same loss (two index_add
     passes, norm, mean -- the form tests/test_stage1_reference.py pins to the unchanged laplacian_smooth_loss): value and gradient, on a
@@ -294,4 +346,5 @@ def test_stage1_executor_reproduces_the_autograd_trainer():
         d_te, d_tt = rel(pa[k], pb[k]), rel(pa[k], pa2[k])
         print(f"{k:14s} trainer-vs-executor {d_te:.3g}   trainer-vs-trainer {d_tt:.3g}")
         assert d_te <= 10 * d_tt + 2e-3, k
-    assert b.global_step == a.global_step == 16 and b.covered_seen == a.covered_seen
+    # (covered pixels: float-atomics noise in the offsets moves a vertex across a pixel centre now and then, between two autograd runs too)
+    assert b.global_step == a.global_step == 16 and abs(b.covered_seen - a.covered_seen) <= max(16, 4 * abs(a2.covered_seen - a.covered_seen))
