@@ -262,7 +262,7 @@ def bench_stage1(args, rank, world, device):
     tr.preload()                     # rays + ground truth of all views on the device, as the reference's --preload
     from nerf2mesh_amd.engine_stage1 import Stage1Engine
     use_engine = not args.autograd and Stage1Engine.supported(tr)
-    stepper = Stage1Engine(tr) if use_engine else tr      # the fixed launch sequence (engine_stage1.py) or the autograd trainer (--autograd, multi-rank)
+    stepper = Stage1Engine(tr) if use_engine else tr      # the fixed launch sequence (engine_stage1.py) or the autograd trainer (--autograd)
     for _ in range(args.warmup):
         stepper.train_step()
     torch.cuda.synchronize()

@@ -31,13 +31,13 @@ class Stage1Engine:
     @staticmethod
     def supported(tr):
         opt, model = tr.opt, tr.model
-        return (tr.amp_adam and tr.fused_head and tr.packed_aa and tr.world == 1 and bool(getattr(opt, "fused_mlp", False)) and not opt.contract
+        return (tr.amp_adam and tr.fused_head and tr.packed_aa and bool(getattr(opt, "fused_mlp", False)) and not opt.contract
                 and not opt.enable_offset_nerf_grad and getattr(model, "individual_dim", 0) == 0 and opt.lambda_lap > 0 and opt.lambda_offsets > 0
                 and model.vertices.is_cuda and int(opt.ssaa) in (1, 2))
 
     def __init__(self, trainer):
         if not self.supported(trainer):
-            raise ValueError("Stage1Engine covers the fused stage-1 recipe on one GPU (fused_mlp, fp16, fused image head, packed antialias); "
+            raise ValueError("Stage1Engine covers the fused stage-1 recipe (fused_mlp, fp16, fused image head, packed antialias); "
                              "use trainer.Stage1Trainer.train_step for anything else")
         self.tr = tr = trainer
         model, opt, dev = tr.model, tr.opt, tr.device
@@ -85,6 +85,11 @@ class Stage1Engine:
         for i, p in enumerate(self.mlp):
             opt_.ext_grads[p] = (lambda i=i: self.dw_views[i] if self._live[i] else None)
         self._live = [False] * 7
+        # more than one rank (views shard): every gradient carries scale / world and is SUMMED over the ranks before the optimizer,
+        # exactly as trainer.Stage1Trainer does it -- fp16 colour-table gradient and vertex gradient as they are, the weight gradients and the
+        # non-finite flag in one small bucket
+        self.world = int(tr.world)
+        self.seed = tr.optimizer.scale if self.world == 1 else torch.empty_like(tr.optimizer.scale)
 
     def _grow(self, K):
         if K > self.cap:
@@ -113,6 +118,8 @@ class Stage1Engine:
         tri, mvp = model.triangles, tr.mvps[v]
         shading = SHADING["diffuse" if opt.diffuse_only else "full"]
         with torch.no_grad():
+            if self.world > 1:
+                torch.div(o.scale, float(self.world), out=self.seed)
             # ---- front half (nerf/renderer.py:855-872)
             torch.add(model.vertices, model.vertices_offsets.detach(), out=self.verts)
             L.call("n2m_to_clip", _p(self.verts), _p(mvp), V, _p(self.clip), s)
@@ -149,7 +156,7 @@ class Stage1Engine:
             te = (model.triangles_errors, model.triangles_errors_cnt) if opt.refine else (None, None)
             L.call("n2m_stage1_head", self.aa.data_ptr() + 12, _p(self.aa), _p(self.rast), h0, w0, int(opt.ssaa), _p(rgba_gt), _p(bg), 0.0, float(opt.lambda_rgb),
                    float(max(opt.lambda_mask, 0.0)), _p(self.image), _p(self.depth), _p(self.ws), _p(self.trig), _p(self.loss_px), self.d_aa.data_ptr() + 12,
-                   _p(self.d_aa), _p(self.partial), _p(te[0]), _p(te[1]), 1, _p(o.scale), _p(self.d_rgba), s)
+                   _p(self.d_aa), _p(self.partial), _p(te[0]), _p(te[1]), 1, _p(self.seed), _p(self.d_rgba), s)
             # ---- backward
             self.d_clip.zero_()
             L.call("n2m_antialias_backward_seeded", _p(self.rgba), _p(self.rast), _p(self.clip), _p(tri), _p(self.table), self.table.shape[0], _p(self.d_aa), V, F, 4, h, w,
@@ -167,12 +174,16 @@ class Stage1Engine:
                 L.call("n2m_grid_encode_backward_binned_pair", None, _p(self.d_h2), _p(x01), self.ho.ctypes.data, None, _p(self.g2), K, self.levels, self.levels,
                        self.geo[0], self.geo[1], self.geo[2], self.geo[3], self.geo[4], None, 0.0, 0.0, 1.0, None, _p(o.found_inf), 1.0, 0.0, 1, _p(wsb),
                        wsb.numel(), s)
+                if self.world > 1:        # the two large sums travel while the vertex path finishes
+                    tok = tr.sync.all_reduce_sum_begin([self.g2], [self.dw])
                 # coverage: its gradient reaches the vertex positions through the barycentrics (the interpolated attribute is the constant 1)
                 L.call("n2m_interpolate_backward_strided", _p(self.ones), _p(self.rast), _p(tri), self.d_rgba.data_ptr() + 12, 4, V, F, 1, h, w, None,
                        _p(self.d_rast), s)
                 L.call("n2m_rasterize_backward", _p(self.clip), _p(tri), _p(self.rast), _p(self.d_rast), V, F, h, w, _p(self.d_clip), s)
             else:
                 self.g2.zero_()
+                if self.world > 1:
+                    tok = tr.sync.all_reduce_sum_begin([self.g2], [self.dw])
             L.call("n2m_to_clip_backward", _p(self.d_clip), _p(mvp), V, _p(self.d_verts), s)
             # ---- mesh regularisers (nerf/utils.py:761-789): value and gradient, the gradient scaled like everything else
             off = model.vertices_offsets.detach()
@@ -187,12 +198,19 @@ class Stage1Engine:
             L.call("n2m_laplacian_forward", _p(self.verts), _p(lap.row_ptr), _p(lap.col), V, _p(off), float(opt.lambda_lap) * Npx, w_in * Npx, w_out * Npx, n_in,
                    _p(self.Lv), _p(self.norm), _p(self.reg_partial), s)
             # d offsets = rendering gradient of the vertices + smoothness + offset penalty, and its non-finite check, in one pass
-            L.call("n2m_laplacian_backward_acc", _p(self.Lv), _p(self.norm), _p(lap.row_ptr), _p(lap.col), V, _p(o.scale), float(opt.lambda_lap), _p(off), w_in,
+            L.call("n2m_laplacian_backward_acc", _p(self.Lv), _p(self.norm), _p(lap.row_ptr), _p(lap.col), V, _p(self.seed), float(opt.lambda_lap), _p(off), w_in,
                    w_out, n_in, _p(self.d_verts), _p(o.found_inf), s)
             model.vertices_offsets.grad = self.d_verts
             loss = self.partials.sum() / Npx
             # ---- optimizer: colour table (fp16 gradient) and weight gradients were checked by the kernels that produced them
             flagged = [model.vertices_offsets] + (([self.enc.embeddings] + [p for p, lv in zip(self.mlp, self._live) if lv]) if K > 0 else [])
+            if self.world > 1:
+                # a rank whose view shows nothing still takes part (its gradients are zeros); a sum of finite values can overflow, so the
+                # optimizer checks the reduced gradients again
+                tr.sync.all_reduce_sum_end(tok)
+                tr.sync.all_reduce_sum([self.d_verts, o.found_inf], [])
+                self._live = [False, False, True, True, True, shading != 0, shading != 0]
+                flagged = []
             o.step(flagged=flagged)
         tr.scheduler.step()
         return loss

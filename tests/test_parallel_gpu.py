@@ -48,12 +48,14 @@ def test_sharded_optimizer_equals_the_all_reduce_path(tmp_path):
 
 
 @pytest.mark.gpu
-def test_stage1_two_ranks_views_sharded():
-    """Stage 1 on two ranks (views shard): the fused AMP optimizer stays on, replicas bit-identical, the per-face error accumulators
-    summed over the ranks before a refinement, rank 0's new mesh taken over by everybody (tools/dist_check_stage1.py)."""
+@pytest.mark.parametrize("driver", ["trainer", "engine"])
+def test_stage1_two_ranks_views_sharded(driver):
+    """Stage 1 on two ranks (views shard), autograd trainer and step executor: the fused AMP optimizer stays on, replicas
+    bit-identical, the per-face error accumulators summed over the ranks before a refinement, rank 0's new mesh taken over by everybody
+    (tools/dist_check_stage1.py)."""
     env = dict(os.environ, N2M_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "tools", "dist_check_stage1.py"), "6"]
+           "--master-port", {"trainer": "29541", "engine": "29543"}[driver], os.path.join(ROOT, "tools", "dist_check_stage1.py"), "6", driver]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DIST_CHECK_S1 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 

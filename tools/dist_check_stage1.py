@@ -16,6 +16,7 @@ from nerf2mesh_amd.parallel import init_from_env
 from nerf2mesh_amd.trainer import Stage1Trainer
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+driver = sys.argv[2] if len(sys.argv) > 2 else "trainer"           # "engine": engine_stage1.Stage1Engine drives the trainer's state
 rank, world, local = init_from_env()
 device = torch.device("cuda", local % torch.cuda.device_count())
 torch.cuda.set_device(device)
@@ -24,6 +25,17 @@ opt = make_options(O=True, bound=1, dt_gamma=0, stage=1, fused_mlp=True)
 v, f = synthetic.scene_mesh(20000)
 tr = Stage1Trainer(NeRFNetwork(opt), opt, synthetic.make_cameras(8, seed=0), v, f, device, H=200, W=200, rank=rank, world_size=world)
 assert tr.amp_adam, "the fused AMP optimizer must stay on with more than one rank"
+
+
+def stepper():
+    if driver != "engine":
+        return tr.train_step
+    from nerf2mesh_amd.engine_stage1 import Stage1Engine
+    assert Stage1Engine.supported(tr)
+    return Stage1Engine(tr).train_step
+
+
+step = stepper()
 
 
 def digest():
@@ -38,7 +50,7 @@ def same_everywhere(t):
     return all(torch.equal(g, got[0]) for g in got)
 
 
-losses = [float(tr.train_step()) for _ in range(steps)]
+losses = [float(step()) for _ in range(steps)]
 torch.cuda.synchronize()
 d, flat = digest()
 ok = bool(torch.isfinite(flat).all()) and all(l == l for l in losses) and same_everywhere(d.to(device))
@@ -57,13 +69,14 @@ n_faces_before = f.shape[0]
 tr.broadcast_mesh(src=0)
 nf = torch.tensor([tr.model.triangles.shape[0]], device=device)
 ok = ok and same_everywhere(nf) and int(nf) < n_faces_before and same_everywhere(tr.model.triangles.double().sum().reshape(1))
-more = [float(tr.train_step()) for _ in range(2)]
+step = stepper()               # the mesh changed: the trainer rebuilt its state, the executor its buffers
+more = [float(step()) for _ in range(2)]
 torch.cuda.synchronize()
 d2, flat2 = digest()
 ok = ok and bool(torch.isfinite(flat2).all()) and same_everywhere(d2.to(device)) and all(l == l for l in more)
 dist.barrier()
 if rank == 0:
-    print(f"DIST_CHECK_S1 {'OK' if ok else 'FAILED'} world={world} backend={dist.get_backend()} steps={steps} loss {losses[0]:.5f} -> {losses[-1]:.5f} "
+    print(f"DIST_CHECK_S1 {'OK' if ok else 'FAILED'} driver={driver} world={world} backend={dist.get_backend()} steps={steps} loss {losses[0]:.5f} -> {losses[-1]:.5f} "
           f"offsets_moved={moved} faces {n_faces_before} -> {int(nf)} digest={[float(x) for x in d2]}")
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
