@@ -122,6 +122,17 @@ SIGNATURES = {
     "n2m_scatter_rows_strided": [_vp, _vp, _u32, _u32, _u32, _vp, _u32, _vp],
     "n2m_scatter_rows": [_vp, _vp, _u32, _u32, _vp, _vp],
     "n2m_stage1_head": [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp],
+    # include/n2m_peer.h
+    "n2m_peer_alloc": [ctypes.c_size_t, _int, ctypes.POINTER(_vp)],
+    "n2m_peer_free": [_vp],
+    "n2m_peer_export": [_vp, _vp],
+    "n2m_peer_import": [_vp, ctypes.POINTER(_vp)],
+    "n2m_peer_unmap": [_vp],
+    "n2m_peer_signal": [_vp, _u32, _vp],
+    "n2m_peer_wait": [_vp, _u32, _u32, _u32, _u32, _vp, _vp],
+    "n2m_peer_copy": [_vp, _vp, ctypes.c_size_t, _vp],
+    "n2m_peer_reduce_slices": [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
+    "n2m_grid_backward_peer_route": [_vp],
     "n2m_prof_enable": [_int],
     "n2m_prof_reset": [],
     "n2m_prof_read": [_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
@@ -140,6 +151,19 @@ class AdamDesc(ctypes.Structure):
     _fields_ = [("param", _vp * ADAM_MAX), ("grad", _vp * ADAM_MAX), ("exp_avg", _vp * ADAM_MAX), ("exp_avg_sq", _vp * ADAM_MAX),
                 ("half_shadow", _vp * ADAM_MAX), ("numel", _u32 * ADAM_MAX), ("lr", _f32 * ADAM_MAX), ("grad_is_half", _i32 * ADAM_MAX),
                 ("shadow_mode", _i32 * ADAM_MAX), ("clear_grad", _i32 * ADAM_MAX), ("slot", _i32 * ADAM_MAX), ("count", _u32)]
+
+
+PEER_MAX = 8
+
+
+class PeerPtrs(ctypes.Structure):
+    """N2mPeerPtrs of include/n2m_peer.h."""
+    _fields_ = [("ptr", _vp * PEER_MAX), ("count", _u32)]
+
+
+class PeerRoute(ctypes.Structure):
+    """N2mPeerRoute of include/n2m_peer.h."""
+    _fields_ = [("world", _u32), ("split_row", _u32), ("rows_c", _u32), ("rows_f", _u32), ("g1", (_vp * PEER_MAX) * 2), ("g2", (_vp * PEER_MAX) * 2)]
 
 
 class AdamFuse(ctypes.Structure):

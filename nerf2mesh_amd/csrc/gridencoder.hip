@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "n2m_common.hpp"
+#include "../../include/n2m_peer.h"
 
 namespace {
 
@@ -2580,6 +2581,16 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
 // slot, the last of the Gl items to arrive (a ticket per partition group) adds the slots and flushes the rows with plain stores.  Integer
 // sums are exact whatever the cut: the whole table backward is bit-reproducible run to run (the tile-major path ends these levels in
 // float atomics), and the fill no longer clears rows for atomics to land on.
+// Peer-store routing of the flush (include/n2m_peer.h): the row's owner keeps a staging slot for this rank; world == 0: off.
+struct PeerRouteK { uint32_t world, split, rows_c, rows_f; };
+struct PeerRouteT { void* base[2][N2M_PEER_MAX]; };
+template <typename T, uint32_t C>
+__device__ __forceinline__ T* peer_row(const PeerRouteK& k, const PeerRouteT& t, uint32_t abs_row) {
+    const uint32_t half = abs_row >= k.split ? 1u : 0u, rel = abs_row - (half ? k.split : 0u), n = half ? k.rows_f : k.rows_c;
+    const uint32_t owner = rel / n;
+    return reinterpret_cast<T*>(t.base[half][owner]) + (size_t)(rel - owner * n) * C;
+}
+
 struct PmSplit {
     uint32_t slot0[kMaxLevels];         // first scratch slot of the level's work items (slot = SUB * P * C u64; levels with Gl > 1 only)
     uint32_t tick0[kMaxLevels];         // first ticket of the level's partition groups
@@ -2592,7 +2603,7 @@ __device__ __forceinline__ void pm_accumulate_items(uint32_t first_item, uint32_
                      const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ ovf_cursor,
                      const uint16_t* __restrict__ log_rel, const uint32_t* __restrict__ log_val, const uint32_t* __restrict__ ovf_key,
                      const uint32_t* __restrict__ ovf_val, unsigned long long* __restrict__ slots, uint32_t* __restrict__ tickets,
-                     float* __restrict__ found_inf, bool overwrite, uint32_t dbg, float inf_bound) {
+                     float* __restrict__ found_inf, bool overwrite, uint32_t dbg, float inf_bound, const PeerRouteK& prk, const PeerRouteT& prt) {
     constexpr uint32_t kLog2P = 31u - __builtin_clz(P);
     constexpr uint32_t kSlot = SUB * P * C;
     extern __shared__ __attribute__((aligned(16))) unsigned long long bin_acc[];   // SUB * P * C
@@ -2757,8 +2768,9 @@ __device__ __forceinline__ void pm_accumulate_items(uint32_t first_item, uint32_
                 if (a != 0 || overwrite) {
                     const float f = (float)a * inv;
                     if (!(fabsf(f) <= (inf_bound > 0.0f ? inf_bound : 3.0e38f)) && found_inf) *found_inf = 1.0f;
-                    if (overwrite) gtab[row] = f;
-                    else gtab[row] += f;
+                    float* dst = prk.world ? peer_row<float, 1>(prk, prt, row0 + row) : gtab + row;
+                    if (overwrite) *dst = f;
+                    else *dst += f;
                 }
             } else {
                 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -2767,7 +2779,7 @@ __device__ __forceinline__ void pm_accumulate_items(uint32_t first_item, uint32_
                     const float f0 = (float)a0 * inv, f1 = (float)a1 * inv;
                     const float b16 = inf_bound > 0.0f ? inf_bound : 65504.0f;
                     if (!(fabsf(f0) <= b16 && fabsf(f1) <= b16) && found_inf) *found_inf = 1.0f;       // rounds to inf in fp16 (or could, summed over ranks)
-                    h2* dst = reinterpret_cast<h2*>(gtab + (size_t)row * 2u);
+                    h2* dst = reinterpret_cast<h2*>(prk.world ? peer_row<_Float16, 2>(prk, prt, row0 + row) : gtab + (size_t)row * 2u);
                     h2 o;
                     if (overwrite) {
                         o.x = (_Float16)f0;          // == (half)(0 + f): the sum below starts from +0
@@ -2782,7 +2794,9 @@ __device__ __forceinline__ void pm_accumulate_items(uint32_t first_item, uint32_
             }
         }
         __syncthreads();
-        if (second_walk) {
+        if (second_walk && prk.world) {
+            if (tid == 0 && found_inf) *found_inf = 1.0f;                  // routed rows live on another rank: no atomics across the link, the step is skipped anyway
+        } else if (second_walk) {
             __threadfence();                                               // the stores above before the atomics below
             walk([&](uint32_t rel0, uint32_t u, uint32_t bits) { if (!finite(bits)) bypass(rel0, u, bits); }, Gl > 1u);
             __syncthreads();
@@ -2798,9 +2812,9 @@ pm_accumulate_kernel(T* __restrict__ grad_table, BinPlan plan, PmPlan pm, PmSpli
                      const uint32_t* __restrict__ level_max, const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ ovf_cursor,
                      const uint16_t* __restrict__ log_rel, const uint32_t* __restrict__ log_val, const uint32_t* __restrict__ ovf_key,
                      const uint32_t* __restrict__ ovf_val, unsigned long long* __restrict__ slots, uint32_t* __restrict__ tickets,
-                     float* __restrict__ found_inf, bool overwrite, uint32_t dbg, float inf_bound) {
+                     float* __restrict__ found_inf, bool overwrite, uint32_t dbg, float inf_bound, PeerRouteK prk, PeerRouteT prt) {
     pm_accumulate_items<T, C, P, SUB>(blockIdx.x, gridDim.x, grad_table, plan, pm, sp, lv, gridtype, align_corners, level_max, cursors, ovf_cursor, log_rel, log_val,
-                                      ovf_key, ovf_val, slots, tickets, found_inf, overwrite, dbg, inf_bound);
+                                      ovf_key, ovf_val, slots, tickets, found_inf, overwrite, dbg, inf_bound, prk, prt);
 }
 
 struct PmBoth {
@@ -2813,13 +2827,14 @@ pm_accumulate_both_kernel(float* __restrict__ table1, _Float16* __restrict__ tab
                           const uint16_t* __restrict__ log_rel, const uint32_t* __restrict__ log_v1, const uint32_t* __restrict__ log_v2,
                           const uint32_t* __restrict__ ovf_key, const uint32_t* __restrict__ ovf_v1, const uint32_t* __restrict__ ovf_v2,
                           unsigned long long* __restrict__ slots1, unsigned long long* __restrict__ slots2, uint32_t* __restrict__ tickets1,
-                          uint32_t* __restrict__ tickets2, float* __restrict__ found_inf, bool overwrite, uint32_t dbg, float bound1, float bound2, uint32_t nb1) {
+                          uint32_t* __restrict__ tickets2, float* __restrict__ found_inf, bool overwrite, uint32_t dbg, float bound1, float bound2, uint32_t nb1,
+                          PeerRouteK prk, PeerRouteT prt1, PeerRouteT prt2) {
     if (blockIdx.x < nb1)
         pm_accumulate_items<float, 1, kPairP, 2>(blockIdx.x, nb1, table1, pb.plan1, pm, pb.sp1, lv, gridtype, align_corners, level_max, cursors, ovf_cursor, log_rel,
-                                                 log_v1, ovf_key, ovf_v1, slots1, tickets1, found_inf, overwrite, dbg, bound1);
+                                                 log_v1, ovf_key, ovf_v1, slots1, tickets1, found_inf, overwrite, dbg, bound1, prk, prt1);
     else
         pm_accumulate_items<_Float16, 2, kPairP, 1>(blockIdx.x - nb1, gridDim.x - nb1, table2, pb.plan2, pm, pb.sp2, lv, gridtype, align_corners, level_max + kMaxLevels,
-                                                    cursors, ovf_cursor, log_rel, log_v2, ovf_key, ovf_v2, slots2, tickets2, found_inf, overwrite, dbg, bound2);
+                                                    cursors, ovf_cursor, log_rel, log_v2, ovf_key, ovf_v2, slots2, tickets2, found_inf, overwrite, dbg, bound2, prk, prt2);
 }
 
 // grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]; accumulates in T like the reference (:357-365)
@@ -3009,6 +3024,7 @@ struct ThreadCfg { uint32_t v; uint32_t load() const { return v; } };
 struct ThreadCfgF { float v; float load() const { return v; } };
 static thread_local ThreadCfg g_cfg_tv_stride{1};
 static thread_local ThreadCfgF g_cfg_overflow_div{1.0f};
+static thread_local N2mPeerRoute g_peer_route{};          // world == 0: off (n2m_grid_backward_peer_route)
 
 constexpr size_t kBinHeaderBytes = 512;          // [level maxima 2 x 32 words][ready token 8 B][pad]
 
@@ -3327,26 +3343,35 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
         static const uint32_t acc_cap = getenv("N2M_ACC_GRID") ? (uint32_t)atoi(getenv("N2M_ACC_GRID")) : 4096u;
         static const uint32_t acc_dbg = getenv("N2M_ACC_DEBUG") ? (uint32_t)atoi(getenv("N2M_ACC_DEBUG")) : 0u;
         const float odiv = g_cfg_overflow_div.load();
+        PeerRouteK prk{};
+        PeerRouteT prt1{}, prt2{};
+        if (g_peer_route.world) {
+            N2M_REQUIRE(ow && B <= kBinChunk && max_level == L && !fold, N2M_EUNSUPPORTED,
+                        "%s: a routed flush (n2m_grid_backward_peer_route) needs overwrite mode, one pass, all levels and no folded copies", fn);
+            prk = PeerRouteK{g_peer_route.world, g_peer_route.split_row, g_peer_route.rows_c, g_peer_route.rows_f};
+            for (int h = 0; h < 2; ++h)
+                for (uint32_t r = 0; r < g_peer_route.world; ++r) { prt1.base[h][r] = g_peer_route.g1[h][r]; prt2.base[h][r] = g_peer_route.g2[h][r]; }
+        }
         const uint32_t nb1 = items1 < acc_cap ? items1 : acc_cap, nb2 = items2 < acc_cap ? items2 : acc_cap;
         static const bool one_launch = getenv("N2M_PM_ACC_SPLIT") == nullptr;
         if (both && has2 && one_launch) {
             PmBoth pb{plan1, plan2, sp1, sp2};
             N2M_LAUNCH(pm_accumulate_both_kernel, nb1 + nb2, 1024, kPairP * 16, s, table1, table2, pb, pl.pm, lv, gridtype, align, level_max, cursors, ovf_cursor, log_rel, log_v1,
                                                                            log_v2, ovf_key, ovf_v1, ovf_v2, slots, slots_t2, tickets, tickets2, found_inf, ow, acc_dbg,
-                                                                           3.0e38f / odiv, 65504.0f / odiv, nb1);
+                                                                           3.0e38f / odiv, 65504.0f / odiv, nb1, prk, prt1, prt2);
             N2M_CHECK_LAUNCH();
             continue;
         }
         if (both) {
             N2M_LAUNCH((pm_accumulate_kernel<float, 1, kPairP, 2>), nb1, 1024, kPairP * 16, s, 
                 table1, plan1, pl.pm, sp1, lv, gridtype, align, level_max, cursors, ovf_cursor, log_rel, log_v1, ovf_key, ovf_v1, slots, tickets, found_inf, ow, acc_dbg,
-                3.0e38f / odiv);
+                3.0e38f / odiv, prk, prt1);
             N2M_CHECK_LAUNCH();
         }
         if (has2) {
             N2M_LAUNCH((pm_accumulate_kernel<_Float16, 2, kPairP, 1>), nb2, 1024, kPairP * 16, s, 
                 table2, plan2, pl.pm, sp2, lv, gridtype, align, level_max + kMaxLevels, cursors, ovf_cursor, log_rel, log_v2, ovf_key, ovf_v2, slots_t2, tickets2, found_inf, ow,
-                acc_dbg, 65504.0f / odiv);
+                acc_dbg, 65504.0f / odiv, prk, prt2);
             N2M_CHECK_LAUNCH();
         }
     }
@@ -3378,6 +3403,7 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         if (rc != -1) return rc;
         n2m_prof_fall_back_to_markers(s);                      // the tile-major launches below are plain ones
     }
+    N2M_REQUIRE(g_peer_route.world == 0, N2M_EUNSUPPORTED, "%s: a routed flush (n2m_grid_backward_peer_route) needs the partition-major path", fn);
     N2M_REQUIRE(in_level_stride == 0 || B <= kBinChunk, N2M_EINVAL, "%s: per-level point lists need one pass (B <= %u)", fn, kBinChunk);
     for (uint32_t b0 = 0; b0 < B; b0 += kBinChunk) {
         const uint32_t Bc = B - b0 < kBinChunk ? B - b0 : kBinChunk;
@@ -4130,6 +4156,17 @@ extern "C" int n2m_debug_fill_times(int on, unsigned long long* out) {
     if (out) N2M_HIP(hipMemcpyFromSymbol(out + 96, HIP_SYMBOL(g_acc_t), sizeof(unsigned long long) * 20));
     const unsigned int v = (unsigned int)on;        // bit 0: stamps, bit 1: plain log stores (measurement)
     N2M_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fill_timing_on), &v, sizeof(v)));
+    return 0;
+}
+
+extern "C" int n2m_grid_backward_peer_route(const N2mPeerRoute* route) {
+    if (!route) { g_peer_route = N2mPeerRoute{}; return 0; }
+    N2M_REQUIRE(route->world >= 1 && route->world <= N2M_PEER_MAX && route->rows_c > 0 && route->rows_f > 0 && route->split_row == route->world * route->rows_c,
+                N2M_EINVAL, "grid_backward_peer_route: 1..%d ranks, split_row = world * rows_c", N2M_PEER_MAX);
+    for (int h = 0; h < 2; ++h)
+        for (uint32_t r = 0; r < route->world; ++r)
+            N2M_REQUIRE(route->g1[h][r] && route->g2[h][r], N2M_ENULL, "grid_backward_peer_route: NULL staging slot (half %d, owner %u)", h, r);
+    g_peer_route = *route;
     return 0;
 }
 

@@ -172,6 +172,20 @@ class Stage0Engine:
         # reads the density column of the packed table (row stride 2); W ranks -> gradients are SUMMED, so a local fp16 row above max / W
         # raises found_inf already
         self._bwd_cfg = (2 if self.shard else 1, float(world_size))
+        # [opt-in, N2M_PEER_STORE=1] the sharded exchange without a collective in the data path (parallel.PeerExchange, include/n2m_peer.h): the
+        # table backward's flush stores gradient rows into their owner's staging slots, the owner sums the W slots in rank order, Adam's
+        # refreshed packed rows are stored into every rank's packed table; epoch flags instead of reduce-scatter / all-gather.  Tested between
+        # two processes on one GPU, never run over xGMI: off by default.
+        self.peer = None
+        if self.shard and os.environ.get("N2M_PEER_STORE", "0") == "1":
+            if opt.sdf:
+                raise ValueError("N2M_PEER_STORE covers the NeRF recipes (the SDF head's folded backward is not routed)")
+            from .parallel import PeerExchange
+            self.peer = PeerExchange(rank, world_size, self.rows, self._split, self._Cs, self._Fs, dev)
+            pk = model.packed_tables()
+            self.peer.packed.copy_(pk)
+            model._packed = self.peer.packed          # same values, exported memory; _packed_key stays valid
+            self._peer_route = self.peer.route()
         if self.shard:
             self.optimizer.shard_sync = lambda: self.sync_parameters(moments=True)      # state_dict() of a sharded run: gather first
         # ---- single GPU, measured alternative (N2M_FUSE_ADAM=1, off by default): the optimizer pass of the hashed levels (94 % of the rows)
@@ -590,7 +604,13 @@ class Stage0Engine:
         if fused is not None:      # behind both optimizer passes, in front of the scaler update that clears found_inf
             L.call("n2m_adam_fuse_restore", ctypes.addressof(fused), self.ho.ctypes.data, self.Lv, _p(o.found_inf), s)
             self._fuse_swap()
-        if self.shard:
+        if self.peer is not None:      # this rank's refreshed rows into every rank's packed table, coarse chunk first; the next lookup waits per half
+            for h, (row0, n) in self._shard_ranges().items():
+                self.peer.push_rows(h, row0, n)
+            self._gathers = self.peer.rows_tokens()
+            if not self.chunked_gather:
+                self._wait_gather()
+        elif self.shard:
             self._gather_packed()
         gf, bf, gi = o.growth
         if loss_out is None:
@@ -733,7 +753,19 @@ class Stage0Engine:
                                          L.call("n2m_grid_encode_backward_binned_pair_half", *common, *tv_args, *tail, half))
             if self.marker_at == 1:
                 self._marker = torch.cuda.Event(); self._marker.record()
-            if self.shard:
+            if self.peer is not None:
+                # the flush of each level half stores its rows into their owners' slots; the signal behind it is the whole exchange
+                self.peer.begin_step()
+                L.call("n2m_grid_backward_peer_route", ctypes.byref(self._peer_route))
+                try:
+                    backward(1)
+                    self.peer.signal_grad("f")
+                    backward(2)
+                    self.peer.signal_grad("c")
+                finally:
+                    L.call("n2m_grid_backward_peer_route", None)
+                early = []
+            elif self.shard:
                 import torch.distributed as dist
                 sp = self._split
                 rs = lambda out, src: dist.reduce_scatter_tensor(out.view(-1), src.view(-1), op=dist.ReduceOp.SUM, async_op=True)
@@ -766,7 +798,12 @@ class Stage0Engine:
             # no sample in the batch: every gradient is zero (the reduction below still takes part on every rank)
             self.g1.zero_()
             self.g2.zero_()
-            if self.shard:      # same collectives in the same ORDER as on the ranks that have samples (fine halves, coarse halves, then the bucket)
+            if self.peer is not None:     # zeros into this rank's slots -- once every owner's rows of the last step have arrived (see PeerExchange)
+                self._wait_gather()
+                self.peer.begin_step()
+                self.peer.zero_slots()
+                early = []
+            elif self.shard:      # same collectives in the same ORDER as on the ranks that have samples (fine halves, coarse halves, then the bucket)
                 import torch.distributed as dist
                 sp = self._split
                 rs = lambda out, src: dist.reduce_scatter_tensor(out.view(-1), src.view(-1), op=dist.ReduceOp.SUM, async_op=True)
@@ -778,6 +815,9 @@ class Stage0Engine:
             token = self.sync.all_reduce_sum_begin([], [self.dw, o.found_inf])
             for w_ in early:
                 w_.wait()
+            if self.peer is not None:     # owner side: all W slots of a half have landed -> their sum in rank order, where the reduce-scatter would have put it
+                for h in ("f", "c"):
+                    self.peer.reduce(h, self.g1s[h], self.g2s[h])
             self.sync.all_reduce_sum_end(token)
         elif self.sync is not None:
             if early is not None:

@@ -142,3 +142,192 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+# ------------------------------------------------------------------------------------------------ peer-store exchange (include/n2m_peer.h)
+class _DevArray:
+    """A raw device range as something torch.as_tensor() takes without a copy (__cuda_array_interface__, version 2)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class PeerMemory:
+    """One device allocation per rank that every other rank of the node maps (hipIpcGetMemHandle / hipIpcOpenMemHandle through
+    n2m_peer_export / n2m_peer_import).  COLLECTIVE constructor: the handles travel through all_gather_object.  ptrs[r] is rank r's
+    allocation as THIS process addresses it (its own: the local pointer)."""
+
+    def __init__(self, nbytes, fine_grained, rank, world, group=None):
+        import ctypes
+        from . import _lib as L
+        self.rank, self.world, self.nbytes = rank, world, int(nbytes)
+        p = ctypes.c_void_p()
+        L.call("n2m_peer_alloc", self.nbytes, 1 if fine_grained else 0, ctypes.byref(p))
+        self.local = int(p.value)
+        h = ctypes.create_string_buffer(64)
+        L.call("n2m_peer_export", self.local, h)
+        handles = [None] * world
+        dist.all_gather_object(handles, bytes(h.raw), group=group)
+        self.ptrs, self._mapped = [], []
+        for r in range(world):
+            if r == rank:
+                self.ptrs.append(self.local)
+                continue
+            q = ctypes.c_void_p()
+            L.call("n2m_peer_import", ctypes.create_string_buffer(handles[r], 64), ctypes.byref(q))
+            self.ptrs.append(int(q.value))
+            self._mapped.append(int(q.value))
+
+    def tensor(self, dtype, numel, offset_bytes=0, device=None):
+        """The rank's OWN allocation (a range of it) as a torch tensor -- no copy, no ownership: keep this object alive."""
+        nbytes = numel * torch.empty((), dtype=dtype).element_size()
+        assert offset_bytes + nbytes <= self.nbytes
+        t = torch.as_tensor(_DevArray(self.local + offset_bytes, nbytes), device=device or torch.device("cuda", torch.cuda.current_device()))
+        assert t.data_ptr() == self.local + offset_bytes, "torch copied the range instead of aliasing it"
+        return t.view(dtype)
+
+    def close(self):
+        from . import _lib as L
+        for q in self._mapped:
+            L.call("n2m_peer_unmap", q)
+        self._mapped = []
+        if self.local:
+            L.call("n2m_peer_free", self.local)
+            self.local = 0
+
+
+class PeerExchange:
+    """The sharded optimizer's exchange without a collective in the data path (include/n2m_peer.h):
+
+      gradients   the table backward's flush stores every row into the slot its OWNER keeps for this rank (`route()` names the slots to
+                  n2m_grid_backward_peer_route); signal_grad(half) behind each level half; the owner waits for all W signals of a half
+                  and sums its W slots in rank order (reduce(half, g1, g2)) into the slices its Adam pass reads.
+      parameters  after Adam, push_rows(half, packed) stores the rank's refreshed packed rows into every rank's packed table and signals;
+                  wait_rows(half) in front of whatever reads the table next (the lookup of that level half).
+
+    Row layout = engine.Stage0Engine's shards: coarse half [0, split) in W chunks of rows_c, fine half in chunks of rows_f.  Flags are
+    epoch counters (one step = one epoch, begin_step()): a wait is "flag >= epoch", nothing is ever reset.  Why a slot is free when it is
+    written again: a rank writes step e+1's gradients only after its step-e+1 lookup, which waited for every owner's step-e rows, which an
+    owner sends after the Adam pass that follows its step-e reduction.  Why the packed table is quiet while a rank reads it: an owner sends
+    step-e rows after its reduction, which waited for every rank's step-e gradient signals, which follow that rank's last read of the table
+    (its table backward's TV stencil).  A rank without samples stores zeros into its slots (zero_slots) after waiting for the rows.
+    Built and tested between two processes on ONE GPU; not run over xGMI -- opt-in (N2M_PEER_STORE=1)."""
+    GF, GC, RC, RF = 0, 1, 2, 3            # flag kinds: gradients fine / coarse half, rows coarse / fine half
+
+    def __init__(self, rank, world, rows, split, rows_c, rows_f, device, group=None, timeout_ms=None):
+        import os
+        assert split == world * rows_c and rows - split == world * rows_f and world <= 8
+        self.rank, self.world, self.rows, self.split, self.rows_c, self.rows_f, self.device = rank, world, rows, split, rows_c, rows_f, device
+        al = lambda n: (n + 255) & ~255
+        n = {"c": rows_c, "f": rows_f}
+        # staging: per half one fp32 region [W slots][rows of the half] and one fp16-pair region; then the packed table (8 bytes per row)
+        self.off, o = {}, 0
+        for h in ("c", "f"):
+            self.off["s1" + h] = o; o += al(world * n[h] * 4)
+            self.off["s2" + h] = o; o += al(world * n[h] * 4)
+        self.off["pk"] = o; o += al(rows * 8)
+        self.data = PeerMemory(o, False, rank, world, group)
+        self.flags = PeerMemory(4096, True, rank, world, group)          # [4 kinds][W] uint32 epoch counters, then the error word
+        self.epoch = 0
+        self.timeout_ms = int(timeout_ms if timeout_ms is not None else os.environ.get("N2M_PEER_TIMEOUT_MS", "10000"))
+        self._err_off = 4 * world * 4
+        self._n = n
+        self.packed = self.data.tensor(torch.float32, rows * 2, self.off["pk"], device).view(rows, 2)
+        self._flag_t = self.flags.tensor(torch.int32, 4 * world + 1, 0, device)
+        dist.barrier(group=group)
+
+    # ---- gradients
+    def route(self):
+        from . import _lib as L
+        r = L.PeerRoute()
+        r.world, r.split_row, r.rows_c, r.rows_f = self.world, self.split, self.rows_c, self.rows_f
+        for hi, h in enumerate(("c", "f")):
+            for owner in range(self.world):
+                base = self.data.ptrs[owner]
+                r.g1[hi][owner] = base + self.off["s1" + h] + self.rank * self._n[h] * 4
+                r.g2[hi][owner] = base + self.off["s2" + h] + self.rank * self._n[h] * 4
+        return r
+
+    def begin_step(self):
+        self.epoch += 1
+        return self.epoch
+
+    def _signal(self, kind):
+        import ctypes
+        from . import _lib as L
+        p = L.PeerPtrs()
+        p.count = self.world
+        for dst in range(self.world):
+            p.ptr[dst] = self.flags.ptrs[dst] + (kind * self.world + self.rank) * 4
+        L.call("n2m_peer_signal", ctypes.byref(p), self.epoch, L.stream())
+
+    def _wait(self, kind):
+        from . import _lib as L
+        L.call("n2m_peer_wait", self.flags.local + kind * self.world * 4, self.world, 1, self.epoch, self.timeout_ms, self.flags.local + self._err_off,
+               L.stream())
+
+    def signal_grad(self, half):
+        self._signal(self.GF if half == "f" else self.GC)
+
+    def zero_slots(self):
+        """A rank whose batch is empty: zeros into its slot on every owner, both halves, both tables."""
+        import ctypes
+        from . import _lib as L
+        for h in ("f", "c"):
+            for key in ("s1", "s2"):
+                p = L.PeerPtrs()
+                p.count = self.world
+                for owner in range(self.world):
+                    p.ptr[owner] = self.data.ptrs[owner] + self.off[key + h] + self.rank * self._n[h] * 4
+                L.call("n2m_peer_copy", None, ctypes.byref(p), self._n[h] * 4, L.stream())
+            self.signal_grad(h)
+
+    def reduce(self, half, g1, g2):
+        """Owner side: wait for every rank's signal of this half, then g1 / g2 = the W slots summed in rank order."""
+        from . import _lib as L
+        self._wait(self.GF if half == "f" else self.GC)
+        n = self._n[half]
+        L.call("n2m_peer_reduce_slices", self.data.local + self.off["s1" + half], self.data.local + self.off["s2" + half], self.world, n, L.ptr(g1), L.ptr(g2),
+               None, L.stream())
+
+    # ---- parameters
+    def push_rows(self, half, row0, n):
+        """This rank's refreshed packed rows [row0, row0 + n) into every other rank's packed table, then the signal (own flag included)."""
+        import ctypes
+        from . import _lib as L
+        p = L.PeerPtrs()
+        k = 0
+        for dst in range(self.world):
+            if dst != self.rank:
+                p.ptr[k] = self.data.ptrs[dst] + self.off["pk"] + row0 * 8
+                k += 1
+        p.count = k
+        if k:
+            L.call("n2m_peer_copy", self.data.local + self.off["pk"] + row0 * 8, ctypes.byref(p), n * 8, L.stream())
+        self._signal(self.RC if half == "c" else self.RF)
+
+    def wait_rows(self, half):
+        self._wait(self.RC if half == "c" else self.RF)
+
+    class _Token:
+        def __init__(self, ex, half):
+            self.ex, self.half = ex, half
+
+        def wait(self):
+            self.ex.wait_rows(self.half)
+
+    def rows_tokens(self):
+        return {"c": self._Token(self, "c"), "f": self._Token(self, "f")}
+
+    def check(self):
+        """Host read of the error word: raises when a wait ran into its timeout (a peer never signalled)."""
+        torch.cuda.synchronize()
+        e = int(self._flag_t[4 * self.world])
+        if e:
+            raise RuntimeError(f"peer-store exchange: rank {self.rank} timed out waiting for rank {(e - 1)} (epoch {self.epoch})")
+
+    def close(self):
+        torch.cuda.synchronize()
+        self.packed = self._flag_t = None
+        self.flags.close()
+        self.data.close()

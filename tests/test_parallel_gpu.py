@@ -47,6 +47,57 @@ def test_sharded_optimizer_equals_the_all_reduce_path(tmp_path):
     assert max(d_s1, d_s2) <= 2.5 * d_rr + 3e-4
 
 
+def _dist_check(port, steps, extra_env, dump=None, timeout=400):
+    env = dict(os.environ, N2M_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", **extra_env)
+    if dump:
+        env["N2M_DIST_DUMP"] = dump
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "dist_check.py"), str(steps), "engine"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and "DIST_CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    return [l for l in r.stdout.splitlines() if l.startswith("DIST_CHECK")][0]
+
+
+@pytest.mark.gpu
+def test_peer_store_exchange_equals_the_collective_path(tmp_path):
+    """N2M_PEER_STORE=1 (include/n2m_peer.h, parallel.PeerExchange): two PROCESSES on the one GPU map each other's staging buffers
+    (hipIpcGetMemHandle / hipIpcOpenMemHandle), the table backward's flush stores gradient rows into their owner's slots, the owner sums
+    the slots in rank order, Adam's packed rows are stored into both ranks' tables, epoch flags order it all.  24 steps (one occupancy
+    refresh inside): replicas bit-identical (DIST_CHECK OK), no wait timed out, and the parameters are as close to the reduce-scatter /
+    all-gather run as two of those runs are to each other (the peer path sums fp16 slots in fp32 and rounds once; gloo rounds per hop)."""
+    import torch
+    dumps = {}
+    for name, port, env in (("rs1", 29551, {"N2M_SHARD_ADAM": "1"}), ("rs2", 29553, {"N2M_SHARD_ADAM": "1"}),
+                            ("peer", 29555, {"N2M_SHARD_ADAM": "1", "N2M_PEER_STORE": "1"})):
+        path = str(tmp_path / f"{name}.pt")
+        line = _dist_check(port, 24, env, dump=path)
+        assert f"peer_store={name == 'peer'}" in line and "shard=True" in line, line
+        dumps[name] = torch.load(path)
+    dist = lambda a, b: float((dumps[a] - dumps[b]).norm() / dumps[b].norm())
+    d_rr, d_p1, d_p2 = dist("rs1", "rs2"), dist("peer", "rs1"), dist("peer", "rs2")
+    print(f"relative distance: collective run vs run {d_rr:.3e}, peer-store vs collective {d_p1:.3e} / {d_p2:.3e}")
+    assert max(d_p1, d_p2) <= 2.5 * d_rr + 3e-4
+
+
+@pytest.mark.gpu
+def test_peer_store_with_a_rank_without_samples():
+    """The peer-store exchange with rank 1 looking away from the scene: it stores zeros into its slots and signals, takes the other rank's
+    rows, and the replicas stay bit-identical -- no hang, no timeout."""
+    _dist_check(29557, 24, {"N2M_SHARD_ADAM": "1", "N2M_PEER_STORE": "1", "N2M_DIST_BLIND_RANK": "1"})
+
+
+@pytest.mark.gpu
+def test_peer_store_primitives_and_timeout():
+    """n2m_peer_* between two processes on one GPU (tools/peer_check.py): a buffer one process allocates is written by the other through
+    the mapped pointer; signal / wait hand over in both directions; the slot sum is the rank-order sum; a wait for a signal that never
+    comes returns after its timeout and leaves the error word -- the stream, and the GPU, go on."""
+    env = dict(os.environ, N2M_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29559", os.path.join(ROOT, "tools", "peer_check.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "PEER_CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("driver", ["trainer", "engine"])
 def test_stage1_two_ranks_views_sharded(driver):

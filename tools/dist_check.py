@@ -37,6 +37,8 @@ losses = [float(tr.train_step()) for _ in range(steps)]
 if hasattr(tr, "sync_parameters"):
     tr.sync_parameters()              # sharded optimizer: every rank owns 1/W of the table rows until the fp32 tensors are gathered
 torch.cuda.synchronize()
+if getattr(tr, "peer", None) is not None:
+    tr.peer.check()                   # a wait that ran into its timeout would have left its mark
 flat = torch.cat([p.detach().float().reshape(-1) for p in tr.model.parameters()])
 digest = torch.stack([flat.double().sum(), flat.double().abs().sum(), tr.optimizer.scale.double() if hasattr(tr.optimizer, "scale") else torch.zeros((), device=device).double(),
                       tr.optimizer.step_count.double() if hasattr(tr.optimizer, "step_count") else torch.zeros((), device=device).double()]).cpu()
@@ -69,7 +71,7 @@ if os.environ.get("N2M_DIST_CKPT"):
     if world > 1:
         dist.barrier()
 if rank == 0:
-    print(f"DIST_CHECK {'OK' if ok else 'FAILED'} driver={type(tr).__name__} shard={getattr(tr, 'shard', False)} backend={dist.get_backend() if world > 1 else 'none'} world={world} steps={steps} loss {first:.5f} -> {last:.5f} digest={[float(x) for x in digest]}")
+    print(f"DIST_CHECK {'OK' if ok else 'FAILED'} driver={type(tr).__name__} shard={getattr(tr, 'shard', False)} peer_store={getattr(tr, 'peer', None) is not None} backend={dist.get_backend() if world > 1 else 'none'} world={world} steps={steps} loss {first:.5f} -> {last:.5f} digest={[float(x) for x in digest]}")
 if world > 1:
     dist.destroy_process_group()
 sys.exit(0 if ok else 1)
