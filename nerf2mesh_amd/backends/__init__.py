@@ -21,4 +21,10 @@ def install():
     p = path()
     if p not in sys.path:
         sys.path.insert(0, p)
+    # a test harness may have parked empty stand-ins under these names (oracle/ref_python.py does, to import the reference Python without
+    # its third-party packages): they must not shadow the modules of this directory
+    for name in ("mcubes", "nvdiffrast.torch", "nvdiffrast", "torch_scatter", "_raymarching_mob", "_gridencoder", "_shencoder", "_freqencoder"):
+        m = sys.modules.get(name)
+        if m is not None and getattr(m, "__n2m_stub__", False):
+            del sys.modules[name]
     return p
