@@ -557,7 +557,10 @@ def main():
                    "shading": shading, "timed_steps": [first_timed, first_timed + args.steps - 1], "diffuse_step": int(opt.diffuse_step),
                    "refresh_steps_in_window": sum(1 for j in range(first_timed, first_timed + args.steps) if (j - 1) % int(opt.update_extra_interval) == 0),
                    "refresh_share_long_run": 1.0 / int(opt.update_extra_interval),
-                   "parallelism": (f"dp{world} (rays sharded; table gradients reduce-scattered, Adam sharded over the ranks, packed rows all-gathered; "
+                   "parallelism": (f"dp{world} (rays sharded; peer-store exchange, N2M_PEER_STORE=1: gradient rows stored into their owners' slots by the table "
+                                   f"backward, Adam sharded over the ranks, packed rows stored to every rank; no collective in the step)"
+                                   if getattr(tr, "peer", None) is not None else
+                                   f"dp{world} (rays sharded; table gradients reduce-scattered, Adam sharded over the ranks, packed rows all-gathered; "
                                    f"{dist.get_backend()})" if getattr(tr, "shard", False) else
                                    f"dp{world} (rays sharded, grad all-reduce over {dist.get_backend()})") if world > 1 else "single GPU",
                    "mlp": "nn.Linear (unfused)" if args.unfused else "fused MFMA field kernels",

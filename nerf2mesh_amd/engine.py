@@ -181,7 +181,8 @@ class Stage0Engine:
             if opt.sdf:
                 raise ValueError("N2M_PEER_STORE covers the NeRF recipes (the SDF head's folded backward is not routed)")
             from .parallel import PeerExchange
-            self.peer = PeerExchange(rank, world_size, self.rows, self._split, self._Cs, self._Fs, dev)
+            self.peer = PeerExchange(rank, world_size, self.rows, self._split, self._Cs, self._Fs, dev, small_n=self.dw.numel() + 1)
+            self._peer_small = torch.empty(self.dw.numel() + 1, dtype=torch.float32, device=dev)
             pk = model.packed_tables()
             self.peer.packed.copy_(pk)
             model._packed = self.peer.packed          # same values, exported memory; _packed_key stays valid
@@ -811,13 +812,20 @@ class Stage0Engine:
             elif self.sync is not None and self.split_backward and self.Lv == 16:
                 early = self.sync.all_reduce_sum_begin([self.g1[int(self.ho[8]):], self.g2[int(self.ho[8]):]], [])
         # ---- [multi-GPU] one SUM all-reduce per fixed gradient buffer (the colour table's stays fp16) + the small bucket
-        if self.shard:
+        if self.peer is not None:
+            # no collective anywhere in the step: weight gradients + non-finite flag go to every rank's slot and are summed in rank order
+            # everywhere; then, owner side, the W gradient slots of each level half -> their sum where the reduce-scatter would have put it
+            n_dw = self.dw.numel()
+            torch.cat([self.dw, o.found_inf.reshape(-1)], out=self._peer_small)
+            self.peer.all_sum_small(self._peer_small)
+            self.dw.copy_(self._peer_small[:n_dw])
+            o.found_inf.copy_(self._peer_small[n_dw:].view_as(o.found_inf))
+            for h in ("f", "c"):
+                self.peer.reduce(h, self.g1s[h], self.g2s[h])
+        elif self.shard:
             token = self.sync.all_reduce_sum_begin([], [self.dw, o.found_inf])
             for w_ in early:
                 w_.wait()
-            if self.peer is not None:     # owner side: all W slots of a half have landed -> their sum in rank order, where the reduce-scatter would have put it
-                for h in ("f", "c"):
-                    self.peer.reduce(h, self.g1s[h], self.g2s[h])
             self.sync.all_reduce_sum_end(token)
         elif self.sync is not None:
             if early is not None:

@@ -212,9 +212,10 @@ class PeerExchange:
     step-e rows after its reduction, which waited for every rank's step-e gradient signals, which follow that rank's last read of the table
     (its table backward's TV stencil).  A rank without samples stores zeros into its slots (zero_slots) after waiting for the rows.
     Built and tested between two processes on ONE GPU; not run over xGMI -- opt-in (N2M_PEER_STORE=1)."""
-    GF, GC, RC, RF = 0, 1, 2, 3            # flag kinds: gradients fine / coarse half, rows coarse / fine half
+    GF, GC, RC, RF, SM = 0, 1, 2, 3, 4     # flag kinds: gradients fine / coarse half, rows coarse / fine half, the small bucket
+    KINDS = 5
 
-    def __init__(self, rank, world, rows, split, rows_c, rows_f, device, group=None, timeout_ms=None):
+    def __init__(self, rank, world, rows, split, rows_c, rows_f, device, group=None, timeout_ms=None, small_n=0):
         import os
         assert split == world * rows_c and rows - split == world * rows_f and world <= 8
         self.rank, self.world, self.rows, self.split, self.rows_c, self.rows_f, self.device = rank, world, rows, split, rows_c, rows_f, device
@@ -226,14 +227,16 @@ class PeerExchange:
             self.off["s1" + h] = o; o += al(world * n[h] * 4)
             self.off["s2" + h] = o; o += al(world * n[h] * 4)
         self.off["pk"] = o; o += al(rows * 8)
+        self.small_n = int(small_n)            # fp32 words every rank hands to every rank per step (MLP weight gradients + the non-finite flag)
+        self.off["sm"] = o; o += al(world * max(self.small_n, 1) * 4)
         self.data = PeerMemory(o, False, rank, world, group)
-        self.flags = PeerMemory(4096, True, rank, world, group)          # [4 kinds][W] uint32 epoch counters, then the error word
+        self.flags = PeerMemory(4096, True, rank, world, group)          # [KINDS][W] uint32 epoch counters, then the error word
         self.epoch = 0
         self.timeout_ms = int(timeout_ms if timeout_ms is not None else os.environ.get("N2M_PEER_TIMEOUT_MS", "10000"))
-        self._err_off = 4 * world * 4
+        self._err_off = self.KINDS * world * 4
         self._n = n
         self.packed = self.data.tensor(torch.float32, rows * 2, self.off["pk"], device).view(rows, 2)
-        self._flag_t = self.flags.tensor(torch.int32, 4 * world + 1, 0, device)
+        self._flag_t = self.flags.tensor(torch.int32, self.KINDS * world + 1, 0, device)
         dist.barrier(group=group)
 
     # ---- gradients
@@ -290,6 +293,21 @@ class PeerExchange:
         L.call("n2m_peer_reduce_slices", self.data.local + self.off["s1" + half], self.data.local + self.off["s2" + half], self.world, n, L.ptr(g1), L.ptr(g2),
                None, L.stream())
 
+    # ---- the small bucket: every rank's copy to every rank, summed in rank order everywhere (bit-identical results without a collective)
+    def all_sum_small(self, t):
+        """t (contiguous fp32, small_n values) <- sum over ranks of t, in rank order."""
+        import ctypes
+        from . import _lib as L
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == self.small_n
+        p = L.PeerPtrs()
+        p.count = self.world
+        for dst in range(self.world):
+            p.ptr[dst] = self.data.ptrs[dst] + self.off["sm"] + self.rank * self.small_n * 4
+        L.call("n2m_peer_copy", t.data_ptr(), ctypes.byref(p), self.small_n * 4, L.stream())
+        self._signal(self.SM)
+        self._wait(self.SM)
+        L.call("n2m_peer_reduce_slices", self.data.local + self.off["sm"], None, self.world, self.small_n, t.data_ptr(), None, None, L.stream())
+
     # ---- parameters
     def push_rows(self, half, row0, n):
         """This rank's refreshed packed rows [row0, row0 + n) into every other rank's packed table, then the signal (own flag included)."""
@@ -322,7 +340,7 @@ class PeerExchange:
     def check(self):
         """Host read of the error word: raises when a wait ran into its timeout (a peer never signalled)."""
         torch.cuda.synchronize()
-        e = int(self._flag_t[4 * self.world])
+        e = int(self._flag_t[self.KINDS * self.world])
         if e:
             raise RuntimeError(f"peer-store exchange: rank {self.rank} timed out waiting for rank {(e - 1)} (epoch {self.epoch})")
 

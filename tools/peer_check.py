@@ -66,7 +66,7 @@ ok = ok and int(ft[256]) == 1 and 0.25 <= dt < 5.0
 
 # ---- the exchange object end to end on a toy layout: every rank contributes its rank + 1 everywhere
 rows_c, rows_f = 512, 1024
-ex = PeerExchange(rank, world, world * (rows_c + rows_f), world * rows_c, rows_c, rows_f, dev, timeout_ms=3000)
+ex = PeerExchange(rank, world, world * (rows_c + rows_f), world * rows_c, rows_c, rows_f, dev, timeout_ms=3000, small_n=777)
 ex.begin_step()
 ex.zero_slots()
 for h, nrow in (("f", rows_f), ("c", rows_c)):
@@ -74,6 +74,10 @@ for h, nrow in (("f", rows_f), ("c", rows_c)):
     ex.reduce(h, g1, g2)
     torch.cuda.synchronize()
     ok = ok and float(g1.abs().sum()) == 0.0 and float(g2.float().abs().sum()) == 0.0
+small = torch.arange(777, device=dev, dtype=torch.float32) * (rank + 1)          # the small bucket: same sum, same bits, on every rank
+ex.all_sum_small(small)
+torch.cuda.synchronize()
+ok = ok and torch.equal(small.cpu(), torch.arange(777, dtype=torch.float32) * sum(r + 1 for r in range(world)))
 ex.packed.fill_(float(rank + 1))
 torch.cuda.synchronize()
 dist.barrier()
