@@ -45,6 +45,37 @@ def test_rasterize_matches_oracle(dr, oracle, H, W, persp):
     assert (ref[..., 3] > 0).mean() > 0.5
 
 
+def test_rasterize_size_classes_match_oracle(dr, oracle):
+    """The rasteriser's three size classes (raster.hip: a lane walks boxes up to 16 pixels, boxes up to 1024 get 16 lanes, anything larger
+    or touching w <= 0 a workgroup) at their boundaries: right triangles whose bounding boxes hold exactly 15, 16, 17, 18, 1024 and 1056
+    pixel centres, thin 17 x 1 / 1 x 17 / 1 x 1024 slivers, overlapping in depth, one partly off screen -- ids bit-exact against the scalar
+    oracle, (u, v, z/w) to 3e-5."""
+    dr, torch = dr
+    H, W = 160, 192
+    boxes = [(5, 3), (4, 4), (17, 1), (1, 17), (6, 3), (32, 32), (33, 32), (1024 // 8, 8), (2, 8), (16, 1), (1, 16), (40, 30)]
+    rng = np.random.default_rng(7)
+    pos, tri = [], []
+    for i, (bw, bh) in enumerate(boxes * 3):
+        x0, y0 = int(rng.integers(-8, W - 4)), int(rng.integers(-8, H - 4))          # some start off screen (the box is clipped to the image)
+        z = float(rng.uniform(-0.9, 0.9))
+        px = np.array([[x0 + 0.25, y0 + 0.25], [x0 + bw - 0.25, y0 + 0.25], [x0 + 0.25, y0 + bh - 0.25]], np.float64)
+        if i % 2:
+            px = px[[0, 2, 1]]                                                       # both orientations
+        ndc = np.stack([px[:, 0] / W * 2 - 1, px[:, 1] / H * 2 - 1], 1)
+        w = float(rng.uniform(0.8, 2.0)) if i % 3 == 0 else 1.0
+        pos += [[ndc[k, 0] * w, ndc[k, 1] * w, z * w, w] for k in range(3)]
+        tri.append([3 * i, 3 * i + 1, 3 * i + 2])
+    pos, tri = np.asarray(pos, np.float32), np.asarray(tri, np.int32)
+    ctx = dr.RasterizeGLContext(output_db=False)
+    rast, _ = dr.rasterize(ctx, torch.from_numpy(pos).cuda()[None], torch.from_numpy(tri).cuda(), (H, W))
+    ref = oracle.rasterize(pos, tri, H, W)
+    got = rast[0].cpu().numpy()
+    assert np.array_equal(got[..., 3], ref[..., 3]), f"{(got[..., 3] != ref[..., 3]).sum()} pixels with a different triangle id"
+    np.testing.assert_allclose(got[..., :3], ref[..., :3], rtol=0, atol=3e-5)
+    seen = set(np.unique(ref[..., 3]).astype(int)) - {0}
+    assert len(seen) >= 20                                                            # most of the 36 triangles own pixels
+
+
 def test_rasterize_large_mesh_properties(dr):
     """Full-size stage-1 case: ~300k faces at 1600x1600 (ssaa 2). Properties: each box face tessellation is watertight, ids valid,
     re-running gives identical output (deterministic z-buffer), interpolating ones gives the coverage mask."""
