@@ -163,23 +163,31 @@ __device__ __forceinline__ bool depth_at(const Setup& s, int ix, int iy, uint32_
     return zw >= -1.0f && zw <= 1.0f;
 }
 
-// queue[count++] = f for the lanes that `want`, one atomic per wave.  Every lane of the wave must call it.
-__device__ __forceinline__ void wave_append(uint32_t* __restrict__ queue, uint32_t* __restrict__ count, bool want, uint32_t f) {
+// queue[count++] = f for the threads that `want`, ONE atomic per workgroup of 256 (a returning atomic per wave -- 4 761 of them on one address
+// per frame -- cost the small-triangle kernel 10 of its 30 us).  Every thread of the workgroup must call it; `slot` picks the LDS scratch.
+__device__ __forceinline__ void block_append(uint32_t* __restrict__ queue, uint32_t* __restrict__ count, bool want, uint32_t f, uint32_t (&scratch)[5]) {
     const unsigned long long m = __ballot(want);
-    if (m == 0ull) return;
-    const uint32_t lane = __lane_id();
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
-    base = __shfl(base, leader);
-    if (want) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = f;
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    if (lane == 0) scratch[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+        scratch[4] = total ? atomicAdd(count, total) : 0u;
+    }
+    __syncthreads();
+    if (want) {
+        uint32_t at = scratch[4] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) at += scratch[w];
+        queue[at] = f;
+    }
+    __syncthreads();                      // the scratch is reused by the next call
 }
 
 // Three size classes.  A kernel of one lane per triangle lasts as long as its slowest wave, i.e. as the largest box anywhere in the frame: a
 // decimated mesh seen at 1600 x 1600 has a median box of 8 pixels and a 99th percentile of 180, and the one-class kernel of rounds 1-3 spent
 // 78 us on 20 us of work (the wave with the 14 x 14 boxes ran 200 iterations, the median wave 14).  So: a lane walks boxes up to kLaneBox
-// pixels itself (flat loop: nested loops would cost max(width) x max(height) of the wave); boxes up to kSmallBox go to the `mid` queue and
-// are walked by 16 lanes each; anything larger, or touching w <= 0, goes to the `big` queue and gets a whole workgroup.
+// pixels itself (flat loop: nested loops would cost max(width) x max(height) of the wave); boxes up to kSmallBox go to the `mid` queue (one atomic per workgroup)
+// and are walked by 16 lanes each; anything larger, or touching w <= 0, goes to the `big` queue and gets a whole workgroup.
 __global__ void __launch_bounds__(256)
 raster_small_kernel(const float* __restrict__ pos, const int32_t* __restrict__ tri, uint32_t V, uint32_t F, uint32_t H, uint32_t W,
                     unsigned long long* __restrict__ zbuf, uint32_t* __restrict__ mid_queue, uint32_t* __restrict__ mid_count,
@@ -198,8 +206,9 @@ raster_small_kernel(const float* __restrict__ pos, const int32_t* __restrict__ t
             n = (uint32_t)box;
         }
     }
-    wave_append(mid_queue, mid_count, mid, f);
-    wave_append(big_queue, big_count, big, f);
+    __shared__ uint32_t scratch[5];
+    block_append(mid_queue, mid_count, mid, f, scratch);
+    if (__syncthreads_or(big)) block_append(big_queue, big_count, big, f, scratch);
     if (!own) return;
     EdgeOrigin o;
     edge_origin(s, o);
