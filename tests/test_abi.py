@@ -66,6 +66,30 @@ def test_argument_validation_without_gpu(libpath):
         L.call("n2m_grad_total_variation", 1, 1, 1, 1, 1e-3, 8, 3, 2, 16, 0.5, 16, 0, 0, L.F16, None)
     with pytest.raises(RuntimeError, match="odd C"):
         L.call("n2m_grid_encode_backward", 1, 1, 1, 1, 1, 8, 3, 1, 16, 16, 0.5, 16, None, None, 0, 0, 0, L.F16, None)
+    # round 4: the stage-1 executor's strided forms and the peer-store exchange (include/n2m_peer.h)
+    import ctypes
+    with pytest.raises(RuntimeError, match="row stride below the row length"):
+        L.call("n2m_gather_rows_strided", 16, 16, 0, 3, 2, 16, 3, None)
+    with pytest.raises(RuntimeError, match="pixel stride below the attribute count"):
+        L.call("n2m_interpolate_backward_strided", 16, 16, 16, 16, 2, 4, 4, 3, 8, 8, None, 16, None)
+    with pytest.raises(RuntimeError, match="second buffer"):
+        L.call("n2m_antialias_backward_seeded", 16, 16, 16, 16, 16, 8, 32, 4, 4, 4, 8, 8, 1.0, 32, None, None)
+    route = L.PeerRoute()
+    route.world, route.split_row, route.rows_c, route.rows_f = 2, 10, 4, 4            # split_row != world * rows_c
+    with pytest.raises(RuntimeError, match="split_row = world \\* rows_c"):
+        L.call("n2m_grid_backward_peer_route", ctypes.byref(route))
+    route.split_row = 8
+    with pytest.raises(RuntimeError, match="NULL staging slot"):
+        L.call("n2m_grid_backward_peer_route", ctypes.byref(route))
+    L.call("n2m_grid_backward_peer_route", None)                                       # clearing is always fine
+    ptrs = L.PeerPtrs()
+    with pytest.raises(RuntimeError, match="1..8 flags"):
+        L.call("n2m_peer_signal", ctypes.byref(ptrs), 1, None)
+    ptrs.count, ptrs.ptr[0] = 1, 16
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        L.call("n2m_peer_copy", None, ctypes.byref(ptrs), 6, None)
+    with pytest.raises(RuntimeError, match="1..8 ranks"):
+        L.call("n2m_peer_reduce_slices", 16, None, 0, 8, 16, None, None, None)
 
 
 REFERENCE_TABLES = {   # raymarching/src/bindings.cpp:5-20, gridencoder/src/bindings.cpp:5-9, shencoder/src/bindings.cpp:5-8
