@@ -87,6 +87,9 @@ def test_engine_runs_the_outdoor_recipe_like_the_trainer():
     assert abs(lc[0] - lb[0]) > 1e-5 * abs(lb[0])
 
 
+PRE_CHAOS_TOL = 1e-5
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("iters,steps", [(30000, 30), (120, 30), (40, 22)])
 def test_engine_runs_the_sdf_recipe_like_the_trainer(iters, steps):
@@ -127,9 +130,21 @@ def test_engine_runs_the_sdf_recipe_like_the_trainer(iters, steps):
     for (n, p), (_, q), (_, r) in zip(a.model.named_parameters(), b.model.named_parameters(), a2.model.named_parameters()):
         d_te, d_tt = rel(p, q), rel(p, r)
         print(f"{n:36s} trainer-vs-engine {d_te:.3g}   trainer-vs-trainer {d_tt:.3g}")
-        # (+ 2e-3: a single yardstick pair underestimates the spread -- the same comparison has been seen at 0.0012 and at 0.0022 for
-        # sigma_net.net.0.weight against 0.00012 between the two trainer runs)
-        assert d_te <= 10 * d_tt + 2e-3, f"{n}: executor differs from the trainer by {d_te:.3g}, two trainer runs differ by {d_tt:.3g}"
+        # (+ floor: a single yardstick pair underestimates the spread -- at iters = 40 the same comparison has been seen at 0.0012, 0.0022 and
+        # 0.0045 for the sigma network against 1e-5 .. 1e-4 between the two trainer runs: the last steps of that schedule amplify any
+        # rounding-sized difference by orders of magnitude, the pre-chaos check below is the tight one)
+        floor = 2e-2 if iters == 40 else 2e-3
+        assert d_te <= 10 * d_tt + floor, f"{n}: executor differs from the trainer by {d_te:.3g}, two trainer runs differ by {d_tt:.3g}"
+    if iters == 40:
+        # before the recipe turns chaotic (14 steps: 12 levels, epsilon 0.03) trainer and executor must hold the same parameters to fp32 /
+        # fp16 association: no farther apart than a trainer whose parameters started ten fp32 roundings away
+        a14, _ = _run(Stage0Trainer, 14, **cfg)
+        b14, _ = _run(Stage0Engine, 14, **cfg)
+        c14, _ = _run(Stage0Trainer, 14, perturb=1e-6, **cfg)
+        for (n, p), (_, q), (_, r) in zip(a14.model.named_parameters(), b14.model.named_parameters(), c14.model.named_parameters()):
+            print(f"after 14 steps: {n:36s} trainer-vs-engine {rel(p, q):.3g}   trainer-vs-nudged-trainer {rel(p, r):.3g}")
+            # (measured: the executor is 2 to 60 times CLOSER to the trainer than the trainer nudged by 1e-6 is, on every parameter)
+            assert rel(p, q) <= 2 * rel(p, r) + PRE_CHAOS_TOL, n
     # loss scale / step counts: identical while no overflow is borderline; late in the schedule (eps = 1e-4: gradients of order 1 / eps on an
     # fp16 path) one run may skip a step the other takes -- two trainer runs do
     if iters == 30000:
