@@ -342,28 +342,14 @@ __device__ __forceinline__ float wave_scan_max_dpp(float v) {
 struct ChunkRec { unsigned long long mask; uint32_t tbits; uint32_t m; };
 constexpr uint32_t kChunkRecCap = 24;
 
-// WRITE: emit samples (offset / budget from `rays`, or given by the caller when RECORD is set too: the single-pass marcher's fallback).
-// !WRITE: count; with RECORD the non-empty chunks are logged into rec[0..kChunkRecCap) (wave-private LDS) and n_rec counts them all.
+// One ray, one wave: the candidates of the ray from t_start to `far`, at most `budget` samples kept (WRITE: stored at rows out, out + 1, ...).
+// Shared by the training marcher (march_train_one_ray: start = near + jitter, budget = max_steps or the counted samples) and the
+// wave-per-ray inference marcher (march_infer_wave_*: start = the ray's current t, budget = n_step).
 template <bool WRITE, bool RECORD = false>
-__device__ __forceinline__ uint32_t march_train_one_ray(uint32_t n, int lane, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                        const uint8_t* __restrict__ grid,
-                        float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
-                        const float* __restrict__ nears, const float* __restrict__ fars, float* __restrict__ xyzs,
-                        float* __restrict__ dirs, float* __restrict__ ts, int32_t* __restrict__ rays,
-                        const float* __restrict__ noises, uint32_t max_points, bool force_serial,
-                        ChunkRec* rec = nullptr, uint32_t* n_rec_out = nullptr, size_t out_given = 0, uint32_t budget_given = 0) {
-    MarchCtx c;
-    march_ctx_init(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, 0.0f, grid, bound, contract, dt_gamma, max_steps, C, H);
-    uint32_t budget = max_steps;
-    size_t out = 0;
+__device__ __forceinline__ uint32_t march_one_ray_core(const MarchCtx& c, int lane, float far, float t_start, uint32_t budget, size_t out,
+                        float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ ts, bool force_serial,
+                        ChunkRec* rec = nullptr, uint32_t* n_rec_out = nullptr) {
     uint32_t n_rec = 0;
-    if (WRITE) {
-        out = RECORD ? out_given : (size_t)(uint32_t)rays[2 * n];
-        budget = RECORD ? budget_given : (uint32_t)rays[2 * n + 1];
-        if (budget == 0 || out + budget > (size_t)max_points) return 0;     // does not fit the sample buffers (raymarching.cu:417)
-    }
-    const float far = fars[n];
-    const float t_start = nears[n] + n2m_clampf(nears[n] * dt_gamma, c.dt_min, c.dt_max) * noises[n];
     // Resolution of the visited subsequence, two ways.  PARALLEL (first attempt): the serial chain keeps an occupied candidate j
     // unless a VISITED empty candidate i < j jumps over it, i.e. has exit time tt_i > T_j.  If no empty candidate at all -- visited
     // or not -- has tt_i > T_j for any later occupied j (a prefix maximum over the lanes, carried across chunks), the chain never
@@ -499,8 +485,33 @@ restart_ray:
         if (done) break;
         t_base = t_next_base;
     }
-    if (!WRITE && lane == 0) rays[2 * n + 1] = (int32_t)kept;
     if (!WRITE && RECORD) *n_rec_out = n_rec;
+    return kept;
+}
+
+// WRITE: emit samples (offset / budget from `rays`, or given by the caller when RECORD is set too: the single-pass marcher's fallback).
+// !WRITE: count; with RECORD the non-empty chunks are logged into rec[0..kChunkRecCap) (wave-private LDS) and n_rec counts them all.
+template <bool WRITE, bool RECORD = false>
+__device__ __forceinline__ uint32_t march_train_one_ray(uint32_t n, int lane, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                        const uint8_t* __restrict__ grid,
+                        float bound, bool contract, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                        const float* __restrict__ nears, const float* __restrict__ fars, float* __restrict__ xyzs,
+                        float* __restrict__ dirs, float* __restrict__ ts, int32_t* __restrict__ rays,
+                        const float* __restrict__ noises, uint32_t max_points, bool force_serial,
+                        ChunkRec* rec = nullptr, uint32_t* n_rec_out = nullptr, size_t out_given = 0, uint32_t budget_given = 0) {
+    MarchCtx c;
+    march_ctx_init(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, 0.0f, grid, bound, contract, dt_gamma, max_steps, C, H);
+    uint32_t budget = max_steps;
+    size_t out = 0;
+    if (WRITE) {
+        out = RECORD ? out_given : (size_t)(uint32_t)rays[2 * n];
+        budget = RECORD ? budget_given : (uint32_t)rays[2 * n + 1];
+        if (budget == 0 || out + budget > (size_t)max_points) return 0;     // does not fit the sample buffers (raymarching.cu:417)
+    }
+    const float far = fars[n];
+    const float t_start = nears[n] + n2m_clampf(nears[n] * dt_gamma, c.dt_min, c.dt_max) * noises[n];
+    const uint32_t kept = march_one_ray_core<WRITE, RECORD>(c, lane, far, t_start, budget, out, xyzs, dirs, ts, force_serial, rec, n_rec_out);
+    if (!WRITE && lane == 0) rays[2 * n + 1] = (int32_t)kept;
     return kept;
 }
 
@@ -727,6 +738,61 @@ march_infer_dev_kernel(const int32_t* __restrict__ state, uint32_t N, const int3
     // which ends the ray in composite_rays (:877).  The buffers persist here, so the unused slots are cleared by their owner; positions and
     // directions of unused slots keep older (finite, in-range) values -- the field evaluates them, nobody reads the result.
     for (; kept < n_step; ++kept) { *reinterpret_cast<float2*>(pt) = make_float2(0.0f, 0.0f); pt += 2; }
+}
+
+// The same round with ONE WAVE PER ALIVE RAY (march_one_ray_core: 64 candidates at a time, the sample budget = n_step).  One lane per ray
+// walks its ray alone, and a round lasts as long as its longest walk -- a ray that leaves the object and crosses empty space to `far` makes
+// ~200 dependent occupancy loads -- whatever the number of rays still alive: 265 us per round, 28 rounds per 800 x 800 frame, measured.  A
+// wave resolves 64 candidates per memory round trip, so a round of few rays is short; a round of MANY rays (the first ones: every pixel
+// of the frame) is throughput-bound and stays with the lane-per-ray kernel (host-side switch in n2m_march_rays / n2m_march_rays_dev).
+// Same samples, bit for bit: the wave marcher is the training marcher, which tests/ hold to the serial chain.
+__device__ __forceinline__ void march_infer_wave_ray(uint32_t n, uint32_t n_step, int lane, const int32_t* __restrict__ rays_alive,
+                                                     const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                                                     const float* __restrict__ rays_d, float bound, bool contract, float dt_gamma,
+                                                     uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                                                     const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                     float* __restrict__ ts, const float* __restrict__ noises) {
+    const int32_t ray = rays_alive[n];
+    MarchCtx c;
+    march_ctx_init(c, rays_o + 3 * (size_t)ray, rays_d + 3 * (size_t)ray, 1e-10f, grid, bound, contract, dt_gamma, max_steps, C, H);
+    const float far = fars[ray];
+    float t = rays_t[ray];
+    t += n2m_clampf(t * dt_gamma, c.dt_min, c.dt_max) * (noises ? noises[n] : 0.0f);
+    const size_t out = (size_t)n * n_step;
+    const uint32_t kept = march_one_ray_core<true, false>(c, lane, far, t, n_step, out, xyzs, dirs, ts, false);
+    // unused slots: ts == 0 ends the ray in composite_rays (see march_infer_dev_kernel)
+    if ((uint32_t)lane < n_step - kept) *reinterpret_cast<float2*>(ts + 2 * (out + kept + (uint32_t)lane)) = make_float2(0.0f, 0.0f);
+}
+
+__global__ void __launch_bounds__(256)
+march_infer_wave_kernel(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive, const float* __restrict__ rays_t,
+                        const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound, bool contract,
+                        float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                        const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs,
+                        float* __restrict__ ts, const float* __restrict__ noises) {
+    const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (n >= n_alive) return;
+    march_infer_wave_ray(n, n_step, (int)(threadIdx.x & 63u), rays_alive, rays_t, rays_o, rays_d, bound, contract, dt_gamma, max_steps, C, H, grid, fars,
+                         xyzs, dirs, ts, noises);
+}
+
+__global__ void __launch_bounds__(256)
+march_infer_wave_dev_kernel(const int32_t* __restrict__ state, uint32_t N, const int32_t* __restrict__ rays_alive, const float* __restrict__ rays_t,
+                            const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound, bool contract,
+                            float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                            const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs,
+                            float* __restrict__ ts, const float* __restrict__ noises) {
+    const InferRound rd = infer_round(state, N, max_steps);
+    const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (!rd.active || n >= rd.n_alive) return;
+    march_infer_wave_ray(n, rd.n_step, (int)(threadIdx.x & 63u), rays_alive, rays_t, rays_o, rays_d, bound, contract, dt_gamma, max_steps, C, H, grid,
+                         fars, xyzs, dirs, ts, noises);
+}
+
+// rays alive at or below which a round marches one wave per ray (N2M_INFER_WAVE: 0 = never, 1 = always, else the threshold itself)
+static uint32_t infer_wave_threshold() {
+    static const long v = getenv("N2M_INFER_WAVE") ? atol(getenv("N2M_INFER_WAVE")) : 131072;
+    return v == 0 ? 0u : (v == 1 ? 0xFFFFFFFFu : (uint32_t)v);
 }
 
 // -------------------------------------------------------------------------------------- exclusive scans
@@ -1682,10 +1748,15 @@ extern "C" int n2m_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* 
     N2M_NOTNULL(rays_alive); N2M_NOTNULL(rays_t); N2M_NOTNULL(rays_o); N2M_NOTNULL(rays_d); N2M_NOTNULL(grid);
     N2M_NOTNULL(fars); N2M_NOTNULL(xyzs); N2M_NOTNULL(dirs); N2M_NOTNULL(ts); N2M_NOTNULL(noises);
     N2M_REQUIRE(C >= 1 && H >= 1 && H <= 1024 && max_steps >= 1, N2M_EINVAL, "march_rays: bad C/H/max_steps");
-    march_infer_kernel<<<n2m_ceil_div(n_alive, 64), 64, 0, (hipStream_t)stream>>>(n_alive, n_step, rays_alive, rays_t, rays_o,
-                                                                                 rays_d, bound, contract != 0, dt_gamma,
-                                                                                 max_steps, C, H, grid, fars, xyzs, dirs, ts,
-                                                                                 noises);
+    if (n_alive <= infer_wave_threshold() && n_step <= 64u)
+        march_infer_wave_kernel<<<n2m_ceil_div(n_alive, 4), 256, 0, (hipStream_t)stream>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
+                                                                                          contract != 0, dt_gamma, max_steps, C, H, grid, fars, xyzs,
+                                                                                          dirs, ts, noises);
+    else
+        march_infer_kernel<<<n2m_ceil_div(n_alive, 64), 64, 0, (hipStream_t)stream>>>(n_alive, n_step, rays_alive, rays_t, rays_o,
+                                                                                     rays_d, bound, contract != 0, dt_gamma,
+                                                                                     max_steps, C, H, grid, fars, xyzs, dirs, ts,
+                                                                                     noises);
     N2M_CHECK_LAUNCH();
     return 0;
 }
@@ -1723,9 +1794,15 @@ extern "C" int n2m_march_rays_dev(const int32_t* state, uint32_t n_alive_ub, uin
     N2M_NOTNULL(state); N2M_NOTNULL(rays_alive); N2M_NOTNULL(rays_t); N2M_NOTNULL(rays_o); N2M_NOTNULL(rays_d); N2M_NOTNULL(grid);
     N2M_NOTNULL(fars); N2M_NOTNULL(xyzs); N2M_NOTNULL(dirs); N2M_NOTNULL(ts);
     N2M_REQUIRE(C >= 1 && H >= 1 && H <= 1024 && max_steps >= 1 && N >= n_alive_ub, N2M_EINVAL, "march_rays_dev: bad C/H/max_steps/N");
-    march_infer_dev_kernel<<<n2m_ceil_div(n_alive_ub, 64), 64, 0, (hipStream_t)stream>>>(state, N, rays_alive, rays_t, rays_o, rays_d, bound,
-                                                                                        contract != 0, dt_gamma, max_steps, C, H, grid, fars,
-                                                                                        xyzs, dirs, ts, noises);
+    // (the device-side n_step is at most 8: the clear of unused slots by lanes 0 .. n_step - 1 always fits a wave)
+    if (n_alive_ub <= infer_wave_threshold())
+        march_infer_wave_dev_kernel<<<n2m_ceil_div(n_alive_ub, 4), 256, 0, (hipStream_t)stream>>>(state, N, rays_alive, rays_t, rays_o, rays_d, bound,
+                                                                                                 contract != 0, dt_gamma, max_steps, C, H, grid, fars,
+                                                                                                 xyzs, dirs, ts, noises);
+    else
+        march_infer_dev_kernel<<<n2m_ceil_div(n_alive_ub, 64), 64, 0, (hipStream_t)stream>>>(state, N, rays_alive, rays_t, rays_o, rays_d, bound,
+                                                                                            contract != 0, dt_gamma, max_steps, C, H, grid, fars,
+                                                                                            xyzs, dirs, ts, noises);
     N2M_CHECK_LAUNCH();
     return 0;
 }

@@ -410,6 +410,34 @@ def test_inference_loop(be, oracle, scene):
     assert total > 5000
 
 
+def test_inference_march_lane_and_wave_forms(be, oracle, scene):
+    """n2m_march_rays picks its kernel by the number of rays alive (raymarching.hip: one lane per ray for a whole frame, one wave per ray at
+    or below 131 072): both against the oracle, bit for bit -- a first round of 140 000 rays (lane form), then the survivors' second round
+    with n_step = 2 (wave form, starting mid-ray from the t the first round's samples ended at)."""
+    torch, rm = be["torch"], be["rm"]
+    N = 140000
+    o, d = make_rays(scene, N, seed=21)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.05)
+    O, D, B, NE, FA = dev(be, o), dev(be, d), dev(be, scene["bits"]), dev(be, nears), dev(be, fars)
+    alive = np.arange(N, dtype=np.int32)
+    rays_t = nears.copy()
+    for n_step in (1, 2):
+        n_alive = alive.shape[0]
+        M = n_alive * n_step
+        noises = np.zeros(n_alive, np.float32)
+        xyzs = torch.zeros(M, 3, device="cuda"); dirs = torch.zeros(M, 3, device="cuda"); ts = torch.zeros(M, 2, device="cuda")
+        rm.march_rays(n_alive, n_step, dev(be, alive), dev(be, rays_t), O, D, 1.0, False, 0.0, 1024, 1, 128, B, NE, FA, xyzs, dirs, ts, dev(be, noises))
+        ox, od, ot = oracle.march_rays(n_alive, n_step, alive, rays_t, o, d, 1.0, False, scene["bits"], 1, 128, nears, fars, noises)
+        assert bits_equal(xyzs.cpu().numpy(), ox) and bits_equal(dirs.cpu().numpy(), od) and bits_equal(ts.cpu().numpy(), ot)
+        # next round: the rays that found a sample go on from where it ended (what composite_rays would leave in rays_t for a transparent sample)
+        hit = ot.reshape(n_alive, n_step, 2)[:, -1, 0] > 0
+        rays_t = rays_t.copy()
+        rays_t[alive[hit]] = ot.reshape(n_alive, n_step, 2)[hit, -1, 0]
+        alive = alive[hit]
+        assert 1000 < alive.shape[0] <= 131072 or n_step == 2
+
+
 def test_compact_alive_large(be, oracle):
     torch = be["torch"]
     from nerf2mesh_amd import raymarching
