@@ -158,7 +158,14 @@ def test_fixture_is_what_the_reference_python_produces_today():
     live, fx = RC.compress_for_fixture(out), fixture("nerf")
     assert set(live) == set(fx)
     for k in fx:
-        assert np.array_equal(live[k], fx[k]), k
+        if np.array_equal(live[k], fx[k]):
+            continue
+        # Everything behind an MLP (image, depth, weights, the density grid) goes through torch's CPU GEMMs, whose summation order depends on
+        # the host (core count, BLAS kernel choice): seen 1 ulp apart on another box of the pool.  Integers, and anything more than a few
+        # ulp away, still fail.
+        a, b = np.asarray(live[k]), np.asarray(fx[k])
+        assert a.shape == b.shape and a.dtype.kind == "f" and b.dtype.kind == "f", k
+        np.testing.assert_allclose(a, b, rtol=3e-6, atol=1e-7, err_msg=k)
 
 
 # ------------------------------------------------------------------------------------------------------------------ GPU
