@@ -640,6 +640,11 @@ int n2m_prof_read(int kernel_id, uint64_t* launches, double* total_ms, double* a
 int n2m_prof_seen(int kernel_id, uint64_t* launches_seen);
 const char* n2m_prof_name(int kernel_id);
 
+/* Device-to-device copy of `bytes` (multiple of 16, 16-byte aligned) as a grid-stride kernel of 16 bytes per lane (nontemporal load and
+ * store); workgroups = 0 picks 8 per CU.  bench.py times it as `peak_measured`: the streaming ceiling HBM-bound kernels are priced against
+ * next to the nominal 8 TB/s (MI355X_MICROARCH.md: 6.29 TB/s for this form). */
+int n2m_stream_copy(const void* src, void* dst, uint64_t bytes, uint32_t workgroups, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

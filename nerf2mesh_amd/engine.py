@@ -971,8 +971,10 @@ class Stage0Engine:
                         break
                 K = int(sb["fold_host"][:ml].max())
                 self.last_fold_left = int(sb["fold_host"][:ml].sum())
+                if K > (1 << 20):      # a level's list of unfolded copies exceeds the one-pass limit of the lists call: this step keeps the stacked pass
+                    fold = False
+            if fold:
                 L.call("n2m_grid_encode_backward_binned_pair_fold", *batch_args, _p(fb["flags"]), _p(sb["d_h6"]), eps, float(model.bound), s)
-                assert K <= (1 << 20), "a level's list of unfolded copies exceeds the one-pass limit of the lists call"     # (K <= 6 M / ... : M <= 2^20 keeps ~10 % of 6 M below it)
                 if K > 0:
                     L.call("n2m_sdf_fold_gather", _p(sb["d_h6"]), M, ml, _p(fb["src"]), _p(fb["pts"]), fb["cap"],
                            sb["fold_cnt"].data_ptr() + 128 * par, K, _p(fb["g"]), s)

