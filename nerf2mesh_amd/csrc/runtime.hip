@@ -22,10 +22,11 @@ extern "C" const char* n2m_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------------ stream copy (measurement support)
 // The practical HBM streaming ceiling of this device, as bench.py's second denominator: a grid-stride copy of 16 bytes per lane (the form
 // MI355X_MICROARCH.md measures 6.29 TB/s with), read + write counted by the caller.  Nontemporal on both sides: nothing is re-read.
-__global__ void __launch_bounds__(256) stream_copy_f4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+typedef float n2m_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) stream_copy_f4_kernel(const n2m_f4* __restrict__ src, n2m_f4* __restrict__ dst, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float4 v = __builtin_nontemporal_load(src + i);
+        const n2m_f4 v = __builtin_nontemporal_load(src + i);
         __builtin_nontemporal_store(v, dst + i);
     }
 }
@@ -37,7 +38,7 @@ extern "C" int n2m_stream_copy(const void* src, void* dst, uint64_t bytes, uint3
     const size_t n = (size_t)(bytes / 16u);
     size_t wg = workgroups ? workgroups : 256u * 8u;                   // 8 workgroups of 256 threads per CU
     if (wg > (n + 255u) / 256u) wg = (n + 255u) / 256u;
-    hipLaunchKernelGGL(stream_copy_f4_kernel, dim3((unsigned)wg), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n);
+    hipLaunchKernelGGL(stream_copy_f4_kernel, dim3((unsigned)wg), dim3(256), 0, (hipStream_t)stream, (const n2m_f4*)src, (n2m_f4*)dst, n);
     N2M_CHECK_LAUNCH();
     return 0;
 }
