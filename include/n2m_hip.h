@@ -535,6 +535,21 @@ int n2m_composite_loss_train_ex(const float* sigmas, const float* rgbs, const fl
                                 const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas, float* grad_rgbs, float* partial,
                                 uint32_t* ticket, float* loss, float* loss_sum, float lambda_entropy, int alpha_mode, void* stream);
 
+/* Live-first sample order for the table backward (no reference counterpart; raymarching.cu:553,640: composite_rays_train stops a ray at
+ * T < T_thresh, every later sample of the ray gets weight 0 and gradient 0 -- about half of the samples of a trained batch).
+ * n2m_composite_live_counts: optional outputs of the NEXT n2m_composite_loss_train* calls of this thread (sticky; clear with NULL, NULL):
+ *   live [N] <- per ray the number of samples up to and including the one the early stop fell on, block_live [ceil(N/16)] <- their sums per 16 rays.
+ * n2m_sample_order_live_first: perm [M] <- sample indices with every ray's live prefix first (ray order), then every ray's remaining samples.
+ * n2m_grid_backward_sample_order (include below, gridencoder): the binned pair backward then visits the samples in that order. */
+int n2m_composite_live_counts(int32_t* live, uint32_t* block_live);
+int n2m_sample_order_live_first(const int32_t* rays, const int32_t* live, const uint32_t* block_live, uint32_t N, uint32_t M,
+                                uint32_t* perm, void* stream);
+/* Sticky, per thread; NULL clears it.  perm [B]: the i-th sample the next n2m_grid_encode_backward_binned_pair[_half|_tvt] calls visit.  The
+ * result is the same sum (fixed point) whatever the order; only the fp32 rounding of the same-cell run merge on the coarse levels follows it.
+ * Waves whose 64 samples all have zero feature gradients on a level take a TV-only path (one log entry per sample instead of eight).
+ * Needs the partition-major path, one pass (B <= 2^20), no folded copies, no per-level point lists. */
+int n2m_grid_backward_sample_order(const uint32_t* perm);
+
 /* Adam + GradScaler for the whole parameter set in two launches (torch.optim.Adam(fused=True) + torch.amp.GradScaler of
  * main.py:221 / nerf/utils.py:506,1187-1190).  All tensors fp32 and 16-byte aligned, except grad which may be fp16
  * (grad_is_half) and half_shadow (fp16 copy of the updated parameter, or NULL).  Gradients are still multiplied by *scale

@@ -2173,7 +2173,9 @@ struct PmPlan {
 // Lean form of pair_entries for pm_fill_pair_kernel (the fill's SIMDs issue VALU work more than half of the time: ~815 instructions per
 // (sample, level) before this): the colour products leave as PACKED halves (no f32 round trip on the levels that do not merge runs),
 // smoothstep only when asked for (a uniform branch instead of a select over both forms), the partition key in two instructions.
-template <int TV, int IMODE, bool ILV>
+// DEAD: every sample of the wave has a zero feature gradient on this level (wave-uniform, decided by the caller): the only entry such a sample
+// can deliver is its TV term on vertex 000 -- cell, the rows the stencil reads and that one partition key are all that is computed.
+template <int TV, int IMODE, bool ILV, bool DEAD = false>
 __device__ __forceinline__ void pm_entries(const PairCtx& cx, const Indexer<3>& ix, const PartMap& pm, const float (&x)[3], float g1,
                                            float g2x, float g2y, float a1, float& vmax1, uint32_t (&e_pr)[8], float (&f1)[8],
                                            uint32_t (&p2)[8], uint32_t (&cell)[3], float tv_given, float& tv_out) {
@@ -2186,7 +2188,7 @@ __device__ __forceinline__ void pm_entries(const PairCtx& cx, const Indexer<3>& 
         cell[d] = (uint32_t)floorf(p);
         frac[d] = p - (float)cell[d];
     }
-    if (cx.interp == 1) {
+    if (!DEAD && cx.interp == 1) {
         asm volatile("" ::: "memory");                                   // (keeps this a branch: linear interpolation is what nerf2mesh runs)
 #pragma unroll
         for (uint32_t d = 0; d < D; ++d) frac[d] = frac[d] * frac[d] * (3.0f - 2.0f * frac[d]);
@@ -2216,18 +2218,23 @@ __device__ __forceinline__ void pm_entries(const PairCtx& cx, const Indexer<3>& 
     tv_out = tvv;
     const float wx[2] = {1 - frac[0], frac[0]}, wy[2] = {1 - frac[1], frac[1]}, wz[2] = {1 - frac[2], frac[2]};
 #pragma unroll
-    for (uint32_t corner = 0; corner < 8; ++corner) {
+    for (uint32_t corner = 0; corner < (DEAD ? 1u : 8u); ++corner) {
         const uint32_t i = corner & 1u, j = (corner >> 1) & 1u, k = corner >> 2;
-        const float w = (wx[i] * wy[j]) * wz[k];                     // forward's association
-        float p1 = w * g1;
-        if (TV != 0 && corner == 0) p1 += tvv;
-        f1[corner] = p1;
-        float pa = w * g2x, pb = w * g2y;                            // rounded to fp32, THEN to half (gridencoder.cu:326; see half_product)
-        asm volatile("" : "+v"(pa), "+v"(pb));
-        h2 hp;
-        hp.x = (_Float16)pa;
-        hp.y = (_Float16)pb;
-        p2[corner] = __builtin_bit_cast(uint32_t, hp);
+        if constexpr (DEAD) {
+            f1[0] = tvv;                                             // (w * g1 is +-0 here: the live path's sum is the TV term, or a zero that is dropped)
+            p2[0] = 0u;
+        } else {
+            const float w = (wx[i] * wy[j]) * wz[k];                     // forward's association
+            float p1 = w * g1;
+            if (TV != 0 && corner == 0) p1 += tvv;
+            f1[corner] = p1;
+            float pa = w * g2x, pb = w * g2y;                            // rounded to fp32, THEN to half (gridencoder.cu:326; see half_product)
+            asm volatile("" : "+v"(pa), "+v"(pb));
+            h2 hp;
+            hp.x = (_Float16)pa;
+            hp.y = (_Float16)pb;
+            p2[corner] = __builtin_bit_cast(uint32_t, hp);
+        }
         const uint32_t row = rows[corner];
         if constexpr (IMODE == 0) {
             uint32_t part_, rel_;
@@ -2242,6 +2249,28 @@ __device__ __forceinline__ void pm_entries(const PairCtx& cx, const Indexer<3>& 
             e_pr[corner] = row + (row >> pm.log2p) * (65536u - (1u << pm.log2p));
         }
     }
+}
+
+// merge_runs for a wave whose samples deliver at most their TV term: one value per lane instead of twenty-four.
+__device__ __forceinline__ bool merge_runs_tv(bool inside, const uint32_t (&cell)[3], float& f, uint32_t lane) {
+    const uint32_t key0 = inside ? cell[0] : 0xFFFFFFFFu;
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)key0, 0x111, 0xF, 0xF, false);
+    const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)cell[1], 0x111, 0xF, 0xF, false);
+    const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)cell[2], 0x111, 0xF, 0xF, false);
+    const bool same = inside && (lane & 15u) != 0u && p0 == key0 && p1 == cell[1] && p2 == cell[2];
+    const unsigned long long heads = __ballot(!same);
+    const unsigned long long upto = heads & (~0ull >> (63u - lane));
+    const uint32_t dist = lane - (63u - (uint32_t)__builtin_clzll(upto));
+    const bool last = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
+    if (__builtin_popcountll(heads) == 64) return true;
+#pragma unroll
+    for (int d = 1; d <= 8; d <<= 1) {
+        const bool take = dist >= (uint32_t)d;
+        if (__ballot(take) == 0ull) break;
+        const float a = dpp_row_shr(f, d);
+        if (take) f += a;
+    }
+    return last;
 }
 
 // TS = samples per tile = threads per workgroup.  LDS (dynamic): three u32 staging arrays of 8 TS entries, then
@@ -2261,7 +2290,8 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
                     uint32_t* __restrict__ log_v2, uint32_t* __restrict__ ovf_key, uint32_t* __restrict__ ovf_v1, uint32_t* __restrict__ ovf_v2,
                     float* __restrict__ found_inf, float in_scale, float in_offset, float* __restrict__ clear1, _Float16* __restrict__ clear2,
                     uint32_t clear_mask1, uint32_t clear_mask2, uint32_t merge_levels, uint32_t groups_x, uint32_t slot_begin,
-                    unsigned long long* __restrict__ lm_ready, unsigned long long lm_token, uint32_t in_level_stride, FoldArgs fold) {
+                    unsigned long long* __restrict__ lm_ready, unsigned long long lm_token, uint32_t in_level_stride, FoldArgs fold,
+                    const uint32_t* __restrict__ perm /*[B] or NULL: the order the samples are visited in (n2m_grid_backward_sample_order)*/) {
     constexpr uint32_t D = 3, kWaves = TS / 64u, kEntries = TS * 8u;
     constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -2326,11 +2356,19 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
     // the next tile's inputs, RAW: the affine input map is applied when they are consumed, a tile later.  (Until round 4 the map sat here,
     // right behind the loads -- the compiler put s_waitcnt vmcnt(0) between them and the "prefetch" was a full DRAM round trip at the top of
     // every tile, draining the previous tile's log stores with it.)
-    bool nvalid = false;
-    auto request = [&](uint32_t t) {
-        const uint32_t s = t * TS + tid;
-        nvalid = t < plan.tiles && s < B;
+    bool nvalid = false, pvalid = false;
+    uint32_t pidx = 0u;
+    // which sample this thread visits in tile t: loaded TWO tiles ahead when the caller hands an order (the inputs of tile t+1 are requested
+    // at the top of tile t and need the index then -- a load issued only there would be a dependent round trip in front of every request)
+    auto fetch_index = [&](uint32_t t) {
+        const uint32_t s0 = t * TS + tid;
+        pvalid = t < plan.tiles && s0 < B;
+        pidx = pvalid ? (perm ? perm[s0] : s0) : 0u;
+    };
+    auto request = [&]() {
+        nvalid = pvalid;
         if (nvalid) {
+            const uint32_t s = pidx;
             load_point<D>(inputs + (size_t)level * in_level_stride, s, nx);
             ng1 = grad1 ? grad1[(size_t)level * Bstride + s] : 0.0f;
             if (grad2) ng2 = *reinterpret_cast<const h2*>(grad2 + ((size_t)level * Bstride + s) * 2);
@@ -2338,7 +2376,9 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
             if (TV == 2) ntv = tv_terms[(size_t)level * Bstride + s];
         }
     };
-    request(tile);
+    fetch_index(tile);
+    request();
+    fetch_index(tile + n_groups);
     __syncthreads();
 
     for (uint32_t it = 0; tile < plan.tiles; tile += n_groups, ++it) {
@@ -2350,7 +2390,8 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
         const float g1 = ng1, tvg = ntv;
         const h2 g2 = ng2;
 #if !N2M_PM_PREFETCH_LATE
-        request(tile + n_groups);
+        request();                                       // tile + n_groups
+        fetch_index(tile + 2u * n_groups);
 #endif
 
         uint32_t e_pr[8], e_v1[8], e_v2[8], e_slot[8];
@@ -2370,11 +2411,26 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
             if ((!(a1 <= 3.0e38f) || bad2) && found_inf) *found_inf = 1.0f;
             if (bad2) vmax2 = fmaxf(vmax2, 1.0f);
             gnz = (g1 != 0.0f) | ((__builtin_bit_cast(uint32_t, g2) & 0x7FFF7FFFu) != 0u);
+        }
+        // A wave none of whose samples carries a gradient on this level (the dead tails of the rays, visited together when the caller
+        // hands the live-first order: n2m_grid_backward_sample_order) delivers TV terms only: one entry per sample instead of eight, one
+        // value through the run merge instead of twenty-four.  Wave-uniform; the folded-copies form keeps the full path.
+        const bool wave_live = FOLD || (dbg & 128u) || __ballot(inside && gnz) != 0ull;       // (dbg 128: measurement switch, the full path for every wave)
+        if (inside) {
+            const float g2x = (float)g2.x, g2y = (float)g2.y;
+            const float a1 = fabsf(g1);
             float tvv = 0.0f;
-            if (fast_hash) pm_entries<TV, 1, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
-            else if (fast_dense && parts > 1u) pm_entries<TV, 2, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
-            else if (fast_dense) pm_entries<TV, 2, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
-            else pm_entries<TV, 0, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+            if (wave_live) {
+                if (fast_hash) pm_entries<TV, 1, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+                else if (fast_dense && parts > 1u) pm_entries<TV, 2, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+                else if (fast_dense) pm_entries<TV, 2, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+                else pm_entries<TV, 0, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+            } else if (TV != 0) {
+                if (fast_hash) pm_entries<TV, 1, false, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+                else if (fast_dense && parts > 1u) pm_entries<TV, 2, true, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+                else if (fast_dense) pm_entries<TV, 2, false, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+                else pm_entries<TV, 0, false, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+            }
             tvnz = tvv != 0.0f;
             if constexpr (FOLD) {
                 const uint32_t sidx = tile * TS + tid;
@@ -2383,8 +2439,22 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
             }
         }
 #if N2M_PM_PREFETCH_LATE
-        request(tile + n_groups);                        // behind the stencil gathers: the vector memory counter is in order, a wait for a gather also waits for every older load
+        request();                                       // behind the stencil gathers: the vector memory counter is in order, a wait for a gather also waits for every older load
+        fetch_index(tile + 2u * n_groups);
 #endif
+        if (level < merge_levels && !(dbg & 64u) && !wave_live) {
+            // a wave of TV-only samples: one value per lane through the run merge
+            const bool keep = merge_runs_tv(inside, cell, f1[0], lane) && inside;
+            if (keep) {
+                const float m1 = fabsf(f1[0]);
+                vmax1 = fmaxf(vmax1, m1 <= 3.0e38f ? m1 : 1.0f);
+                if (!(m1 <= 3.0e38f) && found_inf) *found_inf = 1.0f;
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c) e_v1[c] = 0u;
+            e_v1[0] = __float_as_uint(f1[0]);
+            if (keep && (e_v1[0] << 1) != 0u) vmask = 1u;
+        } else
         if (level < merge_levels && !(dbg & 64u)) {      // block-uniform: same-cell runs of consecutive samples become one entry per vertex
             float f2x[8], f2y[8];
 #pragma unroll
@@ -2422,6 +2492,7 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
             const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
             for (uint32_t c = 0; c < 8; ++c) {
+                if (c != 0u && !wave_live) break;                        // (a TV-only wave holds entries on vertex 000 only)
                 const bool v = (vmask >> c) & 1u;
                 const unsigned long long m = __ballot(v);
                 uint32_t base = 0;
@@ -2431,8 +2502,10 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
             }
         } else {
 #pragma unroll
-            for (uint32_t c = 0; c < 8; ++c)
+            for (uint32_t c = 0; c < 8; ++c) {
+                if (c != 0u && !wave_live) break;
                 if ((vmask >> c) & 1u) e_slot[c] = atomicAdd(&cnt[e_pr[c] >> 16], 1u);
+            }
         }
         __syncthreads();                                                     // (1) counters complete
 
@@ -2465,15 +2538,20 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
         if (!(dbg & 8u)) {
             uint32_t pos[8];
 #pragma unroll
-            for (uint32_t c = 0; c < 8; ++c) pos[c] = start[e_pr[c] >> 16];          // (all eight lookups in flight; a dropped entry reads partition 0's)
+            for (uint32_t c = 0; c < 8; ++c) {
+                if (c != 0u && !wave_live) break;
+                pos[c] = start[e_pr[c] >> 16];          // (all eight lookups in flight; a dropped entry reads partition 0's)
+            }
 #pragma unroll
-            for (uint32_t c = 0; c < 8; ++c)
+            for (uint32_t c = 0; c < 8; ++c) {
+                if (c != 0u && !wave_live) break;
                 if ((vmask >> c) & 1u) {
                     const uint32_t at = pos[c] + e_slot[c];
                     stage_v1[at] = e_v1[c];
                     stage_v2[at] = e_v2[c];
                     stage_e[at] = e_pr[c];
                 }
+            }
         }
         for (uint32_t i = tid; i < parts; i += TS) cnt_next[i] = 0;
         if (tid == 0u) tile_ovf[(it & 1u) ^ 1u] = 0u;
@@ -3178,13 +3256,23 @@ extern "C" int n2m_grid_backward_mid_event(void* event) {
     return 0;
 }
 
+// The order in which the table backward of this thread visits its samples (sticky until cleared with NULL): perm[i] = index of the i-th
+// sample to visit.  Results do not depend on it beyond fp32 rounding of the run merge (the sums are fixed point); with the LIVE-FIRST
+// order of n2m_sample_order_live_first the samples without a gradient -- the tails of the rays behind the early stop, about half of a
+// trained batch -- fill whole waves, which take the fill's TV-only path.
+static thread_local const uint32_t* g_sample_order = nullptr;
+extern "C" int n2m_grid_backward_sample_order(const uint32_t* perm) {
+    g_sample_order = perm;
+    return 0;
+}
+
 template <uint32_t TS>
 int launch_pm_fill(dim3 grid, size_t lds, hipStream_t s, bool fold_on, int tvmode, const float* g1, const _Float16* g2, const float* x, TvParams tv,
                    const float* tvt, uint32_t Bc, uint32_t B, const BinPlan& plan, const PmPlan& pm, const LevelTable& lv, uint32_t gridtype, bool align,
                    uint32_t interp, uint32_t* level_max, uint32_t* cursors, uint32_t* ovf_cursor, uint16_t* log_rel, uint32_t* log_v1, uint32_t* log_v2,
                    uint32_t* ovf_key, uint32_t* ovf_v1, uint32_t* ovf_v2, float* found_inf, float in_scale, float in_offset, float* clear1,
                    _Float16* clear2, uint32_t cm1, uint32_t cm2, uint32_t merge_levels, uint32_t groups_x, uint32_t slot_begin,
-                   unsigned long long* lm_ready, unsigned long long lm_token, uint32_t in_level_stride, const FoldArgs& fo) {
+                   unsigned long long* lm_ready, unsigned long long lm_token, uint32_t in_level_stride, const FoldArgs& fo, const uint32_t* perm) {
     static bool attr_set = false;
     if (!attr_set) {
         const int cap = 160 * 1024 - 1024;
@@ -3196,7 +3284,7 @@ int launch_pm_fill(dim3 grid, size_t lds, hipStream_t s, bool fold_on, int tvmod
         attr_set = true;
     }
 #define N2M_PM_ARGS g1, g2, x, tv, tvt, Bc, B, plan, pm, lv, gridtype, align, interp, level_max, cursors, ovf_cursor, log_rel, log_v1, log_v2, ovf_key, ovf_v1, \
-                    ovf_v2, found_inf, in_scale, in_offset, clear1, clear2, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token, in_level_stride, fo
+                    ovf_v2, found_inf, in_scale, in_offset, clear1, clear2, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token, in_level_stride, fo, perm
     if (fold_on) {
         if (tvmode == 1) N2M_LAUNCH((pm_fill_pair_kernel<1, true, TS>), grid, TS, lds, s, N2M_PM_ARGS);
         else N2M_LAUNCH((pm_fill_pair_kernel<0, true, TS>), grid, TS, lds, s, N2M_PM_ARGS);
@@ -3326,11 +3414,14 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
         const uint32_t MP = (pl.pm.max_parts + 127u) & ~127u;
         const size_t lds = (size_t)TS * 8u * 12u + (size_t)MP * 5u * 4u;
         const int tvmode = tv.table ? 1 : (tvt ? 2 : 0);
+        const uint32_t* perm = g_sample_order;
+        N2M_REQUIRE(perm == nullptr || (B <= kBinChunk && !fold && in_level_stride == 0), N2M_EUNSUPPORTED,
+                    "%s: a sample order (n2m_grid_backward_sample_order) needs one pass (B <= %u), one point list and no folded copies", fn, kBinChunk);
         int rc;
 #define N2M_PM_CALL(TSV) launch_pm_fill<TSV>(grid, lds, s, fold != nullptr, tvmode, g1, g2, x, tv, tvt, Bc, B, lay.plan, pl.pm, lv, gridtype, align, interp, level_max, \
                                              cursors, ovf_cursor, log_rel, log_v1, log_v2, ovf_key, ovf_v1, ovf_v2, found_inf, in_scale, in_offset,                   \
                                              ow ? table1 : nullptr, ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token,      \
-                                             in_level_stride, fo)
+                                             in_level_stride, fo, perm)
         if (TS == 256u) rc = N2M_PM_CALL(256);
         else if (TS == 1024u) rc = N2M_PM_CALL(1024);
         else rc = N2M_PM_CALL(512);
@@ -3403,6 +3494,7 @@ int launch_binned_pair(const float* grad1, const _Float16* grad2, const float* i
         if (rc != -1) return rc;
         n2m_prof_fall_back_to_markers(s);                      // the tile-major launches below are plain ones
     }
+    N2M_REQUIRE(g_sample_order == nullptr, N2M_EUNSUPPORTED, "%s: a sample order (n2m_grid_backward_sample_order) needs the partition-major path", fn);
     N2M_REQUIRE(g_peer_route.world == 0, N2M_EUNSUPPORTED, "%s: a routed flush (n2m_grid_backward_peer_route) needs the partition-major path", fn);
     N2M_REQUIRE(in_level_stride == 0 || B <= kBinChunk, N2M_EINVAL, "%s: per-level point lists need one pass (B <= %u)", fn, kBinChunk);
     for (uint32_t b0 = 0; b0 < B; b0 += kBinChunk) {

@@ -1095,12 +1095,15 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
                             const float* __restrict__ bg, float bg_scalar, float lambda_rgb, float lambda_mask,
                             const float* __restrict__ grad_loss, float* __restrict__ weights_sum, float* __restrict__ image,
                             float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs, float* __restrict__ partial,
-                            uint32_t* __restrict__ ticket, float* __restrict__ loss, float* __restrict__ loss_sum, float lambda_entropy) {
+                            uint32_t* __restrict__ ticket, float* __restrict__ loss, float* __restrict__ loss_sum, float lambda_entropy,
+                            int32_t* __restrict__ live_out, uint32_t* __restrict__ block_live_out) {
     __shared__ float wave_loss[16];
+    __shared__ uint32_t wave_live[16];
     __shared__ bool last_block;
     const uint32_t wid = threadIdx.x >> 6, n = blockIdx.x * 16 + wid;
     const int lane = threadIdx.x & 63;
     float l_ray = 0.0f;
+    uint32_t n_live = 0u;                  // samples of this ray up to and including the one the early stop fell on: the others get zero gradients
     if (n < N) {
         const uint32_t off = (uint32_t)rays[2 * n], cnt = (uint32_t)rays[2 * n + 1];
         const bool whole = cnt != 0 && off + cnt <= M;
@@ -1118,6 +1121,7 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
         uint32_t visited = 0;
         if (whole) {
             float carry_T = 1.0f;
+            n_live = cnt;
             for (uint32_t base = 0; base < cnt; base += 64) {
                 const uint32_t k = base + lane;
                 const bool valid = k < cnt;
@@ -1140,7 +1144,7 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
                     if (valid) entF += n2m_entropy(fminf(fmaxf(w, 1e-5f), 1.0f - 1e-5f));
                     visited = min(cnt, base + 64u);
                 }
-                if (stop) break;
+                if (stop) { n_live = base + (uint32_t)last + 1u; break; }
                 carry_T = n2m_lane63(T_after);
             }
             rF = n2m_wave_sum(rF); gF = n2m_wave_sum(gF); bF = n2m_wave_sum(bF); wsF = n2m_wave_sum(wsF);
@@ -1174,6 +1178,7 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
         if (lane == 0) {
             if (weights_sum) weights_sum[n] = wsF;
             if (image) { image[3 * n] = rF; image[3 * n + 1] = gF; image[3 * n + 2] = bF; }
+            if (live_out) live_out[n] = (int32_t)n_live;
         }
         // ---- backward
         if (cnt != 0 && !whole) {                       // cut off by M: no gradient, the part inside [0, M) is zeroed
@@ -1228,13 +1233,19 @@ composite_loss_train_kernel(const float* __restrict__ sigmas, const float* __res
         }
     }
     // ---- loss value: per-workgroup partial, the last workgroup to arrive sums them in index order (reproducible)
-    if (lane == 0) wave_loss[wid] = l_ray;
+    if (lane == 0) { wave_loss[wid] = l_ray; wave_live[wid] = n_live; }
     __syncthreads();
     if (threadIdx.x == 0) {
         float p = 0.0f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) p += wave_loss[q];
         partial[blockIdx.x] = p;
+        if (block_live_out) {
+            uint32_t c = 0u;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) c += wave_live[q];
+            block_live_out[blockIdx.x] = c;
+        }
         last_block = false;
         if (ticket) {           // ticket == NULL: the caller reduces the partials itself (n2m_scaler_update_slots_loss)
             __threadfence();
@@ -1674,6 +1685,77 @@ extern "C" int n2m_composite_rays_train_forward(const float* sigmas, const float
 
 // Training fast path: compositing, loss head and both backward passes of n2m_composite_rays_train_forward/backward +
 // n2m_photo_loss_forward/backward in one launch (density mode; no grad_weights / grad_depth: the plain rgb + mask loss).
+// Optional outputs of the NEXT n2m_composite_loss_train* calls of this thread (sticky until cleared with NULLs): per ray the number of
+// samples up to and including the one the early stop fell on (every later sample of the ray receives exactly zero gradients: raymarching.cu:
+// 553,640 `break`), and their sums per workgroup of 16 rays.  n2m_sample_order_live_first turns them into the order the table backward wants.
+static thread_local int32_t* g_live_out = nullptr;
+static thread_local uint32_t* g_block_live_out = nullptr;
+extern "C" int n2m_composite_live_counts(int32_t* live /*[N]*/, uint32_t* block_live /*[ceil(N / 16)]*/) {
+    N2M_REQUIRE((live == nullptr) == (block_live == nullptr), N2M_ENULL, "n2m_composite_live_counts: both outputs or neither");
+    g_live_out = live;
+    g_block_live_out = block_live;
+    return 0;
+}
+
+// perm[0 .. M) <- the samples of a marched batch with every ray's live prefix first (ray order, sample order inside a ray), then every
+// ray's dead tail (same order): position of sample off_r + k = live_before(r) + k for k < live_r, else M_live + (off_r - live_before(r)) +
+// (k - live_r).  One launch: a workgroup owns 16 rays (one workgroup of the compositing kernel) and derives its two offsets from the
+// per-workgroup sums itself (N / 16 values, L2-resident).  Rays cut off by M (off + cnt > M) count as dead over [off, M).  If the ranges
+// do not tile [0, M) -- never the case for n2m_march_rays_train's (offset, count) pairs -- the order degrades to the identity.
+__global__ void __launch_bounds__(256) sample_order_kernel(const int32_t* __restrict__ rays, const int32_t* __restrict__ live,
+                                                           const uint32_t* __restrict__ block_live, uint32_t N, uint32_t M,
+                                                           uint32_t* __restrict__ perm) {
+    __shared__ uint32_t red[2][4];
+    __shared__ uint32_t ray_live_off[16], ray_off[16], ray_cnt[16], ray_live[16];
+    const uint32_t nblk = (N + 15u) / 16u, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    uint32_t before = 0u, total = 0u;
+    for (uint32_t i = tid; i < nblk; i += 256u) {
+        const uint32_t v = block_live[i];
+        total += v;
+        if (i < b) before += v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o, 64); total += __shfl_xor(total, o, 64); }
+    if (lane == 0u) { red[0][wid] = before; red[1][wid] = total; }
+    __syncthreads();
+    before = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (tid < 16u) {
+        const uint32_t n = b * 16u + tid;
+        uint32_t off = 0u, c = 0u, lv = 0u;
+        if (n < N) {
+            off = (uint32_t)rays[2 * n];
+            const uint32_t cnt = (uint32_t)rays[2 * n + 1];
+            c = off < M ? min(cnt, M - off) : 0u;
+            lv = min((uint32_t)live[n], c);
+        }
+        // exclusive prefix of the 16 rays' live counts (lanes 0..15 of wave 0)
+        uint32_t incl = lv;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if ((int)tid >= d) incl += t; }
+        ray_live_off[tid] = before + incl - lv;
+        ray_off[tid] = off; ray_cnt[tid] = c; ray_live[tid] = lv;
+    }
+    __syncthreads();
+    for (uint32_t r = wid; r < 16u; r += 4u) {
+        const uint32_t off = ray_off[r], c = ray_cnt[r], lv = ray_live[r], lo = ray_live_off[r];
+        const uint32_t dead0 = total + (off - lo);
+        for (uint32_t k = lane; k < c; k += 64u) {
+            const uint32_t pos = k < lv ? lo + k : dead0 + (k - lv);
+            if (pos < M) perm[pos] = off + k;
+        }
+    }
+}
+
+extern "C" int n2m_sample_order_live_first(const int32_t* rays, const int32_t* live, const uint32_t* block_live, uint32_t N, uint32_t M,
+                                           uint32_t* perm, void* stream) {
+    if (N == 0 || M == 0) return 0;
+    N2M_NOTNULL(rays); N2M_NOTNULL(live); N2M_NOTNULL(block_live); N2M_NOTNULL(perm);
+    hipLaunchKernelGGL(sample_order_kernel, dim3(n2m_ceil_div(N, 16)), dim3(256), 0, (hipStream_t)stream, rays, live, block_live, N, M, perm);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int n2m_composite_loss_train_ex(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays, uint32_t M, uint32_t N,
                                         float T_thresh, const float* gt_rgba, const float* bg, float bg_scalar, float lambda_rgb,
                                         float lambda_mask, const float* grad_loss, float* weights_sum, float* image, float* grad_sigmas,
@@ -1689,15 +1771,15 @@ extern "C" int n2m_composite_loss_train_ex(const float* sigmas, const float* rgb
         N2M_REQUIRE(lambda_entropy <= 0.0f, N2M_EUNSUPPORTED, "composite_loss_train: alpha mode with the entropy term is not built");
         N2M_LAUNCH((composite_loss_train_kernel<false, true>), n2m_ceil_div(N, 16), 1024, 0, s, sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar,
                                                                                      lambda_rgb, lambda_mask, grad_loss, weights_sum, image, grad_sigmas,
-                                                                                     grad_rgbs, partial, ticket, loss, loss_sum, 0.0f);
+                                                                                     grad_rgbs, partial, ticket, loss, loss_sum, 0.0f, g_live_out, g_block_live_out);
     } else if (lambda_entropy > 0.0f)
         N2M_LAUNCH((composite_loss_train_kernel<true>), n2m_ceil_div(N, 16), 1024, 0, s, sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar,
                                                                               lambda_rgb, lambda_mask, grad_loss, weights_sum, image, grad_sigmas,
-                                                                              grad_rgbs, partial, ticket, loss, loss_sum, lambda_entropy);
+                                                                              grad_rgbs, partial, ticket, loss, loss_sum, lambda_entropy, g_live_out, g_block_live_out);
     else
         N2M_LAUNCH((composite_loss_train_kernel<false>), n2m_ceil_div(N, 16), 1024, 0, s, sigmas, rgbs, ts, rays, M, N, T_thresh, gt_rgba, bg, bg_scalar,
                                                                                lambda_rgb, lambda_mask, grad_loss, weights_sum, image, grad_sigmas,
-                                                                               grad_rgbs, partial, ticket, loss, loss_sum, 0.0f);
+                                                                               grad_rgbs, partial, ticket, loss, loss_sum, 0.0f, g_live_out, g_block_live_out);
     N2M_CHECK_LAUNCH();
     return 0;
 }

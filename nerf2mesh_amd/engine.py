@@ -113,6 +113,19 @@ class Stage0Engine:
         # 67.8 us) and off Adam (99 -> 91) but doubles the accumulate beside it (backward 235 -> 301 us): 0.569 -> 0.613 ms/step.
         self.marker_at = int(os.environ.get("N2M_MARKER_AT", "0"))
         self._mid_events = None
+        # Live-first sample order for the table backward (round 5; MEASURED AND REJECTED, off by default -- N2M_LIVE_FIRST=1 turns it on).
+        # The compositing kernel leaves per ray how many samples precede its early stop -- the others, 48 % of a trained lego batch
+        # (profiles/r05_fill_stats.txt), receive exactly zero gradients (raymarching.cu:553,640) and deliver at most a TV term;
+        # n2m_sample_order_live_first turns that into a permutation and the fill visits the samples in that order, so that the dead tails fill
+        # whole waves, which take a TV-only path (one entry, one value through the run merge, ~30 % of the VALU work).  Same sums (fixed point).
+        # Measured (profiles/r05_live_first_ab.txt, table backward per step): off 211.1 us | identity order 212.7 | live-first 212.7 | live-first
+        # with the TV-only path switched off 218.7: the path saves 6 us, the order costs 7.6 (a ray's live prefix is 5.5 samples: 22-66 byte
+        # pieces per gathered input instead of whole lines) + 4 us of order kernel and longer compositing: the fill is bound by its waits
+        # (SQ: waiting 0.51 of wave cycles), not by the instructions the dead half of the batch issues.
+        self.live_first = os.environ.get("N2M_LIVE_FIRST", "0") not in ("0", "")
+        self._identity_order = os.environ.get("N2M_LIVE_FIRST", "0") == "2"      # (measurement: the order's indirection alone)
+        if os.environ.get("N2M_FILL_DBG"):                                        # (measurement switches of the fill, wrong results for most)
+            L.call("n2m_debug_fill_times", int(os.environ["N2M_FILL_DBG"]), None)
 
         e1, e2 = model.encoder, model.encoder_color
         self.rows = e1.embeddings.shape[0]
@@ -258,6 +271,9 @@ class Stage0Engine:
             w["spec_partial"] = torch.zeros(self._n_spec, dtype=torch.float32, device=dev)
             w["ws"], w["depth"], w["image"], w["d_image"], w["d_ws"], w["bg"] = f(cn), f(cn), f(3 * cn), f(3 * cn), f(cn), f(3 * cn)
             w["partial"] = f((cn + 3) // 4 + 1)
+            w["live"] = torch.zeros(cn, dtype=torch.int32, device=dev)
+            w["block_live"] = torch.zeros((cn + 15) // 16 + 1, dtype=torch.int32, device=dev)
+            w["perm"] = torch.empty(cm, dtype=torch.int32, device=dev)
             w["zeros"] = torch.zeros(max(cm, 3 * cn), dtype=torch.float32, device=dev)
             self._work_cap = (cm, cn)
         return self._w
@@ -718,8 +734,19 @@ class Stage0Engine:
         early = None
         d_sigma, d_rgb = w["d_sr"][:max(M, 1)], w["d_sr"][max(M, 1):4 * max(M, 1)]
         # (+ the entropy regulariser of config 4, nerf/utils.py:728-733: its per-sample gradient is the backward's grad_weights)
-        L.call("n2m_composite_loss_train_ent", _p(w["sigma"]), _p(w["rgb"]), _p(ts), _p(b.rays), M, N, 1e-4, _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask,
-               _p(seed), None, None, _p(d_sigma), _p(d_rgb), _p(w["partial"]), None, None, None, float(max(opt.lambda_entropy, 0.0)), s)      # loss value: summed by the scaler kernel
+        order = self.live_first and M > 0 and M <= (1 << 20) and self.peer is None
+        if order:
+            L.call("n2m_composite_live_counts", _p(w["live"]), _p(w["block_live"]))
+        try:
+            L.call("n2m_composite_loss_train_ent", _p(w["sigma"]), _p(w["rgb"]), _p(ts), _p(b.rays), M, N, 1e-4, _p(b.rgba), _p(bg_t), bg_s, lam_rgb, lam_mask,
+                   _p(seed), None, None, _p(d_sigma), _p(d_rgb), _p(w["partial"]), None, None, None, float(max(opt.lambda_entropy, 0.0)), s)      # loss value: summed by the scaler kernel
+        finally:
+            if order:
+                L.call("n2m_composite_live_counts", None, None)
+        if order:
+            L.call("n2m_sample_order_live_first", _p(b.rays), _p(w["live"]), _p(w["block_live"]), N, M, _p(w["perm"]), s)
+            if self._identity_order:
+                torch.arange(M, dtype=torch.int32, device=dev, out=w["perm"][:M])
         if M > 0:
             if want_tv and self.tv_at == 2:
                 start_tv()
@@ -754,6 +781,19 @@ class Stage0Engine:
                                          L.call("n2m_grid_encode_backward_binned_pair_half", *common, *tv_args, *tail, half))
             if self.marker_at == 1:
                 self._marker = torch.cuda.Event(); self._marker.record()
+            if order and fused is None:
+                L.call("n2m_grid_backward_sample_order", _p(w["perm"]))
+                plain_backward = backward
+
+                def backward(half, _b=plain_backward):
+                    done = False
+                    try:
+                        r = _b(half)
+                        done = True
+                        return r
+                    finally:
+                        if half != 1 or not done:          # (1 = the fine half of a two-call backward: the coarse half follows)
+                            L.call("n2m_grid_backward_sample_order", None)
             if self.peer is not None:
                 # the flush of each level half stores its rows into their owners' slots; the signal behind it is the whole exchange
                 self.peer.begin_step()

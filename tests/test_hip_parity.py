@@ -1112,6 +1112,84 @@ def _half_ulp(v):
     return np.exp2(e - 10)
 
 
+def test_live_first_sample_order_and_the_fill_path_of_dead_waves(be, oracle, scene):
+    """Round 5: n2m_composite_live_counts -> n2m_sample_order_live_first -> n2m_grid_backward_sample_order.
+    (a) The permutation is exactly: every ray's live prefix (ray order), then every ray's remaining samples (ray order).
+    (b) The table backward in that order against the same call in index order: the unmerged levels (9..15) are BIT-identical (fixed-point
+        sums do not depend on the order), the merged levels (0..8) agree to the rounding of the run merge (whose runs the order regroups).
+    (c) The TV-only path whole waves of dead samples take is the full path's result bit for bit (measurement switch 128 turns it off)."""
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L, raymarching, synthetic as S
+    from nerf2mesh_amd.gridencoder import GridEncoder, binned_backward_pair
+    poses = S.make_cameras(64, seed=1).cuda()
+    bits = raymarching.packbits(S.scene_density_grid(H=128, device="cuda"), 10.0)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    o, d = S.random_rays(poses, 20011, g)
+    nears, fars = raymarching.near_far_from_aabb(o, d, torch.tensor([-1, -1, -1, 1, 1, 1.0], device="cuda"), 0.05)
+    xyzs, _, _, rays = raymarching.march_rays_train(o, d, 1.0, False, bits, 1, 128, nears, fars, True, 0.0, 1024)
+    M, N = xyzs.shape[0], rays.shape[0]
+    assert M > 150000
+    x_t = ((xyzs + 1) / 2).contiguous()
+    rays_np = rays.cpu().numpy()
+    rng = np.random.default_rng(12)
+    # per ray: an early stop somewhere (a third of the rays: none, all of their samples are live; a few: at the first sample)
+    cnt = rays_np[:, 1].astype(np.int64)
+    live = np.minimum(cnt, np.where(rng.random(N) < 0.33, cnt, (rng.random(N) * 0.6 * cnt).astype(np.int64) + (rng.random(N) < 0.9)))
+    live_t = torch.from_numpy(live.astype(np.int32)).cuda()
+    nblk = (N + 15) // 16
+    blk = np.add.reduceat(live, np.arange(0, N, 16)).astype(np.uint32)
+    perm = torch.full((M,), -1, dtype=torch.int32, device="cuda")
+    L.call("n2m_sample_order_live_first", L.ptr(rays), L.ptr(live_t), L.ptr(torch.from_numpy(blk.view(np.int32)).cuda()), N, M, L.ptr(perm), L.stream())
+    # (a) numpy statement
+    off = rays_np[:, 0].astype(np.int64)
+    idx_live = np.concatenate([off[r] + np.arange(live[r]) for r in range(N)])
+    idx_dead = np.concatenate([off[r] + np.arange(live[r], cnt[r]) for r in range(N)])
+    want = np.concatenate([idx_live, idx_dead])
+    got = perm.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(got), np.arange(M)), "not a permutation"
+    assert np.array_equal(got, want)
+    # gradients: zero on every level behind the stop, like composite_rays_train's backward leaves them
+    alive = np.zeros(M, bool)
+    alive[idx_live] = True
+    d1 = (rng.standard_normal((16, M, 1)) * np.exp(rng.normal(-6, 2, (1, M, 1))) * alive[None, :, None]).astype(np.float32)
+    d2 = (rng.standard_normal((16, M, 2)) * np.exp(rng.normal(-6, 2, (1, M, 1))) * alive[None, :, None] * 128).astype(np.float16)
+    e1 = GridEncoder(level_dim=1, desired_resolution=2048).cuda()
+    e2 = GridEncoder(level_dim=2, desired_resolution=2048).cuda()
+    offs = np.asarray(e1.host_offsets, np.int64)
+    rows = int(offs[-1])
+    emb1 = dev(be, ((rng.random((rows, 1), dtype=np.float32) * 2 - 1) * 1e-2))
+    D1, D2 = dev(be, d1), dev(be, d2)
+
+    def run(order, mode=0, tv=True):
+        a1 = torch.zeros(rows, 1, device="cuda"); a2 = torch.zeros(rows, 2, device="cuda", dtype=torch.float16)
+        L.call("n2m_debug_fill_times", mode, None)
+        L.call("n2m_grid_backward_sample_order", L.ptr(perm) if order else None)
+        try:
+            assert binned_backward_pair(e1, e2, D1, D2, x_t, a1, a2, 16, tv=(emb1, 1e-4, 1e-4, 1.0, None) if tv else None)
+        finally:
+            L.call("n2m_grid_backward_sample_order", None)
+            L.call("n2m_debug_fill_times", 0, None)
+        torch.cuda.synchronize()
+        return a1.cpu().numpy(), a2.cpu().numpy()
+    for tv in (True, False):
+        p1, p2 = run(False, tv=tv)
+        q1, q2 = run(True, tv=tv)
+        f1, f2 = run(True, mode=128, tv=tv)
+        assert bits_equal(q1, f1) and bits_equal(q2, f2), "the TV-only path of dead waves differs from the full path"      # (c)
+        lo = int(offs[9])
+        assert bits_equal(p1[lo:], q1[lo:]) and bits_equal(p2[lo:], q2[lo:]), "unmerged levels must not depend on the sample order"      # (b)
+        for l in range(9):
+            a, b = slice(int(offs[l]), int(offs[l + 1])), None
+            m1, m2 = np.abs(p1[a]).max(), np.abs(p2[a].astype(np.float32)).max()
+            assert np.abs(p1[a] - q1[a]).max() <= 1e-5 * m1 + 1e-30, f"level {l} fp32"
+            assert np.abs(p2[a].astype(np.float32) - q2[a].astype(np.float32)).max() <= 2e-3 * m2 + 1e-30, f"level {l} fp16"
+        assert np.abs(q1).max() > 0 and np.abs(q2.astype(np.float32)).max() > 0
+    # and bit-reproducible run to run in the live-first order
+    r1, r2 = run(True)
+    s1, s2 = run(True)
+    assert bits_equal(r1, s1) and bits_equal(r2, s2)
+
+
 @pytest.mark.parametrize("with_tv", [False, True])
 def test_binned_pair_backward_is_the_exact_sum_at_full_batch(be, oracle, scene, with_tv):
     """B = 2^18 samples of the marcher (ray-ordered, so the run merge is active), lego tables, both table gradients from the shared

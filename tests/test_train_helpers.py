@@ -90,13 +90,35 @@ def test_fused_composite_loss_equals_the_four_kernel_chain(bg_kind):
     ticket = torch.zeros(1, dtype=torch.int32, device=dev)
     lv, lsum = torch.zeros(1, device=dev), torch.full((1,), 2.0, device=dev)
     bg_t = bg if torch.is_tensor(bg) else None
-    L.call("n2m_composite_loss_train", L.ptr(sig.detach()), L.ptr(rgb.detach()), L.ptr(ts), L.ptr(rays), M, N, 1e-4, L.ptr(gt), L.ptr(bg_t),
-           1.0 if bg_t is None else 0.0, 1.0, 0.1, L.ptr(scale), L.ptr(out_ws), L.ptr(out_im), L.ptr(d_sr[:M]), L.ptr(d_sr[M:]), L.ptr(partial),
-           L.ptr(ticket), L.ptr(lv), L.ptr(lsum), L.stream())
+    # + the optional live counts (round 5, n2m_composite_live_counts): per ray the samples up to and including the early stop
+    live = torch.full((N,), -7, dtype=torch.int32, device=dev)
+    block_live = torch.full(((N + 15) // 16,), -7, dtype=torch.int32, device=dev)
+    L.call("n2m_composite_live_counts", L.ptr(live), L.ptr(block_live))
+    try:
+        L.call("n2m_composite_loss_train", L.ptr(sig.detach()), L.ptr(rgb.detach()), L.ptr(ts), L.ptr(rays), M, N, 1e-4, L.ptr(gt), L.ptr(bg_t),
+               1.0 if bg_t is None else 0.0, 1.0, 0.1, L.ptr(scale), L.ptr(out_ws), L.ptr(out_im), L.ptr(d_sr[:M]), L.ptr(d_sr[M:]), L.ptr(partial),
+               L.ptr(ticket), L.ptr(lv), L.ptr(lsum), L.stream())
+    finally:
+        L.call("n2m_composite_live_counts", None, None)
     assert torch.equal(out_ws, ws.detach()) and torch.equal(out_im, im.detach())
     assert torch.equal(d_sr[:M], sig.grad) and torch.equal(d_sr[M:].view(M, 3), rgb.grad)
     np.testing.assert_allclose(lv.item(), loss.item(), rtol=5e-6)
     assert abs(lsum.item() - (2.0 + lv.item())) < 1e-6 and int(ticket) == 0
+    # the stop position is where the forward's weights end: behind it composite_rays_train leaves zeros (raymarching.cu:553), and the
+    # sample the stop fell on still has a weight (sigma > 0 everywhere here)
+    rays_np, w_np, live_np = rays.cpu().numpy(), w.detach().cpu().numpy(), live.cpu().numpy()
+    gs, gr = d_sr[:M].cpu().numpy(), d_sr[M:].view(M, 3).cpu().numpy()
+    stopped = 0
+    for r in range(N):
+        off, cnt = int(rays_np[r, 0]), int(rays_np[r, 1])
+        nz = np.flatnonzero(w_np[off:off + cnt])
+        want = (int(nz[-1]) + 1) if nz.size else 0
+        if cnt and want < cnt:
+            stopped += 1
+        assert live_np[r] == (want if cnt else 0), (r, live_np[r], want, cnt)
+        assert not gs[off + live_np[r]:off + cnt].any() and not gr[off + live_np[r]:off + cnt].any()
+    assert stopped > 200
+    assert np.array_equal(block_live.cpu().numpy(), np.add.reduceat(live_np, np.arange(0, N, 16)))
 
 
 def test_fused_composite_loss_with_the_entropy_regulariser():
