@@ -447,7 +447,53 @@ def other_configs(timeout_s=300):
     return out
 
 
+# ---- a first multi-GPU invocation must end in a LINE, not in a hang: RCCL / IPC set-up has never run on this code (one-GPU leases)
+_WATCH = {"deadline": None, "phase": "start", "done": False}
+
+
+def _error_line(msg):
+    return json.dumps({"metric": "train_samples_per_sec", "value": None, "unit": "samples/s", "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
+                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic", "error": msg[:1200],
+                       "config": {"workload": "nerf_synthetic/lego stage-0 -O --bound 1 --dt_gamma 0", "phase": _WATCH["phase"]}})
+
+
+def _phase(name, seconds):
+    """Names the phase the run is in and the time it may take; the watchdog thread ends the process with an error line when it is exceeded."""
+    _WATCH["phase"], _WATCH["deadline"] = name, time.monotonic() + seconds
+
+
+def _start_watchdog():
+    import threading
+
+    def watch():
+        while not _WATCH["done"]:
+            time.sleep(1.0)
+            d = _WATCH["deadline"]
+            if d is not None and time.monotonic() > d and not _WATCH["done"]:
+                if int(os.environ.get("RANK", "0")) == 0:
+                    print(_error_line(f"watchdog: phase '{_WATCH['phase']}' exceeded its time limit (a collective or the IPC mapping hangs?); "
+                                      "N2M_BENCH_TIMEOUT raises the limits"), flush=True)
+                os._exit(4)
+    threading.Thread(target=watch, daemon=True).start()
+
+
 def main():
+    try:
+        return _main()
+    except SystemExit:
+        raise
+    except BaseException as e:      # an error line on rank 0 instead of a bare traceback (the driver parses stdout)
+        import traceback
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(_error_line(f"{type(e).__name__}: {e}"), flush=True)
+        _WATCH["done"] = True
+        os._exit(1)
+    finally:
+        _WATCH["done"] = True
+
+
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -515,6 +561,10 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         os.execv(sys.executable, cmd)
+    slack = float(os.environ.get("N2M_BENCH_TIMEOUT", "1.0"))       # multiplies every phase limit below
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        _start_watchdog()
+        _phase("process group set-up + first collective", 240 * slack)
     rank, world, local = init_from_env()
     if world != args.gpus:
         sys.exit(f"[bench] launched with WORLD_SIZE={world} but --gpus {args.gpus}: the two must agree")
@@ -522,6 +572,12 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     _lib.lib()
+    if world > 1:      # pre-flight: one small collective end to end before anything expensive is built on it
+        probe = torch.full((1024,), float(rank + 1), device=device)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        assert float(probe[0]) == world * (world + 1) / 2, f"all-reduce probe returned {float(probe[0])}"
+        _phase("model + pre-training", 900 * slack)
 
     if args.stage == 1:
         return bench_stage1(args, rank, world, device)
@@ -562,6 +618,8 @@ def main():
     for _ in range(args.pretrain + args.warmup):
         tr.train_step()
     barrier()
+    if world > 1:
+        _phase("timed window", 600 * slack)
     first_timed = tr.global_step + 1
     shading_of = lambda it: "diffuse" if (it < opt.diffuse_step or opt.diffuse_only) else "full"       # nerf/utils.py:669-672
     shading = shading_of(first_timed) if shading_of(first_timed) == shading_of(first_timed + args.steps - 1) else "mixed"
@@ -607,6 +665,8 @@ def main():
         long_run = {"steps": 192, "ms_per_step": 1e3 * float(lr_stats[0]) / 192, "value": float(lr_stats[1]) / float(lr_stats[0]), "unit": "samples/s",
                     "refresh_steps_in_window": 12, "note": "the 192 steps behind the headline window, no per-kernel events"}
 
+    if world > 1:
+        _phase("parameter gather + evaluation", 600 * slack)
     # sharded optimizer: every rank owns 1/W of the fp32 table rows -- gather them while all ranks are still here (collective), so that
     # rank 0's PSNR evaluation below runs on complete tables without talking to anybody
     if world > 1 and hasattr(tr, "sync_parameters"):
@@ -711,6 +771,8 @@ def main():
                                    f"dp{world} (rays sharded; table gradients reduce-scattered, Adam sharded over the ranks, packed rows all-gathered; "
                                    f"{dist.get_backend()})" if getattr(tr, "shard", False) else
                                    f"dp{world} (rays sharded, grad all-reduce over {dist.get_backend()})") if world > 1 else "single GPU",
+                   "occupancy_refresh": ("sharded over the ranks by Morton range + all-gather of the densities" if getattr(model, "refresh_shard", None) else
+                                         "replicated on every rank (N2M_SHARD_REFRESH=0)") if world > 1 else "single GPU",
                    "mlp": "nn.Linear (unfused)" if args.unfused else "fused MFMA field kernels",
                    "driver": "engine.Stage0Engine (fixed launch sequence)" if use_engine else "trainer.Stage0Trainer (torch.autograd)", "pretrain_steps": args.pretrain, "samples_per_step_per_gpu": samples / args.steps / world,
                    "rays_per_step_per_gpu": rays / args.steps / world, "params": 18367240},

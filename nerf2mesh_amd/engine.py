@@ -97,6 +97,9 @@ class Stage0Engine:
         if world_size > 1:
             from .parallel import GradSync
             self.sync = GradSync(model, world_size)
+            # occupancy refresh: every rank queries 1 / W of the cells (Morton ranges) and the densities are all-gathered -- the bit field
+            # stays the replicated path's, bit for bit (renderer.update_extra_state; A/B: N2M_SHARD_REFRESH=0)
+            self.model.refresh_shard = (rank, world_size) if os.environ.get("N2M_SHARD_REFRESH", "1") != "0" else None
         self.side = L.side_stream(dev, slot=2)
         # TV terms of the batch as their own kernel on a third stream beside the field kernels (n2m_grid_tv_terms + ..._pair_tvt): takes the
         # stencil's gathers out of the fill (backward 286 -> 250 us) -- but whatever kernel the terms' launch overlaps slows down by about its
@@ -199,6 +202,7 @@ class Stage0Engine:
             pk = model.packed_tables()
             self.peer.packed.copy_(pk)
             model._packed = self.peer.packed          # same values, exported memory; _packed_key stays valid
+            model._packed_buffer = self.peer.packed   # ... and every later rebuild of the copy (load_state_dict, an edited table) lands in it too
             self._peer_route = self.peer.route()
         if self.shard:
             self.optimizer.shard_sync = lambda: self.sync_parameters(moments=True)      # state_dict() of a sharded run: gather first
@@ -284,6 +288,8 @@ class Stage0Engine:
         optimizer update of the step before."""
         if self.sync is not None:
             self.sync.sync_rng_for_grid_update(self.global_step)
+        if self.peer is not None:
+            self.peer.check()                            # (the refresh drains the queue anyway: a blocking look at the error word)
         if self.shard:
             self.sync_parameters(density_only=True)      # the refresh evaluates the density from the fp32 table: gather the other ranks' rows
         self.model.update_extra_state()
@@ -423,6 +429,8 @@ class Stage0Engine:
         # descriptor carries its address (Adam refreshes the copy the forward gathers from), so the address is part of the key
         pk = model.packed_tables()
         assert pk is not None
+        if self.peer is not None and pk.data_ptr() != self.peer.packed.data_ptr():
+            raise RuntimeError("peer-store exchange: the packed table left the exported buffer (peers would keep writing into the old one)")
         key = (full, getattr(o, "state_epoch", 0), pk.data_ptr(), model.encoder.embeddings.data_ptr(), model.encoder_color.embeddings.data_ptr(),
                dense_only)
         d = self._desc.get(key)
@@ -586,6 +594,8 @@ class Stage0Engine:
         if not self.shard:
             return
         self._wait_gather()
+        if self.peer is not None:
+            self.peer.check()
         # COLLECTIVE: every rank must call it at the same step.  A repeat at the same step is a no-op (so a rank may evaluate or save on
         # its own after all ranks have synchronised once -- bench.py's rank 0 does).  moments=True also gathers Adam's exp_avg / exp_avg_sq
         # of both tables (each rank has only advanced its own rows): what a checkpoint needs -- FusedAdamAMP.state_dict() of a sharded
@@ -862,6 +872,10 @@ class Stage0Engine:
             o.found_inf.copy_(self._peer_small[n_dw:].view_as(o.found_inf))
             for h in ("f", "c"):
                 self.peer.reduce(h, self.g1s[h], self.g2s[h])
+            # a wait that ran into its timeout has summed stale slots: the step is skipped on the device (found_inf) and the host raises as
+            # soon as it sees the error word (one step later at most: the word travels to pinned memory behind the step's last wait)
+            self.peer.fold_error_into(o.found_inf)
+            self.peer.raise_if_failed()
         elif self.shard:
             token = self.sync.all_reduce_sum_begin([], [self.dw, o.found_inf])
             for w_ in early:

@@ -90,6 +90,9 @@ class Stage1Engine:
         # non-finite flag in one small bucket
         self.world = int(tr.world)
         self.seed = tr.optimizer.scale if self.world == 1 else torch.empty_like(tr.optimizer.scale)
+        # what was captured above belongs to THIS mesh and THIS optimizer: a refinement / broadcast_mesh() re-initialises the trainer (new
+        # vertices, triangles, optimizer) and the executor must be rebuilt with it -- train_step checks
+        self._captured = (int(model.vertices.shape[0]), int(model.triangles.shape[0]), model.triangles.data_ptr(), id(tr.optimizer))
 
     def _grow(self, K):
         if K > self.cap:
@@ -102,6 +105,10 @@ class Stage1Engine:
 
     def train_step(self):
         tr, model, opt, dev = self.tr, self.model, self.opt, self.device
+        now = (int(model.vertices.shape[0]), int(model.triangles.shape[0]), model.triangles.data_ptr(), id(tr.optimizer))
+        if now != self._captured:
+            raise RuntimeError("Stage1Engine: the mesh or the optimizer changed since the executor was built (refinement, broadcast_mesh): its buffers, "
+                               "antialias topology and gradient hooks are stale -- build a new Stage1Engine(trainer)")
         if not model.training:
             model.train()
         v = tr.views[tr.global_step % len(tr.views)]

@@ -71,7 +71,11 @@ class NeRFNetwork(NeRFRenderer):
             if not same_geometry(e1, e2):
                 return None
             with torch.no_grad():
-                pk = torch.empty(a.shape[0], 2, dtype=torch.float32, device=a.device)
+                # `_packed_buffer`: memory the copy must LIVE in (engine.Stage0Engine's peer-store mode exports it to the other ranks, who
+                # store their rows into it: a rebuild -- load_state_dict, an in-place edit of a table -- must not move it)
+                pk = getattr(self, "_packed_buffer", None)
+                if pk is None or pk.shape != (a.shape[0], 2) or pk.device != a.device:
+                    pk = torch.empty(a.shape[0], 2, dtype=torch.float32, device=a.device)
                 pk[:, 0] = a.detach()[:, 0]
                 pk.view(torch.float16)[:, 2:] = b.detach().half()
             self._packed, self._packed_key = pk, key

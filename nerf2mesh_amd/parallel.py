@@ -337,6 +337,22 @@ class PeerExchange:
     def rows_tokens(self):
         return {"c": self._Token(self, "c"), "f": self._Token(self, "f")}
 
+    def fold_error_into(self, found_inf):
+        """Device side: found_inf += (error word != 0), so that the optimizer skips a step whose exchange timed out (its slots are stale);
+        and the word starts its way to pinned host memory for raise_if_failed()."""
+        word = self._flag_t[self.KINDS * self.world:self.KINDS * self.world + 1]
+        found_inf.add_((word != 0).to(found_inf.dtype).view_as(found_inf))
+        if getattr(self, "_err_host", None) is None:
+            self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._err_host.copy_(word, non_blocking=True)
+
+    def raise_if_failed(self):
+        """Host side, non-blocking: raises when an EARLIER fold_error_into() has delivered a non-zero error word (normally the last step's)."""
+        h = getattr(self, "_err_host", None)
+        if h is not None and int(h[0]):
+            raise RuntimeError(f"peer-store exchange: rank {self.rank} timed out waiting for rank {int(h[0]) - 1} (epoch <= {self.epoch}); the step "
+                               "was skipped on the device (found_inf)")
+
     def check(self):
         """Host read of the error word: raises when a wait ran into its timeout (a peer never signalled)."""
         torch.cuda.synchronize()

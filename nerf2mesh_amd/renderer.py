@@ -360,6 +360,23 @@ class NeRFRenderer(nn.Module):
         n_cells = cells.shape[0]
         if any(v is not None for v in st["valid"]):
             tmp_grid.fill_(-1.0)
+        # Multi-GPU: the cells to query are dealt to the ranks by MORTON RANGE -- rank r evaluates the r-th slice of every cascade's
+        # list -- and the densities are all-gathered (4 bytes per queried cell in all): 1 / W of the query per rank instead of a replicated
+        # one.  The jitter is still drawn for every cell from the generator the ranks seeded identically (parallel.sync_rng_for_grid_update),
+        # so a cell gets the point it would have got on one GPU and the bit field is the replicated one, bit for bit.
+        shard = getattr(self, "refresh_shard", None)
+        if shard is not None and shard[1] <= 1:
+            shard = None
+        if shard is not None and st.get("shard_key") != key:
+            # the ranks must hold the SAME list of cells to query (same cameras -> same untrained mask; a checkpoint loaded everywhere):
+            # checked once per list (a collective: the lists are rebuilt by symmetric events -- marking, loading), replicated query otherwise
+            import torch.distributed as dist
+            mine = [(-1, 0) if v is None else (int(v[0].numel()), int(v[1].sum())) for v in st["valid"]]
+            every = [None] * shard[1]
+            dist.all_gather_object(every, mine)
+            st["shard_key"], st["shard_ok"] = key, all(e == every[0] for e in every)
+        if shard is not None and not st.get("shard_ok", False):
+            shard = None
         for cas in range(self.cascade):
             bound = min(2 ** cas, self.bound)
             hgs = bound / self.grid_size
@@ -368,18 +385,40 @@ class NeRFRenderer(nn.Module):
             u = torch.rand_like(cells)                    # (drawn for every cascade, whether or not any of its cells is valid)
             if n == 0:
                 continue
-            # xyzs = cells * (bound - hgs) + (u * 2 - 1) * hgs: the draws stay torch's, the arithmetic is one launch
-            L.call("n2m_occupancy_points", _p(cells), _p(u), _p(idx[0]) if idx is not None else None, float(bound - hgs), float(hgs), _p(xyzs), n,
-                   L.stream())
-            with torch.autocast(device_type="cuda", dtype=torch.float16, enabled=bool(self.opt.fp16)):
-                sigmas = self.density(xyzs[:n])["sigma"].reshape(-1).detach()
-                if self.opt.sdf:
-                    inv_s = torch.exp(self.variance * 10.0).clip(1e-6, 1e6)
-                    sigmas = torch.sigmoid(-sigmas * inv_s) * inv_s
+            lo, m = 0, n
+            if shard is not None:
+                rank, world = shard
+                per = (n + world - 1) // world
+                lo = min(n, rank * per)
+                m = min(n, lo + per) - lo
+            sigmas = None
+            if m > 0:
+                # xyzs = cells * (bound - hgs) + (u * 2 - 1) * hgs: the draws stay torch's, the arithmetic is one launch
+                if idx is not None:
+                    L.call("n2m_occupancy_points", _p(cells), _p(u), _p(idx[0][lo:lo + m]), float(bound - hgs), float(hgs), _p(xyzs), m, L.stream())
+                else:
+                    L.call("n2m_occupancy_points", _p(cells[lo:lo + m]), _p(u[lo:lo + m]), None, float(bound - hgs), float(hgs), _p(xyzs), m, L.stream())
+                with torch.autocast(device_type="cuda", dtype=torch.float16, enabled=bool(self.opt.fp16)):
+                    sigmas = self.density(xyzs[:m])["sigma"].reshape(-1).detach()
+                    if self.opt.sdf:
+                        inv_s = torch.exp(self.variance * 10.0).clip(1e-6, 1e6)
+                        sigmas = torch.sigmoid(-sigmas * inv_s) * inv_s
+                sigmas = sigmas.float()
+            if shard is not None:
+                import torch.distributed as dist
+                gath = st.get("gather")
+                if gath is None or gath.numel() < per * world:
+                    gath = st["gather"] = torch.empty(per * world, dtype=torch.float32, device=dev)
+                mine = gath[rank * per:(rank + 1) * per]
+                if m > 0:
+                    mine[:m].copy_(sigmas)
+                # (RCCL gathers in place; gloo -- the CPU / shared-GPU tests -- gets a copy of the slice)
+                dist.all_gather_into_tensor(gath[:per * world], mine if dist.get_backend() == "nccl" else mine.clone())
+                sigmas = gath[:n]                         # slices are full except the last non-empty one: the first n values are the list, in order
             if idx is None:
-                tmp_grid[cas] = sigmas.float()
+                tmp_grid[cas] = sigmas
             else:
-                tmp_grid[cas].index_copy_(0, idx[1], sigmas.float())
+                tmp_grid[cas].index_copy_(0, idx[1], sigmas)
         # grid = max(grid * decay, sample) where both are valid; mean of max(grid, 0); threshold = min(mean, density_thresh): one launch, and
         # both scalars stay on the device (the reference reads the mean back every refresh, :1142): no queue drain
         L.call("n2m_occupancy_update", _p(grid), _p(tmp_grid), float(decay), grid.numel(), float(self.density_thresh), _p(st["partials"]),

@@ -91,6 +91,8 @@ class Stage0Trainer:
             self.optimizer, lambda it: 0.01 + 0.99 * (it / 500) if it <= 500 else 0.1 ** ((it - 500) / (iters - 500)))   # main.py:239
         self.scaler = torch.amp.GradScaler("cuda", enabled=bool(opt.fp16) and device.type == "cuda")
         self.sync = GradSync(model, world_size) if world_size > 1 else None
+        if world_size > 1:      # the occupancy refresh's density query sharded over the ranks by Morton range (renderer.update_extra_state)
+            self.model.refresh_shard = (rank, world_size) if os.environ.get("N2M_SHARD_REFRESH", "1") != "0" else None
         self.scene = getattr(opt, "scene", "lego")
         self.boxes = synthetic.boxes(device, self.scene)
         # --enable_cam_near_far (main.py:40): every ray is clamped to its camera's sparse-point depth range (nerf/renderer.py:689-691)

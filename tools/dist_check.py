@@ -19,7 +19,9 @@ rank, world, local = init_from_env()
 device = torch.device("cuda", local % torch.cuda.device_count())
 torch.cuda.set_device(device)
 torch.manual_seed(0)
-opt = make_options(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=True)
+GARDEN = os.environ.get("N2M_DIST_RECIPE") == "garden"       # BASELINE config 4's recipe: 5 cascades, per-view near / far, entropy term
+opt = (make_options(O=True, bound=16, dt_gamma=1 / 256, lambda_entropy=1e-3, enable_cam_near_far=True, scene="garden", iters=30000, fused_mlp=True)
+       if GARDEN else make_options(O=True, bound=1, dt_gamma=0, iters=30000, fused_mlp=True))
 poses = synthetic.make_cameras(100, seed=0)
 if os.environ.get("N2M_DIST_BLIND_RANK") == str(rank):
     # this rank's cameras are moved 50 units back and turned around: every ray misses the scene, every batch of the rank has zero samples.
@@ -27,11 +29,14 @@ if os.environ.get("N2M_DIST_BLIND_RANK") == str(rank):
     poses = poses.clone()
     poses[:, :3, 3] = poses[:, :3, 3] + poses[:, :3, 2] * 50.0
     poses[:, :3, :3] = poses[:, :3, :3] @ torch.diag(torch.tensor([1.0, -1.0, -1.0]))
+model = NeRFNetwork(opt)
+if GARDEN:
+    model.update_aabb(synthetic.pts_aabb("garden"))
 if ENGINE:
     from nerf2mesh_amd.engine import Stage0Engine
-    tr = Stage0Engine(NeRFNetwork(opt), opt, poses, device, rank=rank, world_size=world, seed=0)
+    tr = Stage0Engine(model, opt, poses, device, rank=rank, world_size=world, seed=0)
 else:
-    tr = Stage0Trainer(NeRFNetwork(opt), opt, poses, device, rank=rank, world_size=world, seed=0)
+    tr = Stage0Trainer(model, opt, poses, device, rank=rank, world_size=world, seed=0)
 tr.mark_untrained()
 losses = [float(tr.train_step()) for _ in range(steps)]
 if hasattr(tr, "sync_parameters"):
@@ -42,6 +47,8 @@ if getattr(tr, "peer", None) is not None:
 flat = torch.cat([p.detach().float().reshape(-1) for p in tr.model.parameters()])
 digest = torch.stack([flat.double().sum(), flat.double().abs().sum(), tr.optimizer.scale.double() if hasattr(tr.optimizer, "scale") else torch.zeros((), device=device).double(),
                       tr.optimizer.step_count.double() if hasattr(tr.optimizer, "step_count") else torch.zeros((), device=device).double()]).cpu()
+if rank == 0 and os.environ.get("N2M_DIST_DUMP_GRID"):     # occupancy state: bit field + density grid (sharded vs replicated refresh)
+    torch.save({"bits": tr.model.density_bitfield.cpu(), "grid": tr.model.density_grid.cpu()}, os.environ["N2M_DIST_DUMP_GRID"])
 if rank == 0 and os.environ.get("N2M_DIST_DUMP"):          # every 97th parameter, for run-to-run comparisons (tests/test_parallel_gpu.py)
     torch.save(flat[::97].cpu(), os.environ["N2M_DIST_DUMP"])
 ok = torch.isfinite(flat).all().item() and all(l == l for l in losses)
@@ -71,7 +78,7 @@ if os.environ.get("N2M_DIST_CKPT"):
     if world > 1:
         dist.barrier()
 if rank == 0:
-    print(f"DIST_CHECK {'OK' if ok else 'FAILED'} driver={type(tr).__name__} shard={getattr(tr, 'shard', False)} peer_store={getattr(tr, 'peer', None) is not None} backend={dist.get_backend() if world > 1 else 'none'} world={world} steps={steps} loss {first:.5f} -> {last:.5f} digest={[float(x) for x in digest]}")
+    print(f"DIST_CHECK {'OK' if ok else 'FAILED'} driver={type(tr).__name__} shard={getattr(tr, 'shard', False)} peer_store={getattr(tr, 'peer', None) is not None} refresh_sharded={bool(getattr(tr.model, 'refresh_shard', None)) and bool((getattr(tr.model, '_refresh_bufs', None) or {}).get('shard_ok'))} backend={dist.get_backend() if world > 1 else 'none'} world={world} steps={steps} loss {first:.5f} -> {last:.5f} digest={[float(x) for x in digest]}")
 if world > 1:
     dist.destroy_process_group()
 sys.exit(0 if ok else 1)
