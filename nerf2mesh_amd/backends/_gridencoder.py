@@ -20,16 +20,8 @@ _GENERIC_ONLY = os.environ.get("N2M_SHIM_GENERIC", "0") == "1"
 
 
 def _host_offsets(offsets, L_):
-    """The level offsets as a HOST int32 array (the binned entry points plan on the host): read back once per offsets TENSOR OBJECT (the
-    encoder's buffer; the copy rides on the object -- an address-keyed cache would hand a new model the offsets of a freed one)."""
-    cached = getattr(offsets, "_n2m_host_offsets", None)
-    if cached is None or cached[0] != (offsets._version, int(L_)):
-        ho = np.ascontiguousarray(offsets.detach().cpu().numpy()[:L_ + 1].astype(np.int32))
-        try:
-            offsets._n2m_host_offsets = cached = ((offsets._version, int(L_)), ho)
-        except AttributeError:      # (an object that takes no attributes: read back per call)
-            return ho
-    return cached[1]
+    from nerf2mesh_amd.gridencoder import host_offsets_of
+    return host_offsets_of(offsets, L_)
 
 
 def _dtype_id(t, name):

@@ -2350,6 +2350,11 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
     const uint32_t dbg = g_fill_timing_on;               // measurement switches (tools/pm_lab.sh; wrong results when set)
     if ((dbg >> 8) != 0u && level != (dbg >> 8) - 1u) return;          // (measurement: one level alone, tools/pm_levels.sh)
 
+    // (measurement, n2m_debug_fill_times bit 0: shader-clock stamps of two workgroups' first 8 tiles -- lane 0 of wave 0, and of the LAST wave in
+    //  the second half of the record: loop top | entries ready | barrier 1 passed | staged | barrier 2 passed | log stores issued)
+    const bool stamp = (dbg & 1u) != 0u && (tid == 0u || tid == TS - 64u) && (blockIdx.x == 3u || blockIdx.x == gridDim.x / 2u + 3u);
+    const uint32_t stamp_w = blockIdx.x == 3u ? 0u : 1u;
+#define N2M_PM_STAMP(i) do { if (stamp && it < 4u) g_fill_t[stamp_w][it + (tid == 0u ? 0u : 4u)][(i)] = __builtin_readcyclecounter(); } while (0)
     uint32_t tile = group;
     float nx[D] = {2.f, 2.f, 2.f}, ng1 = 0.0f, ntv = 0.0f;
     h2 ng2 = {(_Float16)0, (_Float16)0};
@@ -2382,6 +2387,7 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
     __syncthreads();
 
     for (uint32_t it = 0; tile < plan.tiles; tile += n_groups, ++it) {
+        N2M_PM_STAMP(0);
         uint32_t* cnt = cnt2 + (it & 1u) * MP;
         uint32_t* cnt_next = cnt2 + ((it & 1u) ^ 1u) * MP;
         float x[D];
@@ -2484,6 +2490,7 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
             for (uint32_t c = 0; c < 8; ++c) e_v1[c] = __float_as_uint(f1[c]);
             vmask = !inside ? 0u : (gnz ? 0xFFu : (tvnz ? 1u : 0u));
         }
+        N2M_PM_STAMP(1);
         // slot of every entry inside its partition's run of this tile
         if (dbg & 16u) {
 #pragma unroll
@@ -2508,6 +2515,7 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
             }
         }
         __syncthreads();                                                     // (1) counters complete
+        N2M_PM_STAMP(2);
 
         // Run starts: EVERY wave scans the counters itself (128 per step, two per lane) and writes the same values -- a wave reads
         // back what it has written itself (LDS operations of a wave complete in order), so no barrier separates scan and staging.
@@ -2578,7 +2586,9 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
             }
             if (__ballot(ovf_here) != 0ull && lane == 0u) tile_ovf[it & 1u] = 1u;
         }
+        N2M_PM_STAMP(3);
         __syncthreads();                                                     // (2) tile staged, regions reserved
+        N2M_PM_STAMP(4);
 
         if (dbg & 12u) {
         } else if (tile_ovf[it & 1u] == 0u) {
@@ -2631,6 +2641,7 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
                 }
             }
         }
+        N2M_PM_STAMP(5);
         // no barrier here: the next tile writes the stage / start / delta only after its barrier (1)
     }
 

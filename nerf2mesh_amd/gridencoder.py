@@ -79,7 +79,9 @@ class _grid_encode(Function):
         grad = grad.to(embeddings.dtype)
         grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = None
-        if dy_dx is None:
+        if dy_dx is None and _binned_single(grad, inputs, offsets, grad_embeddings, B, D, C, Lv, max_level, S, H, gridtype, align, interpolation, dt):
+            pass                                           # exact fixed-point sums instead of order-dependent atomics
+        elif dy_dx is None:
             grad = grad.contiguous()                       # [B, L*C], consumed as is
             L.call("n2m_grid_encode_backward_bm", _p(grad), _p(inputs), _p(embeddings), _p(offsets), _p(grad_embeddings), B, D, C,
                    Lv, max_level, S, H, gridtype, align, interpolation, dt, s)
@@ -90,6 +92,40 @@ class _grid_encode(Function):
                    max_level, S, H, _p(dy_dx), _p(grad_inputs), gridtype, align, interpolation, dt, s)
             grad_inputs = grad_inputs.to(inputs.dtype)
         return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None
+
+
+def host_offsets_of(offsets, Lv):
+    """The level offsets of an `offsets` tensor as a HOST int32 array (the binned entry points plan on the host): read back once per tensor
+    OBJECT -- the copy rides on the object; an address-keyed cache would hand a new model the offsets of a freed one."""
+    cached = getattr(offsets, "_n2m_host_offsets", None)
+    if cached is None or cached[0] != (offsets._version, int(Lv)):
+        ho = np.ascontiguousarray(offsets.detach().cpu().numpy()[:Lv + 1].astype(np.int32))
+        try:
+            offsets._n2m_host_offsets = cached = ((offsets._version, int(Lv)), ho)
+        except AttributeError:      # (an object that takes no attributes: read back per call)
+            return ho
+    return cached[1]
+
+
+_GENERIC_ONLY = os.environ.get("N2M_SHIM_GENERIC", "0") == "1"
+
+
+def _binned_single(grad_bm, inputs, offsets, grad_embeddings, B, D, C, Lv, max_level, S, H, gridtype, align, interp, dt):
+    """One table's backward through the shared-fill kernels (the other table NULL) when the call is covered: D = 3, fp32 C = 1 or fp16
+    C = 2, grad sample-major [B, L*C]; adds onto grad_embeddings.  False: the caller runs the generic kernel."""
+    if _GENERIC_ONLY or D != 3 or B == 0 or max_level <= 0 or not ((C == 1 and dt == L.F32) or (C == 2 and dt == L.F16)):
+        return False
+    ho = host_offsets_of(offsets, Lv)
+    need = L.lib().n2m_grid_binned_pair_workspace_bytes(B, max_level, ho.ctypes.data)
+    if need == 0:
+        return False
+    g = grad_bm.view(B, Lv, C).permute(1, 0, 2).contiguous()
+    ws = L.workspace(inputs.device, need, 0)
+    L.grid_backward_config(1, 1.0)
+    g1, g2, t1, t2 = (g, None, grad_embeddings, None) if C == 1 else (None, g, None, grad_embeddings)
+    L.call("n2m_grid_encode_backward_binned_pair", _p(g1), _p(g2), _p(inputs), ho.ctypes.data, _p(t1), _p(t2), B, Lv, max_level, float(S), int(H),
+           gridtype, int(align), interp, None, 0.0, 0.0, 1.0, None, None, 1.0, 0.0, 0, _p(ws), ws.numel(), L.stream())
+    return True
 
 
 def _host_offsets(enc):
