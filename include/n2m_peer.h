@@ -18,6 +18,7 @@
 #define N2M_PEER_H
 #include <stddef.h>
 #include <stdint.h>
+#include "n2m_hip.h"      /* N2mAdamDesc (n2m_adam_step_peer) */
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -66,6 +67,23 @@ typedef struct {
     void* g2[2][N2M_PEER_MAX];
 } N2mPeerRoute;
 int n2m_grid_backward_peer_route(const N2mPeerRoute* route);
+
+/* n2m_adam_step (include/n2m_hip.h) with the two exchange passes around it folded in: for a descriptor entry k with slots[k][0] != NULL the
+ * gradient is the rank-order sum of the `world` staging slots slots[k][0..world) -- this rank's own memory, the other ranks have stored into it:
+ * what n2m_peer_reduce_slices would have left in desc->grad[k] (fp16 gradients: summed in fp32, rounded to half once; reads bypass the caches) --
+ * and every packed row the pass refreshes (shadow modes 2 / 3) is stored to packed_remote[r] + (its offset from packed_local) as well: what
+ * n2m_peer_copy would have sent afterwards.  Element for element the arithmetic of the three separate passes.  Covers the sharded tables at an even
+ * split (element counts multiples of 4, the paired 16-byte packed-row form); N2M_EUNSUPPORTED otherwise -- the caller keeps the separate passes.
+ * Hand-over as before: n2m_peer_wait in front (the slots are complete), n2m_peer_signal behind (the rows have been stored). */
+typedef struct {
+    uint32_t world;
+    const void* slots[N2M_ADAM_MAX][N2M_PEER_MAX];
+    void* packed_local;
+    void* packed_remote[N2M_PEER_MAX];
+    uint32_t n_remote;
+} N2mAdamPeer;
+int n2m_adam_step_peer(const N2mAdamDesc* desc, double beta1, double beta2, float eps, const float* scale, const float* found_inf,
+                       const float* bias, const N2mAdamPeer* peer, void* stream);
 
 #ifdef __cplusplus
 }

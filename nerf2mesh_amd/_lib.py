@@ -136,6 +136,7 @@ SIGNATURES = {
     "n2m_peer_wait": [_vp, _u32, _u32, _u32, _u32, _vp, _vp],
     "n2m_peer_copy": [_vp, _vp, ctypes.c_size_t, _vp],
     "n2m_peer_reduce_slices": [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
+    "n2m_adam_step_peer": [_vp, ctypes.c_double, ctypes.c_double, _f32, _vp, _vp, _vp, _vp, _vp],
     "n2m_grid_backward_peer_route": [_vp],
     "n2m_prof_enable": [_int],
     "n2m_prof_reset": [],
@@ -163,6 +164,11 @@ PEER_MAX = 8
 class PeerPtrs(ctypes.Structure):
     """N2mPeerPtrs of include/n2m_peer.h."""
     _fields_ = [("ptr", _vp * PEER_MAX), ("count", _u32)]
+
+
+class AdamPeer(ctypes.Structure):
+    """N2mAdamPeer of include/n2m_peer.h."""
+    _fields_ = [("world", _u32), ("slots", (_vp * PEER_MAX) * 16), ("packed_local", _vp), ("packed_remote", _vp * PEER_MAX), ("n_remote", _u32)]
 
 
 class PeerRoute(ctypes.Structure):

@@ -2281,7 +2281,10 @@ __device__ __forceinline__ bool merge_runs_tv(bool inside, const uint32_t (&cell
 #ifndef N2M_PM_PREFETCH_LATE
 #define N2M_PM_PREFETCH_LATE 0
 #endif
-template <int TV, bool FOLD, uint32_t TS>
+// EX (template): the round-5 additions of the fill -- a caller-given sample order, the TV-only path of waves of dead samples, phase stamps.
+// They cost the plain kernel 6.5 us per launch even when unused (measured, ABBA on one box: 213.9 vs 207.2 us), so they are a second
+// instantiation the launcher picks only when an order is set or a measurement switch is on.
+template <int TV, bool FOLD, uint32_t TS, bool EX = false>
 __global__ void __launch_bounds__(TS) __attribute__((amdgpu_waves_per_eu(N2M_PM_WAVES, N2M_PM_WAVES)))
 pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Float16* __restrict__ grad2 /*[L,Bstride,2]*/,
                     const float* __restrict__ inputs, TvParams tv, const float* __restrict__ tv_terms, uint32_t B, uint32_t Bstride, BinPlan plan,
@@ -2352,7 +2355,7 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
 
     // (measurement, n2m_debug_fill_times bit 0: shader-clock stamps of two workgroups' first 8 tiles -- lane 0 of wave 0, and of the LAST wave in
     //  the second half of the record: loop top | entries ready | barrier 1 passed | staged | barrier 2 passed | log stores issued)
-    const bool stamp = (dbg & 1u) != 0u && (tid == 0u || tid == TS - 64u) && (blockIdx.x == 3u || blockIdx.x == gridDim.x / 2u + 3u);
+    const bool stamp = EX && (dbg & 1u) != 0u && (tid == 0u || tid == TS - 64u) && (blockIdx.x == 3u || blockIdx.x == gridDim.x / 2u + 3u);
     const uint32_t stamp_w = blockIdx.x == 3u ? 0u : 1u;
 #define N2M_PM_STAMP(i) do { if (stamp && it < 4u) g_fill_t[stamp_w][it + (tid == 0u ? 0u : 4u)][(i)] = __builtin_readcyclecounter(); } while (0)
     uint32_t tile = group;
@@ -2368,7 +2371,7 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
     auto fetch_index = [&](uint32_t t) {
         const uint32_t s0 = t * TS + tid;
         pvalid = t < plan.tiles && s0 < B;
-        pidx = pvalid ? (perm ? perm[s0] : s0) : 0u;
+        pidx = pvalid ? ((EX && perm) ? perm[s0] : s0) : 0u;
     };
     auto request = [&]() {
         nvalid = pvalid;
@@ -2421,7 +2424,7 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
         // A wave none of whose samples carries a gradient on this level (the dead tails of the rays, visited together when the caller
         // hands the live-first order: n2m_grid_backward_sample_order) delivers TV terms only: one entry per sample instead of eight, one
         // value through the run merge instead of twenty-four.  Wave-uniform; the folded-copies form keeps the full path.
-        const bool wave_live = FOLD || (dbg & 128u) || __ballot(inside && gnz) != 0ull;       // (dbg 128: measurement switch, the full path for every wave)
+        const bool wave_live = !EX || FOLD || (dbg & 128u) || __ballot(inside && gnz) != 0ull;       // (dbg 128: measurement switch, the full path for every wave)
         if (inside) {
             const float g2x = (float)g2.x, g2y = (float)g2.y;
             const float a1 = fabsf(g1);
@@ -3271,6 +3274,7 @@ extern "C" int n2m_grid_backward_mid_event(void* event) {
 // sample to visit.  Results do not depend on it beyond fp32 rounding of the run merge (the sums are fixed point); with the LIVE-FIRST
 // order of n2m_sample_order_live_first the samples without a gradient -- the tails of the rays behind the early stop, about half of a
 // trained batch -- fill whole waves, which take the fill's TV-only path.
+static unsigned int g_fill_dbg_host = 0u;          // host mirror of g_fill_timing_on (n2m_debug_fill_times): a non-zero word selects the EX kernels
 static thread_local const uint32_t* g_sample_order = nullptr;
 extern "C" int n2m_grid_backward_sample_order(const uint32_t* perm) {
     g_sample_order = perm;
@@ -3296,7 +3300,20 @@ int launch_pm_fill(dim3 grid, size_t lds, hipStream_t s, bool fold_on, int tvmod
     }
 #define N2M_PM_ARGS g1, g2, x, tv, tvt, Bc, B, plan, pm, lv, gridtype, align, interp, level_max, cursors, ovf_cursor, log_rel, log_v1, log_v2, ovf_key, ovf_v1, \
                     ovf_v2, found_inf, in_scale, in_offset, clear1, clear2, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token, in_level_stride, fo, perm
-    if (fold_on) {
+    const bool extras = perm != nullptr || g_fill_dbg_host != 0u;
+    if (extras && !fold_on) {
+        static bool attr_ex = false;
+        if (!attr_ex) {
+            const int cap = 160 * 1024 - 1024;
+            (void)hipFuncSetAttribute((const void*)pm_fill_pair_kernel<0, false, TS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute((const void*)pm_fill_pair_kernel<1, false, TS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute((const void*)pm_fill_pair_kernel<2, false, TS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            attr_ex = true;
+        }
+        if (tvmode == 1) N2M_LAUNCH((pm_fill_pair_kernel<1, false, TS, true>), grid, TS, lds, s, N2M_PM_ARGS);
+        else if (tvmode == 2) N2M_LAUNCH((pm_fill_pair_kernel<2, false, TS, true>), grid, TS, lds, s, N2M_PM_ARGS);
+        else N2M_LAUNCH((pm_fill_pair_kernel<0, false, TS, true>), grid, TS, lds, s, N2M_PM_ARGS);
+    } else if (fold_on) {
         if (tvmode == 1) N2M_LAUNCH((pm_fill_pair_kernel<1, true, TS>), grid, TS, lds, s, N2M_PM_ARGS);
         else N2M_LAUNCH((pm_fill_pair_kernel<0, true, TS>), grid, TS, lds, s, N2M_PM_ARGS);
     } else if (tvmode == 1) N2M_LAUNCH((pm_fill_pair_kernel<1, false, TS>), grid, TS, lds, s, N2M_PM_ARGS);
@@ -4259,6 +4276,7 @@ extern "C" int n2m_debug_fill_times(int on, unsigned long long* out) {
     if (out) N2M_HIP(hipMemcpyFromSymbol(out + 96, HIP_SYMBOL(g_acc_t), sizeof(unsigned long long) * 20));
     const unsigned int v = (unsigned int)on;        // bit 0: stamps, bit 1: plain log stores (measurement)
     N2M_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fill_timing_on), &v, sizeof(v)));
+    g_fill_dbg_host = v;
     return 0;
 }
 

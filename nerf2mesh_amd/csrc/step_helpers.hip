@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include "n2m_common.hpp"
+#include "../../include/n2m_peer.h"
 
 namespace {
 
@@ -411,9 +412,24 @@ __device__ __forceinline__ void shadow_store(_Float16* S, uint32_t mode, uint32_
     }
 }
 
+// Peer-store form (n2m_adam_step_peer, include/n2m_peer.h): a table entry's gradient is the rank-order sum of W staging slots (what
+// n2m_peer_reduce_slices would have written for n2m_adam_step to read), and every packed row the pass refreshes is also stored into the other
+// ranks' packed tables (what n2m_peer_copy would have sent afterwards).  Same arithmetic, element for element; two passes over the rows fewer.
+struct AdamPeerK {
+    uint32_t world, n_remote;
+    int8_t entry[N2M_ADAM_MAX];                  // tensor k -> row of `slots`, or -1 (reads t.g[k])
+    uint64_t slots[4][N2M_PEER_MAX];             // the W slots of that entry, in this rank's own staging memory
+    long long remote_delta[N2M_PEER_MAX];        // byte offset from this rank's packed table to rank r's mapping of its own
+};
+
+__device__ __forceinline__ uint32_t peer_load32(const void* at) {      // the slots were written by other agents: bypass the caches
+    return __hip_atomic_load(reinterpret_cast<const uint32_t*>(at), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <bool PEER>
 __global__ void __launch_bounds__(256)
 adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, float eps, const float* __restrict__ scale,
-            const float* __restrict__ found_inf, const float* __restrict__ bias /*[2]: 1-b1^t, sqrt(1-b2^t) of THIS step*/) {
+            const float* __restrict__ found_inf, const float* __restrict__ bias /*[2]: 1-b1^t, sqrt(1-b2^t) of THIS step*/, AdamPeerK pe) {
     uint32_t k = 0;
     while (k + 1 < t.count && blockIdx.x >= t.first_block[k + 1]) ++k;
     const uint32_t i0 = ((blockIdx.x - t.first_block[k]) * 256u + threadIdx.x) * 4u;
@@ -449,6 +465,12 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
         for (uint32_t e = 0; e < 2; ++e) {
             if (r0 + e >= n1) continue;
             p1[e] = P1[r0 + e]; m1v[e] = M1[r0 + e]; v1v[e] = V1[r0 + e];
+            if (PEER && pe.entry[pk] >= 0) {               // (fp32 [rows,1] table: one value per row and slot)
+                float a = 0.0f;
+                for (uint32_t sl = 0; sl < pe.world; ++sl) a += __uint_as_float(peer_load32(reinterpret_cast<const float*>(pe.slots[pe.entry[pk]][sl]) + r0 + e));
+                g1v[e] = a;
+                continue;
+            }
             g1v[e] = g1_half ? (float)reinterpret_cast<const _Float16*>(t.g[pk])[r0 + e] : reinterpret_cast<const float*>(t.g[pk])[r0 + e];
         }
     }
@@ -461,7 +483,23 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
         p[0] = pp.x; p[1] = pp.y; p[2] = pp.z; p[3] = pp.w;
         m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
         v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; v[3] = vv.w;
-        if (g_half) {
+        if (PEER && pe.entry[k] >= 0) {
+            // rank-order sum of the W slots; an fp16 gradient is summed in fp32 and rounded to half ONCE, like n2m_peer_reduce_slices
+            typedef _Float16 h2p __attribute__((ext_vector_type(2)));
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            for (uint32_t sl = 0; sl < pe.world; ++sl) {
+                const char* base = reinterpret_cast<const char*>(pe.slots[pe.entry[k]][sl]);
+                if (g_half) {
+                    const h2p u0 = __builtin_bit_cast(h2p, peer_load32(base + (size_t)i0 * 2u)), u1 = __builtin_bit_cast(h2p, peer_load32(base + (size_t)i0 * 2u + 4u));
+                    a[0] += (float)u0.x; a[1] += (float)u0.y; a[2] += (float)u1.x; a[3] += (float)u1.y;
+                } else {
+#pragma unroll
+                    for (uint32_t e = 0; e < 4; ++e) a[e] += __uint_as_float(peer_load32(base + ((size_t)i0 + e) * 4u));
+                }
+            }
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) g[e] = g_half ? (float)(_Float16)a[e] : a[e];
+        } else if (g_half) {
             typedef _Float16 h4v __attribute__((ext_vector_type(4)));
             const h4v gg = *reinterpret_cast<const h4v*>(reinterpret_cast<const _Float16*>(t.g[k]) + i0);
             g[0] = (float)gg.x; g[1] = (float)gg.y; g[2] = (float)gg.z; g[3] = (float)gg.w;
@@ -522,9 +560,12 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
         h2v c0, c1;
         c0.x = (_Float16)p[0]; c0.y = (_Float16)p[1]; c1.x = (_Float16)p[2]; c1.y = (_Float16)p[3];
         uint32_t* U = reinterpret_cast<uint32_t*>(S) + (size_t)r0 * 2u;
-        if (full && r0 + 2u <= n1)
-            *reinterpret_cast<uint4*>(U) = make_uint4(__float_as_uint(q[0]), __builtin_bit_cast(uint32_t, c0), __float_as_uint(q[1]), __builtin_bit_cast(uint32_t, c1));
-        else {
+        if (full && r0 + 2u <= n1) {
+            const uint4 rows2 = make_uint4(__float_as_uint(q[0]), __builtin_bit_cast(uint32_t, c0), __float_as_uint(q[1]), __builtin_bit_cast(uint32_t, c1));
+            *reinterpret_cast<uint4*>(U) = rows2;
+            if (PEER)
+                for (uint32_t r = 0; r < pe.n_remote; ++r) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(U) + pe.remote_delta[r]) = rows2;
+        } else {
             if (i0 + 1u < n) { U[1] = __builtin_bit_cast(uint32_t, c0); if (r0 < n1) U[0] = __float_as_uint(q[0]); }
             if (i0 + 3u < n) { U[3] = __builtin_bit_cast(uint32_t, c1); if (r0 + 1u < n1) U[2] = __float_as_uint(q[1]); }
         }
@@ -869,8 +910,8 @@ extern "C" int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const
     return 0;
 }
 
-extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, float eps, const float* scale, const float* found_inf,
-                             const float* bias, void* stream) {
+static int adam_step_impl(const N2mAdamDesc* d, double beta1, double beta2, float eps, const float* scale, const float* found_inf,
+                          const float* bias, const N2mAdamPeer* peer, void* stream) {
     N2M_REQUIRE(d != nullptr && bias != nullptr, N2M_ENULL, "adam_step: NULL descriptor / bias");
     N2M_REQUIRE(d->count >= 1 && d->count <= N2M_ADAM_MAX, N2M_EINVAL, "adam_step: 1..%d tensors per call (got %u)", N2M_ADAM_MAX, d->count);
     AdamTensors t;
@@ -924,12 +965,64 @@ extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, f
         double bytes = 0;
         for (uint32_t k = 0; k < d->count; ++k)
             bytes += (double)d->numel[k] * (24.0 + (d->grad_is_half[k] ? 2.0 : 4.0) + (t.shadow_mode[k] == 1 ? 2.0 : (t.shadow_mode[k] == 2 ? 4.0 : (t.shadow_mode[k] == 3 ? 2.0 : 0.0))));
+        AdamPeerK pe;
+        memset(&pe, 0, sizeof(pe));
+        for (uint32_t k = 0; k < N2M_ADAM_MAX; ++k) pe.entry[k] = -1;
+        if (peer) {
+            N2M_REQUIRE(peer->world >= 1 && peer->world <= N2M_PEER_MAX && peer->n_remote < N2M_PEER_MAX, N2M_EINVAL, "adam_step_peer: 1..%d ranks", N2M_PEER_MAX);
+            N2M_REQUIRE(peer->n_remote == 0 || peer->packed_local != nullptr, N2M_ENULL, "adam_step_peer: remote packed tables need the local base");
+            pe.world = peer->world;
+            pe.n_remote = peer->n_remote;
+            for (uint32_t r = 0; r < peer->n_remote; ++r) {
+                N2M_REQUIRE(peer->packed_remote[r] != nullptr && (((uintptr_t)peer->packed_remote[r] ^ (uintptr_t)peer->packed_local) & 15u) == 0, N2M_EINVAL,
+                            "adam_step_peer: remote packed table %u NULL or aligned differently from the local one", r);
+                pe.remote_delta[r] = (long long)((intptr_t)peer->packed_remote[r] - (intptr_t)peer->packed_local);
+            }
+            uint32_t rows_used = 0;
+            for (uint32_t k = 0; k < d->count; ++k) {
+                if (peer->slots[k][0] == nullptr) continue;
+                N2M_REQUIRE(rows_used < 4u, N2M_EUNSUPPORTED, "adam_step_peer: at most four tensors take their gradient from slots");
+                // the fused form covers what the sharded tables are at an even split: whole float4 / half4 vectors, and the paired packed-row
+                // store (a [rows,1] + a [rows,2] tensor on one 16-byte aligned packed slice); anything else keeps the separate passes
+                N2M_REQUIRE(d->numel[k] % 4u == 0u && !((t.clear_mask >> k) & 1u), N2M_EUNSUPPORTED,
+                            "adam_step_peer: tensor %u: element count not a multiple of 4, or clear_grad set", k);
+                for (uint32_t sl = 0; sl < peer->world; ++sl) {
+                    N2M_REQUIRE(peer->slots[k][sl] != nullptr && ((uintptr_t)peer->slots[k][sl] & 3u) == 0, N2M_EINVAL, "adam_step_peer: slot %u of tensor %u", sl, k);
+                    pe.slots[rows_used][sl] = (uint64_t)peer->slots[k][sl];
+                }
+                pe.entry[k] = (int8_t)rows_used++;
+            }
+            for (uint32_t k = 0; k < d->count; ++k) {
+                if (t.shadow_mode[k] == 2 || t.shadow_mode[k] == 3) {
+                    bool paired = t.partner[k] >= 0;
+                    for (uint32_t j = 0; j < d->count; ++j) paired |= t.partner[j] == (int8_t)k;
+                    N2M_REQUIRE(peer->n_remote == 0 || paired, N2M_EUNSUPPORTED,
+                                "adam_step_peer: tensor %u refreshes a packed table outside the paired 16-byte form (odd or unaligned slice)", k);
+                    if (t.partner[k] >= 0) N2M_REQUIRE(d->numel[k] == 2u * d->numel[t.partner[k]], N2M_EUNSUPPORTED, "adam_step_peer: tensor %u: unequal row counts", k);
+                }
+            }
+        }
         N2M_PROF_K(N2M_K_ADAM, (hipStream_t)stream, bytes);
-        N2M_LAUNCH(adam_kernel, blocks, 256, 0, (hipStream_t)stream, t, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, scale,
-                                                             found_inf, bias);
+        if (peer)
+            N2M_LAUNCH((adam_kernel<true>), blocks, 256, 0, (hipStream_t)stream, t, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, scale,
+                                                                        found_inf, bias, pe);
+        else
+            N2M_LAUNCH((adam_kernel<false>), blocks, 256, 0, (hipStream_t)stream, t, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, scale,
+                                                                         found_inf, bias, pe);
     }
     N2M_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, float eps, const float* scale, const float* found_inf,
+                             const float* bias, void* stream) {
+    return adam_step_impl(d, beta1, beta2, eps, scale, found_inf, bias, nullptr, stream);
+}
+
+extern "C" int n2m_adam_step_peer(const N2mAdamDesc* d, double beta1, double beta2, float eps, const float* scale, const float* found_inf,
+                                  const float* bias, const N2mAdamPeer* peer, void* stream) {
+    N2M_REQUIRE(peer != nullptr, N2M_ENULL, "adam_step_peer: NULL peer description (use n2m_adam_step)");
+    return adam_step_impl(d, beta1, beta2, eps, scale, found_inf, bias, peer, stream);
 }
 
 // The same with one step count PER TENSOR SLOT (torch.optim.Adam keeps `state[p]["step"]` per parameter: a parameter that gets its

@@ -121,7 +121,7 @@ class Stage0Engine:
         # (profiles/r05_fill_stats.txt), receive exactly zero gradients (raymarching.cu:553,640) and deliver at most a TV term;
         # n2m_sample_order_live_first turns that into a permutation and the fill visits the samples in that order, so that the dead tails fill
         # whole waves, which take a TV-only path (one entry, one value through the run merge, ~30 % of the VALU work).  Same sums (fixed point).
-        # Measured (profiles/r05_live_first_ab.txt, table backward per step): off 211.1 us | identity order 212.7 | live-first 212.7 | live-first
+        # Measured (profiles/r05_live_first_ab.txt, table backward per step, kernel with the additions): off 211.1 us | identity order 212.7 | live-first 212.7 | live-first
         # with the TV-only path switched off 218.7: the path saves 6 us, the order costs 7.6 (a ray's live prefix is 5.5 samples: 22-66 byte
         # pieces per gathered input instead of whole lines) + 4 us of order kernel and longer compositing: the fill is bound by its waits
         # (SQ: waiting 0.51 of wave cycles), not by the instructions the dead half of the batch issues.
@@ -204,6 +204,10 @@ class Stage0Engine:
             model._packed = self.peer.packed          # same values, exported memory; _packed_key stays valid
             model._packed_buffer = self.peer.packed   # ... and every later rebuild of the copy (load_state_dict, an edited table) lands in it too
             self._peer_route = self.peer.route()
+            # n2m_adam_step_peer: the slot sum inside Adam's gradient load, the row push inside its packed-row store (two passes over the rows and
+            # four launches fewer per step); covers even splits (rows per rank a multiple of 2, 16-byte aligned slices), else the separate passes
+            self._peer_fused = (os.environ.get("N2M_PEER_FUSED", "1") != "0" and self._Cs % 4 == 0 and self._Fs % 4 == 0 and self._split % 2 == 0)
+            self._adam_peer = None
         if self.shard:
             self.optimizer.shard_sync = lambda: self.sync_parameters(moments=True)      # state_dict() of a sharded run: gather first
         # ---- single GPU, measured alternative (N2M_FUSE_ADAM=1, off by default): the optimizer pass of the hashed levels (94 % of the rows)
@@ -626,14 +630,24 @@ class Stage0Engine:
             desc.lr[k] = float(o.param_groups[gi]["initial_lr"]) * lr_factor
         b1, b2 = o.param_groups[0]["betas"]
         s = L.stream()
-        L.call("n2m_adam_step", ctypes.addressof(desc), float(b1), float(b2), float(o.param_groups[0]["eps"]), _p(o.scale), _p(o.found_inf),
-               _p(o.bias), s)
+        peer_fused = self.peer is not None and self._peer_fused
+        if peer_fused:
+            if self._adam_peer is None:     # entries 0..3 of the sharded descriptor: (density, colour) of the coarse half, then of the fine half
+                self._adam_peer = self.peer.adam_peer([("s1", "c"), ("s2", "c"), ("s1", "f"), ("s2", "f")] + [None] * (desc.count - 4))
+            L.call("n2m_adam_step_peer", ctypes.addressof(desc), float(b1), float(b2), float(o.param_groups[0]["eps"]), _p(o.scale), _p(o.found_inf),
+                   _p(o.bias), ctypes.addressof(self._adam_peer), s)
+        else:
+            L.call("n2m_adam_step", ctypes.addressof(desc), float(b1), float(b2), float(o.param_groups[0]["eps"]), _p(o.scale), _p(o.found_inf),
+                   _p(o.bias), s)
         if fused is not None:      # behind both optimizer passes, in front of the scaler update that clears found_inf
             L.call("n2m_adam_fuse_restore", ctypes.addressof(fused), self.ho.ctypes.data, self.Lv, _p(o.found_inf), s)
             self._fuse_swap()
         if self.peer is not None:      # this rank's refreshed rows into every rank's packed table, coarse chunk first; the next lookup waits per half
             for h, (row0, n) in self._shard_ranges().items():
-                self.peer.push_rows(h, row0, n)
+                if peer_fused:
+                    self.peer.signal_rows(h)               # (Adam has stored them everywhere itself)
+                else:
+                    self.peer.push_rows(h, row0, n)
             self._gathers = self.peer.rows_tokens()
             if not self.chunked_gather:
                 self._wait_gather()
@@ -871,7 +885,10 @@ class Stage0Engine:
             self.dw.copy_(self._peer_small[:n_dw])
             o.found_inf.copy_(self._peer_small[n_dw:].view_as(o.found_inf))
             for h in ("f", "c"):
-                self.peer.reduce(h, self.g1s[h], self.g2s[h])
+                if self._peer_fused:
+                    self.peer.wait_grad(h)                    # (the sum itself happens in n2m_adam_step_peer's gradient load)
+                else:
+                    self.peer.reduce(h, self.g1s[h], self.g2s[h])
             # a wait that ran into its timeout has summed stale slots: the step is skipped on the device (found_inf) and the host raises as
             # soon as it sees the error word (one step later at most: the word travels to pinned memory behind the step's last wait)
             self.peer.fold_error_into(o.found_inf)

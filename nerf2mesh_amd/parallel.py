@@ -293,6 +293,36 @@ class PeerExchange:
         L.call("n2m_peer_reduce_slices", self.data.local + self.off["s1" + half], self.data.local + self.off["s2" + half], self.world, n, L.ptr(g1), L.ptr(g2),
                None, L.stream())
 
+    # ---- the fused form: n2m_adam_step_peer sums the slots in its gradient load and stores the packed rows to every rank itself
+    def wait_grad(self, half):
+        """Owner side of the fused form: the W ranks' rows of this half have arrived (the wait reduce() starts with)."""
+        self._wait(self.GF if half == "f" else self.GC)
+
+    def signal_rows(self, half):
+        """Behind n2m_adam_step_peer: this rank's refreshed packed rows of the half are in every rank's table (push_rows() without its copy)."""
+        self._signal(self.RC if half == "c" else self.RF)
+
+    def adam_peer(self, entries):
+        """N2mAdamPeer for a descriptor whose entry k takes its gradient from the slots of (table, half) = entries[k] ("s1" | "s2", "c" | "f"),
+        or from its own grad pointer where entries[k] is None.  Pointers are fixed for the life of the exchange."""
+        from . import _lib as L
+        a = L.AdamPeer()
+        a.world = self.world
+        for k, ent in enumerate(entries):
+            if ent is None:
+                continue
+            key, h = ent
+            for sl in range(self.world):
+                a.slots[k][sl] = self.data.local + self.off[key + h] + sl * self._n[h] * 4
+        a.packed_local = self.data.local + self.off["pk"]
+        r = 0
+        for dst in range(self.world):
+            if dst != self.rank:
+                a.packed_remote[r] = self.data.ptrs[dst] + self.off["pk"]
+                r += 1
+        a.n_remote = r
+        return a
+
     # ---- the small bucket: every rank's copy to every rank, summed in rank order everywhere (bit-identical results without a collective)
     def all_sum_small(self, t):
         """t (contiguous fp32, small_n values) <- sum over ranks of t, in rank order."""

@@ -75,6 +75,78 @@ def test_adam_refreshes_packed_table_columns():
     assert torch.equal(pk.view(torch.float16)[:, 2:], b.detach().half())
 
 
+def test_adam_step_peer_is_reduce_slices_then_adam_then_copy():
+    """n2m_adam_step_peer (include/n2m_peer.h, round 5): the slot sum inside the gradient load and the packed-row store to the other ranks'
+    tables inside the update pass -- against n2m_peer_reduce_slices -> n2m_adam_step -> n2m_peer_copy on the same inputs: parameter, both
+    moments, the local packed rows and the "remote" packed tables bit for bit, for the fp32 [rows,1] and the fp16-gradient [rows,2] table of a
+    sharded slice (slots and remote tables are plain local buffers here; the mapped-memory side is tests/test_parallel_gpu.py's)."""
+    import ctypes
+    import torch
+    from nerf2mesh_amd import _lib as L
+    torch.manual_seed(11)
+    dev = torch.device("cuda")
+    W, rows = 3, 4096 + 8                                       # three "ranks", a slice of rows (even: whole 16-byte packed pairs)
+
+    def state():
+        g = torch.Generator(device=dev).manual_seed(5)
+        p1 = torch.randn(rows, 1, device=dev, generator=g); p2 = torch.randn(rows, 2, device=dev, generator=g)
+        return [p1, torch.zeros_like(p1), torch.zeros_like(p1), p2, torch.zeros_like(p2), torch.zeros_like(p2), torch.zeros(rows, 2, device=dev)]
+    g = torch.Generator(device=dev).manual_seed(6)
+    slots1 = torch.randn(W, rows, device=dev, generator=g) * 300.0                     # scaled gradients, as the flush stores them
+    slots2 = (torch.randn(W, rows, 2, device=dev, generator=g) * 300.0).half()
+    scale = torch.tensor(512.0, device=dev)
+    found = torch.zeros((), device=dev)
+    bias = torch.tensor([[0.1, (1 - 0.999) ** 0.5]] * 17, device=dev)
+
+    def desc_for(st, g1, g2):
+        d = L.AdamDesc()
+        for k, (p, m, v, gr, half, mode) in enumerate(((st[0], st[1], st[2], g1, 0, 2), (st[3], st[4], st[5], g2, 1, 3))):
+            d.param[k], d.grad[k], d.exp_avg[k], d.exp_avg_sq[k] = p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr()
+            d.half_shadow[k], d.shadow_mode[k] = st[6].data_ptr(), mode
+            d.numel[k], d.lr[k], d.grad_is_half[k], d.clear_grad[k], d.slot[k] = p.numel(), 1e-2, half, 0, 0
+        d.count = 2
+        return d
+    for step in range(2):
+        # ---- separate passes
+        if step == 0:
+            a = state(); b = state()
+            remote_a = [torch.zeros(rows, 2, device=dev) for _ in range(W - 1)]
+            remote_b = [torch.zeros(rows, 2, device=dev) for _ in range(W - 1)]
+        g1 = torch.empty(rows, 1, device=dev); g2 = torch.empty(rows, 2, device=dev, dtype=torch.float16)
+        L.call("n2m_peer_reduce_slices", L.ptr(slots1), L.ptr(slots2), W, rows, L.ptr(g1), L.ptr(g2), None, L.stream())
+        da = desc_for(a, g1, g2)
+        L.call("n2m_adam_step", ctypes.addressof(da), 0.9, 0.999, 1e-15, L.ptr(scale), L.ptr(found), L.ptr(bias), L.stream())
+        ptrs = L.PeerPtrs()
+        ptrs.count = W - 1
+        for r in range(W - 1):
+            ptrs.ptr[r] = remote_a[r].data_ptr()
+        L.call("n2m_peer_copy", a[6].data_ptr(), ctypes.byref(ptrs), rows * 8, L.stream())
+        # ---- fused
+        db = desc_for(b, slots1, slots2)                         # (grad pointers of slot-fed entries are not read)
+        ap = L.AdamPeer()
+        ap.world = W
+        for sl in range(W):
+            ap.slots[0][sl] = slots1[sl].data_ptr()
+            ap.slots[1][sl] = slots2[sl].data_ptr()
+        ap.packed_local = b[6].data_ptr()
+        for r in range(W - 1):
+            ap.packed_remote[r] = remote_b[r].data_ptr()
+        ap.n_remote = W - 1
+        L.call("n2m_adam_step_peer", ctypes.addressof(db), 0.9, 0.999, 1e-15, L.ptr(scale), L.ptr(found), L.ptr(bias), ctypes.addressof(ap), L.stream())
+        torch.cuda.synchronize()
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        for x, y in zip(remote_a, remote_b):
+            assert torch.equal(x, y) and torch.equal(x, a[6])
+        assert torch.equal(a[6][:, 0], a[0][:, 0]) and a[1].abs().max() > 0
+        slots1 = slots1 * 0.5 + 1.0; slots2 = (slots2.float() * 0.5 - 1.0).half()      # a second step from the updated state
+    # a slice the fused form does not cover is refused, not mangled
+    bad = desc_for(b, slots1, slots2)
+    bad.numel[0] = rows - 1
+    with pytest.raises(RuntimeError):
+        L.call("n2m_adam_step_peer", ctypes.addressof(bad), 0.9, 0.999, 1e-15, L.ptr(scale), L.ptr(found), L.ptr(bias), ctypes.addressof(ap), L.stream())
+
+
 def test_adam_refreshes_packed_rows_at_an_odd_row_offset():
     """The same with every tensor starting at an ODD row of its buffer -- what a rank of the sharded optimizer gets at 8 GPUs (its slice
     of the coarse levels starts at row r * 240 695): the packed rows are then 8- but not 16-byte aligned, the kernel falls back to separate

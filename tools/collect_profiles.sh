@@ -15,7 +15,7 @@ python $R/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $O/${TAG}_pmc_traffic.json 
 timeout 250 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d /tmp/pmc_s -- $B > /tmp/psq.log 2>&1
 python $R/tools/pmc_sq.py /tmp/pmc_s $O/${TAG}_pmc_sq.json > $O/pmc_sq.txt 2>&1; head -14 $O/pmc_sq.txt
 # the bench command itself under the tracer (per-kernel hipEvents on, as the driver runs it minus the CPU leg)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_traced.json 2>/tmp/ps.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $O/${TAG}_bench_traced.json 2>/tmp/ps.log
 cp $(find /tmp/prof_s -name "*kernel_stats.csv" | head -1) $O/${TAG}_step_kernel_stats.csv
 TR=$(find /tmp/prof_s -name "*kernel_trace.csv" | head -1)
 python $R/tools/step_timeline.py $TR > $O/${TAG}_step_timeline.txt

@@ -5,7 +5,7 @@ set -u
 R=$(pwd); TAG=${1:-r04}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_s /tmp/prof_1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_traced.json 2>/tmp/ps.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $O/${TAG}_bench_traced.json 2>/tmp/ps.log
 cp $(find /tmp/prof_s -name "*kernel_stats.csv" | head -1) $O/${TAG}_step_kernel_stats.csv
 TR=$(find /tmp/prof_s -name "*kernel_trace.csv" | head -1)
 python $R/tools/step_timeline.py $TR > $O/${TAG}_step_timeline.txt
