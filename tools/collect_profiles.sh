@@ -6,7 +6,7 @@ set -u
 R=$(pwd); TAG=${1:-r04}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # steady-state step (shading = full: global_step >= diffuse_step), short runs for the counter passes
-B="python $R/bench.py --pretrain 1000 --warmup 5 --steps 20 --no-prof --no-cpu-baseline"
+B="python $R/bench.py --pretrain 1000 --warmup 5 --steps 20 --no-prof --no-cpu-baseline --no-other-configs"
 rm -rf /tmp/pmc_f /tmp/pmc_w /tmp/pmc_s /tmp/prof_s
 # counters in their own passes, with --kernel-trace only (no other trace domains)
 timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- $B > /tmp/pf.log 2>&1
