@@ -3252,6 +3252,9 @@ static uint32_t pm_tile_samples() {
     static const uint32_t ts = [] {
         const char* e = getenv("N2M_PM_TS");
         const uint32_t v = e ? (uint32_t)atoi(e) : 512u;
+#ifdef N2M_PM_TS_EXTRA                 // (lab builds, tools/build_variant.py: one more tile size, e.g. 640 = ten waves)
+        if (v == (uint32_t)N2M_PM_TS_EXTRA) return v;
+#endif
         return (v == 256u || v == 512u || v == 1024u) ? v : 512u;
     }();
     return ts;
@@ -3452,6 +3455,9 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
                                              in_level_stride, fo, perm)
         if (TS == 256u) rc = N2M_PM_CALL(256);
         else if (TS == 1024u) rc = N2M_PM_CALL(1024);
+#ifdef N2M_PM_TS_EXTRA
+        else if (TS == (uint32_t)N2M_PM_TS_EXTRA) rc = N2M_PM_CALL(N2M_PM_TS_EXTRA);
+#endif
         else rc = N2M_PM_CALL(512);
 #undef N2M_PM_CALL
         if (rc) return rc;
