@@ -415,7 +415,7 @@ def bench_stage1(args, rank, world, device):
         dist.destroy_process_group()
 
 
-def other_configs(timeout_s=300):
+def other_configs(timeout_s=180):
     """BASELINE configs 3, 4, 5 and the drop-in path, measured by this same script in child processes behind the headline window (rank 0, one
     GPU; ~50 timed steps each after the recipe's own pre-training): driver-visible evidence for what the headline line does not cover.
     Every entry is a summary of the child's own JSON line (or says why there is none); the headline fields are not touched."""

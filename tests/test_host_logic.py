@@ -129,3 +129,28 @@ def test_plain_lambda_lr_equals_torch_lambda_lr():
     sc = LambdaLR(c, f)
     sc.load_state_dict(sb.state_dict())
     assert [g["lr"] for g in c.param_groups] == [g["lr"] for g in b.param_groups]
+
+
+def test_bench_watchdog_ends_a_hung_phase_with_an_error_line():
+    """bench.py --gpus N must end in a JSON line, not in a hang (RCCL / IPC set-up has never run on an 8-GPU node): a phase that exceeds its limit
+    makes the watchdog thread print ONE line with an `error` field naming the phase on rank 0 and end the process (exit code 4)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "import bench\n"
+            "bench._start_watchdog()\n"
+            "bench._phase('process group set-up + first collective', 0.5)\n"
+            "time.sleep(30)\n"                       # the 'hung collective'
+            "print('not reached')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, RANK="0", WORLD_SIZE="8"))
+    assert r.returncode == 4, (r.returncode, r.stderr[-500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "not reached" not in r.stdout
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 8 and "process group set-up" in d["error"] and d["metric"] == "train_samples_per_sec"
+    # a rank other than 0 ends too, silently
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, RANK="3", WORLD_SIZE="8"))
+    assert r.returncode == 4 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
