@@ -119,7 +119,7 @@ def _binned_single(grad_bm, inputs, offsets, grad_embeddings, B, D, C, Lv, max_l
     need = L.lib().n2m_grid_binned_pair_workspace_bytes(B, max_level, ho.ctypes.data)
     if need == 0:
         return False
-    g = grad_bm.view(B, Lv, C).permute(1, 0, 2).contiguous()
+    g = grad_bm.reshape(B, Lv, C).permute(1, 0, 2).contiguous()
     ws = L.workspace(inputs.device, need, 0)
     L.grid_backward_config(1, 1.0)
     g1, g2, t1, t2 = (g, None, grad_embeddings, None) if C == 1 else (None, g, None, grad_embeddings)
