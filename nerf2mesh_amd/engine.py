@@ -32,6 +32,11 @@ from .optim import FusedAdamAMP
 _p = L.ptr
 
 
+def _shard_refresh_default():
+    from .parallel import shard_refresh_default
+    return shard_refresh_default()
+
+
 def lr_lambda(it, iters):
     """main.py:239: 0.01 -> 1 over the first 500 iterations, then 0.1 ** ((it - 500) / (iters - 500))."""
     return 0.01 + 0.99 * (it / 500) if it <= 500 else 0.1 ** ((it - 500) / (iters - 500))
@@ -99,7 +104,7 @@ class Stage0Engine:
             self.sync = GradSync(model, world_size)
             # occupancy refresh: every rank queries 1 / W of the cells (Morton ranges) and the densities are all-gathered -- the bit field
             # stays the replicated path's, bit for bit (renderer.update_extra_state; A/B: N2M_SHARD_REFRESH=0)
-            self.model.refresh_shard = (rank, world_size) if os.environ.get("N2M_SHARD_REFRESH", "1") != "0" else None
+            self.model.refresh_shard = (rank, world_size) if _shard_refresh_default() else None
         self.side = L.side_stream(dev, slot=2)
         # TV terms of the batch as their own kernel on a third stream beside the field kernels (n2m_grid_tv_terms + ..._pair_tvt): takes the
         # stencil's gathers out of the fill (backward 286 -> 250 us) -- but whatever kernel the terms' launch overlaps slows down by about its

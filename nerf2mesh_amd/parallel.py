@@ -120,6 +120,17 @@ class GradSync:
             dist.broadcast(t.data, src=src, group=self.group)
 
 
+def shard_refresh_default():
+    """Whether the occupancy refresh's density query is dealt to the ranks (renderer.update_extra_state).  N2M_SHARD_REFRESH=1 / 0 decides; unset:
+    on over RCCL (stream-ordered collectives, one device per rank), off over gloo -- the test mode in which ranks share a GPU and every collective
+    blocks the host: there a refresh step now and then stalls for 10-40 s, and the replicated query needs no collective at all."""
+    import os
+    flag = os.environ.get("N2M_SHARD_REFRESH")
+    if flag is not None:
+        return flag != "0"
+    return dist.is_initialized() and dist.get_backend() == "nccl"
+
+
 def shard_views(n_views, rank, world):
     """Stage-1 sharding: views rank, rank+world, ... (one full image per rank per step)."""
     return list(range(rank, n_views, world))

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from . import synthetic
 from .losses import photo_loss
-from .parallel import GradSync
+from .parallel import GradSync, shard_refresh_default as _shard_refresh_default
 
 
 class LambdaLR:
@@ -92,7 +92,7 @@ class Stage0Trainer:
         self.scaler = torch.amp.GradScaler("cuda", enabled=bool(opt.fp16) and device.type == "cuda")
         self.sync = GradSync(model, world_size) if world_size > 1 else None
         if world_size > 1:      # the occupancy refresh's density query sharded over the ranks by Morton range (renderer.update_extra_state)
-            self.model.refresh_shard = (rank, world_size) if os.environ.get("N2M_SHARD_REFRESH", "1") != "0" else None
+            self.model.refresh_shard = (rank, world_size) if _shard_refresh_default() else None
         self.scene = getattr(opt, "scene", "lego")
         self.boxes = synthetic.boxes(device, self.scene)
         # --enable_cam_near_far (main.py:40): every ray is clamped to its camera's sparse-point depth range (nerf/renderer.py:689-691)
