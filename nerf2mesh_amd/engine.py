@@ -132,6 +132,13 @@ class Stage0Engine:
         # (SQ: waiting 0.51 of wave cycles), not by the instructions the dead half of the batch issues.
         self.live_first = os.environ.get("N2M_LIVE_FIRST", "0") not in ("0", "")
         self._identity_order = os.environ.get("N2M_LIVE_FIRST", "0") == "2"      # (measurement: the order's indirection alone)
+        # [experiment, N2M_LOOKUP_OVERLAP=1, single GPU] Adam in two calls by level half -- fine rows first -- and the NEXT step's lookup of the fine
+        # levels on a stream of its own behind the first call: the lookup (L2-request bound) beside the optimizer pass of the coarse rows + the MLP
+        # weights (HBM-stream bound).  Same bits (Adam is element-wise, the lookup's levels write disjoint rows).  Measured: see DESIGN section 7.
+        self.lookup_overlap = os.environ.get("N2M_LOOKUP_OVERLAP", "0") == "1" and world_size == 1 and not opt.sdf
+        self._fine_ready = None
+        if self.lookup_overlap:
+            self.s_lookup = L.side_stream(dev, slot=4)
         if os.environ.get("N2M_FILL_DBG"):                                        # (measurement switches of the fill, wrong results for most)
             L.call("n2m_debug_fill_times", int(os.environ["N2M_FILL_DBG"]), None)
 
@@ -481,6 +488,49 @@ class Stage0Engine:
         d = self._desc[key] = (desc, participants, groups)
         return d
 
+    def _adam_desc_halves(self, full, lr_factor):
+        """(fine, coarse) descriptors of the single-GPU optimizer pass in two calls: rows [ho[8], rows) of both tables | rows [0, ho[8]) of both
+        tables + the MLP weights.  Pointers are offsets into the same tensors n2m_adam_step takes in one call (_adam_desc)."""
+        o, model = self.optimizer, self.model
+        pk = model.packed_tables()
+        key = ("halves", full, getattr(o, "state_epoch", 0), pk.data_ptr(), model.encoder.embeddings.data_ptr(), model.encoder_color.embeddings.data_ptr())
+        cached = self._desc.get(key)
+        if cached is None:
+            self._packed = pk
+            split = int(self.ho[8])
+            group_of = {p: gi for gi, g in enumerate(o.param_groups) for p in g["params"]}
+            e1p, e2p = model.encoder.embeddings, model.encoder_color.embeddings
+            out = []
+            for row0, n, with_mlp in ((split, self.rows - split, False), (0, split, True)):
+                d, k, groups = L.AdamDesc(), 0, []
+                for p, C, g, is_half, mode, gb in ((e1p, 1, self.g1, 0, 2, 4), (e2p, 2, self.g2, 1, 3, 2)):
+                    st = o.state[p]
+                    off = row0 * C * 4
+                    d.param[k], d.grad[k] = p.data_ptr() + off, g.data_ptr() + row0 * C * gb
+                    d.exp_avg[k], d.exp_avg_sq[k] = st["exp_avg"].data_ptr() + off, st["exp_avg_sq"].data_ptr() + off
+                    d.half_shadow[k], d.shadow_mode[k] = pk.data_ptr() + row0 * 8, mode
+                    d.numel[k], d.grad_is_half[k], d.clear_grad[k], d.slot[k] = n * C, is_half, 0, o._slot[p]
+                    groups.append(group_of[p]); k += 1
+                if with_mlp:
+                    live = set(self.mlp_params[:5]) | (set(self.mlp_params[5:]) if full else set())
+                    views = dict(zip(self.mlp_params, self.dw_views))
+                    for p in [q for g in o.param_groups for q in g["params"]]:
+                        if p not in live:
+                            continue
+                        st = o.state[p]
+                        d.param[k], d.grad[k] = p.data_ptr(), views[p].data_ptr()
+                        d.exp_avg[k], d.exp_avg_sq[k] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                        d.half_shadow[k], d.shadow_mode[k] = None, 0
+                        d.numel[k], d.grad_is_half[k], d.clear_grad[k], d.slot[k] = p.numel(), 0, 1, o._slot[p]
+                        groups.append(group_of[p]); k += 1
+                d.count = k
+                out.append((d, groups))
+            cached = self._desc[key] = tuple(out)
+        for d, groups in cached:
+            for k, gi in enumerate(groups):
+                d.lr[k] = float(o.param_groups[gi]["initial_lr"]) * lr_factor
+        return cached[0][0], cached[1][0]
+
     # ---- double-buffered table state of the fused optimizer pass
     def _is_alt(self, p1_ptr, p2_ptr):
         alt = self.fuse_adam["alt"]
@@ -636,7 +686,16 @@ class Stage0Engine:
         b1, b2 = o.param_groups[0]["betas"]
         s = L.stream()
         peer_fused = self.peer is not None and self._peer_fused
-        if peer_fused:
+        if self.lookup_overlap and fused is None and not self.shard and self.Lv == 16:
+            # fine rows (levels 8..15) first, an event behind them, then the coarse rows + every other tensor
+            d_f, d_c = self._adam_desc_halves(full, lr_factor)
+            for d in (d_f, d_c):
+                L.call("n2m_adam_step", ctypes.addressof(d), float(b1), float(b2), float(o.param_groups[0]["eps"]), _p(o.scale), _p(o.found_inf),
+                       _p(o.bias), s)
+                if d is d_f:
+                    self._fine_ready = torch.cuda.Event()
+                    self._fine_ready.record()
+        elif peer_fused:
             if self._adam_peer is None:     # entries 0..3 of the sharded descriptor: (density, colour) of the coarse half, then of the fine half
                 self._adam_peer = self.peer.adam_peer([("s1", "c"), ("s2", "c"), ("s1", "f"), ("s2", "f")] + [None] * (desc.count - 4))
             L.call("n2m_adam_step_peer", ctypes.addressof(desc), float(b1), float(b2), float(o.param_groups[0]["eps"]), _p(o.scale), _p(o.found_inf),
@@ -725,6 +784,15 @@ class Stage0Engine:
                 L.call("n2m_grid_encode_forward_packed_levels", *fwd, 0, 8, s)
                 self._wait_gather(("f",))
                 L.call("n2m_grid_encode_forward_packed_levels", *fwd, 8, 8, s)
+            elif self.lookup_overlap and self._fine_ready is not None and self.Lv == 16:
+                # fine levels on their own stream behind the fine half of the last optimizer pass, coarse levels on the main stream behind all of it
+                self.s_lookup.wait_event(self._fine_ready)
+                with torch.cuda.stream(self.s_lookup):
+                    L.call("n2m_grid_encode_forward_packed_levels", *fwd, 8, 8, L.stream())
+                    done = torch.cuda.Event()
+                    done.record()
+                L.call("n2m_grid_encode_forward_packed_levels", *fwd, 0, 8, s)
+                torch.cuda.current_stream(dev).wait_event(done)
             else:
                 self._wait_gather()
                 L.call("n2m_grid_encode_forward_packed", *fwd, s)
