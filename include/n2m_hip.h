@@ -570,6 +570,20 @@ typedef struct {
 } N2mAdamDesc;   /* HOST struct */
 int n2m_adam_step(const N2mAdamDesc* desc, double beta1, double beta2, float eps, const float* scale,
                   const float* found_inf, const float* bias, void* stream);
+/* torch_ema.ExponentialMovingAverage.update() (torch-ema is an un-vendored dependency of the reference, requirements.txt:11, imported at
+ * nerf/utils.py:29; the Trainer builds it over model.parameters() with decay 0.95 for stage 0 -- nerf/utils.py:544-545, main.py:241 -- and
+ * updates it once per epoch, :1213-1214) for up to N2M_EMA_MAX fp32 tensors in one launch:
+ *     shadow[i] = shadow[i] - (shadow[i] - param[i]) * one_minus_decay
+ * in that association and without FMA contraction, i.e. bit-identical to the library's `tmp = s - p; tmp.mul_(1 - decay); s.sub_(tmp)`.
+ * The decay schedule (min(decay, (1 + n) / (10 + n)) at the n-th update) is host logic: nerf2mesh_amd/ema.py. */
+#define N2M_EMA_MAX 16
+typedef struct {
+    void* shadow[N2M_EMA_MAX]; const void* param[N2M_EMA_MAX];
+    uint32_t numel[N2M_EMA_MAX];
+    uint32_t count;
+} N2mEmaDesc;   /* HOST struct */
+int n2m_ema_update(const N2mEmaDesc* desc, float one_minus_decay, void* stream);
+
 /* GradScaler.update() on device scalars (floats): found_inf != 0 -> scale *= backoff, tracker = 0; else step += 1,
  * tracker += 1 and scale *= growth every growth_interval good steps; found_inf is reset to 0 and bias [2] recomputed (in
  * double) for the next step.  scale / growth_tracker / step / bias may be NULL. */

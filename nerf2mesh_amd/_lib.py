@@ -86,6 +86,7 @@ SIGNATURES = {
     "n2m_batch_rays": [_vp, _vp, _u32, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_batch_rays_cnf": [_vp, _vp, _u32, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_adam_step": [_vp, ctypes.c_double, ctypes.c_double, _f32, _vp, _vp, _vp, _vp],
+    "n2m_ema_update": [_vp, _f32, _vp],
     "n2m_scaler_update": [_vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp],
     "n2m_scaler_update_slots": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp],
     "n2m_scaler_update_slots_loss": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp, _u32, _u32, _vp, _vp, _vp],
@@ -156,6 +157,14 @@ class AdamDesc(ctypes.Structure):
     _fields_ = [("param", _vp * ADAM_MAX), ("grad", _vp * ADAM_MAX), ("exp_avg", _vp * ADAM_MAX), ("exp_avg_sq", _vp * ADAM_MAX),
                 ("half_shadow", _vp * ADAM_MAX), ("numel", _u32 * ADAM_MAX), ("lr", _f32 * ADAM_MAX), ("grad_is_half", _i32 * ADAM_MAX),
                 ("shadow_mode", _i32 * ADAM_MAX), ("clear_grad", _i32 * ADAM_MAX), ("slot", _i32 * ADAM_MAX), ("count", _u32)]
+
+
+EMA_MAX = 16
+
+
+class EmaDesc(ctypes.Structure):
+    """N2mEmaDesc of include/n2m_hip.h."""
+    _fields_ = [("shadow", _vp * EMA_MAX), ("param", _vp * EMA_MAX), ("numel", _u32 * EMA_MAX), ("count", _u32)]
 
 
 PEER_MAX = 8

@@ -1149,3 +1149,58 @@ extern "C" int n2m_scaler_update(float* scale, float* growth_tracker, float* fou
     N2M_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ EMA of the parameters
+// torch_ema.ExponentialMovingAverage.update() (un-vendored dependency of the reference; nerf/utils.py:544-545 builds it with decay 0.95,
+// :1213-1214 updates it once per epoch) for up to N2M_EMA_MAX tensors in ONE launch: shadow -= (1 - decay) * (shadow - param), in exactly
+// that association (the library forms tmp = shadow - param, scales it in place and subtracts; no FMA: -ffp-contract=off), so the shadow is
+// bit-identical to what the torch ops produce.  16 bytes per lane, streaming accesses: a once-per-epoch pass over 73 MB of parameters.
+struct EmaTensors {
+    uint64_t shadow[N2M_EMA_MAX], param[N2M_EMA_MAX];
+    uint32_t n[N2M_EMA_MAX], first_block[N2M_EMA_MAX + 1];
+    uint32_t count;
+};
+
+__global__ void __launch_bounds__(256) ema_update_kernel(EmaTensors t, float one_minus_decay) {
+    uint32_t k = 0;
+    while (k + 1 < t.count && blockIdx.x >= t.first_block[k + 1]) ++k;
+    const uint32_t i0 = ((blockIdx.x - t.first_block[k]) * 256u + threadIdx.x) * 4u;
+    const uint32_t n = t.n[k];
+    if (i0 >= n) return;
+    float* __restrict__ S = reinterpret_cast<float*>(t.shadow[k]);
+    const float* __restrict__ P = reinterpret_cast<const float*>(t.param[k]);
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    if (i0 + 4u <= n && (((t.shadow[k] | t.param[k]) & 15u) == 0)) {
+        f4v s = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(S + i0));
+        const f4v p = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(P + i0));
+        s.x = s.x - (s.x - p.x) * one_minus_decay; s.y = s.y - (s.y - p.y) * one_minus_decay;
+        s.z = s.z - (s.z - p.z) * one_minus_decay; s.w = s.w - (s.w - p.w) * one_minus_decay;
+        __builtin_nontemporal_store(s, reinterpret_cast<f4v*>(S + i0));
+    } else {
+        for (uint32_t e = 0; e < 4u && i0 + e < n; ++e) S[i0 + e] = S[i0 + e] - (S[i0 + e] - P[i0 + e]) * one_minus_decay;
+    }
+}
+
+extern "C" int n2m_ema_update(const N2mEmaDesc* d, float one_minus_decay, void* stream) {
+    N2M_REQUIRE(d != nullptr, N2M_ENULL, "ema_update: NULL descriptor");
+    N2M_REQUIRE(d->count >= 1 && d->count <= N2M_EMA_MAX, N2M_EINVAL, "ema_update: 1..%d tensors per call (got %u)", N2M_EMA_MAX, d->count);
+    N2M_REQUIRE(one_minus_decay >= 0.0f && one_minus_decay <= 1.0f, N2M_EINVAL, "ema_update: 1 - decay = %g outside [0, 1]", (double)one_minus_decay);
+    EmaTensors t;
+    t.count = d->count;
+    uint32_t blocks = 0;
+    for (uint32_t k = 0; k < d->count; ++k) {
+        N2M_REQUIRE(d->shadow[k] && d->param[k], N2M_ENULL, "ema_update: NULL tensor %u", k);
+        N2M_REQUIRE((((uintptr_t)d->shadow[k] | (uintptr_t)d->param[k]) & 3u) == 0, N2M_EINVAL, "ema_update: tensor %u is not 4-byte aligned", k);
+        N2M_REQUIRE(d->shadow[k] != d->param[k], N2M_EINVAL, "ema_update: tensor %u: shadow and parameter are the same memory", k);
+        t.shadow[k] = (uint64_t)(uintptr_t)d->shadow[k];
+        t.param[k] = (uint64_t)(uintptr_t)d->param[k];
+        t.n[k] = d->numel[k];
+        t.first_block[k] = blocks;
+        blocks += (d->numel[k] + 1023u) / 1024u;
+    }
+    t.first_block[d->count] = blocks;
+    if (blocks == 0) return 0;
+    ema_update_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(t, one_minus_decay);
+    N2M_CHECK_LAUNCH();
+    return 0;
+}

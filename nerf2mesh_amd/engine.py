@@ -71,7 +71,7 @@ class _RayBufs:
 
 
 class Stage0Engine:
-    def __init__(self, model, opt, poses, device, rank=0, world_size=1, seed=0):
+    def __init__(self, model, opt, poses, device, rank=0, world_size=1, seed=0, ema_decay=0.95):
         self.model, self.opt, self.device = model.to(device), opt, torch.device(device)
         dev = self.device
         assert dev.type == "cuda", "the step executor drives HIP kernels: no CPU path"
@@ -90,6 +90,13 @@ class Stage0Engine:
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed + rank)
         self.optimizer = FusedAdamAMP(model.get_params(opt.lr), eps=1e-15, amp=True)
+        # EMA of the parameters (main.py:241: decay 0.95 for stage 0; nerf/utils.py:544-545), updated once per epoch = every len(loader) =
+        # number-of-training-views steps (nerf/utils.py:1213-1214); evaluation runs on the averaged weights (averaged_parameters())
+        self.ema = None
+        self.epoch_len = max(1, int(poses.shape[0]))
+        if ema_decay is not None:
+            from .ema import ExponentialMovingAverage
+            self.ema = ExponentialMovingAverage(model.parameters(), decay=ema_decay)
         self.images = None
         self.scene = getattr(opt, "scene", "lego")
         self.boxes = synthetic.boxes(dev, self.scene)
@@ -1156,9 +1163,29 @@ class Stage0Engine:
     def _lr_step(self, full, loss_out=None, fused=None):
         if full is not None:
             self._optimizer_step(full, lr_lambda(self.global_step - 1, self.opt.iters), loss_out, fused)
+        if self.ema is not None and self.global_step % self.epoch_len == 0:      # end of an epoch (nerf/utils.py:1213-1214)
+            self.ema_update()
+
+    def ema_update(self):
+        """One update of the averaged weights from the current parameters (one launch, stream-ordered behind the optimizer pass)."""
+        if self.shard:
+            self.sync_parameters()          # each rank has advanced its own rows of the fp32 tables only (a collective, at a symmetric step)
+        self.ema.update()
+
+    def averaged_parameters(self):
+        """Context: the model carries the EMA weights (store / copy_to ... restore, nerf/utils.py:1250-1252,1340-1341); no-op without EMA."""
+        import contextlib
+        if self.ema is None:
+            return contextlib.nullcontext()
+        self.sync_parameters()
+        return self.ema.average_parameters()
 
     @torch.no_grad()
-    def eval_psnr(self, cam=0, downscale=4):
+    def eval_psnr(self, cam=0, downscale=4, use_ema=False):
+        """use_ema: evaluate the averaged weights, as the reference's evaluate_one_epoch does (nerf/utils.py:1250-1252)."""
         from .trainer import Stage0Trainer
         self.sync_parameters()
+        if use_ema and self.ema is not None:
+            with self.averaged_parameters():
+                return Stage0Trainer.eval_psnr(self, cam, downscale)
         return Stage0Trainer.eval_psnr(self, cam, downscale)

@@ -47,9 +47,16 @@ class LambdaLR:
 
 
 class Stage0Trainer:
-    def __init__(self, model, opt, poses, device, rank=0, world_size=1, seed=0):
+    def __init__(self, model, opt, poses, device, rank=0, world_size=1, seed=0, ema_decay=0.95):
         self.model, self.opt, self.device = model.to(device), opt, device
         self.poses = poses.to(device)
+        # EMA of the parameters: main.py:241 (0.95 for stage 0), nerf/utils.py:544-545; one update per epoch = len(loader) steps (:1213-1214).
+        # Device tensors only (the update is a HIP kernel); the CPU drivers of tests/test_parallel.py run without it.
+        self.ema = None
+        self.epoch_len = max(1, int(poses.shape[0]))
+        if ema_decay is not None and torch.device(device).type == "cuda":
+            from .ema import ExponentialMovingAverage
+            self.ema = ExponentialMovingAverage(model.parameters(), decay=ema_decay)
         self.rank, self.world = rank, world_size
         self.global_step = 0
         self.num_rays = opt.num_rays
@@ -304,6 +311,8 @@ class Stage0Trainer:
             self.scaler.step(self.optimizer)
             self.scaler.update()
         self.scheduler.step()
+        if self.ema is not None and self.global_step % self.epoch_len == 0:      # end of an epoch (nerf/utils.py:1213-1214)
+            self.ema.update()
         self._loss_pending.append(loss.detach())       # summed lazily (loss_acc): no per-step add kernel
         if len(self._loss_pending) >= 1024:
             _ = self.loss_acc
@@ -328,8 +337,17 @@ class Stage0Trainer:
             model.encoder.grad_total_variation(lam, xyzs, model.bound, scale=scale_tensor)
 
     @torch.no_grad()
-    def eval_psnr(self, cam=0, downscale=4):
-        """PSNR of one rendered view against the analytic ground truth (white background)."""
+    def averaged_parameters(self):
+        """Context: the model carries the EMA weights (store / copy_to ... restore, nerf/utils.py:1250-1252,1340-1341); no-op without EMA."""
+        import contextlib
+        return self.ema.average_parameters() if self.ema is not None else contextlib.nullcontext()
+
+    def eval_psnr(self, cam=0, downscale=4, use_ema=False):
+        """PSNR of one rendered view against the analytic ground truth (white background).  use_ema: with the averaged weights, as the
+        reference's evaluate_one_epoch renders (nerf/utils.py:1250-1252)."""
+        if use_ema and getattr(self, "ema", None) is not None:
+            with self.averaged_parameters():
+                return type(self).eval_psnr(self, cam, downscale)
         self.model.eval()
         H = W = synthetic.LEGO_HW // downscale
         dev = self.device
