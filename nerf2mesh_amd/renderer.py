@@ -367,16 +367,25 @@ class NeRFRenderer(nn.Module):
         shard = getattr(self, "refresh_shard", None)
         if shard is not None and shard[1] <= 1:
             shard = None
-        if shard is not None and st.get("shard_key") != key:
-            # the ranks must hold the SAME list of cells to query (same cameras -> same untrained mask; a checkpoint loaded everywhere):
-            # checked once per list (a collective: the lists are rebuilt by symmetric events -- marking, loading), replicated query otherwise
+        if shard is not None:
+            # The ranks must hold the SAME list of cells to query, or the gathers below have different shapes on different ranks (a hang or
+            # garbage over RCCL).  The decision is made SYMMETRICALLY at every refresh: each rank's summary of its lists -- per cascade
+            # (count, index sum), recomputed only when its own list was rebuilt -- is all-gathered (a few dozen bytes) and read on the host;
+            # any difference (a rank-local write to density_grid: a checkpoint loaded on rank 0 only, a reset, a mark) puts EVERY rank on
+            # the replicated query for this refresh.  One small collective + one host read per 16 steps; no rank ever decides alone.
             import torch.distributed as dist
-            mine = [(-1, 0) if v is None else (int(v[0].numel()), int(v[1].sum())) for v in st["valid"]]
-            every = [None] * shard[1]
-            dist.all_gather_object(every, mine)
-            st["shard_key"], st["shard_ok"] = key, all(e == every[0] for e in every)
-        if shard is not None and not st.get("shard_ok", False):
-            shard = None
+            if st.get("summary_key") != key:
+                vals = []
+                for v in st["valid"]:
+                    vals += [-1, 0] if v is None else [int(v[0].numel()), int(v[1].sum())]
+                st["summary_key"] = key
+                st["summary"] = torch.tensor(vals, dtype=torch.int64, device=dev)
+                st["summary_all"] = torch.empty(shard[1], len(vals), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(st["summary_all"], st["summary"])
+            every = st["summary_all"].cpu()
+            st["shard_ok"] = bool((every == every[0:1]).all())
+            if not st["shard_ok"]:
+                shard = None
         for cas in range(self.cascade):
             bound = min(2 ** cas, self.bound)
             hgs = bound / self.grid_size

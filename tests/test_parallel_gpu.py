@@ -71,6 +71,17 @@ def test_sharded_occupancy_refresh_leaves_the_replicated_bit_field(tmp_path, rec
     assert torch.equal(pa, pb), "parameters after 20 steps differ between the sharded and the replicated refresh"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["touch", "mark"])
+def test_sharded_refresh_decides_symmetrically_after_a_rank_local_grid_write(mode):
+    """a torch-side write to density_grid on ONE rank used to make that rank alone enter the list check's collective (a hang
+    over RCCL).  The check now runs on every rank at every refresh.  Rank 1 alone rewrites its grid after step 10 -- "touch": same values, new
+    version counter (the sharded query stays on); "mark": one empty cell set to -1, so the ranks' lists differ and EVERY rank takes the
+    replicated query from then on.  Either way the run ends, and the replicas stay bit-identical (DIST_CHECK OK)."""
+    line = _dist_check(29571 if mode == "touch" else 29573, 20, {"N2M_SHARD_REFRESH": "1", "N2M_DIST_ASYM": mode})
+    assert f"refresh_sharded={mode == 'touch'}" in line, line
+
+
 def _dist_check(port, steps, extra_env, dump=None, timeout=400):
     env = dict(os.environ, N2M_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", **extra_env)
     if dump:

@@ -38,7 +38,15 @@ if ENGINE:
 else:
     tr = Stage0Trainer(model, opt, poses, device, rank=rank, world_size=world, seed=0)
 tr.mark_untrained()
-losses = [float(tr.train_step()) for _ in range(steps)]
+ASYM = os.environ.get("N2M_DIST_ASYM")                       # a torch-side write to density_grid on RANK 1 ONLY after step 10 (tests/test_parallel_gpu.py):
+losses = []                                                  # "touch": same values, new version counter; "mark": one empty cell set to -1 (the lists differ)
+for it in range(steps):
+    losses.append(float(tr.train_step()))
+    if ASYM and it == 9 and rank == 1:
+        if ASYM == "touch":
+            tr.model.density_grid.mul_(1.0)
+        else:
+            tr.model.density_grid[0, 0] = -1.0                # Morton cell 0 = the (-1,-1,-1) corner: empty, its bit is 0 either way
 if hasattr(tr, "sync_parameters"):
     tr.sync_parameters()              # sharded optimizer: every rank owns 1/W of the table rows until the fp32 tensors are gathered
 torch.cuda.synchronize()
