@@ -2278,6 +2278,9 @@ __device__ __forceinline__ bool merge_runs_tv(bool inside, const uint32_t (&cell
 #ifndef N2M_PM_WAVES
 #define N2M_PM_WAVES 4
 #endif
+#ifndef N2M_PM_FINE_WAVES
+#define N2M_PM_FINE_WAVES 6
+#endif
 #ifndef N2M_PM_PREFETCH_LATE
 #define N2M_PM_PREFETCH_LATE 0
 #endif
@@ -2300,7 +2303,11 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     // Workgroup 0 (always resident first) clears the level maxima, the cursors and the overflow cursor, then publishes this launch's
     // token; a workgroup waits for the token before its first reservation (a whole entries phase later: never seen to spin).
-    if (blockIdx.x == 0u && blockIdx.y == 0u) {
+    // (bit 31 of slot_begin: this launch CONTINUES a fill -- pm_fill_fine_kernel has cleared and published the token for the fine levels,
+    //  whose cursors and maxima are live -- so workgroup 0 clears nothing and every token wait passes at once)
+    const bool continues = (slot_begin >> 31) != 0u;
+    slot_begin &= 0x7FFFFFFFu;
+    if (blockIdx.x == 0u && blockIdx.y == 0u && !continues) {
         if (threadIdx.x < 2u * kMaxLevels) level_max[threadIdx.x] = 0u;
         for (uint32_t i = threadIdx.x; i < pm.cursors; i += TS) cursors[i] = 0u;
         if (threadIdx.x == 0u) *ovf_cursor = 0u;
@@ -2645,6 +2652,255 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
             }
         }
         N2M_PM_STAMP(5);
+        // no barrier here: the next tile writes the stage / start / delta only after its barrier (1)
+    }
+
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        vmax1 = fmaxf(vmax1, __shfl_xor(vmax1, o, 64));
+        vmax2 = fmaxf(vmax2, __shfl_xor(vmax2, o, 64));
+    }
+    if (lane == 0) { wave_max[0][wid] = __float_as_uint(vmax1); wave_max[1][wid] = __float_as_uint(vmax2); }
+    __syncthreads();
+    if (tid < 2u) {
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kWaves; ++w) m = max(m, wave_max[tid][w]);
+        uint32_t* dst = level_max + tid * kMaxLevels + level;
+        while (__hip_atomic_load(lm_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != lm_token) __builtin_amdgcn_s_sleep(8);
+        if (m > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, m);
+    }
+}
+
+// ---- The fill of the FINE levels (round 6): levels 8..15 of the standard table -- hashed, power-of-two, 2..128 partitions, no run merging --
+// deliver 4/5 of the log's entries, and in pm_fill_pair_kernel they carry the register budget of everything the coarse levels need (the run
+// merge's f2x/f2y, three indexers, the folded copies): 124 VGPRs = two workgroups per CU for a kernel whose waves wait half of their time.
+// This instantiation serves exactly those levels and is written for a THIRD resident workgroup (<= 80 VGPRs, 6 waves per SIMD, 3 x 50 KB
+// of LDS): what crosses barrier 1 is not the sample's 24 finished values but what they are made from -- the three interpolation
+// fractions, the two gradients, the TV term -- plus ONE word per entry {slot in the partition's run : 13 | table row : 19}; products,
+// half rounding and partition keys are formed when the entry is staged (a few dozen VALU instructions per sample in a kernel bound by
+// its waits).  Same arithmetic in the same association as pm_entries: the log holds the same bits, the level maxima are the same, the
+// accumulate does not know which kernel filled a region.  One level per XCD (level = first_level + (blockIdx.x & 7)): the level's 2 MB
+// table slice (TV stencil) and its regions stay in that XCD's L2, as in the paired mapping of the general kernel.
+template <int TV>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(N2M_PM_FINE_WAVES, N2M_PM_FINE_WAVES)))
+pm_fill_fine_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Float16* __restrict__ grad2 /*[L,Bstride,2]*/,
+                    const float* __restrict__ inputs, TvParams tv, const float* __restrict__ tv_terms, uint32_t B, uint32_t Bstride, BinPlan plan,
+                    PmPlan pm, LevelTable lv, bool align_corners, uint32_t interp, uint32_t* __restrict__ level_max /*[2][32]*/,
+                    uint32_t* __restrict__ cursors, uint32_t* __restrict__ ovf_cursor, uint16_t* __restrict__ log_rel, uint32_t* __restrict__ log_v1,
+                    uint32_t* __restrict__ log_v2, uint32_t* __restrict__ ovf_key, uint32_t* __restrict__ ovf_v1, uint32_t* __restrict__ ovf_v2,
+                    float* __restrict__ found_inf, float in_scale, float in_offset, uint32_t groups_x, uint32_t first_level,
+                    unsigned long long* __restrict__ lm_ready, unsigned long long lm_token, uint32_t in_level_stride) {
+    constexpr uint32_t D = 3, TS = 512u, kWaves = TS / 64u, kEntries = TS * 8u, MP = 128u;
+    constexpr uint32_t kLog2P = 31u - __builtin_clz(kPairP);
+    constexpr uint32_t kRowBits = 19u, kRowMask = (1u << kRowBits) - 1u;          // rows of a level < 2^19, slots of a tile's run < 2^13
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    if (blockIdx.x == 0u) {                              // (see pm_fill_pair_kernel: workgroup 0 clears, then publishes this launch's token)
+        if (threadIdx.x < 2u * kMaxLevels) level_max[threadIdx.x] = 0u;
+        for (uint32_t i = threadIdx.x; i < pm.cursors; i += TS) cursors[i] = 0u;
+        if (threadIdx.x == 0u) *ovf_cursor = 0u;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0u) __hip_atomic_store(lm_ready, lm_token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    extern __shared__ __attribute__((aligned(16))) uint32_t pm_lds[];
+    uint32_t* stage_v1 = pm_lds;
+    uint32_t* stage_v2 = stage_v1 + kEntries;
+    uint32_t* stage_e = stage_v2 + kEntries;             // partition << 16 | row in partition
+    uint32_t* cnt2 = stage_e + kEntries;                 // [2][MP]
+    uint32_t* start = cnt2 + 2u * MP;
+    uint32_t* delta = start + MP;
+    uint32_t* ovfb = delta + MP;
+    __shared__ uint32_t wave_max[2][kWaves], tile_ovf[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t level = first_level + (blockIdx.x & 7u), group = blockIdx.x >> 3, n_groups = groups_x;
+    if (level >= plan.levels) return;
+    const uint32_t parts = plan.parts[level], size = plan.size[level];
+    for (uint32_t i = tid; i < 2u * MP; i += TS) cnt2[i] = 0u;
+    if (tid < 2u) tile_ovf[tid] = 0u;
+    const float scale = lv.scale[level];
+    const Indexer<D> ix(size, lv.resolution[level], 0u, align_corners);
+    const uint32_t cap = pm.home_cap[level], region0 = pm.home_base[level];
+    uint32_t* __restrict__ cur_l = cursors + pm.cur_base[level];
+    float vmax1 = 0.0f, vmax2 = 0.0f;
+    bool token_seen = false;
+    const PairCtx cx = make_pair_ctx(tv, tv.table ? tv.table + (size_t)plan.row0[level] * tv.stride : nullptr, scale, lv.resolution[level], align_corners, interp);
+
+    uint32_t tile = group;
+    float nx[D] = {2.f, 2.f, 2.f}, ng1 = 0.0f, ntv = 0.0f;
+    h2 ng2 = {(_Float16)0, (_Float16)0};
+    bool nvalid = false;
+    auto request = [&](uint32_t t) {                     // the inputs of tile t, RAW (the affine map is applied when they are consumed)
+        const uint32_t s = t * TS + tid;
+        nvalid = t < plan.tiles && s < B;
+        if (nvalid) {
+            load_point<D>(inputs + (size_t)level * in_level_stride, s, nx);
+            ng1 = grad1 ? grad1[(size_t)level * Bstride + s] : 0.0f;
+            if (grad2) ng2 = *reinterpret_cast<const h2*>(grad2 + ((size_t)level * Bstride + s) * 2);
+            else ng2 = h2{(_Float16)0, (_Float16)0};
+            if (TV == 2) ntv = tv_terms[(size_t)level * Bstride + s];
+        }
+    };
+    request(tile);
+    __syncthreads();
+
+    for (uint32_t it = 0; tile < plan.tiles; tile += n_groups, ++it) {
+        uint32_t* cnt = cnt2 + (it & 1u) * MP;
+        uint32_t* cnt_next = cnt2 + ((it & 1u) ^ 1u) * MP;
+        float x[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; ++d) x[d] = nvalid ? nx[d] * in_scale + in_offset : 2.0f;
+        const float g1 = ng1, tvg = ntv;
+        const h2 g2 = ng2;
+        request(tile + n_groups);
+
+        // ---- what the sample's entries are made from
+        uint32_t e[8];                                   // slot << 19 | row (valid where vmask has the bit)
+        float frac[D] = {0.f, 0.f, 0.f}, tvv = 0.0f;
+        uint32_t vmask = 0u;
+        const float g2x = (float)g2.x, g2y = (float)g2.y;
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) e[c] = 0u;
+        if (!outside_unit_cube<D>(x)) {
+            const float a1 = fabsf(g1), a2 = fmaxf(fabsf(g2x), fabsf(g2y));
+            vmax1 = fmaxf(vmax1, a1 <= 3.0e38f ? a1 : 1.0f);
+            vmax2 = fmaxf(vmax2, a2 <= 3.0e38f ? a2 : 1.0f);
+            const bool bad2 = !(fabsf(g2x) <= 3.0e38f) || !(fabsf(g2y) <= 3.0e38f);
+            if ((!(a1 <= 3.0e38f) || bad2) && found_inf) *found_inf = 1.0f;
+            if (bad2) vmax2 = fmaxf(vmax2, 1.0f);
+            const bool gnz = (g1 != 0.0f) | ((__builtin_bit_cast(uint32_t, g2) & 0x7FFF7FFFu) != 0u);
+            uint32_t cell[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; ++d) {
+                const float p = x[d] * scale + (align_corners ? 0.0f : 0.5f);
+                cell[d] = (uint32_t)floorf(p);
+                frac[d] = p - (float)cell[d];
+            }
+            if (interp == 1) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (uint32_t d = 0; d < D; ++d) frac[d] = frac[d] * frac[d] * (3.0f - 2.0f * frac[d]);
+            }
+            const uint32_t sy = kPrimes[1], sz = kPrimes[2];
+            const uint32_t tx[2] = {cell[0], cell[0] + 1u};
+            const uint32_t ty0 = cell[1] * sy, tz0 = cell[2] * sz;
+            const uint32_t ty[2] = {ty0, ty0 + sy}, tz[2] = {tz0, tz0 + sz};
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c) e[c] = (tx[c & 1u] ^ ty[(c >> 1) & 1u] ^ tz[c >> 2]) & ix.mask;
+            if constexpr (TV != 0) {
+                if constexpr (TV == 1) tvv = pair_tv_value<1>(cx, ix, x, cell, e, tx, ty, tz, sy, sz);
+                else tvv = tvg;
+                const float a = fabsf(tvv);
+                vmax1 = fmaxf(vmax1, (a1 <= 3.0e38f ? a1 : 1.0f) + (a <= 3.0e38f ? a : 1.0f));
+            }
+            // a sample with a gradient delivers its eight entries, one without at most its TV term on vertex 000
+            vmask = gnz ? 0xFFu : (tvv != 0.0f ? 1u : 0u);
+        }
+        // slot of every entry inside its partition's run of this tile
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c)
+            if ((vmask >> c) & 1u) e[c] |= atomicAdd(&cnt[e[c] >> kLog2P], 1u) << kRowBits;
+        __syncthreads();                                                     // (1) counters complete
+
+        // run starts: every wave scans the <= 128 counters itself; wave 0 also reserves the runs' room in the partitions' regions
+        uint32_t total = 0, q0 = 0u, q1 = 0u, ra0 = 0u, ra1 = 0u, rs0 = 0u, rs1 = 0u;
+        {
+            const uint32_t i0 = 2u * lane, i1 = i0 + 1u;
+            const uint32_t a0 = i0 < parts ? cnt[i0] : 0u, a1c = i1 < parts ? cnt[i1] : 0u;
+            const uint32_t incl = n2m_wave_scan_add_u32(a0 + a1c, (int)lane);
+            const uint32_t s0 = incl - (a0 + a1c), s1 = s0 + a0;
+            if (i0 < parts) start[i0] = s0;
+            if (i1 < parts) start[i1] = s1;
+            total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (wid == 0u) {
+                if (!token_seen) {
+                    while (__hip_atomic_load(lm_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != lm_token) __builtin_amdgcn_s_sleep(8);
+                    token_seen = true;
+                }
+                ra0 = a0; ra1 = a1c; rs0 = s0; rs1 = s1;
+                if (a0) q0 = atomicAdd(cur_l + i0, a0);
+                if (a1c) q1 = atomicAdd(cur_l + i1, a1c);
+            }
+        }
+        {   // staging: the entries are FORMED here (pm_entries' arithmetic, association and rounding points)
+            uint32_t pos[8];
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c) pos[c] = start[(e[c] & kRowMask) >> kLog2P];      // (all eight lookups in flight)
+            const float wx[2] = {1 - frac[0], frac[0]}, wy[2] = {1 - frac[1], frac[1]}, wz[2] = {1 - frac[2], frac[2]};
+#pragma unroll
+            for (uint32_t c = 0; c < 8; ++c) {
+                if ((vmask >> c) & 1u) {
+                    const uint32_t row = e[c] & kRowMask, at = pos[c] + (e[c] >> kRowBits);
+                    const float w = (wx[c & 1u] * wy[(c >> 1) & 1u]) * wz[c >> 2];                  // forward's association
+                    float p1 = w * g1;
+                    if (TV != 0 && c == 0) p1 += tvv;
+                    float pa = w * g2x, pb = w * g2y;                                               // rounded to fp32, THEN to half (gridencoder.cu:326)
+                    asm volatile("" : "+v"(pa), "+v"(pb));
+                    h2 hp;
+                    hp.x = (_Float16)pa;
+                    hp.y = (_Float16)pb;
+                    stage_v1[at] = __float_as_uint(p1);
+                    stage_v2[at] = __builtin_bit_cast(uint32_t, hp);
+                    stage_e[at] = row + (row >> kLog2P) * (65536u - (1u << kLog2P));                // (row >> 12) << 16 | row & 4095
+                }
+            }
+        }
+        if (tid < parts) cnt_next[tid] = 0u;
+        if (tid == 0u) tile_ovf[(it & 1u) ^ 1u] = 0u;
+        if (wid == 0u) {
+            bool ovf_here = false;
+            auto finish = [&](uint32_t i, uint32_t a, uint32_t s, uint32_t q) {
+                if (a == 0u) return;
+                delta[i] = region0 + i * cap + q - s;
+                if (q + a > cap) {
+                    ovfb[i] = atomicAdd(ovf_cursor, min(a, q + a - cap));
+                    ovf_here = true;
+                }
+            };
+            finish(2u * lane, ra0, rs0, q0);
+            finish(2u * lane + 1u, ra1, rs1, q1);
+            if (__ballot(ovf_here) != 0ull && lane == 0u) tile_ovf[it & 1u] = 1u;
+        }
+        __syncthreads();                                                     // (2) tile staged, regions reserved
+
+        if (tile_ovf[it & 1u] == 0u) {
+            uint32_t ce[8], cv1[8], cv2[8], cd[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) {
+                const uint32_t i = tid + q * TS;
+                ce[q] = 0u; cv1[q] = 0u; cv2[q] = 0u;
+                if (i < total) { ce[q] = stage_e[i]; cv1[q] = stage_v1[i]; cv2[q] = stage_v2[i]; }
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) cd[q] = delta[ce[q] >> 16] + tid + q * TS;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q)
+                if (tid + q * TS < total) {
+                    if (log_v1) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(log_v1) + (cd[q] << 2)) = cv1[q];
+                    if (log_v2) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(log_v2) + (cd[q] << 2)) = cv2[q];
+                    *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(log_rel) + (cd[q] << 1)) = (uint16_t)ce[q];
+                }
+        } else {
+            for (uint32_t i = tid; i < total; i += TS) {
+                const uint32_t ee = stage_e[i], p = ee >> 16;
+                const uint32_t st = start[p];
+                const uint32_t qr = delta[p] + st - (region0 + p * cap);
+                const uint32_t qi = qr + (i - st);
+                if (qi < cap) {
+                    const uint32_t d = delta[p] + i;
+                    if (log_v1) log_v1[d] = stage_v1[i];
+                    if (log_v2) log_v2[d] = stage_v2[i];
+                    log_rel[d] = (uint16_t)ee;
+                } else {
+                    const uint32_t o = ovfb[p] + qi - max(qr, cap);
+                    if (o < pm.ovf_cap) {
+                        ovf_key[o] = (level << 27) | ee;
+                        if (ovf_v1) ovf_v1[o] = stage_v1[i];
+                        if (ovf_v2) ovf_v2[o] = stage_v2[i];
+                    }
+                }
+            }
+        }
         // no barrier here: the next tile writes the stage / start / delta only after its barrier (1)
     }
 
@@ -3449,6 +3705,47 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
         N2M_REQUIRE(perm == nullptr || (B <= kBinChunk && !fold && in_level_stride == 0), N2M_EUNSUPPORTED,
                     "%s: a sample order (n2m_grid_backward_sample_order) needs one pass (B <= %u), one point list and no folded copies", fn, kBinChunk);
         int rc;
+        // Fine levels (8..15) through pm_fill_fine_kernel at three workgroups per CU, the coarse levels through the general kernel behind it
+        // (same stream; it continues the fill: no clear, same token).  Covers the standard table (16 levels, the upper eight hashed with
+        // 2..128 partitions each), 512-sample tiles, no folded copies, no sample order, no measurement switches; level 8 then goes unmerged
+        // (its same-cell runs were merged by the general kernel: +4 % log entries, one rounding fewer).  N2M_PM_SPLIT=0: the one-kernel fill.
+        static const bool split_env = getenv("N2M_PM_SPLIT") == nullptr || atoi(getenv("N2M_PM_SPLIT")) != 0;
+        bool fine = split_env && TS == 512u && xcd_map && max_level == 16u && gridtype == 0u && !fold && perm == nullptr && g_fill_dbg_host == 0u &&
+                    merge_levels <= 9u && lay.plan.tiles >= 8u;
+        for (uint32_t l = 8; fine && l < 16u; ++l) {
+            const uint64_t R = align ? lv.resolution[l] : lv.resolution[l] + 1u;
+            const uint32_t sz = lay.plan.size[l];
+            fine = R * R * R > sz && (sz & (sz - 1u)) == 0u && sz <= (1u << 19) && lay.plan.parts[l] >= 2u && lay.plan.parts[l] <= 128u &&
+                   lay.plan.parts[l] * kPairP == sz;
+        }
+        if (fine) {
+            static bool attr_fine = false;
+            if (!attr_fine) {
+                const int capb = 160 * 1024 - 1024;
+                (void)hipFuncSetAttribute((const void*)pm_fill_fine_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, capb);
+                (void)hipFuncSetAttribute((const void*)pm_fill_fine_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, capb);
+                (void)hipFuncSetAttribute((const void*)pm_fill_fine_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, capb);
+                attr_fine = true;
+            }
+            static const uint32_t fine_groups = getenv("N2M_PM_FINE_GROUPS") ? (uint32_t)atoi(getenv("N2M_PM_FINE_GROUPS")) : 96u;      // 3 workgroups x 32 CUs of an XCD
+            if (half != 2) {
+                const uint32_t gx = lay.plan.tiles < fine_groups ? lay.plan.tiles : fine_groups;
+                const size_t lds_f = (size_t)512u * 8u * 12u + (size_t)128u * 5u * 4u;
+#define N2M_PM_FINE_ARGS g1, g2, x, tv, tvt, Bc, B, lay.plan, pl.pm, lv, align, interp, level_max, cursors, ovf_cursor, log_rel, log_v1, log_v2, ovf_key, ovf_v1, \
+                         ovf_v2, found_inf, in_scale, in_offset, gx, 8u, lm_ready, lm_token, in_level_stride
+                if (tvmode == 1) N2M_LAUNCH((pm_fill_fine_kernel<1>), dim3(8u * gx), 512, lds_f, s, N2M_PM_FINE_ARGS);
+                else if (tvmode == 2) N2M_LAUNCH((pm_fill_fine_kernel<2>), dim3(8u * gx), 512, lds_f, s, N2M_PM_FINE_ARGS);
+                else N2M_LAUNCH((pm_fill_fine_kernel<0>), dim3(8u * gx), 512, lds_f, s, N2M_PM_FINE_ARGS);
+#undef N2M_PM_FINE_ARGS
+                N2M_CHECK_LAUNCH();
+            }
+            if (half == 0) {                 // the coarse half through the general kernel: slot 1 of the paired mapping = levels 0..7, continuing
+                slot_begin = 1u | 0x80000000u;
+                grid = dim3(8u * groups_x, 1);
+            }
+        }
+        if (fine && half == 1) rc = 0;
+        else
 #define N2M_PM_CALL(TSV) launch_pm_fill<TSV>(grid, lds, s, fold != nullptr, tvmode, g1, g2, x, tv, tvt, Bc, B, lay.plan, pl.pm, lv, gridtype, align, interp, level_max, \
                                              cursors, ovf_cursor, log_rel, log_v1, log_v2, ovf_key, ovf_v1, ovf_v2, found_inf, in_scale, in_offset,                   \
                                              ow ? table1 : nullptr, ow ? table2 : nullptr, cm1, cm2, merge_levels, groups_x, slot_begin, lm_ready, lm_token,      \

@@ -886,18 +886,16 @@ class Stage0Engine:
             if self.marker_at == 1:
                 self._marker = torch.cuda.Event(); self._marker.record()
             if order and fused is None:
-                L.call("n2m_grid_backward_sample_order", _p(w["perm"]))
                 plain_backward = backward
 
-                def backward(half, _b=plain_backward):
-                    done = False
+                def backward(half, _b=plain_backward, _perm=w["perm"]):
+                    # the order is a sticky thread-local of the library: set right in front of the call it is meant for, cleared behind it
+                    # whatever happens in between (an exception must not leave a stale pointer for the next backward of this thread)
+                    L.call("n2m_grid_backward_sample_order", _p(_perm))
                     try:
-                        r = _b(half)
-                        done = True
-                        return r
+                        return _b(half)
                     finally:
-                        if half != 1 or not done:          # (1 = the fine half of a two-call backward: the coarse half follows)
-                            L.call("n2m_grid_backward_sample_order", None)
+                        L.call("n2m_grid_backward_sample_order", None)
             if self.peer is not None:
                 # the flush of each level half stores its rows into their owners' slots; the signal behind it is the whole exchange
                 self.peer.begin_step()
