@@ -232,7 +232,7 @@ def measured_stream_peak(device, mbytes=1024, reps=20):
     return best
 
 
-def dropin_reference_loop(device, steps=50, warmup=20, pretrain=300):
+def dropin_reference_loop(device, steps=50, warmup=20, pretrain=300, fused_field=False, return_losses=False):
     """What a reference user gets by putting nerf2mesh_amd/backends/_*.py on sys.path and changing nothing else: the reference's OWN
     `Trainer.train_step` / `post_train_step` (nerf/utils.py:628-823) inside the loop of `train_one_epoch` (:1152-1180: occupancy refresh every
     16 steps, zero_grad, scaler.scale(loss).backward(), TV, scaler.step, scaler.update, LambdaLR step, loss.item()) with main.py:221's
@@ -247,6 +247,9 @@ def dropin_reference_loop(device, steps=50, warmup=20, pretrain=300):
         return {"value": None, "note": "reference Python not available on this box (oracle/_ref/pyref not built)"}
     ns = RP.load("hip")
     RP.use_backend("hip")
+    if fused_field:      # opt-in: the fused MFMA field behind the unchanged class (`install(fused_mlp=True)`)
+        from nerf2mesh_amd import backends
+        backends.fuse_field(ns.network.NeRFNetwork)
     torch.manual_seed(0)
     d = dict(vars(RP.reference_opt()))
     d.update(vars(make_options(O=True, bound=1, dt_gamma=0, iters=30000)))
@@ -266,6 +269,8 @@ def dropin_reference_loop(device, steps=50, warmup=20, pretrain=300):
     model.train()
     samples = rays = 0
 
+    losses = []
+
     def step():
         nonlocal samples, rays
         if me.global_step % opt.update_extra_interval == 0:                                               # nerf/utils.py:1155-1156
@@ -280,7 +285,7 @@ def dropin_reference_loop(device, steps=50, warmup=20, pretrain=300):
         me.scaler.step(optimizer)
         me.scaler.update()
         scheduler.step()
-        loss.item()                                                                                       # :1182 (the loop's host read-back)
+        losses.append(loss.item())                                                                        # :1182 (the loop's host read-back)
         samples += int(me.tmp_xyzs.shape[0]) if me.tmp_xyzs is not None else 0
         rays += n
     for _ in range(pretrain + warmup):
@@ -294,6 +299,9 @@ def dropin_reference_loop(device, steps=50, warmup=20, pretrain=300):
     dt = time.perf_counter() - t0
     return {"ms_per_step": 1e3 * dt / steps, "value": samples / dt, "unit": "samples/s", "rays_per_sec": rays / dt, "steps": steps,
             "samples_per_step": samples / steps, "first_timed_step": pretrain + warmup + 1,
+            **({"losses": losses} if return_losses else {}),
+            "field": ("fused MFMA field behind the unchanged NeRFNetwork (backends.fuse_field, opt-in)" if fused_field else
+                      "the reference's own nn.Linear graph"),
             "what": "the reference's unchanged Python (Trainer.train_step / post_train_step, render, NeRFNetwork, autograd wrappers; byte-compiled copy "
                     "oracle/_ref/pyref) + torch.optim.Adam + GradScaler over nerf2mesh_amd/backends/_*.py (libn2m_hip.so): the drop-in path of "
                     "INTEGRATION.md section A, nothing fused, nothing restated; shading "
@@ -415,6 +423,85 @@ def bench_stage1(args, rank, world, device):
         dist.destroy_process_group()
 
 
+def bench_pipeline(args, device):
+    """BASELINE config 5 end to end on one GPU (scripts/runall_syn_sdf.sh:1-2): `--sdf` stage 0 (short schedule: iters0 steps, the ramps of
+    nerf/utils.py:651-655 over its first half) -> export_stage0 (density volume -> device marching cubes at the zero level of the sdf,
+    nerf/renderer.py:472-545 without the pymeshlab cleaning / decimation: SURVEY section 2 OUT) -> stage 1 WITHOUT --sdf on that mesh (the
+    stage-0 weights stay, nerf/utils.py:585-588), step executor -> PSNR of the stage-1 RASTER render against the analytic ground truth.
+    One JSON line: wall time and throughput per phase + both PSNRs."""
+    import tempfile
+    from nerf2mesh_amd import export, synthetic
+    from nerf2mesh_amd.engine import Stage0Engine
+    from nerf2mesh_amd.engine_stage1 import Stage1Engine
+    from nerf2mesh_amd.network import NeRFNetwork
+    from nerf2mesh_amd.options import make_options
+    from nerf2mesh_amd.trainer import Stage1Trainer
+    it0, it1, res = int(args.pipeline_iters0), int(args.pipeline_iters1), int(args.pipeline_resolution)
+    torch.manual_seed(0)
+    opt = make_options(O=True, bound=1, dt_gamma=0, sdf=True, iters=it0, fused_mlp=True)
+    poses = synthetic.make_cameras(100, seed=0)
+    model = NeRFNetwork(opt)
+    t0 = time.perf_counter()
+    model.to(device).init_double_sphere(iters=1024)              # (nerf/utils.py:594; the reference runs 8192 such steps)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t0
+    eng = Stage0Engine(model, opt, poses, device, seed=0)
+    eng.mark_untrained()
+    eng.train_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(it0 - 1):
+        eng.train_step()
+    torch.cuda.synchronize()
+    t_s0 = time.perf_counter() - t0
+    psnr0 = [eng.eval_psnr(cam=c, use_ema=True) for c in (0, 33, 66)]
+    phases = {"stage0 (--sdf, step executor)": {"steps": it0, "wall_s": t_s0, "ms_per_step": 1e3 * t_s0 / (it0 - 1), "samples_per_sec": eng.samples_seen / t_s0,
+                                               "rays_per_sec": eng.rays_seen / t_s0, "psnr_volume_render_ema_quarter_res": sum(psnr0) / len(psnr0),
+                                               "sdf_pretraining_s": t_init}}
+    with tempfile.TemporaryDirectory() as tmp:
+        with eng.averaged_parameters():                          # the reference exports from the best (EMA) checkpoint
+            t0 = time.perf_counter()
+            meshes = model.export_stage0(os.path.join(tmp, "mesh_stage0"), resolution=res)
+            torch.cuda.synchronize()
+            t_ex = time.perf_counter() - t0
+        v, f = meshes[0]
+        phases["export_stage0 (device marching cubes)"] = {"wall_s": t_ex, "resolution": res, "vertices": int(v.shape[0]), "faces": int(f.shape[0]),
+                                                            "note": "raw iso-surface: clean_mesh / decimate_mesh (pymeshlab) are out of scope"}
+        rv, rt = export.read_ply(os.path.join(tmp, "mesh_stage0", "mesh_0.ply"))
+    if rt.shape[0] == 0:
+        print(json.dumps({"metric": "pipeline", "value": None, "error": "the stage-0 iso-surface is empty", "phases": phases}))
+        return
+    # stage 1 runs WITHOUT --sdf (runall_syn_sdf.sh:2): main.py's plain -O options on the stage-0 weights (nerf/utils.py:585-588 loads them model_only)
+    opt = make_options(O=True, bound=1, dt_gamma=0, stage=1, iters=max(it1, 501), fused_mlp=True)
+    model.opt = opt
+    tr = Stage1Trainer(model, opt, poses, torch.from_numpy(rv), torch.from_numpy(rt), device)
+    stepper = Stage1Engine(tr) if Stage1Engine.supported(tr) else tr
+    stepper.train_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(it1 - 1):
+        stepper.train_step()
+    torch.cuda.synchronize()
+    t_s1 = time.perf_counter() - t0
+    # PSNR of the RASTER render (what stage 1 ships), white background, full resolution
+    model.eval()
+    ps = []
+    with torch.no_grad():
+        for vw in (0, 33, 66):
+            rays_o, rays_d, rgba = tr._view(vw)
+            with torch.autocast("cuda", dtype=torch.float16):
+                out = model.render_stage1(rays_o, rays_d, tr.mvps[vw], tr.H, tr.W, bg_color=1, shading="full")
+            gt = rgba[..., :3] * rgba[..., 3:] + (1 - rgba[..., 3:])
+            ps.append(float(-10 * torch.log10(torch.mean((out["image"].reshape(-1, 3).float() - gt.reshape(-1, 3)) ** 2))))
+    phases["stage1 (raster refinement, step executor)" if stepper is not tr else "stage1 (raster refinement, autograd trainer)"] = {
+        "steps": it1, "wall_s": t_s1, "ms_per_step": 1e3 * t_s1 / (it1 - 1), "output_px_per_sec": 800 * 800 * (it1 - 1) / t_s1, "psnr_raster_render_full_res": sum(ps) / len(ps)}
+    total = t_init + t_s0 + t_ex + t_s1
+    print(json.dumps({"metric": "pipeline_wall_seconds", "value": total, "unit": "s", "n_gpus": 1, "higher_is_better": False, "data": "synthetic",
+                      "config": {"workload": f"nerf_synthetic/lego --sdf stage 0 ({it0} steps) -> export_stage0 ({res}^3) -> stage 1 ({it1} steps), -O --bound 1 --dt_gamma 0, "
+                                             "800x800 x 100 synthetic views, one GPU (BASELINE config 5's pipeline at a short schedule)"},
+                      "phases": phases, "psnr_stage0_volume": sum(psnr0) / len(psnr0), "psnr_stage1_raster": sum(ps) / len(ps)}))
+
+
 def other_configs(timeout_s=180, budget_s=480):
     """BASELINE configs 3, 4, 5 and the drop-in path, measured by this same script in child processes behind the headline window (rank 0, one
     GPU; ~50 timed steps each after the recipe's own pre-training): driver-visible evidence for what the headline line does not cover.
@@ -424,7 +511,9 @@ def other_configs(timeout_s=180, budget_s=480):
     runs = {"sdf (config 5, stage 0, end of the schedule)": ["--recipe", "sdf", "--steps", "48", "--warmup", "8"],
             "garden (config 4's recipe)": ["--recipe", "garden", "--steps", "48", "--warmup", "8"],
             "stage1 (config 3)": ["--stage", "1", "--steps", "50", "--warmup", "10"],
-            "dropin (unchanged reference Python over backends/_*.py, config 2's recipe)": ["--dropin", "--steps", "48", "--warmup", "16"]}
+            "dropin (unchanged reference Python over backends/_*.py, config 2's recipe)": ["--dropin", "--steps", "48", "--warmup", "16"],
+            "dropin + opt-in fused field (backends.install(fused_mlp=True))": ["--dropin-fused", "--steps", "48", "--warmup", "16"],
+            "pipeline (config 5 end to end, short schedule)": ["--pipeline"]}
     out = {}
     t_all = time.perf_counter()
     for name, extra in runs.items():
@@ -446,7 +535,10 @@ def other_configs(timeout_s=180, budget_s=480):
                          "rays_per_sec": j.get("rays_per_sec"), "workload": (j.get("config") or {}).get("workload"),
                          "driver": (j.get("config") or {}).get("driver"), "sdf_schedule": (j.get("config") or {}).get("sdf_schedule"),
                          "dominant_kernel": {"kernel": roof.get("kernel"), "avg_us": roof.get("avg_us"), "frac": roof.get("frac")} if roof else None,
-                         "what": j.get("what"), "wall_s": round(time.perf_counter() - t0, 1), "command": "python bench.py " + " ".join(extra)}
+                         "what": j.get("what"), "field": j.get("field"), "phases": j.get("phases"), "psnr_stage0_volume": j.get("psnr_stage0_volume"),
+                         "psnr_stage1_raster": j.get("psnr_stage1_raster"),
+                         "wall_s": round(time.perf_counter() - t0, 1), "command": "python bench.py " + " ".join(extra)}
+            out[name] = {k: v for k, v in out[name].items() if v is not None}
         except Exception as e:        # a reported extra: never lose the headline over it
             out[name] = {"error": repr(e)[:400]}
     return out
@@ -526,6 +618,11 @@ def _main():
     ap.add_argument("--no-other-configs", action="store_true", help="do not append `other_configs` (BASELINE configs 3, 4, 5 and the drop-in path, each "
                     "~50 timed steps in a child process behind the headline window) and `long_run` (192 more steps) to the default line")
     ap.add_argument("--dropin", action="store_true", help="time the drop-in path instead: the reference's unchanged Python over backends/_*.py (dropin_reference_loop)")
+    ap.add_argument("--pipeline", action="store_true", help="BASELINE config 5 end to end on one GPU at a short schedule: --sdf stage 0 -> export_stage0 -> stage 1 -> PSNR")
+    ap.add_argument("--pipeline-iters0", type=int, default=2000)
+    ap.add_argument("--pipeline-iters1", type=int, default=400)
+    ap.add_argument("--pipeline-resolution", type=int, default=256)
+    ap.add_argument("--dropin-fused", action="store_true", help="--dropin with backends.install(fused_mlp=True): the fused MFMA field behind the unchanged NeRFNetwork")
     args = ap.parse_args()
 
     from nerf2mesh_amd import _lib, synthetic
@@ -584,12 +681,16 @@ def _main():
         assert float(probe[0]) == world * (world + 1) / 2, f"all-reduce probe returned {float(probe[0])}"
         _phase("model + pre-training", 900 * slack)
 
+    if args.pipeline:
+        return bench_pipeline(args, device)
     if args.stage == 1:
         return bench_stage1(args, rank, world, device)
-    if args.dropin:
-        r = dropin_reference_loop(device, steps=args.steps, warmup=args.warmup, pretrain=1000 if args.pretrain is None or args.pretrain >= 1000 else args.pretrain)
+    if args.dropin or args.dropin_fused:
+        r = dropin_reference_loop(device, steps=args.steps, warmup=args.warmup, pretrain=1000 if args.pretrain is None or args.pretrain >= 1000 else args.pretrain,
+                                  fused_field=args.dropin_fused)
         print(json.dumps({"metric": "train_samples_per_sec", "unit": "samples/s", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
-                          "config": {"workload": "nerf_synthetic/lego stage-0 -O --bound 1 --dt_gamma 0 -- the reference's unchanged Python over the drop-in backends"}, **r}))
+                          "config": {"workload": "nerf_synthetic/lego stage-0 -O --bound 1 --dt_gamma 0 -- the reference's unchanged Python over the drop-in backends"
+                                                 + (" + the opt-in fused field (backends.install(fused_mlp=True))" if args.dropin_fused else "")}, **r}))
         return
 
     torch.manual_seed(0)                                           # seed_everything(0), identical init on every rank

@@ -3705,11 +3705,16 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
         N2M_REQUIRE(perm == nullptr || (B <= kBinChunk && !fold && in_level_stride == 0), N2M_EUNSUPPORTED,
                     "%s: a sample order (n2m_grid_backward_sample_order) needs one pass (B <= %u), one point list and no folded copies", fn, kBinChunk);
         int rc;
-        // Fine levels (8..15) through pm_fill_fine_kernel at three workgroups per CU, the coarse levels through the general kernel behind it
-        // (same stream; it continues the fill: no clear, same token).  Covers the standard table (16 levels, the upper eight hashed with
-        // 2..128 partitions each), 512-sample tiles, no folded copies, no sample order, no measurement switches; level 8 then goes unmerged
-        // (its same-cell runs were merged by the general kernel: +4 % log entries, one rounding fewer).  N2M_PM_SPLIT=0: the one-kernel fill.
-        static const bool split_env = getenv("N2M_PM_SPLIT") == nullptr || atoi(getenv("N2M_PM_SPLIT")) != 0;
+        // [round 6, MEASURED AND REJECTED -- off by default, N2M_PM_SPLIT=1 turns it on] Fine levels (8..15) through pm_fill_fine_kernel at three
+        // workgroups per CU, the coarse levels through the general kernel behind it (same stream; it continues the fill: no clear, same
+        // token).  Covers the standard table (16 levels, the upper eight hashed with 2..128 partitions each), 512-sample tiles, no folded
+        // copies, no sample order, no measurement switches; level 8 then goes unmerged.  Measured (ABBA on one box, profiles/r06_fill_split.txt):
+        // backward 207.6 -> 224.8 us.  By kernel: fine levels alone 87.8 us at 96 workgroups per XCD (3 per CU), 92.3 at 64 (2 per CU), 102.6
+        // at 48, 98.9 at 128 -- a third resident workgroup buys 5 %, i.e. the fine levels are NOT bound by their waits but by what eight
+        // levels' worth of scattered requests cost their XCD's L2 (six TV stencil gathers per sample and level + the log's run stores); the
+        // coarse levels alone take 86-88 us at two workgroups per CU, and the one-kernel fill (158.5 us in the same trace) wins because a
+        // fine and a coarse workgroup SHARE each CU: different bottlenecks side by side.
+        static const bool split_env = getenv("N2M_PM_SPLIT") != nullptr && atoi(getenv("N2M_PM_SPLIT")) != 0;
         bool fine = split_env && TS == 512u && xcd_map && max_level == 16u && gridtype == 0u && !fold && perm == nullptr && g_fill_dbg_host == 0u &&
                     merge_levels <= 9u && lay.plan.tiles >= 8u;
         for (uint32_t l = 8; fine && l < 16u; ++l) {

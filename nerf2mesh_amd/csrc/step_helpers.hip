@@ -366,6 +366,9 @@ get_rays_kernel(const float* __restrict__ poses /*[V,4,4]*/, const int64_t* __re
 // can refresh an fp16 shadow copy of a table in the same pass (the colour table is consumed as fp16 by the encoder, grid.py:45).
 // A one-thread kernel then does GradScaler.update() and the step count.  Math as in torch's fused kernel:
 //   g = grad / scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+#ifndef N2M_ADAM_NT_ALL
+#define N2M_ADAM_NT_ALL 0
+#endif
 struct AdamTensors {
     uint64_t p[N2M_ADAM_MAX], g[N2M_ADAM_MAX], m[N2M_ADAM_MAX], v[N2M_ADAM_MAX], shadow[N2M_ADAM_MAX];
     uint32_t n[N2M_ADAM_MAX], first_block[N2M_ADAM_MAX + 1];
@@ -459,14 +462,23 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
 #pragma unroll
         for (uint32_t e = 0; e < 2; ++e) {
             if (r0 + e >= n1) continue;
+#if N2M_ADAM_NT_ALL      // every pure stream of the pass bypasses the caches; only the packed rows (what the next lookup gathers) allocate
+            p1[e] = __builtin_nontemporal_load(P1 + r0 + e); m1v[e] = __builtin_nontemporal_load(M1 + r0 + e); v1v[e] = __builtin_nontemporal_load(V1 + r0 + e);
+#else
             p1[e] = P1[r0 + e]; m1v[e] = M1[r0 + e]; v1v[e] = V1[r0 + e];
+#endif
             if (PEER && pe.entry[pk] >= 0) {               // (fp32 [rows,1] table: one value per row and slot)
                 float a = 0.0f;
                 for (uint32_t sl = 0; sl < pe.world; ++sl) a += __uint_as_float(peer_load32(reinterpret_cast<const float*>(pe.slots[pe.entry[pk]][sl]) + r0 + e));
                 g1v[e] = a;
                 continue;
             }
+#if N2M_ADAM_NT_ALL
+            g1v[e] = g1_half ? (float)__builtin_nontemporal_load(reinterpret_cast<const _Float16*>(t.g[pk]) + r0 + e)
+                             : __builtin_nontemporal_load(reinterpret_cast<const float*>(t.g[pk]) + r0 + e);
+#else
             g1v[e] = g1_half ? (float)reinterpret_cast<const _Float16*>(t.g[pk])[r0 + e] : reinterpret_cast<const float*>(t.g[pk])[r0 + e];
+#endif
         }
     }
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -496,10 +508,19 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
             for (uint32_t e = 0; e < 4; ++e) g[e] = g_half ? (float)(_Float16)a[e] : a[e];
         } else if (g_half) {
             typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+#if N2M_ADAM_NT_ALL
+            const h4v gg = __builtin_nontemporal_load(reinterpret_cast<const h4v*>(reinterpret_cast<const _Float16*>(t.g[k]) + i0));
+#else
             const h4v gg = *reinterpret_cast<const h4v*>(reinterpret_cast<const _Float16*>(t.g[k]) + i0);
+#endif
             g[0] = (float)gg.x; g[1] = (float)gg.y; g[2] = (float)gg.z; g[3] = (float)gg.w;
         } else {
+#if N2M_ADAM_NT_ALL
+            const f4v gg = clear_g ? *reinterpret_cast<const f4v*>(reinterpret_cast<const float*>(t.g[k]) + i0)
+                                   : __builtin_nontemporal_load(reinterpret_cast<const f4v*>(reinterpret_cast<const float*>(t.g[k]) + i0));
+#else
             const float4 gg = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(t.g[k]) + i0);
+#endif
             g[0] = gg.x; g[1] = gg.y; g[2] = gg.z; g[3] = gg.w;
         }
     } else {
@@ -549,7 +570,11 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
             const float m1 = beta1 * m1v[e] + omb1 * gr;
             const float v1 = beta2 * v1v[e] + omb2 * gr * gr;
             q[e] = p1[e] - step1 * m1 / (sqrtf(v1) / bc2p_sqrt + eps);
+#if N2M_ADAM_NT_ALL
+            __builtin_nontemporal_store(q[e], P1 + r0 + e); __builtin_nontemporal_store(m1, M1 + r0 + e); __builtin_nontemporal_store(v1, V1 + r0 + e);
+#else
             P1[r0 + e] = q[e]; M1[r0 + e] = m1; V1[r0 + e] = v1;
+#endif
         }
         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
         h2v c0, c1;

@@ -131,6 +131,18 @@ def shard_refresh_default():
     return dist.is_initialized() and dist.get_backend() == "nccl"
 
 
+def all_ranks_hold(summary, world):
+    """True on EVERY rank iff every rank passed the same `summary` (a small 1-D integer tensor); a collective all ranks must enter together.
+    The sharded occupancy refresh decides with it, at every refresh, whether the ranks hold the same lists of cells (renderer.update_extra_state):
+    the decision is made from the gathered summaries, i.e. identically everywhere -- no rank ever falls back (or stays) on its own.
+    (gloo wants a flat output tensor; RCCL takes either.)"""
+    flat = summary.reshape(-1)
+    out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(out, flat)
+    every = out.view(world, -1).cpu()                      # one host read per refresh (every 16 steps)
+    return bool((every == every[:1]).all())
+
+
 def shard_views(n_views, rank, world):
     """Stage-1 sharding: views rank, rank+world, ... (one full image per rank per step)."""
     return list(range(rank, n_views, world))

@@ -373,17 +373,14 @@ class NeRFRenderer(nn.Module):
             # (count, index sum), recomputed only when its own list was rebuilt -- is all-gathered (a few dozen bytes) and read on the host;
             # any difference (a rank-local write to density_grid: a checkpoint loaded on rank 0 only, a reset, a mark) puts EVERY rank on
             # the replicated query for this refresh.  One small collective + one host read per 16 steps; no rank ever decides alone.
-            import torch.distributed as dist
+            from .parallel import all_ranks_hold
             if st.get("summary_key") != key:
                 vals = []
                 for v in st["valid"]:
                     vals += [-1, 0] if v is None else [int(v[0].numel()), int(v[1].sum())]
                 st["summary_key"] = key
                 st["summary"] = torch.tensor(vals, dtype=torch.int64, device=dev)
-                st["summary_all"] = torch.empty(shard[1], len(vals), dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(st["summary_all"], st["summary"])
-            every = st["summary_all"].cpu()
-            st["shard_ok"] = bool((every == every[0:1]).all())
+            st["shard_ok"] = all_ranks_hold(st["summary"], shard[1])
             if not st["shard_ok"]:
                 shard = None
         for cas in range(self.cascade):

@@ -88,7 +88,7 @@ def initial_state(recipe, seed, steps, device):
 
 
 # ----------------------------------------------------------------------------------------------------------------- (a) the reference loop
-def train_reference(recipe, seed, steps, poses, images, init, device, log=None, draw_seed=None):
+def train_reference(recipe, seed, steps, poses, images, init, device, log=None, draw_seed=None, fused_field=False):
     """Returns (model state_dict, EMA shadow list in model.parameters() order, wall seconds).  draw_seed: seed of everything random about the
     batches (pixels, background colours, march jitter, refresh jitter); default = `seed`."""
     draw_seed = seed if draw_seed is None else draw_seed
@@ -98,6 +98,9 @@ def train_reference(recipe, seed, steps, poses, images, init, device, log=None, 
     assert RP.available(), "reference Python not available (neither /root/reference nor oracle/_ref/pyref)"
     ns = RP.load("hip")
     RP.use_backend("hip")
+    from nerf2mesh_amd import backends
+    # (triangulation aid: the same unchanged loop with the opt-in fused MFMA field behind the unchanged class, backends.fuse_field)
+    (backends.fuse_field if fused_field else backends.unfuse_field)(ns.network.NeRFNetwork)
     torch.manual_seed(draw_seed)
     d = dict(vars(RP.reference_opt()))
     d.update(vars(make_opt(recipe, steps, fused=False)))
@@ -159,7 +162,14 @@ def train_reference(recipe, seed, steps, poses, images, init, device, log=None, 
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     names = [n for n, p in model.named_parameters() if p.requires_grad]
     shadow = {n: s.clone() for n, s in zip(names, ema.shadow_params)}
+    # optimizer steps actually TAKEN (GradScaler skips a step whose gradients hold an inf / nan) and the loss scale the run ended at
+    st = optimizer.state[model.encoder.embeddings]
+    backends.unfuse_field(ns.network.NeRFNetwork)
+    DIAG["reference-fused" if fused_field else "reference"] = {"adam_steps_taken": int(st["step"]) if "step" in st else 0, "loss_scale": float(me.scaler.get_scale()), "num_rays": int(opt.num_rays)}
     return sd, shadow, wall
+
+
+DIAG = {}
 
 
 # ----------------------------------------------------------------------------------------------------------------------- (b) the executor
@@ -186,6 +196,33 @@ def train_engine(recipe, seed, steps, poses, init, device, log=None):
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     names = [n for n, p in model.named_parameters() if p.requires_grad]
     shadow = {n: s.clone() for n, s in zip(names, eng.ema.shadow_params)}
+    o = eng.optimizer
+    DIAG["engine"] = {"adam_steps_taken": int(o.steps.max()) if hasattr(o, "steps") else None, "loss_scale": float(o.scale), "num_rays": int(eng.num_rays)}
+    return sd, shadow, wall
+
+
+def train_trainer(recipe, seed, steps, poses, init, device, log=None):
+    """(triangulation aid) trainer.Stage0Trainer: the executor's kernels driven through torch.autograd."""
+    from nerf2mesh_amd import synthetic
+    from nerf2mesh_amd.network import NeRFNetwork
+    from nerf2mesh_amd.trainer import Stage0Trainer
+    torch.manual_seed(seed)
+    opt = make_opt(recipe, steps, fused=True)
+    model = NeRFNetwork(opt)
+    if recipe == "garden":
+        model.update_aabb(synthetic.pts_aabb("garden"))
+    model = model.to(device)
+    model.load_state_dict(init, strict=True)
+    tr = Stage0Trainer(model, opt, poses, device, seed=seed, ema_decay=EMA_DECAY)
+    tr.mark_untrained()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        tr.train_step()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    shadow = {n: s.clone() for n, s in zip(names, tr.ema.shadow_params)}
     return sd, shadow, wall
 
 
@@ -255,10 +292,15 @@ def run(recipe="lego", seeds=3, steps=2000, views=8, train_views=100, paths=("re
             log(f"  seed {s}: {path} ...")
             if path == "reference":
                 sd, sh, wall = train_reference(recipe, s, steps, poses, images, init, device, log)
+            elif path == "reference-fused":
+                sd, sh, wall = train_reference(recipe, s, steps, poses, images, init, device, log, fused_field=True)
+            elif path == "trainer":
+                sd, sh, wall = train_trainer(recipe, s, steps, poses, init, device, log)
             else:
                 sd, sh, wall = train_engine(recipe, s, steps, poses, init, device, log)
             ev = evaluate(recipe, steps, sd, sh, held_out, device)
-            row[path] = {"psnr_ema": ev["ema"], "psnr_raw": ev["raw"], "train_wall_s": wall, "ms_per_step": 1e3 * wall / steps}
+            row[path] = {"psnr_ema": ev["ema"], "psnr_raw": ev["raw"], "train_wall_s": wall, "ms_per_step": 1e3 * wall / steps, **DIAG.get(path, {})}
+            log(f"  seed {s}: {path}: optimizer steps taken {row[path].get('adam_steps_taken')} of {steps}, final loss scale {row[path].get('loss_scale')}")
             log(f"  seed {s}: {path}: PSNR (EMA weights) {sum(ev['ema']) / views:.3f} dB, (raw) {sum(ev['raw']) / views:.3f} dB, {1e3 * wall / steps:.2f} ms/step")
             if path == "reference" and reference_redraw:
                 sd2, sh2, _ = train_reference(recipe, s, steps, poses, images, init, device, draw_seed=s + 1000)
@@ -288,6 +330,13 @@ def run(recipe="lego", seeds=3, steps=2000, views=8, train_views=100, paths=("re
             dif = [sum(r["engine"][kind]) / views - sum(r["reference"][kind]) / views for r in res["runs"]]
             m, se = mean_se(dif)
             summ[f"delta_{kind}"] = {"mean": m, "se": se, "per_seed": dif}
+    for other in paths:
+        if other in ("reference", "engine") or "reference" not in paths:
+            continue
+        for kind in ("psnr_ema", "psnr_raw"):
+            dif = [sum(r[other][kind]) / views - sum(r["reference"][kind]) / views for r in res["runs"]]
+            m, se = mean_se(dif)
+            summ[f"{other}_minus_reference_{kind}"] = {"mean": m, "se": se, "per_seed": dif}
     if reference_redraw and "reference" in paths:
         for kind in ("psnr_ema", "psnr_raw"):
             dif = [sum(r["reference_redraw"][kind]) / views - sum(r["reference"][kind]) / views for r in res["runs"]]
@@ -306,14 +355,17 @@ def format_table(res):
     lines = [f"run parity -- recipe {res['recipe']}, {res['seeds']} seed(s) x {res['steps']} steps, {res['train_views']} training views, "
              f"{v} held-out 800x800 views, one inference path (nerf2mesh_amd renderer, eval mode)",
              "PSNR in dB against the analytic ground truth; EMA = averaged weights (decay 0.95, one update per epoch), raw = last iterate", ""]
-    paths = [p for p in ("reference", "engine") if p in res["runs"][0]]
-    lines.append("seed | " + " | ".join(f"{p:>9} EMA   raw  ms/step" for p in paths) + (" | delta EMA  delta raw" if len(paths) == 2 else ""))
+    paths = [p for p in ("reference", "engine", "reference-fused", "trainer") if p in res["runs"][0]]
+    two = paths == ["reference", "engine"]
+    lines.append("seed | " + " | ".join(f"{p[-9:]:>9} EMA   raw  ms/step" for p in paths) + (" | delta EMA  delta raw" if two else ""))
     for r in res["runs"]:
         cells = [f"{sum(r[p]['psnr_ema']) / v:13.3f} {sum(r[p]['psnr_raw']) / v:6.3f} {r[p]['ms_per_step']:7.2f}" for p in paths]
         tail = ""
-        if len(paths) == 2:
+        if two:
             tail = f" | {sum(r['engine']['psnr_ema']) / v - sum(r['reference']['psnr_ema']) / v:+9.3f}  {sum(r['engine']['psnr_raw']) / v - sum(r['reference']['psnr_raw']) / v:+9.3f}"
         lines.append(f"{r['seed']:4d} | " + " | ".join(cells) + tail)
+        lines.append("     |   optimizer steps taken (GradScaler skips overflowing ones) / final loss scale: " +
+                     ", ".join(f"{p} {r[p].get('adam_steps_taken')} / {r[p].get('loss_scale'):g}" for p in paths if r[p].get("loss_scale") is not None))
         if "reference_redraw" in r:
             e = r["reference_redraw"]
             lines.append(f"     |   reference loop again, same initial state, other draws: EMA {sum(e['psnr_ema']) / v:.3f} raw {sum(e['psnr_raw']) / v:.3f} "
@@ -338,9 +390,12 @@ def main(argv=None):
     ap.add_argument("--engine-repeat", action="store_true")
     ap.add_argument("--reference-redraw", action="store_true")
     ap.add_argument("--only", default=None, choices=["reference", "engine"])
+    ap.add_argument("--paths", default=None, help="comma-separated: reference, engine, reference-fused, trainer")
     ap.add_argument("--out", default=None, help="write the table (.txt) and the raw numbers (.json) under this path prefix")
     a = ap.parse_args(argv)
     paths = ("reference", "engine") if a.only is None else (a.only,)
+    if a.paths:
+        paths = tuple(a.paths.split(","))
     res = run(a.recipe, a.seeds, a.steps, a.views, a.train_views, paths, engine_repeat=a.engine_repeat, reference_redraw=a.reference_redraw)
     table = format_table(res)
     print(table)

@@ -71,6 +71,13 @@ def _worker(rank, world, port, q):
     dist.all_gather(gathered, r)
     ok &= all(torch.equal(gathered[0], t) for t in gathered)
     ok &= shard_views(10, rank, world) == list(range(rank, 10, world))
+    # the sharded refresh's symmetric list check: every rank gets the SAME verdict, whichever rank differs
+    from nerf2mesh_amd.parallel import all_ranks_hold
+    same = torch.tensor([-1, 0, 12345, 678901234567], dtype=torch.int64)
+    ok &= all_ranks_hold(same, world) is True
+    mine = same.clone()
+    mine[2] += rank                                                  # rank 1 holds a different list
+    ok &= all_ranks_hold(mine, world) is False
     # broadcast_parameters makes replicas identical
     with torch.no_grad():
         model.w2.fill_(float(rank + 1))

@@ -1,7 +1,7 @@
-"""Driver-visible statement of tools/train_check.py: the lego recipe on the synthetic scene converges, and the step executor, the
-fused autograd path and the unfused nn.Linear graph reach the same quality.  (PSNR against the analytic ground truth of the synthetic
-scene, quarter-resolution held-in view; BASELINE's "final PSNR within 0.1 dB" is a statement about full runs on the real dataset --
-here the bar is what 1 500 iterations of a 20-view synthetic scene support: a floor and agreement between the paths.)"""
+"""Driver-visible statement of tools/train_check.py: the lego recipe on the synthetic scene converges on every driver of the kernels -- the
+step executor, the fused autograd path and the unfused nn.Linear graph.  (PSNR against the analytic ground truth of the synthetic scene,
+quarter-resolution held-in views.)  The parity statement -- executor against the REFERENCE's own loop, held-out views, EMA weights, the bar
+derived from the reference's own run-to-run spread -- is tests/test_run_parity.py; the executor's own run-to-run spread is zero (asserted there)."""
 import pytest
 import torch
 
@@ -30,6 +30,8 @@ def test_psnr_floor_and_agreement_between_the_paths():
     psnr = {k: _train(k, steps) for k in ("engine", "fused", "unfused")}
     print("\nPSNR after", steps, "iterations:", {k: round(v, 2) for k, v in psnr.items()})
     assert min(psnr.values()) >= 33.0, psnr          # measured: 36.0 / 36.5 / 36.0 dB
-    # same recipe, same draws; the paths differ in fp16 rounding points and summation order only -- and 1 500 Adam steps amplify that
-    # into a run-to-run spread of ~0.5 dB (two runs of ONE path differ as much)
+    # Same recipe, same draws; the three differ in fp16 rounding points and summation order only.  500 steps behind the switch to full
+    # shading (diffuse_step = 1 000) the run is in its chaotic recovery: two runs of the REFERENCE loop that differ only in their draws sit
+    # 1.5 dB rms apart at 2 000 steps and 0.09 dB at 5 000 (profiles/r06_run_parity.txt), so agreement between drivers is asserted where it
+    # means something -- tests/test_run_parity.py, 5 000 steps -- and here only that no driver falls out of the others' reach.
     assert max(psnr.values()) - min(psnr.values()) <= 1.2, psnr
