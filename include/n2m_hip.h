@@ -550,6 +550,12 @@ int n2m_sample_order_live_first(const int32_t* rays, const int32_t* live, const 
  * Needs the partition-major path, one pass (B <= 2^20), no folded copies, no per-level point lists. */
 int n2m_grid_backward_sample_order(const uint32_t* perm);
 
+/* Sticky, per thread; 0 restores the default (9).  The number of levels, from the coarsest, on which the fill of the next
+ * n2m_grid_encode_backward_binned_pair* calls (partition-major path) merges same-cell runs of consecutive samples into one log entry per vertex.
+ * Marched samples stop sharing cells around level 9; the covered pixels of a rasterised frame (stage 1) share them on every level: engine_stage1
+ * sets 16 around its call.  The sums are the same fixed-point sums; a merged run is added in fp32 before it enters them. */
+int n2m_grid_backward_merge_levels(uint32_t levels);
+
 /* Adam + GradScaler for the whole parameter set in two launches (torch.optim.Adam(fused=True) + torch.amp.GradScaler of
  * main.py:221 / nerf/utils.py:506,1187-1190).  All tensors fp32 and 16-byte aligned, except grad which may be fp16
  * (grad_is_half) and half_shadow (fp16 copy of the updated parameter, or NULL).  Gradients are still multiplied by *scale

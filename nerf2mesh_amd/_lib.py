@@ -31,6 +31,7 @@ SIGNATURES = {
     "n2m_sample_order_live_first": [_vp, _vp, _vp, _u32, _u32, _vp, _vp],
     "n2m_grid_backward_sample_order": [_vp],
     "n2m_grid_backward_config": [_int, _f32],
+    "n2m_grid_backward_merge_levels": [_u32],
     "n2m_grid_backward_mid_event": [_vp],
     "n2m_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _int, _vp, _vp, _vp, _vp, _vp],
     "n2m_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _int, _vp, _vp, _vp],

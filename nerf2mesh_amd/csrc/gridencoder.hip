@@ -3533,6 +3533,17 @@ extern "C" int n2m_grid_backward_mid_event(void* event) {
 // sample to visit.  Results do not depend on it beyond fp32 rounding of the run merge (the sums are fixed point); with the LIVE-FIRST
 // order of n2m_sample_order_live_first the samples without a gradient -- the tails of the rays behind the early stop, about half of a
 // trained batch -- fill whole waves, which take the fill's TV-only path.
+// How many levels (from the coarsest) merge same-cell runs of consecutive samples in the NEXT table backwards of this thread (sticky; 0 = the
+// default, kPairMergeLevels / N2M_BIN_MERGE_LEVELS).  Stage 1 sets 16: consecutive covered pixels of a frame share cells up to resolution ~800,
+// where marched samples (the default's audience) stop sharing them at level 9.  Same sums either way (fixed point); only the fp32 rounding of a
+// merged run differs.
+static thread_local uint32_t g_merge_levels = 0u;
+extern "C" int n2m_grid_backward_merge_levels(uint32_t levels) {
+    N2M_REQUIRE(levels <= kMaxLevels, N2M_EINVAL, "n2m_grid_backward_merge_levels: %u > %u", levels, kMaxLevels);
+    g_merge_levels = levels;
+    return 0;
+}
+
 static unsigned int g_fill_dbg_host = 0u;          // host mirror of g_fill_timing_on (n2m_debug_fill_times): a non-zero word selects the EX kernels
 static thread_local const uint32_t* g_sample_order = nullptr;
 extern "C" int n2m_grid_backward_sample_order(const uint32_t* perm) {
@@ -3677,7 +3688,7 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
             if (has2) N2M_HIP(hipMemsetAsync(table2 + t0 * 2u, 0, (t1 - t0) * 2u * sizeof(_Float16), s));
         }
         static const uint32_t merge_env = getenv("N2M_BIN_MERGE_LEVELS") ? (uint32_t)atoi(getenv("N2M_BIN_MERGE_LEVELS")) : kPairMergeLevels;
-        const uint32_t merge_levels = has2 ? merge_env : kMaxLevels;
+        const uint32_t merge_levels = has2 ? (g_merge_levels ? g_merge_levels : merge_env) : kMaxLevels;
         static const bool xcd_map = getenv("N2M_FILL_NO_XCD") == nullptr;
         static const uint32_t tiles_per_wg = getenv("N2M_PM_TILES") ? (uint32_t)atoi(getenv("N2M_PM_TILES")) : kPairTilesPerWg;
         dim3 grid((lay.plan.tiles + tiles_per_wg - 1) / tiles_per_wg, max_level);

@@ -366,8 +366,13 @@ get_rays_kernel(const float* __restrict__ poses /*[V,4,4]*/, const int64_t* __re
 // can refresh an fp16 shadow copy of a table in the same pass (the colour table is consumed as fp16 by the encoder, grid.py:45).
 // A one-thread kernel then does GradScaler.update() and the step count.  Math as in torch's fused kernel:
 //   g = grad / scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+// Access form of the partner tensor (the [rows,1] table a [rows,2] table's threads update alongside) and of the gradients:
+//   0: scalar, cache-allocating (rounds 2-5)              Adam 99.3 us, lookup 71.7 us in the step
+//   1: scalar, every pure stream non-temporal              Adam 112 us (+15), lookup 66.0 us (-5.5): a loss of 10 us -- profiles/r06_adam_nt_ab.txt
+//   2: the partner's two rows as ONE 8-byte streaming access per array, gradients streaming (round 6 default)
+//                                                          Adam 93.5 us (-5.8), lookup 71.1: bit-identical, tests/test_optim.py
 #ifndef N2M_ADAM_NT_ALL
-#define N2M_ADAM_NT_ALL 0
+#define N2M_ADAM_NT_ALL 2
 #endif
 struct AdamTensors {
     uint64_t p[N2M_ADAM_MAX], g[N2M_ADAM_MAX], m[N2M_ADAM_MAX], v[N2M_ADAM_MAX], shadow[N2M_ADAM_MAX];
@@ -459,10 +464,22 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
         const float* __restrict__ M1 = reinterpret_cast<const float*>(t.m[pk]);
         const float* __restrict__ V1 = reinterpret_cast<const float*>(t.v[pk]);
         const bool g1_half = (t.g_half_mask >> pk) & 1u;
+        bool pair8 = false;
+#if N2M_ADAM_NT_ALL == 2
+        // the partner's two rows as ONE 8-byte streaming access per array (r0 is even: 8-byte aligned whenever the slice starts on an even row)
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        pair8 = r0 + 2u <= n1 && ((t.p[pk] | t.m[pk] | t.v[pk] | t.g[pk]) & 7u) == 0u && !g1_half && !(PEER && pe.entry[pk] >= 0);
+        if (pair8) {
+            const f2v a = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(P1 + r0)), b = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(M1 + r0)),
+                      c = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(V1 + r0)),
+                      d = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(reinterpret_cast<const float*>(t.g[pk]) + r0));
+            p1[0] = a.x; p1[1] = a.y; m1v[0] = b.x; m1v[1] = b.y; v1v[0] = c.x; v1v[1] = c.y; g1v[0] = d.x; g1v[1] = d.y;
+        }
+#endif
 #pragma unroll
         for (uint32_t e = 0; e < 2; ++e) {
-            if (r0 + e >= n1) continue;
-#if N2M_ADAM_NT_ALL      // every pure stream of the pass bypasses the caches; only the packed rows (what the next lookup gathers) allocate
+            if (pair8 || r0 + e >= n1) continue;
+#if N2M_ADAM_NT_ALL == 1      // every pure stream of the pass bypasses the caches; only the packed rows (what the next lookup gathers) allocate
             p1[e] = __builtin_nontemporal_load(P1 + r0 + e); m1v[e] = __builtin_nontemporal_load(M1 + r0 + e); v1v[e] = __builtin_nontemporal_load(V1 + r0 + e);
 #else
             p1[e] = P1[r0 + e]; m1v[e] = M1[r0 + e]; v1v[e] = V1[r0 + e];
@@ -473,7 +490,7 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
                 g1v[e] = a;
                 continue;
             }
-#if N2M_ADAM_NT_ALL
+#if N2M_ADAM_NT_ALL == 1
             g1v[e] = g1_half ? (float)__builtin_nontemporal_load(reinterpret_cast<const _Float16*>(t.g[pk]) + r0 + e)
                              : __builtin_nontemporal_load(reinterpret_cast<const float*>(t.g[pk]) + r0 + e);
 #else
@@ -563,6 +580,11 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
         const float bc1p = bias[2u * t.slot[pk]], bc2p_sqrt = bias[2u * t.slot[pk] + 1u];      // the partner tensor's own step count
         const float step1 = t.lr[pk] / bc1p;
         float q[2] = {0.f, 0.f};
+#if N2M_ADAM_NT_ALL == 2
+        typedef float f2s __attribute__((ext_vector_type(2)));
+        const bool st8 = r0 + 2u <= n1 && ((t.p[pk] | t.m[pk] | t.v[pk]) & 7u) == 0u;
+        float mo[2] = {0.f, 0.f}, vo[2] = {0.f, 0.f};
+#endif
 #pragma unroll
         for (uint32_t e = 0; e < 2; ++e) {
             if (r0 + e >= n1) continue;
@@ -570,12 +592,22 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
             const float m1 = beta1 * m1v[e] + omb1 * gr;
             const float v1 = beta2 * v1v[e] + omb2 * gr * gr;
             q[e] = p1[e] - step1 * m1 / (sqrtf(v1) / bc2p_sqrt + eps);
-#if N2M_ADAM_NT_ALL
+#if N2M_ADAM_NT_ALL == 2
+            mo[e] = m1; vo[e] = v1;
+            if (!st8) { P1[r0 + e] = q[e]; M1[r0 + e] = m1; V1[r0 + e] = v1; }
+#elif N2M_ADAM_NT_ALL == 1
             __builtin_nontemporal_store(q[e], P1 + r0 + e); __builtin_nontemporal_store(m1, M1 + r0 + e); __builtin_nontemporal_store(v1, V1 + r0 + e);
 #else
             P1[r0 + e] = q[e]; M1[r0 + e] = m1; V1[r0 + e] = v1;
 #endif
         }
+#if N2M_ADAM_NT_ALL == 2
+        if (st8) {
+            __builtin_nontemporal_store((f2s){q[0], q[1]}, reinterpret_cast<f2s*>(P1 + r0));
+            __builtin_nontemporal_store((f2s){mo[0], mo[1]}, reinterpret_cast<f2s*>(M1 + r0));
+            __builtin_nontemporal_store((f2s){vo[0], vo[1]}, reinterpret_cast<f2s*>(V1 + r0));
+        }
+#endif
         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
         h2v c0, c1;
         c0.x = (_Float16)p[0]; c0.y = (_Float16)p[1]; c1.x = (_Float16)p[2]; c1.y = (_Float16)p[3];

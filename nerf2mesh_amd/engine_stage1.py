@@ -15,6 +15,8 @@ Every kernel is the one the autograd path launches, fed the same inputs; what di
 gradients land in one buffer, the three vertex gradients are added in a fixed order) -- tests/test_stage1.py holds the executor to the
 distance between two runs of the autograd trainer.  Reference call sites: `render_stage1` (nerf/renderer.py:816-921),
 `update_triangles_errors` (:924-943), `train_step` stage-1 branch (nerf/utils.py:708-721), regularisers (:745-789)."""
+import os
+
 import numpy as np
 import torch
 
@@ -65,6 +67,7 @@ class Stage1Engine:
         enc = model.encoder_color
         self.enc = enc
         self.levels = int(enc.num_levels)
+        self.merge_levels = int(os.environ.get("N2M_S1_MERGE_LEVELS", "16"))      # (A/B: 9 = the marched-sample default)
         self.geo = (float(np.log2(enc.per_level_scale)), int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), enc.interp_id)
         from .gridencoder import _host_offsets
         self.ho = _host_offsets(enc)
@@ -178,9 +181,15 @@ class Stage1Engine:
                 need = L.lib().n2m_grid_binned_pair_workspace_bytes(K, self.levels, self.ho.ctypes.data)
                 wsb = L.workspace(dev, need)
                 L.grid_backward_config(1, 1.0)
-                L.call("n2m_grid_encode_backward_binned_pair", None, _p(self.d_h2), _p(x01), self.ho.ctypes.data, None, _p(self.g2), K, self.levels, self.levels,
-                       self.geo[0], self.geo[1], self.geo[2], self.geo[3], self.geo[4], None, 0.0, 0.0, 1.0, None, _p(o.found_inf), 1.0, 0.0, 1, _p(wsb),
-                       wsb.numel(), s)
+                # consecutive covered pixels share cells on EVERY level (a frame samples the surface at ~1 / 1600 of its extent): merge runs on all
+                # sixteen for this call (sticky thread-local: set in front of the call, restored behind it whatever happens)
+                L.call("n2m_grid_backward_merge_levels", self.merge_levels)
+                try:
+                    L.call("n2m_grid_encode_backward_binned_pair", None, _p(self.d_h2), _p(x01), self.ho.ctypes.data, None, _p(self.g2), K, self.levels, self.levels,
+                           self.geo[0], self.geo[1], self.geo[2], self.geo[3], self.geo[4], None, 0.0, 0.0, 1.0, None, _p(o.found_inf), 1.0, 0.0, 1, _p(wsb),
+                           wsb.numel(), s)
+                finally:
+                    L.call("n2m_grid_backward_merge_levels", 0)
                 if self.world > 1:        # the two large sums travel while the vertex path finishes
                     tok = tr.sync.all_reduce_sum_begin([self.g2], [self.dw])
                 # coverage: its gradient reaches the vertex positions through the barycentrics (the interpolated attribute is the constant 1)

@@ -621,7 +621,13 @@ class Stage1Trainer:
             if self._amp_mlp:
                 self._amp["mlp"] = dict(found_inf=o.found_inf, flagged=False, persistent_dw=True)
                 model.amp_request = self._amp["mlp"]
-            o.backward(loss, self.world)
+            # (the colour table's backward merges same-cell runs on all sixteen levels, like engine_stage1: consecutive covered pixels share cells)
+            from . import _lib as L
+            L.call("n2m_grid_backward_merge_levels", int(os.environ.get("N2M_S1_MERGE_LEVELS", "16")))
+            try:
+                o.backward(loss, self.world)
+            finally:
+                L.call("n2m_grid_backward_merge_levels", 0)
             model.encoder_color.amp_request = model.amp_request = None
             flagged = [model.encoder_color.embeddings] if self._amp["color"]["flagged"] else []
             if "mlp" in self._amp and self._amp["mlp"]["flagged"]:
