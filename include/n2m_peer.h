@@ -57,7 +57,8 @@ int n2m_peer_reduce_slices(const float* stage1, const void* stage2, uint32_t wor
                            void* stream);
 
 /* Routing of the table backward's flush (n2m_grid_encode_backward_binned_pair*, overwrite mode, partition-major path): rows [0, split_row) are
- * owned in `world` chunks of rows_c, rows [split_row, ...) in chunks of rows_f; the gradient of absolute row a goes to
+ * owned in `world` chunks of rows_c (the last chunk may be shorter: (world - 1) * rows_c < split_row <= world * rows_c -- chunks padded to a
+ * multiple of four rows keep every chunk 16-byte aligned in the packed table), rows [split_row, ...) in chunks of rows_f; the gradient of absolute row a goes to
  * g1[half][owner] + local (fp32) / g2[half][owner] + 2 * local (fp16 pairs), local = the row's index inside the owner's chunk -- pointers into
  * the owners' staging slots of the calling rank (its own included).  A setting of the CALLING THREAD, consumed by its table-backward
  * calls until cleared with NULL; the grad_table arguments of those calls are not written. */

@@ -4601,8 +4601,11 @@ extern "C" int n2m_debug_fill_times(int on, unsigned long long* out) {
 
 extern "C" int n2m_grid_backward_peer_route(const N2mPeerRoute* route) {
     if (!route) { g_peer_route = N2mPeerRoute{}; return 0; }
-    N2M_REQUIRE(route->world >= 1 && route->world <= N2M_PEER_MAX && route->rows_c > 0 && route->rows_f > 0 && route->split_row == route->world * route->rows_c,
-                N2M_EINVAL, "grid_backward_peer_route: 1..%d ranks, split_row = world * rows_c", N2M_PEER_MAX);
+    // (the LAST owner's chunk of the coarse half may be shorter: chunks are padded to a multiple of four rows so that every chunk starts 16-byte
+    //  aligned in the packed table -- W = 4 and W = 8 at the standard table, where split_row / W is not a multiple of four)
+    N2M_REQUIRE(route->world >= 1 && route->world <= N2M_PEER_MAX && route->rows_c > 0 && route->rows_f > 0 &&
+                (uint64_t)route->world * route->rows_c >= route->split_row && (uint64_t)(route->world - 1u) * route->rows_c < route->split_row,
+                N2M_EINVAL, "grid_backward_peer_route: 1..%d ranks, (world - 1) * rows_c < split_row <= world * rows_c", N2M_PEER_MAX);
     for (int h = 0; h < 2; ++h)
         for (uint32_t r = 0; r < route->world; ++r)
             N2M_REQUIRE(route->g1[h][r] && route->g2[h][r], N2M_ENULL, "grid_backward_peer_route: NULL staging slot (half %d, owner %u)", h, r);

@@ -42,6 +42,16 @@ def lr_lambda(it, iters):
     return 0.01 + 0.99 * (it / 500) if it <= 500 else 0.1 ** ((it - 500) / (iters - 500))
 
 
+def peer_chunk_rows(split, world, pad=0):
+    """Rows of one rank's chunk of the coarse half [0, split) in peer-store mode: split / world rounded UP to a multiple of four (+ pad), so that
+    every chunk starts 16-byte aligned in the packed table (8-byte rows, stored as 16-byte row pairs) and holds a multiple of four rows; the last
+    rank's chunk is what is left.  None when the layout does not exist (split not a multiple of four, or the padding leaves the last rank empty)."""
+    if split % 4 != 0 or pad % 4 != 0:
+        return None
+    cs = (split + 4 * world - 1) // (4 * world) * 4 + pad
+    return cs if (world - 1) * cs < split else None
+
+
 class _RayBufs:
     """Per-batch ray-side tensors.  Three sets rotate: while step i consumes batch i, batch i+1 waits for its turn and batch i+2 is
     produced on the side stream (behind the marker in front of Adam(i), i.e. after the last kernel that read batch i-1's set)."""
@@ -193,10 +203,23 @@ class Stage0Engine:
             fine = self.rows - split
             # (a slice that starts at an odd row -- the coarse half at 8 ranks -- leaves the packed rows 8-byte aligned only: n2m_adam_step then
             # writes the two columns separately instead of whole 16-byte row pairs; tests/test_optim.py covers that form)
-            ok = self.Lv == 16 and split % W == 0 and fine % W == 0 and os.environ.get("N2M_SHARD_ADAM", "1") != "0"
+            # peer-store mode: coarse chunks padded to a multiple of FOUR rows (the last rank's is shorter), so that every chunk starts 16-byte aligned
+            # in the packed table and n2m_adam_step_peer's fused form covers W = 4 and W = 8 too (split / W = 481 390 / 240 695 rows there: not
+            # multiples of four, the second one odd); the collective path needs equal chunks (reduce_scatter_tensor) and keeps split / W.
+            # (N2M_PEER_PAD_ROWS: extra padding, a multiple of four -- exercises the uneven layout with two ranks, tests/test_parallel_gpu.py)
+            peer_mode = os.environ.get("N2M_PEER_STORE", "0") == "1" and not opt.sdf
+            cs = split // W
+            self._uneven = False
+            padded = peer_chunk_rows(split, W, int(os.environ.get("N2M_PEER_PAD_ROWS", "0"))) if peer_mode else None
+            if padded is not None:
+                cs, even_ok = padded, True
+                self._uneven = cs * W != split
+            else:
+                even_ok = split % W == 0
+            ok = self.Lv == 16 and even_ok and fine % W == 0 and os.environ.get("N2M_SHARD_ADAM", "1") != "0"
             if ok:
                 self.shard = True
-                self._split, self._Cs, self._Fs = split, split // W, fine // W
+                self._split, self._Cs, self._Fs = split, cs, fine // W
                 f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
                 f16 = lambda *sh: torch.empty(*sh, dtype=torch.float16, device=dev)
                 self.g1s = {"c": f32(self._Cs, 1), "f": f32(self._Fs, 1)}
@@ -585,8 +608,11 @@ class Stage0Engine:
 
     def _shard_ranges(self):
         """(first row, rows) of this rank's slice of the coarse half (levels 0..7) and of the fine half (levels 8..15)."""
-        r = self.rank
-        return {"c": (r * self._Cs, self._Cs), "f": (self._split + r * self._Fs, self._Fs)}
+        return self._shard_ranges_of(self.rank)
+
+    def _shard_ranges_of(self, r):
+        c0 = min(self._split, r * self._Cs)
+        return {"c": (c0, min(self._Cs, self._split - c0)), "f": (self._split + r * self._Fs, self._Fs)}
 
     def _adam_desc_sharded(self, full, key, pk, params):
         """Descriptor of the rank's OWN rows: per level half one [rows,1] + one [rows,2] entry (pointers offset into the full state
@@ -682,6 +708,12 @@ class Stage0Engine:
             flat = t.view(-1)
             for h, (row0, n) in self._shard_ranges().items():
                 lo = 0 if h == "c" else self._split
+                if h == "c" and getattr(self, "_uneven", False):      # padded chunks (peer-store mode): the last one is shorter -- one broadcast per owner
+                    for r in range(self.world):
+                        r0, rn = self._shard_ranges_of(r)["c"]
+                        if rn > 0:
+                            dist.broadcast(flat[r0 * C:(r0 + rn) * C], src=r)
+                    continue
                 dist.all_gather_into_tensor(flat[lo * C:(lo + self.world * n) * C], flat[row0 * C:(row0 + n) * C].clone())
 
     def _optimizer_step(self, full, lr_factor, loss_out=None, fused=None):

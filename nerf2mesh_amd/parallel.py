@@ -240,7 +240,8 @@ class PeerExchange:
 
     def __init__(self, rank, world, rows, split, rows_c, rows_f, device, group=None, timeout_ms=None, small_n=0):
         import os
-        assert split == world * rows_c and rows - split == world * rows_f and world <= 8
+        # rows_c = rows of a coarse CHUNK (slot size); the last rank's chunk may be shorter (chunks padded to a multiple of four rows)
+        assert (world - 1) * rows_c < split <= world * rows_c and rows - split == world * rows_f and world <= 8
         self.rank, self.world, self.rows, self.split, self.rows_c, self.rows_f, self.device = rank, world, rows, split, rows_c, rows_f, device
         al = lambda n: (n + 255) & ~255
         n = {"c": rows_c, "f": rows_f}

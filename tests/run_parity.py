@@ -273,7 +273,7 @@ def mean_se(xs):
 
 
 def run(recipe="lego", seeds=3, steps=2000, views=8, train_views=100, paths=("reference", "engine"), device=None, log=print, engine_repeat=False,
-        reference_redraw=False):
+        reference_redraw=False, first_seed=0):
     """Returns the result table (dict).  engine_repeat: a second executor run per seed from the same state -- its distance from the first
     is the executor's own run-to-run spread (0 when the step is bit-reproducible).  reference_redraw: a second REFERENCE run per seed from
     the same initial state with other random draws (pixels, backgrounds, jitter) -- the distance between the two reference runs is the
@@ -285,7 +285,7 @@ def run(recipe="lego", seeds=3, steps=2000, views=8, train_views=100, paths=("re
     held_out = synthetic.make_cameras(views, seed=HELD_OUT_SEED).to(device).float().contiguous()
     images = synthetic.preload_images(poses, synthetic.boxes(device, scene))
     res = {"recipe": recipe, "steps": steps, "seeds": seeds, "held_out_views": views, "train_views": train_views, "runs": []}
-    for s in range(seeds):
+    for s in range(first_seed, first_seed + seeds):
         init = initial_state(recipe, s, steps, device)
         row = {"seed": s}
         for path in paths:
@@ -384,6 +384,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--recipe", default="lego", choices=sorted(RECIPES))
     ap.add_argument("--seeds", type=int, default=3)
+    ap.add_argument("--first-seed", type=int, default=0)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--train-views", type=int, default=100)
@@ -396,7 +397,7 @@ def main(argv=None):
     paths = ("reference", "engine") if a.only is None else (a.only,)
     if a.paths:
         paths = tuple(a.paths.split(","))
-    res = run(a.recipe, a.seeds, a.steps, a.views, a.train_views, paths, engine_repeat=a.engine_repeat, reference_redraw=a.reference_redraw)
+    res = run(a.recipe, a.seeds, a.steps, a.views, a.train_views, paths, engine_repeat=a.engine_repeat, reference_redraw=a.reference_redraw, first_seed=a.first_seed)
     table = format_table(res)
     print(table)
     if a.out:

@@ -154,3 +154,25 @@ def test_bench_watchdog_ends_a_hung_phase_with_an_error_line():
     # a rank other than 0 ends too, silently
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, RANK="3", WORLD_SIZE="8"))
     assert r.returncode == 4 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_peer_store_chunks_are_aligned_at_every_world_size():
+    """Peer-store mode pads the coarse half's chunks to a multiple of four rows (engine.peer_chunk_rows): at the standard table split / W is
+    481 390 (W = 4) and 240 695 (W = 8) -- not multiples of four, the second one odd -- which kept n2m_adam_step_peer's fused form (16-byte row
+    pairs) off for those world sizes until round 6.  Every chunk must start on a multiple of four rows, hold a multiple of four, and the chunks
+    must tile [0, split) exactly."""
+    from nerf2mesh_amd.engine import peer_chunk_rows
+    from nerf2mesh_amd.gridencoder import level_offsets
+    off = level_offsets(3, 16, float(np.exp2(np.log2(2048 / 16) / 15)), 16, 19, False)
+    split = off[8]
+    assert split == 1925560
+    for W in (2, 3, 4, 8):
+        cs = peer_chunk_rows(split, W)
+        assert cs is not None and cs % 4 == 0
+        starts = [min(split, r * cs) for r in range(W)]
+        lens = [min(cs, split - s0) for s0 in starts]
+        assert sum(lens) == split and all(l > 0 and l % 4 == 0 for l in lens) and all(s0 % 4 == 0 for s0 in starts), (W, cs, lens)
+        assert (W - 1) * cs < split <= W * cs                      # what n2m_grid_backward_peer_route checks
+    assert peer_chunk_rows(split, 8) == 240696 and peer_chunk_rows(split, 4) == 481392 and peer_chunk_rows(split, 2) == 962780
+    assert peer_chunk_rows(split + 2, 4) is None                   # a half that is not a multiple of four rows has no such layout
+    assert peer_chunk_rows(split, 2, pad=52) == 962832 and peer_chunk_rows(1000, 2, pad=600) is None

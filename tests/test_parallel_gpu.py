@@ -105,7 +105,10 @@ def test_peer_store_exchange_equals_the_collective_path(tmp_path):
     dumps = {}
     for name, port, env in (("rs1", 29551, {"N2M_SHARD_ADAM": "1"}), ("rs2", 29553, {"N2M_SHARD_ADAM": "1"}),
                             ("peer", 29555, {"N2M_SHARD_ADAM": "1", "N2M_PEER_STORE": "1"}),
-                            ("peer_unfused", 29569, {"N2M_SHARD_ADAM": "1", "N2M_PEER_STORE": "1", "N2M_PEER_FUSED": "0"})):
+                            ("peer_unfused", 29569, {"N2M_SHARD_ADAM": "1", "N2M_PEER_STORE": "1", "N2M_PEER_FUSED": "0"}),
+                            # round 6: coarse chunks PADDED to a multiple of four rows, the last rank's shorter -- the layout W = 4 / W = 8 get
+                            # at the standard table (split / W = 481 390 / 240 695 rows), forced here on two ranks by 52 rows of extra padding
+                            ("peer_padded", 29575, {"N2M_SHARD_ADAM": "1", "N2M_PEER_STORE": "1", "N2M_PEER_PAD_ROWS": "52"})):
         path = str(tmp_path / f"{name}.pt")
         line = _dist_check(port, 24, env, dump=path)
         assert f"peer_store={name.startswith('peer')}" in line and "shard=True" in line, line
@@ -117,6 +120,8 @@ def test_peer_store_exchange_equals_the_collective_path(tmp_path):
     # round 5: the slot sum inside Adam's gradient load and the row push inside its packed-row store (n2m_adam_step_peer, the default in peer
     # mode) against the separate passes (n2m_peer_reduce_slices -> n2m_adam_step -> n2m_peer_copy): the same arithmetic, bit for bit
     assert torch.equal(dumps["peer"], dumps["peer_unfused"])
+    # ... and where the chunk boundaries lie changes nothing either (rank 0 owns 52 rows more, rank 1 104 fewer than its slot holds)
+    assert torch.equal(dumps["peer"], dumps["peer_padded"])
     if d_rr == 0.0:
         # the step is bit-reproducible (fixed-point table backward) and a sum of TWO ranks does not depend on its order or on where the fp16
         # rounding happens: the peer-store run must then reproduce the collective run bit for bit (measured: it does)
