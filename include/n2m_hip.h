@@ -299,6 +299,22 @@ int n2m_grid_encode_forward_packed(const float* inputs, const void* packed, cons
                                    void* outputs2, uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H,
                                    uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
                                    void* stream);
+/* n2m_grid_encode_forward_packed that also LEAVES, per hashed level and sample, the density column of corners 000 / 100 / 010 / 001 of the sample's
+ * interpolation cell: tv_corners [L, B, 4] fp32, 16-byte aligned (rows of dense levels and of samples outside the unit cube are not written;
+ * NULL = the plain call).  Those four values are the centre and the +x / +y / +z neighbours of the TV stencil of gridencoder.cu:505-609 (the TV
+ * cell floor(x * scale + 0.5) is the interpolation cell's vertex 000), so a table backward over the SAME samples and the SAME table state that
+ * folds the TV term in (tv_embeddings != NULL) can take them from here -- n2m_grid_backward_tv_corners -- and gather three neighbours per
+ * (sample, level) instead of six: the fill's fine levels are bound by exactly those scattered requests.  Outputs bit-identical to the plain call. */
+int n2m_grid_encode_forward_packed_tv(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1,
+                                      void* outputs2, uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                      uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
+                                      float* tv_corners, void* stream);
+/* Sticky, per thread; NULL clears it.  The corner records the next n2m_grid_encode_backward_binned_pair[_half] calls of this thread may use for
+ * their folded TV term (see above).  Used when the call computes the term itself, runs in one pass (B <= 2^20) over one point list in input
+ * order without folded copies; ignored otherwise.  The caller guarantees: same B, same inputs, same table values as the forward that wrote them.
+ * The gradients are bit-identical with and without the records. */
+int n2m_grid_backward_tv_corners(const float* tv_corners);
+
 /* The same lookup for the levels [level_begin, level_begin + n_levels) only (the rows of outputs1 / outputs2 of those levels, bit-identical
  * to the full call's).  For a caller whose packed rows arrive in level chunks -- multi-GPU with the optimizer sharded over the ranks
  * (nerf/utils.py:517-519 is the reference's DDP wrapper): every rank refreshes its own rows, the others' arrive by all-gather,

@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(256)
 grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __restrict__ packed, const int32_t* __restrict__ offsets,
                             float* __restrict__ out1, _Float16* __restrict__ out2, uint32_t B, uint32_t max_level, LevelTable lv,
                             uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t n_tiles, float in_scale, float in_offset,
-                            uint32_t xcd_group, uint32_t level_begin = 0u, uint32_t n_levels = 16u) {
+                            uint32_t xcd_group, uint32_t level_begin = 0u, uint32_t n_levels = 16u, float4* __restrict__ tv4 = nullptr) {
     __builtin_amdgcn_s_setprio(3);      // runs beside the next batch's marcher (second stream): win the issue arbitration
     constexpr uint32_t D = 3;
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -526,6 +526,10 @@ grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __res
             g[2 * q] = odd_row ? hi : lo;
             g[2 * q + 1] = x_even ? (odd_row ? lo : hi) : extra[q];
         }
+        // the density column of corners 000 / 100 / 010 / 001 = centre and +x / +y / +z neighbours of this sample's TV stencil (the TV cell
+        // floor(x * scale + 0.5) IS the interpolation cell's vertex 000): one coalesced 16-byte record for the table backward's fill, which then
+        // gathers three neighbours instead of six (n2m_grid_encode_forward_packed_tv; hashed levels only -- dense stencils hit the L1)
+        if (tv4) tv4[(size_t)level * B + b] = make_float4(__uint_as_float(g[0].x), __uint_as_float(g[1].x), __uint_as_float(g[2].x), __uint_as_float(g[4].x));
     } else {
 #pragma unroll
         for (uint32_t corner = 0; corner < 8; ++corner) {
@@ -1136,6 +1140,10 @@ struct TvParams {
     float weight, weight_outer, inner01;      // inner01: half extent of the inner region in [0,1] input space (>= 0.5: everything is inner)
     const float* scale_ptr;
     uint32_t stride = 1;      // floats between consecutive rows of `table`: 2 reads the density column of a packed {fp32, half2} table
+    // [L, Bstride, 4] fp32 or NULL: per (level, sample) the table's values at corners 000 / 100 / 010 / 001 of the sample's interpolation cell, left
+    // by the forward lookup of the SAME samples on the SAME table state (n2m_grid_encode_forward_packed_tv, hashed levels only).  They are the
+    // centre and the +x / +y / +z neighbours of the TV stencil: the fill then gathers three neighbours instead of six (round 6).
+    const float* corners = nullptr;
 };
 
 // MODE 0: backward entries; MODE 1: TV entries only (8 samples per thread); MODE 2: backward + TV folded into vertex 000's
@@ -1331,10 +1339,13 @@ __device__ __forceinline__ PairCtx make_pair_ctx(const TvParams& tv, const float
 // TV term of one (sample, level): gridencoder.cu:505-609 on the cell floor(x * scale + 0.5) -- vertex 000 of the interpolation cell.  One
 // function for the fill that computes it in place (TV mode 1) and for the stand-alone pre-pass n2m_grid_tv_terms (whose result the fill
 // of TV mode 2 reads back): identical bits either way.
+#ifndef N2M_TV_ABLATE
+#define N2M_TV_ABLATE 0
+#endif
 template <int IMODE>
 __device__ __forceinline__ float pair_tv_value(const PairCtx& cx, const Indexer<3>& ix, const float (&x)[3], uint32_t (&cell)[3],
                                                const uint32_t (&rows)[8], const uint32_t (&tx)[2], const uint32_t (&ty)[2],
-                                               const uint32_t (&tz)[2], uint32_t sy, uint32_t sz) {
+                                               const uint32_t (&tz)[2], uint32_t sy, uint32_t sz, const float4* corners = nullptr) {
     constexpr uint32_t D = 3;
     auto comb = [&](uint32_t a, uint32_t b, uint32_t c) { return IMODE == 1 ? ((a ^ b ^ c) & ix.mask) : (a + b + c); };
     float tvv = 0.0f;
@@ -1350,11 +1361,31 @@ __device__ __forceinline__ float pair_tv_value(const PairCtx& cx, const Indexer<
                                    cell[2] < cx.resolution, cell[2] > 0u};
             const uint32_t st = cx.tv.stride;
             float centre, nb[6];
-            if (st == 1u) {
+            if (IMODE == 1 && corners != nullptr) {
+                // Round 6.  The fine levels of the fill are bound by their XCD's L2 REQUEST rate, and six of the ~8 scattered requests a (sample,
+                // level) costs were this stencil (profiles/r06_fill_split.txt).  Four of its seven values are corners 000 / 100 / 010 / 001 of the
+                // sample's interpolation cell, which the forward lookup has just gathered: it leaves them as ONE coalesced 16-byte record per
+                // (sample, level), and only the -x / -y / -z neighbours are gathered here.  Same table, same state, same bits.
+                const float4 c4 = *corners;
+                centre = c4.x; nb[0] = c4.y; nb[2] = c4.z; nb[4] = c4.w;
+                nb[1] = tab[(size_t)(nb_ok[1] ? nb_row[1] : rows[0]) * st];
+                nb[3] = tab[(size_t)(nb_ok[3] ? nb_row[3] : rows[0]) * st];
+                nb[5] = tab[(size_t)(nb_ok[5] ? nb_row[5] : rows[0]) * st];
+            } else if (st == 1u) {
                 // Seven scattered 4-byte reads per (sample, level) pace the fine levels (a fully divergent wave load costs the CU 64 address
                 // cycles).  One of them is free: on a hashed level the x prime is 1, so the +x (cell even) or -x (cell odd) neighbour is row
                 // r ^ 1 -- the other half of the centre's aligned 8 bytes; on a dense level +x is row r + 1.  Six reads instead of seven.
                 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+#if N2M_TV_ABLATE      // (measurement build, WRONG results: what the fill would gain if the forward lookup handed over the centre and the +x / +y / +z
+                       //  neighbours -- corners 000 / 100 / 010 / 001 of its interpolation cell -- and only -x / -y / -z were gathered here)
+                if constexpr (IMODE == 1) {
+                    centre = __uint_as_float(rows[0] & 0x3F800000u);
+                    nb[0] = centre; nb[2] = centre; nb[4] = centre;
+                    nb[1] = tab[nb_ok[1] ? nb_row[1] : rows[0]];
+                    nb[3] = tab[nb_ok[3] ? nb_row[3] : rows[0]];
+                    nb[5] = tab[nb_ok[5] ? nb_row[5] : rows[0]];
+                } else
+#endif
                 if constexpr (IMODE == 1) {
                     const float2 pr = *reinterpret_cast<const float2*>(tab + (rows[0] & ~1u));
                     const bool odd_row = (rows[0] & 1u) != 0u, even_cell = (cell[0] & 1u) == 0u;
@@ -1371,8 +1402,13 @@ __device__ __forceinline__ float pair_tv_value(const PairCtx& cx, const Indexer<
                     nb[0] = pr.y;
                     nb[1] = tab[nb_ok[1] ? nb_row[1] : rows[0]];
                 }
+#if N2M_TV_ABLATE
+                if constexpr (IMODE != 1)
+#endif
+                {
 #pragma unroll
-                for (uint32_t k = 2; k < 6; ++k) nb[k] = tab[nb_ok[k] ? nb_row[k] : rows[0]];
+                    for (uint32_t k = 2; k < 6; ++k) nb[k] = tab[nb_ok[k] ? nb_row[k] : rows[0]];
+                }
             } else {
                 centre = tab[(size_t)rows[0] * st];
 #pragma unroll
@@ -2178,7 +2214,7 @@ struct PmPlan {
 template <int TV, int IMODE, bool ILV, bool DEAD = false>
 __device__ __forceinline__ void pm_entries(const PairCtx& cx, const Indexer<3>& ix, const PartMap& pm, const float (&x)[3], float g1,
                                            float g2x, float g2y, float a1, float& vmax1, uint32_t (&e_pr)[8], float (&f1)[8],
-                                           uint32_t (&p2)[8], uint32_t (&cell)[3], float tv_given, float& tv_out) {
+                                           uint32_t (&p2)[8], uint32_t (&cell)[3], float tv_given, float& tv_out, const float4* corners = nullptr) {
     constexpr uint32_t D = 3;
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     float frac[D];
@@ -2210,7 +2246,7 @@ __device__ __forceinline__ void pm_entries(const PairCtx& cx, const Indexer<3>& 
     }
     float tvv = 0.0f;
     if constexpr (TV != 0) {
-        if constexpr (TV == 1) tvv = pair_tv_value<IMODE>(cx, ix, x, cell, rows, tx, ty, tz, sy, sz);
+        if constexpr (TV == 1) tvv = pair_tv_value<IMODE>(cx, ix, x, cell, rows, tx, ty, tz, sy, sz, corners);
         else tvv = tv_given;
         const float a = fabsf(tvv);
         vmax1 = fmaxf(vmax1, (a1 <= 3.0e38f ? a1 : 1.0f) + (a <= 3.0e38f ? a : 1.0f));
@@ -2373,6 +2409,9 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
     // every tile, draining the previous tile's log stores with it.)
     bool nvalid = false, pvalid = false;
     uint32_t pidx = 0u;
+    // (the forward lookup's corner records, tv.corners: read where they are used.  Requested a tile ahead with the inputs they cost four more
+    //  registers across both barriers: 122 VGPRs + 32 bytes of scratch, measured slower -- round 6)
+    const bool use_corners = TV == 1 && !EX && !FOLD && tv.corners != nullptr && fast_hash;
     // which sample this thread visits in tile t: loaded TWO tiles ahead when the caller hands an order (the inputs of tile t+1 are requested
     // at the top of tile t and need the index then -- a load issued only there would be a dependent round trip in front of every request)
     auto fetch_index = [&](uint32_t t) {
@@ -2432,17 +2471,19 @@ pm_fill_pair_kernel(const float* __restrict__ grad1 /*[L,Bstride]*/, const _Floa
         // hands the live-first order: n2m_grid_backward_sample_order) delivers TV terms only: one entry per sample instead of eight, one
         // value through the run merge instead of twenty-four.  Wave-uniform; the folded-copies form keeps the full path.
         const bool wave_live = !EX || FOLD || (dbg & 128u) || __ballot(inside && gnz) != 0ull;       // (dbg 128: measurement switch, the full path for every wave)
+        // the forward lookup's record of this (level, sample): only where the launcher handed one over (TV computed here, samples in input order)
+        const float4* corner_rec = use_corners ? reinterpret_cast<const float4*>(tv.corners) + ((size_t)level * Bstride + tile * TS + tid) : nullptr;
         if (inside) {
             const float g2x = (float)g2.x, g2y = (float)g2.y;
             const float a1 = fabsf(g1);
             float tvv = 0.0f;
             if (wave_live) {
-                if (fast_hash) pm_entries<TV, 1, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+                if (fast_hash) pm_entries<TV, 1, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv, corner_rec);
                 else if (fast_dense && parts > 1u) pm_entries<TV, 2, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
                 else if (fast_dense) pm_entries<TV, 2, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
                 else pm_entries<TV, 0, false>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
             } else if (TV != 0) {
-                if (fast_hash) pm_entries<TV, 1, false, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
+                if (fast_hash) pm_entries<TV, 1, false, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv, corner_rec);
                 else if (fast_dense && parts > 1u) pm_entries<TV, 2, true, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
                 else if (fast_dense) pm_entries<TV, 2, false, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
                 else pm_entries<TV, 0, false, true>(cx, ix, pmap, x, g1, g2x, g2y, a1, vmax1, e_pr, f1, e_v2, cell, tvg, tvv);
@@ -3544,6 +3585,16 @@ extern "C" int n2m_grid_backward_merge_levels(uint32_t levels) {
     return 0;
 }
 
+// The forward lookup's corner records for the NEXT table backward of this thread (sticky until cleared with NULL): [L, B, 4] fp32 written by
+// n2m_grid_encode_forward_packed_tv over the SAME B samples and the SAME table state.  Consumed by the partition-major fill when it computes
+// the TV term itself (tv_embeddings given), one pass (B <= 2^20), samples in input order, no folded copies, one point list; ignored otherwise.
+static thread_local const float* g_tv_corners = nullptr;
+extern "C" int n2m_grid_backward_tv_corners(const float* corners) {
+    N2M_REQUIRE(((uintptr_t)corners & 15u) == 0, N2M_EINVAL, "n2m_grid_backward_tv_corners: records must be 16-byte aligned");
+    g_tv_corners = corners;
+    return 0;
+}
+
 static unsigned int g_fill_dbg_host = 0u;          // host mirror of g_fill_timing_on (n2m_debug_fill_times): a non-zero word selects the EX kernels
 static thread_local const uint32_t* g_sample_order = nullptr;
 extern "C" int n2m_grid_backward_sample_order(const uint32_t* perm) {
@@ -3713,6 +3764,8 @@ int launch_binned_pair_pm(const float* grad1, const _Float16* grad2, const float
         const size_t lds = (size_t)TS * 8u * 12u + (size_t)MP * 5u * 4u;
         const int tvmode = tv.table ? 1 : (tvt ? 2 : 0);
         const uint32_t* perm = g_sample_order;
+        tv.corners = (g_tv_corners && tv.table && B <= kBinChunk && b0 == 0 && !fold && in_level_stride == 0 && perm == nullptr && g_fill_dbg_host == 0u)
+                         ? g_tv_corners : nullptr;
         N2M_REQUIRE(perm == nullptr || (B <= kBinChunk && !fold && in_level_stride == 0), N2M_EUNSUPPORTED,
                     "%s: a sample order (n2m_grid_backward_sample_order) needs one pass (B <= %u), one point list and no folded copies", fn, kBinChunk);
         int rc;
@@ -4536,7 +4589,7 @@ extern "C" int n2m_grid_encode_forward_pair(const float* inputs, const float* em
 
 static int forward_packed(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1, void* outputs2, uint32_t B, uint32_t L,
                           uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
-                          void* stream, uint32_t level_begin, uint32_t n_levels);
+                          void* stream, uint32_t level_begin, uint32_t n_levels, float* tv_corners = nullptr);
 
 extern "C" int n2m_grid_encode_forward_packed(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1, void* outputs2,
                                               uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
@@ -4560,7 +4613,7 @@ extern "C" int n2m_grid_encode_forward_packed_levels(const float* inputs, const 
 
 static int forward_packed(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1, void* outputs2, uint32_t B, uint32_t L,
                           uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
-                          void* stream, uint32_t level_begin, uint32_t n_levels) {
+                          void* stream, uint32_t level_begin, uint32_t n_levels, float* tv_corners) {
     const char* fn = "grid_encode_forward_packed";
     if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
     // outputs2 == NULL: the density encoder alone from the packed rows.  (Built for the occupancy refresh's 2 M-point query and measured
@@ -4583,9 +4636,17 @@ static int forward_packed(const float* inputs, const void* packed, const int32_t
     const uint32_t blocks = xg ? 8u * (n_levels / (8u / xg)) * n2m_ceil_div(n_tiles, xg) : n_tiles * n_levels;
     N2M_LAUNCH(grid_forward3_packed_kernel, blocks, 256, 0, s, inputs, (const uint2*)packed, offsets, outputs1, (_Float16*)outputs2, B,
                                                        level_begin + n_levels, lv, gridtype, align_corners != 0, interp, n_tiles, in_scale,
-                                                       in_offset, xg, level_begin, n_levels);
+                                                       in_offset, xg, level_begin, n_levels, reinterpret_cast<float4*>(tv_corners));
     N2M_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int n2m_grid_encode_forward_packed_tv(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1, void* outputs2,
+                                                 uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                                 uint32_t interp, float in_scale, float in_offset, float* tv_corners, void* stream) {
+    N2M_REQUIRE(tv_corners == nullptr || ((uintptr_t)tv_corners & 15u) == 0, N2M_EINVAL, "grid_encode_forward_packed_tv: tv_corners must be 16-byte aligned");
+    return forward_packed(inputs, packed, offsets, outputs1, outputs2, B, L, max_level, S, H, gridtype, align_corners, interp, in_scale, in_offset, stream,
+                          0u, max_level < L ? max_level : L, tv_corners);
 }
 
 // Measurement aid: on != 0 arms the stamps of bin_fill_pair_kernel (two workgroups, tid 0); out (may be NULL, else 116 words) receives the 2 x 8 x 6 fill stamps

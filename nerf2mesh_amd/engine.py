@@ -137,6 +137,17 @@ class Stage0Engine:
         # fill and its accumulate (n2m_grid_backward_mid_event).  Measured (round 4, 200 steps): 3 takes the marcher off the lookup (71.4 ->
         # 67.8 us) and off Adam (99 -> 91) but doubles the accumulate beside it (backward 235 -> 301 us): 0.569 -> 0.613 ms/step.
         self.marker_at = int(os.environ.get("N2M_MARKER_AT", "0"))
+        # [round 6, MEASURED AND REJECTED: off by default, N2M_TV_CORNERS=1 turns it on]  The forward lookup leaves, per (hashed level, sample), the
+        # density values of corners 000 / 100 / 010 / 001 of the sample's cell (n2m_grid_encode_forward_packed_tv): centre and +x / +y / +z
+        # neighbours of the TV stencil the table backward's fill evaluates for the same sample a few kernels later on the same table -- which
+        # then gathers three neighbours instead of six.  Why it was built: the fill's fine levels are bound by their XCD's L2 request rate, that
+        # stencil is six of their ~8 scattered requests per (sample, level), and an ABLATION build (three gathers, no records: wrong results)
+        # ran the backward 20.8 us faster (208.8 -> 188.0 us, step 0.541 -> 0.516 ms).  What the real thing does (profiles/r06_tv_corners.txt,
+        # ABBA): backward 210.9 -> 206.8 us, lookup 71.3 -> 77.1 us (46 MB more stores), step 0.5394 -> 0.5431 ms -- the 16-byte record comes
+        # from HBM where the three gathers it replaces hit the L2, and requested a tile ahead like the other inputs it costs the fill's 124-VGPR
+        # kernel its last registers (122 + 32 bytes of scratch).  Same bits either way (tests/test_tv_corners.py).
+        self.tv_corners = (os.environ.get("N2M_TV_CORNERS", "0") == "1" and world_size == 1 and not opt.sdf and opt.lambda_tv > 0
+                           and not self.tv_split)
         self._mid_events = None
         # Live-first sample order for the table backward (round 5; MEASURED AND REJECTED, off by default -- N2M_LIVE_FIRST=1 turns it on).
         # The compositing kernel leaves per ray how many samples precede its early stop -- the others, 48 % of a trained lego batch
@@ -318,6 +329,8 @@ class Stage0Engine:
             w["d_h2"] = torch.empty(32 * cm, dtype=torch.float16, device=dev)
             w["sigma"], w["rgb"], w["weights"], w["d_sr"] = f(cm), f(3 * cm), f(cm), f(4 * cm)
             w["tv"] = f(16 * cm)
+            # the forward lookup's corner records for the table backward's TV stencil ([16, M, 4] fp32; hashed levels written): see tv_corners below
+            w["tv4"] = f(64 * cm) if self.tv_corners else None
             w["spec_partial"] = torch.zeros(self._n_spec, dtype=torch.float32, device=dev)
             w["ws"], w["depth"], w["image"], w["d_image"], w["d_ws"], w["bg"] = f(cn), f(cn), f(3 * cn), f(3 * cn), f(cn), f(3 * cn)
             w["partial"] = f((cn + 3) // 4 + 1)
@@ -832,6 +845,9 @@ class Stage0Engine:
                     done.record()
                 L.call("n2m_grid_encode_forward_packed_levels", *fwd, 0, 8, s)
                 torch.cuda.current_stream(dev).wait_event(done)
+            elif self.tv_corners and self.Lv == 16 and self.fuse_adam is None:
+                L.call("n2m_grid_encode_forward_packed_tv", *fwd, _p(w["tv4"]), s)
+                self._corners_of = (self.global_step, M)          # the records in w["tv4"] belong to THIS step's samples
             else:
                 self._wait_gather()
                 L.call("n2m_grid_encode_forward_packed", *fwd, s)
@@ -966,7 +982,15 @@ class Stage0Engine:
                             e.record()
                     ev = self._mid_events[self.global_step % len(self._mid_events)]
                     L.call("n2m_grid_backward_mid_event", ctypes.c_void_p(ev.cuda_event))
-                backward(0)
+                use_corners = (self.tv_corners and fused is None and tv_terms is None and tv
+                               and getattr(self, "_corners_of", None) == (self.global_step, M))      # ... and only if THIS step's forward wrote them
+                if use_corners:      # (sticky thread-local of the library: set in front of the call it is meant for, cleared behind it whatever happens)
+                    L.call("n2m_grid_backward_tv_corners", _p(w["tv4"]))
+                try:
+                    backward(0)
+                finally:
+                    if use_corners:
+                        L.call("n2m_grid_backward_tv_corners", None)
                 if mid:
                     self._marker = ev
         else:

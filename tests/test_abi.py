@@ -75,13 +75,26 @@ def test_argument_validation_without_gpu(libpath):
     with pytest.raises(RuntimeError, match="second buffer"):
         L.call("n2m_antialias_backward_seeded", 16, 16, 16, 16, 16, 8, 32, 4, 4, 4, 8, 8, 1.0, 32, None, None)
     route = L.PeerRoute()
-    route.world, route.split_row, route.rows_c, route.rows_f = 2, 10, 4, 4            # split_row != world * rows_c
-    with pytest.raises(RuntimeError, match="split_row = world \\* rows_c"):
+    route.world, route.split_row, route.rows_c, route.rows_f = 2, 10, 4, 4            # the chunks do not cover the coarse half: 2 * 4 < 10
+    with pytest.raises(RuntimeError, match="split_row <= world \\* rows_c"):
         L.call("n2m_grid_backward_peer_route", ctypes.byref(route))
+    route.rows_c = 12                                                                   # ... or leave the last rank nothing: (2 - 1) * 12 >= 10
+    with pytest.raises(RuntimeError, match="split_row <= world \\* rows_c"):
+        L.call("n2m_grid_backward_peer_route", ctypes.byref(route))
+    route.rows_c = 8                                                                    # a padded layout (round 6): chunks of 8 and 2 rows -- accepted
+    with pytest.raises(RuntimeError, match="NULL staging slot"):
+        L.call("n2m_grid_backward_peer_route", ctypes.byref(route))
+    route.rows_c = 4
     route.split_row = 8
     with pytest.raises(RuntimeError, match="NULL staging slot"):
         L.call("n2m_grid_backward_peer_route", ctypes.byref(route))
     L.call("n2m_grid_backward_peer_route", None)                                       # clearing is always fine
+    with pytest.raises(RuntimeError, match="16-byte aligned"):                          # round 6: the forward lookup's corner records
+        L.call("n2m_grid_backward_tv_corners", 8)
+    L.call("n2m_grid_backward_tv_corners", None)
+    with pytest.raises(RuntimeError, match="> 32|> 16"):
+        L.call("n2m_grid_backward_merge_levels", 99)
+    L.call("n2m_grid_backward_merge_levels", 0)
     ptrs = L.PeerPtrs()
     with pytest.raises(RuntimeError, match="1..8 flags"):
         L.call("n2m_peer_signal", ctypes.byref(ptrs), 1, None)
