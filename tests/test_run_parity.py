@@ -8,12 +8,13 @@ random draws (pixels, backgrounds, jitter) end this far apart (profiles/r06_run_
 
     lego,   2 000 steps:  rms 1.5 dB (raw) / 2.3 dB (EMA)   -- the run is still recovering from the switch to full shading at step 1 000
     lego,   5 000 steps:  rms 0.09 dB (raw) / 0.12 dB (EMA)
+    lego,  30 000 steps:  rms 0.27 dB (raw) / 0.16 dB (EMA)  -- the reference's full schedule
     garden, 2 000 steps:  rms 0.02 dB
     sdf,    2 000 steps:  rms 0.12 dB
 
 and the executor necessarily draws differently from the reference loop (one [N,6] draw per batch instead of torch's global generator), so
-|executor - reference| is compared with THAT spread: at 5 000 lego steps the paired difference over 4 seeds is -0.04 +- 0.10 dB (EMA),
--0.06 +- 0.07 dB (raw).  The executor itself is bit-reproducible: two runs from one state end in identical bits (spread 0, asserted).
+|executor - reference| is compared with THAT spread: at the full 30 000 steps the paired difference over 6 seeds is -0.004 +- 0.058 dB (EMA),
+-0.02 +- 0.06 dB (raw); at 5 000 steps over 4 seeds -0.04 +- 0.10 dB (EMA), -0.06 +- 0.07 dB (raw); garden at 30 000 steps -0.001 +- 0.004 dB.  The executor itself is bit-reproducible: two runs from one state end in identical bits (spread 0, asserted).
 
 The driver-visible test below runs the lego recipe at 5 000 steps on 2 seeds (~2.5 minutes: the reference loop takes 9-10 ms per step) and
 holds the mean difference to 0.3 dB = 0.1 dB + twice the standard error two seeds leave (0.1 dB per seed rms / sqrt(2) ~ 0.07);
