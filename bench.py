@@ -876,7 +876,7 @@ def _main():
                                    f"{dist.get_backend()})" if getattr(tr, "shard", False) else
                                    f"dp{world} (rays sharded, grad all-reduce over {dist.get_backend()})") if world > 1 else "single GPU",
                    "occupancy_refresh": ("sharded over the ranks by Morton range + all-gather of the densities" if getattr(model, "refresh_shard", None) else
-                                         "replicated on every rank (N2M_SHARD_REFRESH=0, or a gloo run without N2M_SHARD_REFRESH=1)") if world > 1 else "single GPU",
+                                         "replicated on every rank (N2M_SHARD_REFRESH=0)") if world > 1 else "single GPU",
                    "mlp": "nn.Linear (unfused)" if args.unfused else "fused MFMA field kernels",
                    "driver": "engine.Stage0Engine (fixed launch sequence)" if use_engine else "trainer.Stage0Trainer (torch.autograd)", "pretrain_steps": args.pretrain, "samples_per_step_per_gpu": samples / args.steps / world,
                    "rays_per_step_per_gpu": rays / args.steps / world, "params": 18367240},

@@ -122,13 +122,16 @@ class GradSync:
 
 def shard_refresh_default():
     """Whether the occupancy refresh's density query is dealt to the ranks (renderer.update_extra_state).  N2M_SHARD_REFRESH=1 / 0 decides; unset:
-    on over RCCL (stream-ordered collectives, one device per rank), off over gloo -- the test mode in which ranks share a GPU and every collective
-    blocks the host: there a refresh step now and then stalls for 10-40 s, and the replicated query needs no collective at all."""
+    on whenever there is more than one rank.  (Rounds 4-5 kept it off over gloo -- the test mode in which two ranks time-share ONE GPU -- because
+    "a refresh step now and then stalls for 10-40 s" there.  Round 6 measured where those stalls sit (tools/two_rank_steps.py, 320 steps per mode,
+    profiles/r06_two_ranks_gloo_stalls.txt): in ORDINARY steps, at the same rate with the replicated refresh (40.4 s at step 36, 0.9 s at step 307)
+    as with the sharded one (3.2 s at step 54, 9.4 s at step 228); every refresh step takes its 60-70 ms in both.  They belong to gloo's
+    host-blocking collectives between two processes that share a device, not to the refresh.)"""
     import os
     flag = os.environ.get("N2M_SHARD_REFRESH")
     if flag is not None:
         return flag != "0"
-    return dist.is_initialized() and dist.get_backend() == "nccl"
+    return dist.is_initialized() and dist.get_world_size() > 1
 
 
 def all_ranks_hold(summary, world):
