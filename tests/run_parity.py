@@ -185,6 +185,11 @@ def train_engine(recipe, seed, steps, poses, init, device, log=None):
     model = model.to(device)
     model.load_state_dict(init, strict=True)
     eng = Stage0Engine(model, opt, poses, device, seed=seed, ema_decay=EMA_DECAY)
+    if os.environ.get("N2M_PARITY_ENGINE_NO_SCALE_GROWTH") == "1":
+        # (triangulation aid: the loss scale never grows beyond GradScaler's initial 65536 -- the reference's fp16 graph overflows above ~2^16 and
+        #  lives at 2^15-2^16, the executor's fused field keeps intermediate gradients in fp32 and climbs to 2^24-2^27)
+        gf, bf, gi = eng.optimizer.growth
+        eng.optimizer.growth = (1.0, bf, gi)
     eng.mark_untrained()
     t0 = time.perf_counter()
     for it in range(steps):
