@@ -309,6 +309,18 @@ int n2m_grid_encode_forward_packed_tv(const float* inputs, const void* packed, c
                                       void* outputs2, uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H,
                                       uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
                                       float* tv_corners, void* stream);
+/* Round 6.  The packed lookup that also leaves the FINISHED total-variation terms of its samples: tv_out [L, B] fp32, tv_out[level, b] = the term
+ * gridencoder.cu:505-609 (kernel_grad_tv) adds to the gradient of the cell of sample b on `level`, weighted like nerf/utils.py:800-823 (tv_weight inside
+ * the inner region |x - 0.5| <= tv_inner01, tv_weight_outer outside, both times *tv_scale when given = the GradScaler factor) -- bit for bit what
+ * n2m_grid_tv_terms computes from the packed table's density column.  Four of the stencil's seven values are corners 000 / 100 / 010 / 001 of the
+ * interpolation cell, which the lookup holds in registers; at most three more rows are gathered.  n2m_grid_encode_backward_binned_pair_tvt
+ * consumes tv_out: the table backward's fill then reads 4 coalesced bytes per (sample, level) instead of gathering the stencil.  max_level == L.
+ * outputs1 / outputs2 are bit-identical to n2m_grid_encode_forward_packed's. */
+int n2m_grid_encode_forward_packed_tvterms(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1,
+                                           void* outputs2, uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H,
+                                           uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
+                                           float tv_weight, float tv_weight_outer, float tv_inner01, const float* tv_scale,
+                                           float* tv_out, void* stream);
 /* Sticky, per thread; NULL clears it.  The corner records the next n2m_grid_encode_backward_binned_pair[_half] calls of this thread may use for
  * their folded TV term (see above).  Used when the call computes the term itself, runs in one pass (B <= 2^20) over one point list in input
  * order without folded copies; ignored otherwise.  The caller guarantees: same B, same inputs, same table values as the forward that wrote them.

@@ -55,6 +55,7 @@ SIGNATURES = {
     "n2m_grid_encode_forward_pair": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _f32, _f32, _vp],
     "n2m_grid_encode_forward_packed": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _f32, _f32, _vp],
     "n2m_grid_encode_forward_packed_tv": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _f32, _f32, _vp, _vp],
+    "n2m_grid_encode_forward_packed_tvterms": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp],
     "n2m_grid_backward_tv_corners": [_vp],
     "n2m_grid_encode_forward_packed_levels": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32, _f32, _f32, _u32, _u32, _vp],
     "n2m_grid_binned_pair_workspace_bytes": [_u32, _u32, _vp],                                  # returns uint64 (RESTYPES)

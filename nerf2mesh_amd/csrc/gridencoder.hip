@@ -428,16 +428,63 @@ __device__ __forceinline__ void atomic_add_row(float* dst, const float* v, uint3
     for (uint32_t c = 0; c < C; ++c) unsafeAtomicAdd(dst + c, v[c]);
 }
 
+// TV weighting of the fused / stand-alone TV: weight (inner region) or weight_outer (|xyz|_inf > 1, nerf/utils.py:815-821),
+// both times *scale_ptr when given (the GradScaler factor, so that the term can be added to still-scaled gradients).
+struct TvParams {
+    const float* table;       // fp32 [rows, 1]; NULL = no TV
+    float weight, weight_outer, inner01;      // inner01: half extent of the inner region in [0,1] input space (>= 0.5: everything is inner)
+    const float* scale_ptr;
+    uint32_t stride = 1;      // floats between consecutive rows of `table`: 2 reads the density column of a packed {fp32, half2} table
+    // [L, Bstride, 4] fp32 or NULL: per (level, sample) the table's values at corners 000 / 100 / 010 / 001 of the sample's interpolation cell, left
+    // by the forward lookup of the SAME samples on the SAME table state (n2m_grid_encode_forward_packed_tv, hashed levels only).  They are the
+    // centre and the +x / +y / +z neighbours of the TV stencil: the fill then gathers three neighbours instead of six (round 6).
+    const float* corners = nullptr;
+};
+
+// (w = inner ? weight : weight_outer; w *= *scale_ptr; w /= 2 D -- the reference's operations, once per kernel: an IEEE division, ten
+// instructions, per (sample, level) until round 4.)  One function for every kernel that forms TV terms: the fill, n2m_grid_tv_terms and the forward lookup
+// that leaves finished terms (n2m_grid_encode_forward_packed_tvterms).
+__device__ __forceinline__ void tv_weights(const TvParams& tv, float& w_in, float& w_out) {
+    float wi = tv.weight, wo = tv.weight_outer;
+    if (tv.table && tv.scale_ptr) { const float s = *tv.scale_ptr; wi *= s; wo *= s; }
+    w_in = wi / 6.0f; w_out = wo / 6.0f;
+}
+__device__ __forceinline__ bool tv_inner(const TvParams& tv, const float (&x)[3]) {
+    return fmaxf(fmaxf(fabsf(x[0] - 0.5f), fabsf(x[1] - 0.5f)), fabsf(x[2] - 0.5f)) <= tv.inner01;
+}
+// gridencoder.cu:505-609 behind the gathers: the sum over the in-grid neighbours in the reference's order (+x -x +y -y +z -z).
+// rsqrtf like the reference (gridencoder.cu:606; an approximate intrinsic there too): v_rsq_f32, 1 ulp -- IEEE sqrt + IEEE division
+// were ~22 instructions per (sample, level) in a kernel whose SIMDs are busy issuing VALU work more than half of the time
+__device__ __forceinline__ float tv_reduce6(float centre, const float (&nb)[6], const bool (&nb_ok)[6], float w) {
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (uint32_t k = 0; k < 6; ++k)
+        if (nb_ok[k]) { const float dv = centre - nb[k]; sum += dv; sq += dv * dv; }
+    return w * sum * __builtin_amdgcn_rsqf(sq + 1e-9f);
+}
+
 // one thread per (sample, level): scatter w * grad into the 2^D rows
 // The same forward on a PACKED table: row r = 8 bytes {fp32 density feature, 2 x fp16 colour features}.  The gathers of this
 // kernel move one 64-byte line from L2 per vertex pair to use 8 bytes of it; with the two tables interleaved the same line
 // serves both encoders, i.e. half the line traffic for the pair (the packed copy is kept fresh by the optimizer's update pass,
 // n2m_adam_step shadow modes 2/3).  Arithmetic and outputs are identical to grid_forward3_pair_kernel.
+//
+// TVT (round 6, n2m_grid_encode_forward_packed_tvterms): the lookup also leaves the FINISHED total-variation term of the sample's cell,
+// tv_out[level, b] = what the table backward's fill adds to vertex 000's density entry (gridencoder.cu:505-609; nerf/utils.py:800-823 applies it to the
+// marched samples of the same step, on the same table state).  The TV cell floor(x * scale + 0.5) IS the interpolation cell's vertex 000, so four of
+// the stencil's seven values -- centre and +x / +y / +z -- are corners 000 / 100 / 010 / 001, already in registers here; on a hashed level the -x
+// neighbour of an odd cell is the other half of corner 000's 16-byte pair.  Left to gather: -y, -z and (even cells) -x.  The fill then reads 4 coalesced
+// bytes per (sample, level) instead of gathering six rows inside its tile's dependent chain.  Same function of the same values as the in-place
+// stencil (tv_reduce6, tv_weights): identical bits.
+__device__ __forceinline__ float tv_term(const float* __restrict__ tab, const Indexer<3>& ix, uint32_t (&cell)[3], uint32_t here, uint32_t resolution,
+                                         float w, uint32_t stride);
+template <bool TVT>
 __global__ void __launch_bounds__(256)
 grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __restrict__ packed, const int32_t* __restrict__ offsets,
                             float* __restrict__ out1, _Float16* __restrict__ out2, uint32_t B, uint32_t max_level, LevelTable lv,
                             uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t n_tiles, float in_scale, float in_offset,
-                            uint32_t xcd_group, uint32_t level_begin = 0u, uint32_t n_levels = 16u, float4* __restrict__ tv4 = nullptr) {
+                            uint32_t xcd_group, uint32_t level_begin, uint32_t n_levels, float4* __restrict__ tv4, TvParams tv,
+                            float* __restrict__ tv_out) {
     __builtin_amdgcn_s_setprio(3);      // runs beside the next batch's marcher (second stream): win the issue arbitration
     constexpr uint32_t D = 3;
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -484,6 +531,7 @@ grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __res
         Row<_Float16, 2> z;
         z.v[0] = z.v[1] = (_Float16)0;
         if (o2) z.store(o2);
+        if constexpr (TVT) tv_out[(size_t)level * B + b] = 0.0f;
         return;
     }
     uint32_t cell[D];
@@ -491,9 +539,19 @@ grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __res
     locate<D>(x, scale, align_corners, interp, cell, frac, dfrac);
 
     uint2 g[8];                                           // packed rows of the 8 vertices
+    // TVT: the -x / -y / -z neighbours' density values (requested together with the corners), and whether the fast forms found them
+    [[maybe_unused]] float tvm[3] = {0.f, 0.f, 0.f};
+    [[maybe_unused]] bool tv_fast = true;
+    [[maybe_unused]] const uint32_t tv_res = lv.resolution[level];
+    [[maybe_unused]] const float* __restrict__ tabf = reinterpret_cast<const float*>(tab);
     const bool dense = !ix.hashed && !ix.wrap;
     if (dense) {
         const uint32_t base = cell[0] + cell[1] * ix.stride[1] + cell[2] * ix.stride[2];
+        if constexpr (TVT) {
+            tvm[0] = tabf[(size_t)(cell[0] > 0u ? base - 1u : base) * 2u];
+            tvm[1] = tabf[(size_t)(cell[1] > 0u ? base - ix.stride[1] : base) * 2u];
+            tvm[2] = tabf[(size_t)(cell[2] > 0u ? base - ix.stride[2] : base) * 2u];
+        }
 #pragma unroll
         for (uint32_t q = 0; q < 4; ++q) {
             const uint32_t r = base + ((q & 1u) ? ix.stride[1] : 0u) + ((q & 2u) ? ix.stride[2] : 0u);
@@ -519,12 +577,20 @@ grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __res
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) extra[q] = tab[rx1[q]];
         }
+        if constexpr (TVT) {
+            // the x prime is 1: the -x neighbour of an odd cell is row rx[0] ^ 1, the other half of corner 000's pair (filled in below)
+            const uint32_t h00 = hy0 ^ hz0;
+            if (x_even) tvm[0] = tabf[(size_t)(cell[0] > 0u ? ((cell[0] - 1u) ^ h00) & ix.mask : rx[0]) * 2u];
+            tvm[1] = tabf[(size_t)(cell[1] > 0u ? (cell[0] ^ (hy0 - kPrimes[1]) ^ hz0) & ix.mask : rx[0]) * 2u];
+            tvm[2] = tabf[(size_t)(cell[2] > 0u ? (cell[0] ^ hy0 ^ (hz0 - kPrimes[2])) & ix.mask : rx[0]) * 2u];
+        }
 #pragma unroll
         for (uint32_t q = 0; q < 4; ++q) {
             const bool odd_row = (rx[q] & 1u) != 0u;
             const uint2 lo = make_uint2(pr[q].x, pr[q].y), hi = make_uint2(pr[q].z, pr[q].w);
             g[2 * q] = odd_row ? hi : lo;
             g[2 * q + 1] = x_even ? (odd_row ? lo : hi) : extra[q];
+            if constexpr (TVT) { if (q == 0u && !x_even) tvm[0] = __uint_as_float(odd_row ? lo.x : hi.x); }
         }
         // the density column of corners 000 / 100 / 010 / 001 = centre and +x / +y / +z neighbours of this sample's TV stencil (the TV cell
         // floor(x * scale + 0.5) IS the interpolation cell's vertex 000): one coalesced 16-byte record for the table backward's fill, which then
@@ -536,6 +602,21 @@ grid_forward3_packed_kernel(const float* __restrict__ inputs, const uint2* __res
             const uint32_t v[D] = {cell[0] + (corner & 1u), cell[1] + ((corner >> 1) & 1u), cell[2] + (corner >> 2)};
             g[corner] = tab[ix.row(v)];
         }
+        tv_fast = false;
+    }
+    if constexpr (TVT) {
+        float w_in, w_out;
+        tv_weights(tv, w_in, w_out);
+        const float w = tv_inner(tv, x) ? w_in : w_out;
+        float tvv;
+        if (tv_fast) {
+            const float nb[6] = {__uint_as_float(g[1].x), tvm[0], __uint_as_float(g[2].x), tvm[1], __uint_as_float(g[4].x), tvm[2]};
+            const bool nb_ok[6] = {cell[0] < tv_res, cell[0] > 0u, cell[1] < tv_res, cell[1] > 0u, cell[2] < tv_res, cell[2] > 0u};
+            tvv = tv_reduce6(__uint_as_float(g[0].x), nb, nb_ok, w);
+        } else {
+            tvv = tv_term(tabf, ix, cell, ix.row(cell), tv_res, w, 2u);      // generic indexer (wrapping / non-power-of-two hash): the fill's IMODE 0
+        }
+        tv_out[(size_t)level * B + b] = tvv;
     }
     float a1 = 0.0f;
     _Float16 a2[2] = {(_Float16)0, (_Float16)0};
@@ -1133,19 +1214,6 @@ __device__ __forceinline__ float tv_term(const float* __restrict__ tab, const In
     return w * sum * (1.0f / sqrtf(sq + 1e-9f));
 }
 
-// TV weighting of the fused / stand-alone TV: weight (inner region) or weight_outer (|xyz|_inf > 1, nerf/utils.py:815-821),
-// both times *scale_ptr when given (the GradScaler factor, so that the term can be added to still-scaled gradients).
-struct TvParams {
-    const float* table;       // fp32 [rows, 1]; NULL = no TV
-    float weight, weight_outer, inner01;      // inner01: half extent of the inner region in [0,1] input space (>= 0.5: everything is inner)
-    const float* scale_ptr;
-    uint32_t stride = 1;      // floats between consecutive rows of `table`: 2 reads the density column of a packed {fp32, half2} table
-    // [L, Bstride, 4] fp32 or NULL: per (level, sample) the table's values at corners 000 / 100 / 010 / 001 of the sample's interpolation cell, left
-    // by the forward lookup of the SAME samples on the SAME table state (n2m_grid_encode_forward_packed_tv, hashed levels only).  They are the
-    // centre and the +x / +y / +z neighbours of the TV stencil: the fill then gathers three neighbours instead of six (round 6).
-    const float* corners = nullptr;
-};
-
 // MODE 0: backward entries; MODE 1: TV entries only (8 samples per thread); MODE 2: backward + TV folded into vertex 000's
 // entry (the TV cell floor(x*scale+0.5) IS that vertex) -- fp32 C=1 tables.
 template <typename T, uint32_t C, int MODE>
@@ -1331,9 +1399,9 @@ struct PairCtx {
 };
 // (w = inner ? weight : weight_outer; w *= *scale_ptr; w /= 2 D -- an IEEE division, ten instructions, per (sample, level) until round 4)
 __device__ __forceinline__ PairCtx make_pair_ctx(const TvParams& tv, const float* tv_tab, float scale, uint32_t resolution, bool align_corners, uint32_t interp) {
-    float wi = tv.weight, wo = tv.weight_outer;
-    if (tv.table && tv.scale_ptr) { const float s = *tv.scale_ptr; wi *= s; wo *= s; }
-    return PairCtx{tv, tv_tab, scale, resolution, align_corners, interp, wi / 6.0f, wo / 6.0f};
+    float w_in, w_out;
+    tv_weights(tv, w_in, w_out);
+    return PairCtx{tv, tv_tab, scale, resolution, align_corners, interp, w_in, w_out};
 }
 
 // TV term of one (sample, level): gridencoder.cu:505-609 on the cell floor(x * scale + 0.5) -- vertex 000 of the interpolation cell.  One
@@ -1349,8 +1417,7 @@ __device__ __forceinline__ float pair_tv_value(const PairCtx& cx, const Indexer<
     constexpr uint32_t D = 3;
     auto comb = [&](uint32_t a, uint32_t b, uint32_t c) { return IMODE == 1 ? ((a ^ b ^ c) & ix.mask) : (a + b + c); };
     float tvv = 0.0f;
-        const bool inner = fmaxf(fmaxf(fabsf(x[0] - 0.5f), fabsf(x[1] - 0.5f)), fabsf(x[2] - 0.5f)) <= cx.tv.inner01;
-        const float w = inner ? cx.tv_w_in : cx.tv_w_out;
+        const float w = tv_inner(cx.tv, x) ? cx.tv_w_in : cx.tv_w_out;
         if constexpr (IMODE == 0) tvv = tv_term(cx.tv_tab, ix, cell, rows[0], cx.resolution, w, cx.tv.stride);
         else {
             // gridencoder.cu:505-609, neighbours in the reference's order: +x -x +y -y +z -z; out-of-grid ones are skipped
@@ -1414,13 +1481,7 @@ __device__ __forceinline__ float pair_tv_value(const PairCtx& cx, const Indexer<
 #pragma unroll
                 for (uint32_t k = 0; k < 6; ++k) nb[k] = tab[(size_t)(nb_ok[k] ? nb_row[k] : rows[0]) * st];
             }
-            float sum = 0.f, sq = 0.f;
-#pragma unroll
-            for (uint32_t k = 0; k < 6; ++k)
-                if (nb_ok[k]) { const float dv = centre - nb[k]; sum += dv; sq += dv * dv; }
-            // rsqrtf like the reference (gridencoder.cu:606; an approximate intrinsic there too): v_rsq_f32, 1 ulp -- IEEE sqrt + IEEE division
-            // were ~22 instructions per (sample, level) in a kernel whose SIMDs are busy issuing VALU work more than half of the time
-            tvv = w * sum * __builtin_amdgcn_rsqf(sq + 1e-9f);
+            tvv = tv_reduce6(centre, nb, nb_ok, w);
         }
     return tvv;
 }
@@ -4589,7 +4650,8 @@ extern "C" int n2m_grid_encode_forward_pair(const float* inputs, const float* em
 
 static int forward_packed(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1, void* outputs2, uint32_t B, uint32_t L,
                           uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
-                          void* stream, uint32_t level_begin, uint32_t n_levels, float* tv_corners = nullptr);
+                          void* stream, uint32_t level_begin, uint32_t n_levels, float* tv_corners = nullptr, const TvParams* tvp = nullptr,
+                          float* tv_out = nullptr);
 
 extern "C" int n2m_grid_encode_forward_packed(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1, void* outputs2,
                                               uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
@@ -4613,7 +4675,7 @@ extern "C" int n2m_grid_encode_forward_packed_levels(const float* inputs, const 
 
 static int forward_packed(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1, void* outputs2, uint32_t B, uint32_t L,
                           uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, float in_scale, float in_offset,
-                          void* stream, uint32_t level_begin, uint32_t n_levels, float* tv_corners) {
+                          void* stream, uint32_t level_begin, uint32_t n_levels, float* tv_corners, const TvParams* tvp, float* tv_out) {
     const char* fn = "grid_encode_forward_packed";
     if (int rc = check_dims(fn, 3, 2, L, max_level, N2M_F16)) return rc;
     // outputs2 == NULL: the density encoder alone from the packed rows.  (Built for the occupancy refresh's 2 M-point query and measured
@@ -4626,17 +4688,27 @@ static int forward_packed(const float* inputs, const void* packed, const int32_t
     const LevelTable lv = make_levels(L, S, H);
     // algorithmic bytes of both encoders' forward (588 B/sample each at L = 16, one 12-byte input read shared)
     // (one scope object for the whole launch: its destructor records the closing event)
+    // (+ with the TV terms: the stencil's three rows beyond the corners and the 4-byte term, per level)
     N2M_PROF_K(outputs2 ? N2M_K_GRID_FWD_PACKED : N2M_K_GRID_FWD, s,
-             outputs2 ? (double)B * (12.0 + (double)n_levels * 8 * (4 + 4) + (double)n_levels * (4 + 4))
-                      : (double)B * (12.0 + (double)n_levels * 8 * 4 + (double)n_levels * 4));
+             (outputs2 ? (double)B * (12.0 + (double)n_levels * 8 * (4 + 4) + (double)n_levels * (4 + 4))
+                       : (double)B * (12.0 + (double)n_levels * 8 * 4 + (double)n_levels * 4)) + (tv_out ? (double)B * n_levels * (3 * 4.0 + 4.0) : 0.0));
     const uint32_t n_tiles = n2m_ceil_div(B, 256);
     static const uint32_t xg_env = getenv("N2M_FWD_XCD_GROUP") ? (uint32_t)atoi(getenv("N2M_FWD_XCD_GROUP")) : 4u;     // A/B switch: 0 = level-major grid
     // XCD groups: every group of 8 / xg XCD sets owns n_levels / groups levels in pairs (coarse with fine): 16 levels, or a half of 8
     const uint32_t xg = ((n_levels == 16u || n_levels == 8u) && (xg_env == 1u || xg_env == 2u || xg_env == 4u) && n_levels % (2u * (8u / xg_env)) == 0u) ? xg_env : 0u;
     const uint32_t blocks = xg ? 8u * (n_levels / (8u / xg)) * n2m_ceil_div(n_tiles, xg) : n_tiles * n_levels;
-    N2M_LAUNCH(grid_forward3_packed_kernel, blocks, 256, 0, s, inputs, (const uint2*)packed, offsets, outputs1, (_Float16*)outputs2, B,
-                                                       level_begin + n_levels, lv, gridtype, align_corners != 0, interp, n_tiles, in_scale,
-                                                       in_offset, xg, level_begin, n_levels, reinterpret_cast<float4*>(tv_corners));
+    if (tv_out) {
+        TvParams tv = *tvp;
+        tv.table = reinterpret_cast<const float*>(packed);      // the density column of the packed rows (stride 2), the table the lookup reads anyway
+        tv.stride = 2u;
+        N2M_LAUNCH(grid_forward3_packed_kernel<true>, blocks, 256, 0, s, inputs, (const uint2*)packed, offsets, outputs1, (_Float16*)outputs2, B,
+                   level_begin + n_levels, lv, gridtype, align_corners != 0, interp, n_tiles, in_scale, in_offset, xg, level_begin, n_levels,
+                   (float4*)nullptr, tv, tv_out);
+    } else {
+        N2M_LAUNCH(grid_forward3_packed_kernel<false>, blocks, 256, 0, s, inputs, (const uint2*)packed, offsets, outputs1, (_Float16*)outputs2, B,
+                   level_begin + n_levels, lv, gridtype, align_corners != 0, interp, n_tiles, in_scale, in_offset, xg, level_begin, n_levels,
+                   reinterpret_cast<float4*>(tv_corners), TvParams{}, (float*)nullptr);
+    }
     N2M_CHECK_LAUNCH();
     return 0;
 }
@@ -4647,6 +4719,22 @@ extern "C" int n2m_grid_encode_forward_packed_tv(const float* inputs, const void
     N2M_REQUIRE(tv_corners == nullptr || ((uintptr_t)tv_corners & 15u) == 0, N2M_EINVAL, "grid_encode_forward_packed_tv: tv_corners must be 16-byte aligned");
     return forward_packed(inputs, packed, offsets, outputs1, outputs2, B, L, max_level, S, H, gridtype, align_corners, interp, in_scale, in_offset, stream,
                           0u, max_level < L ? max_level : L, tv_corners);
+}
+
+// The lookup that also leaves the FINISHED TV terms of its samples (round 6): tv_out [L, B] fp32, tv_out[level, b] = the value n2m_grid_tv_terms computes
+// for (sample b, level) from the same packed table (density column) -- bit for bit -- at the cost of at most three more gathers per (sample, level):
+// the stencil's centre and +x / +y / +z neighbours are corners the lookup has in registers.  n2m_grid_encode_backward_binned_pair_tvt consumes the
+// terms.  tv_scale (device, may be NULL) multiplies both weights (the GradScaler factor the backward of the same step will run under).
+// Reference semantics: gridencoder.cu:505-609 (kernel_grad_tv) at nerf/utils.py:800-823's samples and weights.
+extern "C" int n2m_grid_encode_forward_packed_tvterms(const float* inputs, const void* packed, const int32_t* offsets, float* outputs1, void* outputs2,
+                                                      uint32_t B, uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype,
+                                                      int align_corners, uint32_t interp, float in_scale, float in_offset, float tv_weight,
+                                                      float tv_weight_outer, float tv_inner01, const float* tv_scale, float* tv_out, void* stream) {
+    N2M_REQUIRE(tv_out != nullptr, N2M_ENULL, "grid_encode_forward_packed_tvterms: NULL tv_out");
+    N2M_REQUIRE(max_level == L, N2M_EINVAL, "grid_encode_forward_packed_tvterms: TV terms need max_level == L (every level of tv_out is written)");
+    const TvParams tv{nullptr, tv_weight, tv_weight_outer, tv_inner01, tv_scale, 2u};
+    return forward_packed(inputs, packed, offsets, outputs1, outputs2, B, L, max_level, S, H, gridtype, align_corners, interp, in_scale, in_offset, stream,
+                          0u, L, nullptr, &tv, tv_out);
 }
 
 // Measurement aid: on != 0 arms the stamps of bin_fill_pair_kernel (two workgroups, tid 0); out (may be NULL, else 116 words) receives the 2 x 8 x 6 fill stamps

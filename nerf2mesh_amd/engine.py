@@ -148,6 +148,13 @@ class Stage0Engine:
         # kernel its last registers (122 + 32 bytes of scratch).  Same bits either way (tests/test_tv_corners.py).
         self.tv_corners = (os.environ.get("N2M_TV_CORNERS", "0") == "1" and world_size == 1 and not opt.sdf and opt.lambda_tv > 0
                            and not self.tv_split)
+        # [round 6]  TV terms from the forward lookup (N2M_TV_FWD=1): n2m_grid_encode_forward_packed_tvterms leaves the FINISHED term of every
+        # (sample, level) -- the stencil's centre and +x / +y / +z values are corners the lookup holds in registers, at most three more rows are
+        # gathered -- and the table backward consumes them through n2m_grid_encode_backward_binned_pair_tvt: its fill reads 4 coalesced bytes per
+        # (sample, level) instead of gathering six rows inside its tile's dependent chain (what the corner records above could not deliver: they
+        # still left three gathers and a 16-byte record in that chain).  Same bits (tests/test_tv_fwd.py).  Measured: DESIGN 4.4 / 7.
+        self.tv_fwd = (os.environ.get("N2M_TV_FWD", "0") == "1" and world_size == 1 and not opt.sdf and opt.lambda_tv > 0
+                       and not self.tv_split and not self.tv_corners)
         self._mid_events = None
         # Live-first sample order for the table backward (round 5; MEASURED AND REJECTED, off by default -- N2M_LIVE_FIRST=1 turns it on).
         # The compositing kernel leaves per ray how many samples precede its early stop -- the others, 48 % of a trained lego batch
@@ -827,6 +834,7 @@ class Stage0Engine:
         if opt.sdf:
             return self._step_sdf(b, M, N, w, xyzs, dirs, ts, shading, seed, pk)
         # ---- forward
+        fwd_terms = False
         if M > 0:
             fwd = (_p(xyzs), _p(pk), _p(e1.offsets), _p(w["h1"]), _p(w["h2"]), M, self.Lv, self.Lv, self.S, self.H0, e1.gridtype_id,
                    int(bool(e1.align_corners)), e1.interp_id, float(self.aff[0]), float(self.aff[1]))
@@ -848,6 +856,12 @@ class Stage0Engine:
             elif self.tv_corners and self.Lv == 16 and self.fuse_adam is None:
                 L.call("n2m_grid_encode_forward_packed_tv", *fwd, _p(w["tv4"]), s)
                 self._corners_of = (self.global_step, M)          # the records in w["tv4"] belong to THIS step's samples
+            elif self.tv_fwd and self.Lv == 16 and self.fuse_adam is None:
+                # (weights as in the backward's tv_args below; `seed` = the loss scale this step's backward runs under: the scaler's update of the
+                #  last step is ahead of this launch on the stream)
+                L.call("n2m_grid_encode_forward_packed_tvterms", *fwd, float(opt.lambda_tv), float(opt.lambda_tv * (10 if opt.bound > 1 else 1)),
+                       float(0.5 / model.bound), _p(seed), _p(w["tv"]), s)
+                fwd_terms = True
             else:
                 self._wait_gather()
                 L.call("n2m_grid_encode_forward_packed", *fwd, s)
@@ -872,6 +886,9 @@ class Stage0Engine:
                 tv_terms = w["tv"]
                 if self.tv_at == 0:
                     start_tv()
+            elif fwd_terms:
+                tv_terms = w["tv"]                               # written by this step's lookup, on this stream
+                self._tv_done = None
             # full shading: the specular regulariser (nerf/utils.py:733-737) rides in the field kernels -- the forward leaves per-workgroup
             # sums of specular^2, the backward adds 2 lambda / M * specular * seed to the recomputed activation's gradient; the [M,3]
             # specular tensor is neither written nor read
@@ -924,7 +941,8 @@ class Stage0Engine:
                 backward = lambda half: L.call("n2m_grid_encode_backward_binned_pair_adam", *common, *tv_args, *tail[:3], _p(ws), ws.numel(),
                                                ctypes.addressof(fused), s)
             elif tv_terms is not None:
-                torch.cuda.current_stream(dev).wait_event(self._tv_done)
+                if self._tv_done is not None:
+                    torch.cuda.current_stream(dev).wait_event(self._tv_done)
                 backward = lambda half: L.call("n2m_grid_encode_backward_binned_pair_tvt", *common, _p(tv_terms), *tail, half)
             else:
                 tv_args = ((_p(pk) if self._bwd_cfg[0] == 2 else _p(e1.embeddings)) if tv else None, float(opt.lambda_tv),
