@@ -186,6 +186,11 @@ int n2m_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int al
 int n2m_compact_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out, int32_t* n_out_dev,
                       void* stream);
 
+/* New (no reference counterpart): out_idx[0..n_out) = the indices i in [0, n) with values[i * stride] > 0, ascending (int64, what torch indexing
+ * takes); *n_out_dev = their number.  Replaces `torch.nonzero(mask > 0)` in front of the stage-1 shading (the covered pixels of
+ * nerf/renderer.py:873-875, `mask` = the interpolated coverage) by the library's own scan: same indices, three launches, no host read inside. */
+int n2m_select_positive(const float* values, uint32_t n, uint32_t stride, int64_t* out_idx, int32_t* n_out_dev, void* stream);
+
 /* The inference loop of nerf/renderer.py:764-802 with the ray count kept ON THE DEVICE.  The reference reads n_alive back every round
  * (`rays_alive = rays_alive[rays_alive >= 0]`, :799) to size the next round's launches and to derive n_step = max(min(N // n_alive, 8), 1)
  * (:775).  Here `state` = {n_alive, step} (int32 x 2, device) carries both; the three kernels of a round read it, derive n_step the same way

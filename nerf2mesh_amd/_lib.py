@@ -41,6 +41,7 @@ SIGNATURES = {
     "n2m_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_composite_rays": [_u32, _u32, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_compact_alive": [_vp, _u32, _vp, _vp, _vp],
+    "n2m_select_positive": [_vp, _u32, _u32, _vp, _vp, _vp],
     "n2m_march_rays_dev": [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _f32, _int, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_composite_rays_dev": [_vp, _u32, _u32, _u32, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_compact_alive_dev": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],

@@ -921,6 +921,17 @@ struct CompactOp {
     __device__ void finish(uint32_t total) const { n_out[0] = (int32_t)total; }
 };
 
+struct SelectPositiveOp {  // out[k] = index of the k-th item whose value is > 0 (ascending), n_out = their number: torch.nonzero(v > 0) without its host read
+    const float* values;
+    uint32_t stride;
+    int64_t* out;
+    int32_t* n_out;
+    __device__ uint32_t base() const { return 0u; }
+    __device__ uint32_t load(uint32_t i) const { return values[(size_t)i * stride] > 0.0f ? 1u : 0u; }
+    __device__ void store(uint32_t i, uint32_t v, uint32_t excl) const { if (v) out[excl] = (int64_t)i; }
+    __device__ void finish(uint32_t total) const { n_out[0] = (int32_t)total; }
+};
+
 struct CompactDevOp {      // the same with the item count in device memory; writes the NEXT round's state {n_alive, step + n_step}
     const int32_t* in;
     int32_t* out;
@@ -1863,6 +1874,16 @@ extern "C" int n2m_compact_alive(const int32_t* rays_alive, uint32_t n_alive, in
     if (n_alive > 0) { N2M_NOTNULL(rays_alive); N2M_NOTNULL(out); }
     const int rc = run_exclusive_scan(CompactOp{rays_alive, out, n_out_dev}, n_alive, (hipStream_t)stream);
     if (rc) { n2m_set_error("compact_alive: scan failed (%d)", rc); return rc; }
+    N2M_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int n2m_select_positive(const float* values, uint32_t n, uint32_t stride, int64_t* out_idx, int32_t* n_out_dev, void* stream) {
+    N2M_NOTNULL(n_out_dev);
+    N2M_REQUIRE(stride >= 1, N2M_EINVAL, "select_positive: stride must be >= 1 float");
+    if (n > 0) { N2M_NOTNULL(values); N2M_NOTNULL(out_idx); }
+    const int rc = run_exclusive_scan(SelectPositiveOp{values, stride, out_idx, n_out_dev}, n, (hipStream_t)stream);
+    if (rc) { n2m_set_error("select_positive: scan failed (%d)", rc); return rc; }
     N2M_CHECK_LAUNCH();
     return 0;
 }

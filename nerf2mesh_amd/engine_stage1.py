@@ -16,6 +16,7 @@ gradients land in one buffer, the three vertex gradients are added in a fixed or
 distance between two runs of the autograd trainer.  Reference call sites: `render_stage1` (nerf/renderer.py:816-921),
 `update_triangles_errors` (:924-943), `train_step` stage-1 branch (nerf/utils.py:708-721), regularisers (:745-789)."""
 import os
+import time
 
 import numpy as np
 import torch
@@ -64,6 +65,13 @@ class Stage1Engine:
         self.half = torch.tensor(0.5, dtype=torch.float32, device=dev)
         self.zero = torch.zeros((), dtype=torch.float32, device=dev)
         self.cap = 0
+        # covered pixels of the frame (nerf/renderer.py:862-863 `mask_flatten`): the library's own order-preserving selection (n2m_select_positive: three
+        # launches, the count lands in pinned memory) instead of torch.nonzero's compare + count + select + blocking read (A/B: N2M_S1_NONZERO=torch)
+        self.own_select = os.environ.get("N2M_S1_NONZERO", "n2m") != "torch"
+        self.idx_buf = torch.empty(hw, dtype=torch.int64, device=dev)
+        self.k_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.k_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.k_ready = torch.cuda.Event()
         enc = model.encoder_color
         self.enc = enc
         self.levels = int(enc.num_levels)
@@ -138,8 +146,20 @@ class Stage1Engine:
             # is covered, like the other three), and the RGB of the covered pixels overwrites their positions once those have been gathered
             self.verts1[:, :3] = self.verts
             L.call("n2m_interpolate_forward", _p(self.verts1), _p(self.rast), _p(tri), V, F, 4, h, w, _p(self.rgba), s)
-            idx = torch.nonzero(self.rgba[:, 3] > 0, as_tuple=False).squeeze(1)                 # the step's one host read (sizes the shading kernels)
-            K = int(idx.numel())
+            if self.own_select:
+                L.call("n2m_select_positive", self.rgba.data_ptr() + 12, hw, 4, _p(self.idx_buf), _p(self.k_dev), s)
+                self.k_host.copy_(self.k_dev, non_blocking=True)
+                self.k_ready.record()
+                t0 = time.perf_counter()
+                while not self.k_ready.query():                                                  # the step's one host read (sizes the shading kernels):
+                    if time.perf_counter() - t0 > 5e-3:                                          # polled -- a parked thread wakes tens of microseconds late
+                        self.k_ready.synchronize()
+                        break
+                K = int(self.k_host[0])
+                idx = self.idx_buf[:K]
+            else:
+                idx = torch.nonzero(self.rgba[:, 3] > 0, as_tuple=False).squeeze(1)
+                K = int(idx.numel())
             model.last_covered = K
             tr.covered_seen += K
             if K > 0:

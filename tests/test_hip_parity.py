@@ -501,6 +501,33 @@ def test_compact_alive_large(be, oracle):
         assert np.array_equal(got, oracle.compact_alive(a))
 
 
+@pytest.mark.parametrize("stride", [1, 4])
+def test_select_positive_is_torch_nonzero(be, stride):
+    """n2m_select_positive (the covered pixels of a stage-1 frame, nerf/renderer.py:862-863): the indices of torch.nonzero(v > 0), in its order,
+    and their number -- single-block and three-phase scan paths, strided column, NaN / -0 / denormal / inf values, nothing and everything selected."""
+    torch = be["torch"]
+    from nerf2mesh_amd import _lib as L
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 63, 1025, 131072, 131073, 2560000):
+        buf = np.zeros((max(n, 1), stride), np.float32)
+        v = rng.standard_normal(n).astype(np.float32)
+        v[rng.random(n) < 0.6] = 0.0
+        if n > 8:
+            v[:8] = [np.nan, -0.0, 1e-42, np.inf, -np.inf, 0.0, 1.0, -1.0]
+        for fill in ("mixed", "none", "all"):
+            w = {"mixed": v, "none": -np.abs(v), "all": np.abs(v) + 1.0}[fill]
+            buf[:n, stride - 1] = w
+            t = dev(be, buf)
+            out = torch.full((max(n, 1),), -7, dtype=torch.int64, device="cuda")
+            k = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+            L.call("n2m_select_positive", t.data_ptr() + 4 * (stride - 1), n, stride, L.ptr(out), L.ptr(k), L.stream())
+            torch.cuda.synchronize()
+            want = torch.nonzero(t[:n, stride - 1] > 0, as_tuple=False).squeeze(1)
+            assert int(k) == want.numel(), (n, fill)
+            assert torch.equal(out[:want.numel()], want), (n, fill)
+            assert bool((out[want.numel():] == -7).all()), "nothing is written behind the selection"
+
+
 GRID_CASES = [
     (3, 1, False, 0, False, 0),
     (3, 2, True, 0, False, 0),
