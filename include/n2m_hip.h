@@ -654,6 +654,23 @@ int n2m_scaler_update_slots_loss3(float* scale, float* growth_tracker, float* fo
                                   float* loss_sum, const float* extra_partial, uint32_t n_extra, float extra_scale,
                                   const float* extra2_partial, uint32_t n_extra2, float extra2_scale, void* stream);
 
+/* n2m_adam_step + n2m_scaler_update_slots_loss3 in ONE launch (round 6): the optimizer pass whose last workgroup to finish also does the
+ * GradScaler / per-slot step count / bias-correction / loss-value bookkeeping (GradScaler.update of nerf/utils.py:1176-1177 behind
+ * optimizer.step; main.py:221's torch.optim.Adam semantics as n2m_adam_step) -- the same code on the same 256 threads, bit-identical state and
+ * loss value; scale / found_inf / bias are the arrays n2m_adam_step reads (here also written: the next step's values).  `ticket`: N2M_TAIL_TICKET_WORDS
+ * uint32 of device memory (64 arrival counters, one 128-byte line each), zero before the first call; the launch leaves them zero.  One launch less on the step's critical path. */
+#define N2M_TAIL_TICKET_WORDS (64 * 32)
+typedef struct {
+    float* growth_tracker; float* steps;
+    uint32_t participants; float growth_factor, backoff_factor, growth_interval;
+    const float* loss_partial; uint32_t n_partial; uint32_t n_rays; float* loss; float* loss_sum;
+    const float* extra_partial; uint32_t n_extra; float extra_scale;           /* NULL: no second term */
+    const float* extra2_partial; uint32_t n_extra2; float extra2_scale;        /* NULL: no third term */
+    uint32_t* ticket;
+} N2mScalerTail;   /* HOST struct */
+int n2m_adam_step_scaler(const N2mAdamDesc* desc, double beta1, double beta2, float eps, float* scale, float* found_inf, float* bias,
+                         const N2mScalerTail* tail, void* stream);
+
 /* SDF head of the step executor (config 5; the caller-side arithmetic of nerf/renderer.py:724-739, nerf/network.py:143-154 and the eikonal
  * loss of nerf/utils.py:740-743 -- the torch statement in nerf2mesh_amd/{renderer,network}.py is the parity baseline):
  *  n2m_sdf_offsets        pts [M, 6, 3] = clamp(xyz +- eps e_axis, -bound, bound) (k = 2 axis + (minus ? 1 : 0)), pts01 = (pts + bound) / (2 bound);

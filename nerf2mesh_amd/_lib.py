@@ -91,6 +91,7 @@ SIGNATURES = {
     "n2m_batch_rays": [_vp, _vp, _u32, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_batch_rays_cnf": [_vp, _vp, _u32, _u32, _u32, _u32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "n2m_adam_step": [_vp, ctypes.c_double, ctypes.c_double, _f32, _vp, _vp, _vp, _vp],
+    "n2m_adam_step_scaler": [_vp, ctypes.c_double, ctypes.c_double, _f32, _vp, _vp, _vp, _vp, _vp],
     "n2m_ema_update": [_vp, _f32, _vp],
     "n2m_scaler_update": [_vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp],
     "n2m_scaler_update_slots": [_vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_double, ctypes.c_double, _f32, _f32, _f32, _vp],
@@ -162,6 +163,14 @@ class AdamDesc(ctypes.Structure):
     _fields_ = [("param", _vp * ADAM_MAX), ("grad", _vp * ADAM_MAX), ("exp_avg", _vp * ADAM_MAX), ("exp_avg_sq", _vp * ADAM_MAX),
                 ("half_shadow", _vp * ADAM_MAX), ("numel", _u32 * ADAM_MAX), ("lr", _f32 * ADAM_MAX), ("grad_is_half", _i32 * ADAM_MAX),
                 ("shadow_mode", _i32 * ADAM_MAX), ("clear_grad", _i32 * ADAM_MAX), ("slot", _i32 * ADAM_MAX), ("count", _u32)]
+
+
+class ScalerTail(ctypes.Structure):
+    """N2mScalerTail of include/n2m_hip.h."""
+    _fields_ = [("growth_tracker", _vp), ("steps", _vp), ("participants", _u32), ("growth_factor", _f32), ("backoff_factor", _f32),
+                ("growth_interval", _f32), ("loss_partial", _vp), ("n_partial", _u32), ("n_rays", _u32), ("loss", _vp), ("loss_sum", _vp),
+                ("extra_partial", _vp), ("n_extra", _u32), ("extra_scale", _f32), ("extra2_partial", _vp), ("n_extra2", _u32),
+                ("extra2_scale", _f32), ("ticket", _vp)]
 
 
 EMA_MAX = 16

@@ -429,24 +429,31 @@ __device__ __forceinline__ uint32_t peer_load32(const void* at) {      // the sl
     return __hip_atomic_load(reinterpret_cast<const uint32_t*>(at), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Wave-uniform state of the step (found_inf, bias corrections, loss scale) through the scalar data cache: in a kernel that also WRITES those
+// words (adam_kernel_with_scaler's last workgroup) the compiler must otherwise fetch them with vector loads -- three dependent L2 round trips at the
+// top of every one of 18 000 short-lived workgroups (measured: the pass 136 us instead of 93).  Nobody writes them before every workgroup has read them.
+__device__ __forceinline__ float uniform_f32(const float* p) {
+    return *(const __attribute__((address_space(4))) float*)(p);
+}
+
 template <bool PEER>
-__global__ void __launch_bounds__(256)
-adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, float eps, const float* __restrict__ scale,
-            const float* __restrict__ found_inf, const float* __restrict__ bias /*[2]: 1-b1^t, sqrt(1-b2^t) of THIS step*/, AdamPeerK pe) {
+__device__ __forceinline__ void
+adam_body(const AdamTensors& t, float beta1, float beta2, float omb1, float omb2, float eps, const float* scale,
+          const float* found_inf, const float* bias /*[2]: 1-b1^t, sqrt(1-b2^t) of THIS step*/, const AdamPeerK& pe) {
     uint32_t k = 0;
     while (k + 1 < t.count && blockIdx.x >= t.first_block[k + 1]) ++k;
     const uint32_t i0 = ((blockIdx.x - t.first_block[k]) * 256u + threadIdx.x) * 4u;
     const uint32_t n = t.n[k];
     if (i0 >= n) return;
     const bool clear_g = (t.clear_mask >> k) & 1u;                     // consume-and-clear: the producer accumulates into a persistent buffer
-    if (found_inf && *found_inf != 0.0f) {                             // GradScaler: skip the whole step (the gradients are still consumed)
+    if (found_inf && uniform_f32(found_inf) != 0.0f) {                     // GradScaler: skip the whole step (the gradients are still consumed)
         if (clear_g)
             for (uint32_t e = 0; e < 4u && i0 + e < n; ++e) reinterpret_cast<float*>(t.g[k])[i0 + e] = 0.0f;
         return;
     }
-    const float bc1 = bias[2u * t.slot[k]], bc2_sqrt = bias[2u * t.slot[k] + 1u];
+    const float bc1 = uniform_f32(bias + 2u * t.slot[k]), bc2_sqrt = uniform_f32(bias + 2u * t.slot[k] + 1u);
     const float step_size = t.lr[k] / bc1;
-    const float inv_scale = scale ? 1.0f / *scale : 1.0f;
+    const float inv_scale = scale ? 1.0f / uniform_f32(scale) : 1.0f;
     float* __restrict__ P = reinterpret_cast<float*>(t.p[k]);
     float* __restrict__ M = reinterpret_cast<float*>(t.m[k]);
     float* __restrict__ V = reinterpret_cast<float*>(t.v[k]);
@@ -577,7 +584,7 @@ adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, flo
         float* __restrict__ P1 = reinterpret_cast<float*>(t.p[pk]);
         float* __restrict__ M1 = reinterpret_cast<float*>(t.m[pk]);
         float* __restrict__ V1 = reinterpret_cast<float*>(t.v[pk]);
-        const float bc1p = bias[2u * t.slot[pk]], bc2p_sqrt = bias[2u * t.slot[pk] + 1u];      // the partner tensor's own step count
+        const float bc1p = uniform_f32(bias + 2u * t.slot[pk]), bc2p_sqrt = uniform_f32(bias + 2u * t.slot[pk] + 1u);      // the partner tensor's own step count
         const float step1 = t.lr[pk] / bc1p;
         float q[2] = {0.f, 0.f};
 #if N2M_ADAM_NT_ALL == 2
@@ -962,8 +969,86 @@ extern "C" int n2m_stage1_head(const float* aa_alpha, const float* aa_rgb, const
     return 0;
 }
 
+template <bool PEER>
+__global__ void __launch_bounds__(256)
+adam_kernel(AdamTensors t, float beta1, float beta2, float omb1, float omb2, float eps, const float* scale, const float* found_inf,
+            const float* bias, AdamPeerK pe) {
+    adam_body<PEER>(t, beta1, beta2, omb1, omb2, eps, scale, found_inf, bias, pe);
+}
+
+// n2m_adam_step_scaler: the optimizer pass whose LAST workgroup to finish also does the GradScaler / step-count / loss-value bookkeeping that
+// n2m_scaler_update_slots_loss3 does as a one-workgroup launch behind it (scaler_update_slots_body: the same code walking the partials in the same
+// order -- identical bits).  Every wave reads found_inf / bias before its update and leaves an arrival mark when it is done; the one wave that waits
+// for all marks knows that nobody will read that state again in this launch and rewrites it for the next step.  No fence: the bookkeeping reads
+// nothing the other workgroups of this launch wrote.  Saves the step one launch on its critical path (a single workgroup that
+// waits for a free CU beside the marcher: ~10 us + the queue gap in front of the next lookup).
+struct ScalerTailK {
+    float* scale; float* growth_tracker; float* found_inf; float* steps; float* bias;
+    uint32_t participants; double beta1, beta2; float growth_factor, backoff_factor, growth_interval;
+    const float* loss_partial; uint32_t n_partial; float inv_rays; float* loss; float* loss_sum;
+    const float* extra_partial; uint32_t n_extra; float extra_scale;
+    const float* extra2_partial; uint32_t n_extra2; float extra2_scale;
+    uint32_t* ticket;
+};
+template <bool ONE_WAVE>
+__device__ __forceinline__ void scaler_update_slots_body(float* scale, float* growth_tracker, float* found_inf, float* steps, float* bias,
+                                                         uint32_t participants, double beta1, double beta2, float growth_factor, float backoff_factor,
+                                                         float growth_interval, const float* __restrict__ loss_partial, uint32_t n_partial, float inv_rays,
+                                                         float* __restrict__ loss, float* __restrict__ loss_sum, const float* __restrict__ extra_partial,
+                                                         uint32_t n_extra, float extra_scale, const float* __restrict__ extra2_partial, uint32_t n_extra2,
+                                                         float extra2_scale);
+
+constexpr uint32_t kTailSlots = 64;        // arrival counters, one 128-byte line each (N2M_TAIL_TICKET_WORDS = 32 x this; 1 024 of them: no faster)
+// (the kernel's argument block as the hardware lays it out: where `tail` sits in the kernarg segment)
+struct AdamTailArgs {
+    AdamTensors t; float beta1, beta2, omb1, omb2, eps; const float* scale; const float* found_inf; const float* bias; ScalerTailK tail;
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(48)))      // (the bookkeeping's scalars spill; the update keeps the pass's occupancy)
+adam_kernel_with_scaler(AdamTensors t, float beta1, float beta2, float omb1, float omb2, float eps, const float* scale, const float* found_inf,
+                        const float* bias, ScalerTailK tail) {
+    adam_body<false>(t, beta1, beta2, omb1, omb2, eps, scale, found_inf, bias, AdamPeerK{});
+    // Arrival without a round trip: every wave but ONE leaves a fire-and-forget add on counter (workgroup % 64) -- its own 128-byte line -- behind
+    // its reads of found_inf / bias / scale (consumed long before: the update depends on them), and is gone.  Wave 0 of the workgroup with the highest
+    // index does its own rows, then waits until the counters hold the other 4 x gridDim - 1 arrivals: that workgroup is dispatched last and nobody
+    // waits for it, so the wait blocks no one.  Then it does the bookkeeping alone (scaler_update_slots_body<true>).  No LDS and no barrier anywhere in
+    // this kernel; SGPRs capped at the update's own need (amdgpu_num_sgpr: the bookkeeping's scalars spill); the bookkeeping's arguments are read
+    // from the kernarg segment through a laundered offset inside that one wave's branch, not at the top of every wave.
+    // MEASURED, NOT ADOPTED (the step executor keeps the separate launch, N2M_ADAM_TAIL=1 selects this kernel).  The pass alone takes
+    // 93 us.  In one kernel with the bookkeeping: 182 us with a RETURNING ticket per workgroup + barrier on one counter (18 000 same-address round
+    // trips), 136 us on 64 counters; 135 us with this arrival scheme while the bookkeeping used LDS / __syncthreads -- and still 135 us with the update
+    // ALONE followed by an immediate return, as long as the rest of the code was in the kernel: it raised the kernel's SGPR count from 45 to 100 and
+    // with it the pass lost waves per SIMD.  Capped at 48 SGPRs: 116 us (121 us with 1 024 counters).  The 22 us that remain are more than the 10 us +
+    // queue gap the separate one-workgroup launch costs: step 0.543 -> 0.548 ms.
+    if (blockIdx.x != gridDim.x - 1u || threadIdx.x >= 64u) {
+        if ((threadIdx.x & 63u) == 0u)
+            (void)__hip_atomic_fetch_add(tail.ticket + 32u * (blockIdx.x & (kTailSlots - 1u)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    uint32_t off = (uint32_t)offsetof(AdamTailArgs, tail);
+    asm volatile("" : "+s"(off));                          // (not a constant any more: the loads below stay inside this branch)
+    const ScalerTailK* tp = reinterpret_cast<const ScalerTailK*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+    {
+        const uint32_t expected = 4u * gridDim.x - 1u;
+        uint32_t* mine = tp->ticket + 32u * threadIdx.x;
+        for (;;) {
+            uint32_t v = 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < kTailSlots / 64u; ++k) v += __hip_atomic_load(mine + 32u * 64u * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n2m_wave_sum_u32(v) >= expected) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kTailSlots / 64u; ++k) __hip_atomic_store(mine + 32u * 64u * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    scaler_update_slots_body<true>(tp->scale, tp->growth_tracker, tp->found_inf, tp->steps, tp->bias, tp->participants, tp->beta1, tp->beta2,
+                                   tp->growth_factor, tp->backoff_factor, tp->growth_interval, tp->loss_partial, tp->n_partial, tp->inv_rays,
+                                   tp->loss, tp->loss_sum, tp->extra_partial, tp->n_extra, tp->extra_scale, tp->extra2_partial, tp->n_extra2,
+                                   tp->extra2_scale);
+}
+
 static int adam_step_impl(const N2mAdamDesc* d, double beta1, double beta2, float eps, const float* scale, const float* found_inf,
-                          const float* bias, const N2mAdamPeer* peer, void* stream) {
+                          const float* bias, const N2mAdamPeer* peer, void* stream, const N2mScalerTail* tail = nullptr) {
     N2M_REQUIRE(d != nullptr && bias != nullptr, N2M_ENULL, "adam_step: NULL descriptor / bias");
     N2M_REQUIRE(d->count >= 1 && d->count <= N2M_ADAM_MAX, N2M_EINVAL, "adam_step: 1..%d tensors per call (got %u)", N2M_ADAM_MAX, d->count);
     AdamTensors t;
@@ -1055,7 +1140,18 @@ static int adam_step_impl(const N2mAdamDesc* d, double beta1, double beta2, floa
             }
         }
         N2M_PROF_K(N2M_K_ADAM, (hipStream_t)stream, bytes);
-        if (peer)
+        if (tail) {
+            N2M_REQUIRE(!peer, N2M_EUNSUPPORTED, "adam_step_scaler: not with the peer-store form");
+            N2M_REQUIRE(tail->ticket && found_inf && tail->steps && tail->loss_partial && tail->n_rays > 0, N2M_ENULL,
+                        "adam_step_scaler: NULL ticket / found_inf / steps / loss partials (or no rays)");
+            const ScalerTailK tk{const_cast<float*>(scale), tail->growth_tracker, const_cast<float*>(found_inf), tail->steps, const_cast<float*>(bias),
+                                 tail->participants, beta1, beta2, tail->growth_factor, tail->backoff_factor, tail->growth_interval, tail->loss_partial,
+                                 tail->n_partial, 1.0f / (float)tail->n_rays, tail->loss, tail->loss_sum, tail->extra_partial,
+                                 tail->extra_partial ? tail->n_extra : 0u, tail->extra_scale, tail->extra2_partial,
+                                 tail->extra2_partial ? tail->n_extra2 : 0u, tail->extra2_scale, tail->ticket};
+            N2M_LAUNCH(adam_kernel_with_scaler, blocks, 256, 0, (hipStream_t)stream, t, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps,
+                       scale, found_inf, bias, tk);
+        } else if (peer)
             N2M_LAUNCH((adam_kernel<true>), blocks, 256, 0, (hipStream_t)stream, t, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, scale,
                                                                         found_inf, bias, pe);
         else
@@ -1071,6 +1167,12 @@ extern "C" int n2m_adam_step(const N2mAdamDesc* d, double beta1, double beta2, f
     return adam_step_impl(d, beta1, beta2, eps, scale, found_inf, bias, nullptr, stream);
 }
 
+extern "C" int n2m_adam_step_scaler(const N2mAdamDesc* d, double beta1, double beta2, float eps, float* scale, float* found_inf, float* bias,
+                                    const N2mScalerTail* tail, void* stream) {
+    N2M_REQUIRE(tail != nullptr, N2M_ENULL, "adam_step_scaler: NULL tail (use n2m_adam_step + n2m_scaler_update_slots_loss3)");
+    return adam_step_impl(d, beta1, beta2, eps, scale, found_inf, bias, nullptr, stream, tail);
+}
+
 extern "C" int n2m_adam_step_peer(const N2mAdamDesc* d, double beta1, double beta2, float eps, const float* scale, const float* found_inf,
                                   const float* bias, const N2mAdamPeer* peer, void* stream) {
     N2M_REQUIRE(peer != nullptr, N2M_ENULL, "adam_step_peer: NULL peer description (use n2m_adam_step)");
@@ -1080,50 +1182,84 @@ extern "C" int n2m_adam_step_peer(const N2mAdamDesc* d, double beta1, double bet
 // The same with one step count PER TENSOR SLOT (torch.optim.Adam keeps `state[p]["step"]` per parameter: a parameter that gets its
 // first gradient late -- nerf2mesh's specular head after `diffuse_step` -- starts its bias corrections at t = 1).  Thread 0 does the
 // scaler bookkeeping and the global count (slot 0), thread s the count and the next-step corrections of slot s.
-__global__ void scaler_update_slots_kernel(float* scale, float* growth_tracker, float* found_inf, float* steps /*[1+MAX]*/,
-                                           float* bias /*[1+MAX][2]*/, uint32_t participants, double beta1, double beta2,
-                                           float growth_factor, float backoff_factor, float growth_interval,
-                                           const float* __restrict__ loss_partial, uint32_t n_partial, float inv_rays,
-                                           float* __restrict__ loss, float* __restrict__ loss_sum,
-                                           const float* __restrict__ extra_partial, uint32_t n_extra, float extra_scale,
-                                           const float* __restrict__ extra2_partial = nullptr, uint32_t n_extra2 = 0, float extra2_scale = 0.0f) {
-    __builtin_amdgcn_s_setprio(3);
-    const uint32_t s = threadIdx.x;
-    __shared__ float wave_part[16], wave_extra[16], wave_extra2[16];
-    if (extra2_partial) {     // a third term (SDF recipe: the eikonal loss, lambda / M x sum of (|normal| - 1)^2)
-        float acc = 0.0f;
-        for (uint32_t i = s; i < n_extra2; i += blockDim.x) acc += extra2_partial[i];
-        acc = n2m_wave_sum(acc);
-        if ((s & 63u) == 0u) wave_extra2[s >> 6] = acc;
+// (one body for the stand-alone launch below -- a workgroup of `blockDim.x` threads, partial sums through LDS -- and for ONE WAVE at the end of
+//  adam_kernel_with_scaler above, ONE_WAVE = true: no LDS and no barrier in that kernel -- a kernel that has either gets its workgroups placed as
+//  units, which costs the optimizer pass of 18 000 short-lived workgroups 40 us, measured -- the wave walks the partials in the order a
+//  256-thread workgroup does: virtual wave w, lane l takes partials 64 w + l, + 256, ...; the same wave sums, added in wave order: identical bits)
+template <bool ONE_WAVE>
+__device__ __forceinline__ void scaler_update_slots_body(float* scale, float* growth_tracker, float* found_inf, float* steps /*[1+MAX]*/,
+                                                         float* bias /*[1+MAX][2]*/, uint32_t participants, double beta1, double beta2,
+                                                         float growth_factor, float backoff_factor, float growth_interval,
+                                                         const float* __restrict__ loss_partial, uint32_t n_partial, float inv_rays,
+                                                         float* __restrict__ loss, float* __restrict__ loss_sum,
+                                                         const float* __restrict__ extra_partial, uint32_t n_extra, float extra_scale,
+                                                         const float* __restrict__ extra2_partial, uint32_t n_extra2, float extra2_scale) {
+    const uint32_t s = ONE_WAVE ? (threadIdx.x & 63u) : threadIdx.x;
+    float tot_part = 0.0f, tot_extra = 0.0f, tot_extra2 = 0.0f;       // thread 0: the three sums
+    bool ok;
+    if constexpr (ONE_WAVE) {
+        // (the 32 values of a chunk of 2 048 partials are requested together and added in order afterwards: one memory round trip per chunk -- the
+        //  plain loop's one round trip per value made this tail 45 us long)
+        auto sum256 = [&](const float* __restrict__ part, uint32_t n) {
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (uint32_t base = 0; base < n; base += 2048u) {
+                float x[8][4];
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k)
+#pragma unroll
+                    for (uint32_t w = 0; w < 4u; ++w) {
+                        const uint32_t i = base + 256u * k + 64u * w + s;
+                        x[k][w] = i < n ? part[i] : 0.0f;
+                    }
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k)
+#pragma unroll
+                    for (uint32_t w = 0; w < 4u; ++w)
+                        if (base + 256u * k + 64u * w + s < n) acc[w] += x[k][w];
+            }
+            float tot = 0.0f;
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) tot += n2m_wave_sum(acc[w]);
+            return tot;
+        };
+        if (extra2_partial) tot_extra2 = sum256(extra2_partial, n_extra2);
+        if (extra_partial) tot_extra = sum256(extra_partial, n_extra);
+        if (loss_partial) tot_part = sum256(loss_partial, n_partial);
+        ok = *found_inf == 0.0f;                          // (one wave: every lane has its verdict before lane 0's store below is issued)
+    } else {
+        __shared__ float wave_part[16], wave_extra[16], wave_extra2[16];
+        if (extra2_partial) {     // a third term (SDF recipe: the eikonal loss, lambda / M x sum of (|normal| - 1)^2)
+            float acc = 0.0f;
+            for (uint32_t i = s; i < n_extra2; i += blockDim.x) acc += extra2_partial[i];
+            acc = n2m_wave_sum(acc);
+            if ((s & 63u) == 0u) wave_extra2[s >> 6] = acc;
+        }
+        if (extra_partial) {      // a second term of the loss value with its own normalisation (specular regulariser: lambda / M x sum of squares)
+            float acc = 0.0f;
+            for (uint32_t i = s; i < n_extra; i += blockDim.x) acc += extra_partial[i];
+            acc = n2m_wave_sum(acc);
+            if ((s & 63u) == 0u) wave_extra[s >> 6] = acc;
+        }
+        if (loss_partial) {       // the step's loss VALUE (nobody on the GPU waits for it): per-workgroup partials of n2m_composite_loss_train,
+            float acc = 0.0f;     // summed in a fixed order: thread j takes partials j, j + blockDim, ...; lanes in scan order; waves 0, 1, ...
+            for (uint32_t i = s; i < n_partial; i += blockDim.x) acc += loss_partial[i];      // (one wave did this alone: 17 serial round trips, 8 us)
+            acc = n2m_wave_sum(acc);
+            if ((s & 63u) == 0u) wave_part[s >> 6] = acc;
+        }
+        ok = *found_inf == 0.0f;
+        __syncthreads();                                  // everyone has read the verdict before thread 0 clears it
+        if (s == 0) {
+            for (uint32_t w = 0; w < (blockDim.x + 63u) / 64u; ++w) {
+                if (loss_partial) tot_part += wave_part[w];
+                if (extra_partial) tot_extra += wave_extra[w];
+                if (extra2_partial) tot_extra2 += wave_extra2[w];
+            }
+        }
     }
-    if (extra_partial) {      // a second term of the loss value with its own normalisation (specular regulariser: lambda / M x sum of squares)
-        float acc = 0.0f;
-        for (uint32_t i = s; i < n_extra; i += blockDim.x) acc += extra_partial[i];
-        acc = n2m_wave_sum(acc);
-        if ((s & 63u) == 0u) wave_extra[s >> 6] = acc;
-    }
-    if (loss_partial) {       // the step's loss VALUE (nobody on the GPU waits for it): per-workgroup partials of n2m_composite_loss_train,
-        float acc = 0.0f;     // summed in a fixed order: thread j takes partials j, j + blockDim, ...; lanes in scan order; waves 0, 1, ...
-        for (uint32_t i = s; i < n_partial; i += blockDim.x) acc += loss_partial[i];      // (one wave did this alone: 17 serial round trips, 8 us)
-        acc = n2m_wave_sum(acc);
-        if ((s & 63u) == 0u) wave_part[s >> 6] = acc;
-    }
-    const bool ok = *found_inf == 0.0f;
-    __syncthreads();                                  // everyone has read the verdict before thread 0 clears it
     if (loss_partial && s == 0) {
-        float acc = 0.0f;
-        for (uint32_t w = 0; w < (blockDim.x + 63u) / 64u; ++w) acc += wave_part[w];
-        float v = acc * inv_rays;
-        if (extra_partial) {
-            float e = 0.0f;
-            for (uint32_t w = 0; w < (blockDim.x + 63u) / 64u; ++w) e += wave_extra[w];
-            v += e * extra_scale;
-        }
-        if (extra2_partial) {
-            float e = 0.0f;
-            for (uint32_t w = 0; w < (blockDim.x + 63u) / 64u; ++w) e += wave_extra2[w];
-            v += e * extra2_scale;
-        }
+        float v = tot_part * inv_rays;
+        if (extra_partial) v += tot_extra * extra_scale;
+        if (extra2_partial) v += tot_extra2 * extra2_scale;
         if (loss) *loss = v;
         if (loss_sum) *loss_sum += v;
     }
@@ -1149,6 +1285,18 @@ __global__ void scaler_update_slots_kernel(float* scale, float* growth_tracker, 
         bias[2u * s] = (float)(1.0 - pow(beta1, t));
         bias[2u * s + 1u] = (float)sqrt(1.0 - pow(beta2, t));
     }
+}
+
+__global__ void scaler_update_slots_kernel(float* scale, float* growth_tracker, float* found_inf, float* steps /*[1+MAX]*/,
+                                           float* bias /*[1+MAX][2]*/, uint32_t participants, double beta1, double beta2,
+                                           float growth_factor, float backoff_factor, float growth_interval,
+                                           const float* __restrict__ loss_partial, uint32_t n_partial, float inv_rays,
+                                           float* __restrict__ loss, float* __restrict__ loss_sum,
+                                           const float* __restrict__ extra_partial, uint32_t n_extra, float extra_scale,
+                                           const float* __restrict__ extra2_partial = nullptr, uint32_t n_extra2 = 0, float extra2_scale = 0.0f) {
+    __builtin_amdgcn_s_setprio(3);
+    scaler_update_slots_body<false>(scale, growth_tracker, found_inf, steps, bias, participants, beta1, beta2, growth_factor, backoff_factor, growth_interval,
+                             loss_partial, n_partial, inv_rays, loss, loss_sum, extra_partial, n_extra, extra_scale, extra2_partial, n_extra2, extra2_scale);
 }
 
 extern "C" int n2m_scaler_update_slots(float* scale, float* growth_tracker, float* found_inf, float* steps, float* bias,

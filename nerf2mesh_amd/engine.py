@@ -155,6 +155,13 @@ class Stage0Engine:
         # still left three gathers and a 16-byte record in that chain).  Same bits (tests/test_tv_fwd.py).  Measured: DESIGN 4.4 / 7.
         self.tv_fwd = (os.environ.get("N2M_TV_FWD", "0") == "1" and world_size == 1 and not opt.sdf and opt.lambda_tv > 0
                        and not self.tv_split and not self.tv_corners)
+        # [round 6, MEASURED AND NOT ADOPTED: off by default, N2M_ADAM_TAIL=1 turns it on]  The scaler / step-count / loss-value bookkeeping behind the
+        # optimizer pass as the TAIL of that pass (n2m_adam_step_scaler: one wave of its last workgroup runs the code of n2m_scaler_update_slots_loss3
+        # once every other wave has left an arrival mark) instead of a one-workgroup launch of its own on the step's critical path (~10 us + the queue gap
+        # in front of the next lookup).  Identical bits (tests/test_optim.py, tests/test_adam_tail.py) -- but the optimizer pass takes 136 us instead of 93
+        # in the kernel that also holds the bookkeeping code, whatever the arrival scheme: step 0.540 -> 0.563 ms.
+        self.adam_tail = os.environ.get("N2M_ADAM_TAIL", "0") == "1" and world_size == 1
+        self._tail_ticket = torch.zeros(64 * 32, dtype=torch.int32, device=dev)       # N2M_TAIL_TICKET_WORDS
         self._mid_events = None
         # Live-first sample order for the table backward (round 5; MEASURED AND REJECTED, off by default -- N2M_LIVE_FIRST=1 turns it on).
         # The compositing kernel leaves per ray how many samples precede its early stop -- the others, 48 % of a trained lego batch
@@ -745,6 +752,7 @@ class Stage0Engine:
         b1, b2 = o.param_groups[0]["betas"]
         s = L.stream()
         peer_fused = self.peer is not None and self._peer_fused
+        scaler_done = False
         if self.lookup_overlap and fused is None and not self.shard and self.Lv == 16:
             # fine rows (levels 8..15) first, an event behind them, then the coarse rows + every other tensor
             d_f, d_c = self._adam_desc_halves(full, lr_factor)
@@ -759,6 +767,19 @@ class Stage0Engine:
                 self._adam_peer = self.peer.adam_peer([("s1", "c"), ("s2", "c"), ("s1", "f"), ("s2", "f")] + [None] * (desc.count - 4))
             L.call("n2m_adam_step_peer", ctypes.addressof(desc), float(b1), float(b2), float(o.param_groups[0]["eps"]), _p(o.scale), _p(o.found_inf),
                    _p(o.bias), ctypes.addressof(self._adam_peer), s)
+        elif (self.adam_tail and loss_out is not None and fused is None and self.peer is None and not self.shard):
+            # optimizer pass + the scaler / step counts / loss value in one launch (the tail of the pass's last workgroup)
+            gf, bf, gi = o.growth
+            n_rays, buf, extra = loss_out[:3]
+            extra2 = loss_out[3] if len(loss_out) > 3 else None
+            ex_buf, ex_scale = extra if extra is not None else (None, 0.0)
+            e2_buf, e2_n, e2_scale = extra2 if extra2 is not None else (None, 0, 0.0)
+            tail = L.ScalerTail(_p(o.growth_tracker), _p(o.steps), participants, gf, bf, gi, _p(self._w["partial"]), (n_rays + 15) // 16, n_rays,
+                                _p(buf), _p(self._loss_sum), _p(ex_buf), self._n_spec, float(ex_scale), _p(e2_buf), int(e2_n), float(e2_scale),
+                                _p(self._tail_ticket))
+            L.call("n2m_adam_step_scaler", ctypes.addressof(desc), float(b1), float(b2), float(o.param_groups[0]["eps"]), _p(o.scale), _p(o.found_inf),
+                   _p(o.bias), ctypes.addressof(tail), s)
+            scaler_done = True
         else:
             L.call("n2m_adam_step", ctypes.addressof(desc), float(b1), float(b2), float(o.param_groups[0]["eps"]), _p(o.scale), _p(o.found_inf),
                    _p(o.bias), s)
@@ -777,7 +798,9 @@ class Stage0Engine:
         elif self.shard:
             self._gather_packed()
         gf, bf, gi = o.growth
-        if loss_out is None:
+        if scaler_done:
+            pass
+        elif loss_out is None:
             L.call("n2m_scaler_update_slots", _p(o.scale), _p(o.growth_tracker), _p(o.found_inf), _p(o.steps), _p(o.bias), participants,
                    float(b1), float(b2), gf, bf, gi, s)
         else:        # + the step's loss value from the compositing kernel's per-workgroup partials

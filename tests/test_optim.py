@@ -284,3 +284,77 @@ def test_state_dict_round_trip_resumes_bias_corrections_and_loss_scale():
     for p, q in zip(a, b):
         assert torch.equal(p, q)
     assert float(ob.scale) == float(oa.scale) and torch.equal(ob.steps, oa.steps)
+
+
+@pytest.mark.parametrize("overflow", [False, True])
+def test_adam_step_with_the_scaler_tail_is_the_two_launches(overflow):
+    """n2m_adam_step_scaler (round 6): the optimizer pass whose last workgroup also does the scaler / step-count / loss-value bookkeeping ==
+    n2m_adam_step followed by n2m_scaler_update_slots_loss3, bit for bit, over several steps -- parameters, moments, packed rows, loss scale, growth
+    tracker, per-slot step counts and bias corrections, the cleared found_inf flag, the loss value and its running sum; the ticket ends at zero.  A
+    GradScaler overflow in the middle (overflow=True) skips the step on both sides and backs the scale off."""
+    import ctypes
+    import torch
+    from nerf2mesh_amd import _lib as L
+    p = L.ptr
+    torch.manual_seed(3)
+    rows = 70001                                   # several workgroups per tensor, a ragged tail
+    shapes = [(rows, 1), (rows, 2), (64, 35), (3, 32)]
+    n_partial, n_extra, n_extra2, n_rays = 93, 17, 29, 1481
+
+    def fresh():
+        g = torch.Generator(device="cuda").manual_seed(5)
+        st = {"p": [torch.randn(s, device="cuda", generator=g) for s in shapes]}
+        st["m"] = [torch.zeros_like(t) for t in st["p"]]
+        st["v"] = [torch.zeros_like(t) for t in st["p"]]
+        st["pk"] = torch.zeros(rows, 2, device="cuda")
+        st["scale"] = torch.tensor(65536.0, device="cuda")
+        st["growth"] = torch.zeros((), device="cuda")
+        st["found_inf"] = torch.zeros((), device="cuda")
+        st["steps"] = torch.zeros(1 + L.ADAM_MAX, device="cuda")
+        st["bias"] = torch.zeros(1 + L.ADAM_MAX, 2, device="cuda")
+        st["bias"][:, 0] = 1.0 - 0.9
+        st["bias"][:, 1] = float(np.sqrt(1.0 - 0.999))
+        st["loss"], st["loss_sum"] = torch.zeros((), device="cuda"), torch.zeros(1, device="cuda")
+        st["ticket"] = torch.zeros(64 * 32, dtype=torch.int32, device="cuda")        # N2M_TAIL_TICKET_WORDS
+        return st
+
+    def desc_of(st, grads):
+        d = L.AdamDesc()
+        for k, (t, g) in enumerate(zip(st["p"], grads)):
+            d.param[k], d.grad[k], d.exp_avg[k], d.exp_avg_sq[k] = p(t), p(g), p(st["m"][k]), p(st["v"][k])
+            d.numel[k], d.lr[k], d.grad_is_half[k], d.clear_grad[k], d.slot[k] = t.numel(), 1e-2 / (k + 1), int(g.dtype == torch.float16), 0, k + 1
+            d.half_shadow[k], d.shadow_mode[k] = (p(st["pk"]), 2 + k) if k < 2 else (None, 0)
+        d.count = len(grads)
+        return d
+
+    a, b = fresh(), fresh()
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    growth = (2.0, 0.5, 3.0)                       # growth interval 3: the scale grows inside the test
+    for step in range(7):
+        grads = [torch.randn(shapes[0], device="cuda", generator=gen) * 65536, (torch.randn(shapes[1], device="cuda", generator=gen) * 100).half(),
+                 torch.randn(shapes[2], device="cuda", generator=gen) * 65536, torch.randn(shapes[3], device="cuda", generator=gen) * 65536]
+        part = torch.rand(n_partial, device="cuda", generator=gen)
+        ex, ex2 = torch.rand(n_extra, device="cuda", generator=gen), torch.rand(n_extra2, device="cuda", generator=gen)
+        participants = 0b0111 if step < 2 else 0b1111          # the fourth tensor joins late (its own step count starts then)
+        n = 3 if step < 2 else 4
+        for st in (a, b):
+            st["found_inf"].fill_(1.0 if (overflow and step == 3) else 0.0)
+        # (a) two launches
+        da = desc_of(a, grads[:n])
+        L.call("n2m_adam_step", ctypes.addressof(da), 0.9, 0.999, 1e-15, p(a["scale"]), p(a["found_inf"]), p(a["bias"]), L.stream())
+        L.call("n2m_scaler_update_slots_loss3", p(a["scale"]), p(a["growth"]), p(a["found_inf"]), p(a["steps"]), p(a["bias"]), participants, 0.9, 0.999,
+               *growth, p(part), n_partial, n_rays, p(a["loss"]), p(a["loss_sum"]), p(ex), n_extra, 0.25, p(ex2), n_extra2, 0.125, L.stream())
+        # (b) one launch
+        db = desc_of(b, grads[:n])
+        tail = L.ScalerTail(p(b["growth"]), p(b["steps"]), participants, *growth, p(part), n_partial, n_rays, p(b["loss"]), p(b["loss_sum"]), p(ex), n_extra,
+                            0.25, p(ex2), n_extra2, 0.125, p(b["ticket"]))
+        L.call("n2m_adam_step_scaler", ctypes.addressof(db), 0.9, 0.999, 1e-15, p(b["scale"]), p(b["found_inf"]), p(b["bias"]), ctypes.addressof(tail), L.stream())
+        torch.cuda.synchronize()
+        for key in ("scale", "growth", "found_inf", "steps", "bias", "loss", "loss_sum", "pk"):
+            assert torch.equal(a[key], b[key]), (step, key, a[key], b[key])
+        for key in ("p", "m", "v"):
+            for ta, tb in zip(a[key], b[key]):
+                assert torch.equal(ta, tb), (step, key)
+        assert int(b["ticket"].abs().sum()) == 0 and float(b["found_inf"]) == 0.0
+    assert float(a["steps"][1]) == (6 if overflow else 7) and float(a["steps"][4]) == (4 if overflow else 5)
+    assert float(a["scale"]) != 65536.0
