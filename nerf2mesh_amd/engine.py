@@ -8,8 +8,9 @@ streams, the random generators and torch.distributed -- and does the rest itself
 
   prepare (side stream, for batch i+2):  torch.rand(N, 6) -> n2m_batch_rays (pixels, rays, ground truth, near/far, jitter, background)
         -> n2m_march_rays_train_fused (one march: counts + recorded chunks, replay) -> count to pinned memory + event
-  step (main stream, batch i):  n2m_grid_encode_forward_packed -> n2m_field_forward -> n2m_composite_loss_train (compositing, loss head,
-        both backward passes) -> n2m_field_backward -> n2m_grid_encode_backward_binned_pair (+TV) -> [world > 1: SUM all-reduce of the
+  step (main stream, batch i):  n2m_grid_encode_forward_packed[_tvterms: one GPU, the lookup also leaves the backward's TV terms] ->
+        n2m_field_forward -> n2m_composite_loss_train (compositing, loss head,
+        both backward passes) -> n2m_field_backward -> n2m_grid_encode_backward_binned_pair (+TV) / ..._pair_tvt -> [world > 1: SUM all-reduce of the
         fixed gradient buffers, fine levels first] -> n2m_adam_step -> n2m_scaler_update_slots_loss
 
 Same kernels, same arguments, same random draws in the same order as Stage0Trainer: the two produce the same parameters
@@ -148,12 +149,13 @@ class Stage0Engine:
         # kernel its last registers (122 + 32 bytes of scratch).  Same bits either way (tests/test_tv_corners.py).
         self.tv_corners = (os.environ.get("N2M_TV_CORNERS", "0") == "1" and world_size == 1 and not opt.sdf and opt.lambda_tv > 0
                            and not self.tv_split)
-        # [round 6]  TV terms from the forward lookup (N2M_TV_FWD=1): n2m_grid_encode_forward_packed_tvterms leaves the FINISHED term of every
+        # [round 6; the default on one GPU, A/B: N2M_TV_FWD=0]  TV terms from the forward lookup: n2m_grid_encode_forward_packed_tvterms leaves the FINISHED term of every
         # (sample, level) -- the stencil's centre and +x / +y / +z values are corners the lookup holds in registers, at most three more rows are
         # gathered -- and the table backward consumes them through n2m_grid_encode_backward_binned_pair_tvt: its fill reads 4 coalesced bytes per
         # (sample, level) instead of gathering six rows inside its tile's dependent chain (what the corner records above could not deliver: they
-        # still left three gathers and a 16-byte record in that chain).  Same bits (tests/test_tv_fwd.py).  Measured: DESIGN 4.4 / 7.
-        self.tv_fwd = (os.environ.get("N2M_TV_FWD", "0") == "1" and world_size == 1 and not opt.sdf and opt.lambda_tv > 0
+        # still left three gathers and a 16-byte record in that chain).  Same bits (tests/test_tv_fwd.py).  Measured (profiles/r06_tv_fwd.txt):
+        # backward 208 -> 180 us, lookup 72 -> 94 us; lego step -0.7 % over 40-step windows, -1.4 % over 192 steps, -2.0 % in the diffuse phase; garden +-0.
+        self.tv_fwd = (os.environ.get("N2M_TV_FWD", "1") != "0" and world_size == 1 and not opt.sdf and opt.lambda_tv > 0
                        and not self.tv_split and not self.tv_corners)
         # [round 6, MEASURED AND NOT ADOPTED: off by default, N2M_ADAM_TAIL=1 turns it on]  The scaler / step-count / loss-value bookkeeping behind the
         # optimizer pass as the TAIL of that pass (n2m_adam_step_scaler: one wave of its last workgroup runs the code of n2m_scaler_update_slots_loss3
